@@ -1,0 +1,241 @@
+/* vilo_gpu.h — C ABI of the MI355X-native sliding-window VILO solver.
+ *
+ * Drop-in boundary for the hot path of ShuoYangRobotics/Cerberus:
+ *     void Estimator::optimization()          src/estimator/estimator.cpp:1054-1458
+ * i.e. per-frame nonlinear least squares over the 11-frame window (IMU-leg contact-preintegration
+ * factors, stereo reprojection factors, marginalisation prior; Ceres DENSE_SCHUR + DOGLEG) followed by
+ * Schur-complement marginalisation. All entry points take plain pointers and sizes; there are no
+ * torch / Eigen / Ceres types in any signature. Everything is FP64, like the reference.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the Cerberus tree).
+ * Return value: 0 on success, negative vilo_status on error (the reference's factors silently
+ * `return true`, imu_leg_factor.cpp:385; numerical blow-ups only ROS_WARN, imu_factor.h:88-93).
+ */
+#ifndef VILO_GPU_H
+#define VILO_GPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VILO_WINDOW_SIZE 10           /* parameters.h:23 */
+#define VILO_MAX_FRAMES 11            /* WINDOW_SIZE + 1 */
+#define VILO_NUM_OF_F 1000            /* parameters.h:24 */
+#define VILO_RESIDUAL_STATE_SIZE 31   /* parameters.h:103 */
+#define VILO_NOISE_SIZE 46            /* parameters.h:104 */
+#define VILO_MAX_PRIOR_BLOCKS 40
+#define VILO_MAX_PRIOR_DIM 96         /* n <= 10*6 + 9 + 4 + 12 + 1 = 86 in the reference */
+
+typedef enum {
+  VILO_OK = 0,
+  VILO_ERR_NO_DEVICE = -1,      /* no HIP device / extension cannot run: never falls back to CPU */
+  VILO_ERR_BAD_ARG = -2,
+  VILO_ERR_HIP = -3,
+  VILO_ERR_NUMERIC = -4,        /* NaN/Inf or non-PD reduced system after mu escalation */
+  VILO_ERR_UNSUPPORTED = -5
+} vilo_status;
+
+/* The reference's mutable config globals (src/utils/parameters.cpp:13-74) as one POD. */
+typedef struct {
+  double acc_n, acc_n_z, acc_w, gyr_n, gyr_w;
+  double g_norm;
+  double phi_n, dphi_n;
+  double rho_c_n, rho_nc_n;
+  double v_n_min_xy, v_n_min_z, v_n_min, v_n_max;
+  double v_n_force_thres_ratio, v_n_term1_steep, v_n_term2_var_rescale, v_n_term3_distance_rescale;
+  int32_t contact_sensor_type;
+  int32_t pad0;
+  double rho_fix[4][4];   /* per leg [ox, oy, d, lt]   (estimator.cpp:142-163) */
+  double p_br[3];         /* estimator.cpp:140 */
+  double R_br[9];         /* row-major, estimator.cpp:141 */
+  double focal_length;    /* FOCAL_LENGTH, parameters.h:22; Projection*Factor::sqrt_info = f/1.5 I (estimator.cpp:124-126) */
+  double huber_delta;     /* ceres::HuberLoss(1.0), estimator.cpp:1062 */
+} vilo_config;
+
+/* Values of config/a1_config/hardware_a1_vilo_config.yaml. */
+void vilo_default_config(vilo_config *cfg);
+
+/* One sample of IMULegIntegrationBase::push_back (imu_leg_integration_base.h:33-34): 35 doubles. */
+typedef struct {
+  double dt;
+  double acc[3], gyr[3];
+  double phi[12], dphi[12];
+  double c[4];
+} vilo_sample;
+
+/* Public state of an IMULegIntegrationBase (imu_leg_integration_base.h:73-84). */
+typedef struct {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4];      /* x y z w */
+  double delta_v[3];
+  double delta_eps[12];
+  double lin_ba[3], lin_bg[3], lin_rho[4];
+  double jacobian[31 * 31];    /* row-major */
+  double covariance[31 * 31];  /* row-major */
+} vilo_preint;
+
+/* Public state of an IntegrationBase (integration_base.h:201-220). */
+typedef struct {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4];
+  double delta_v[3];
+  double lin_ba[3], lin_bg[3];
+  double jacobian[15 * 15];
+  double covariance[15 * 15];
+} vilo_preint_imu;
+
+/* Parameter-block ids replace the raw addresses MarginalizationInfo keys on
+ * (marginalization_factor.cpp:98-117, estimator.cpp:1358-1370): id = kind*16 + index. */
+#define VILO_BLK_POSE 0
+#define VILO_BLK_SB 1
+#define VILO_BLK_LB 2
+#define VILO_BLK_EX 3
+#define VILO_BLK_TD 4
+#define VILO_BLK_FEAT 5
+
+/* MarginalizationInfo's product (marginalization_factor.h:57-82): the prior consumed by
+ * MarginalizationFactor::Evaluate (marginalization_factor.cpp:347-395). */
+typedef struct {
+  int32_t n;                                  /* residuals = kept local dimension */
+  int32_t n_blocks;
+  int32_t block_id[VILO_MAX_PRIOR_BLOCKS];    /* after addr_shift */
+  int32_t block_size[VILO_MAX_PRIOR_BLOCKS];  /* keep_block_size (global) */
+  int32_t block_idx[VILO_MAX_PRIOR_BLOCKS];   /* keep_block_idx - m */
+  double *x0;                                 /* keep_block_data, concatenated */
+  double *J0;                                 /* linearized_jacobians, n x n row-major */
+  double *r0;                                 /* linearized_residuals */
+  int32_t valid;
+  int32_t pad;
+} vilo_prior;
+
+/* What Estimator::optimization() reads (estimator.h:139-205 + f_manager.feature), flattened. */
+typedef struct {
+  int32_t n_frames;     /* frame_count + 1 */
+  int32_t n_landmarks;  /* features with used_num >= 4 in list order (feature_manager.cpp:179-195) */
+  int32_t n_obs;
+  int32_t use_leg;      /* 1: IMULegFactor (estimator.cpp:1114-1159), 0: IMUFactor (:1160-1171) */
+  const int32_t *lm_start_frame;   /* [L] FeaturePerId::start_frame */
+  const int32_t *lm_obs_offset;    /* [L+1] into obs; a landmark's observations are consecutive frames */
+  const double *obs;               /* [n_obs][11] FeaturePerFrame: point3 pointRight3 velocity2 velocityRight2 cur_td */
+  const uint8_t *obs_is_stereo;    /* [n_obs] */
+  const vilo_preint *preint;          /* [n_frames-1] il_pre_integrations[i+1] */
+  const vilo_preint_imu *preint_imu;  /* [n_frames-1] pre_integrations[i+1] (use_leg == 0) */
+  const vilo_prior *prior;            /* last_marginalization_info; NULL or !valid: none */
+  int32_t leg_bias_const, ex_const, td_const;   /* SetParameterBlockConstant, estimator.cpp:1074-1105 */
+  int32_t pad;
+} vilo_window_desc;
+
+/* para_Pose / para_SpeedBias / para_LegBias / para_Ex_Pose / para_Td / para_Feature
+ * (estimator.h:189-196) in the layouts of vector2double (estimator.cpp:848-901). */
+typedef struct {
+  double *pose;        /* [n_frames][7]  px py pz qx qy qz qw */
+  double *speed_bias;  /* [n_frames][9]  v ba bg */
+  double *leg_bias;    /* [n_frames][4]  rho FL FR RL RR */
+  double *ex_pose;     /* [2][7] */
+  double *td;          /* [1] */
+  double *inv_depth;   /* [L] */
+} vilo_window_state;
+
+/* ceres::Solver::Options as set at estimator.cpp:1221-1233 plus the Ceres 1.14 defaults in play. */
+typedef struct {
+  int32_t max_num_iterations;      /* NUM_ITERATIONS = 12 */
+  int32_t fixed_iterations;        /* 1: no tolerance-based early exit (reproducible work; bench/parity) */
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double min_lm_diagonal, max_lm_diagonal;
+  int32_t jacobi_scaling;
+  int32_t reserved;
+} vilo_solve_opts;
+void vilo_default_solve_opts(vilo_solve_opts *o);
+
+/* ceres::Solver::Summary subset. */
+typedef struct {
+  int32_t iterations, num_successful, termination /* 0 no_convergence, 1 convergence, 2 failure */, pad;
+  double initial_cost, final_cost;
+  double cost_trace[64];
+  double radius_trace[64];
+} vilo_solve_summary;
+
+typedef struct vilo_ctx vilo_ctx;      /* one per host thread / GPU; owns device buffers and one HIP stream */
+typedef struct vilo_batch vilo_batch;  /* device-resident batch of independent windows */
+
+/* Replaces Estimator::setParameter (estimator.cpp:112-174) for the solver side. device = HIP ordinal. */
+int vilo_create(vilo_ctx **ctx, const vilo_config *cfg, int device);
+void vilo_destroy(vilo_ctx *ctx);
+const char *vilo_last_error(const vilo_ctx *ctx);
+
+/* ---- ceres::CostFunction-shaped batched factor evaluation (host pointers) ------------------------
+ * Semantics of CostFunction::Evaluate(double const* const* parameters, double* residuals, double** jacobians):
+ * for factor f of n, parameter block k is params_k[f * size_k .. ]; residuals r[f * num_res ..];
+ * jac_k, if non-NULL, receives row-major num_res x size_k per factor (global sizes, 7th pose column = 0).
+ * obs: [n][12] = pts_i(3) pts_j(3) vel_i(2) vel_j(2) td_i td_j (Projection*Factor constructor arguments). */
+/* ProjectionTwoFrameOneCamFactor::Evaluate <2,7,7,7,1,1>  projectionTwoFrameOneCamFactor.cpp:43-150 */
+int vilo_eval_proj2f1c(vilo_ctx *ctx, int n, const double *obs, const double *pose_i, const double *pose_j,
+                       const double *ex0, const double *inv_dep, const double *td, double *r, double *J_pose_i,
+                       double *J_pose_j, double *J_ex0, double *J_feat, double *J_td);
+/* ProjectionTwoFrameTwoCamFactor::Evaluate <2,7,7,7,7,1,1>  projectionTwoFrameTwoCamFactor.cpp:43-166 */
+int vilo_eval_proj2f2c(vilo_ctx *ctx, int n, const double *obs, const double *pose_i, const double *pose_j,
+                       const double *ex0, const double *ex1, const double *inv_dep, const double *td, double *r,
+                       double *J_pose_i, double *J_pose_j, double *J_ex0, double *J_ex1, double *J_feat, double *J_td);
+/* ProjectionOneFrameTwoCamFactor::Evaluate <2,7,7,1,1>  projectionOneFrameTwoCamFactor.cpp:42-134 */
+int vilo_eval_proj1f2c(vilo_ctx *ctx, int n, const double *obs, const double *ex0, const double *ex1,
+                       const double *inv_dep, const double *td, double *r, double *J_ex0, double *J_ex1,
+                       double *J_feat, double *J_td);
+/* IMULegFactor::Evaluate <31,7,9,4,7,9,4>  imu_leg_factor.cpp:173-386 */
+int vilo_eval_imu_leg(vilo_ctx *ctx, int n, const vilo_preint *pre, const double *pose_i, const double *sb_i,
+                      const double *lb_i, const double *pose_j, const double *sb_j, const double *lb_j, double *r,
+                      double *J_pose_i, double *J_sb_i, double *J_lb_i, double *J_pose_j, double *J_sb_j, double *J_lb_j);
+/* IMUFactor::Evaluate <15,7,9,7,9>  imu_factor.h:28-188 */
+int vilo_eval_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *pre, const double *pose_i, const double *sb_i,
+                  const double *pose_j, const double *sb_j, double *r, double *J_pose_i, double *J_sb_i,
+                  double *J_pose_j, double *J_sb_j);
+/* MarginalizationFactor::Evaluate  marginalization_factor.cpp:347-395. params: concatenated kept blocks in
+ * prior order, n_eval evaluations back to back; J (optional): n x sum(block_size) row-major per evaluation. */
+int vilo_eval_prior(vilo_ctx *ctx, int n_eval, const vilo_prior *prior, const double *params, double *r, double *J);
+/* PoseLocalParameterization::Plus  pose_local_parameterization.cpp:12-27 (batched) */
+int vilo_pose_plus(vilo_ctx *ctx, int n, const double *x, const double *delta, double *x_plus_delta);
+/* ceres::HuberLoss::Evaluate (used at marginalization_factor.cpp:53) — host-side helper */
+void vilo_huber(double delta, double s, double rho[3]);
+
+/* ---- IMULegIntegrationBase(ctor) + push_back/repropagate  imu_leg_integration_base.cpp:7-136 ---------
+ * Interval i integrates samples[offsets[i] .. offsets[i+1]): the first sample of the range plays the
+ * constructor's (acc_0, gyr_0, phi_0, dphi_0, c_0) (its dt is ignored), the rest are push_back()ed.
+ * lin: [n][10] = ba(3) bg(3) rho(4). */
+int vilo_preintegrate(vilo_ctx *ctx, int n_intervals, const vilo_sample *samples, const int32_t *offsets,
+                      const double *lin, vilo_preint *out);
+/* IntegrationBase equivalent (integration_base.h:18-170); lin: [n][6] = ba bg. */
+int vilo_preintegrate_imu(vilo_ctx *ctx, int n_intervals, const vilo_sample *samples, const int32_t *offsets,
+                          const double *lin, vilo_preint_imu *out);
+
+/* ---- Estimator::optimization(), solve half (estimator.cpp:1054-1245) --------------------------------
+ * Synchronous; n_windows = 1 reproduces the reference call. States are updated in place with the
+ * solver result (double2vector's gauge fix is vilo_gauge_fix below). */
+int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                       const vilo_solve_opts *opts, vilo_solve_summary *out);
+
+/* Device-resident form of the same call, for batches (independent windows: robots / replays / seeds). */
+int vilo_batch_create(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *init,
+                      vilo_batch **batch);
+int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *batch);  /* restore the uploaded initial states (device-side copy) */
+int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *batch, const vilo_solve_opts *opts);
+int vilo_batch_download(vilo_ctx *ctx, vilo_batch *batch, vilo_window_state *out, vilo_solve_summary *summaries);
+void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *batch);
+/* GPU time of the last vilo_batch_solve on ctx's stream (HIP events), and per-kernel-group breakdown. */
+double vilo_last_solve_ms(const vilo_ctx *ctx);
+
+/* double2vector gauge fix (estimator.cpp:903-957): yaw/position re-anchoring of the solver output. */
+int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before, vilo_window_state *after, int n_frames);
+
+/* ---- marginalisation half (estimator.cpp:1247-1455; MarginalizationInfo::{preMarginalize,marginalize,
+ * getParameterBlocks} marginalization_factor.cpp:119-333). mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW.
+ * out->x0/J0/r0 must point at caller buffers of >= 7*VILO_MAX_PRIOR_BLOCKS, VILO_MAX_PRIOR_DIM^2, VILO_MAX_PRIOR_DIM doubles. */
+int vilo_marginalize(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
+                     int mode, vilo_prior *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILO_GPU_H */
