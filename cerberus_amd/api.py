@@ -1,0 +1,234 @@
+"""Thin ctypes binding of the C-ABI in include/vilo_gpu.h (libvilo_gpu.so).
+
+There is no CPU fallback: constructing a Context without the HIP library or without a GPU raises.
+The methods mirror the reference's operator interface for the hot path:
+  eval_* ........ ceres::CostFunction::Evaluate of the five factor classes (src/factor/*)
+  preintegrate .. IMULegIntegrationBase ctor + push_back (imu_leg_integration_base.cpp:7-136)
+  solve_windows . Estimator::optimization() solve half (estimator.cpp:1054-1245)
+  marginalize ... Estimator::optimization() marginalisation half (estimator.cpp:1247-1455)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ctypes as T
+
+_lib = None
+
+
+class ViloError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(T.LIB_DIR, "libvilo_gpu.so")
+        if not os.path.exists(path):
+            raise ViloError("libvilo_gpu.so is missing (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.vilo_last_error.restype = C.c_char_p
+        L.vilo_last_solve_ms.restype = C.c_double
+        L.vilo_solve_lds_bytes.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def default_solve_opts(fixed_iterations=False, max_num_iterations=12):
+    o = T.SolveOpts()
+    lib().vilo_default_solve_opts(C.byref(o))
+    o.fixed_iterations = 1 if fixed_iterations else 0
+    o.max_num_iterations = max_num_iterations
+    return o
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(T.c_double_p)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Batch:
+    """Device-resident batch of windows (vilo_batch)."""
+
+    def __init__(self, ctx, windows):
+        self.ctx, self.windows = ctx, windows
+        n = len(windows)
+        self._descs = (T.WindowDesc * n)()
+        self._states = (T.WindowState * n)()
+        for i, w in enumerate(windows):
+            d, s = w.desc(T)
+            self._descs[i], self._states[i] = d, s
+        self.handle = C.c_void_p()
+        ctx._check(lib().vilo_batch_create(ctx.h, n, self._descs, self._states, C.byref(self.handle)))
+
+    def reset(self):
+        self.ctx._check(lib().vilo_batch_reset(self.ctx.h, self.handle))
+
+    def solve(self, opts):
+        self.ctx._check(lib().vilo_batch_solve(self.ctx.h, self.handle, C.byref(opts)))
+        return lib().vilo_last_solve_ms(self.ctx.h)
+
+    def download(self):
+        """Write the solver output into the windows' state arrays; returns the list of summaries."""
+        n = len(self.windows)
+        summ = (T.SolveSummary * n)()
+        self.ctx._check(lib().vilo_batch_download(self.ctx.h, self.handle, self._states, summ))
+        return list(summ)
+
+    def fetch(self, what, win=0, max_n=1 << 22):
+        out = np.zeros(max_n)
+        n = lib().vilo_debug_fetch(self.ctx.h, self.handle, what, win, _p(out), max_n)
+        if n < 0:
+            raise ViloError("vilo_debug_fetch(%d) -> %d" % (what, n))
+        return out[:n].copy()
+
+    def close(self):
+        if self.handle:
+            lib().vilo_batch_destroy(self.ctx.h, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, cfg, device=0):
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = lib().vilo_create(C.byref(self.h), C.byref(cfg), device)
+        if rc != 0:
+            raise ViloError("vilo_create failed (%d): no usable HIP device %d; this library has no CPU path" % (rc, device))
+
+    def close(self):
+        if self.h:
+            lib().vilo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ViloError("vilo error %d: %s" % (rc, lib().vilo_last_error(self.h).decode()))
+
+    # ---- ceres::CostFunction-shaped batched evaluation ----
+    def eval_proj(self, kind, obs, params, want_jac=True):
+        """kind 0/1/2 = TwoFrameOneCam / TwoFrameTwoCam / OneFrameTwoCam; params: list of (n, size) arrays."""
+        obs = _c(obs)
+        n = obs.shape[0]
+        params = [_c(p) for p in params]
+        sizes = [[7, 7, 7, 1, 1], [7, 7, 7, 7, 1, 1], [7, 7, 1, 1]][kind]
+        r = np.zeros((n, 2))
+        Js = [np.zeros((n, 2, s)) for s in sizes] if want_jac else [None] * len(sizes)
+        fn = [lib().vilo_eval_proj2f1c, lib().vilo_eval_proj2f2c, lib().vilo_eval_proj1f2c][kind]
+        self._check(fn(self.h, n, _p(obs), *[_p(p) for p in params], _p(r), *[_p(j) for j in Js]))
+        return r, Js
+
+    def eval_imu_leg(self, preint, params, want_jac=True):
+        preint = _c(preint)
+        n = preint.shape[0]
+        params = [_c(p) for p in params]
+        sizes = [7, 9, 4, 7, 9, 4]
+        r = np.zeros((n, 31))
+        Js = [np.zeros((n, 31, s)) for s in sizes] if want_jac else [None] * 6
+        self._check(lib().vilo_eval_imu_leg(self.h, n, C.cast(preint.ctypes.data, C.POINTER(T.Preint)), *[_p(p) for p in params],
+                                            _p(r), *[_p(j) for j in Js]))
+        return r, Js
+
+    def eval_imu(self, preint, params, want_jac=True):
+        preint = _c(preint)
+        n = preint.shape[0]
+        params = [_c(p) for p in params]
+        sizes = [7, 9, 7, 9]
+        r = np.zeros((n, 15))
+        Js = [np.zeros((n, 15, s)) for s in sizes] if want_jac else [None] * 4
+        self._check(lib().vilo_eval_imu(self.h, n, C.cast(preint.ctypes.data, C.POINTER(T.PreintImu)), *[_p(p) for p in params],
+                                        _p(r), *[_p(j) for j in Js]))
+        return r, Js
+
+    def eval_prior(self, prior, params_concat, want_jac=True):
+        """prior: synth.PriorData; params_concat: (n_eval, sum of global block sizes)."""
+        pc = _c(params_concat)
+        n_eval = pc.shape[0]
+        n = prior.struct.n
+        sg = sum(prior.struct.block_size[k] for k in range(prior.struct.n_blocks))
+        r = np.zeros((n_eval, n))
+        J = np.zeros((n_eval, n, sg)) if want_jac else None
+        self._check(lib().vilo_eval_prior(self.h, n_eval, C.byref(prior.struct), _p(pc), _p(r), _p(J)))
+        return r, J
+
+    def pose_plus(self, x, d):
+        x, d = _c(x), _c(d)
+        out = np.zeros_like(x)
+        self._check(lib().vilo_pose_plus(self.h, x.shape[0], _p(x), _p(d), _p(out)))
+        return out
+
+    # ---- preintegration ----
+    def preintegrate(self, samples, offsets, lin):
+        samples, lin = _c(samples), _c(lin)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = offsets.shape[0] - 1
+        out = np.zeros((n, T.PREINT_DOUBLES))
+        self._check(lib().vilo_preintegrate(self.h, n, C.cast(samples.ctypes.data, C.POINTER(T.Sample)), T.iptr(offsets), _p(lin),
+                                            C.cast(out.ctypes.data, C.POINTER(T.Preint))))
+        return out
+
+    def preintegrate_imu(self, samples, offsets, lin6):
+        samples, lin6 = _c(samples), _c(lin6)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = offsets.shape[0] - 1
+        out = np.zeros((n, T.PREINT_IMU_DOUBLES))
+        self._check(lib().vilo_preintegrate_imu(self.h, n, C.cast(samples.ctypes.data, C.POINTER(T.Sample)), T.iptr(offsets),
+                                                _p(lin6), C.cast(out.ctypes.data, C.POINTER(T.PreintImu))))
+        return out
+
+    def preintegrate_window(self, w):
+        """Fill w.preint (and w.preint_imu) from w.samples on the GPU."""
+        w.preint[...] = self.preintegrate(w.samples, w.sample_offsets, w.lin)
+        w.preint_imu[...] = self.preintegrate_imu(w.samples, w.sample_offsets, np.ascontiguousarray(w.lin[:, :6]))
+
+    def preintegrate_windows(self, windows):
+        """One launch for all intervals of all windows."""
+        samples = np.concatenate([w.samples[: w.sample_offsets[-1]] for w in windows])
+        offs, base = [0], 0
+        for w in windows:
+            offs.extend((w.sample_offsets[1:] + base).tolist())
+            base += int(w.sample_offsets[-1])
+        lin = np.concatenate([w.lin for w in windows])
+        out = self.preintegrate(samples, np.array(offs, np.int32), lin)
+        k = 0
+        for w in windows:
+            w.preint[...] = out[k:k + w.F - 1]
+            k += w.F - 1
+
+    # ---- solve ----
+    def solve_windows(self, windows, opts=None):
+        """Estimator::optimization() solve half on a list of windows; states updated in place."""
+        opts = opts or default_solve_opts()
+        b = Batch(self, windows)
+        try:
+            b.solve(opts)
+            return b.download()
+        finally:
+            b.close()
+
+    def gauge_fix(self, before_arrays, w):
+        keep = [np.ascontiguousarray(a) for a in before_arrays]
+        sb = T.WindowState()
+        sb.pose, sb.speed_bias, sb.leg_bias, sb.ex_pose, sb.td, sb.inv_depth = [T.dptr(k) for k in keep]
+        _, sa = w.desc(T)
+        self._check(lib().vilo_gauge_fix(self.h, 1, C.byref(sb), C.byref(sa), w.F))
+
+    def marginalize(self, w, mode, prior_out):
+        d, s = w.desc(T)
+        self._check(lib().vilo_marginalize(self.h, 1, C.byref(d), C.byref(s), mode, C.byref(prior_out.struct)))

@@ -1,0 +1,411 @@
+// ceres::CostFunction-shaped batched factor evaluation on gfx950 (API-compatibility path: Jacobians are
+// materialised in the reference's row-major global-size layout). The fused solver (kernels_solve.hip)
+// reuses the same device functions from factors.hpp but never materialises Jacobians.
+#include "vilo_internal.hpp"
+
+using namespace vilo;
+
+// -------------------------------------------------------------------------------------------------
+// sqrt_info = LLT(cov^-1).matrixL()^T  (imu_leg_factor.cpp:197-198, imu_factor.h:73), hoisted out of the
+// iteration loop: one wave per interval, computed once per solve. cov = M M^T with M upper triangular
+// (Cholesky of the index-reversed matrix), sqrt_info = M^-1. No explicit inverse of cov is formed.
+// -------------------------------------------------------------------------------------------------
+template <int N>
+__device__ void sqrt_info_wave(const double *cov, double *U_out, double *R /*LDS N*(N+1)*/, double *Ub /*LDS N*(N+1)*/,
+                               int *status) {
+  const int lane = threadIdx.x;
+  const int LD = N + 1;
+  for (int e = lane; e < N * N; e += 64) {
+    const int i = e / N, j = e % N;
+    R[i * LD + j] = cov[(N - 1 - i) * N + (N - 1 - j)];
+  }
+  __syncthreads();
+  for (int j = 0; j < N; ++j) {
+    double s = 0.0;
+    if (lane >= j && lane < N) {
+      s = R[lane * LD + j];
+      for (int k = 0; k < j; ++k) s -= R[lane * LD + k] * R[j * LD + k];
+    }
+    __syncthreads();
+    if (lane == j) {
+      if (!(s > 0.0) || !isfinite(s)) { *status = 1; s = 1.0; }
+      R[j * LD + j] = sqrt(s);
+    }
+    __syncthreads();
+    if (lane > j && lane < N) R[lane * LD + j] = s / R[j * LD + j];
+    __syncthreads();
+  }
+  // M(i,k) = L(N-1-i, N-1-k) (upper). Column c of U = M^-1 by back substitution, one lane per column.
+  if (lane < N) {
+    const int c = lane;
+    for (int i = N - 1; i >= 0; --i) {
+      double v = 0.0;
+      if (i <= c) {
+        double s = (i == c) ? 1.0 : 0.0;
+        for (int k = i + 1; k <= c; ++k) s -= R[(N - 1 - i) * LD + (N - 1 - k)] * Ub[k * LD + c];
+        v = s / R[(N - 1 - i) * LD + (N - 1 - i)];
+      }
+      Ub[i * LD + c] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < N * N; e += 64) U_out[e] = Ub[(e / N) * LD + (e % N)];
+}
+
+__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status) {
+  __shared__ double R[31 * 32], Ub[31 * 32];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const vilo_preint &p = pre[f];
+  if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
+  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status);
+}
+
+__global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status) {
+  __shared__ double R[15 * 16], Ub[15 * 16];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const vilo_preint_imu &p = pre[f];
+  if (threadIdx.x == 0) fill_preint_head_imu(p, out[f].head);
+  // 15x15 sqrt_info stored in the leading 225 doubles
+  sqrt_info_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status);
+}
+
+int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status) {
+  if (n <= 0) return VILO_OK;
+  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
+}
+int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status) {
+  if (n <= 0) return VILO_OK;
+  hipLaunchKernelGGL(k_prepare_preint_imu, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Projection factors: one thread per residual block.
+// -------------------------------------------------------------------------------------------------
+__device__ inline void store_2x7(double *dst, const double *J6) {
+  if (!dst) return;
+  for (int r = 0; r < 2; ++r) {
+    for (int c = 0; c < 6; ++c) dst[r * 7 + c] = J6[r * 6 + c];
+    dst[r * 7 + 6] = 0.0;
+  }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(128) k_eval_proj(int n, double sq, const double *obs, const double *pose_i, const double *pose_j, const double *ex0,
+                            const double *ex1, const double *inv_dep, const double *td, double *r, double *J_pi, double *J_pj,
+                            double *J_e0, double *J_e1, double *J_l, double *J_td) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  double Ji[12], Jj[12], Je0[12], Je1[12], Jl[2], Jt[2], res[2];
+  const bool want = J_pi || J_pj || J_e0 || J_e1 || J_l || J_td;
+  proj_factor<KIND>(obs + 12 * f, KIND == 2 ? nullptr : pose_i + 7 * f, KIND == 2 ? nullptr : pose_j + 7 * f, ex0 + 7 * f,
+                    KIND == 0 ? nullptr : ex1 + 7 * f, inv_dep[f], td[f], sq, res, want, Ji, Jj, Je0, Je1, Jl, Jt);
+  r[2 * f] = res[0];
+  r[2 * f + 1] = res[1];
+  if (!want) return;
+  if (KIND != 2) {
+    store_2x7(J_pi ? J_pi + 14 * f : nullptr, Ji);
+    store_2x7(J_pj ? J_pj + 14 * f : nullptr, Jj);
+  }
+  store_2x7(J_e0 ? J_e0 + 14 * f : nullptr, Je0);
+  if (KIND != 0) store_2x7(J_e1 ? J_e1 + 14 * f : nullptr, Je1);
+  if (J_l) { J_l[2 * f] = Jl[0]; J_l[2 * f + 1] = Jl[1]; }
+  if (J_td) { J_td[2 * f] = Jt[0]; J_td[2 * f + 1] = Jt[1]; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// IMU(-leg) factor: one wave per factor. Raw Jacobian staged in LDS, whitened by the hoisted sqrt_info.
+// -------------------------------------------------------------------------------------------------
+template <int NRES, int NLOC, bool LEG>
+__global__ void __launch_bounds__(64) k_eval_imu_family(int n, double g_norm, const PreintPrepared *pre, const double *pose_i,
+                                                        const double *sb_i, const double *lb_i, const double *pose_j,
+                                                        const double *sb_j, const double *lb_j, double *r, double *J0, double *J1,
+                                                        double *J2, double *J3, double *J4, double *J5) {
+  __shared__ double Jraw[NRES * NLOC];
+  __shared__ double rraw[NRES];
+  __shared__ double U[NRES * NRES];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const int lane = threadIdx.x;
+  for (int e = lane; e < NRES * NLOC; e += 64) Jraw[e] = 0.0;
+  for (int e = lane; e < NRES * NRES; e += 64) U[e] = pre[f].sqrt_info[e];
+  __syncthreads();
+  const bool want = J0 || J1 || J2 || J3 || J4 || J5;
+  if (lane == 0) {
+    if (LEG)
+      imu_leg_raw(pre[f].head, g_norm, pose_i + 7 * f, sb_i + 9 * f, lb_i + 4 * f, pose_j + 7 * f, sb_j + 9 * f, lb_j + 4 * f, rraw,
+                  want, Jraw, NLOC);
+    else
+      imu_raw(pre[f].head, g_norm, pose_i + 7 * f, sb_i + 9 * f, pose_j + 7 * f, sb_j + 9 * f, rraw, want, Jraw, NLOC);
+  }
+  __syncthreads();
+  if (lane < NRES) {
+    double s = 0.0;
+    for (int k = lane; k < NRES; ++k) s += U[lane * NRES + k] * rraw[k];
+    r[NRES * f + lane] = s;
+  }
+  if (!want) return;
+  // local column -> (block, column-in-block, global size)
+  constexpr int NBLK = LEG ? 6 : 4;
+  const int loff[6] = {0, 6, 15, 19, 25, 34}, lsz[6] = {6, 9, 4, 6, 9, 4}, gsz[6] = {7, 9, 4, 7, 9, 4};
+  const int ioff[4] = {0, 6, 15, 21}, isz[4] = {6, 9, 6, 9}, igsz[4] = {7, 9, 7, 9};
+  double *outs[6] = {J0, J1, J2, J3, J4, J5};
+  for (int b = 0; b < NBLK; ++b) {
+    double *dst = outs[b];
+    if (!dst) continue;
+    const int lo = LEG ? loff[b] : ioff[b], ls = LEG ? lsz[b] : isz[b], gs = LEG ? gsz[b] : igsz[b];
+    dst += (size_t)f * NRES * gs;
+    for (int e = lane; e < NRES * gs; e += 64) {
+      const int i = e / gs, c = e % gs;
+      double s = 0.0;
+      if (c < ls)
+        for (int k = i; k < NRES; ++k) s += U[i * NRES + k] * Jraw[k * NLOC + lo + c];
+      dst[e] = s;
+    }
+  }
+}
+
+// MarginalizationFactor::Evaluate: one block per evaluation.
+__global__ void __launch_bounds__(128) k_eval_prior(int n_eval, int n, int n_blocks, const int *block_size, const int *block_idx,
+                                                    const double *x0, const double *J0, const double *r0, const double *params,
+                                                    int param_stride, double *r, double *J, int sum_gsize) {
+  __shared__ double dx[VILO_MAX_PRIOR_DIM];
+  const int e = blockIdx.x;
+  if (e >= n_eval) return;
+  const int t = threadIdx.x;
+  if (t < n_blocks) {
+    int off = 0;
+    for (int b = 0; b < t; ++b) off += block_size[b];
+    prior_dx(params + (size_t)e * param_stride + off, x0 + off, block_size[t], dx + block_idx[t]);
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += blockDim.x) {
+    double s = r0[i];
+    for (int k = 0; k < n; ++k) s += J0[(size_t)i * n + k] * dx[k];
+    r[(size_t)e * n + i] = s;
+  }
+  if (J) {
+    double *Je = J + (size_t)e * n * sum_gsize;
+    int goff = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+      const int gs = block_size[b], ls = gs == 7 ? 6 : gs, idx = block_idx[b];
+      for (int q = t; q < n * gs; q += blockDim.x) {
+        const int i = q / gs, c = q % gs;
+        Je[(size_t)i * sum_gsize + goff + c] = (c < ls) ? J0[(size_t)i * n + idx + c] : 0.0;
+      }
+      goff += gs;
+    }
+  }
+}
+
+__global__ void k_pose_plus(int n, const double *x, const double *d, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pose_plus(x + 7 * i, d + 6 * i, out + 7 * i);
+}
+
+// -------------------------------------------------------------------------------------------------
+// C-ABI entry points (host pointers in, host pointers out).
+// -------------------------------------------------------------------------------------------------
+namespace {
+struct Stage {
+  vilo_ctx *ctx;
+  std::vector<DevBuf *> bufs;
+  ~Stage() { for (auto *b : bufs) delete b; }
+  int up(const double *h, size_t n, double **d) {
+    *d = nullptr;
+    if (!h) return VILO_OK;
+    DevBuf *b = new DevBuf();
+    bufs.push_back(b);
+    VILO_HIP(b->alloc(n * sizeof(double)));
+    VILO_HIP(hipMemcpyAsync(b->p, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    *d = b->as<double>();
+    return VILO_OK;
+  }
+  int out(const double *h, size_t n, double **d) {
+    *d = nullptr;
+    if (!h) return VILO_OK;
+    DevBuf *b = new DevBuf();
+    bufs.push_back(b);
+    VILO_HIP(b->alloc(n * sizeof(double)));
+    *d = b->as<double>();
+    return VILO_OK;
+  }
+  int down(double *h, const double *d, size_t n) {
+    if (!h) return VILO_OK;
+    VILO_HIP(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return VILO_OK;
+  }
+};
+#define TRY(x) do { int rc_ = (x); if (rc_ != VILO_OK) return rc_; } while (0)
+}  // namespace
+
+template <int KIND>
+static int eval_proj_impl(vilo_ctx *ctx, int n, const double *obs, const double *pose_i, const double *pose_j, const double *ex0,
+                          const double *ex1, const double *inv_dep, const double *td, double *r, double *J_pi, double *J_pj,
+                          double *J_e0, double *J_e1, double *J_l, double *J_td) {
+  if (!ctx || n < 0 || !obs || !ex0 || !inv_dep || !td || !r) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  Stage S{ctx};
+  double *d_obs, *d_pi, *d_pj, *d_e0, *d_e1, *d_l, *d_td, *d_r, *dJ[6];
+  TRY(S.up(obs, 12 * (size_t)n, &d_obs));
+  TRY(S.up(pose_i, 7 * (size_t)n, &d_pi));
+  TRY(S.up(pose_j, 7 * (size_t)n, &d_pj));
+  TRY(S.up(ex0, 7 * (size_t)n, &d_e0));
+  TRY(S.up(ex1, 7 * (size_t)n, &d_e1));
+  TRY(S.up(inv_dep, n, &d_l));
+  TRY(S.up(td, n, &d_td));
+  TRY(S.out(r, 2 * (size_t)n, &d_r));
+  double *hJ[6] = {J_pi, J_pj, J_e0, J_e1, J_l, J_td};
+  const size_t jsz[6] = {14, 14, 14, 14, 2, 2};
+  for (int k = 0; k < 6; ++k) TRY(S.out(hJ[k], jsz[k] * n, &dJ[k]));
+  const double sq = ctx->cfg.focal_length / 1.5;
+  hipLaunchKernelGGL(k_eval_proj<KIND>, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, n, sq, d_obs, d_pi, d_pj, d_e0, d_e1, d_l,
+                     d_td, d_r, dJ[0], dJ[1], dJ[2], dJ[3], dJ[4], dJ[5]);
+  VILO_HIP(hipGetLastError());
+  TRY(S.down(r, d_r, 2 * (size_t)n));
+  for (int k = 0; k < 6; ++k) TRY(S.down(hJ[k], dJ[k], jsz[k] * n));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+
+extern "C" int vilo_eval_proj2f1c(vilo_ctx *ctx, int n, const double *obs, const double *pose_i, const double *pose_j,
+                                  const double *ex0, const double *inv_dep, const double *td, double *r, double *J_pose_i,
+                                  double *J_pose_j, double *J_ex0, double *J_feat, double *J_td) {
+  if (!pose_i || !pose_j) return VILO_ERR_BAD_ARG;
+  return eval_proj_impl<0>(ctx, n, obs, pose_i, pose_j, ex0, nullptr, inv_dep, td, r, J_pose_i, J_pose_j, J_ex0, nullptr, J_feat, J_td);
+}
+extern "C" int vilo_eval_proj2f2c(vilo_ctx *ctx, int n, const double *obs, const double *pose_i, const double *pose_j,
+                                  const double *ex0, const double *ex1, const double *inv_dep, const double *td, double *r,
+                                  double *J_pose_i, double *J_pose_j, double *J_ex0, double *J_ex1, double *J_feat, double *J_td) {
+  if (!pose_i || !pose_j || !ex1) return VILO_ERR_BAD_ARG;
+  return eval_proj_impl<1>(ctx, n, obs, pose_i, pose_j, ex0, ex1, inv_dep, td, r, J_pose_i, J_pose_j, J_ex0, J_ex1, J_feat, J_td);
+}
+extern "C" int vilo_eval_proj1f2c(vilo_ctx *ctx, int n, const double *obs, const double *ex0, const double *ex1,
+                                  const double *inv_dep, const double *td, double *r, double *J_ex0, double *J_ex1, double *J_feat,
+                                  double *J_td) {
+  if (!ex1) return VILO_ERR_BAD_ARG;
+  return eval_proj_impl<2>(ctx, n, obs, nullptr, nullptr, ex0, ex1, inv_dep, td, r, nullptr, nullptr, J_ex0, J_ex1, J_feat, J_td);
+}
+
+extern "C" int vilo_eval_imu_leg(vilo_ctx *ctx, int n, const vilo_preint *pre, const double *pose_i, const double *sb_i,
+                                 const double *lb_i, const double *pose_j, const double *sb_j, const double *lb_j, double *r,
+                                 double *J_pose_i, double *J_sb_i, double *J_lb_i, double *J_pose_j, double *J_sb_j, double *J_lb_j) {
+  if (!ctx || n < 0 || !pre || !pose_i || !sb_i || !lb_i || !pose_j || !sb_j || !lb_j || !r) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  Stage S{ctx};
+  DevBuf d_pre, d_prep, d_status;
+  VILO_HIP(d_pre.alloc(sizeof(vilo_preint) * (size_t)n));
+  VILO_HIP(d_prep.alloc(sizeof(PreintPrepared) * (size_t)n));
+  VILO_HIP(d_status.alloc(sizeof(int)));
+  VILO_HIP(hipMemsetAsync(d_status.p, 0, sizeof(int), ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_pre.p, pre, sizeof(vilo_preint) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  TRY(vilo_launch_prepare_preint(ctx, n, d_pre.as<vilo_preint>(), d_prep.as<PreintPrepared>(), d_status.as<int>()));
+  double *d_in[6], *d_r, *dJ[6];
+  const double *h_in[6] = {pose_i, sb_i, lb_i, pose_j, sb_j, lb_j};
+  const size_t gs[6] = {7, 9, 4, 7, 9, 4};
+  for (int k = 0; k < 6; ++k) TRY(S.up(h_in[k], gs[k] * n, &d_in[k]));
+  TRY(S.out(r, 31 * (size_t)n, &d_r));
+  double *hJ[6] = {J_pose_i, J_sb_i, J_lb_i, J_pose_j, J_sb_j, J_lb_j};
+  for (int k = 0; k < 6; ++k) TRY(S.out(hJ[k], 31 * gs[k] * n, &dJ[k]));
+  hipLaunchKernelGGL((k_eval_imu_family<31, 38, true>), dim3(n), dim3(64), 0, ctx->stream, n, ctx->cfg.g_norm,
+                     d_prep.as<PreintPrepared>(), d_in[0], d_in[1], d_in[2], d_in[3], d_in[4], d_in[5], d_r, dJ[0], dJ[1], dJ[2],
+                     dJ[3], dJ[4], dJ[5]);
+  VILO_HIP(hipGetLastError());
+  TRY(S.down(r, d_r, 31 * (size_t)n));
+  for (int k = 0; k < 6; ++k) TRY(S.down(hJ[k], dJ[k], 31 * gs[k] * n));
+  int status = 0;
+  VILO_HIP(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  if (status) { ctx->err = "covariance not positive definite"; return VILO_ERR_NUMERIC; }
+  return VILO_OK;
+}
+
+extern "C" int vilo_eval_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *pre, const double *pose_i, const double *sb_i,
+                             const double *pose_j, const double *sb_j, double *r, double *J_pose_i, double *J_sb_i,
+                             double *J_pose_j, double *J_sb_j) {
+  if (!ctx || n < 0 || !pre || !pose_i || !sb_i || !pose_j || !sb_j || !r) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  Stage S{ctx};
+  DevBuf d_pre, d_prep, d_status;
+  VILO_HIP(d_pre.alloc(sizeof(vilo_preint_imu) * (size_t)n));
+  VILO_HIP(d_prep.alloc(sizeof(PreintPrepared) * (size_t)n));
+  VILO_HIP(d_status.alloc(sizeof(int)));
+  VILO_HIP(hipMemsetAsync(d_status.p, 0, sizeof(int), ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_pre.p, pre, sizeof(vilo_preint_imu) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  TRY(vilo_launch_prepare_preint_imu(ctx, n, d_pre.as<vilo_preint_imu>(), d_prep.as<PreintPrepared>(), d_status.as<int>()));
+  double *d_in[4], *d_r, *dJ[4];
+  const double *h_in[4] = {pose_i, sb_i, pose_j, sb_j};
+  const size_t gs[4] = {7, 9, 7, 9};
+  for (int k = 0; k < 4; ++k) TRY(S.up(h_in[k], gs[k] * n, &d_in[k]));
+  TRY(S.out(r, 15 * (size_t)n, &d_r));
+  double *hJ[4] = {J_pose_i, J_sb_i, J_pose_j, J_sb_j};
+  for (int k = 0; k < 4; ++k) TRY(S.out(hJ[k], 15 * gs[k] * n, &dJ[k]));
+  hipLaunchKernelGGL((k_eval_imu_family<15, 30, false>), dim3(n), dim3(64), 0, ctx->stream, n, ctx->cfg.g_norm,
+                     d_prep.as<PreintPrepared>(), d_in[0], d_in[1], (const double *)nullptr, d_in[2], d_in[3],
+                     (const double *)nullptr, d_r, dJ[0], dJ[1], dJ[2], dJ[3], (double *)nullptr, (double *)nullptr);
+  VILO_HIP(hipGetLastError());
+  TRY(S.down(r, d_r, 15 * (size_t)n));
+  for (int k = 0; k < 4; ++k) TRY(S.down(hJ[k], dJ[k], 15 * gs[k] * n));
+  int status = 0;
+  VILO_HIP(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  if (status) { ctx->err = "covariance not positive definite"; return VILO_ERR_NUMERIC; }
+  return VILO_OK;
+}
+
+extern "C" int vilo_eval_prior(vilo_ctx *ctx, int n_eval, const vilo_prior *prior, const double *params, double *r, double *J) {
+  if (!ctx || !prior || !params || !r || n_eval < 0) return VILO_ERR_BAD_ARG;
+  if (!prior->valid || prior->n <= 0 || prior->n > VILO_MAX_PRIOR_DIM || prior->n_blocks > VILO_MAX_PRIOR_BLOCKS) return VILO_ERR_BAD_ARG;
+  if (n_eval == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  const int n = prior->n, nb = prior->n_blocks;
+  int sum_g = 0;
+  for (int b = 0; b < nb; ++b) sum_g += prior->block_size[b];
+  Stage S{ctx};
+  double *d_x0, *d_J0, *d_r0, *d_par, *d_r, *d_J;
+  TRY(S.up(prior->x0, sum_g, &d_x0));
+  TRY(S.up(prior->J0, (size_t)n * n, &d_J0));
+  TRY(S.up(prior->r0, n, &d_r0));
+  TRY(S.up(params, (size_t)sum_g * n_eval, &d_par));
+  TRY(S.out(r, (size_t)n * n_eval, &d_r));
+  TRY(S.out(J, (size_t)n * sum_g * n_eval, &d_J));
+  DevBuf d_bs, d_bi;
+  VILO_HIP(d_bs.alloc(sizeof(int) * nb));
+  VILO_HIP(d_bi.alloc(sizeof(int) * nb));
+  VILO_HIP(hipMemcpyAsync(d_bs.p, prior->block_size, sizeof(int) * nb, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_bi.p, prior->block_idx, sizeof(int) * nb, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_eval_prior, dim3(n_eval), dim3(128), 0, ctx->stream, n_eval, n, nb, d_bs.as<int>(), d_bi.as<int>(), d_x0, d_J0,
+                     d_r0, d_par, sum_g, d_r, d_J, sum_g);
+  VILO_HIP(hipGetLastError());
+  TRY(S.down(r, d_r, (size_t)n * n_eval));
+  TRY(S.down(J, d_J, (size_t)n * sum_g * n_eval));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+
+extern "C" int vilo_pose_plus(vilo_ctx *ctx, int n, const double *x, const double *delta, double *out) {
+  if (!ctx || n < 0 || !x || !delta || !out) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  Stage S{ctx};
+  double *d_x, *d_d, *d_o;
+  TRY(S.up(x, 7 * (size_t)n, &d_x));
+  TRY(S.up(delta, 6 * (size_t)n, &d_d));
+  TRY(S.out(out, 7 * (size_t)n, &d_o));
+  hipLaunchKernelGGL(k_pose_plus, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, n, d_x, d_d, d_o);
+  VILO_HIP(hipGetLastError());
+  TRY(S.down(out, d_o, 7 * (size_t)n));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+
+extern "C" void vilo_huber(double delta, double s, double rho[3]) { vilo::huber_rho(delta, s, rho); }

@@ -1,0 +1,526 @@
+// Marginalisation half of Estimator::optimization() (estimator.cpp:1247-1455) and MarginalizationInfo
+// (marginalization_factor.cpp:98-333) on gfx950, plus double2vector's gauge fix (estimator.cpp:903-957).
+//
+// The factors touching the dropped blocks are linearised by the same kernels the solver uses
+// (k_visual_linearize / k_imu_linearize: residuals, Jacobians, Huber corrector), then one workgroup per window
+//   * scatters J^T J / J^T r into A, b ordered [dropped | kept] (ThreadsConstructA, :150-181, without the 4 zero-
+//     initialised thread-local copies),
+//   * eigen-decomposes Amm by a parallel cyclic Jacobi method and forms the eps-thresholded pseudo-inverse (:281-286),
+//   * forms the Schur complement A' = Arr - Arm Amm^+ Amr, b' = brr - Arm Amm^+ bmm (:289-295),
+//   * eigen-decomposes A' and emits J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b' (:297-305).
+// Address-keyed bookkeeping (addr_shift, estimator.cpp:1358-1370) is replaced by integer block ids.
+#include <algorithm>
+
+#include "solver_types.hpp"
+
+using namespace vilo;
+
+int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b);   // kernels_solve.hip
+
+namespace {
+
+#define MT 256
+
+__device__ double blk_sum(double v, double *red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = MT / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// Parallel two-sided cyclic Jacobi: A (n x n symmetric, row-major, ld = n, global/L2) -> diag(A) = eigenvalues,
+// V columns = eigenvectors. Round-robin pairing gives n/2 disjoint rotations per step; row phase then column phase.
+__device__ void jacobi_eigh_dev(double *A, double *V, int n, double *cs /*LDS 2*(n/2+1)*/, int *pq /*LDS 2*(n/2+1)*/, double *red) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+  __syncthreads();
+  const int ne = (n + 1) & ~1, half = ne / 2;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (int e = tid; e < n * n; e += MT) {
+      const int i = e / n, j = e % n;
+      const double v = A[e];
+      if (i == j) dg += v * v; else if (j > i) off += v * v;
+    }
+    off = blk_sum(off, red);
+    dg = blk_sum(dg, red);
+    if (off <= 1e-60 || off <= 1e-32 * dg) break;
+    for (int step = 0; step < ne - 1; ++step) {
+      if (tid < half) {
+        // circle method: position tid plays position ne-1-tid; player at position k is (k == ne-1) ? ne-1 : (k + step) % (ne-1)
+        const int ka = tid, kb = ne - 1 - tid;
+        int p = (ka == ne - 1) ? ne - 1 : (ka + step) % (ne - 1);
+        int q = (kb == ne - 1) ? ne - 1 : (kb + step) % (ne - 1);
+        if (p > q) { const int t_ = p; p = q; q = t_; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double apq = A[p * n + q];
+          if (apq != 0.0) {
+            const double app = A[p * n + p], aqq = A[q * n + q];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
+          }
+        } else {
+          q = -1;
+        }
+        pq[2 * tid] = p; pq[2 * tid + 1] = q;
+        cs[2 * tid] = c; cs[2 * tid + 1] = s;
+      }
+      __syncthreads();
+      // rows: A <- J^T A
+      for (int e = tid; e < half * n; e += MT) {
+        const int r = e / n, k = e % n;
+        const int p = pq[2 * r], q = pq[2 * r + 1];
+        if (q < 0) continue;
+        const double c = cs[2 * r], s = cs[2 * r + 1];
+        const double apk = A[p * n + k], aqk = A[q * n + k];
+        A[p * n + k] = c * apk - s * aqk;
+        A[q * n + k] = s * apk + c * aqk;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J
+      for (int e = tid; e < half * n; e += MT) {
+        const int r = e / n, k = e % n;
+        const int p = pq[2 * r], q = pq[2 * r + 1];
+        if (q < 0) continue;
+        const double c = cs[2 * r], s = cs[2 * r + 1];
+        const double akp = A[k * n + p], akq = A[k * n + q];
+        A[k * n + p] = c * akp - s * akq;
+        A[k * n + q] = s * akp + c * akq;
+        const double vkp = V[k * n + p], vkq = V[k * n + q];
+        V[k * n + p] = c * vkp - s * vkq;
+        V[k * n + q] = s * vkp + c * vkq;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+struct MargWin {
+  int m, n;             // dropped / kept local dims
+  int n_drop_lm;        // landmarks among the dropped dims (they follow the 19 frame-0 dims; mode 0)
+  int mode;
+  int has_imu, prior_n, pad0, pad1;
+  long long scratch_off;  // doubles into the scratch arena
+  int cdmap[CD_N];      // camera dim -> index in [dropped | kept] ordering, -1 if absent
+};
+
+// scratch layout per window (doubles): A (T*T) | b (T) | Amm (m*m) | Vm (m*m) | Ainv (m*m) | tmp (n*m) | Ar (n*n) | V2 (n*n) | br (n)
+__global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *mw, const int *drop_lm /*[W][maxL0] device-order local idx*/,
+                                                    int max_l0, double *scratch, double *J0_out, double *r0_out, int *status) {
+  __shared__ double red[MT];
+  __shared__ double cs[2 * 600];
+  __shared__ int pq[2 * 600];
+  __shared__ double dx[VILO_MAX_PRIOR_DIM];
+  const int win = blockIdx.x, tid = threadIdx.x;
+  const MargWin &M = mw[win];
+  const WinMeta wm = bd.win[win];
+  const int m = M.m, n = M.n, T = m + n;
+  if (m == 0 || n == 0) return;
+  double *A = scratch + M.scratch_off, *bv = A + (size_t)T * T, *Amm = bv + T, *Vm = Amm + (size_t)m * m, *Ainv = Vm + (size_t)m * m;
+  double *tmp = Ainv + (size_t)m * m, *Ar = tmp + (size_t)n * m, *V2 = Ar + (size_t)n * n, *br = V2 + (size_t)n * n;
+  const double *x = bd.x + (size_t)win * XSTRIDE;
+  for (size_t e = tid; e < (size_t)T * T + T; e += MT) A[e] = 0.0;
+  __syncthreads();
+  auto add = [&](int ci, int cj, double v) {   // camera dims -> A
+    const int i = M.cdmap[ci], j = M.cdmap[cj];
+    if (i >= 0 && j >= 0) A[(size_t)i * T + j] += v;
+  };
+  // ---- prior factor: J^T J = H_prior, J^T r = b0 + H_prior dx ----
+  if (M.prior_n > 0) {
+    const int pn = M.prior_n;
+    const double *Hp = bd.prior_H + (size_t)win * 96 * 96, *b0 = bd.prior_b0 + (size_t)win * 96;
+    const int *pmap = bd.prior_map + (size_t)win * 96;
+    if (tid < wm.prior_nb)
+      prior_dx(x + bd.prior_bstate[win * 40 + tid], bd.prior_x0 + (size_t)win * 280 + bd.prior_bxoff[win * 40 + tid],
+               bd.prior_bsize[win * 40 + tid], dx + bd.prior_bidx[win * 40 + tid]);
+    __syncthreads();
+    for (int e = tid; e < pn * pn; e += MT) add(pmap[e / pn], pmap[e % pn], Hp[e]);
+    for (int i = tid; i < pn; i += MT) {
+      double s = b0[i];
+      for (int q = 0; q < pn; ++q) s += Hp[(size_t)q * pn + i] * dx[q];
+      const int t = M.cdmap[pmap[i]];
+      if (t >= 0) bv[t] += s;
+    }
+    __syncthreads();
+  }
+  if (M.mode == 0) {
+    // ---- IMULegFactor(0, 1) ----
+    if (M.has_imu) {
+      const double *lin = bd.imu_lin + (size_t)win * 10 * 31 * 39;
+      for (int e = tid; e < 39 * 39; e += MT) {
+        const int a = e / 39, c = e % 39;
+        if (a == 38) continue;
+        double s = 0.0;
+        for (int i = 0; i < 31; ++i) s += lin[i * 39 + a] * lin[i * 39 + c];
+        auto cdof = [](int cc) { return cc < 6 ? cc : (cc < 19 ? CD_B0 + (cc - 6) : (cc < 25 ? 6 + (cc - 19) : CD_B0 + 13 + (cc - 25))); };
+        if (c == 38) { const int t = M.cdmap[cdof(a)]; if (t >= 0) bv[t] += s; }
+        else add(cdof(a), cdof(c), s);
+      }
+      __syncthreads();
+    }
+    // ---- visual factors of the landmarks that start in frame 0: camera-side Gram slots of the s = 0 chunks ----
+    for (int ch = 0; ch < wm.n_chunks; ++ch) {
+      const ChunkMeta cm = bd.chunk[wm.chunk_off + ch];
+      if (cm.s != 0) continue;
+      for (int t = 0; t < cm.kmax; ++t) {
+        const double *gs = bd.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
+        for (int e = tid; e < VILO_GRAM; e += MT) {
+          int a = 0, rem = e;
+          while (rem >= 26 - a) { rem -= 26 - a; ++a; }
+          const int bc = a + rem;
+          if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;
+          auto cdof = [&](int c) { return c < 6 ? c : (c < 12 ? 6 * t + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
+          const double v = gs[e];
+          if (bc == 25) { if (a < 25) { const int q = M.cdmap[cdof(a)]; if (q >= 0) bv[q] += v; } }
+          else {
+            add(cdof(a), cdof(bc), v);
+            if (cdof(a) != cdof(bc)) add(cdof(bc), cdof(a), v);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // landmark (inverse depth) rows / columns
+    const double *wl = bd.lm_w + 80 * (size_t)wm.lm_off;
+    for (int e = tid; e < M.n_drop_lm * 80; e += MT) {
+      const int li = e / 80, a = e % 80;
+      const int l = drop_lm[(size_t)win * max_l0 + li];
+      const int row = 19 + li;
+      if (a == 79) {
+        A[(size_t)row * T + row] += bd.lm_E[wm.lm_off + l];
+        bv[row] += bd.lm_g[wm.lm_off + l];
+      } else {
+        const int t = M.cdmap[a];
+        const double v = wl[(size_t)a * wm.L + l];
+        if (t >= 0) { A[(size_t)row * T + t] += v; A[(size_t)t * T + row] += v; }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- Amm = 1/2 (Amm + Amm^T), eigen, pseudo-inverse (eps = 1e-8) ----
+  const double eps = 1e-8;
+  for (int e = tid; e < m * m; e += MT) {
+    const int i = e / m, j = e % m;
+    Amm[e] = 0.5 * (A[(size_t)i * T + j] + A[(size_t)j * T + i]);
+  }
+  __syncthreads();
+  jacobi_eigh_dev(Amm, Vm, m, cs, pq, red);
+  for (int e = tid; e < m * m; e += MT) {
+    const int i = e / m, j = e % m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) {
+      const double w = Amm[(size_t)k * m + k];
+      if (w > eps) s += Vm[(size_t)i * m + k] * (1.0 / w) * Vm[(size_t)j * m + k];
+    }
+    Ainv[e] = s;
+  }
+  __syncthreads();
+  // tmp = Arm Amm^+ ; A' = Arr - tmp Amr ; b' = brr - tmp bmm
+  for (int e = tid; e < n * m; e += MT) {
+    const int i = e / m, j = e % m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += A[(size_t)(m + i) * T + k] * Ainv[(size_t)k * m + j];
+    tmp[e] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += MT) {
+    const int i = e / n, j = e % n;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += tmp[(size_t)i * m + k] * A[(size_t)k * T + m + j];
+    Ar[e] = A[(size_t)(m + i) * T + m + j] - s;
+  }
+  for (int i = tid; i < n; i += MT) {
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += tmp[(size_t)i * m + k] * bv[k];
+    br[i] = bv[m + i] - s;
+  }
+  __syncthreads();
+  // SelfAdjointEigenSolver reads the lower triangle: symmetrise from it
+  for (int e = tid; e < n * n; e += MT) {
+    const int i = e / n, j = e % n;
+    if (j > i) Ar[e] = Ar[(size_t)j * n + i];
+  }
+  __syncthreads();
+  // keep A' for the caller's invariants before it is diagonalised: stored after br
+  double *Akeep = br + n;
+  for (int e = tid; e < n * n; e += MT) Akeep[e] = Ar[e];
+  __syncthreads();
+  jacobi_eigh_dev(Ar, V2, n, cs, pq, red);
+  double *J0 = J0_out + (size_t)win * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, *r0 = r0_out + (size_t)win * VILO_MAX_PRIOR_DIM;
+  for (int e = tid; e < n * n; e += MT) {
+    const int i = e / n, j = e % n;
+    const double S = Ar[(size_t)i * n + i];
+    J0[e] = (S > eps) ? sqrt(S) * V2[(size_t)j * n + i] : 0.0;
+  }
+  for (int i = tid; i < n; i += MT) {
+    const double S = Ar[(size_t)i * n + i];
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += V2[(size_t)j * n + i] * br[j];
+    r0[i] = (S > eps) ? sqrt(1.0 / S) * s : 0.0;
+    if (!isfinite(r0[i])) *status = 1;
+  }
+}
+
+// double2vector gauge fix + re-pack (estimator.cpp:903-957, 848-873)
+__device__ v3 R2ypr_deg(const m3 &R) {
+  const v3 nn = mk3(R.a[0], R.a[3], R.a[6]), o = mk3(R.a[1], R.a[4], R.a[7]), a = mk3(R.a[2], R.a[5], R.a[8]);
+  const double y = atan2(nn.y, nn.x);
+  const double p = atan2(-nn.z, nn.x * cos(y) + nn.y * sin(y));
+  const double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+  return mk3(y, p, r) * (180.0 / M_PI);
+}
+__device__ quat quat_from_R_dev(const m3 &m) {
+  quat q;
+  double t = m.a[0] + m.a[4] + m.a[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m.a[7] - m.a[5]) * t; q.y = (m.a[2] - m.a[6]) * t; q.z = (m.a[3] - m.a[1]) * t;
+  } else {
+    int i = 0;
+    if (m.a[4] > m.a[0]) i = 1;
+    if (m.a[8] > m.a[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m.a[4 * i] - m.a[4 * j] - m.a[4 * k] + 1.0);
+    double vi = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m.a[3 * k + j] - m.a[3 * j + k]) * t;
+    const double vj = (m.a[3 * j + i] + m.a[3 * i + j]) * t, vk = (m.a[3 * k + i] + m.a[3 * i + k]) * t;
+    q.x = (i == 0) ? vi : (j == 0 ? vj : vk);
+    q.y = (i == 1) ? vi : (j == 1 ? vj : vk);
+    q.z = (i == 2) ? vi : (j == 2 ? vj : vk);
+  }
+  return q;
+}
+
+__global__ void k_gauge_fix(int W, int F, const double *before_pose0 /*[W][7]*/, double *pose /*[W][F][7]*/, double *sb /*[W][F][9]*/,
+                            double *ex /*[W][2][7]*/) {
+  const int w = blockIdx.x, t = threadIdx.x;
+  if (w >= W) return;
+  const double *bp = before_pose0 + 7 * w;
+  double *pw = pose + (size_t)w * F * 7, *sw = sb + (size_t)w * F * 9;
+  const m3 Rs0 = qR(ldq_pose(bp));
+  const m3 R00 = qR(ldq_pose(pw));
+  const v3 o0 = R2ypr_deg(Rs0), o00 = R2ypr_deg(R00);
+  const double yd = (o0.x - o00.x) / 180.0 * M_PI;
+  m3 rot = m3_eye();
+  rot.a[0] = cos(yd); rot.a[1] = -sin(yd); rot.a[3] = sin(yd); rot.a[4] = cos(yd);
+  if (fabs(fabs(o0.y) - 90) < 1.0 || fabs(fabs(o00.y) - 90) < 1.0) rot = Rs0 * tr(R00);
+  const v3 P0 = ld3(pw), origin = ld3(bp);
+  __syncthreads();
+  if (t < F) {
+    double *pp = pw + 7 * t, *ss = sw + 9 * t;
+    const m3 Ri = rot * qR(qnormalized(ldq_pose(pp)));
+    const v3 Pi = rot * (ld3(pp) - P0) + origin;
+    const v3 Vi = rot * ld3(ss);
+    const quat q = quat_from_R_dev(Ri);
+    __syncthreads();
+    st3(pp, Pi);
+    pp[3] = q.x; pp[4] = q.y; pp[5] = q.z; pp[6] = q.w;
+    st3(ss, Vi);
+  } else {
+    __syncthreads();
+    if (t < F + 2) {
+      double *pp = ex + (size_t)w * 14 + 7 * (t - F);
+      const quat q = quat_from_R_dev(qR(qnormalized(ldq_pose(pp))));
+      pp[3] = q.x; pp[4] = q.y; pp[5] = q.z; pp[6] = q.w;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vilo_gauge_fix(vilo_ctx *ctx, int W, const vilo_window_state *before, vilo_window_state *after, int F) {
+  if (!ctx || W <= 0 || !before || !after || F < 1 || F > VILO_MAX_FRAMES) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  std::vector<double> bp((size_t)W * 7), pose((size_t)W * F * 7), sb((size_t)W * F * 9), ex((size_t)W * 14);
+  for (int w = 0; w < W; ++w) {
+    memcpy(&bp[(size_t)w * 7], before[w].pose, 7 * sizeof(double));
+    memcpy(&pose[(size_t)w * F * 7], after[w].pose, sizeof(double) * F * 7);
+    memcpy(&sb[(size_t)w * F * 9], after[w].speed_bias, sizeof(double) * F * 9);
+    memcpy(&ex[(size_t)w * 14], after[w].ex_pose, sizeof(double) * 14);
+  }
+  DevBuf d_bp, d_pose, d_sb, d_ex;
+  VILO_HIP(d_bp.alloc(bp.size() * 8)); VILO_HIP(d_pose.alloc(pose.size() * 8)); VILO_HIP(d_sb.alloc(sb.size() * 8)); VILO_HIP(d_ex.alloc(ex.size() * 8));
+  VILO_HIP(hipMemcpyAsync(d_bp.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_pose.p, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_sb.p, sb.data(), sb.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_ex.p, ex.data(), ex.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_gauge_fix, dim3(W), dim3(64), 0, ctx->stream, W, F, d_bp.as<double>(), d_pose.as<double>(), d_sb.as<double>(), d_ex.as<double>());
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipMemcpyAsync(pose.data(), d_pose.p, pose.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(sb.data(), d_sb.p, sb.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(ex.data(), d_ex.p, ex.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  for (int w = 0; w < W; ++w) {
+    memcpy(after[w].pose, &pose[(size_t)w * F * 7], sizeof(double) * F * 7);
+    memcpy(after[w].speed_bias, &sb[(size_t)w * F * 9], sizeof(double) * F * 9);
+    memcpy(after[w].ex_pose, &ex[(size_t)w * 14], sizeof(double) * 14);
+  }
+  return VILO_OK;
+}
+
+// Batch internals needed here (defined in vilo_batch.hip)
+struct vilo_batch;
+BatchDev *vilo_batch_dev(vilo_batch *bt);
+const int *vilo_batch_perm(vilo_batch *bt, int win, int *L);
+
+extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *state, int mode,
+                                vilo_prior *out) {
+  if (!ctx || W <= 0 || !in || !state || !out || (mode != 0 && mode != 1)) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_batch *bt = nullptr;
+  int rc = vilo_batch_create(ctx, W, in, state, &bt);
+  if (rc != VILO_OK) return rc;
+  BatchDev &bd = *vilo_batch_dev(bt);
+  std::vector<MargWin> mws(W);
+  std::vector<std::vector<int>> kept_ids(W), kept_cd(W), kept_gs(W), kept_soff(W);
+  int max_l0 = 1;
+  std::vector<std::vector<int>> drops(W);
+  size_t scratch_total = 0;
+  for (int w = 0; w < W; ++w) {
+    const vilo_window_desc &d = in[w];
+    MargWin &M = mws[w];
+    memset(&M, 0, sizeof(M));
+    for (int i = 0; i < CD_N; ++i) M.cdmap[i] = -1;
+    M.mode = mode;
+    const int F = d.n_frames, WS = F - 1;
+    const bool has_prior = d.prior && d.prior->valid && d.prior->n > 0;
+    M.prior_n = has_prior ? d.prior->n : 0;
+    // which camera blocks take part (id = kind*16 + index), in the oracle's canonical order
+    std::vector<int> present;   // block ids
+    auto mark = [&](int id) { if (std::find(present.begin(), present.end(), id) == present.end()) present.push_back(id); };
+    if (has_prior)
+      for (int k = 0; k < d.prior->n_blocks; ++k) mark(d.prior->block_id[k]);
+    std::vector<int> dropped_ids;
+    if (mode == 0) {
+      M.has_imu = d.preint[0].sum_dt < 10.0 ? 1 : 0;
+      if (M.has_imu)
+        for (int kind = 0; kind < 3; ++kind) { mark(kind * 16 + 0); mark(kind * 16 + 1); }
+      int L; const int *perm = vilo_batch_perm(bt, w, &L);
+      for (int i = 0; i < L; ++i) {
+        const int l = perm[i];
+        if (d.lm_start_frame[l] != 0) continue;
+        const int K = d.lm_obs_offset[l + 1] - d.lm_obs_offset[l];
+        mark(VILO_BLK_POSE * 16 + 0);
+        for (int t = 1; t < K; ++t) mark(VILO_BLK_POSE * 16 + t);
+        mark(VILO_BLK_EX * 16 + 0); mark(VILO_BLK_EX * 16 + 1); mark(VILO_BLK_TD * 16);
+      }
+      // dropped landmark list in ORIGINAL feature order (oracle: ascending parameter index)
+      std::vector<std::pair<int, int>> dl;
+      for (int i = 0; i < L; ++i)
+        if (d.lm_start_frame[perm[i]] == 0) dl.push_back({perm[i], i});
+      std::sort(dl.begin(), dl.end());
+      for (auto &pr : dl) drops[w].push_back(pr.second);
+      M.n_drop_lm = (int)drops[w].size();
+      max_l0 = std::max(max_l0, M.n_drop_lm);
+      for (int kind = 0; kind < 3; ++kind)
+        if (std::find(present.begin(), present.end(), kind * 16) != present.end()) dropped_ids.push_back(kind * 16);
+    } else {
+      if (!has_prior || std::find(present.begin(), present.end(), VILO_BLK_POSE * 16 + (WS - 1)) == present.end()) {
+        out[w].valid = 0; M.m = 0; M.n = 0;
+        continue;
+      }
+      dropped_ids.push_back(VILO_BLK_POSE * 16 + (WS - 1));
+    }
+    auto blk = [&](int id, int &cd, int &ls, int &gs, int &soff) {
+      const int kind = id / 16, index = id % 16;
+      if (kind == VILO_BLK_POSE) { cd = 6 * index; ls = 6; gs = 7; soff = XO_POSE + 7 * index; }
+      else if (kind == VILO_BLK_SB) { cd = CD_B0 + 13 * index; ls = 9; gs = 9; soff = XO_SB + 9 * index; }
+      else if (kind == VILO_BLK_LB) { cd = CD_B0 + 13 * index + 9; ls = 4; gs = 4; soff = XO_LB + 4 * index; }
+      else if (kind == VILO_BLK_EX) { cd = CD_EX0 + 6 * index; ls = 6; gs = 7; soff = XO_EX + 7 * index; }
+      else { cd = CD_TD; ls = 1; gs = 1; soff = XO_TD; }
+    };
+    int pos = 0;
+    std::sort(dropped_ids.begin(), dropped_ids.end());
+    for (int id : dropped_ids) {
+      int cd, ls, gs, soff; blk(id, cd, ls, gs, soff);
+      for (int c = 0; c < ls; ++c) M.cdmap[cd + c] = pos + c;
+      pos += ls;
+    }
+    if (mode == 0 && pos != 19 && M.n_drop_lm > 0) { vilo_batch_destroy(ctx, bt); ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
+    pos += M.n_drop_lm;
+    M.m = pos;
+    std::vector<int> kept;
+    for (int id : present)
+      if (std::find(dropped_ids.begin(), dropped_ids.end(), id) == dropped_ids.end()) kept.push_back(id);
+    std::sort(kept.begin(), kept.end());
+    for (int id : kept) {
+      int cd, ls, gs, soff; blk(id, cd, ls, gs, soff);
+      for (int c = 0; c < ls; ++c) M.cdmap[cd + c] = pos + c;
+      kept_ids[w].push_back(id); kept_cd[w].push_back(pos - M.m); kept_gs[w].push_back(gs); kept_soff[w].push_back(soff);
+      pos += ls;
+    }
+    M.n = pos - M.m;
+    if (M.n > VILO_MAX_PRIOR_DIM || (int)kept.size() > VILO_MAX_PRIOR_BLOCKS || M.m > 1200) { vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    M.scratch_off = (long long)scratch_total;
+    const size_t T = (size_t)M.m + M.n;
+    scratch_total += T * T + T + 3 * (size_t)M.m * M.m + (size_t)M.n * M.m + 3 * (size_t)M.n * M.n + 2 * M.n + 64;
+  }
+  std::vector<int> drop_flat((size_t)W * max_l0, 0);
+  for (int w = 0; w < W; ++w)
+    for (size_t i = 0; i < drops[w].size(); ++i) drop_flat[(size_t)w * max_l0 + i] = drops[w][i];
+  DevBuf d_mw, d_drop, d_scr, d_J0, d_r0, d_status;
+  auto fail = [&](int code) { vilo_batch_destroy(ctx, bt); return code; };
+  if (d_mw.alloc(sizeof(MargWin) * W) != hipSuccess || d_drop.alloc(sizeof(int) * drop_flat.size()) != hipSuccess ||
+      d_scr.alloc(sizeof(double) * std::max<size_t>(1, scratch_total)) != hipSuccess ||
+      d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
+      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int)) != hipSuccess)
+    return fail(VILO_ERR_HIP);
+  if (hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_drop.p, drop_flat.data(), sizeof(int) * drop_flat.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(d_status.p, 0, sizeof(int)) != hipSuccess)
+    return fail(VILO_ERR_HIP);
+  // preMarginalize: evaluate the factors at the current state (marginalization_factor.cpp:119-138)
+  rc = vilo_marg_linearize(ctx, bd);
+  if (rc != VILO_OK) return fail(rc);
+  hipLaunchKernelGGL(k_marginalize, dim3(W), dim3(MT), 0, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_scr.as<double>(),
+                     d_J0.as<double>(), d_r0.as<double>(), d_status.as<int>());
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize launch failed"; return fail(VILO_ERR_HIP); }
+  std::vector<double> J0((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM), r0((size_t)W * VILO_MAX_PRIOR_DIM);
+  int status = 0;
+  if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(VILO_ERR_HIP);
+  for (int w = 0; w < W; ++w) {
+    const MargWin &M = mws[w];
+    vilo_prior &p = out[w];
+    if (M.m == 0 || M.n == 0) { p.valid = 0; continue; }
+    const int WS = in[w].n_frames - 1;
+    p.n = M.n; p.n_blocks = (int)kept_ids[w].size(); p.valid = 1;
+    int xo = 0;
+    const double *xs[6] = {state[w].pose, state[w].speed_bias, state[w].leg_bias, state[w].ex_pose, state[w].td, nullptr};
+    for (int k = 0; k < p.n_blocks; ++k) {
+      int id = kept_ids[w][k];
+      const int kind = id / 16, index = id % 16;
+      const double *src = kind == VILO_BLK_POSE ? xs[0] + 7 * index : kind == VILO_BLK_SB ? xs[1] + 9 * index : kind == VILO_BLK_LB ? xs[2] + 4 * index : kind == VILO_BLK_EX ? xs[3] + 7 * index : xs[4];
+      // addr_shift: MARGIN_OLD frame k -> k-1 (estimator.cpp:1358-1368); MARGIN_SECOND_NEW frame WS -> WS-1 (:1413-1447)
+      if (kind <= VILO_BLK_LB) {
+        if (mode == 0) id = kind * 16 + (index - 1);
+        else if (index == WS) id = kind * 16 + (index - 1);
+      }
+      p.block_id[k] = id; p.block_size[k] = kept_gs[w][k]; p.block_idx[k] = kept_cd[w][k];
+      for (int c = 0; c < kept_gs[w][k]; ++c) p.x0[xo + c] = src[c];
+      xo += kept_gs[w][k];
+    }
+    for (int i = 0; i < M.n; ++i) {
+      for (int j = 0; j < M.n; ++j) p.J0[(size_t)i * M.n + j] = J0[(size_t)w * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM + (size_t)i * M.n + j];
+      p.r0[i] = r0[(size_t)w * VILO_MAX_PRIOR_DIM + i];
+    }
+  }
+  vilo_batch_destroy(ctx, bt);
+  if (status) { ctx->err = "non-finite marginalisation result"; return VILO_ERR_NUMERIC; }
+  return VILO_OK;
+}

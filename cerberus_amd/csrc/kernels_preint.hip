@@ -1,0 +1,384 @@
+// Contact (IMU + leg) preintegration on gfx950: IMULegIntegrationBase's constructor + push_back()/propagate()/
+// midPointIntegration() (imu_leg_integration_base.cpp:7-470) and the classic IntegrationBase
+// (integration_base.h:18-170), batched over intervals: one wave per interval, samples sequential (each step
+// depends on the previous one), the 31x31 jacobian / covariance updates parallel over columns (lane = column),
+// F / V / jacobian / covariance resident in LDS, leg kinematics of the 4 legs x 2 endpoints on 8 lanes.
+#include "vilo_internal.hpp"
+
+using namespace vilo;
+
+namespace {
+
+// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (:467-468 / integration_base.h:136-137)
+template <int NS, int NN>
+__device__ void jac_cov_update(const double *Fm, const double *Vm, const double *nd, double *Jm, double *Pm, double *Qm) {
+  const int c = threadIdx.x;
+  constexpr int LD = NS + 1;
+  double col[NS];
+  if (c < NS) {
+    for (int r = 0; r < NS; ++r) {
+      double s = 0.0;
+      for (int k = 0; k < NS; ++k) s += Fm[r * NS + k] * Jm[k * LD + c];
+      col[r] = s;
+    }
+  }
+  __syncthreads();
+  if (c < NS)
+    for (int r = 0; r < NS; ++r) Jm[r * LD + c] = col[r];
+  // Q = F P
+  if (c < NS) {
+    for (int r = 0; r < NS; ++r) {
+      double s = 0.0;
+      for (int k = 0; k < NS; ++k) s += Fm[r * NS + k] * Pm[k * LD + c];
+      Qm[r * LD + c] = s;
+    }
+  }
+  __syncthreads();
+  // P' = Q F^T + V N V^T, column c
+  if (c < NS) {
+    for (int r = 0; r < NS; ++r) {
+      double s = 0.0;
+      for (int k = 0; k < NS; ++k) s += Qm[r * LD + k] * Fm[c * NS + k];
+      double t = 0.0;
+      for (int k = 0; k < NN; ++k) t += Vm[r * NN + k] * nd[k] * Vm[c * NN + k];
+      Pm[r * LD + c] = s + t;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ inline void put33(double *M, int ld, int r0, int c0, const m3 &A) {
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) M[(r0 + a) * ld + c0 + b] = A.a[3 * a + b];
+}
+
+struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
+  double f[3], J[9], v[3], g[3], h[9];
+};
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
+                                                       const double *lin, vilo_preint *out) {
+  __shared__ double Fm[31 * 31], Vm[31 * 46], nd[46];
+  __shared__ double Jm[31 * 32], Pm[31 * 32], Qm[31 * 32];
+  __shared__ LegTerms lt[8];
+  __shared__ double ubuf[64];   // uniform scratch written by lane 0: R0 (9) R1 (9) dq (4) rq (4) misc
+  __shared__ int cflag[4];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const vilo_config &cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int s_begin = offsets[f], s_end = offsets[f + 1];
+  const double *ln = lin + 10 * f;
+  const v3 ba = ld3(ln), bg = ld3(ln + 3);
+  double rho[4] = {ln[6], ln[7], ln[8], ln[9]};
+  // state (uniform; kept redundantly in every lane's registers, updated identically)
+  v3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
+  quat dq = mkq(1, 0, 0, 0);
+  v3 eps[4];
+  for (int j = 0; j < 4; ++j) eps[j] = mk3(0, 0, 0);
+  double sum_dt = 0.0;
+  // type-2 contact filter state (imu_leg_integration_base.h:100-108)
+  double ff_min[4] = {0, 0, 0, 0}, ff_max[4] = {0, 0, 0, 0}, ff_win[4][5], ff_var[4] = {0, 0, 0, 0};
+  int ff_idx[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < 5; ++k) ff_win[j][k] = 0.0;
+  for (int e = lane; e < 31 * 32; e += 64) { Jm[e] = ((e / 32) == (e % 32)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  __syncthreads();
+  const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
+  const v3 pbr = ld3(cfg.p_br);
+  const m3 I3 = m3_eye();
+
+  for (int si = s_begin + 1; si < s_end; ++si) {
+    const vilo_sample &s0 = samples[si - 1], &s1 = samples[si];
+    const double dt = s1.dt;
+    const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
+    // IMU midpoint update (:152-160)
+    const v3 un_acc_0 = qrot(dq, acc_0 - ba);
+    const v3 un_gyr = (gyr_0 + gyr_1) * 0.5 - bg;
+    const quat rq = qmul(dq, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
+    const v3 un_acc_1 = qrot(rq, acc_1 - ba);
+    const v3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+    const v3 r_dp = dp + dv * dt + un_acc * (0.5 * dt * dt);
+    const v3 r_dv = dv + un_acc * dt;
+    const v3 w0 = gyr_0 - bg, w1 = gyr_1 - bg;
+    const m3 R0 = qR(dq), R1 = qR(rq);
+    // contact flags (:183-229); integer-valued as in the reference (Vector4i foot_contact_flag)
+    int flag[4];
+    if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
+      for (int j = 0; j < 4; ++j) flag[j] = s1.c[j] >= 0.5 ? 1 : 0;
+    } else {
+      for (int j = 0; j < 4; ++j) {
+        const double force_mag = 0.5 * (s0.c[j] + s1.c[j]);
+        if (force_mag < ff_min[j]) ff_min[j] = 0.9 * ff_min[j] + 0.1 * force_mag;
+        if (force_mag > ff_max[j]) ff_max[j] = 0.9 * ff_max[j] + 0.1 * force_mag;
+        ff_min[j] *= 0.9991;
+        ff_max[j] *= 0.997;
+        const double thr = ff_min[j] + cfg.v_n_force_thres_ratio * (ff_max[j] - ff_min[j]);
+        flag[j] = (int)(1.0 / (1 + exp(-cfg.v_n_term1_steep * (force_mag - thr))));
+        ff_idx[j] = (ff_idx[j] + 1) % 5;
+        // dynamic index into a register array would go to scratch: rewrite the 5-window by select
+        for (int k = 0; k < 5; ++k) ff_win[j][k] = (k == ff_idx[j]) ? force_mag : ff_win[j][k];
+        double mean = 0;
+        for (int k = 0; k < 5; ++k) mean += ff_win[j][k];
+        mean /= 5;
+        double ss = 0;
+        for (int k = 0; k < 5; ++k) ss += (ff_win[j][k] - mean) * (ff_win[j][k] - mean);
+        ff_var[j] = ss / 4;
+      }
+    }
+    // leg terms on lanes 0..7: lane = 2*leg + endpoint (:232-287)
+    if (lane < 8) {
+      const int j = lane >> 1, e = lane & 1;
+      const vilo_sample &ss = e ? s1 : s0;
+      const m3 &Re = e ? R1 : R0;
+      const v3 we = e ? w1 : w0;
+      LegKin k;
+      leg_kin_full(ss.phi + 3 * j, rho[j], cfg.rho_fix[j], k);
+      const v3 dphi = ld3(ss.dphi + 3 * j);
+      const m3 Rw = skew(we);
+      const v3 v = -(Rbr * (k.J * dphi)) - Rw * (pbr + Rbr * k.f);
+      // (dphi^T kron I) dJ/drho = dJ_drho * dphi ; (dphi^T kron I) dJ/dq = [dJ0 dphi, dJ1 dphi, dJ2 dphi]
+      const v3 g = -(Re * (Rbr * (k.dJ_drho * dphi) + Rw * (Rbr * k.df_drho)));
+      m3 K;
+      const v3 k0 = k.dJ[0] * dphi, k1 = k.dJ[1] * dphi, k2 = k.dJ[2] * dphi;
+      K.a[0] = k0.x; K.a[3] = k0.y; K.a[6] = k0.z;
+      K.a[1] = k1.x; K.a[4] = k1.y; K.a[7] = k1.z;
+      K.a[2] = k2.x; K.a[5] = k2.y; K.a[8] = k2.z;
+      const m3 h = Re * (Rbr * K + Rw * Rbr * k.J);
+      st3(lt[lane].f, k.f); st3(lt[lane].v, v); st3(lt[lane].g, g);
+      for (int q = 0; q < 9; ++q) { lt[lane].J[q] = k.J.a[q]; lt[lane].h[q] = h.a[q]; }
+    }
+    for (int e = lane; e < 31 * 31; e += 64) Fm[e] = 0.0;
+    for (int e = lane; e < 31 * 46; e += 64) Vm[e] = 0.0;
+    __syncthreads();
+    // epsilon update + noise (uniform, every lane) (:245, :288-374)
+    v3 lo_v[4], r_eps[4];
+    for (int j = 0; j < 4; ++j) {
+      lo_v[j] = (qrot(dq, ld3(lt[2 * j].v)) + qrot(rq, ld3(lt[2 * j + 1].v))) * 0.5;
+      r_eps[j] = eps[j] + lo_v[j] * dt;
+    }
+    if (lane == 0) {
+      double unc[12], rho_unc[4];
+      if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
+        for (int j = 0; j < 4; ++j) {
+          const double n_xy = cfg.v_n_max * (1 - flag[j]) + flag[j] * cfg.v_n_min_xy;
+          const double n_z = cfg.v_n_max * (1 - flag[j]) + flag[j] * cfg.v_n_min_z;
+          unc[3 * j] = n_xy; unc[3 * j + 1] = n_xy; unc[3 * j + 2] = n_z;
+        }
+      } else {
+        for (int j = 0; j < 4; ++j) {
+          const double n1 = cfg.v_n_max * (1 - flag[j]) + cfg.v_n_min;
+          const double n2 = cfg.v_n_term2_var_rescale * ff_var[j];
+          const v3 tmp = lo_v[j] - dv;
+          unc[3 * j] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.x * tmp.x;
+          unc[3 * j + 1] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.y * tmp.y;
+          unc[3 * j + 2] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.z * tmp.z;
+        }
+      }
+      int fsum = 0;
+      for (int j = 0; j < 4; ++j) { rho_unc[j] = cfg.rho_c_n * flag[j] + cfg.rho_nc_n; fsum += flag[j]; }
+      if (fsum < 1e-6) {
+        for (int j = 0; j < 4; ++j) rho_unc[j] = cfg.rho_nc_n;
+        for (int k = 0; k < 12; ++k) unc[k] = 10e10;
+      }
+      const double an2 = cfg.acc_n * cfg.acc_n, anz2 = cfg.acc_n_z * cfg.acc_n_z, gn2 = cfg.gyr_n * cfg.gyr_n;
+      const double aw2 = cfg.acc_w * cfg.acc_w, gw2 = cfg.gyr_w * cfg.gyr_w, pn2 = cfg.phi_n * cfg.phi_n, dpn2 = cfg.dphi_n * cfg.dphi_n;
+      nd[0] = an2; nd[1] = an2; nd[2] = anz2; nd[3] = gn2; nd[4] = gn2; nd[5] = gn2;
+      nd[6] = an2; nd[7] = an2; nd[8] = anz2; nd[9] = gn2; nd[10] = gn2; nd[11] = gn2;
+      for (int k = 0; k < 3; ++k) { nd[12 + k] = aw2; nd[15 + k] = gw2; }
+      for (int k = 0; k < 6; ++k) { nd[18 + k] = pn2; nd[24 + k] = dpn2; }
+      for (int k = 0; k < 12; ++k) nd[30 + k] = unc[k];
+      for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
+    }
+    // F and V blocks (:376-465): lane 0 the IMU rows, lanes 1..4 the epsilon rows of leg (lane - 1), lane 5 the identities
+    const v3 a0 = acc_0 - ba, a1 = acc_1 - ba;
+    const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
+    const m3 kappa_7 = I3 - Rwx * dt;
+    if (lane == 0) {
+      const m3 kappa_1 = (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * kappa_7) * (-0.5 * dt);
+      put33(Fm, 31, 0, 0, I3);
+      put33(Fm, 31, 0, 3, kappa_1 * (0.5 * dt));
+      put33(Fm, 31, 0, 6, I3 * dt);
+      put33(Fm, 31, 0, 21, (R0 + R1) * (-0.25 * dt * dt));
+      put33(Fm, 31, 0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
+      put33(Fm, 31, 3, 3, kappa_7);
+      put33(Fm, 31, 3, 24, I3 * (-1.0 * dt));
+      put33(Fm, 31, 6, 3, kappa_1);
+      put33(Fm, 31, 6, 6, I3);
+      put33(Fm, 31, 6, 21, (R0 + R1) * (-0.5 * dt));
+      put33(Fm, 31, 6, 24, (R1 * Ra1) * (0.5 * dt * dt));
+      const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt);
+      put33(Vm, 46, 0, 0, R0 * (0.25 * dt * dt));
+      put33(Vm, 46, 0, 3, VpG);
+      put33(Vm, 46, 0, 6, R1 * (0.25 * dt * dt));
+      put33(Vm, 46, 0, 9, VpG);
+      put33(Vm, 46, 3, 3, I3 * (0.5 * dt));
+      put33(Vm, 46, 3, 9, I3 * (0.5 * dt));
+      const m3 VvG = (R1 * Ra1) * (-0.5 * dt * 0.5 * dt);
+      put33(Vm, 46, 6, 0, R0 * (0.5 * dt));
+      put33(Vm, 46, 6, 3, VvG);
+      put33(Vm, 46, 6, 6, R1 * (0.5 * dt));
+      put33(Vm, 46, 6, 9, VvG);
+    } else if (lane >= 1 && lane <= 4) {
+      const int j = lane - 1, e = 9 + 3 * j;
+      const v3 vi = ld3(lt[2 * j].v), vi1 = ld3(lt[2 * j + 1].v), fi = ld3(lt[2 * j].f), fi1 = ld3(lt[2 * j + 1].f);
+      const m3 Ji = ld_m3_rowmajor(lt[2 * j].J), Ji1 = ld_m3_rowmajor(lt[2 * j + 1].J);
+      const m3 hi = ld_m3_rowmajor(lt[2 * j].h), hi1 = ld_m3_rowmajor(lt[2 * j + 1].h);
+      const v3 gi = ld3(lt[2 * j].g), gi1 = ld3(lt[2 * j + 1].g);
+      put33(Fm, 31, e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
+      put33(Fm, 31, e, e, I3);
+      put33(Fm, 31, e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(pbr + Rbr * fi) + R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
+      const v3 gsum = (gi + gi1) * (0.5 * dt);
+      Fm[(e + 0) * 31 + 27 + j] = gsum.x; Fm[(e + 1) * 31 + 27 + j] = gsum.y; Fm[(e + 2) * 31 + 27 + j] = gsum.z;
+      put33(Vm, 46, e, 3, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R0 * skew(pbr + Rbr * fi)) * (0.5 * dt));
+      put33(Vm, 46, e, 9, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
+      put33(Vm, 46, e, 18, hi * (-0.5 * dt));
+      put33(Vm, 46, e, 21, hi1 * (-0.5 * dt));
+      put33(Vm, 46, e, 24, (R0 * Rbr * Ji) * (-0.5 * dt));
+      put33(Vm, 46, e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
+      put33(Vm, 46, e, 30 + 3 * j, I3 * (-dt));
+    } else if (lane == 5) {
+      put33(Fm, 31, 21, 21, I3);
+      put33(Fm, 31, 24, 24, I3);
+      for (int j = 0; j < 4; ++j) { Fm[(27 + j) * 31 + 27 + j] = 1.0; Vm[(27 + j) * 46 + 42 + j] = -dt; }
+      put33(Vm, 46, 21, 12, I3 * (-dt));
+      put33(Vm, 46, 24, 15, I3 * (-dt));
+    }
+    __syncthreads();
+    jac_cov_update<31, 46>(Fm, Vm, nd, Jm, Pm, Qm);
+    // propagate() (:88-136)
+    dp = r_dp; dv = r_dv; dq = qnormalized(rq);
+    for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
+    sum_dt += dt;
+  }
+  vilo_preint &o = out[f];
+  if (lane == 0) {
+    o.sum_dt = sum_dt;
+    st3(o.delta_p, dp); st3(o.delta_v, dv);
+    o.delta_q[0] = dq.x; o.delta_q[1] = dq.y; o.delta_q[2] = dq.z; o.delta_q[3] = dq.w;
+    for (int j = 0; j < 4; ++j) { st3(o.delta_eps + 3 * j, eps[j]); o.lin_rho[j] = rho[j]; }
+    st3(o.lin_ba, ba); st3(o.lin_bg, bg);
+  }
+  for (int e = lane; e < 31 * 31; e += 64) {
+    o.jacobian[e] = Jm[(e / 31) * 32 + (e % 31)];
+    o.covariance[e] = Pm[(e / 31) * 32 + (e % 31)];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
+                                                   const double *lin, vilo_preint_imu *out) {
+  __shared__ double Fm[15 * 15], Vm[15 * 18], nd[18];
+  __shared__ double Jm[15 * 16], Pm[15 * 16], Qm[15 * 16];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const vilo_config &cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int s_begin = offsets[f], s_end = offsets[f + 1];
+  const v3 ba = ld3(lin + 6 * f), bg = ld3(lin + 6 * f + 3);
+  v3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
+  quat dq = mkq(1, 0, 0, 0);
+  double sum_dt = 0.0;
+  for (int e = lane; e < 15 * 16; e += 64) { Jm[e] = ((e / 16) == (e % 16)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  if (lane < 18) {   // integration_base.h:31-37 (ACC_N on all axes)
+    const int blk = lane / 3;
+    nd[lane] = (blk == 0 || blk == 2) ? cfg.acc_n * cfg.acc_n : (blk == 1 || blk == 3) ? cfg.gyr_n * cfg.gyr_n : (blk == 4) ? cfg.acc_w * cfg.acc_w : cfg.gyr_w * cfg.gyr_w;
+  }
+  __syncthreads();
+  const m3 I3 = m3_eye();
+  for (int si = s_begin + 1; si < s_end; ++si) {
+    const vilo_sample &s0 = samples[si - 1], &s1 = samples[si];
+    const double dt = s1.dt;
+    const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
+    const v3 un_acc_0 = qrot(dq, acc_0 - ba);
+    const v3 un_gyr = (gyr_0 + gyr_1) * 0.5 - bg;
+    const quat rq = qmul(dq, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
+    const v3 un_acc_1 = qrot(rq, acc_1 - ba);
+    const v3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+    const v3 r_dp = dp + dv * dt + un_acc * (0.5 * dt * dt);
+    const v3 r_dv = dv + un_acc * dt;
+    for (int e = lane; e < 15 * 15; e += 64) Fm[e] = 0.0;
+    for (int e = lane; e < 15 * 18; e += 64) Vm[e] = 0.0;
+    __syncthreads();
+    if (lane == 0) {
+      const m3 R0 = qR(dq), R1 = qR(rq), Rwx = skew(un_gyr), Ra0 = skew(acc_0 - ba), Ra1 = skew(acc_1 - ba);
+      const m3 K7 = I3 - Rwx * dt;
+      put33(Fm, 15, 0, 0, I3);
+      put33(Fm, 15, 0, 3, (R0 * Ra0) * (-0.25 * dt * dt) + (R1 * Ra1 * K7) * (-0.25 * dt * dt));
+      put33(Fm, 15, 0, 6, I3 * dt);
+      put33(Fm, 15, 0, 9, (R0 + R1) * (-0.25 * dt * dt));
+      put33(Fm, 15, 0, 12, (R1 * Ra1) * (-0.25 * dt * dt * -dt));
+      put33(Fm, 15, 3, 3, K7);
+      put33(Fm, 15, 3, 12, I3 * (-dt));
+      put33(Fm, 15, 6, 3, (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * K7) * (-0.5 * dt));
+      put33(Fm, 15, 6, 6, I3);
+      put33(Fm, 15, 6, 9, (R0 + R1) * (-0.5 * dt));
+      put33(Fm, 15, 6, 12, (R1 * Ra1) * (-0.5 * dt * -dt));
+      put33(Fm, 15, 9, 9, I3);
+      put33(Fm, 15, 12, 12, I3);
+      const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt), VvG = (R1 * Ra1) * (-0.5 * dt * 0.5 * dt);
+      put33(Vm, 18, 0, 0, R0 * (0.25 * dt * dt));
+      put33(Vm, 18, 0, 3, VpG);
+      put33(Vm, 18, 0, 6, R1 * (0.25 * dt * dt));
+      put33(Vm, 18, 0, 9, VpG);
+      put33(Vm, 18, 3, 3, I3 * (0.5 * dt));
+      put33(Vm, 18, 3, 9, I3 * (0.5 * dt));
+      put33(Vm, 18, 6, 0, R0 * (0.5 * dt));
+      put33(Vm, 18, 6, 3, VvG);
+      put33(Vm, 18, 6, 6, R1 * (0.5 * dt));
+      put33(Vm, 18, 6, 9, VvG);
+      put33(Vm, 18, 9, 12, I3 * dt);
+      put33(Vm, 18, 12, 15, I3 * dt);
+    }
+    __syncthreads();
+    jac_cov_update<15, 18>(Fm, Vm, nd, Jm, Pm, Qm);
+    dp = r_dp; dv = r_dv; dq = qnormalized(rq);
+    sum_dt += dt;
+  }
+  vilo_preint_imu &o = out[f];
+  if (lane == 0) {
+    o.sum_dt = sum_dt;
+    st3(o.delta_p, dp); st3(o.delta_v, dv);
+    o.delta_q[0] = dq.x; o.delta_q[1] = dq.y; o.delta_q[2] = dq.z; o.delta_q[3] = dq.w;
+    st3(o.lin_ba, ba); st3(o.lin_bg, bg);
+  }
+  for (int e = lane; e < 15 * 15; e += 64) {
+    o.jacobian[e] = Jm[(e / 15) * 16 + (e % 15)];
+    o.covariance[e] = Pm[(e / 15) * 16 + (e % 15)];
+  }
+}
+
+template <class OUT, class KERNEL>
+static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin, int lin_w,
+                             OUT *out, KERNEL kern) {
+  if (!ctx || n < 0 || !samples || !offsets || !lin || !out) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  const int ns = offsets[n];
+  for (int i = 0; i < n; ++i)
+    if (offsets[i + 1] <= offsets[i]) return VILO_ERR_BAD_ARG;
+  DevBuf d_s, d_o, d_l, d_out;
+  VILO_HIP(d_s.alloc(sizeof(vilo_sample) * (size_t)ns));
+  VILO_HIP(d_o.alloc(sizeof(int) * (size_t)(n + 1)));
+  VILO_HIP(d_l.alloc(sizeof(double) * (size_t)lin_w * n));
+  VILO_HIP(d_out.alloc(sizeof(OUT) * (size_t)n));
+  VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * (size_t)lin_w * n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(),
+                     d_o.as<int>(), d_l.as<double>(), d_out.as<OUT>());
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(OUT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+
+extern "C" int vilo_preintegrate(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
+                                 vilo_preint *out) {
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 10, out, k_preint_imu_leg);
+}
+extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
+                                     vilo_preint_imu *out) {
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu);
+}

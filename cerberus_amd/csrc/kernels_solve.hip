@@ -1,0 +1,1008 @@
+// Fused sliding-window solver for gfx950: what ceres::Solve does for Estimator::optimization()
+// (estimator.cpp:1054-1245; DENSE_SCHUR + traditional DOGLEG, Ceres 1.14 semantics) as a batched kernel
+// pipeline over independent windows. Jacobians are never materialised in HBM:
+//
+//   k_visual_linearize  one wave per (window, start-frame) landmark chunk, lane = landmark. Evaluates the
+//                       Projection*Factor residual blocks + Huber corrector in registers, reduces the landmark's
+//                       1x1 Hessian / gradient / camera coupling row in registers, and forms the camera-side Gram
+//                       blocks of every (start, t) pair through an LDS-staged wave reduction.
+//   k_imu_linearize     one wave per IMULegFactor: raw Jacobian in LDS, whitened by the hoisted sqrt_info.
+//   k_build_solve       one workgroup per window, everything LDS-resident: assembles the block-arrow camera system
+//                       (dense 80x80 pose/extrinsic/td part + block-tridiagonal speed-bias/leg-bias part), Jacobi
+//                       scaling, dogleg quantities, landmark Schur complement, block elimination, dense Cholesky,
+//                       back-substitution, dogleg step, candidate state.
+//   k_visual_cost / k_imu_cost / k_accept   trial-point cost and the trust-region accept/reject logic.
+#include "solver_types.hpp"
+
+using namespace vilo;
+
+__device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
+// block-wide sum through LDS (all threads must call); red has blockDim.x entries
+__device__ double block_sum(double v, double *red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+__device__ double block_max(double v, double *red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// =================================================================================================
+// k_visual_linearize
+// =================================================================================================
+#define XLANE 53  // LDS stride per lane: 2 rows x 26 cols + 1 pad (conflict-free ds_write_b64)
+
+__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) {
+  __shared__ double X[64 * XLANE + 16];
+  const ChunkMeta cm = b.chunk[blockIdx.x];
+  const SolverState &st = b.st[cm.win];
+  if (st.done || !st.need_lin) return;
+  const WinMeta wm = b.win[cm.win];
+  const int lane = threadIdx.x;
+  const bool active = lane < cm.n;
+  const int n = cm.n, L = wm.L, s = cm.s;
+  const double *x = b.x + (size_t)cm.win * XSTRIDE;
+  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
+  const int li = cm.lm_local + lane;
+
+  // Gram ownership: lane owns one segment (a, b0 .. b0+len-1) of the packed upper triangle (62 segments of <= 7)
+  int seg_a = 0, seg_b0 = 0, seg_len = 0;
+  {
+    int cnt = 0;
+    for (int a = 0; a < 26; ++a) {
+      const int len = 26 - a, nseg = (len + 6) / 7;
+      for (int q = 0; q < nseg; ++q) {
+        if (cnt == lane) { seg_a = a; seg_b0 = a + 7 * q; seg_len = min(7, 26 - seg_b0); }
+        ++cnt;
+      }
+    }
+  }
+  if (active)
+    for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
+
+  const double *obs = b.obs + cm.obs_off;
+  const unsigned char *flg = b.flags + cm.flag_off;
+  double o12[12];
+  double lam = 1.0;
+  if (active) {
+    lam = b.lam[cm.lm_off + lane];
+    o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
+    o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
+  }
+  const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
+  const double td = x[XO_TD];
+
+  double E = 0.0, gl = 0.0, cost = 0.0;
+  double wc_s[6], wc_e0[6], wc_e1[6], wc_td = 0.0;
+  for (int c = 0; c < 6; ++c) wc_s[c] = wc_e0[c] = wc_e1[c] = 0.0;
+
+  for (int t = 0; t < cm.kmax; ++t) {
+    const int j = s + t;
+    const unsigned char fl = active ? flg[(size_t)t * n + lane] : 0;
+    const double *pose_j = x + XO_POSE + 7 * j;
+    const double *ob = obs + (size_t)t * 11 * n;
+    double acc[7];
+    for (int m = 0; m < 7; ++m) acc[m] = 0.0;
+    double wj[6];
+    for (int c = 0; c < 6; ++c) wj[c] = 0.0;
+
+    for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
+      // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
+      const bool produce = (fl & 1) && (cam == 0 || (fl & 2));
+      double *xr0 = &X[lane * XLANE], *xr1 = xr0 + 26;
+      if (produce) {
+        double r[2], Ji[12], Jj[12], Je0[12], Je1[12], Jl[2], Jt[2];
+        for (int c = 0; c < 12; ++c) Ji[c] = Jj[c] = Je0[c] = Je1[c] = 0.0;
+        if (cam == 0) {
+          o12[3] = ob[(size_t)0 * n + lane]; o12[4] = ob[(size_t)1 * n + lane]; o12[5] = ob[(size_t)2 * n + lane];
+          o12[8] = ob[(size_t)6 * n + lane]; o12[9] = ob[(size_t)7 * n + lane];
+        } else {
+          o12[3] = ob[(size_t)3 * n + lane]; o12[4] = ob[(size_t)4 * n + lane]; o12[5] = ob[(size_t)5 * n + lane];
+          o12[8] = ob[(size_t)8 * n + lane]; o12[9] = ob[(size_t)9 * n + lane];
+        }
+        o12[11] = ob[(size_t)10 * n + lane];
+        if (cam == 0) proj_factor<0>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
+        else if (t > 0) proj_factor<1>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
+        else proj_factor<2>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
+        const Corrector cr = make_corrector(huber_a, r[0] * r[0] + r[1] * r[1]);
+        cost += cr.rho0;
+        for (int c = 0; c < 6; ++c) {
+          correct_col(cr, r[0], r[1], Ji[c], Ji[6 + c]);
+          correct_col(cr, r[0], r[1], Jj[c], Jj[6 + c]);
+          correct_col(cr, r[0], r[1], Je0[c], Je0[6 + c]);
+          correct_col(cr, r[0], r[1], Je1[c], Je1[6 + c]);
+        }
+        correct_col(cr, r[0], r[1], Jl[0], Jl[1]);
+        correct_col(cr, r[0], r[1], Jt[0], Jt[1]);
+        r[0] *= cr.residual_scaling;
+        r[1] *= cr.residual_scaling;
+        // landmark-side reductions (the e-block of Ceres' Schur eliminator)
+        E += Jl[0] * Jl[0] + Jl[1] * Jl[1];
+        gl += Jl[0] * r[0] + Jl[1] * r[1];
+        for (int c = 0; c < 6; ++c) {
+          wc_s[c] += Ji[c] * Jl[0] + Ji[6 + c] * Jl[1];
+          wj[c] += Jj[c] * Jl[0] + Jj[6 + c] * Jl[1];
+          wc_e0[c] += Je0[c] * Jl[0] + Je0[6 + c] * Jl[1];
+          wc_e1[c] += Je1[c] * Jl[0] + Je1[6 + c] * Jl[1];
+        }
+        wc_td += Jt[0] * Jl[0] + Jt[1] * Jl[1];
+        for (int c = 0; c < 6; ++c) {
+          xr0[c] = Ji[c]; xr1[c] = Ji[6 + c];
+          xr0[6 + c] = Jj[c]; xr1[6 + c] = Jj[6 + c];
+          xr0[12 + c] = Je0[c]; xr1[12 + c] = Je0[6 + c];
+          xr0[18 + c] = Je1[c]; xr1[18 + c] = Je1[6 + c];
+        }
+        xr0[24] = Jt[0]; xr1[24] = Jt[1];
+        xr0[25] = r[0]; xr1[25] = r[1];
+      } else {
+        for (int c = 0; c < 26; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+      }
+      __syncthreads();
+      for (int row = 0; row < 2 * n; ++row) {
+        const int base = (row >> 1) * XLANE + (row & 1) * 26;
+        const double xa = X[base + seg_a];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) acc[m] += xa * X[base + seg_b0 + m];
+      }
+      __syncthreads();
+    }
+    double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
+    for (int m = 0; m < seg_len; ++m) gs[tri26(seg_a, seg_b0 + m)] = acc[m];
+    if (active && t > 0 && (fl & 1))
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
+  }
+  if (active) {
+    b.lm_E[cm.lm_off + lane] = E;
+    b.lm_g[cm.lm_off + lane] = gl;
+    for (int c = 0; c < 6; ++c) {
+      wbase[(size_t)(6 * s + c) * L + li] = wc_s[c];
+      wbase[(size_t)(CD_EX0 + c) * L + li] = wc_e0[c];
+      wbase[(size_t)(CD_EX1 + c) * L + li] = wc_e1[c];
+    }
+    wbase[(size_t)CD_TD * L + li] = wc_td;
+  }
+  const double csum = wave_sum(active ? cost : 0.0);
+  if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
+}
+
+// Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
+// Also forms the candidate inverse depth: lambda_c = lambda - a * g_l / dhat_l^2 - b * y_l.
+__global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, double huber_a, int init_mode) {
+  const ChunkMeta cm = b.chunk[blockIdx.x];
+  const SolverState &st = b.st[cm.win];
+  if (st.done || (!init_mode && !st.step_valid)) return;
+  const int lane = threadIdx.x;
+  const bool active = lane < cm.n;
+  const int n = cm.n, s = cm.s;
+  const double *x = b.xc + (size_t)cm.win * XSTRIDE;
+  const double *obs = b.obs + cm.obs_off;
+  const unsigned char *flg = b.flags + cm.flag_off;
+  double cost = 0.0;
+  if (active) {
+    const int gi = cm.lm_off + lane;
+    double lam = b.lam[gi];
+    if (!init_mode) lam += -st.coef_a * b.lm_g[gi] / b.lm_dh2[gi] - st.coef_b * b.lm_y[gi];
+    b.lamc[gi] = lam;
+    double o12[12];
+    o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
+    o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
+    const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
+    const double td = x[XO_TD];
+    for (int t = 0; t < cm.kmax; ++t) {
+      const unsigned char fl = flg[(size_t)t * n + lane];
+      if (!(fl & 1)) continue;
+      const double *pose_j = x + XO_POSE + 7 * (s + t);
+      const double *ob = obs + (size_t)t * 11 * n;
+      o12[11] = ob[(size_t)10 * n + lane];
+      double r[2];
+      if (t > 0) {
+        o12[3] = ob[(size_t)0 * n + lane]; o12[4] = ob[(size_t)1 * n + lane]; o12[5] = ob[(size_t)2 * n + lane];
+        o12[8] = ob[(size_t)6 * n + lane]; o12[9] = ob[(size_t)7 * n + lane];
+        proj_factor<0>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        double rho[3];
+        huber_rho(huber_a, r[0] * r[0] + r[1] * r[1], rho);
+        cost += rho[0];
+      }
+      if (fl & 2) {
+        o12[3] = ob[(size_t)3 * n + lane]; o12[4] = ob[(size_t)4 * n + lane]; o12[5] = ob[(size_t)5 * n + lane];
+        o12[8] = ob[(size_t)8 * n + lane]; o12[9] = ob[(size_t)9 * n + lane];
+        if (t > 0) proj_factor<1>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else proj_factor<2>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        double rho[3];
+        huber_rho(huber_a, r[0] * r[0] + r[1] * r[1], rho);
+        cost += rho[0];
+      }
+    }
+  }
+  const double csum = wave_sum(active ? cost : 0.0);
+  if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
+}
+
+// =================================================================================================
+// IMU-leg factors
+// =================================================================================================
+#define IMU_LIN_STRIDE (31 * 39)
+
+__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm) {
+  __shared__ double Jraw[31 * 38];
+  __shared__ double rraw[31];
+  __shared__ double U[31 * 31];
+  const int win = blockIdx.x / 10, k = blockIdx.x % 10;
+  const SolverState &st = b.st[win];
+  if (st.done || !st.need_lin) return;
+  const int lane = threadIdx.x;
+  const PreintPrepared &pp = b.prep[(size_t)win * 10 + k];
+  for (int e = lane; e < 31 * 38; e += 64) Jraw[e] = 0.0;
+  for (int e = lane; e < 31 * 31; e += 64) U[e] = pp.sqrt_info[e];
+  __syncthreads();
+  if (lane == 0) {
+    const double *x = b.x + (size_t)win * XSTRIDE;
+    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), rraw, true, Jraw, 38);
+  }
+  __syncthreads();
+  double *out = b.imu_lin + ((size_t)win * 10 + k) * IMU_LIN_STRIDE;
+  for (int e = lane; e < 31 * 39; e += 64) {
+    const int i = e / 39, c = e % 39;
+    double sacc = 0.0;
+    if (c < 38) {
+      for (int q = i; q < 31; ++q) sacc += U[i * 31 + q] * Jraw[q * 38 + c];
+    } else {
+      for (int q = i; q < 31; ++q) sacc += U[i * 31 + q] * rraw[q];
+    }
+    out[e] = sacc;
+  }
+}
+
+// residual-only at the candidate: one thread per factor
+__global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int init_mode) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= b.W * 10) return;
+  const int win = f / 10, k = f % 10;
+  const SolverState &st = b.st[win];
+  if (st.done || (!init_mode && !st.step_valid)) return;
+  const PreintPrepared &pp = b.prep[f];
+  const double *x = b.xc + (size_t)win * XSTRIDE;
+  double r[31];
+  imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+              x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
+  double c = 0.0;
+  for (int i = 0; i < 31; ++i) {
+    double sacc = 0.0;
+    for (int q = i; q < 31; ++q) sacc += pp.sqrt_info[i * 31 + q] * r[q];
+    c += sacc * sacc;
+  }
+  b.imu_cost[f] = c;
+}
+
+// =================================================================================================
+// k_build_solve
+// =================================================================================================
+struct SolveParams {
+  double min_lm_diagonal, max_lm_diagonal;
+  double min_radius, gradient_tolerance;
+  int jacobi_scaling, fixed_iterations;
+};
+
+// DoglegStrategy::ComputeTraditionalDoglegStep in scalar form + TrustRegionMinimizer's model_cost_change.
+__device__ void dogleg_scalars(SolverState &s) {
+  const double gradient_norm = sqrt(s.gnorm2), gn_norm = sqrt(s.gnnorm2), radius = s.radius;
+  double a, bb, step_norm;
+  if (gn_norm <= radius) {
+    a = 0.0; bb = 1.0; step_norm = gn_norm;
+  } else if (gradient_norm * s.alpha >= radius) {
+    a = radius / gradient_norm; bb = 0.0; step_norm = radius;
+  } else {
+    const double b_dot_a = -s.alpha * s.gdotgn;
+    const double a_squared_norm = (s.alpha * gradient_norm) * (s.alpha * gradient_norm);
+    const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gn_norm * gn_norm;
+    const double c = b_dot_a - a_squared_norm;
+    const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+    const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
+    a = s.alpha * (1.0 - beta); bb = beta;
+    step_norm = sqrt(fmax(0.0, a * a * s.gnorm2 - 2.0 * a * bb * s.gdotgn + bb * bb * s.gnnorm2));
+  }
+  s.coef_a = a; s.coef_b = bb; s.dogleg_step_norm = step_norm;
+  // -(J d)^T (r + J d / 2) with d = -a D^-2 g - b y, (H + mu D^2) y = g
+  const double gy = -s.gdotgn;
+  s.model_cost_change = a * s.gnorm2 + bb * gy -
+                        0.5 * (a * a * s.q + 2.0 * a * bb * (s.gnorm2 - s.mu * gy) + bb * bb * (gy - s.mu * s.gnnorm2));
+  s.step_valid = (s.model_cost_change > 0.0) ? 1 : 0;
+}
+
+// camera dim of column c (0..37) of IMULegFactor(k, k+1)'s local Jacobian
+__device__ __forceinline__ int imu_col_cd(int k, int c) {
+  if (c < 6) return 6 * k + c;
+  if (c < 19) return CD_B0 + 13 * k + (c - 6);
+  if (c < 25) return 6 * (k + 1) + (c - 19);
+  return CD_B0 + 13 * (k + 1) + (c - 25);
+}
+
+// H(ci, cj) += v into the block-arrow storage. C: LDS 80x80; A/B: global scratch of this window.
+__device__ __forceinline__ void arrow_add(double *C, double *A_diag, double *A_off, double *Bm, int ci, int cj, double v) {
+  if (ci < CD_B0 && cj < CD_B0) {
+    C[ci * VILO_NP + cj] += v;
+  } else if (ci >= CD_B0 && cj >= CD_B0) {
+    const int ki = (ci - CD_B0) / 13, ri = (ci - CD_B0) % 13, kj = (cj - CD_B0) / 13, rj = (cj - CD_B0) % 13;
+    if (ki == kj) A_diag[ki * 169 + ri * 13 + rj] += v;
+    else if (ki == kj + 1) A_off[kj * 169 + ri * 13 + rj] += v;   // rows frame kj+1, cols frame kj
+    // (ki == kj - 1 is the transpose; stored once)
+  } else if (ci >= CD_B0) {
+    const int ki = (ci - CD_B0) / 13, ri = (ci - CD_B0) % 13;
+    Bm[ki * 1040 + ri * VILO_NP + cj] += v;                       // rows B dims, cols P dims
+  }
+  // (ci in P, cj in B) is the transpose of the case above; stored once
+}
+
+#define SOLVE_THREADS 256
+#define LDS_C 0
+#define LDS_G (LDS_C + 6400)
+#define LDS_DH2 (LDS_G + CD_N)
+#define LDS_Y (LDS_DH2 + CD_N)
+#define LDS_TMP (LDS_Y + CD_N)
+#define LDS_ACT (LDS_TMP + CD_N)
+#define LDS_BK (LDS_ACT + CD_N)
+#define LDS_BKM1 (LDS_BK + 1040)
+#define LDS_AKK (LDS_BKM1 + 1040)
+#define LDS_AKM1 (LDS_AKK + 169)
+#define LDS_AOFF (LDS_AKM1 + 169)
+#define LDS_LK (LDS_AOFF + 169)
+#define LDS_T (LDS_LK + 169)
+#define LDS_S (LDS_T + 13 * 96)
+#define LDS_RED (LDS_S + 2560)
+#define LDS_TOTAL (LDS_RED + SOLVE_THREADS)
+
+extern "C" size_t vilo_solve_lds_bytes() { return (size_t)LDS_TOTAL * sizeof(double); }
+
+__global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int win = blockIdx.x;
+  SolverState &st = b.st[win];
+  if (st.done) return;
+  const int tid = threadIdx.x;
+  const WinMeta wm = b.win[win];
+  double *C = lds + LDS_C, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y, *tmp = lds + LDS_TMP, *act = lds + LDS_ACT;
+  double *Bk = lds + LDS_BK, *Bkm1 = lds + LDS_BKM1, *Akk = lds + LDS_AKK, *Akm1 = lds + LDS_AKM1, *Aoff = lds + LDS_AOFF;
+  double *Lk = lds + LDS_LK, *T = lds + LDS_T, *S = lds + LDS_S, *red = lds + LDS_RED;
+  double *A_diag = b.A_diag + (size_t)win * 11 * 169, *A_off = b.A_off + (size_t)win * 10 * 169;
+  double *Bm = b.Bm + (size_t)win * 11 * 1040, *Tm = b.Tm + (size_t)win * 11 * 13 * 96, *Lkm = b.Lk + (size_t)win * 11 * 169;
+  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
+  double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
+  double *cam_scale = b.cam_scale + (size_t)win * CD_N;
+  const int L = wm.L;
+  const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
+  const int F = wm.n_frames;
+
+  if (st.need_lin) {
+    // activity mask of camera dims (SetParameterBlockConstant, estimator.cpp:1074-1105)
+    for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+      double a = 1.0;
+      if (cd >= CD_EX0 && cd < CD_TD && (wm.const_mask & CONST_EX)) a = 0.0;
+      if (cd == CD_TD && (wm.const_mask & CONST_TD)) a = 0.0;
+      if (cd == 79 || cd >= CD_B0 + 143) a = 0.0;
+      if (cd < 66 && cd / 6 >= F) a = 0.0;
+      if (cd >= CD_B0 && cd < CD_B0 + 143) {
+        const int k = (cd - CD_B0) / 13, c = (cd - CD_B0) % 13;
+        if (k >= F) a = 0.0;
+        if (c >= 9 && (wm.const_mask & CONST_LB)) a = 0.0;
+      }
+      act[cd] = a;
+    }
+    bool solved = false;
+    while (!solved) {
+      __syncthreads();
+      const double mu = st.mu;
+      // ---- P0: clear ----
+      for (int e = tid; e < 6400; e += SOLVE_THREADS) C[e] = 0.0;
+      for (int e = tid; e < CD_N; e += SOLVE_THREADS) g[e] = 0.0;
+      for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) A_diag[e] = 0.0;
+      for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) A_off[e] = 0.0;
+      for (int e = tid; e < 11 * 1040; e += SOLVE_THREADS) Bm[e] = 0.0;
+      __syncthreads();
+      // ---- P1: visual Gram slots -> C, g ----
+      for (int ch = 0; ch < wm.n_chunks; ++ch) {
+        const ChunkMeta cm = b.chunk[wm.chunk_off + ch];
+        for (int t = 0; t < cm.kmax; ++t) {
+          const double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
+          const int j = cm.s + t;
+          for (int e = tid; e < VILO_GRAM; e += SOLVE_THREADS) {
+            // decode packed index e -> (a, bcol)
+            int a = 0, rem = e;
+            while (rem >= 26 - a) { rem -= 26 - a; ++a; }
+            const int bc = a + rem;
+            if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;  // no pose_j columns in OneFrameTwoCam
+            const double v = gs[e];
+            auto cdof = [&](int c) { return c < 6 ? 6 * cm.s + c : (c < 12 ? 6 * j + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
+            if (bc == 25) {
+              if (a < 25) g[cdof(a)] += v;
+            } else {
+              const int pa = cdof(a), pb = cdof(bc);
+              C[pa * VILO_NP + pb] += v;
+              if (pa != pb) C[pb * VILO_NP + pa] += v;
+            }
+          }
+          __syncthreads();
+        }
+      }
+      // ---- P2: IMU-leg factors ----
+      for (int k = 0; k + 1 < F; ++k) {
+        const double *lin = b.imu_lin + ((size_t)win * 10 + k) * IMU_LIN_STRIDE;
+        for (int e = tid; e < IMU_LIN_STRIDE; e += SOLVE_THREADS) S[e] = lin[e];
+        __syncthreads();
+        // 39 x 39 Gram (column 38 = whitened residual): upper triangle incl. diagonal = 780 entries
+        for (int e = tid; e < 780; e += SOLVE_THREADS) {
+          int a = 0, rem = e;
+          while (rem >= 39 - a) { rem -= 39 - a; ++a; }
+          const int bc = a + rem;
+          double sacc = 0.0;
+          for (int i = 0; i < 31; ++i) sacc += S[i * 39 + a] * S[i * 39 + bc];
+          if (bc == 38) {
+            if (a < 38) g[imu_col_cd(k, a)] += sacc;   // distinct a -> distinct target
+          } else {
+            const int ca = imu_col_cd(k, a), cb = imu_col_cd(k, bc);
+            if (ca == cb) {
+              arrow_add(C, A_diag, A_off, Bm, ca, cb, sacc);
+            } else {
+              arrow_add(C, A_diag, A_off, Bm, ca, cb, sacc);
+              arrow_add(C, A_diag, A_off, Bm, cb, ca, sacc);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // ---- P3: marginalisation prior: H += J0^T J0, g += J0^T (r0 + J0 dx) ----
+      if (wm.prior_n > 0) {
+        const int n = wm.prior_n;
+        const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
+        const int *pmap = b.prior_map + (size_t)win * 96;
+        double *dx = S;
+        if (tid < wm.prior_nb) {
+          const int bs = b.prior_bsize[win * 40 + tid];
+          prior_dx(x + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid], bs,
+                   dx + b.prior_bidx[win * 40 + tid]);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += SOLVE_THREADS) {
+          double sacc = b0[i];
+          for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + i] * dx[q];   // Hp symmetric: column read is coalesced
+          g[pmap[i]] += sacc;
+        }
+        for (int e = tid; e < n * n; e += SOLVE_THREADS) {
+          const int i = e / n, q = e % n;
+          arrow_add(C, A_diag, A_off, Bm, pmap[i], pmap[q], Hp[e]);
+        }
+        __syncthreads();
+      }
+      // ---- P4: constant dims ----
+      for (int e = tid; e < 6400; e += SOLVE_THREADS) {
+        const int i = e / VILO_NP, j = e % VILO_NP;
+        if (act[i] == 0.0 || act[j] == 0.0) C[e] = (i == j) ? 1.0 : 0.0;
+      }
+      for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) {
+        const int k = e / 169, i = (e % 169) / 13, j = e % 13;
+        if (act[CD_B0 + 13 * k + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) A_diag[e] = (i == j) ? 1.0 : 0.0;
+      }
+      for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) {
+        const int k = e / 169, i = (e % 169) / 13, j = e % 13;
+        if (act[CD_B0 + 13 * (k + 1) + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) A_off[e] = 0.0;
+      }
+      for (int e = tid; e < 11 * 1040; e += SOLVE_THREADS) {
+        const int k = e / 1040, i = (e % 1040) / VILO_NP, j = e % VILO_NP;
+        if (act[CD_B0 + 13 * k + i] == 0.0 || act[j] == 0.0) Bm[e] = 0.0;
+      }
+      for (int e = tid; e < CD_N; e += SOLVE_THREADS)
+        if (act[e] == 0.0) g[e] = 0.0;
+      __syncthreads();
+      // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
+      {
+        for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+          double hii = 1.0;
+          if (cd < CD_B0) hii = C[cd * VILO_NP + cd];
+          else if (cd < CD_B0 + 143) hii = A_diag[((cd - CD_B0) / 13) * 169 + ((cd - CD_B0) % 13) * 14];
+          double sc = 1.0;
+          if (act[cd] != 0.0) {
+            if (!st.scale_ready) {
+              sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
+              cam_scale[cd] = sc;
+            } else {
+              sc = cam_scale[cd];
+            }
+            const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
+            dh2[cd] = d2 / (sc * sc);
+            tmp[cd] = g[cd] / dh2[cd];
+          } else {
+            dh2[cd] = 1.0;
+            tmp[cd] = 0.0;
+          }
+        }
+        __syncthreads();
+      }
+      // camera part of |D^-1 g|^2, max|g|, and q = v^T H v (C, A, B before regularisation / Schur)
+      double part_gn = 0.0, part_q = 0.0, part_gmax = 0.0;
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+        part_gn += g[cd] * tmp[cd];
+        part_gmax = fmax(part_gmax, fabs(g[cd]));
+      }
+      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) {
+        double sacc = 0.0;
+        for (int j = 0; j < VILO_NP; ++j) sacc += C[i * VILO_NP + j] * tmp[j];
+        part_q += tmp[i] * sacc;
+      }
+      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) {
+        const int k = e / 13, i = e % 13;
+        const double vi = tmp[CD_B0 + 13 * k + i];
+        double sacc = 0.0;
+        for (int j = 0; j < 13; ++j) sacc += A_diag[k * 169 + i * 13 + j] * tmp[CD_B0 + 13 * k + j];
+        double cross = 0.0;
+        if (k > 0)
+          for (int j = 0; j < 13; ++j) cross += A_off[(k - 1) * 169 + i * 13 + j] * tmp[CD_B0 + 13 * (k - 1) + j];
+        double bp = 0.0;
+        for (int j = 0; j < VILO_NP; ++j) bp += Bm[k * 1040 + i * VILO_NP + j] * tmp[j];
+        part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
+      }
+      // ---- P6: landmarks pass 1 ----
+      double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off;
+      double *lm_scale = b.lm_scale + wm.lm_off, *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
+      for (int l = tid; l < L; l += SOLVE_THREADS) {
+        const double E = lm_E[l], gl = lm_g[l];
+        double sc;
+        if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
+        else sc = lm_scale[l];
+        const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
+        lm_dh2[l] = d2;
+        const double vl = gl / d2;
+        double tl = 0.0;
+        for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * tmp[a];
+        part_q += 2.0 * vl * tl + E * vl * vl;
+        part_gn += gl * vl;
+        part_gmax = fmax(part_gmax, fabs(gl));
+        lm_einv[l] = 1.0 / (E + mu * d2);
+      }
+      const double gnorm2 = block_sum(part_gn, red);
+      const double qq = block_sum(part_q, red);
+      const double gmax = block_max(part_gmax, red);
+      // termination tests of FinalizeIterationAndCheckIfMinimizerCanContinue that need the fresh gradient
+      if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
+        if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
+        return;
+      }
+      // Schur complement: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2), g_P -= sum_l w_l g_l / (...)
+      if (tid < VILO_NP) y[tid] = 0.0;   // y[0..79] accumulates the landmark part of the reduced rhs
+      for (int l0 = 0; l0 < L; l0 += 32) {
+        const int nl = min(32, L - l0);
+        for (int e = tid; e < 80 * 32; e += SOLVE_THREADS) {
+          const int a = e / 32, q = e % 32;
+          S[e] = (q < nl && a < VILO_NPU) ? wl[(size_t)a * L + l0 + q] * act[a] : 0.0;
+        }
+        if (tid < 32) {
+          red[tid] = (tid < nl) ? lm_einv[l0 + tid] : 0.0;
+          red[32 + tid] = (tid < nl) ? lm_g[l0 + tid] * lm_einv[l0 + tid] : 0.0;
+        }
+        __syncthreads();
+        for (int e = tid; e < 6400; e += SOLVE_THREADS) {
+          const int i = e / VILO_NP, j = e % VILO_NP;
+          double sacc = 0.0;
+          for (int q = 0; q < 32; ++q) sacc += S[i * 32 + q] * S[j * 32 + q] * red[q];
+          C[e] -= sacc;
+        }
+        if (tid < VILO_NP) {
+          double sacc = 0.0;
+          for (int q = 0; q < 32; ++q) sacc += S[tid * 32 + q] * red[32 + q];
+          y[tid] += sacc;
+        }
+        __syncthreads();
+      }
+      // rhs of the reduced system: gred = g - (landmark part)
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < VILO_NP) ? y[cd] : 0.0);
+      __syncthreads();
+      // ---- P7/P8: regularise + block elimination of the B part (frames F-1 .. 0) ----
+      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) C[i * VILO_NP + i] += mu * dh2[i];
+      int fail = 0;
+      for (int k = F - 1; k >= 0; --k) {
+        if (k == F - 1) {
+          for (int e = tid; e < 169; e += SOLVE_THREADS) Akk[e] = A_diag[k * 169 + e] + ((e / 13 == e % 13) ? mu * dh2[CD_B0 + 13 * k + e / 13] : 0.0);
+          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bm[k * 1040 + e];
+        }
+        if (k > 0) {
+          for (int e = tid; e < 169; e += SOLVE_THREADS) {
+            Aoff[e] = A_off[(k - 1) * 169 + e];
+            Akm1[e] = A_diag[(k - 1) * 169 + e] + ((e / 13 == e % 13) ? mu * dh2[CD_B0 + 13 * (k - 1) + e / 13] : 0.0);
+          }
+          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bkm1[e] = Bm[(k - 1) * 1040 + e];
+        }
+        __syncthreads();
+        // Cholesky of the 13x13 diagonal block (thread 0; 13^3/6 flops)
+        if (tid == 0) {
+          for (int j = 0; j < 13; ++j) {
+            double sacc = Akk[j * 13 + j];
+            for (int q = 0; q < j; ++q) sacc -= Lk[j * 13 + q] * Lk[j * 13 + q];
+            if (!(sacc > 0.0) || !isfinite(sacc)) { fail = 1; sacc = 1.0; }
+            const double ljj = sqrt(sacc);
+            Lk[j * 13 + j] = ljj;
+            for (int i = j + 1; i < 13; ++i) {
+              double tacc = Akk[i * 13 + j];
+              for (int q = 0; q < j; ++q) tacc -= Lk[i * 13 + q] * Lk[j * 13 + q];
+              Lk[i * 13 + j] = tacc / ljj;
+            }
+            for (int i = 0; i < j; ++i) Lk[i * 13 + j] = 0.0;
+          }
+          red[0] = (double)fail;
+        }
+        __syncthreads();
+        fail = (int)red[0];
+        __syncthreads();
+        // T = Lk^-1 [Aoff | Bk | g_k]: one thread per column (13 + 80 + 1 = 94)
+        if (tid < 94) {
+          double col[13];
+          for (int i = 0; i < 13; ++i) {
+            double v = (tid < 13) ? ((k > 0) ? Aoff[i * 13 + tid] : 0.0) : (tid < 93 ? Bk[i * VILO_NP + (tid - 13)] : tmp[CD_B0 + 13 * k + i]);
+            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * col[q];
+            col[i] = v / Lk[i * 13 + i];
+          }
+          for (int i = 0; i < 13; ++i) T[i * 96 + tid] = col[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < 13 * 96; e += SOLVE_THREADS) Tm[k * 13 * 96 + e] = T[e];
+        for (int e = tid; e < 169; e += SOLVE_THREADS) Lkm[k * 169 + e] = Lk[e];
+        // Schur updates
+        if (k > 0) {
+          for (int e = tid; e < 169; e += SOLVE_THREADS) {
+            const int i = e / 13, j = e % 13;
+            double sacc = 0.0;
+            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + j];
+            Akm1[e] -= sacc;
+          }
+          for (int e = tid; e < 1040; e += SOLVE_THREADS) {
+            const int i = e / VILO_NP, j = e % VILO_NP;
+            double sacc = 0.0;
+            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + 13 + j];
+            Bkm1[e] -= sacc;
+          }
+          if (tid < 13) {
+            double sacc = 0.0;
+            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + tid] * T[q * 96 + 93];
+            tmp[CD_B0 + 13 * (k - 1) + tid] -= sacc;
+          }
+        }
+        for (int e = tid; e < 6400; e += SOLVE_THREADS) {
+          const int i = e / VILO_NP, j = e % VILO_NP;
+          double sacc = 0.0;
+          for (int q = 0; q < 13; ++q) sacc += T[q * 96 + 13 + i] * T[q * 96 + 13 + j];
+          C[e] -= sacc;
+        }
+        if (tid >= 64 && tid < 64 + VILO_NP) {
+          const int i = tid - 64;
+          double sacc = 0.0;
+          for (int q = 0; q < 13; ++q) sacc += T[q * 96 + 13 + i] * T[q * 96 + 93];
+          tmp[i] -= sacc;
+        }
+        __syncthreads();
+        // roll: (k-1) becomes current
+        if (k > 0) {
+          for (int e = tid; e < 169; e += SOLVE_THREADS) Akk[e] = Akm1[e];
+          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bkm1[e];
+        }
+        __syncthreads();
+      }
+      // dense Cholesky of the 80x80 reduced pose system (right-looking, in place, lower)
+      for (int j = 0; j < VILO_NP; ++j) {
+        if (tid == 0) {
+          double d = C[j * VILO_NP + j];
+          if (!(d > 0.0) || !isfinite(d)) { fail = 1; d = 1.0; }
+          C[j * VILO_NP + j] = sqrt(d);
+          red[0] = (double)fail;
+        }
+        __syncthreads();
+        fail = (int)red[0];
+        const double ljj = C[j * VILO_NP + j];
+        for (int i = j + 1 + tid; i < VILO_NP; i += SOLVE_THREADS) C[i * VILO_NP + j] /= ljj;
+        __syncthreads();
+        const int m = VILO_NP - 1 - j;
+        for (int e = tid; e < m * m; e += SOLVE_THREADS) {
+          const int i = j + 1 + e / m, q = j + 1 + e % m;
+          if (q <= i) C[i * VILO_NP + q] -= C[i * VILO_NP + j] * C[q * VILO_NP + j];
+        }
+        __syncthreads();
+      }
+      if (fail) {
+        // DoglegStrategy::ComputeGaussNewtonStep: mu *= 10 and retry while mu < max_mu (1.0)
+        if (tid == 0) st.mu *= 10.0;
+        __syncthreads();
+        if (!(st.mu < 1.0)) {
+          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = qq; st.gmax = gmax; st.scale_ready = 1; }
+          return;
+        }
+        continue;
+      }
+      // solve L L^T yP = rhs (tmp[0..79])
+      for (int j = 0; j < VILO_NP; ++j) {
+        if (tid == 0) tmp[j] /= C[j * VILO_NP + j];
+        __syncthreads();
+        for (int i = j + 1 + tid; i < VILO_NP; i += SOLVE_THREADS) tmp[i] -= C[i * VILO_NP + j] * tmp[j];
+        __syncthreads();
+      }
+      for (int j = VILO_NP - 1; j >= 0; --j) {
+        if (tid == 0) tmp[j] /= C[j * VILO_NP + j];
+        __syncthreads();
+        for (int i = tid; i < j; i += SOLVE_THREADS) tmp[i] -= C[j * VILO_NP + i] * tmp[j];
+        __syncthreads();
+      }
+      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) y[i] = tmp[i];
+      __syncthreads();
+      // back-substitute the B part, frames 0 .. F-1: L_k^T y_k = t_g - T_A y_{k-1} - T_B y_P
+      for (int k = 0; k < F; ++k) {
+        for (int e = tid; e < 13 * 96; e += SOLVE_THREADS) T[e] = Tm[k * 13 * 96 + e];
+        for (int e = tid; e < 169; e += SOLVE_THREADS) Lk[e] = Lkm[k * 169 + e];
+        __syncthreads();
+        if (tid < 13) {
+          double sacc = T[tid * 96 + 93];
+          if (k > 0)
+            for (int q = 0; q < 13; ++q) sacc -= T[tid * 96 + q] * y[CD_B0 + 13 * (k - 1) + q];
+          for (int q = 0; q < VILO_NP; ++q) sacc -= T[tid * 96 + 13 + q] * y[q];
+          S[tid] = sacc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 12; i >= 0; --i) {
+            double v = S[i];
+            for (int q = i + 1; q < 13; ++q) v -= Lk[q * 13 + i] * y[CD_B0 + 13 * k + q];
+            y[CD_B0 + 13 * k + i] = v / Lk[i * 13 + i];
+          }
+        }
+        __syncthreads();
+      }
+      // ---- P9: landmarks pass 2 (back-substitution) + norms ----
+      double part_gnn = 0.0, part_gy = 0.0;
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+        if (act[cd] == 0.0) y[cd] = 0.0;
+        part_gnn += dh2[cd] * y[cd] * y[cd] * act[cd];
+        part_gy += g[cd] * y[cd];
+      }
+      __syncthreads();
+      for (int l = tid; l < L; l += SOLVE_THREADS) {
+        double tl = 0.0;
+        for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * y[a];
+        const double yl = (lm_g[l] - tl) * lm_einv[l];
+        lm_y[l] = yl;
+        part_gnn += lm_dh2[l] * yl * yl;
+        part_gy += lm_g[l] * yl;
+      }
+      const double gnnorm2 = block_sum(part_gnn, red);
+      const double gy = block_sum(part_gy, red);
+      bool finite_ok = isfinite(gnnorm2) && isfinite(gy);
+      if (!finite_ok) {   // IsArrayValid(gauss_newton_step_) failed: same handling as a failed factorisation
+        if (tid == 0) st.mu *= 10.0;
+        __syncthreads();
+        if (!(st.mu < 1.0)) {
+          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.scale_ready = 1; }
+          return;
+        }
+        continue;
+      }
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) { cam_g[cd] = g[cd]; cam_dh2[cd] = dh2[cd]; cam_y[cd] = y[cd]; }
+      if (tid == 0) {
+        st.gnorm2 = gnorm2; st.gnnorm2 = gnnorm2; st.gdotgn = -gy; st.q = qq; st.gmax = gmax;
+        st.alpha = gnorm2 / qq;
+        st.scale_ready = 1;
+        st.lin_fail = 0;
+      }
+      solved = true;
+    }
+    __syncthreads();
+  } else {
+    for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) { g[cd] = cam_g[cd]; dh2[cd] = cam_dh2[cd]; y[cd] = cam_y[cd]; }
+    __syncthreads();
+  }
+  // ---- P11: dogleg step for the current radius, candidate camera state ----
+  if (tid == 0) {
+    if (st.radius <= sp.min_radius) { st.done = 1; st.termination = 1; st.step_valid = 0; }
+    else dogleg_scalars(st);
+  }
+  __syncthreads();
+  if (st.done || !st.step_valid) return;
+  const double ca = st.coef_a, cb = st.coef_b;
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = -ca * g[cd] / dh2[cd] - cb * y[cd];
+  __syncthreads();
+  if (tid < 11) pose_plus(x + XO_POSE + 7 * tid, tmp + 6 * tid, xc + XO_POSE + 7 * tid);
+  else if (tid < 13) pose_plus(x + XO_EX + 7 * (tid - 11), tmp + CD_EX0 + 6 * (tid - 11), xc + XO_EX + 7 * (tid - 11));
+  else if (tid == 13) xc[XO_TD] = x[XO_TD] + tmp[CD_TD];
+  else if (tid >= 32 && tid < 32 + 143) {
+    const int e = tid - 32, k = e / 13, c = e % 13;
+    if (c < 9) xc[XO_SB + 9 * k + c] = x[XO_SB + 9 * k + c] + tmp[CD_B0 + e];
+    else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + tmp[CD_B0 + e];
+  }
+}
+
+// =================================================================================================
+// k_accept: candidate cost, step quality, accept / reject (TrustRegionMinimizer::{IsStepSuccessful,
+// HandleSuccessfulStep, HandleUnsuccessfulStep, HandleInvalidStep} + DoglegStrategy::Step{Accepted,Rejected,IsInvalid})
+// =================================================================================================
+struct AcceptParams {
+  double min_relative_decrease, function_tolerance, parameter_tolerance;
+  int max_num_iterations, fixed_iterations, init_mode, pad;
+};
+
+__global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
+  __shared__ double red[128];
+  __shared__ double dxs[VILO_MAX_PRIOR_DIM];
+  __shared__ int accept_s;
+  const int win = blockIdx.x, tid = threadIdx.x;
+  SolverState &st = b.st[win];
+  if (st.done) return;
+  const WinMeta wm = b.win[win];
+  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
+  if (!ap.init_mode && !st.step_valid) {
+    if (tid == 0) {
+      // HandleInvalidStep
+      st.num_invalid++;
+      if (st.num_invalid > 5) { st.done = 1; st.termination = 2; }
+      st.mu *= 10.0;
+      st.need_lin = 1;
+      st.iter++;
+      if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
+      if (st.iter >= ap.max_num_iterations && !st.done) { st.done = 1; st.termination = 0; }
+    }
+    return;
+  }
+  // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2)
+  double part = 0.0;
+  for (int c = tid; c < wm.n_chunks; c += 128) part += b.chunk_cost[wm.chunk_off + c];
+  const double vis = block_sum(part, red);
+  part = 0.0;
+  for (int k = tid; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
+  const double imu = block_sum(part, red);
+  double pri = 0.0;
+  if (wm.prior_n > 0) {
+    const int n = wm.prior_n;
+    if (tid < wm.prior_nb)
+      prior_dx(xc + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid],
+               b.prior_bsize[win * 40 + tid], dxs + b.prior_bidx[win * 40 + tid]);
+    __syncthreads();
+    const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
+    part = 0.0;
+    for (int i = tid; i < n; i += 128) {
+      double sacc = 0.0;
+      for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + i] * dxs[q];
+      part += dxs[i] * (sacc + 2.0 * b0[i]);
+    }
+    pri = block_sum(part, red) + b.prior_c0[win];
+  }
+  double cand = 0.5 * (vis + imu + pri);
+  if (!isfinite(cand)) cand = 1.7976931348623157e308;
+  if (ap.init_mode) {
+    if (tid == 0) {
+      st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
+      st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
+    }
+    return;
+  }
+  // ambient-space norms for ParameterToleranceReached
+  bool converged = false;
+  if (!ap.fixed_iterations) {
+    double pn = 0.0, ps = 0.0;
+    for (int e = tid; e < XSTRIDE; e += 128) {
+      bool on = e < XO_TD + 1 && !(e >= XO_EX && e < XO_TD && (wm.const_mask & CONST_EX)) && !(e == XO_TD && (wm.const_mask & CONST_TD)) &&
+                !(e >= XO_LB && e < XO_EX && (wm.const_mask & CONST_LB));
+      if (on) { pn += x[e] * x[e]; ps += (x[e] - xc[e]) * (x[e] - xc[e]); }
+    }
+    for (int l = tid; l < wm.L; l += 128) {
+      const double a = b.lam[wm.lm_off + l], c = b.lamc[wm.lm_off + l];
+      pn += a * a; ps += (a - c) * (a - c);
+    }
+    const double xn = sqrt(block_sum(pn, red)), sn = sqrt(block_sum(ps, red));
+    if (sn <= ap.parameter_tolerance * (xn + ap.parameter_tolerance)) converged = true;
+    if (!converged && fabs(st.x_cost - cand) <= ap.function_tolerance * st.x_cost) converged = true;
+  }
+  if (converged) {
+    if (tid == 0) { st.done = 1; st.termination = 1; st.cand_cost = cand; }
+    return;
+  }
+  if (tid == 0) {
+    const double rel = (st.x_cost - cand) / st.model_cost_change;
+    st.cand_cost = cand;
+    st.num_invalid = 0;
+    if (rel > ap.min_relative_decrease) {
+      accept_s = 1;
+      st.x_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
+      if (rel < 0.25) st.radius *= 0.5;
+      if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
+      st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+      st.need_lin = 1;
+      st.num_successful++;
+    } else {
+      accept_s = 0;
+      st.radius *= 0.5;
+      st.need_lin = 0;
+    }
+    st.iter++;
+    if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
+    if (st.iter >= ap.max_num_iterations) { st.done = 1; st.termination = 0; }
+  }
+  __syncthreads();
+  if (accept_s) {
+    for (int e = tid; e < XSTRIDE; e += 128) x[e] = xc[e];
+    for (int l = tid; l < wm.L; l += 128) b.lam[wm.lm_off + l] = b.lamc[wm.lm_off + l];
+  }
+}
+
+__global__ void k_init_state(BatchDev b, double radius0) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= b.W) return;
+  SolverState &s = b.st[w];
+  memset(&s, 0, sizeof(SolverState));
+  s.radius = radius0;
+  s.mu = 1e-8;
+  s.need_lin = 1;
+}
+
+// =================================================================================================
+// host-side launch sequence
+// =================================================================================================
+int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
+  const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
+  hipStream_t s = ctx->stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = (size_t)LDS_TOTAL * sizeof(double);
+  if (!attr_set) {
+    VILO_HIP(hipFuncSetAttribute((const void *)k_build_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  SolveParams sp;
+  sp.min_lm_diagonal = o->min_lm_diagonal; sp.max_lm_diagonal = o->max_lm_diagonal;
+  sp.min_radius = o->min_trust_region_radius; sp.gradient_tolerance = o->gradient_tolerance;
+  sp.jacobi_scaling = o->jacobi_scaling; sp.fixed_iterations = o->fixed_iterations;
+  AcceptParams ap;
+  ap.min_relative_decrease = o->min_relative_decrease; ap.function_tolerance = o->function_tolerance;
+  ap.parameter_tolerance = o->parameter_tolerance; ap.max_num_iterations = o->max_num_iterations;
+  ap.fixed_iterations = o->fixed_iterations; ap.init_mode = 1; ap.pad = 0;
+  const int W = b.W;
+  hipLaunchKernelGGL(k_init_state, dim3((W + 127) / 128), dim3(128), 0, s, b, o->initial_trust_region_radius);
+  // IterationZero: cost at the initial point
+  VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 1);
+  hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
+  hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+  ap.init_mode = 0;
+  for (int it = 0; it < o->max_num_iterations; ++it) {
+    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha);
+    hipLaunchKernelGGL(k_imu_linearize, dim3(W * 10), dim3(64), 0, s, b, gn);
+    hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
+    hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 0);
+    hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 0);
+    hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+  }
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
+}
+
+// preMarginalize (marginalization_factor.cpp:119-138): evaluate the factors once at the current state.
+int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
+  const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
+  hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4);
+  hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, ctx->stream, b, sq, ha);
+  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, gn);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
+}

@@ -1,0 +1,104 @@
+// Device-resident layout of a batch of independent sliding windows and of the per-window solver state.
+//
+// Camera-side ("f-block") local dimensions of one window (Nc = 11*19 + 13 = 222):
+//   P part (80, dense, lives in LDS):  pose_k -> 6k..6k+5 (k = 0..10), ex0 -> 66..71, ex1 -> 72..77, td -> 78, pad 79
+//   B part (11 x 13, block tridiagonal): frame k -> 80 + 13k + c, c: v 0..2, ba 3..5, bg 6..8, rho 9..12
+// Landmarks (inverse depths) are the eliminated e-blocks (Ceres DENSE_SCHUR ordering).
+#pragma once
+#include "vilo_internal.hpp"
+
+// state vector layout (doubles) per window: vector2double order (estimator.cpp:848-901)
+#define XO_POSE 0
+#define XO_SB 77
+#define XO_LB 176
+#define XO_EX 220
+#define XO_TD 234
+#define XSTRIDE 240
+
+#define CD_EX0 66
+#define CD_EX1 72
+#define CD_TD 78
+#define CD_B0 80
+#define CD_N 224  // 80 + 143 = 223, padded
+
+#define CONST_LB 1
+#define CONST_EX 2
+#define CONST_TD 4
+
+struct WinMeta {
+  int n_frames, L, n_chunks, use_leg;
+  int lm_off;      // first landmark (device order)
+  int chunk_off;   // first group chunk
+  int const_mask;
+  int prior_n;     // 0: no prior
+  int gram_off;    // first Gram slot
+  int n_gram;
+  int prior_nb;
+  int pad;
+};
+
+// One wave-sized chunk of the landmarks of a window that share a start frame.
+struct ChunkMeta {
+  int win, s, n, kmax;      // n <= 64 landmarks, kmax = max observations among them
+  int lm_off;               // global device-order index of lane 0
+  int lm_local;             // index inside the window
+  int gram_off;             // global Gram slot of t = 0 (kmax slots)
+  int pad;
+  long long obs_off;        // doubles: layout [t][11][n]
+  long long flag_off;       // bytes:   layout [t][n]  bit0 valid, bit1 stereo
+};
+
+// Trust-region / dogleg state per window (Ceres 1.14 TrustRegionMinimizer + DoglegStrategy members).
+struct SolverState {
+  double radius, mu;
+  double x_cost, cand_cost, model_cost_change;
+  double gnorm2;      // |D^-1 g|^2           (gradient_.squaredNorm())
+  double gnnorm2;     // |gauss_newton_step_|^2
+  double gdotgn;      // gradient_ . gauss_newton_step_
+  double q;           // |J D^-2 g|^2
+  double alpha;
+  double coef_a, coef_b;   // delta = -a * g / dhat^2 - b * y
+  double dogleg_step_norm;
+  double gmax;        // max |g_i| (unscaled gradient)
+  double x_norm;
+  double vis_cost, imu_cost, prior_cost;
+  int iter, num_successful, termination, done;
+  int need_lin;       // 1: (re)linearise at x before the next step (reuse_ == false)
+  int step_valid;
+  int scale_ready;    // Jacobi scaling computed (iteration 0)
+  int num_invalid;
+  int lin_fail;       // Cholesky failed for every mu < max_mu
+  int pad[3];
+  double cost_trace[64];
+  double radius_trace[64];
+};
+
+struct BatchDev {
+  int W, n_chunks, n_lm, n_gram;
+  WinMeta *win;
+  ChunkMeta *chunk;
+  double *obs;
+  unsigned char *flags;
+  // states
+  double *x, *xc, *x0;        // [W][XSTRIDE] current / candidate / initial
+  double *lam, *lamc, *lam0;  // [n_lm]
+  int *lm_perm;               // device order -> original index within its window
+  // landmark-side linearisation
+  double *lm_E, *lm_g, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
+  double *lm_w;               // per window: [80][L] at 80 * lm_off
+  double *gram;               // [n_gram][VILO_GRAM]
+  double *chunk_cost;         // [n_chunks]
+  // IMU factors
+  PreintPrepared *prep;       // [W][10]
+  double *imu_lin;            // [W][10][31*39]  whitened J (31x38) | whitened r (col 38)
+  double *imu_cost;           // [W][10]
+  // prior
+  double *prior_H, *prior_b0, *prior_c0, *prior_x0;   // [W][96*96], [W][96], [W], [W][280]
+  int *prior_map, *prior_bsize, *prior_bidx, *prior_bxoff, *prior_bstate;  // [W][96], [W][40] x4
+  // camera-side vectors [W][CD_N]
+  double *cam_g, *cam_dh2, *cam_y, *cam_scale;
+  // block scratch
+  double *A_diag, *A_off, *Bm, *Tm, *Lk;   // [W][11][169], [W][10][169], [W][11][13*80], [W][11][13*96], [W][11][169]
+  SolverState *st;
+  int *status;
+};

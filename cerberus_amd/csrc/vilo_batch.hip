@@ -1,0 +1,375 @@
+// Device-resident batches of independent sliding windows: packing (host -> HBM layout), the solve driver and
+// result download. Replaces the pack / unpack halves of Estimator::optimization():
+//   vector2double  estimator.cpp:848-901   (para_* arrays, inverse depths in feature-list order)
+//   problem build  estimator.cpp:1059-1216 (which residual blocks exist; here: landmark-major chunk tables)
+//   double2vector  estimator.cpp:903-1003  (gauge fix: vilo_gauge_fix)
+#include <algorithm>
+#include <cmath>
+
+#include "solver_types.hpp"
+
+int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o);
+
+struct vilo_batch {
+  BatchDev d;
+  std::vector<void *> allocs;
+  std::vector<int> lm_off_host;     // per window
+  std::vector<int> perm_host;       // device order -> original landmark index (per window, concatenated)
+  std::vector<int> L_host;
+  int W;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(vilo_ctx *ctx, vilo_batch *bt, T **p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  void *q = nullptr;
+  VILO_HIP(hipMalloc(&q, n * sizeof(T)));
+  bt->allocs.push_back(q);
+  *p = (T *)q;
+  return VILO_OK;
+}
+template <class T>
+int dev_upload(vilo_ctx *ctx, vilo_batch *bt, T **p, const std::vector<T> &h) {
+  int rc = dev_alloc(ctx, bt, p, h.size());
+  if (rc != VILO_OK) return rc;
+  if (!h.empty()) VILO_HIP(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return VILO_OK;
+}
+#define TRYB(x) do { int rc_ = (x); if (rc_ != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc_; } } while (0)
+
+// camera dim of the first local dim of a prior block id; -1 if unsupported
+int prior_block_cd(int id, int *state_off) {
+  const int kind = id / 16, index = id % 16;
+  switch (kind) {
+    case VILO_BLK_POSE: if (index > 10) return -1; *state_off = XO_POSE + 7 * index; return 6 * index;
+    case VILO_BLK_SB: if (index > 10) return -1; *state_off = XO_SB + 9 * index; return CD_B0 + 13 * index;
+    case VILO_BLK_LB: if (index > 10) return -1; *state_off = XO_LB + 4 * index; return CD_B0 + 13 * index + 9;
+    case VILO_BLK_EX: if (index > 1) return -1; *state_off = XO_EX + 7 * index; return CD_EX0 + 6 * index;
+    case VILO_BLK_TD: *state_off = XO_TD; return CD_TD;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+BatchDev *vilo_batch_dev(vilo_batch *bt) { return &bt->d; }
+const int *vilo_batch_perm(vilo_batch *bt, int win, int *L) {
+  *L = bt->L_host[win];
+  return bt->perm_host.data() + bt->lm_off_host[win];
+}
+
+extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
+  if (!bt) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  for (void *p : bt->allocs) (void)hipFree(p);
+  delete bt;
+}
+
+extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *init, vilo_batch **out) {
+  if (!ctx || !in || !init || !out || W <= 0) return VILO_ERR_BAD_ARG;
+  *out = nullptr;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_batch *bt = new vilo_batch();
+  bt->W = W;
+  memset(&bt->d, 0, sizeof(BatchDev));
+  std::vector<WinMeta> wins(W);
+  std::vector<ChunkMeta> chunks;
+  std::vector<double> obs, x0((size_t)W * XSTRIDE, 0.0), lam0;
+  std::vector<unsigned char> flags;
+  std::vector<vilo_preint> pre((size_t)W * 10);
+  std::vector<double> pH((size_t)W * 96 * 96, 0.0), pb0((size_t)W * 96, 0.0), pc0(W, 0.0), px0((size_t)W * 280, 0.0);
+  std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
+  int lm_total = 0, gram_total = 0;
+  bt->lm_off_host.resize(W);
+  bt->L_host.resize(W);
+  memset(pre.data(), 0, pre.size() * sizeof(vilo_preint));
+
+  for (int w = 0; w < W; ++w) {
+    const vilo_window_desc &d = in[w];
+    const vilo_window_state &s = init[w];
+    if (d.n_frames < 2 || d.n_frames > VILO_MAX_FRAMES || d.n_landmarks < 0 || d.n_landmarks > VILO_NUM_OF_F) {
+      ctx->err = "window sizes out of range"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
+    }
+    if (!d.use_leg) { ctx->err = "solver supports the IMU-leg factor path (use_leg = 1)"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    if (!d.preint || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
+      vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
+    }
+    const int F = d.n_frames, L = d.n_landmarks;
+    WinMeta &wm = wins[w];
+    memset(&wm, 0, sizeof(wm));
+    wm.n_frames = F; wm.L = L; wm.use_leg = d.use_leg;
+    wm.lm_off = lm_total; wm.chunk_off = (int)chunks.size(); wm.gram_off = gram_total;
+    wm.const_mask = (d.leg_bias_const ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
+    bt->lm_off_host[w] = lm_total;
+    bt->L_host[w] = L;
+    // states (vector2double layout)
+    double *xw = &x0[(size_t)w * XSTRIDE];
+    memcpy(xw + XO_POSE, s.pose, sizeof(double) * 7 * F);
+    memcpy(xw + XO_SB, s.speed_bias, sizeof(double) * 9 * F);
+    memcpy(xw + XO_LB, s.leg_bias, sizeof(double) * 4 * F);
+    for (int k = F; k < VILO_MAX_FRAMES; ++k) xw[XO_POSE + 7 * k + 6] = 1.0;
+    memcpy(xw + XO_EX, s.ex_pose, sizeof(double) * 14);
+    xw[XO_TD] = s.td[0];
+    // landmark chunks: group by start frame, <= 64 per chunk, list order preserved inside a group
+    int local = 0;
+    for (int sf = 0; sf < F; ++sf) {
+      std::vector<int> ids;
+      for (int l = 0; l < L; ++l)
+        if (d.lm_start_frame[l] == sf) ids.push_back(l);
+      for (size_t c0 = 0; c0 < ids.size(); c0 += 64) {
+        const int n = (int)std::min<size_t>(64, ids.size() - c0);
+        ChunkMeta cm;
+        memset(&cm, 0, sizeof(cm));
+        cm.win = w; cm.s = sf; cm.n = n; cm.lm_off = lm_total + local; cm.lm_local = local;
+        int kmax = 0;
+        for (int i = 0; i < n; ++i) {
+          const int l = ids[c0 + i];
+          const int K = d.lm_obs_offset[l + 1] - d.lm_obs_offset[l];
+          if (K < 1 || sf + K > F) { ctx->err = "landmark observation range outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+          kmax = std::max(kmax, K);
+        }
+        cm.kmax = kmax;
+        cm.obs_off = (long long)obs.size();
+        cm.flag_off = (long long)flags.size();
+        cm.gram_off = gram_total;
+        gram_total += kmax;
+        obs.resize(obs.size() + (size_t)kmax * 11 * n, 0.0);
+        flags.resize(flags.size() + (size_t)kmax * n, 0);
+        for (int i = 0; i < n; ++i) {
+          const int l = ids[c0 + i];
+          const int o0 = d.lm_obs_offset[l], K = d.lm_obs_offset[l + 1] - o0;
+          for (int t = 0; t < K; ++t) {
+            for (int f = 0; f < 11; ++f) obs[cm.obs_off + ((size_t)t * 11 + f) * n + i] = d.obs[(size_t)(o0 + t) * 11 + f];
+            flags[cm.flag_off + (size_t)t * n + i] = (unsigned char)(1 | (d.obs_is_stereo[o0 + t] ? 2 : 0));
+          }
+          bt->perm_host.push_back(l);
+          lam0.push_back(s.inv_depth[l]);
+        }
+        local += n;
+        chunks.push_back(cm);
+      }
+    }
+    if (local != L) { ctx->err = "landmark start_frame outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+    wm.n_chunks = (int)chunks.size() - wm.chunk_off;
+    wm.n_gram = gram_total - wm.gram_off;
+    lm_total += L;
+    for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k];
+    // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
+    if (d.prior && d.prior->valid && d.prior->n > 0) {
+      const vilo_prior &p = *d.prior;
+      const int n = p.n;
+      if (n > VILO_MAX_PRIOR_DIM || p.n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+      wm.prior_n = n; wm.prior_nb = p.n_blocks;
+      int xo = 0, bframe = -1;
+      for (int k = 0; k < p.n_blocks; ++k) {
+        int soff = 0;
+        const int cd = prior_block_cd(p.block_id[k], &soff);
+        const int gs = p.block_size[k], ls = gs == 7 ? 6 : gs;
+        if (cd < 0 || p.block_idx[k] < 0 || p.block_idx[k] + ls > n) { ctx->err = "unsupported prior block"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+        if (cd >= CD_B0) {
+          const int fr = (cd - CD_B0) / 13;
+          if (bframe >= 0 && bframe != fr) { ctx->err = "prior couples speed/leg biases of two frames"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+          bframe = fr;
+        }
+        pbs[(size_t)w * 40 + k] = gs; pbi[(size_t)w * 40 + k] = p.block_idx[k]; pbx[(size_t)w * 40 + k] = xo; pbst[(size_t)w * 40 + k] = soff;
+        for (int c = 0; c < ls; ++c) pmap[(size_t)w * 96 + p.block_idx[k] + c] = cd + c;
+        for (int c = 0; c < gs; ++c) px0[(size_t)w * 280 + xo + c] = p.x0[xo + c];
+        xo += gs;
+      }
+      double *H = &pH[(size_t)w * 96 * 96], *b0 = &pb0[(size_t)w * 96];
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j <= i; ++j) {
+          double sacc = 0.0;
+          for (int r = 0; r < n; ++r) sacc += p.J0[(size_t)r * n + i] * p.J0[(size_t)r * n + j];
+          H[(size_t)i * n + j] = sacc;
+          H[(size_t)j * n + i] = sacc;
+        }
+        double sb = 0.0;
+        for (int r = 0; r < n; ++r) sb += p.J0[(size_t)r * n + i] * p.r0[r];
+        b0[i] = sb;
+      }
+      double c0 = 0.0;
+      for (int r = 0; r < n; ++r) c0 += p.r0[r] * p.r0[r];
+      pc0[w] = c0;
+    }
+  }
+  BatchDev &D = bt->d;
+  D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total;
+  TRYB(dev_upload(ctx, bt, &D.win, wins));
+  TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
+  TRYB(dev_upload(ctx, bt, &D.obs, obs));
+  TRYB(dev_upload(ctx, bt, &D.flags, flags));
+  TRYB(dev_upload(ctx, bt, &D.x0, x0));
+  TRYB(dev_upload(ctx, bt, &D.lam0, lam0));
+  TRYB(dev_upload(ctx, bt, &D.lm_perm, bt->perm_host));
+  TRYB(dev_alloc(ctx, bt, &D.x, (size_t)W * XSTRIDE));
+  TRYB(dev_alloc(ctx, bt, &D.xc, (size_t)W * XSTRIDE));
+  TRYB(dev_alloc(ctx, bt, &D.lam, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lamc, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_E, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_g, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_dh2, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_y, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_scale, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_einv, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_w, (size_t)lm_total * 80));
+  TRYB(dev_alloc(ctx, bt, &D.gram, (size_t)gram_total * VILO_GRAM));
+  TRYB(dev_alloc(ctx, bt, &D.chunk_cost, chunks.size()));
+  TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
+  TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
+  TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
+  TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
+  TRYB(dev_upload(ctx, bt, &D.prior_b0, pb0));
+  TRYB(dev_upload(ctx, bt, &D.prior_c0, pc0));
+  TRYB(dev_upload(ctx, bt, &D.prior_x0, px0));
+  TRYB(dev_upload(ctx, bt, &D.prior_map, pmap));
+  TRYB(dev_upload(ctx, bt, &D.prior_bsize, pbs));
+  TRYB(dev_upload(ctx, bt, &D.prior_bidx, pbi));
+  TRYB(dev_upload(ctx, bt, &D.prior_bxoff, pbx));
+  TRYB(dev_upload(ctx, bt, &D.prior_bstate, pbst));
+  TRYB(dev_alloc(ctx, bt, &D.cam_g, (size_t)W * CD_N));
+  TRYB(dev_alloc(ctx, bt, &D.cam_dh2, (size_t)W * CD_N));
+  TRYB(dev_alloc(ctx, bt, &D.cam_y, (size_t)W * CD_N));
+  TRYB(dev_alloc(ctx, bt, &D.cam_scale, (size_t)W * CD_N));
+  TRYB(dev_alloc(ctx, bt, &D.A_diag, (size_t)W * 11 * 169));
+  TRYB(dev_alloc(ctx, bt, &D.A_off, (size_t)W * 10 * 169));
+  TRYB(dev_alloc(ctx, bt, &D.Bm, (size_t)W * 11 * 1040));
+  TRYB(dev_alloc(ctx, bt, &D.Tm, (size_t)W * 11 * 13 * 96));
+  TRYB(dev_alloc(ctx, bt, &D.Lk, (size_t)W * 11 * 169));
+  TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));
+  TRYB(dev_alloc(ctx, bt, &D.status, 1));
+  if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
+    vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP;
+  }
+  // hoist sqrt_info = chol(cov^-1)^T out of the iteration loop (the reference recomputes it on every
+  // IMULegFactor::Evaluate, imu_leg_factor.cpp:197-198)
+  {
+    vilo_preint *d_pre = nullptr;
+    if (hipMalloc((void **)&d_pre, sizeof(vilo_preint) * (size_t)W * 10) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    int rc = VILO_OK;
+    if (hipMemcpy(d_pre, pre.data(), sizeof(vilo_preint) * (size_t)W * 10, hipMemcpyHostToDevice) != hipSuccess) rc = VILO_ERR_HIP;
+    if (rc == VILO_OK) rc = vilo_launch_prepare_preint(ctx, W * 10, d_pre, D.prep, D.status);
+    if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    (void)hipFree(d_pre);
+    if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
+  }
+  int rc = vilo_batch_reset(ctx, bt);
+  if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
+  *out = bt;
+  return VILO_OK;
+}
+
+extern "C" int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *bt) {
+  if (!ctx || !bt) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  VILO_HIP(hipMemcpyAsync(bt->d.x, bt->d.x0, sizeof(double) * (size_t)bt->W * XSTRIDE, hipMemcpyDeviceToDevice, ctx->stream));
+  if (bt->d.n_lm > 0)
+    VILO_HIP(hipMemcpyAsync(bt->d.lam, bt->d.lam0, sizeof(double) * (size_t)bt->d.n_lm, hipMemcpyDeviceToDevice, ctx->stream));
+  return VILO_OK;
+}
+
+extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_opts *opts) {
+  if (!ctx || !bt || !opts) return VILO_ERR_BAD_ARG;
+  if (opts->max_num_iterations < 0 || opts->max_num_iterations > 63) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  VILO_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = vilo_solve_launch(ctx, bt->d, opts);
+  if (rc != VILO_OK) return rc;
+  VILO_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  VILO_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  VILO_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->last_solve_ms = ms;
+  return VILO_OK;
+}
+
+extern "C" int vilo_batch_download(vilo_ctx *ctx, vilo_batch *bt, vilo_window_state *out, vilo_solve_summary *summ) {
+  if (!ctx || !bt) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  const int W = bt->W;
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  if (out) {
+    std::vector<double> x((size_t)W * XSTRIDE), lam((size_t)std::max(1, bt->d.n_lm));
+    VILO_HIP(hipMemcpy(x.data(), bt->d.x, sizeof(double) * x.size(), hipMemcpyDeviceToHost));
+    if (bt->d.n_lm > 0) VILO_HIP(hipMemcpy(lam.data(), bt->d.lam, sizeof(double) * (size_t)bt->d.n_lm, hipMemcpyDeviceToHost));
+    std::vector<WinMeta> wins(W);
+    VILO_HIP(hipMemcpy(wins.data(), bt->d.win, sizeof(WinMeta) * W, hipMemcpyDeviceToHost));
+    for (int w = 0; w < W; ++w) {
+      const double *xw = &x[(size_t)w * XSTRIDE];
+      const int F = wins[w].n_frames;
+      memcpy(out[w].pose, xw + XO_POSE, sizeof(double) * 7 * F);
+      memcpy(out[w].speed_bias, xw + XO_SB, sizeof(double) * 9 * F);
+      memcpy(out[w].leg_bias, xw + XO_LB, sizeof(double) * 4 * F);
+      memcpy(out[w].ex_pose, xw + XO_EX, sizeof(double) * 14);
+      out[w].td[0] = xw[XO_TD];
+      for (int i = 0; i < bt->L_host[w]; ++i) out[w].inv_depth[bt->perm_host[bt->lm_off_host[w] + i]] = lam[bt->lm_off_host[w] + i];
+    }
+  }
+  if (summ) {
+    std::vector<SolverState> st(W);
+    VILO_HIP(hipMemcpy(st.data(), bt->d.st, sizeof(SolverState) * W, hipMemcpyDeviceToHost));
+    for (int w = 0; w < W; ++w) {
+      vilo_solve_summary &s = summ[w];
+      memset(&s, 0, sizeof(s));
+      s.iterations = st[w].iter; s.num_successful = st[w].num_successful; s.termination = st[w].termination;
+      s.initial_cost = st[w].cost_trace[0]; s.final_cost = st[w].x_cost;
+      memcpy(s.cost_trace, st[w].cost_trace, sizeof(s.cost_trace));
+      memcpy(s.radius_trace, st[w].radius_trace, sizeof(s.radius_trace));
+    }
+  }
+  return VILO_OK;
+}
+
+extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                                  const vilo_solve_opts *opts, vilo_solve_summary *out) {
+  vilo_batch *bt = nullptr;
+  int rc = vilo_batch_create(ctx, n_windows, in, inout, &bt);
+  if (rc != VILO_OK) return rc;
+  rc = vilo_batch_solve(ctx, bt, opts);
+  if (rc == VILO_OK) rc = vilo_batch_download(ctx, bt, inout, out);
+  if (rc == VILO_OK && out) {
+    for (int w = 0; w < n_windows; ++w)
+      if (out[w].termination == 2) rc = VILO_ERR_NUMERIC;
+  }
+  vilo_batch_destroy(ctx, bt);
+  return rc;
+}
+
+// Test / profiling hook: copy an internal device array of window `win` to the host. Not part of the
+// reference's interface. what: 0 gram slots, 1 lm_E, 2 lm_g, 3 lm_w (80 x L), 4 cam_g, 5 cam_dh2, 6 cam_y,
+// 7 imu_lin, 8 lm_y, 9 lm_dh2, 10 SolverState scalars + cost trace (24 + 64 doubles), 11 landmark permutation (as doubles)
+extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win, double *out, int max_n) {
+  if (!ctx || !bt || win < 0 || win >= bt->W || !out) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  WinMeta wm;
+  VILO_HIP(hipMemcpy(&wm, bt->d.win + win, sizeof(WinMeta), hipMemcpyDeviceToHost));
+  const double *src = nullptr;
+  size_t n = 0;
+  switch (what) {
+    case 0: src = bt->d.gram + (size_t)wm.gram_off * VILO_GRAM; n = (size_t)wm.n_gram * VILO_GRAM; break;
+    case 1: src = bt->d.lm_E + wm.lm_off; n = wm.L; break;
+    case 2: src = bt->d.lm_g + wm.lm_off; n = wm.L; break;
+    case 3: src = bt->d.lm_w + 80 * (size_t)wm.lm_off; n = (size_t)80 * wm.L; break;
+    case 4: src = bt->d.cam_g + (size_t)win * CD_N; n = CD_N; break;
+    case 5: src = bt->d.cam_dh2 + (size_t)win * CD_N; n = CD_N; break;
+    case 6: src = bt->d.cam_y + (size_t)win * CD_N; n = CD_N; break;
+    case 7: src = bt->d.imu_lin + (size_t)win * 10 * 31 * 39; n = 10 * 31 * 39; break;
+    case 8: src = bt->d.lm_y + wm.lm_off; n = wm.L; break;
+    case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
+    case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
+    case 11: {
+      n = wm.L;
+      if ((int)n > max_n) return VILO_ERR_BAD_ARG;
+      for (size_t i = 0; i < n; ++i) out[i] = bt->perm_host[bt->lm_off_host[win] + i];
+      return (int)n;
+    }
+    default: return VILO_ERR_BAD_ARG;
+  }
+  if ((long long)n > max_n) return VILO_ERR_BAD_ARG;
+  if (n) VILO_HIP(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
+  return (int)n;
+}

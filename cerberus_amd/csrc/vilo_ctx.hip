@@ -1,0 +1,77 @@
+// Context management of libvilo_gpu.so. There is deliberately NO CPU fallback anywhere in this library:
+// without a usable HIP device vilo_create fails with VILO_ERR_NO_DEVICE and nothing else can be called.
+#include "vilo_internal.hpp"
+
+extern "C" void vilo_default_config(vilo_config *c) {
+  // config/a1_config/hardware_a1_vilo_config.yaml:24-48,85-99 ; estimator.cpp:140-163 ; parameters.h:22
+  memset(c, 0, sizeof(*c));
+  c->acc_n = 0.9; c->acc_n_z = 2.5; c->acc_w = 0.0004; c->gyr_n = 0.05; c->gyr_w = 0.0002;
+  c->g_norm = 9.805;
+  c->phi_n = 0.00001; c->dphi_n = 0.00001;
+  c->rho_c_n = 0.00000001; c->rho_nc_n = 0.00000000001;
+  c->v_n_min_xy = 0.001; c->v_n_min_z = 0.005; c->v_n_min = 0.005; c->v_n_max = 900.0;
+  c->v_n_force_thres_ratio = 0.8; c->v_n_term1_steep = 10; c->v_n_term2_var_rescale = 1.0e-6;
+  c->v_n_term3_distance_rescale = 1.0e-3;
+  c->contact_sensor_type = 0;
+  const double ox[4] = {0.1805, 0.1805, -0.1805, -0.1805};
+  const double oy[4] = {0.047, -0.047, 0.047, -0.047};
+  const double d[4] = {0.0838, -0.0838, 0.0838, -0.0838};
+  for (int j = 0; j < 4; ++j) {
+    c->rho_fix[j][0] = ox[j]; c->rho_fix[j][1] = oy[j]; c->rho_fix[j][2] = d[j]; c->rho_fix[j][3] = 0.21;
+  }
+  c->R_br[0] = c->R_br[4] = c->R_br[8] = 1.0;
+  c->focal_length = 460.0;
+  c->huber_delta = 1.0;
+}
+
+extern "C" void vilo_default_solve_opts(vilo_solve_opts *o) {
+  // estimator.cpp:1221-1233 + Ceres 1.14 Solver::Options defaults
+  memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 12;
+  o->fixed_iterations = 0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->jacobi_scaling = 1;
+}
+
+extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
+  if (!out || !cfg) return VILO_ERR_BAD_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return VILO_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return VILO_ERR_NO_DEVICE;
+  vilo_ctx *ctx = new vilo_ctx();
+  ctx->cfg = *cfg;
+  ctx->device = device;
+  ctx->last_solve_ms = 0.0;
+  ctx->d_cfg = nullptr;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+      hipEventCreate(&ctx->ev1) != hipSuccess || hipMalloc((void **)&ctx->d_cfg, sizeof(vilo_config)) != hipSuccess ||
+      hipMemcpy(ctx->d_cfg, cfg, sizeof(vilo_config), hipMemcpyHostToDevice) != hipSuccess) {
+    delete ctx;
+    return VILO_ERR_HIP;
+  }
+  *out = ctx;
+  return VILO_OK;
+}
+
+extern "C" void vilo_destroy(vilo_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *vilo_last_error(const vilo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" double vilo_last_solve_ms(const vilo_ctx *ctx) { return ctx ? ctx->last_solve_ms : -1.0; }

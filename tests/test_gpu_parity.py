@@ -1,0 +1,247 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+oracle on the same seeded inputs. Tolerances (FP64): factor residual/Jacobian <= 1e-11 relative to the
+block's scale, whitened IMU quantities <= 1e-8 (conditioning of the 31x31 covariance), normal-equation
+pieces <= 1e-9, states after an equal number of trust-region iterations <= 1e-7."""
+import numpy as np
+import pytest
+
+from conftest import rand_pose
+from oracle import oracle_py as O
+from test_oracle_factors import _proj_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(cfg):
+    from cerberus_amd import api
+    c = api.Context(cfg, 0)
+    yield c
+    c.close()
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_eval_proj(ctx, ocfg, kind):
+    rng = np.random.default_rng(100 + kind)
+    n = 97
+    setups = [_proj_setup(rng, kind) for _ in range(n)]
+    obs = np.stack([s[0] for s in setups])
+    nb = len(setups[0][1])
+    params = [np.stack([s[1][k] for s in setups]) for k in range(nb)]
+    r, Js = ctx.eval_proj(kind, obs, params)
+    for i in range(n):
+        r_o, J_o = O.eval_proj(kind, ocfg, obs[i], [p[i] for p in params])
+        np.testing.assert_allclose(r[i], r_o, rtol=1e-12, atol=1e-11)
+        for k in range(nb):
+            np.testing.assert_allclose(Js[k][i], J_o[k], rtol=1e-11, atol=1e-11 * max(1.0, np.abs(J_o[k]).max()), err_msg="kind %d block %d" % (kind, k))
+    r2, _ = ctx.eval_proj(kind, obs, params, want_jac=False)
+    np.testing.assert_array_equal(r, r2)
+
+
+def test_eval_imu_leg_and_imu(ctx, ocfg, small_window):
+    w = small_window
+    P = [w.pose[:-1], w.speed_bias[:-1], w.leg_bias[:-1], w.pose[1:], w.speed_bias[1:], w.leg_bias[1:]]
+    r, Js = ctx.eval_imu_leg(w.preint, P)
+    for k in range(10):
+        r_o, J_o = O.eval_imu_leg(ocfg, w.preint[k], [p[k] for p in P])
+        assert _rel(r[k], r_o) < 1e-8, ("imu_leg residual", k, _rel(r[k], r_o))
+        for b in range(6):
+            assert _rel(Js[b][k], J_o[b]) < 1e-8, ("imu_leg J", k, b, _rel(Js[b][k], J_o[b]))
+    P4 = [w.pose[:-1], w.speed_bias[:-1], w.pose[1:], w.speed_bias[1:]]
+    r, Js = ctx.eval_imu(w.preint_imu, P4)
+    for k in range(10):
+        r_o, J_o = O.eval_imu(ocfg, w.preint_imu[k], [p[k] for p in P4])
+        assert _rel(r[k], r_o) < 1e-8
+        for b in range(4):
+            assert _rel(Js[b][k], J_o[b]) < 1e-8, ("imu J", k, b)
+
+
+def test_eval_prior_and_pose_plus(ctx, small_window):
+    w = small_window
+    rng = np.random.default_rng(3)
+    blocks = w.prior.blocks()
+    evals = []
+    for _ in range(3):
+        parts, off = [], 0
+        for (bid, size, idx) in blocks:
+            x0 = w.prior.x0[off:off + size]; off += size
+            parts.append(O.pose_plus(x0, 0.01 * rng.normal(size=6)) if size == 7 else x0 + 0.01 * rng.normal(size=size))
+        evals.append(parts)
+    pc = np.stack([np.concatenate(p) for p in evals])
+    r, J = ctx.eval_prior(w.prior, pc)
+    for e, parts in enumerate(evals):
+        r_o, J_o = O.eval_prior(w.prior.struct, parts)
+        np.testing.assert_allclose(r[e], r_o, rtol=1e-12, atol=1e-12 * np.abs(r_o).max())
+        np.testing.assert_allclose(J[e], np.concatenate(J_o, axis=1), rtol=0, atol=0)
+    x = np.stack([rand_pose(rng) for _ in range(33)]); d = 0.1 * rng.normal(size=(33, 6))
+    out = ctx.pose_plus(x, d)
+    for i in range(33):
+        np.testing.assert_allclose(out[i], O.pose_plus(x[i], d[i]), atol=2e-16)
+
+
+def test_preintegrate(ctx, ocfg, small_window):
+    w = small_window
+    out = ctx.preintegrate(w.samples, w.sample_offsets, w.lin)
+    for k in range(10):
+        a, b = out[k], w.preint[k]
+        np.testing.assert_allclose(a[:33], b[:33], rtol=1e-12, atol=1e-14, err_msg="state k=%d" % k)
+        assert _rel(a[33:33 + 961], b[33:33 + 961]) < 1e-11, ("jacobian", k)
+        assert _rel(a[33 + 961:], b[33 + 961:]) < 1e-10, ("covariance", k, _rel(a[33 + 961:], b[33 + 961:]))
+        # entry-wise on the significant entries of the covariance
+        ca, cb = a[33 + 961:], b[33 + 961:]
+        big = np.abs(cb) > 1e-6 * np.abs(cb).max()
+        assert np.abs(ca[big] / cb[big] - 1).max() < 1e-9
+    out_i = ctx.preintegrate_imu(w.samples, w.sample_offsets, np.ascontiguousarray(w.lin[:, :6]))
+    for k in range(10):
+        np.testing.assert_allclose(out_i[k][:17], w.preint_imu[k][:17], rtol=1e-12, atol=1e-14)
+        assert _rel(out_i[k][17:], w.preint_imu[k][17:]) < 1e-10
+
+
+def _cd_to_oracle(cd, F=11):
+    if cd < 66:
+        return 19 * (cd // 6) + cd % 6
+    if cd < 72:
+        return 19 * F + (cd - 66)
+    if cd < 78:
+        return 19 * F + 6 + (cd - 72)
+    if cd == 78:
+        return 19 * F + 12
+    k, c = divmod(cd - 80, 13)
+    return 19 * k + 6 + c
+
+
+def _fresh(cfg, ocfg, **kw):
+    from cerberus_amd import synth
+    w = synth.make_window(cfg, **kw)
+    O.fill_preint(ocfg, w)
+    return w
+
+
+@pytest.mark.parametrize("consts", [(0, 0, 1), (0, 1, 1), (1, 0, 0)])
+def test_linearization_and_gauss_newton_step(ctx, cfg, ocfg, consts):
+    """One linearisation: landmark blocks, gradient and the regularised Gauss-Newton solution against numpy on
+    the oracle's normal equations."""
+    from cerberus_amd import api
+    w = _fresh(cfg, ocfg, n_landmarks=37, seed=5)
+    w.leg_bias_const, w.ex_const, w.td_const = consts
+    H, g, cost = O.window_normal_eq(ocfg, w)
+    F, L = 11, w.L
+    b = api.Batch(ctx, [w])
+    b.solve(api.default_solve_opts(True, 1))
+    perm = b.fetch(11).astype(int)
+    E, gl, wl = b.fetch(1), b.fetch(2), b.fetch(3).reshape(80, L)
+    cam_g, cam_dh2, cam_y, lm_y = b.fetch(4), b.fetch(5), b.fetch(6), b.fetch(8)
+    st = b.fetch(10)
+    lam_idx = 19 * F + 13 + perm
+    np.testing.assert_allclose(E, np.diag(H)[lam_idx], rtol=1e-11)
+    np.testing.assert_allclose(gl, g[lam_idx], rtol=1e-10, atol=1e-10 * np.abs(g).max())
+    active = np.ones(224, bool)
+    active[79] = False; active[223] = False
+    if consts[1]:
+        active[66:78] = False
+    if consts[2]:
+        active[78] = False
+    if consts[0]:
+        for k in range(11):
+            active[80 + 13 * k + 9:80 + 13 * k + 13] = False
+    cds = np.array([cd for cd in range(223) if cd != 79])
+    oidx = np.array([_cd_to_oracle(cd) for cd in cds])
+    for a in range(79):
+        np.testing.assert_allclose(wl[a], H[_cd_to_oracle(a), lam_idx], rtol=1e-10, atol=1e-10 * np.abs(H[:, lam_idx]).max(), err_msg="w row %d" % a)
+    act = active[cds]
+    np.testing.assert_allclose(cam_g[cds][act], g[oidx][act], rtol=1e-9, atol=1e-9 * np.abs(g).max())
+    assert np.all(cam_g[cds][~act] == 0)
+    # regularised GN solution with Jacobi scaling (iteration 0): (H + mu Dhat^2) y = g on the active set
+    sel = np.concatenate([oidx[act], lam_idx])
+    Hs, gs = H[np.ix_(sel, sel)], g[sel]
+    s = 1.0 / (1.0 + np.sqrt(np.diag(Hs)))
+    dh2 = np.clip(s * s * np.diag(Hs), 1e-6, 1e32) / (s * s)
+    y = np.linalg.solve(Hs + 1e-8 * np.diag(dh2), gs)
+    ycam = y[:act.sum()]; ylm = y[act.sum():]
+    np.testing.assert_allclose(cam_dh2[cds][act], dh2[:act.sum()], rtol=1e-10)
+    scale = np.abs(y).max()
+    assert np.abs(cam_y[cds][act] - ycam).max() < 1e-7 * scale, np.abs(cam_y[cds][act] - ycam).max() / scale
+    assert np.abs(lm_y - ylm).max() < 1e-7 * scale
+    # dogleg scalars
+    gt2 = float(np.sum(gs * gs / dh2)); gnn2 = float(np.sum(dh2 * y * y)); gy = float(gs @ y)
+    v = gs / dh2
+    q = float(v @ Hs @ v)
+    np.testing.assert_allclose([st[5], st[6], -st[7], st[8]], [gt2, gnn2, gy, q], rtol=1e-7)
+    np.testing.assert_allclose(st[24], cost, rtol=1e-10)  # cost_trace[0] = cost at the initial point
+    b.close()
+
+
+@pytest.mark.parametrize("iters", [1, 3, 12])
+def test_solve_parity(ctx, cfg, ocfg, iters):
+    """States and cost trace after an equal number of trust-region iterations."""
+    from cerberus_amd import api, synth
+    w_g = _fresh(cfg, ocfg, n_landmarks=40, seed=11)
+    w_o = _fresh(cfg, ocfg, n_landmarks=40, seed=11)
+    summ = ctx.solve_windows([w_g], api.default_solve_opts(True, iters))[0]
+    osum = O.solve_window(ocfg, w_o, O.default_opts(True, iters))
+    ct_g = np.array([summ.cost_trace[i] for i in range(iters + 1)]); ct_o = np.array([osum.cost_trace[i] for i in range(iters + 1)])
+    rt_g = np.array([summ.radius_trace[i] for i in range(iters + 1)]); rt_o = np.array([osum.radius_trace[i] for i in range(iters + 1)])
+    print("cost gpu", ct_g, "\ncost orc", ct_o, "\nradius gpu", rt_g, "\nradius orc", rt_o)
+    assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
+    np.testing.assert_allclose(ct_g, ct_o, rtol=1e-7)
+    np.testing.assert_allclose(rt_g, rt_o, rtol=1e-6)
+    for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
+
+
+def test_solve_config2_window_and_tolerances(ctx, cfg, ocfg):
+    """Full-size config-2 window (200 landmarks), Ceres termination rules enabled."""
+    from cerberus_amd import api
+    w_g = _fresh(cfg, ocfg, n_landmarks=200, seed=20260925)
+    w_o = _fresh(cfg, ocfg, n_landmarks=200, seed=20260925)
+    summ = ctx.solve_windows([w_g], api.default_solve_opts(False, 12))[0]
+    osum = O.solve_window(ocfg, w_o, O.default_opts(False, 12))
+    assert (summ.iterations, summ.termination) == (osum.iterations, osum.termination)
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
+def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
+    """Independent windows in one batch give the same answers as solved alone; ragged landmark counts,
+    a window without prior, >64 landmarks per start frame (multi-chunk groups)."""
+    from cerberus_amd import api
+    specs = [dict(n_landmarks=40, seed=1), dict(n_landmarks=7, seed=2), dict(n_landmarks=500, seed=3), dict(n_landmarks=40, seed=4, with_prior=False)]
+    ws = [_fresh(cfg, ocfg, **s) for s in specs]
+    singles = [_fresh(cfg, ocfg, **s) for s in specs]
+    opts = api.default_solve_opts(True, 5)
+    sb = ctx.solve_windows(ws, opts)
+    for w1, s1 in zip(singles, sb):
+        s = ctx.solve_windows([w1], opts)[0]
+        assert s.final_cost == s1.final_cost
+    for w_b, w_s in zip(ws, singles):
+        for a, bb in zip(w_b.state_arrays(), w_s.state_arrays()):
+            np.testing.assert_array_equal(a, bb)
+    # and against the oracle for the ragged ones
+    for spec, w_b in zip(specs[1:], ws[1:]):
+        w_o = _fresh(cfg, ocfg, **spec)
+        O.solve_window(ocfg, w_o, O.default_opts(True, 5))
+        for a, bb in zip(w_b.state_arrays(), w_o.state_arrays()):
+            assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
+def test_size_independent_properties(ctx, cfg):
+    """Config-2 sized batch: cost never increases along accepted steps, rejected steps leave the state
+    untouched, and re-solving from the solution gains almost nothing."""
+    from cerberus_amd import api, synth
+    ws = [synth.make_window(cfg, n_landmarks=200, seed=900 + i) for i in range(8)]
+    ctx.preintegrate_windows(ws)
+    opts = api.default_solve_opts(True, 12)
+    summ = ctx.solve_windows(ws, opts)
+    for s in summ:
+        ct = np.array([s.cost_trace[i] for i in range(s.iterations + 1)])
+        assert np.all(np.diff(ct) <= 1e-12 * ct[0])
+        assert s.final_cost < s.initial_cost
+    summ2 = ctx.solve_windows(ws, api.default_solve_opts(True, 2))
+    for s, s2 in zip(summ, summ2):
+        assert abs(s2.initial_cost - s.final_cost) <= 1e-9 * s.final_cost
+        assert s2.final_cost >= s2.initial_cost * (1 - 2e-3)   # 12 iterations is not full convergence

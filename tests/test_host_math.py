@@ -1,0 +1,129 @@
+"""CPU: the product's inline device math (cerberus_amd/csrc/factors.hpp, compiled for the host by
+tests/host_check) against the oracle. Catches transcription errors before any GPU minute is spent;
+the GPU parity tests (-m gpu) then check the very same functions as executed by the HIP kernels."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rand_pose
+from oracle import oracle_py as O
+from test_oracle_factors import _proj_setup
+
+dp = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    d = os.path.join(ROOT, "tests", "host_check")
+    so = os.path.join(d, "libhostcheck.so")
+    srcs = [os.path.join(d, "host_check.cpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "factors.hpp"),
+            os.path.join(ROOT, "cerberus_amd", "csrc", "vilo_math.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
+    lib = C.CDLL(so)
+    lib.hc_correct.restype = C.c_double
+    return lib
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_proj_matches_oracle(hc, ocfg, kind):
+    rng = np.random.default_rng(20 + kind)
+    for _ in range(20):
+        obs, params = _proj_setup(rng, kind)
+        r_o, J_o = O.eval_proj(kind, ocfg, obs, params)
+        if kind == 0:
+            pose_i, pose_j, ex0, lam, td = params; ex1 = ex0
+        elif kind == 1:
+            pose_i, pose_j, ex0, ex1, lam, td = params
+        else:
+            ex0, ex1, lam, td = params; pose_i = pose_j = ex0
+        r = np.zeros(2); Ji = np.zeros((2, 6)); Jj = np.zeros((2, 6)); Je0 = np.zeros((2, 6)); Je1 = np.zeros((2, 6))
+        Jl = np.zeros(2); Jt = np.zeros(2)
+        hc.hc_proj(kind, P(obs), P(pose_i), P(pose_j), P(ex0), P(ex1), C.c_double(lam[0]), C.c_double(td[0]),
+                   C.c_double(460.0 / 1.5), P(r), 1, P(Ji), P(Jj), P(Je0), P(Je1), P(Jl), P(Jt))
+        np.testing.assert_allclose(r, r_o, rtol=1e-13, atol=1e-12)
+        mine = {0: [Ji, Jj, Je0, Jl, Jt], 1: [Ji, Jj, Je0, Je1, Jl, Jt], 2: [Je0, Je1, Jl, Jt]}[kind]
+        for a, b in zip(mine, J_o):
+            b = b[:, :6] if b.shape[1] == 7 else b[:, 0]
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-11 * max(1.0, np.abs(b).max()))
+
+
+def test_imu_leg_raw_matches_oracle(hc, ocfg, small_window):
+    w = small_window
+    for k in range(10):
+        params = [w.pose[k], w.speed_bias[k], w.leg_bias[k], w.pose[k + 1], w.speed_bias[k + 1], w.leg_bias[k + 1]]
+        r_o, J_o = O.eval_imu_leg(ocfg, w.preint[k], params)
+        r = np.zeros(31); J = np.zeros((31, 38))
+        pre = np.ascontiguousarray(w.preint[k])
+        hc.hc_imu_leg_raw(P(pre), C.c_double(9.805), *[P(np.ascontiguousarray(p)) for p in params], P(r), P(J))
+        U = O.sqrt_info(pre[33 + 961:].reshape(31, 31))
+        np.testing.assert_allclose(U @ r, r_o, rtol=1e-9, atol=1e-9 * np.abs(r_o).max())
+        Jw = U @ J
+        loc = np.concatenate([J_o[0][:, :6], J_o[1], J_o[2], J_o[3][:, :6], J_o[4], J_o[5]], axis=1)
+        np.testing.assert_allclose(Jw, loc, rtol=1e-9, atol=1e-10 * np.abs(loc).max())
+
+
+def test_imu_raw_matches_oracle(hc, ocfg, small_window):
+    w = small_window
+    for k in (0, 3, 9):
+        params = [w.pose[k], w.speed_bias[k], w.pose[k + 1], w.speed_bias[k + 1]]
+        r_o, J_o = O.eval_imu(ocfg, w.preint_imu[k], params)
+        r = np.zeros(15); J = np.zeros((15, 30))
+        pre = np.ascontiguousarray(w.preint_imu[k])
+        hc.hc_imu_raw(P(pre), C.c_double(9.805), *[P(np.ascontiguousarray(p)) for p in params], P(r), P(J))
+        U = O.sqrt_info(pre[17 + 225:].reshape(15, 15))
+        np.testing.assert_allclose(U @ r, r_o, rtol=1e-9, atol=1e-9 * np.abs(r_o).max())
+        loc = np.concatenate([J_o[0][:, :6], J_o[1], J_o[2][:, :6], J_o[3]], axis=1)
+        np.testing.assert_allclose(U @ J, loc, rtol=1e-9, atol=1e-10 * np.abs(loc).max())
+
+
+def test_leg_kin_matches_oracle(hc):
+    rng = np.random.default_rng(5)
+    rf = np.array([0.1805, -0.047, -0.0838, 0.21])
+    for _ in range(10):
+        q = np.array([0.1, 0.8, -1.5]) + 0.4 * rng.normal(size=3)
+        lc = 0.21 + 0.01 * rng.normal()
+        k = O.kin(q, lc, rf)
+        f = np.zeros(3); J = np.zeros(9); dfr = np.zeros(3); dJ = np.zeros(27); dJr = np.zeros(9)
+        hc.hc_leg_kin(P(q), C.c_double(lc), P(rf), P(f), P(J), P(dfr), P(dJ), P(dJr))
+        np.testing.assert_allclose(f, k["f"], atol=1e-15)
+        np.testing.assert_allclose(J.reshape(3, 3), k["J"], atol=1e-15)
+        np.testing.assert_allclose(dfr, k["df_drho"], atol=1e-15)
+        for n in range(3):  # oracle dJ_dq: 9x3, column n = vec_colmajor(dJ/dq_n)
+            np.testing.assert_allclose(dJ[9 * n:9 * n + 9].reshape(3, 3), k["dJ_dq"][:, n].reshape(3, 3).T, atol=1e-15)
+        np.testing.assert_allclose(dJr.reshape(3, 3), k["dJ_drho"].reshape(3, 3).T, atol=1e-15)
+
+
+def test_pose_plus_and_prior_dx(hc):
+    rng = np.random.default_rng(6)
+    x = rand_pose(rng); d = 0.05 * rng.normal(size=6)
+    out = np.zeros(7)
+    hc.hc_pose_plus(P(x), P(d), P(out))
+    np.testing.assert_allclose(out, O.pose_plus(x, d), atol=1e-15)
+    dx = np.zeros(6)
+    hc.hc_prior_dx(P(out), P(x), 7, P(dx))
+    np.testing.assert_allclose(dx[:3], d[:3], atol=1e-15)
+    np.testing.assert_allclose(dx[3:], d[3:], rtol=2e-3)  # 2 vec(dq) is first order in theta
+
+
+def test_corrector(hc):
+    # ceres Corrector semantics restated at marginalization_factor.cpp:46-77
+    for r in ([0.3, -0.2], [2.0, 1.5], [0.0, 0.0]):
+        r = np.array(r); j = np.array([0.7, -1.1])
+        s = r @ r
+        rho = O.huber(1.0, s)
+        sr1 = np.sqrt(rho[1])
+        jr = sr1 * j  # rho[2] <= 0 for Huber -> alpha = 0
+        rr = sr1 * r
+        r2 = r.copy(); j2 = j.copy()
+        rho0 = hc.hc_correct(C.c_double(1.0), P(r2), P(j2))
+        np.testing.assert_allclose([rho0], [rho[0]])
+        np.testing.assert_allclose(r2, rr, atol=1e-15)
+        np.testing.assert_allclose(j2, jr, atol=1e-15)
