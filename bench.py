@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py — Gauss-Newton (dogleg trust-region) iterations/s of the sliding-window VILO solve on MI355X.
+
+Contract (see task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches
+one rank per GPU through torch.distributed.run. A "step" is one pass of the hot path
+(Estimator::optimization()'s solve half, estimator.cpp:1054-1245) over one batch of synthetic windows per GPU:
+device-side state reset + 12 fixed trust-region iterations on every window. Windows are independent, so ranks
+share nothing (weak scaling, no data-path collective); `value` = window-iterations of all ranks / max-over-ranks
+time. Inputs are resident in HBM before the timed region (batch created + preintegrated during setup).
+
+Workload = BASELINE.json configs[1]: synthetic 10-KF x 200-landmark window, A1 4-leg contact preintegration,
+500 Hz IMU/leg samples; `--windows` independent instances per GPU (config 4 batches 1024 over 8 GPUs).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITERS = 12  # max_num_iterations of the reference (config yaml:86), fixed so every window does identical work
+
+
+def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
+    """compulsory HBM traffic of one window-iteration."""
+    return 88 * sum_k + 16 * L + 8 * (20 * F + 15 + L) + 10 * 8696 + 8 * (n_prior * n_prior + n_prior + 98) + 8 * (20 * F + 15 + L)
+
+
+def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
+    """The oracle (CPU restatement of the reference path, scalar FP64, 1 thread) on windows of the same workload."""
+    import numpy as np  # noqa: F401
+    from cerberus_amd import synth
+    from oracle import oracle_py as O
+    ocfg = O.config_from(cfg)
+    opts = O.default_opts(fixed_iterations=True, max_num_iterations=ITERS)
+    opts.recompute_sqrt_info = 1
+    t_total, n_it, n_win = 0.0, 0, 0
+    while t_total < budget_s and n_win < 256:
+        w = synth.make_window(cfg, n_landmarks=n_landmarks, seed=777000 + n_win)
+        O.fill_preint(ocfg, w)
+        t0 = time.perf_counter()
+        sm = O.solve_window(ocfg, w, opts)
+        t_total += time.perf_counter() - t0
+        n_it += sm.iterations
+        n_win += 1
+    return {"value": n_it / t_total, "unit": "GN iters/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic config-2 windows x %d iterations, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s" % (n_win, ITERS, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU")
+    ap.add_argument("--landmarks", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    from cerberus_amd import api, synth
+    cfg = synth.default_config()
+    ctx = api.Context(cfg, device=local_rank)
+    W = args.windows
+    t0 = time.perf_counter()
+    windows = [synth.make_window(cfg, n_landmarks=args.landmarks, seed=20260925 + rank * W + i) for i in range(W)]
+    ctx.preintegrate_windows(windows)   # K1 on the GPU: contact preintegration of all 10 * W intervals
+    batch = api.Batch(ctx, windows)
+    setup_s = time.perf_counter() - t0
+    opts = api.default_solve_opts(fixed_iterations=True, max_num_iterations=ITERS)
+    lib = api.lib()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.reset()
+        batch.solve(opts)
+    lib.vilo_set_profiling(ctx.h, 1)
+    barrier()
+    t0 = time.perf_counter()
+    gpu_ms = 0.0
+    for _ in range(args.steps):
+        batch.reset()
+        gpu_ms += batch.solve(opts)   # returns after the stream has drained (HIP event)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel GPU time over the timed region (HIP events on the solver's stream)
+    ms = (C.c_double * 8)()
+    launches = (C.c_longlong * 8)()
+    nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 8)
+    lib.vilo_kernel_name.restype = C.c_char_p
+    kern = {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]),
+                                               "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}
+    summ = batch.download()
+    iters_done = sum(s.iterations for s in summ)
+    assert iters_done == W * ITERS, "every window must run the fixed iteration count"
+    final_cost = float(np.mean([s.final_cost for s in summ]))
+
+    if rank == 0:
+        unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
+        value = unit_work / elapsed
+        sum_k = int(windows[0].n_obs)
+        b_alg = algorithmic_bytes(sum_k, args.landmarks)
+        dom = max((k for k in kern if kern[k]["launches"] > 0), key=lambda k: kern[k]["ms_total"])
+        dom_avg_s = kern[dom]["avg_ms"] * 1e-3
+        achieved = b_alg * W / dom_avg_s / 1e9             # one launch of the dominant kernel covers W window-iterations
+        iter_ms = sum(v["ms_total"] for v in kern.values()) / (args.steps * ITERS)
+        out = {
+            "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput",
+            "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (500 Hz), "
+                                   "%d independent windows per GPU, %d fixed dogleg iterations per step" % (args.landmarks, W, ITERS),
+                       "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
+                       "parallelism": "independent windows sharded over ranks, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "algorithmic_bytes_per_window_iteration": b_alg,
+                         "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9},
+            "kernels": kern,
+            "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
+        }
+        if args.single_window_latency:
+            b1 = api.Batch(ctx, windows[:1])
+            lib.vilo_set_profiling(ctx.h, 0)
+            for _ in range(3):
+                b1.reset(); b1.solve(opts)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                b1.reset(); b1.solve(opts)
+            out["single_window_iters_per_s"] = 20 * ITERS / (time.perf_counter() - t1)
+            b1.close()
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

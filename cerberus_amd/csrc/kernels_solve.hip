@@ -978,20 +978,53 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   ap.parameter_tolerance = o->parameter_tolerance; ap.max_num_iterations = o->max_num_iterations;
   ap.fixed_iterations = o->fixed_iterations; ap.init_mode = 1; ap.pad = 0;
   const int W = b.W;
+  int pidx = 0;
+  ctx->pev_kind.clear();
+  auto P0 = [&](int kind) {
+    if (!ctx->profile) return;
+    while ((int)ctx->pev.size() < 2 * (pidx + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ctx->pev.push_back(e); }
+    ctx->pev_kind.push_back(kind);
+    (void)hipEventRecord(ctx->pev[2 * pidx], s);
+  };
+  auto P1 = [&]() {
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->pev[2 * pidx + 1], s);
+    ++pidx;
+  };
+  P0(6);
   hipLaunchKernelGGL(k_init_state, dim3((W + 127) / 128), dim3(128), 0, s, b, o->initial_trust_region_radius);
+  P1();
   // IterationZero: cost at the initial point
   VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
+  P0(3);
   hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 1);
+  P1();
+  P0(4);
   hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
+  P1();
+  P0(5);
   hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+  P1();
   ap.init_mode = 0;
   for (int it = 0; it < o->max_num_iterations; ++it) {
+    P0(0);
     hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha);
+    P1();
+    P0(1);
     hipLaunchKernelGGL(k_imu_linearize, dim3(W * 10), dim3(64), 0, s, b, gn);
+    P1();
+    P0(2);
     hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
+    P1();
+    P0(3);
     hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 0);
+    P1();
+    P0(4);
     hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 0);
+    P1();
+    P0(5);
     hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+    P1();
   }
   VILO_HIP(hipGetLastError());
   return VILO_OK;

@@ -283,6 +283,15 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   float ms = 0.f;
   VILO_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_solve_ms = ms;
+  if (ctx->profile) {
+    for (size_t i = 0; i < ctx->pev_kind.size(); ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ctx->pev[2 * i], ctx->pev[2 * i + 1]) == hipSuccess) {
+        ctx->kernel_ms[ctx->pev_kind[i]] += t;
+        ctx->kernel_launches[ctx->pev_kind[i]] += 1;
+      }
+    }
+  }
   return VILO_OK;
 }
 

@@ -52,6 +52,8 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   ctx->device = device;
   ctx->last_solve_ms = 0.0;
   ctx->d_cfg = nullptr;
+  ctx->profile = 0;
+  for (int i = 0; i < 8; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
       hipEventCreate(&ctx->ev1) != hipSuccess || hipMalloc((void **)&ctx->d_cfg, sizeof(vilo_config)) != hipSuccess ||
       hipMemcpy(ctx->d_cfg, cfg, sizeof(vilo_config), hipMemcpyHostToDevice) != hipSuccess) {
@@ -67,6 +69,7 @@ extern "C" void vilo_destroy(vilo_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
+  for (hipEvent_t e : ctx->pev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);
@@ -75,3 +78,20 @@ extern "C" void vilo_destroy(vilo_ctx *ctx) {
 
 extern "C" const char *vilo_last_error(const vilo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" double vilo_last_solve_ms(const vilo_ctx *ctx) { return ctx ? ctx->last_solve_ms : -1.0; }
+
+// Profiling hooks (not part of the reference interface): per-kernel GPU time of the solve pipeline measured with
+// HIP events on the stream the kernels are launched on.
+extern "C" void vilo_set_profiling(vilo_ctx *ctx, int on) {
+  if (!ctx) return;
+  ctx->profile = on;
+  for (int i = 0; i < 8; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
+}
+extern "C" int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n) {
+  if (!ctx || !ms || !launches) return VILO_ERR_BAD_ARG;
+  for (int i = 0; i < n && i < 8; ++i) { ms[i] = ctx->kernel_ms[i]; launches[i] = ctx->kernel_launches[i]; }
+  return VILO_NKERNEL;
+}
+extern "C" const char *vilo_kernel_name(int kind) {
+  static const char *names[VILO_NKERNEL] = {"k_visual_linearize", "k_imu_linearize", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state"};
+  return (kind >= 0 && kind < VILO_NKERNEL) ? names[kind] : "";
+}

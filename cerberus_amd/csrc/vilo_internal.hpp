@@ -27,7 +27,15 @@ struct vilo_ctx {
   double last_solve_ms;
   std::string err;
   vilo_config *d_cfg;
+  // per-kernel HIP-event timing of the solve pipeline (vilo_set_profiling)
+  int profile;
+  std::vector<hipEvent_t> pev;      // event pool
+  std::vector<int> pev_kind;        // kernel kind of interval i = [pev[2i], pev[2i+1]]
+  double kernel_ms[8];
+  long long kernel_launches[8];
 };
+#define VILO_NKERNEL 7
+
 
 #define VILO_HIP(call)                                                                                   \
   do {                                                                                                   \

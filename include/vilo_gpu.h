@@ -235,6 +235,14 @@ int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before
 int vilo_marginalize(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
                      int mode, vilo_prior *out);
 
+/* ---- measurement / test hooks (no counterpart in the reference) -------------------------------------- */
+/* Per-kernel GPU time of the solve pipeline, HIP events on ctx's stream. kinds: see vilo_kernel_name(). */
+void vilo_set_profiling(vilo_ctx *ctx, int on);
+int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n);
+const char *vilo_kernel_name(int kind);
+/* Copy an internal device array of one window to the host (tests localise parity failures with it). */
+int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *batch, int what, int win, double *out, int max_n);
+
 #ifdef __cplusplus
 }
 #endif

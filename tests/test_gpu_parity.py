@@ -245,3 +245,61 @@ def test_size_independent_properties(ctx, cfg):
     for s, s2 in zip(summ, summ2):
         assert abs(s2.initial_cost - s.final_cost) <= 1e-9 * s.final_cost
         assert s2.final_cost >= s2.initial_cost * (1 - 2e-3)   # 12 iterations is not full convergence
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_marginalize(ctx, cfg, ocfg, mode):
+    """MarginalizationInfo::marginalize: only J0^T J0 and J0^T r0 are ordering/sign invariant (SURVEY §8a note 12)."""
+    from cerberus_amd.synth import PriorData
+    w = _fresh(cfg, ocfg, n_landmarks=60, seed=21)
+    pg, po = PriorData(), PriorData()
+    ctx.marginalize(w, mode, pg)
+    rc, m, A, bvec = O.marginalize(ocfg, w, mode, po, want_A=True)
+    assert rc == 0 and pg.struct.valid == 1
+    assert pg.blocks() == po.blocks()
+    n = pg.n
+    assert n == po.n and n in (80, 86)
+    np.testing.assert_array_equal(pg.x0[:7 * 40], po.x0[:7 * 40])
+    Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+    Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+    assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max(), np.abs(Ag - Ao).max() / np.abs(Ao).max()  # eps * cond(Amm): both sides use the eigen pseudo-inverse
+    bg, bo = Jg.T @ pg.r0[:n], Jo.T @ po.r0[:n]
+    assert np.abs(bg - bo).max() < 1e-6 * np.abs(bo).max()
+    # independent numpy Schur complement of the oracle's A, b
+    Amm, Amr, Arr = A[:m, :m], A[:m, m:], A[m:, m:]
+    Ai = np.linalg.pinv(0.5 * (Amm + Amm.T), rcond=0, hermitian=True)
+    As = Arr - Amr.T @ Ai @ Amr
+    assert np.abs(Ag - As).max() < 1e-6 * np.abs(As).max()
+
+
+def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
+    """Prior produced by GPU marginalisation of one window drives the solve of the next (GPU vs oracle)."""
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w0 = _fresh(cfg, ocfg, n_landmarks=50, seed=31)
+    p = PriorData()
+    ctx.marginalize(w0, 0, p)
+    w_g = _fresh(cfg, ocfg, n_landmarks=50, seed=32)
+    w_o = _fresh(cfg, ocfg, n_landmarks=50, seed=32)
+    for w in (w_g, w_o):
+        w.prior = p.copy()
+    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 6))[0]
+    so = O.solve_window(ocfg, w_o, O.default_opts(True, 6))
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
+def test_gauge_fix(ctx, cfg, ocfg):
+    from cerberus_amd import api
+    w_g = _fresh(cfg, ocfg, n_landmarks=30, seed=41)
+    w_o = _fresh(cfg, ocfg, n_landmarks=30, seed=41)
+    before = w_g.clone_state()
+    ctx.solve_windows([w_g], api.default_solve_opts(True, 3))
+    w_o.set_state(w_g.clone_state())
+    ctx.gauge_fix(before, w_g)
+    O.gauge_fix(before, w_o)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        np.testing.assert_allclose(a, bb, atol=1e-12)
+    # yaw and position of frame 0 are restored
+    np.testing.assert_allclose(w_g.pose[0, :3], before[0][0, :3], atol=1e-12)
