@@ -24,7 +24,7 @@ class ViloError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(T.LIB_DIR, "libvilo_gpu.so")
+        path = os.environ.get("VILO_GPU_LIB") or os.path.join(T.LIB_DIR, "libvilo_gpu.so")
         if not os.path.exists(path):
             raise ViloError("libvilo_gpu.so is missing (run __graft_entry__.build()); there is no CPU fallback")
         L = C.CDLL(path)

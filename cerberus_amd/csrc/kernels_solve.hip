@@ -16,6 +16,35 @@
 
 using namespace vilo;
 
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but leaves global loads in flight
+// (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
+#ifdef VILO_SAFE_BARRIER
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+// broadcast lane `src` (wave-uniform index) of a double through SGPRs (v_readlane): a few cycles, no LDS round trip
+__device__ __forceinline__ double readlane_d(double v, int src) {
+#ifdef VILO_SHFL
+  return __shfl(v, src, 64);
+#endif
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+// inverse of the packed upper-triangle index: row a of entry e for an n x n matrix (start(a) = a (2n + 1 - a) / 2)
+__device__ __forceinline__ int tri_row(int e, int n) {
+  const float tn = (float)(2 * n + 1);
+  int a = (int)((tn - sqrtf(tn * tn - 8.0f * (float)e)) * 0.5f);
+  if (a < 0) a = 0;
+  if (a > n - 1) a = n - 1;
+  while (a > 0 && (a * (2 * n + 1 - a)) / 2 > e) --a;
+  while (((a + 1) * (2 * n - a)) / 2 <= e) ++a;
+  return a;
+}
+
 __device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -263,16 +292,31 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm)
                 x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), rraw, true, Jraw, 38);
   }
   __syncthreads();
+  __shared__ double Jw[31 * 39];
   double *out = b.imu_lin + ((size_t)win * 10 + k) * IMU_LIN_STRIDE;
   for (int e = lane; e < 31 * 39; e += 64) {
     const int i = e / 39, c = e % 39;
     double sacc = 0.0;
+    // sqrt_info is upper triangular: only q >= i contributes (zeros below the diagonal are stored explicitly)
     if (c < 38) {
-      for (int q = i; q < 31; ++q) sacc += U[i * 31 + q] * Jraw[q * 38 + c];
+#pragma unroll
+      for (int q = 0; q < 31; ++q) sacc += (q >= i ? U[i * 31 + q] : 0.0) * Jraw[q * 38 + c];
     } else {
-      for (int q = i; q < 31; ++q) sacc += U[i * 31 + q] * rraw[q];
+#pragma unroll
+      for (int q = 0; q < 31; ++q) sacc += (q >= i ? U[i * 31 + q] : 0.0) * rraw[q];
     }
     out[e] = sacc;
+    Jw[e] = sacc;
+  }
+  __syncthreads();
+  // Gram of [Jw | rw] (39 x 39, packed upper triangle): J^T J, J^T r and r^T r of this factor
+  double *gout = b.imu_gram + ((size_t)win * 10 + k) * 780;
+  for (int e = lane; e < 780; e += 64) {
+    const int a = tri_row(e, 39), bc = a + (e - (a * (79 - a)) / 2);
+    double sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) sacc += Jw[i * 39 + a] * Jw[i * 39 + bc];
+    gout[e] = sacc;
   }
 }
 
@@ -339,64 +383,82 @@ __device__ __forceinline__ int imu_col_cd(int k, int c) {
   if (c < 25) return 6 * (k + 1) + (c - 19);
   return CD_B0 + 13 * (k + 1) + (c - 25);
 }
-
-// H(ci, cj) += v into the block-arrow storage. C: LDS 80x80; A/B: global scratch of this window.
-__device__ __forceinline__ void arrow_add(double *C, double *A_diag, double *A_off, double *Bm, int ci, int cj, double v) {
-  if (ci < CD_B0 && cj < CD_B0) {
-    C[ci * VILO_NP + cj] += v;
-  } else if (ci >= CD_B0 && cj >= CD_B0) {
-    const int ki = (ci - CD_B0) / 13, ri = (ci - CD_B0) % 13, kj = (cj - CD_B0) / 13, rj = (cj - CD_B0) % 13;
-    if (ki == kj) A_diag[ki * 169 + ri * 13 + rj] += v;
-    else if (ki == kj + 1) A_off[kj * 169 + ri * 13 + rj] += v;   // rows frame kj+1, cols frame kj
-    // (ki == kj - 1 is the transpose; stored once)
-  } else if (ci >= CD_B0) {
-    const int ki = (ci - CD_B0) / 13, ri = (ci - CD_B0) % 13;
-    Bm[ki * 1040 + ri * VILO_NP + cj] += v;                       // rows B dims, cols P dims
-  }
-  // (ci in P, cj in B) is the transpose of the case above; stored once
-}
+__device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
 
 #define SOLVE_THREADS 256
+#define CLD 81   // leading dimension of the 80x80 pose system in LDS (odd: conflict-free row and column walks)
 #define LDS_C 0
-#define LDS_G (LDS_C + 6400)
+#define LDS_AD (LDS_C + 80 * CLD)
+#define LDS_AO (LDS_AD + 11 * 169)
+#define LDS_G (LDS_AO + 10 * 169 + 1)
 #define LDS_DH2 (LDS_G + CD_N)
 #define LDS_Y (LDS_DH2 + CD_N)
 #define LDS_TMP (LDS_Y + CD_N)
 #define LDS_ACT (LDS_TMP + CD_N)
-#define LDS_BK (LDS_ACT + CD_N)
-#define LDS_BKM1 (LDS_BK + 1040)
-#define LDS_AKK (LDS_BKM1 + 1040)
-#define LDS_AKM1 (LDS_AKK + 169)
-#define LDS_AOFF (LDS_AKM1 + 169)
-#define LDS_LK (LDS_AOFF + 169)
-#define LDS_T (LDS_LK + 169)
-#define LDS_S (LDS_T + 13 * 96)
-#define LDS_RED (LDS_S + 2560)
-#define LDS_TOTAL (LDS_RED + SOLVE_THREADS)
+#define LDS_LK (LDS_ACT + CD_N)
+#define LDS_BS (LDS_LK + 176)          /* [11][13][18]: B_k x (pose_{k-1}, pose_k, pose_{k+1}) from the IMU factors */
+#define LDS_BP (LDS_BS + 11 * 13 * 18)  /* [13][80]: prior rows of the frame whose speed/leg-bias it touches */
+#define LDS_S (LDS_BP + 13 * 80)
+#define LDS_S_SIZE 3840          /* union: landmark chunk w[32][81] + einv[64]  |  Bk[1040] Bkm1[1040] T[13*96]  |  back-sub blocks */
+#define LDS_RED (LDS_S + LDS_S_SIZE)
+#define LDS_COL (LDS_RED + SOLVE_THREADS)
+#define LDS_TOTAL (LDS_COL + 176)
 
 extern "C" size_t vilo_solve_lds_bytes() { return (size_t)LDS_TOTAL * sizeof(double); }
 
+// 13x13 Cholesky by one wave: lane i (< 13) owns row i in registers, pivots broadcast with shuffles.
+// A: LDS 13x13 row-major in, L (lower, zeros above) written to Lout. Returns 0 ok / 1 not positive definite.
+__device__ int chol13_wave(const double *A, double *Lout) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane < 13 ? lane : 0;
+  double a[13], l[13];
+#pragma unroll
+  for (int j = 0; j < 13; ++j) { a[j] = A[row * 13 + j]; l[j] = 0.0; }
+  int fail = 0;
+#pragma unroll
+  for (int j = 0; j < 13; ++j) {
+    double s = a[j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) s -= l[q] * readlane_d(l[q], j);
+    double piv = readlane_d(s, j);
+    if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+    const double rinv = rsqrt(piv), ljj = piv * rinv;
+    l[j] = (lane == j) ? ljj : (lane > j ? s * rinv : 0.0);
+  }
+  if (lane < 13) {
+#pragma unroll
+    for (int j = 0; j < 13; ++j) Lout[lane * 13 + j] = l[j];
+  }
+  return fail;
+}
+
 __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ unsigned short tab26[352], tab39[784], slot_st[512];
+  __shared__ short inv_pmap[CD_N];
+  __shared__ int s_flag[4];
   const int win = blockIdx.x;
   SolverState &st = b.st[win];
   if (st.done) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const WinMeta wm = b.win[win];
-  double *C = lds + LDS_C, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y, *tmp = lds + LDS_TMP, *act = lds + LDS_ACT;
-  double *Bk = lds + LDS_BK, *Bkm1 = lds + LDS_BKM1, *Akk = lds + LDS_AKK, *Akm1 = lds + LDS_AKM1, *Aoff = lds + LDS_AOFF;
-  double *Lk = lds + LDS_LK, *T = lds + LDS_T, *S = lds + LDS_S, *red = lds + LDS_RED;
-  double *A_diag = b.A_diag + (size_t)win * 11 * 169, *A_off = b.A_off + (size_t)win * 10 * 169;
-  double *Bm = b.Bm + (size_t)win * 11 * 1040, *Tm = b.Tm + (size_t)win * 11 * 13 * 96, *Lkm = b.Lk + (size_t)win * 11 * 169;
+  double *C = lds + LDS_C, *Ad = lds + LDS_AD, *Ao = lds + LDS_AO, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y;
+  double *tmp = lds + LDS_TMP, *act = lds + LDS_ACT, *Lk = lds + LDS_LK, *S = lds + LDS_S, *red = lds + LDS_RED, *col = lds + LDS_COL;
+  double *Bk = S, *Bkm1 = S + 1040, *T = S + 2080, *Bs = lds + LDS_BS, *Bp = lds + LDS_BP;
+  double *Tm = b.Tm + (size_t)win * 11 * 13 * 96, *Lkm = b.Lk + (size_t)win * 11 * 169;
   double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
   double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
   double *cam_scale = b.cam_scale + (size_t)win * CD_N;
-  const int L = wm.L;
+  const int L = wm.L, F = wm.n_frames;
   const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
-  const int F = wm.n_frames;
+  const double *igram = b.imu_gram + (size_t)win * 10 * 780;
+  const int pn = wm.prior_n;
+  const double *Hp = b.prior_H + (size_t)win * 96 * 96;
+  const int *pmap = b.prior_map + (size_t)win * 96;
 
   if (st.need_lin) {
-    // activity mask of camera dims (SetParameterBlockConstant, estimator.cpp:1074-1105)
+    if (tid == 0) st.phase_clk[0] = clock64();
+    // ---- tables ----
     for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
       double a = 1.0;
       if (cd >= CD_EX0 && cd < CD_TD && (wm.const_mask & CONST_EX)) a = 0.0;
@@ -409,158 +471,240 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         if (c >= 9 && (wm.const_mask & CONST_LB)) a = 0.0;
       }
       act[cd] = a;
+      inv_pmap[cd] = -1;
     }
+    for (int e = tid; e < 784; e += SOLVE_THREADS) {
+      if (e < VILO_GRAM) { int a = 0, rem = e; while (rem >= 26 - a) { rem -= 26 - a; ++a; } tab26[e] = (unsigned short)(a | ((a + rem) << 8)); }
+      if (e < 780) { int a = 0, rem = e; while (rem >= 39 - a) { rem -= 39 - a; ++a; } tab39[e] = (unsigned short)(a | ((a + rem) << 8)); }
+    }
+    // slot table (s, t) of the window's Gram slots: chunk metas read in parallel, prefix by thread 0 from LDS
+    if (tid < wm.n_chunks && tid < 256) {
+      const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
+      red[tid] = (double)(cm.s | (cm.kmax << 8));
+    }
+    lds_barrier();
+    if (tid == 0) {
+      int sl = 0;
+      for (int ch = 0; ch < wm.n_chunks && ch < 256; ++ch) {
+        const int v = (int)red[ch], cs = v & 255, km = v >> 8;
+        for (int t = 0; t < km && sl < 512; ++t) slot_st[sl++] = (unsigned short)(cs | (t << 8));
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < pn; i += SOLVE_THREADS) inv_pmap[pmap[i]] = (short)i;
+    int kb = -1;   // frame whose speed/leg-bias block the prior touches
+    for (int i = 0; i < pn; ++i)
+      if (pmap[i] >= CD_B0) { kb = (pmap[i] - CD_B0) / 13; break; }
+    __syncthreads();
+
+    // B_k(i, p): speed/leg-bias (frame k, local row i) x pose-part coupling, gathered from the IMU Grams and the prior
+#ifdef VILO_BVAL_GATHER
+    auto Bval = [&](int k, int i, int p) -> double {
+      if (act[CD_B0 + 13 * k + i] == 0.0 || act[p] == 0.0) return 0.0;
+      double v = 0.0;
+      if (p < 66) {
+        const int f = p / 6, c = p - 6 * f;
+        if (k + 1 < F) {
+          if (f == k) v += igram[k * 780 + tri39(c, 6 + i)];
+          else if (f == k + 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
+        }
+        if (k > 0) {
+          if (f == k - 1) v += igram[(k - 1) * 780 + tri39(c, 25 + i)];
+          else if (f == k) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
+        }
+      }
+      if (k == kb) {
+        const int pi = inv_pmap[CD_B0 + 13 * k + i], pp = inv_pmap[p];
+        if (pi >= 0 && pp >= 0) v += Hp[(size_t)pi * pn + pp];
+      }
+      return v;
+    };
+#else
+    auto Bval = [&](int k, int i, int p) -> double {
+      if (act[CD_B0 + 13 * k + i] == 0.0 || act[p] == 0.0) return 0.0;
+      double v = 0.0;
+      if (p < 66) {
+        const int f = p / 6, df = f - k + 1;
+        if (df >= 0 && df <= 2) v = Bs[(k * 13 + i) * 18 + 6 * df + (p - 6 * f)];
+      }
+      if (k == kb) v += Bp[i * 80 + p];
+      return v;
+    };
+#endif
+
     bool solved = false;
     while (!solved) {
       __syncthreads();
       const double mu = st.mu;
-      // ---- P0: clear ----
-      for (int e = tid; e < 6400; e += SOLVE_THREADS) C[e] = 0.0;
+      if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+      if (tid == 0) { st.phase_clk[1] = clock64(); st.phase_clk[2] = st.phase_clk[1]; st.phase_clk[3] = st.phase_clk[1]; }
+      // ---- assembly: barrier-free scatter with LDS FP64 atomics (ds_add_f64); every Gram entry of every slot is an
+      //      independent coalesced load + 1-2 atomic adds, so the L2 latency overlaps across entries ----
+      for (int e = tid; e < 80 * CLD; e += SOLVE_THREADS) C[e] = 0.0;
+      for (int e = tid; e < 11 * 169 + 10 * 169; e += SOLVE_THREADS) Ad[e] = 0.0;   // Ad and Ao are contiguous
       for (int e = tid; e < CD_N; e += SOLVE_THREADS) g[e] = 0.0;
-      for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) A_diag[e] = 0.0;
-      for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) A_off[e] = 0.0;
-      for (int e = tid; e < 11 * 1040; e += SOLVE_THREADS) Bm[e] = 0.0;
+      if (pn > 0 && tid < wm.prior_nb)
+        prior_dx(x + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid],
+                 b.prior_bsize[win * 40 + tid], S + b.prior_bidx[win * 40 + tid]);
       __syncthreads();
-      // ---- P1: visual Gram slots -> C, g ----
-      for (int ch = 0; ch < wm.n_chunks; ++ch) {
-        const ChunkMeta cm = b.chunk[wm.chunk_off + ch];
-        for (int t = 0; t < cm.kmax; ++t) {
-          const double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
-          const int j = cm.s + t;
-          for (int e = tid; e < VILO_GRAM; e += SOLVE_THREADS) {
-            // decode packed index e -> (a, bcol)
-            int a = 0, rem = e;
-            while (rem >= 26 - a) { rem -= 26 - a; ++a; }
-            const int bc = a + rem;
-            if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;  // no pose_j columns in OneFrameTwoCam
-            const double v = gs[e];
-            auto cdof = [&](int c) { return c < 6 ? 6 * cm.s + c : (c < 12 ? 6 * j + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
-            if (bc == 25) {
-              if (a < 25) g[cdof(a)] += v;
-            } else {
-              const int pa = cdof(a), pb = cdof(bc);
-              C[pa * VILO_NP + pb] += v;
-              if (pa != pb) C[pb * VILO_NP + pa] += v;
-            }
-          }
-          __syncthreads();
-        }
-      }
-      // ---- P2: IMU-leg factors ----
-      for (int k = 0; k + 1 < F; ++k) {
-        const double *lin = b.imu_lin + ((size_t)win * 10 + k) * IMU_LIN_STRIDE;
-        for (int e = tid; e < IMU_LIN_STRIDE; e += SOLVE_THREADS) S[e] = lin[e];
-        __syncthreads();
-        // 39 x 39 Gram (column 38 = whitened residual): upper triangle incl. diagonal = 780 entries
-        for (int e = tid; e < 780; e += SOLVE_THREADS) {
-          int a = 0, rem = e;
-          while (rem >= 39 - a) { rem -= 39 - a; ++a; }
-          const int bc = a + rem;
-          double sacc = 0.0;
-          for (int i = 0; i < 31; ++i) sacc += S[i * 39 + a] * S[i * 39 + bc];
-          if (bc == 38) {
-            if (a < 38) g[imu_col_cd(k, a)] += sacc;   // distinct a -> distinct target
-          } else {
-            const int ca = imu_col_cd(k, a), cb = imu_col_cd(k, bc);
-            if (ca == cb) {
-              arrow_add(C, A_diag, A_off, Bm, ca, cb, sacc);
-            } else {
-              arrow_add(C, A_diag, A_off, Bm, ca, cb, sacc);
-              arrow_add(C, A_diag, A_off, Bm, cb, ca, sacc);
-            }
+      {
+        auto ladd = [](double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        // visual Gram slots -> C, g
+        const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
+        const int nvis = wm.n_gram * VILO_GRAM;
+#pragma unroll 4
+        for (int idx = tid; idx < nvis; idx += SOLVE_THREADS) {
+          const double v = gs[idx];
+          const int sl = idx / VILO_GRAM, e = idx - sl * VILO_GRAM;
+          const int s = slot_st[sl] & 255, t = slot_st[sl] >> 8, j = s + t;
+          const int a = tab26[e] & 255, bc = tab26[e] >> 8;
+          if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;   // OneFrameTwoCam has no pose_j columns
+          const int pa = a < 6 ? 6 * s + a : (a < 12 ? 6 * j + (a - 6) : (a < 18 ? CD_EX0 + a - 12 : (a < 24 ? CD_EX1 + a - 18 : CD_TD)));
+          if (bc == 25) { if (a < 25) ladd(&g[pa], v); }
+          else {
+            const int pb = bc < 6 ? 6 * s + bc : (bc < 12 ? 6 * j + (bc - 6) : (bc < 18 ? CD_EX0 + bc - 12 : (bc < 24 ? CD_EX1 + bc - 18 : CD_TD)));
+            ladd(&C[pa * CLD + pb], v);
+            if (pa != pb) ladd(&C[pb * CLD + pa], v);
           }
         }
-        __syncthreads();
+        // IMULegFactor Grams (39x39 packed, column 38 = residual): P x P -> C, B x B -> Ad / Ao, gradient
+        const int nimu = (F - 1) * 780;
+#pragma unroll 4
+        for (int idx = tid; idx < nimu; idx += SOLVE_THREADS) {
+          const double v = igram[idx];
+          const int k = idx / 780, e = idx - k * 780;
+          const int a = tab39[e] & 255, bc = tab39[e] >> 8;
+          if (bc == 38) { if (a < 38) ladd(&g[imu_col_cd(k, a)], v); continue; }
+          const int ca = imu_col_cd(k, a), cb = imu_col_cd(k, bc);
+          if (ca < CD_B0 && cb < CD_B0) {
+            ladd(&C[ca * CLD + cb], v);
+            if (ca != cb) ladd(&C[cb * CLD + ca], v);
+          } else if (ca >= CD_B0 && cb >= CD_B0) {
+            const int ka = (ca - CD_B0) / 13, ra = (ca - CD_B0) % 13, kc = (cb - CD_B0) / 13, rc = (cb - CD_B0) % 13;
+            if (ka == kc) { ladd(&Ad[ka * 169 + ra * 13 + rc], v); if (ra != rc) ladd(&Ad[ka * 169 + rc * 13 + ra], v); }
+            else ladd(&Ao[ka * 169 + rc * 13 + ra], v);   // a < bc => ka = k, kc = k + 1: rows frame k+1, cols frame k
+          }
+        }
+        // marginalisation prior: H += J0^T J0, g += J0^T (r0 + J0 dx)
+        if (pn > 0) {
+          const double *b0 = b.prior_b0 + (size_t)win * 96;
+          const double *dx = S;
+          for (int i = tid; i < pn; i += SOLVE_THREADS) {
+            double sacc = b0[i];
+#pragma unroll 8
+            for (int q = 0; q < pn; ++q) sacc += Hp[(size_t)q * pn + i] * dx[q];
+            ladd(&g[pmap[i]], sacc);
+          }
+#pragma unroll 4
+          for (int e = tid; e < pn * pn; e += SOLVE_THREADS) {
+            const double v = Hp[e];
+            const int i = e / pn, q = e - i * pn;
+            const int ci = pmap[i], cq = pmap[q];
+            if (ci < CD_B0 && cq < CD_B0) ladd(&C[ci * CLD + cq], v);
+            else if (ci >= CD_B0 && cq >= CD_B0) ladd(&Ad[((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13], v);
+          }
+        }
+        // speed/leg-bias x pose coupling (IMU factors) and the prior's rows for frame kb: one writer per entry
+        for (int e = tid; e < 11 * 13 * 18; e += SOLVE_THREADS) {
+          const int k = e / 234, i = (e % 234) / 18, sl = e % 18, df = sl / 6, c = sl % 6, f = k + df - 1;
+          double v = 0.0;
+          if (k < F && f >= 0 && f < F) {
+            if (k + 1 < F) {
+              if (f == k) v += igram[k * 780 + tri39(c, 6 + i)];
+              else if (f == k + 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
+            }
+            if (k > 0) {
+              if (f == k - 1) v += igram[(k - 1) * 780 + tri39(c, 25 + i)];
+              else if (f == k) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
+            }
+          }
+          Bs[e] = v;
+        }
+        for (int e = tid; e < 13 * 80; e += SOLVE_THREADS) {
+          double v = 0.0;
+          if (kb >= 0) { const int p1 = inv_pmap[CD_B0 + 13 * kb + e / 80], p2 = inv_pmap[e % 80]; if (p1 >= 0 && p2 >= 0) v = Hp[(size_t)p1 * pn + p2]; }
+          Bp[e] = v;
+        }
       }
-      // ---- P3: marginalisation prior: H += J0^T J0, g += J0^T (r0 + J0 dx) ----
-      if (wm.prior_n > 0) {
-        const int n = wm.prior_n;
-        const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
-        const int *pmap = b.prior_map + (size_t)win * 96;
-        double *dx = S;
-        if (tid < wm.prior_nb) {
-          const int bs = b.prior_bsize[win * 40 + tid];
-          prior_dx(x + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid], bs,
-                   dx + b.prior_bidx[win * 40 + tid]);
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += SOLVE_THREADS) {
-          double sacc = b0[i];
-          for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + i] * dx[q];   // Hp symmetric: column read is coalesced
-          g[pmap[i]] += sacc;
-        }
-        for (int e = tid; e < n * n; e += SOLVE_THREADS) {
-          const int i = e / n, q = e % n;
-          arrow_add(C, A_diag, A_off, Bm, pmap[i], pmap[q], Hp[e]);
-        }
-        __syncthreads();
-      }
-      // ---- P4: constant dims ----
-      for (int e = tid; e < 6400; e += SOLVE_THREADS) {
-        const int i = e / VILO_NP, j = e % VILO_NP;
-        if (act[i] == 0.0 || act[j] == 0.0) C[e] = (i == j) ? 1.0 : 0.0;
+      __syncthreads();
+      // constant dims -> identity rows / cols
+      for (int e = tid; e < 80 * 80; e += SOLVE_THREADS) {
+        const int i = e / 80, j = e % 80;
+        if (act[i] == 0.0 || act[j] == 0.0) C[i * CLD + j] = (i == j) ? 1.0 : 0.0;
       }
       for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) {
         const int k = e / 169, i = (e % 169) / 13, j = e % 13;
-        if (act[CD_B0 + 13 * k + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) A_diag[e] = (i == j) ? 1.0 : 0.0;
+        if (act[CD_B0 + 13 * k + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ad[e] = (i == j) ? 1.0 : 0.0;
       }
       for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) {
         const int k = e / 169, i = (e % 169) / 13, j = e % 13;
-        if (act[CD_B0 + 13 * (k + 1) + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) A_off[e] = 0.0;
-      }
-      for (int e = tid; e < 11 * 1040; e += SOLVE_THREADS) {
-        const int k = e / 1040, i = (e % 1040) / VILO_NP, j = e % VILO_NP;
-        if (act[CD_B0 + 13 * k + i] == 0.0 || act[j] == 0.0) Bm[e] = 0.0;
+        if (act[CD_B0 + 13 * (k + 1) + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ao[e] = 0.0;
       }
       for (int e = tid; e < CD_N; e += SOLVE_THREADS)
         if (act[e] == 0.0) g[e] = 0.0;
       __syncthreads();
-      // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
-      {
-        for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-          double hii = 1.0;
-          if (cd < CD_B0) hii = C[cd * VILO_NP + cd];
-          else if (cd < CD_B0 + 143) hii = A_diag[((cd - CD_B0) / 13) * 169 + ((cd - CD_B0) % 13) * 14];
-          double sc = 1.0;
-          if (act[cd] != 0.0) {
-            if (!st.scale_ready) {
-              sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
-              cam_scale[cd] = sc;
-            } else {
-              sc = cam_scale[cd];
-            }
-            const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
-            dh2[cd] = d2 / (sc * sc);
-            tmp[cd] = g[cd] / dh2[cd];
-          } else {
-            dh2[cd] = 1.0;
-            tmp[cd] = 0.0;
-          }
-        }
-        __syncthreads();
+      double Cr[5][5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Cr[r][c] = C[(ty + 16 * r) * CLD + tx + 16 * c];
+      if (ty == tx) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) y[ty + 16 * r] = Cr[r][r];
       }
-      // camera part of |D^-1 g|^2, max|g|, and q = v^T H v (C, A, B before regularisation / Schur)
+      __syncthreads();
+      if (tid == 0) st.phase_clk[4] = clock64();
+      // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+        double hii = 1.0;
+        if (cd < CD_B0) hii = y[cd];
+        else if (cd < CD_B0 + 143) hii = Ad[((cd - CD_B0) / 13) * 169 + ((cd - CD_B0) % 13) * 14];
+        if (act[cd] != 0.0) {
+          double sc;
+          if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
+          else sc = cam_scale[cd];
+          const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
+          dh2[cd] = d2 / (sc * sc);
+          tmp[cd] = g[cd] / dh2[cd];
+        } else {
+          dh2[cd] = 1.0;
+          tmp[cd] = 0.0;
+        }
+      }
+      __syncthreads();
+      // camera part of |D^-1 g|^2, max|g|, q = v^T H v (before regularisation / Schur)
       double part_gn = 0.0, part_q = 0.0, part_gmax = 0.0;
       for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
         part_gn += g[cd] * tmp[cd];
         part_gmax = fmax(part_gmax, fabs(g[cd]));
       }
-      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) {
-        double sacc = 0.0;
-        for (int j = 0; j < VILO_NP; ++j) sacc += C[i * VILO_NP + j] * tmp[j];
-        part_q += tmp[i] * sacc;
+      {
+        double vr[5], vc[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { vr[r] = tmp[ty + 16 * r]; vc[r] = tmp[tx + 16 * r]; }
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+          for (int c = 0; c < 5; ++c) part_q += vr[r] * Cr[r][c] * vc[c];
       }
-      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) {
-        const int k = e / 13, i = e % 13;
-        const double vi = tmp[CD_B0 + 13 * k + i];
-        double sacc = 0.0;
-        for (int j = 0; j < 13; ++j) sacc += A_diag[k * 169 + i * 13 + j] * tmp[CD_B0 + 13 * k + j];
-        double cross = 0.0;
-        if (k > 0)
-          for (int j = 0; j < 13; ++j) cross += A_off[(k - 1) * 169 + i * 13 + j] * tmp[CD_B0 + 13 * (k - 1) + j];
-        double bp = 0.0;
-        for (int j = 0; j < VILO_NP; ++j) bp += Bm[k * 1040 + i * VILO_NP + j] * tmp[j];
-        part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
+      if (tid >= 96 && tid < 96 + 143) {
+        const int e = tid - 96, k = e / 13, i = e % 13;
+        if (k < F) {
+          const double vi = tmp[CD_B0 + e];
+          double sacc = 0.0;
+          for (int j = 0; j < 13; ++j) sacc += Ad[k * 169 + i * 13 + j] * tmp[CD_B0 + 13 * k + j];
+          double cross = 0.0;
+          if (k > 0)
+            for (int j = 0; j < 13; ++j) cross += Ao[(k - 1) * 169 + i * 13 + j] * tmp[CD_B0 + 13 * (k - 1) + j];
+          double bp = 0.0;
+          if (k == kb) {
+            for (int p = 0; p < VILO_NPU; ++p) bp += Bval(k, i, p) * tmp[p];
+          } else {
+            const int p0 = 6 * (k > 0 ? k - 1 : 0), p1 = 6 * (k + 2 < F ? k + 2 : F);
+            for (int p = p0; p < p1; ++p) bp += Bval(k, i, p) * tmp[p];
+          }
+          part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
+        }
       }
       // ---- P6: landmarks pass 1 ----
       double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off;
@@ -574,6 +718,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         lm_dh2[l] = d2;
         const double vl = gl / d2;
         double tl = 0.0;
+#pragma unroll 16
         for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * tmp[a];
         part_q += 2.0 * vl * tl + E * vl * vl;
         part_gn += gl * vl;
@@ -583,100 +728,104 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       const double gnorm2 = block_sum(part_gn, red);
       const double qq = block_sum(part_q, red);
       const double gmax = block_max(part_gmax, red);
-      // termination tests of FinalizeIterationAndCheckIfMinimizerCanContinue that need the fresh gradient
       if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
         if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
         return;
       }
-      // Schur complement: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2), g_P -= sum_l w_l g_l / (...)
-      if (tid < VILO_NP) y[tid] = 0.0;   // y[0..79] accumulates the landmark part of the reduced rhs
+      if (tid == 0) st.phase_clk[5] = clock64();
+      // (the 80x80 pose system already lives in registers: thread (ty, tx) owns C(ty + 16 r, tx + 16 c))
+      // Schur complement of the landmarks: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2), rhs_P -= sum_l w_l g_l / (...)
+      if (tid < 80) y[tid] = 0.0;
+      __syncthreads();
       for (int l0 = 0; l0 < L; l0 += 32) {
         const int nl = min(32, L - l0);
         for (int e = tid; e < 80 * 32; e += SOLVE_THREADS) {
-          const int a = e / 32, q = e % 32;
-          S[e] = (q < nl && a < VILO_NPU) ? wl[(size_t)a * L + l0 + q] * act[a] : 0.0;
+          const int a = e >> 5, q = e & 31;    // global read: consecutive q (landmarks) are contiguous
+          S[q * 81 + a] = (q < nl && a < VILO_NPU) ? wl[(size_t)a * L + l0 + q] * act[a] : 0.0;
         }
         if (tid < 32) {
-          red[tid] = (tid < nl) ? lm_einv[l0 + tid] : 0.0;
-          red[32 + tid] = (tid < nl) ? lm_g[l0 + tid] * lm_einv[l0 + tid] : 0.0;
+          S[2600 + tid] = (tid < nl) ? lm_einv[l0 + tid] : 0.0;
+          S[2640 + tid] = (tid < nl) ? lm_g[l0 + tid] * lm_einv[l0 + tid] : 0.0;
         }
         __syncthreads();
-        for (int e = tid; e < 6400; e += SOLVE_THREADS) {
-          const int i = e / VILO_NP, j = e % VILO_NP;
-          double sacc = 0.0;
-          for (int q = 0; q < 32; ++q) sacc += S[i * 32 + q] * S[j * 32 + q] * red[q];
-          C[e] -= sacc;
+#pragma unroll 2
+        for (int q = 0; q < 32; ++q) {
+          const double ei = S[2600 + q];
+          double wr[5], wc[5];
+#pragma unroll
+          for (int r = 0; r < 5; ++r) { wr[r] = S[q * 81 + ty + 16 * r] * ei; wc[r] = S[q * 81 + tx + 16 * r]; }
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) Cr[r][c] -= wr[r] * wc[c];
         }
-        if (tid < VILO_NP) {
+        if (tid < 80) {
           double sacc = 0.0;
-          for (int q = 0; q < 32; ++q) sacc += S[tid * 32 + q] * red[32 + q];
+          for (int q = 0; q < 32; ++q) sacc += S[q * 81 + tid] * S[2640 + q];
           y[tid] += sacc;
         }
         __syncthreads();
       }
-      // rhs of the reduced system: gred = g - (landmark part)
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < VILO_NP) ? y[cd] : 0.0);
+      if (tid == 0) st.phase_clk[6] = clock64();
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < 80) ? y[cd] : 0.0);   // reduced rhs
+      // regularise: diag += mu dhat^2
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        if (ty == tx) Cr[r][r] += mu * dh2[ty + 16 * r];
+      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
       __syncthreads();
-      // ---- P7/P8: regularise + block elimination of the B part (frames F-1 .. 0) ----
-      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) C[i * VILO_NP + i] += mu * dh2[i];
+      // ---- P8: block elimination of the speed/leg-bias part, frames F-1 .. 0 ----
       int fail = 0;
+      for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bval(F - 1, e / 80, e % 80);
       for (int k = F - 1; k >= 0; --k) {
-        if (k == F - 1) {
-          for (int e = tid; e < 169; e += SOLVE_THREADS) Akk[e] = A_diag[k * 169 + e] + ((e / 13 == e % 13) ? mu * dh2[CD_B0 + 13 * k + e / 13] : 0.0);
-          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bm[k * 1040 + e];
+        if (k > 0)
+          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bkm1[e] = Bval(k - 1, e / 80, e % 80);
+        lds_barrier();
+        if (tid < 64) {
+          const int f = chol13_wave(Ad + k * 169, Lk);
+          if (tid == 0) { s_flag[0] = f; if (f) st.pad[0] = 100 + k; }
         }
-        if (k > 0) {
-          for (int e = tid; e < 169; e += SOLVE_THREADS) {
-            Aoff[e] = A_off[(k - 1) * 169 + e];
-            Akm1[e] = A_diag[(k - 1) * 169 + e] + ((e / 13 == e % 13) ? mu * dh2[CD_B0 + 13 * (k - 1) + e / 13] : 0.0);
-          }
-          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bkm1[e] = Bm[(k - 1) * 1040 + e];
-        }
-        __syncthreads();
-        // Cholesky of the 13x13 diagonal block (thread 0; 13^3/6 flops)
-        if (tid == 0) {
-          for (int j = 0; j < 13; ++j) {
-            double sacc = Akk[j * 13 + j];
-            for (int q = 0; q < j; ++q) sacc -= Lk[j * 13 + q] * Lk[j * 13 + q];
-            if (!(sacc > 0.0) || !isfinite(sacc)) { fail = 1; sacc = 1.0; }
-            const double ljj = sqrt(sacc);
-            Lk[j * 13 + j] = ljj;
-            for (int i = j + 1; i < 13; ++i) {
-              double tacc = Akk[i * 13 + j];
-              for (int q = 0; q < j; ++q) tacc -= Lk[i * 13 + q] * Lk[j * 13 + q];
-              Lk[i * 13 + j] = tacc / ljj;
-            }
-            for (int i = 0; i < j; ++i) Lk[i * 13 + j] = 0.0;
-          }
-          red[0] = (double)fail;
-        }
-        __syncthreads();
-        fail = (int)red[0];
-        __syncthreads();
-        // T = Lk^-1 [Aoff | Bk | g_k]: one thread per column (13 + 80 + 1 = 94)
+        lds_barrier();
+        fail |= s_flag[0];
+        // T = Lk^-1 [A_{k,k-1} | B_k | rhs_k]: one thread per column (13 + 80 + 1); threads 96..108: columns of Lk^-1
         if (tid < 94) {
-          double col[13];
+          double cl[13];
+#pragma unroll
           for (int i = 0; i < 13; ++i) {
-            double v = (tid < 13) ? ((k > 0) ? Aoff[i * 13 + tid] : 0.0) : (tid < 93 ? Bk[i * VILO_NP + (tid - 13)] : tmp[CD_B0 + 13 * k + i]);
-            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * col[q];
-            col[i] = v / Lk[i * 13 + i];
+            double v = (tid < 13) ? ((k > 0) ? Ao[(k - 1) * 169 + i * 13 + tid] : 0.0) : (tid < 93 ? Bk[i * 80 + (tid - 13)] : tmp[CD_B0 + 13 * k + i]);
+#pragma unroll
+            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
+            cl[i] = v / Lk[i * 13 + i];
           }
-          for (int i = 0; i < 13; ++i) T[i * 96 + tid] = col[i];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) T[i * 96 + tid] = cl[i];
+        } else if (tid >= 96 && tid < 109) {
+          const int c = tid - 96;
+          double cl[13];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) {
+            double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
+            cl[i] = v / Lk[i * 13 + i];
+          }
+#pragma unroll
+          for (int i = 0; i < 13; ++i) Lkm[k * 169 + i * 13 + c] = cl[i];   // Lk^-1 (lower), used by the back-substitution
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < 13 * 96; e += SOLVE_THREADS) Tm[k * 13 * 96 + e] = T[e];
-        for (int e = tid; e < 169; e += SOLVE_THREADS) Lkm[k * 169 + e] = Lk[e];
-        // Schur updates
         if (k > 0) {
           for (int e = tid; e < 169; e += SOLVE_THREADS) {
             const int i = e / 13, j = e % 13;
             double sacc = 0.0;
+#pragma unroll
             for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + j];
-            Akm1[e] -= sacc;
+            Ad[(k - 1) * 169 + e] -= sacc;
           }
           for (int e = tid; e < 1040; e += SOLVE_THREADS) {
-            const int i = e / VILO_NP, j = e % VILO_NP;
+            const int i = e / 80, j = e % 80;
             double sacc = 0.0;
+#pragma unroll
             for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + 13 + j];
             Bkm1[e] -= sacc;
           }
@@ -686,49 +835,69 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
             tmp[CD_B0 + 13 * (k - 1) + tid] -= sacc;
           }
         }
-        for (int e = tid; e < 6400; e += SOLVE_THREADS) {
-          const int i = e / VILO_NP, j = e % VILO_NP;
-          double sacc = 0.0;
-          for (int q = 0; q < 13; ++q) sacc += T[q * 96 + 13 + i] * T[q * 96 + 13 + j];
-          C[e] -= sacc;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) {
+          double tr_[5], tc_[5];
+#pragma unroll
+          for (int r = 0; r < 5; ++r) { tr_[r] = T[q * 96 + 13 + ty + 16 * r]; tc_[r] = T[q * 96 + 13 + tx + 16 * r]; }
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) Cr[r][c] -= tr_[r] * tc_[c];
         }
-        if (tid >= 64 && tid < 64 + VILO_NP) {
+        if (tid >= 64 && tid < 64 + 80) {
           const int i = tid - 64;
           double sacc = 0.0;
           for (int q = 0; q < 13; ++q) sacc += T[q * 96 + 13 + i] * T[q * 96 + 93];
           tmp[i] -= sacc;
         }
-        __syncthreads();
-        // roll: (k-1) becomes current
-        if (k > 0) {
-          for (int e = tid; e < 169; e += SOLVE_THREADS) Akk[e] = Akm1[e];
+        lds_barrier();
+        if (k > 0)
           for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bkm1[e];
-        }
-        __syncthreads();
       }
-      // dense Cholesky of the 80x80 reduced pose system (right-looking, in place, lower)
-      for (int j = 0; j < VILO_NP; ++j) {
-        if (tid == 0) {
-          double d = C[j * VILO_NP + j];
-          if (!(d > 0.0) || !isfinite(d)) { fail = 1; d = 1.0; }
-          C[j * VILO_NP + j] = sqrt(d);
-          red[0] = (double)fail;
+      if (tid == 0) st.phase_clk[7] = clock64();
+      // ---- dense Cholesky of the 80x80 reduced pose system: register tiles, pivot column broadcast through LDS,
+      //      reciprocal square root of the pivot (one Newton step on v_rsq_f64) instead of sqrt + 80 divisions ----
+      for (int j = 0; j < 80; ++j) {
+        const int jr = j >> 4, jt = j & 15;
+        if (ty == jt && tx == jt) {
+          double d = 0.0;
+#pragma unroll
+          for (int r = 0; r < 5; ++r) if (r == jr) d = Cr[r][r];
+          if (!(d > 0.0) || !isfinite(d)) { if (!s_flag[1] && st.pad[1] == 0) { st.pad[1] = 1000 + j; st.x_norm = d; } s_flag[1] = 1; d = 1.0; }
+          const double rs = rsqrt(d);
+          col[80] = d * rs;
+          col[81] = rs;
         }
-        __syncthreads();
-        fail = (int)red[0];
-        const double ljj = C[j * VILO_NP + j];
-        for (int i = j + 1 + tid; i < VILO_NP; i += SOLVE_THREADS) C[i * VILO_NP + j] /= ljj;
-        __syncthreads();
-        const int m = VILO_NP - 1 - j;
-        for (int e = tid; e < m * m; e += SOLVE_THREADS) {
-          const int i = j + 1 + e / m, q = j + 1 + e % m;
-          if (q <= i) C[i * VILO_NP + q] -= C[i * VILO_NP + j] * C[q * VILO_NP + j];
+        lds_barrier();
+        const double dj = col[80], rj = col[81];
+        if (tx == jt) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            const int i = ty + 16 * r;
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) if (c == jr) v = Cr[r][c];
+            const double lij = (i > j) ? v * rj : 0.0;
+            col[i] = lij;
+            C[i * CLD + j] = (i > j) ? lij : (i == j ? dj : 0.0);
+          }
         }
-        __syncthreads();
+        lds_barrier();
+        double cr[5], cc[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { cr[r] = col[ty + 16 * r]; cc[r] = col[tx + 16 * r]; }
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+          for (int c = 0; c < 5; ++c) Cr[r][c] -= cr[r] * cc[c];
       }
+      lds_barrier();
+      fail |= s_flag[1];
       if (fail) {
         // DoglegStrategy::ComputeGaussNewtonStep: mu *= 10 and retry while mu < max_mu (1.0)
-        if (tid == 0) st.mu *= 10.0;
+        __syncthreads();
+        if (tid == 0) { st.mu *= 10.0; s_flag[0] = 0; s_flag[1] = 0; }
         __syncthreads();
         if (!(st.mu < 1.0)) {
           if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = qq; st.gmax = gmax; st.scale_ready = 1; }
@@ -736,53 +905,84 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         }
         continue;
       }
-      // solve L L^T yP = rhs (tmp[0..79])
-      for (int j = 0; j < VILO_NP; ++j) {
-        if (tid == 0) tmp[j] /= C[j * VILO_NP + j];
-        __syncthreads();
-        for (int i = j + 1 + tid; i < VILO_NP; i += SOLVE_THREADS) tmp[i] -= C[i * VILO_NP + j] * tmp[j];
-        __syncthreads();
+      if (tid == 0) st.phase_clk[8] = clock64();
+      // ---- triangular solves L L^T yP = rhs by wave 0 (lane owns rows lane and lane + 64); pivots by v_readlane ----
+      if (tid < 80) col[tid] = 1.0 / C[tid * CLD + tid];
+      lds_barrier();
+      if (tid < 64) {
+        const int lane = tid;
+        double b0 = tmp[lane], b1 = lane < 16 ? tmp[lane + 64] : 0.0;
+        for (int j = 0; j < 80; ++j) {
+          const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
+          if (lane > j) b0 -= C[lane * CLD + j] * yj;
+          if (lane < 16 && lane + 64 > j) b1 -= C[(lane + 64) * CLD + j] * yj;
+          if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+        }
+        for (int j = 79; j >= 0; --j) {
+          const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
+          if (lane < j) b0 -= C[j * CLD + lane] * yj;
+          if (lane < 16 && lane + 64 < j) b1 -= C[j * CLD + lane + 64] * yj;
+          if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+        }
+        y[lane] = b0;
+        if (lane < 16) y[lane + 64] = b1;
       }
-      for (int j = VILO_NP - 1; j >= 0; --j) {
-        if (tid == 0) tmp[j] /= C[j * VILO_NP + j];
-        __syncthreads();
-        for (int i = tid; i < j; i += SOLVE_THREADS) tmp[i] -= C[j * VILO_NP + i] * tmp[j];
-        __syncthreads();
+      __syncthreads();   // also orders the Tm / Lkm global stores of the elimination before the loads below
+      if (tid == 0) st.phase_clk[9] = clock64();
+      // ---- back-substitution of the B part: u_k = t_g - T_B yP (parallel), then the chain over frames:
+      //      y_k = L_k^-T (u_k - T_A y_{k-1}) with L_k^-1 precomputed, one LDS round trip per frame (wave 0) ----
+      double *U = S;               // [11][13]
+      double *TA = S + 160;        // [11][169]  T_A blocks
+      double *LI = C;              // [11][169]  L_k^-1 blocks (the pose factor is no longer needed)
+      if (tid < 143) {
+        const int k = tid / 13, i = tid % 13;
+        if (k < F) {
+          const double *trow = Tm + (size_t)k * 13 * 96 + i * 96;
+          double sacc = trow[93];
+#pragma unroll 16
+          for (int q = 0; q < 80; ++q) sacc -= trow[13 + q] * y[q];
+          U[k * 13 + i] = sacc;
+        }
       }
-      for (int i = tid; i < VILO_NP; i += SOLVE_THREADS) y[i] = tmp[i];
+      for (int e = tid; e < F * 169; e += SOLVE_THREADS) {
+        const int k = e / 169, r = (e % 169) / 13, c = e % 13;
+        TA[e] = Tm[(size_t)k * 13 * 96 + r * 96 + c];
+        LI[e] = Lkm[e];
+      }
       __syncthreads();
-      // back-substitute the B part, frames 0 .. F-1: L_k^T y_k = t_g - T_A y_{k-1} - T_B y_P
-      for (int k = 0; k < F; ++k) {
-        for (int e = tid; e < 13 * 96; e += SOLVE_THREADS) T[e] = Tm[k * 13 * 96 + e];
-        for (int e = tid; e < 169; e += SOLVE_THREADS) Lk[e] = Lkm[k * 169 + e];
-        __syncthreads();
-        if (tid < 13) {
-          double sacc = T[tid * 96 + 93];
-          if (k > 0)
-            for (int q = 0; q < 13; ++q) sacc -= T[tid * 96 + q] * y[CD_B0 + 13 * (k - 1) + q];
-          for (int q = 0; q < VILO_NP; ++q) sacc -= T[tid * 96 + 13 + q] * y[q];
-          S[tid] = sacc;
-        }
-        __syncthreads();
-        if (tid == 0) {
-          for (int i = 12; i >= 0; --i) {
-            double v = S[i];
-            for (int q = i + 1; q < 13; ++q) v -= Lk[q * 13 + i] * y[CD_B0 + 13 * k + q];
-            y[CD_B0 + 13 * k + i] = v / Lk[i * 13 + i];
+      if (tid < 64) {
+        const int lane = tid, row = lane < 13 ? lane : 0;
+        double *rb = col;   // rhs broadcast buffer
+        for (int k = 0; k < F; ++k) {
+          double rhs = U[k * 13 + row];
+          if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < 13; ++q) rhs -= TA[k * 169 + row * 13 + q] * y[CD_B0 + 13 * (k - 1) + q];
           }
+          if (lane < 13) rb[lane] = rhs;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          double yk = 0.0;
+#pragma unroll
+          for (int q = 0; q < 13; ++q) yk += LI[k * 169 + q * 13 + row] * rb[q];   // (L^-T rhs)_row = sum_q Linv[q][row] rhs[q]
+          if (lane < 13) y[CD_B0 + 13 * k + lane] = yk;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        __syncthreads();
       }
+      __syncthreads();
+      if (tid == 0) st.phase_clk[10] = clock64();
       // ---- P9: landmarks pass 2 (back-substitution) + norms ----
       double part_gnn = 0.0, part_gy = 0.0;
       for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
         if (act[cd] == 0.0) y[cd] = 0.0;
+      }
+      __syncthreads();
+      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
         part_gnn += dh2[cd] * y[cd] * y[cd] * act[cd];
         part_gy += g[cd] * y[cd];
       }
-      __syncthreads();
       for (int l = tid; l < L; l += SOLVE_THREADS) {
         double tl = 0.0;
+#pragma unroll 16
         for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * y[a];
         const double yl = (lm_g[l] - tl) * lm_einv[l];
         lm_y[l] = yl;
@@ -791,8 +991,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       }
       const double gnnorm2 = block_sum(part_gnn, red);
       const double gy = block_sum(part_gy, red);
-      bool finite_ok = isfinite(gnnorm2) && isfinite(gy);
-      if (!finite_ok) {   // IsArrayValid(gauss_newton_step_) failed: same handling as a failed factorisation
+      if (!(isfinite(gnnorm2) && isfinite(gy))) {   // IsArrayValid(gauss_newton_step_) failed
         if (tid == 0) st.mu *= 10.0;
         __syncthreads();
         if (!(st.mu < 1.0)) {
@@ -815,6 +1014,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
     for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) { g[cd] = cam_g[cd]; dh2[cd] = cam_dh2[cd]; y[cd] = cam_y[cd]; }
     __syncthreads();
   }
+  if (tid == 0) st.phase_clk[11] = clock64();
   // ---- P11: dogleg step for the current radius, candidate camera state ----
   if (tid == 0) {
     if (st.radius <= sp.min_radius) { st.done = 1; st.termination = 1; st.step_valid = 0; }
@@ -833,6 +1033,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
     if (c < 9) xc[XO_SB + 9 * k + c] = x[XO_SB + 9 * k + c] + tmp[CD_B0 + e];
     else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + tmp[CD_B0 + e];
   }
+  if (tid == 0) st.phase_clk[12] = clock64();
 }
 
 // =================================================================================================

@@ -71,6 +71,7 @@ struct SolverState {
   int pad[3];
   double cost_trace[64];
   double radius_trace[64];
+  long long phase_clk[16];   // shader-clock stamps of k_build_solve phases (last linearisation), profiling aid
 };
 
 struct BatchDev {
@@ -91,6 +92,7 @@ struct BatchDev {
   // IMU factors
   PreintPrepared *prep;       // [W][10]
   double *imu_lin;            // [W][10][31*39]  whitened J (31x38) | whitened r (col 38)
+  double *imu_gram;           // [W][10][780]    packed upper triangle of [J | r]^T [J | r]
   double *imu_cost;           // [W][10]
   // prior
   double *prior_H, *prior_b0, *prior_c0, *prior_x0;   // [W][96*96], [W][96], [W], [W][280]

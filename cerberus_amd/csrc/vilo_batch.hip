@@ -220,6 +220,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_alloc(ctx, bt, &D.chunk_cost, chunks.size()));
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
   TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
+  TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
   TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
   TRYB(dev_upload(ctx, bt, &D.prior_b0, pb0));
@@ -370,6 +371,7 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
     case 8: src = bt->d.lm_y + wm.lm_off; n = wm.L; break;
     case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
     case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
+    case 12: src = (const double *)(bt->d.st + win) + 24 + 128; n = 16; break;   // phase_clk (int64 bit patterns)
     case 11: {
       n = wm.L;
       if ((int)n > max_n) return VILO_ERR_BAD_ARG;
