@@ -130,6 +130,15 @@ def main():
         dom_avg_s = kern[dom]["avg_ms"] * 1e-3
         achieved = b_alg * W / dom_avg_s / 1e9             # one launch of the dominant kernel covers W window-iterations
         iter_ms = sum(v["ms_total"] for v in kern.values()) / (args.steps * ITERS)
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh: separate
+        # FETCH_SIZE / WRITE_SIZE runs, calibrated on a known 1 GiB copy); only valid for the profiled configuration
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v3.json")
+        if os.path.exists(pmc_file) and W == 1024 and args.landmarks == 200:
+            try:
+                traffic = json.load(open(pmc_file))["hbm_bytes_per_dispatch"].get(dom)
+            except Exception:
+                traffic = None
         out = {
             "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput",
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,7 +149,7 @@ def main():
                        "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "traffic": traffic, "traffic_source": "profiles/round1_pmc_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9},
             "kernels": kern,

@@ -409,3 +409,22 @@ extern "C" int vilo_pose_plus(vilo_ctx *ctx, int n, const double *x, const doubl
 }
 
 extern "C" void vilo_huber(double delta, double s, double rho[3]) { vilo::huber_rho(delta, s, rho); }
+
+// Calibration aid for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section: the counters
+// must be calibrated on a known byte count in the kernel's own access pattern): streams n doubles, 8 B per lane.
+__global__ void k_calib_copy(const double *src, double *dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] + 1.0;
+}
+extern "C" int vilo_debug_calib_copy(vilo_ctx *ctx, size_t n_doubles, int reps) {
+  if (!ctx || n_doubles == 0) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  DevBuf a, b;
+  VILO_HIP(a.alloc(n_doubles * 8));
+  VILO_HIP(b.alloc(n_doubles * 8));
+  VILO_HIP(hipMemsetAsync(a.p, 0, n_doubles * 8, ctx->stream));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_calib_copy, dim3(2048), dim3(256), 0, ctx->stream, a.as<double>(), b.as<double>(), n_doubles);
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}

@@ -13,6 +13,7 @@
  */
 #ifndef VILO_GPU_H
 #define VILO_GPU_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -242,6 +243,8 @@ int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, 
 const char *vilo_kernel_name(int kind);
 /* Copy an internal device array of one window to the host (tests localise parity failures with it). */
 int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *batch, int what, int win, double *out, int max_n);
+/* Streams n doubles (8 B per lane) `reps` times: known byte count to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE. */
+int vilo_debug_calib_copy(vilo_ctx *ctx, size_t n_doubles, int reps);
 
 #ifdef __cplusplus
 }
