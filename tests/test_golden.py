@@ -1,0 +1,174 @@
+"""Golden vectors: outputs of the REFERENCE's own factor code (compiled from /root/reference into oracle/_ref/libref.so
+and frozen by tests/golden/make_golden.py). CPU tests pin the oracle to them; `-m gpu` tests compare the HIP path,
+called through the C-ABI, with the reference outputs directly. Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+from cerberus_amd import synth
+from oracle import oracle_py as O
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.npz"))
+RF = np.array([0.1805, -0.047, -0.0838, 0.21])
+PROJ_SIZES = [[7, 7, 7, 1, 1], [7, 7, 7, 7, 1, 1], [7, 7, 1, 1]]
+
+
+def _split(v, sizes):
+    out, o = [], 0
+    for s in sizes:
+        out.append(v[..., o:o + s]); o += s
+    return out
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def gwin():
+    return synth.make_window(synth.default_config(), n_landmarks=int(G["win_landmarks"]), seed=int(G["win_seed"]))
+
+
+def _info_blocks(prior):
+    """(ids, H, b, x0) of a prior with blocks sorted by id — same construction as make_golden.py."""
+    from oracle import ref_py as R
+    Hb, bb, x0 = R.prior_information(prior)
+    ids = sorted(x0)
+    return (np.array(ids), np.block([[Hb[(a, c)] for c in ids] for a in ids]), np.concatenate([bb[i] for i in ids]),
+            np.concatenate([x0[i] for i in ids]))
+
+
+# ------------------------------------------------------------------------------------------ oracle vs reference (CPU)
+def test_oracle_kinematics():
+    for i in range(G["kin_q"].shape[0]):
+        k = O.kin(G["kin_q"][i], float(G["kin_lc"][i]), RF)
+        for name in ("f", "J", "df_drho", "dJ_dq", "dJ_drho"):
+            np.testing.assert_allclose(k[name], G["kin_" + name][i], rtol=0, atol=1e-14)
+
+
+def test_oracle_preintegration(gwin):
+    w, cfg = gwin, O.default_config()
+    O.fill_preint(cfg, w)
+    np.testing.assert_allclose(w.preint[:, :33], G["preint"][:, :33], rtol=1e-12, atol=1e-14)          # state + linearisation point
+    np.testing.assert_allclose(w.preint[:, 33:994], G["preint"][:, 33:994], rtol=1e-10, atol=1e-12)    # jacobian
+    for k in range(w.F - 1):
+        cov = G["preint"][k, 994:]
+        np.testing.assert_allclose(w.preint[k, 994:], cov, rtol=1e-9, atol=1e-12 * np.abs(cov).max())
+    np.testing.assert_allclose(w.preint_imu, G["preint_imu"], rtol=1e-10, atol=1e-16)
+
+
+def test_oracle_imu_factors():
+    cfg = O.default_config()
+    for k in range(G["imu_params"].shape[0]):
+        P = _split(G["imu_params"][k], [7, 9, 4, 7, 9, 4])
+        r, J = O.eval_imu_leg(cfg, G["preint"][k], P)
+        Jr = G["imuleg_J"][k]
+        Jo = np.hstack(J)
+        np.testing.assert_allclose(r, G["imuleg_r"][k], rtol=0, atol=1e-6 * np.abs(G["imuleg_r"][k]).max())
+        np.testing.assert_allclose(Jo.T @ Jo, Jr.T @ Jr, rtol=0, atol=1e-6 * np.abs(Jr.T @ Jr).max())
+        ri, Ji = O.eval_imu(cfg, G["preint_imu"][k], [P[0], P[1], P[3], P[4]])
+        np.testing.assert_allclose(ri, G["imu_r"][k], rtol=0, atol=1e-7 * np.abs(G["imu_r"][k]).max())
+        np.testing.assert_allclose(np.hstack(Ji), G["imu_J"][k], rtol=0, atol=1e-7 * np.abs(G["imu_J"][k]).max())
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_oracle_projection(kind):
+    cfg = O.default_config()
+    for i in range(G["proj%d_obs" % kind].shape[0]):
+        P = _split(G["proj%d_params" % kind][i], PROJ_SIZES[kind])
+        r, J = O.eval_proj(kind, cfg, G["proj%d_obs" % kind][i], P)
+        np.testing.assert_allclose(r, G["proj%d_r" % kind][i], rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(np.hstack(J), G["proj%d_J" % kind][i], rtol=1e-11, atol=1e-9)
+
+
+def test_oracle_pose_plus_and_prior(gwin):
+    for i in range(G["plus_x"].shape[0]):
+        np.testing.assert_allclose(O.pose_plus(G["plus_x"][i], G["plus_d"][i]), G["plus_out"][i], rtol=0, atol=1e-15)
+    pr = gwin.prior
+    sizes = [pr.struct.block_size[k] for k in range(pr.struct.n_blocks)]
+    r, J = O.eval_prior(pr.struct, _split(G["prior_params"], sizes))
+    np.testing.assert_allclose(r, G["prior_r"], rtol=1e-12, atol=1e-12 * np.abs(G["prior_r"]).max())
+    np.testing.assert_allclose(np.hstack(J), G["prior_J"], rtol=0, atol=1e-13 * np.abs(G["prior_J"]).max())
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_oracle_marginalization(gwin, mode):
+    w, cfg = gwin, O.default_config()
+    w.preint[...] = G["preint"]
+    p = synth.PriorData()
+    assert O.marginalize(cfg, w, mode, p)[0] == 0
+    ids, H, b, x0 = _info_blocks(p)
+    tol = 1e-5 if mode == 0 else 1e-6    # eps * cond(Amm), see test_oracle_vs_reference.test_marginalization
+    np.testing.assert_array_equal(ids, G["marg%d_ids" % mode])
+    np.testing.assert_allclose(H, G["marg%d_H" % mode], rtol=0, atol=tol * np.abs(G["marg%d_H" % mode]).max())
+    np.testing.assert_allclose(b, G["marg%d_b" % mode], rtol=0, atol=tol * np.abs(G["marg%d_b" % mode]).max())
+    np.testing.assert_array_equal(x0, G["marg%d_x0" % mode])
+
+
+# ------------------------------------------------------------------------------------------ HIP path vs reference (GPU)
+@pytest.fixture(scope="module")
+def ctx(cfg):
+    from cerberus_amd import api
+    c = api.Context(cfg, 0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_preintegration_vs_reference(ctx, gwin):
+    w = gwin
+    ctx.preintegrate_window(w)
+    np.testing.assert_allclose(w.preint[:, :33], G["preint"][:, :33], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(w.preint[:, 33:994], G["preint"][:, 33:994], rtol=1e-9, atol=1e-11)
+    for k in range(w.F - 1):
+        cov = G["preint"][k, 994:]
+        np.testing.assert_allclose(w.preint[k, 994:], cov, rtol=1e-8, atol=1e-11 * np.abs(cov).max())
+    np.testing.assert_allclose(w.preint_imu, G["preint_imu"], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_gpu_imu_factors_vs_reference(ctx):
+    P = _split(G["imu_params"], [7, 9, 4, 7, 9, 4])
+    r, Js = ctx.eval_imu_leg(G["preint"], P)
+    for k in range(r.shape[0]):
+        Jg, Jr = np.hstack([J[k] for J in Js]), G["imuleg_J"][k]
+        assert _rel(r[k], G["imuleg_r"][k]) < 1e-6
+        assert _rel(Jg.T @ Jg, Jr.T @ Jr) < 1e-6
+        assert _rel(Jg.T @ r[k], Jr.T @ G["imuleg_r"][k]) < 1e-6
+    r, Js = ctx.eval_imu(G["preint_imu"], [P[0], P[1], P[3], P[4]])
+    for k in range(r.shape[0]):
+        assert _rel(r[k], G["imu_r"][k]) < 1e-7
+        assert _rel(np.hstack([J[k] for J in Js]), G["imu_J"][k]) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_gpu_projection_vs_reference(ctx, kind):
+    P = _split(G["proj%d_params" % kind], PROJ_SIZES[kind])
+    r, Js = ctx.eval_proj(kind, G["proj%d_obs" % kind], P)
+    np.testing.assert_allclose(r, G["proj%d_r" % kind], rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(np.concatenate(Js, axis=2), G["proj%d_J" % kind], rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_pose_plus_and_prior_vs_reference(ctx, gwin):
+    np.testing.assert_allclose(ctx.pose_plus(G["plus_x"], G["plus_d"]), G["plus_out"], rtol=0, atol=1e-15)
+    r, J = ctx.eval_prior(gwin.prior, G["prior_params"][None, :])
+    np.testing.assert_allclose(r[0], G["prior_r"], rtol=1e-12, atol=1e-12 * np.abs(G["prior_r"]).max())
+    np.testing.assert_allclose(J[0], G["prior_J"], rtol=0, atol=1e-13 * np.abs(G["prior_J"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gpu_marginalization_vs_reference(ctx, gwin, mode):
+    w = gwin
+    w.preint[...] = G["preint"]
+    p = synth.PriorData()
+    ctx.marginalize(w, mode, p)
+    ids, H, b, x0 = _info_blocks(p)
+    tol = 1e-5 if mode == 0 else 1e-6
+    np.testing.assert_array_equal(ids, G["marg%d_ids" % mode])
+    np.testing.assert_allclose(H, G["marg%d_H" % mode], rtol=0, atol=tol * np.abs(G["marg%d_H" % mode]).max())
+    np.testing.assert_allclose(b, G["marg%d_b" % mode], rtol=0, atol=tol * np.abs(G["marg%d_b" % mode]).max())
+    np.testing.assert_array_equal(x0, G["marg%d_x0" % mode])
