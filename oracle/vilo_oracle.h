@@ -9,9 +9,13 @@
  * (third-party, not vendored in the reference; pinned at .devcontainer/Dockerfile:69-83).
  *
  * PARITY STATUS: the reference ships no golden vectors / known-answer tests for this path
- * (SURVEY.md §8c). Factor-level math is pinned against the reference's own sources compiled
- * from /root/reference (oracle/_ref, see oracle/ref_build/); the Ceres trust-region
- * trajectory is "parity unpinned" (restated from the published algorithm only).
+ * (SURVEY.md §8c). Factor-level math (kinematics, both preintegrations, five factors, pose plus,
+ * Huber corrector, marginalisation Schur complement + prior factor) is PINNED against the
+ * reference's own sources compiled from /root/reference (oracle/_ref/libref.so, built by
+ * oracle/ref_build/; tests/test_oracle_vs_reference.py) and against the outputs frozen from that
+ * build (tests/golden/reference_vectors.npz; tests/test_golden.py). The Ceres trust-region
+ * trajectory (orc_solve_window) is "PARITY UNPINNED": restated from the published Ceres 1.14
+ * algorithm only, no Ceres build is available here.
  */
 #ifndef VILO_ORACLE_H
 #define VILO_ORACLE_H
