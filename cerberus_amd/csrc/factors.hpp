@@ -32,7 +32,9 @@ VD void proj_factor(const double *o, const double *pose_i, const double *pose_j,
   const quat qic = ldq_pose(ex0);
   const v3 pts_i_td = pts_i - vel_i * (td - td_i);
   const v3 pts_j_td = pts_j - vel_j * (td - td_j);
-  const v3 pts_camera_i = mk3(pts_i_td.x / inv_dep, pts_i_td.y / inv_dep, pts_i_td.z / inv_dep);
+  // one FP64 division each for 1/lambda and 1/z (a v_div sequence is ~20 instructions); products of reciprocals elsewhere
+  const double inv_lam = 1.0 / inv_dep;
+  const v3 pts_camera_i = mk3(pts_i_td.x * inv_lam, pts_i_td.y * inv_lam, pts_i_td.z * inv_lam);
   const v3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
   v3 pts_imu_j, pts_camera_j;
   v3 Pi = mk3(0, 0, 0), Pj = Pi, tic2 = Pi;
@@ -48,13 +50,14 @@ VD void proj_factor(const double *o, const double *pose_i, const double *pose_j,
     pts_imu_j = qrot(qinv(Qj), pts_w - Pj);
     pts_camera_j = (KIND == 0) ? qrot(qinv(qic), pts_imu_j - tic) : qrot(qinv(qic2), pts_imu_j - tic2);
   }
-  const double dep_j = pts_camera_j.z;
-  r[0] = sq * (pts_camera_j.x / dep_j - pts_j_td.x);
-  r[1] = sq * (pts_camera_j.y / dep_j - pts_j_td.y);
+  const double inv_z = 1.0 / pts_camera_j.z;
+  r[0] = sq * (pts_camera_j.x * inv_z - pts_j_td.x);
+  r[1] = sq * (pts_camera_j.y * inv_z - pts_j_td.y);
   if (!want_jac) return;
 
   // reduce = sqrt_info * [1/z 0 -x/z^2; 0 1/z -y/z^2]
-  const double r00 = sq / dep_j, r02 = -sq * pts_camera_j.x / (dep_j * dep_j), r12 = -sq * pts_camera_j.y / (dep_j * dep_j);
+  const double r00 = sq * inv_z, r02 = -r00 * pts_camera_j.x * inv_z, r12 = -r00 * pts_camera_j.y * inv_z;
+  const double il2 = -(inv_lam * inv_lam), nil = -inv_lam;
   // out(2x3) = reduce * M(3x3): row0 = r00*M.row0 + r02*M.row2 ; row1 = r00*M.row1 + r12*M.row2
   auto red3 = [&](const m3 &M, double *dst, int stride, int c0) {
     for (int c = 0; c < 3; ++c) {
@@ -79,10 +82,8 @@ VD void proj_factor(const double *o, const double *pose_i, const double *pose_j,
     red3(tr(ric) * (tr(Rj) * Ri - m3_eye()), J_e0, 6, 0);
     red3(-(tmp_r * skew(pts_camera_i)) + skew(tmp_r * pts_camera_i) + skew(tr(ric) * (tr(Rj) * (Ri * tic + Pi - Pj) - tic)), J_e0,
          6, 3);
-    v3 jl = (tmp_r * pts_i_td) * -1.0;
-    redv(mk3(jl.x / (inv_dep * inv_dep), jl.y / (inv_dep * inv_dep), jl.z / (inv_dep * inv_dep)), J_l);
-    v3 jt = tmp_r * vel_i;
-    redv(mk3(jt.x / inv_dep * -1.0, jt.y / inv_dep * -1.0, jt.z / inv_dep * -1.0), J_td);
+    redv((tmp_r * pts_i_td) * il2, J_l);
+    redv((tmp_r * vel_i) * nil, J_td);
     J_td[0] += sq * vel_j.x;
     J_td[1] += sq * vel_j.y;
   } else if (KIND == 1) {
@@ -98,10 +99,8 @@ VD void proj_factor(const double *o, const double *pose_i, const double *pose_j,
     red3(ARiric * (-skew(pts_camera_i)), J_e0, 6, 3);
     red3(-tr(ric2), J_e1, 6, 0);
     red3(skew(pts_camera_j), J_e1, 6, 3);
-    v3 jl = (ARiric * pts_i_td) * -1.0;
-    redv(mk3(jl.x / (inv_dep * inv_dep), jl.y / (inv_dep * inv_dep), jl.z / (inv_dep * inv_dep)), J_l);
-    v3 jt = ARiric * vel_i;
-    redv(mk3(jt.x / inv_dep * -1.0, jt.y / inv_dep * -1.0, jt.z / inv_dep * -1.0), J_td);
+    redv((ARiric * pts_i_td) * il2, J_l);
+    redv((ARiric * vel_i) * nil, J_td);
     J_td[0] += sq * vel_j.x;
     J_td[1] += sq * vel_j.y;
   } else {
@@ -112,10 +111,8 @@ VD void proj_factor(const double *o, const double *pose_i, const double *pose_j,
     red3(-tr(ric2), J_e1, 6, 0);
     red3(skew(pts_camera_j), J_e1, 6, 3);
     // NB pts_i, not pts_i_td (projectionOneFrameTwoCamFactor.cpp:119)
-    v3 jl = (A * pts_i) * -1.0;
-    redv(mk3(jl.x / (inv_dep * inv_dep), jl.y / (inv_dep * inv_dep), jl.z / (inv_dep * inv_dep)), J_l);
-    v3 jt = A * vel_i;
-    redv(mk3(jt.x / inv_dep * -1.0, jt.y / inv_dep * -1.0, jt.z / inv_dep * -1.0), J_td);
+    redv((A * pts_i) * il2, J_l);
+    redv((A * vel_i) * nil, J_td);
     J_td[0] += sq * vel_j.x;
     J_td[1] += sq * vel_j.y;
   }

@@ -6,7 +6,9 @@
 //                       Projection*Factor residual blocks + Huber corrector in registers, reduces the landmark's
 //                       1x1 Hessian / gradient / camera coupling row in registers, and forms the camera-side Gram
 //                       blocks of every (start, t) pair through an LDS-staged wave reduction.
-//   k_imu_linearize     one wave per IMULegFactor: raw Jacobian in LDS, whitened by the hoisted sqrt_info.
+//   k_imu_raw           one thread per IMULegFactor: raw residual + 31x38 Jacobian (structural non-zeros only).
+//   k_imu_whiten        one wave per IMULegFactor: whitening by the hoisted sqrt_info and the factor's 39x39 Gram, both
+//                       on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).
 //   k_build_solve       one workgroup per window, everything LDS-resident: assembles the block-arrow camera system
 //                       (dense 80x80 pose/extrinsic/td part + block-tridiagonal speed-bias/leg-bias part), Jacobi
 //                       scaling, dogleg quantities, landmark Schur complement, block elimination, dense Cholesky,
@@ -81,35 +83,42 @@ __device__ double block_max(double v, double *red) {
 // =================================================================================================
 // k_visual_linearize
 // =================================================================================================
-#define XLANE 53  // LDS stride per lane: 2 rows x 26 cols + 1 pad (conflict-free ds_write_b64)
+#define XLANE 54  // LDS stride per lane: 2 rows x 26 cols + 2 pad; even so that every row starts 16-byte aligned (ds_read_b128)
 
 __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) {
-  __shared__ double X[64 * XLANE + 16];
+  __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
   const ChunkMeta cm = b.chunk[blockIdx.x];
-  const SolverState &st = b.st[cm.win];
+  SolverState &st = b.st[cm.win];
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[cm.win];
   const int lane = threadIdx.x;
   const bool active = lane < cm.n;
   const int n = cm.n, L = wm.L, s = cm.s;
+  const bool prof = (blockIdx.x == (unsigned)wm.chunk_off) && lane == 0;
+  long long c_proj = 0, c_gram = 0, c_t0 = clock64(), c_a = 0;
   const double *x = b.x + (size_t)cm.win * XSTRIDE;
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
   const int li = cm.lm_local + lane;
 
-  // Gram ownership: lane owns one segment (a, b0 .. b0+len-1) of the packed upper triangle (62 segments of <= 7)
-  int seg_a = 0, seg_b0 = 0, seg_len = 0;
+  // Gram ownership: lane owns one 8-wide segment (row a, columns b0 .. b0+7) of the upper triangle, b0 even so that the
+  // segment is read with four ds_read_b128 (which reach full LDS rate from one wave per SIMD; ds_read_b64 reaches a
+  // fifth). 56 segments cover the 351 entries; the few columns left of the diagonal / right of column 25 are computed
+  // and dropped.
+  int seg_a = 0, seg_b0 = 0;
+  bool seg_on = false;
   {
     int cnt = 0;
     for (int a = 0; a < 26; ++a) {
-      const int len = 26 - a, nseg = (len + 6) / 7;
+      const int bs = a & ~1, nseg = (26 - bs + 7) / 8;
       for (int q = 0; q < nseg; ++q) {
-        if (cnt == lane) { seg_a = a; seg_b0 = a + 7 * q; seg_len = min(7, 26 - seg_b0); }
+        if (cnt == lane) { seg_a = a; seg_b0 = bs + 8 * q; seg_on = true; }
         ++cnt;
       }
     }
   }
   if (active)
     for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
+  for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
 
   const double *obs = b.obs + cm.obs_off;
   const unsigned char *flg = b.flags + cm.flag_off;
@@ -127,13 +136,31 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   double wc_s[6], wc_e0[6], wc_e1[6], wc_td = 0.0;
   for (int c = 0; c < 6; ++c) wc_s[c] = wc_e0[c] = wc_e1[c] = 0.0;
 
+  // observations of frame t are fetched one iteration ahead (11 coalesced loads in flight behind the previous frame's
+  // factor evaluation and Gram pass; the barriers below are LDS-only and do not drain them)
+  double on[11];
+  unsigned char fl_next = 0;
+  for (int c = 0; c < 11; ++c) on[c] = 0.0;
+  if (active) {
+    fl_next = flg[lane];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) on[c] = obs[(size_t)c * n + lane];
+  }
   for (int t = 0; t < cm.kmax; ++t) {
     const int j = s + t;
-    const unsigned char fl = active ? flg[(size_t)t * n + lane] : 0;
+    const unsigned char fl = fl_next;
     const double *pose_j = x + XO_POSE + 7 * j;
-    const double *ob = obs + (size_t)t * 11 * n;
-    double acc[7];
-    for (int m = 0; m < 7; ++m) acc[m] = 0.0;
+    double ob[11];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) ob[c] = on[c];
+    if (active && t + 1 < cm.kmax) {
+      fl_next = flg[(size_t)(t + 1) * n + lane];
+      const double *obn = obs + (size_t)(t + 1) * 11 * n;
+#pragma unroll
+      for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
+    }
+    double acc[8];
+    for (int m = 0; m < 8; ++m) acc[m] = 0.0;
     double wj[6];
     for (int c = 0; c < 6; ++c) wj[c] = 0.0;
 
@@ -141,17 +168,13 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
       const bool produce = (fl & 1) && (cam == 0 || (fl & 2));
       double *xr0 = &X[lane * XLANE], *xr1 = xr0 + 26;
+      c_a = clock64();
       if (produce) {
         double r[2], Ji[12], Jj[12], Je0[12], Je1[12], Jl[2], Jt[2];
         for (int c = 0; c < 12; ++c) Ji[c] = Jj[c] = Je0[c] = Je1[c] = 0.0;
-        if (cam == 0) {
-          o12[3] = ob[(size_t)0 * n + lane]; o12[4] = ob[(size_t)1 * n + lane]; o12[5] = ob[(size_t)2 * n + lane];
-          o12[8] = ob[(size_t)6 * n + lane]; o12[9] = ob[(size_t)7 * n + lane];
-        } else {
-          o12[3] = ob[(size_t)3 * n + lane]; o12[4] = ob[(size_t)4 * n + lane]; o12[5] = ob[(size_t)5 * n + lane];
-          o12[8] = ob[(size_t)8 * n + lane]; o12[9] = ob[(size_t)9 * n + lane];
-        }
-        o12[11] = ob[(size_t)10 * n + lane];
+        if (cam == 0) { o12[3] = ob[0]; o12[4] = ob[1]; o12[5] = ob[2]; o12[8] = ob[6]; o12[9] = ob[7]; }
+        else { o12[3] = ob[3]; o12[4] = ob[4]; o12[5] = ob[5]; o12[8] = ob[8]; o12[9] = ob[9]; }
+        o12[11] = ob[10];
         if (cam == 0) proj_factor<0>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
         else if (t > 0) proj_factor<1>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
         else proj_factor<2>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
@@ -188,17 +211,52 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
       } else {
         for (int c = 0; c < 26; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
       }
-      __syncthreads();
-      for (int row = 0; row < 2 * n; ++row) {
-        const int base = (row >> 1) * XLANE + (row & 1) * 26;
-        const double xa = X[base + seg_a];
+      lds_barrier();
+      { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
+      // rows of lanes >= n are zero (those lanes store zeros above) and the pad rows behind lane 63 are zeroed once, so
+      // the row count is rounded up to 8; software pipeline: the LDS reads of the next 4 rows are in flight while the
+      // FMAs of the current 4 rows issue
+      const int nrows = (2 * n + 7) & ~7;
+      double xa0[4], xa1[4];
+      double2 xb0[4][4], xb1[4][4];
+      auto ld4 = [&](int row, double *xa, double2 (*xb)[4]) {
 #pragma unroll
-        for (int m = 0; m < 7; ++m) acc[m] += xa * X[base + seg_b0 + m];
+        for (int u = 0; u < 4; ++u) {
+          const int base = ((row + u) >> 1) * XLANE + ((row + u) & 1) * 26;
+          xa[u] = X[base + seg_a];
+          const double2 *p = reinterpret_cast<const double2 *>(&X[base + seg_b0]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xb[u][i] = p[i];
+        }
+      };
+      auto fma4 = [&](const double *xa, const double2 (*xb)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc[2 * i] += xa[u] * xb[u][i].x; acc[2 * i + 1] += xa[u] * xb[u][i].y; }
+      };
+      ld4(0, xa0, xb0);
+      for (int row = 0; row < nrows; row += 8) {
+        ld4(row + 4, xa1, xb1);
+        fma4(xa0, xb0);
+        ld4(row + 8, xa0, xb0);   // rows 128 .. 135 are the zero pad
+        fma4(xa1, xb1);
+        // pin the issue order (the scheduler otherwise hoists all 36 reads above the 64 FMAs and waits for all of them):
+        // 18 LDS reads (16 b128 + 2 read2_b64) in flight behind each group of 32 FMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
       }
-      __syncthreads();
+      lds_barrier();
+      c_gram += clock64() - c_a;
     }
     double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
-    for (int m = 0; m < seg_len; ++m) gs[tri26(seg_a, seg_b0 + m)] = acc[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int bc = seg_b0 + m;
+      if (seg_on && bc >= seg_a && bc < 26) gs[tri26(seg_a, bc)] = acc[m];
+    }
     if (active && t > 0 && (fl & 1))
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
   }
@@ -214,6 +272,7 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   }
   const double csum = wave_sum(active ? cost : 0.0);
   if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
+  if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = cm.n; st.phase_clk[20] = cm.kmax; }
 }
 
 // Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
@@ -273,57 +332,111 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
 // IMU-leg factors
 // =================================================================================================
 #define IMU_LIN_STRIDE (31 * 39)
+__device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
+#define IMU_NTRI 496   // upper triangle of the 31 x 31 sqrt_info
 
-__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm) {
-  __shared__ double Jraw[31 * 38];
-  __shared__ double rraw[31];
-  __shared__ double U[31 * 31];
-  const int win = blockIdx.x / 10, k = blockIdx.x % 10;
-  const SolverState &st = b.st[win];
-  if (st.done || !st.need_lin) return;
-  const int lane = threadIdx.x;
-  const PreintPrepared &pp = b.prep[(size_t)win * 10 + k];
-  for (int e = lane; e < 31 * 38; e += 64) Jraw[e] = 0.0;
-  for (int e = lane; e < 31 * 31; e += 64) U[e] = pp.sqrt_info[e];
-  __syncthreads();
-  if (lane == 0) {
-    const double *x = b.x + (size_t)win * XSTRIDE;
-    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), rraw, true, Jraw, 38);
-  }
-  __syncthreads();
-  __shared__ double Jw[31 * 39];
-  double *out = b.imu_lin + ((size_t)win * 10 + k) * IMU_LIN_STRIDE;
-  for (int e = lane; e < 31 * 39; e += 64) {
-    const int i = e / 39, c = e % 39;
-    double sacc = 0.0;
-    // sqrt_info is upper triangular: only q >= i contributes (zeros below the diagonal are stored explicitly)
-    if (c < 38) {
-#pragma unroll
-      for (int q = 0; q < 31; ++q) sacc += (q >= i ? U[i * 31 + q] : 0.0) * Jraw[q * 38 + c];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 31; ++q) sacc += (q >= i ? U[i * 31 + q] : 0.0) * rraw[q];
-    }
-    out[e] = sacc;
-    Jw[e] = sacc;
-  }
-  __syncthreads();
-  // Gram of [Jw | rw] (39 x 39, packed upper triangle): J^T J, J^T r and r^T r of this factor
-  double *gout = b.imu_gram + ((size_t)win * 10 + k) * 780;
-  for (int e = lane; e < 780; e += 64) {
-    const int a = tri_row(e, 39), bc = a + (e - (a * (79 - a)) / 2);
-    double sacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 31; ++i) sacc += Jw[i * 39 + a] * Jw[i * 39 + bc];
-    gout[e] = sacc;
-  }
-}
-
-// residual-only at the candidate: one thread per factor
-__global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int init_mode) {
+// Stage 1 of the IMULegFactor linearisation: one THREAD per factor evaluates the raw residual and the 31 x 38 local
+// Jacobian (imu_leg_factor.cpp:173-386 before whitening). The code is a long scalar dependency chain, so lanes = factors
+// gives 64-way SIMD instead of one busy lane per wave. Only the structural non-zeros of [J | r] (31 x 39, row-major in
+// b.imu_raw) are written; the zeros are set once when the batch is created.
+__global__ void __launch_bounds__(64) k_imu_raw(BatchDev b, double g_norm) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= b.W * 10) return;
+  const int win = f / 10, k = f % 10;
+  const SolverState &st = b.st[win];
+  if (st.done || !st.need_lin) return;
+  const PreintPrepared &pp = b.prep[f];
+  const double *x = b.x + (size_t)win * XSTRIDE;
+  double *raw = b.imu_raw + (size_t)f * IMU_LIN_STRIDE;
+  double r[31];
+  imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+              x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, raw, 39);
+#pragma unroll
+  for (int i = 0; i < 31; ++i) raw[i * 39 + 38] = r[i];
+}
+
+// Stage 2: one wave per factor, both products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   whitening  Jw = U [J | r]      (U = sqrt_info, upper triangular 31 x 31; 32 x 48 x 32 padded, zero blocks skipped)
+//   Gram       G  = Jw^T Jw        (39 x 39, the factor's J^T J, J^T r and r^T r; upper tiles only)
+// Operand layout of the instruction: A(16 x 4): lane l holds A[l % 16][l / 16]; B(4 x 16): lane l holds B[l / 16][l % 16];
+// C/D(16 x 16): register r of lane l is C[(l / 16) + 4 r][l % 16].
+#define IW_JS 48   // LDS row stride of Jw (conflict-free operand reads of the Gram pass)
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) k_imu_whiten(BatchDev b) {
+  __shared__ double Jw[32 * IW_JS];
+  const int f = blockIdx.x, win = f / 10;
+  SolverState &st = b.st[win];
+  if (st.done || !st.need_lin) return;
+  const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+  const bool prof = (f % 10 == 0 && lane == 0);
+  const long long c0 = clock64();
+  const double *U = b.prep[f].sqrt_info;
+  const double *raw = b.imu_raw + (size_t)f * IMU_LIN_STRIDE;
+  // MFMA operands straight from global memory: 12 A values (U tiles) and 24 B values ([J | r] tiles) per lane, all
+  // loads independent and issued before the first MFMA (one memory round trip, no LDS staging of the inputs)
+  double av[2][8], bv[8][3];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int row = 16 * I + lr, q = 4 * kk + lk;
+      av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
+    }
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      const int q = 4 * kk + lk, col = 16 * J + lr;
+      bv[kk][J] = (q < 31 && col < 39) ? raw[q * 39 + col] : 0.0;
+    }
+  const long long c1 = clock64();
+  double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
+#pragma unroll
+  for (int I = 0; I < 2; ++I) {
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = (I == 0 ? 0 : 4); kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I][kk], bv[kk][J], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + lk + 4 * r, col = 16 * J + lr;
+        Jw[row * IW_JS + col] = acc[r];   // padding rows / columns come out as exact zeros
+        if (row < 31 && col < 39) out[row * 39 + col] = acc[r];
+      }
+    }
+  }
+  lds_barrier();
+  const long long c2 = clock64();
+  double *gout = b.imu_gram + (size_t)f * 780;
+#pragma unroll
+  for (int I = 0; I < 3; ++I) {
+#pragma unroll
+    for (int J = I; J < 3; ++J) {
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const double av = Jw[(4 * kk + lk) * IW_JS + 16 * I + lr];
+        const double bv = Jw[(4 * kk + lk) * IW_JS + 16 * J + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * I + lk + 4 * r, bc = 16 * J + lr;
+        if (a <= bc && bc < 39) gout[tri39(a, bc)] = acc[r];
+      }
+    }
+  }
+  if (prof) { const long long c3 = clock64(); st.phase_clk[24] = c1 - c0; st.phase_clk[25] = c2 - c1; st.phase_clk[26] = c3 - c2; }
+}
+
+// residual-only at the candidate: one thread per factor; sqrt_info is read from its entry-major transpose
+// (b.sqrtT[e][factor], coalesced across the lanes of a wave)
+__global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int init_mode) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NF = b.W * 10;
+  if (f >= NF) return;
   const int win = f / 10, k = f % 10;
   const SolverState &st = b.st[win];
   if (st.done || (!init_mode && !st.step_valid)) return;
@@ -332,13 +445,32 @@ __global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int 
   double r[31];
   imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
               x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
+  const double *ut = b.sqrtT + f;
   double c = 0.0;
+  int e = 0;
+#pragma unroll
   for (int i = 0; i < 31; ++i) {
     double sacc = 0.0;
-    for (int q = i; q < 31; ++q) sacc += pp.sqrt_info[i * 31 + q] * r[q];
+#pragma unroll
+    for (int q = i; q < 31; ++q) { sacc += ut[(size_t)e * NF] * r[q]; ++e; }
     c += sacc * sacc;
   }
   b.imu_cost[f] = c;
+}
+
+// entry-major transpose of the upper triangles of sqrt_info (once per batch)
+__global__ void k_sqrt_transpose(BatchDev b) {
+  const int f = blockIdx.x, NF = b.W * 10;
+  const PreintPrepared &pp = b.prep[f];
+  for (int e = threadIdx.x; e < 31 * 31; e += blockDim.x) {
+    const int i = e / 31, q = e - 31 * i;
+    if (q >= i) b.sqrtT[(size_t)(i * 31 - (i * (i - 1)) / 2 + (q - i)) * NF + f] = pp.sqrt_info[e];
+  }
+}
+int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b) {
+  hipLaunchKernelGGL(k_sqrt_transpose, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
 }
 
 // =================================================================================================
@@ -383,7 +515,6 @@ __device__ __forceinline__ int imu_col_cd(int k, int c) {
   if (c < 25) return 6 * (k + 1) + (c - 19);
   return CD_B0 + 13 * (k + 1) + (c - 25);
 }
-__device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
 
 #define SOLVE_THREADS 256
 #define CLD 81   // leading dimension of the 80x80 pose system in LDS (odd: conflict-free row and column walks)
@@ -1211,8 +1342,11 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     P0(0);
     hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha);
     P1();
+    P0(7);
+    hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn);
+    P1();
     P0(1);
-    hipLaunchKernelGGL(k_imu_linearize, dim3(W * 10), dim3(64), 0, s, b, gn);
+    hipLaunchKernelGGL(k_imu_whiten, dim3(W * 10), dim3(64), 0, s, b);
     P1();
     P0(2);
     hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
@@ -1236,7 +1370,8 @@ int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4);
   hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, ctx->stream, b, sq, ha);
-  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, gn);
+  hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn);
+  hipLaunchKernelGGL(k_imu_whiten, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

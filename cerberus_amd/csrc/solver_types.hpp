@@ -71,7 +71,7 @@ struct SolverState {
   int pad[3];
   double cost_trace[64];
   double radius_trace[64];
-  long long phase_clk[16];   // shader-clock stamps of k_build_solve phases (last linearisation), profiling aid
+  long long phase_clk[32];   // shader-clock stamps (last linearisation), profiling aid: 0..12 k_build_solve, 16..21 k_visual_linearize (first chunk), 24..27 k_imu_linearize (k = 0)
 };
 
 struct BatchDev {
@@ -91,6 +91,8 @@ struct BatchDev {
   double *chunk_cost;         // [n_chunks]
   // IMU factors
   PreintPrepared *prep;       // [W][10]
+  double *imu_raw;            // [W][10][31*39]  raw J (31x38) | raw r; zeros written once, non-zeros per linearisation
+  double *sqrtT;              // [496][W*10]     upper triangles of sqrt_info, entry-major (coalesced per-thread reads)
   double *imu_lin;            // [W][10][31*39]  whitened J (31x38) | whitened r (col 38)
   double *imu_gram;           // [W][10][780]    packed upper triangle of [J | r]^T [J | r]
   double *imu_cost;           // [W][10]

@@ -220,6 +220,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_alloc(ctx, bt, &D.chunk_cost, chunks.size()));
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
   TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
+  TRYB(dev_alloc(ctx, bt, &D.imu_raw, (size_t)W * 10 * 31 * 39));
+  TRYB(dev_alloc(ctx, bt, &D.sqrtT, (size_t)W * 10 * 496));
+  if (hipMemset(D.imu_raw, 0, sizeof(double) * (size_t)W * 10 * 31 * 39) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
   TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
@@ -253,6 +256,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     int rc = VILO_OK;
     if (hipMemcpy(d_pre, pre.data(), sizeof(vilo_preint) * (size_t)W * 10, hipMemcpyHostToDevice) != hipSuccess) rc = VILO_ERR_HIP;
     if (rc == VILO_OK) rc = vilo_launch_prepare_preint(ctx, W * 10, d_pre, D.prep, D.status);
+    if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
     if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
     (void)hipFree(d_pre);
     if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
@@ -371,7 +375,7 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
     case 8: src = bt->d.lm_y + wm.lm_off; n = wm.L; break;
     case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
     case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
-    case 12: src = (const double *)(bt->d.st + win) + 24 + 128; n = 16; break;   // phase_clk (int64 bit patterns)
+    case 12: src = (const double *)(bt->d.st + win) + 24 + 128; n = 32; break;   // phase_clk (int64 bit patterns)
     case 11: {
       n = wm.L;
       if ((int)n > max_n) return VILO_ERR_BAD_ARG;

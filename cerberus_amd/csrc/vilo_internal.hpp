@@ -34,7 +34,7 @@ struct vilo_ctx {
   double kernel_ms[8];
   long long kernel_launches[8];
 };
-#define VILO_NKERNEL 7
+#define VILO_NKERNEL 8
 
 
 #define VILO_HIP(call)                                                                                   \
@@ -72,3 +72,5 @@ static_assert(sizeof(PreintPrepared) == 8 * 1087, "SURVEY 8(d): 1087 doubles per
 // kernels_eval.hip
 int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status);
 int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status);
+struct BatchDev;
+int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b);
