@@ -563,6 +563,59 @@ __device__ int chol13_wave(const double *A, double *Lout) {
   return fail;
 }
 
+// 16x16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80x80 factorisation).
+// A: LDS 16x17 row-major in. Lane i (< 16) owns row i of L in registers; pivots broadcast with v_readlane.
+// Writes L (lower, incl. diagonal, zeros above) to Ldst (leading dimension ldl) and L^-1 (lower) to Linv (16x17).
+// Returns 0 ok / 1 not positive definite (pivot index + 1 in *bad when given).
+__device__ int chol16_wave(const double *A, double *Ldst, int ldl, double *Linv) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane & 15;
+  double a[16], l[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a[j] = A[row * 17 + j]; l[j] = 0.0; }
+  int fail = 0;
+  double myrinv = 1.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double s = a[j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) s -= l[q] * readlane_d(l[q], j);
+    double piv = readlane_d(s, j);
+    if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+    const double rinv = rsqrt(piv), ljj = piv * rinv;
+    l[j] = (lane == j) ? ljj : (lane > j ? s * rinv : 0.0);
+    if (lane == j) myrinv = rinv;
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Ldst[lane * ldl + j] = l[j];
+  }
+  // column c = lane of L^-1 by forward substitution; L(i, q) is register l[q] of lane i
+  double cl[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double v = (i == row) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < i; ++q) v -= readlane_d(l[q], i) * cl[q];
+    cl[i] = v * readlane_d(myrinv, i);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Linv[i * 17 + lane] = (i >= lane) ? cl[i] : 0.0;
+  }
+  return fail;
+}
+
+// The symmetric 80 x 80 pose system as 15 lower 16 x 16 tiles (I >= J) held in FP64-MFMA accumulators: wave w owns
+// tiles w, w + 4, w + 8, w + 12 of this list; register r of lane l of a tile is element (16 I + l / 16 + 4 r, 16 J + l % 16).
+// The tile list is compile-time per wave (WAVE_DISPATCH instantiates each tile phase once per wave index), so operand
+// selection and accumulator indexing are static and the accumulators stay in registers across the phases.
+__device__ constexpr int c_tileI[16] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 0};
+__device__ constexpr int c_tileJ[16] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0};
+template <int N> struct IC { static constexpr int value = N; };
+#define WAVE_DISPATCH(fn) do { if (wv == 0) fn(IC<0>{}); else if (wv == 1) fn(IC<1>{}); else if (wv == 2) fn(IC<2>{}); else fn(IC<3>{}); } while (0)
+#define NTILE(WV) ((WV) == 3 ? 3 : 4)
+
 __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ unsigned short tab26[352], tab39[784], slot_st[512];
@@ -572,6 +625,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
   SolverState &st = b.st[win];
   if (st.done) return;
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = tid & 15, lk = (tid >> 4) & 3;   // wave (uniform), MFMA lane coordinates
   const WinMeta wm = b.win[win];
   double *C = lds + LDS_C, *Ad = lds + LDS_AD, *Ao = lds + LDS_AO, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y;
   double *tmp = lds + LDS_TMP, *act = lds + LDS_ACT, *Lk = lds + LDS_LK, *S = lds + LDS_S, *red = lds + LDS_RED, *col = lds + LDS_COL;
@@ -774,15 +828,21 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       for (int e = tid; e < CD_N; e += SOLVE_THREADS)
         if (act[e] == 0.0) g[e] = 0.0;
       __syncthreads();
-      double Cr[5][5];
+      mfma_d4 acc[4];
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
+      for (int sl = 0; sl < 4; ++sl) acc[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      auto tile_load = [&](auto W_) {
+        constexpr int WV = decltype(W_)::value;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) Cr[r][c] = C[(ty + 16 * r) * CLD + tx + 16 * c];
-      if (ty == tx) {
+        for (int sl = 0; sl < NTILE(WV); ++sl) {
+          constexpr int dummy = 0; (void)dummy;
+          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) y[ty + 16 * r] = Cr[r][r];
-      }
+          for (int r = 0; r < 4; ++r) acc[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+        }
+      };
+      WAVE_DISPATCH(tile_load);
+      if (tid < 80) y[tid] = C[tid * CLD + tid];
       __syncthreads();
       if (tid == 0) st.phase_clk[4] = clock64();
       // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
@@ -809,15 +869,17 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         part_gn += g[cd] * tmp[cd];
         part_gmax = fmax(part_gmax, fabs(g[cd]));
       }
-      {
-        double vr[5], vc[5];
+      auto tile_q = [&](auto W_) {
+        constexpr int WV = decltype(W_)::value;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { vr[r] = tmp[ty + 16 * r]; vc[r] = tmp[tx + 16 * r]; }
+        for (int sl = 0; sl < NTILE(WV); ++sl) {
+          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+          const double vc = tmp[16 * J + lr], sym = (I == J) ? 1.0 : 2.0;
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-          for (int c = 0; c < 5; ++c) part_q += vr[r] * Cr[r][c] * vc[c];
-      }
+          for (int r = 0; r < 4; ++r) part_q += sym * tmp[16 * I + lk + 4 * r] * acc[sl][r] * vc;
+        }
+      };
+      WAVE_DISPATCH(tile_q);
       if (tid >= 96 && tid < 96 + 143) {
         const int e = tid - 96, k = e / 13, i = e % 13;
         if (k < F) {
@@ -848,61 +910,79 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
         lm_dh2[l] = d2;
         const double vl = gl / d2;
-        double tl = 0.0;
-#pragma unroll 16
-        for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * tmp[a];
-        part_q += 2.0 * vl * tl + E * vl * vl;
+        part_q += E * vl * vl;   // the cross term 2 vl w_l^T v is accumulated in the Schur pass below
+        lm_y[l] = vl;            // (scratch until the back-substitution overwrites it)
         part_gn += gl * vl;
         part_gmax = fmax(part_gmax, fabs(gl));
         lm_einv[l] = 1.0 / (E + mu * d2);
       }
       const double gnorm2 = block_sum(part_gn, red);
-      const double qq = block_sum(part_q, red);
       const double gmax = block_max(part_gmax, red);
       if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
         if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
         return;
       }
       if (tid == 0) st.phase_clk[5] = clock64();
-      // (the 80x80 pose system already lives in registers: thread (ty, tx) owns C(ty + 16 r, tx + 16 c))
-      // Schur complement of the landmarks: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2), rhs_P -= sum_l w_l g_l / (...)
-      if (tid < 80) y[tid] = 0.0;
-      __syncthreads();
-      for (int l0 = 0; l0 < L; l0 += 32) {
-        const int nl = min(32, L - l0);
-        for (int e = tid; e < 80 * 32; e += SOLVE_THREADS) {
-          const int a = e >> 5, q = e & 31;    // global read: consecutive q (landmarks) are contiguous
-          S[q * 81 + a] = (q < nl && a < VILO_NPU) ? wl[(size_t)a * L + l0 + q] * act[a] : 0.0;
-        }
-        if (tid < 32) {
-          S[2600 + tid] = (tid < nl) ? lm_einv[l0 + tid] : 0.0;
-          S[2640 + tid] = (tid < nl) ? lm_g[l0 + tid] * lm_einv[l0 + tid] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int q = 0; q < 32; ++q) {
-          const double ei = S[2600 + q];
-          double wr[5], wc[5];
+      // Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One k-step =
+      // 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles (X, .) and as B of
+      // tiles (., X), so a wave issues 5 coalesced-by-row global loads and up to 4 MFMAs per k-step and never touches LDS.
+      // The same operands give rhs_P -= sum_l w_l g_l / (...) and the 2 vl w_l^T v term of q (tile row X = wave, wave 0 also 4).
+      __syncthreads();   // lm_einv / lm_dh2 written above are read through global memory below
+      double actv[5], vv[5], yacc0 = 0.0, yacc1 = 0.0, qacc = 0.0;
 #pragma unroll
-          for (int r = 0; r < 5; ++r) { wr[r] = S[q * 81 + ty + 16 * r] * ei; wc[r] = S[q * 81 + tx + 16 * r]; }
+      for (int X = 0; X < 5; ++X) { actv[X] = act[16 * X + lr]; vv[X] = tmp[16 * X + lr]; }
+      const int nks = (L + 3) >> 2;
+      auto tile_schur = [&](auto W_) {
+        constexpr int WV = decltype(W_)::value;
+        for (int kk0 = 0; kk0 < nks; kk0 += 4) {
+          // 4 k-steps (16 landmarks) per trip: all 32 loads are issued before the first MFMA; landmarks past L are clamped
+          // to a valid address and masked through their 1 / (E + mu d2) factor
+          double opb[4][5], eb[4], gb[4], db[4];
 #pragma unroll
-          for (int r = 0; r < 5; ++r)
+          for (int u = 0; u < 4; ++u) {
+            const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
+            eb[u] = lm_einv[lc]; gb[u] = lm_g[lc]; db[u] = lm_y[lc];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) Cr[r][c] -= wr[r] * wc[c];
+            for (int X = 0; X < 5; ++X) opb[u][X] = wl[(size_t)(16 * X + lr) * L + lc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = 4 * (kk0 + u) + lk;
+            const double ei = (l < L) ? eb[u] : 0.0, ge = gb[u] * ei, vl = (l < L) ? db[u] : 0.0;
+            double op[5];
+#pragma unroll
+            for (int X = 0; X < 5; ++X) op[X] = opb[u][X] * actv[X];
+#pragma unroll
+            for (int sl = 0; sl < NTILE(WV); ++sl) {
+              const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+              acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc[sl], 0, 0, 0);
+            }
+            yacc0 += op[WV] * ge; qacc += op[WV] * vv[WV] * vl;
+            if (WV == 0) { yacc1 += op[4] * ge; qacc += op[4] * vv[4] * vl; }
+          }
         }
-        if (tid < 80) {
-          double sacc = 0.0;
-          for (int q = 0; q < 32; ++q) sacc += S[q * 81 + tid] * S[2640 + q];
-          y[tid] += sacc;
-        }
-        __syncthreads();
-      }
+      };
+      WAVE_DISPATCH(tile_schur);
+      part_q += 2.0 * qacc;
+      yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
+      yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
+      if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv == 0) y[64 + lr] = yacc1; }
+      const double qq = block_sum(part_q, red);   // (also the barrier that publishes y)
       if (tid == 0) st.phase_clk[6] = clock64();
       for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < 80) ? y[cd] : 0.0);   // reduced rhs
       // regularise: diag += mu dhat^2
+      auto tile_reg = [&](auto W_) {
+        constexpr int WV = decltype(W_)::value;
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
-        if (ty == tx) Cr[r][r] += mu * dh2[ty + 16 * r];
+        for (int sl = 0; sl < NTILE(WV); ++sl) {
+          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+          if (I != J) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (lk + 4 * r == lr) acc[sl][r] += mu * dh2[16 * I + lr];
+        }
+      };
+      WAVE_DISPATCH(tile_reg);
       for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
       __syncthreads();
       // ---- P8: block elimination of the speed/leg-bias part, frames F-1 .. 0 ----
@@ -966,16 +1046,25 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
             tmp[CD_B0 + 13 * (k - 1) + tid] -= sacc;
           }
         }
+        // C -= T_P^T T_P (rank 13, padded to 16) on the matrix cores
+        auto tile_rank13 = [&](auto W_) {
+          constexpr int WV = decltype(W_)::value;
+          double opT[4][5];
 #pragma unroll
-        for (int q = 0; q < 13; ++q) {
-          double tr_[5], tc_[5];
+          for (int kk = 0; kk < 4; ++kk) {
+            const int q = 4 * kk + lk, qc = min(q, 12);
 #pragma unroll
-          for (int r = 0; r < 5; ++r) { tr_[r] = T[q * 96 + 13 + ty + 16 * r]; tc_[r] = T[q * 96 + 13 + tx + 16 * r]; }
+            for (int X = 0; X < 5; ++X) { const double v = T[qc * 96 + 13 + 16 * X + lr]; opT[kk][X] = (q < 13) ? v : 0.0; }
+          }
 #pragma unroll
-          for (int r = 0; r < 5; ++r)
+          for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) Cr[r][c] -= tr_[r] * tc_[c];
-        }
+            for (int sl = 0; sl < NTILE(WV); ++sl) {
+              const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+              acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opT[kk][I], opT[kk][J], acc[sl], 0, 0, 0);
+            }
+        };
+        WAVE_DISPATCH(tile_rank13);
         if (tid >= 64 && tid < 64 + 80) {
           const int i = tid - 64;
           double sacc = 0.0;
@@ -989,40 +1078,55 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       if (tid == 0) st.phase_clk[7] = clock64();
       // ---- dense Cholesky of the 80x80 reduced pose system: register tiles, pivot column broadcast through LDS,
       //      reciprocal square root of the pivot (one Newton step on v_rsq_f64) instead of sqrt + 80 divisions ----
-      for (int j = 0; j < 80; ++j) {
-        const int jr = j >> 4, jt = j & 15;
-        if (ty == jt && tx == jt) {
-          double d = 0.0;
+      // ---- dense Cholesky of the 80x80 reduced pose system, blocked by 16: diagonal tile by one wave (registers +
+      //      v_readlane), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores;
+      //      2 workgroup barriers per block column (10 in total). L is left in C (lower triangle) for the solves ----
+      double *P16 = S, *D16 = S + 1100, *LI16 = S + 1400;
+      auto tile_chol = [&](auto W_) {
+        constexpr int WV = decltype(W_)::value;
 #pragma unroll
-          for (int r = 0; r < 5; ++r) if (r == jr) d = Cr[r][r];
-          if (!(d > 0.0) || !isfinite(d)) { if (!s_flag[1] && st.pad[1] == 0) { st.pad[1] = 1000 + j; st.x_norm = d; } s_flag[1] = 1; d = 1.0; }
-          const double rs = rsqrt(d);
-          col[80] = d * rs;
-          col[81] = rs;
-        }
-        lds_barrier();
-        const double dj = col[80], rj = col[81];
-        if (tx == jt) {
+        for (int j = 0; j < 5; ++j) {
 #pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            const int i = ty + 16 * r;
-            double v = 0.0;
+          for (int sl = 0; sl < NTILE(WV); ++sl) {
+            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+            if (I == j && J == j) {
 #pragma unroll
-            for (int c = 0; c < 5; ++c) if (c == jr) v = Cr[r][c];
-            const double lij = (i > j) ? v * rj : 0.0;
-            col[i] = lij;
-            C[i * CLD + j] = (i > j) ? lij : (i == j ? dj : 0.0);
+              for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[sl][r];
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              const int f16 = chol16_wave(D16, C + (16 * j) * CLD + 16 * j, CLD, LI16);
+              if (f16 && (tid & 63) == 0) { if (st.pad[1] == 0) st.pad[1] = 1000 + 16 * j; s_flag[1] = 1; }
+            }
+          }
+          lds_barrier();
+#pragma unroll
+          for (int sl = 0; sl < NTILE(WV); ++sl) {
+            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+            if (J == j && I > j) {
+              double *Pt = P16 + (I - j - 1) * 272;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Pt[(lk + 4 * r) * 17 + lr] = acc[sl][r];
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[lr * 17 + 4 * kk + lk], LI16[lr * 17 + 4 * kk + lk], nacc, 0, 0, 0);
+              acc[sl] = nacc;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * j + lr] = nacc[r];
+            }
+          }
+          lds_barrier();
+#pragma unroll
+          for (int sl = 0; sl < NTILE(WV); ++sl) {
+            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+            if (J > j) {
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk)
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-C[(16 * I + lr) * CLD + 16 * j + 4 * kk + lk], C[(16 * J + lr) * CLD + 16 * j + 4 * kk + lk], acc[sl], 0, 0, 0);
+            }
           }
         }
-        lds_barrier();
-        double cr[5], cc[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { cr[r] = col[ty + 16 * r]; cc[r] = col[tx + 16 * r]; }
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-          for (int c = 0; c < 5; ++c) Cr[r][c] -= cr[r] * cc[c];
-      }
+      };
+      WAVE_DISPATCH(tile_chol);
       lds_barrier();
       fail |= s_flag[1];
       if (fail) {
