@@ -530,7 +530,7 @@ __device__ __forceinline__ int imu_col_cd(int k, int c) {
 #define LDS_BS (LDS_LK + 176)          /* [11][13][18]: B_k x (pose_{k-1}, pose_k, pose_{k+1}) from the IMU factors */
 #define LDS_BP (LDS_BS + 11 * 13 * 18)  /* [13][80]: prior rows of the frame whose speed/leg-bias it touches */
 #define LDS_S (LDS_BP + 13 * 80)
-#define LDS_S_SIZE 3840          /* union: landmark chunk w[32][81] + einv[64]  |  Bk[1040] Bkm1[1040] T[13*96]  |  back-sub blocks */
+#define LDS_S_SIZE 4096          /* union: landmark chunk w[32][81] + einv[64]  |  Bk[1040] Bkm1[1040] T[13*96]  |  back-sub blocks */
 #define LDS_RED (LDS_S + LDS_S_SIZE)
 #define LDS_COL (LDS_RED + SOLVE_THREADS)
 #define LDS_TOTAL (LDS_COL + 176)
@@ -539,7 +539,7 @@ extern "C" size_t vilo_solve_lds_bytes() { return (size_t)LDS_TOTAL * sizeof(dou
 
 // 13x13 Cholesky by one wave: lane i (< 13) owns row i in registers, pivots broadcast with shuffles.
 // A: LDS 13x13 row-major in, L (lower, zeros above) written to Lout. Returns 0 ok / 1 not positive definite.
-__device__ int chol13_wave(const double *A, double *Lout) {
+__device__ int chol13_wave(const double *A, double *Lout, double *rinv_out) {
   const int lane = threadIdx.x & 63;
   const int row = lane < 13 ? lane : 0;
   double a[13], l[13];
@@ -555,6 +555,7 @@ __device__ int chol13_wave(const double *A, double *Lout) {
     if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
     const double rinv = rsqrt(piv), ljj = piv * rinv;
     l[j] = (lane == j) ? ljj : (lane > j ? s * rinv : 0.0);
+    if (lane == j) rinv_out[j] = rinv;
   }
   if (lane < 13) {
 #pragma unroll
@@ -615,6 +616,7 @@ __device__ constexpr int c_tileJ[16] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3
 template <int N> struct IC { static constexpr int value = N; };
 #define WAVE_DISPATCH(fn) do { if (wv == 0) fn(IC<0>{}); else if (wv == 1) fn(IC<1>{}); else if (wv == 2) fn(IC<2>{}); else fn(IC<3>{}); } while (0)
 #define NTILE(WV) ((WV) == 3 ? 3 : 4)
+#define WAVE_DISPATCH3(fn) do { if (wv == 0) fn(IC<0>{}); else if (wv == 1) fn(IC<1>{}); else if (wv == 2) fn(IC<2>{}); } while (0)
 
 __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -828,20 +830,22 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       for (int e = tid; e < CD_N; e += SOLVE_THREADS)
         if (act[e] == 0.0) g[e] = 0.0;
       __syncthreads();
-      mfma_d4 acc[4];
+      // During q and the landmark Schur pass the 15 lower tiles belong to waves 0..2 (tile t -> wave t % 3, 5 each) while
+      // wave 3 runs the block-tridiagonal Cholesky chain of the speed/leg-bias part; afterwards they are redistributed over
+      // all four waves (tile t -> wave t % 4) through LDS.
+      mfma_d4 acc3[5];
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl) acc[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-      auto tile_load = [&](auto W_) {
+      for (int sl = 0; sl < 5; ++sl) acc3[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      auto tile_load3 = [&](auto W_) {
         constexpr int WV = decltype(W_)::value;
 #pragma unroll
-        for (int sl = 0; sl < NTILE(WV); ++sl) {
-          constexpr int dummy = 0; (void)dummy;
-          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+        for (int sl = 0; sl < 5; ++sl) {
+          const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+          for (int r = 0; r < 4; ++r) acc3[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
         }
       };
-      WAVE_DISPATCH(tile_load);
+      WAVE_DISPATCH3(tile_load3);
       if (tid < 80) y[tid] = C[tid * CLD + tid];
       __syncthreads();
       if (tid == 0) st.phase_clk[4] = clock64();
@@ -872,14 +876,14 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       auto tile_q = [&](auto W_) {
         constexpr int WV = decltype(W_)::value;
 #pragma unroll
-        for (int sl = 0; sl < NTILE(WV); ++sl) {
-          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+        for (int sl = 0; sl < 5; ++sl) {
+          const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
           const double vc = tmp[16 * J + lr], sym = (I == J) ? 1.0 : 2.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) part_q += sym * tmp[16 * I + lk + 4 * r] * acc[sl][r] * vc;
+          for (int r = 0; r < 4; ++r) part_q += sym * tmp[16 * I + lk + 4 * r] * acc3[sl][r] * vc;
         }
       };
-      WAVE_DISPATCH(tile_q);
+      WAVE_DISPATCH3(tile_q);
       if (tid >= 96 && tid < 96 + 143) {
         const int e = tid - 96, k = e / 13, i = e % 13;
         if (k < F) {
@@ -923,158 +927,224 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         return;
       }
       if (tid == 0) st.phase_clk[5] = clock64();
-      // Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One k-step =
-      // 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles (X, .) and as B of
-      // tiles (., X), so a wave issues 5 coalesced-by-row global loads and up to 4 MFMAs per k-step and never touches LDS.
-      // The same operands give rhs_P -= sum_l w_l g_l / (...) and the 2 vl w_l^T v term of q (tile row X = wave, wave 0 also 4).
-      __syncthreads();   // lm_einv / lm_dh2 written above are read through global memory below
+      // regularise the speed/leg-bias diagonal blocks (the pose part is regularised after the tile redistribution)
+      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
+      if (tid == 0) { s_flag[0] = 0; }
+      __syncthreads();   // also: lm_einv / lm_y written above are read through global memory below
+      double *Mk = S, *Gk = S + 1859, *TA1 = S + 3718, *rinvk = S + 3887, *TA0 = col;
       double actv[5], vv[5], yacc0 = 0.0, yacc1 = 0.0, qacc = 0.0;
 #pragma unroll
       for (int X = 0; X < 5; ++X) { actv[X] = act[16 * X + lr]; vv[X] = tmp[16 * X + lr]; }
-      const int nks = (L + 3) >> 2;
-      auto tile_schur = [&](auto W_) {
-        constexpr int WV = decltype(W_)::value;
-        for (int kk0 = 0; kk0 < nks; kk0 += 4) {
-          // 4 k-steps (16 landmarks) per trip: all 32 loads are issued before the first MFMA; landmarks past L are clamped
-          // to a valid address and masked through their 1 / (E + mu d2) factor
-          double opb[4][5], eb[4], gb[4], db[4];
+      if (wv == 3) {
+        // ---- block-tridiagonal Cholesky chain of the speed/leg-bias part (13x13 blocks, frames F-1 .. 0), one wave, no
+        //      workgroup barriers:  S_k = A_kk - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,
+        //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
+        //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
+        const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
+        double *TAcur = TA0, *TAprev = TA1;
+        for (int k = F - 1; k >= 0; --k) {
+          const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
+          if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (c < 13 && grp < 3) {
+            double cl[13];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
-            eb[u] = lm_einv[lc]; gb[u] = lm_g[lc]; db[u] = lm_y[lc];
+            for (int i = 0; i < 13; ++i) {
+              double v;
+              if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
+              else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
+              else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
 #pragma unroll
-            for (int X = 0; X < 5; ++X) opb[u][X] = wl[(size_t)(16 * X + lr) * L + lc];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int l = 4 * (kk0 + u) + lk;
-            const double ei = (l < L) ? eb[u] : 0.0, ge = gb[u] * ei, vl = (l < L) ? db[u] : 0.0;
-            double op[5];
-#pragma unroll
-            for (int X = 0; X < 5; ++X) op[X] = opb[u][X] * actv[X];
-#pragma unroll
-            for (int sl = 0; sl < NTILE(WV); ++sl) {
-              const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-              acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc[sl], 0, 0, 0);
+              for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
+              cl[i] = v * rinvk[i];
             }
-            yacc0 += op[WV] * ge; qacc += op[WV] * vv[WV] * vl;
-            if (WV == 0) { yacc1 += op[4] * ge; qacc += op[4] * vv[4] * vl; }
+            if (grp == 0) {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
+            } else if (grp == 1) {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) { Mk[k * 169 + i * 13 + c] = cl[i]; Lkm[k * 169 + i * 13 + c] = cl[i]; }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) Gk[k * 169 + i * 13 + c] = cl[i];
+            }
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (k > 0) {
+            for (int e = lane; e < 169; e += 64) {
+              const int i = e / 13, j = e - 13 * i;
+              double sacc = 0.0;
+#pragma unroll
+              for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
+              Ad[(k - 1) * 169 + e] -= sacc;
+            }
+          }
+          double *sw = TAcur; TAcur = TAprev; TAprev = sw;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-      };
-      WAVE_DISPATCH(tile_schur);
-      part_q += 2.0 * qacc;
-      yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
-      yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
-      if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv == 0) y[64 + lr] = yacc1; }
-      const double qq = block_sum(part_q, red);   // (also the barrier that publishes y)
+      } else {
+        // ---- Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One
+        //      k-step = 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles
+        //      (X, .) and as B of tiles (., X): 5 row-coalesced global loads and 5 MFMAs per k-step per wave, no LDS. The same
+        //      operands give rhs_P -= sum_l w_l g_l / (...) and the 2 vl w_l^T v term of q.
+        const int nks = (L + 3) >> 2;
+        auto tile_schur = [&](auto W_) {
+          constexpr int WV = decltype(W_)::value;
+          double opb[2][4][5], eb[2][4], gb[2][4], db[2][4];
+          auto ldtrip = [&](int kk0, int bsel) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
+              eb[bsel][u] = lm_einv[lc]; gb[bsel][u] = lm_g[lc]; db[bsel][u] = lm_y[lc];
+#pragma unroll
+              for (int X = 0; X < 5; ++X) opb[bsel][u][X] = wl[(size_t)(16 * X + lr) * L + lc];
+            }
+          };
+          auto dotrip = [&](int kk0, int bsel) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int l = 4 * (kk0 + u) + lk;
+              const double ei = (l < L) ? eb[bsel][u] : 0.0, ge = gb[bsel][u] * ei, vl = (l < L) ? db[bsel][u] : 0.0;
+              double op[5];
+#pragma unroll
+              for (int X = 0; X < 5; ++X) op[X] = opb[bsel][u][X] * actv[X];
+#pragma unroll
+              for (int sl = 0; sl < 5; ++sl) {
+                const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
+                acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc3[sl], 0, 0, 0);
+              }
+              yacc0 += op[WV] * ge; qacc += op[WV] * vv[WV] * vl;
+              if (WV < 2) { yacc1 += op[WV + 3] * ge; qacc += op[WV + 3] * vv[WV + 3] * vl; }
+            }
+          };
+          // 4 k-steps (16 landmarks) per trip, the next trip's 32 loads in flight behind the current trip's 20 MFMAs;
+          // landmarks past L are clamped to a valid address and masked through their 1 / (E + mu d2) factor
+          ldtrip(0, 0);
+          for (int kk0 = 0; kk0 < nks; kk0 += 8) {
+            ldtrip(kk0 + 4, 1);
+            dotrip(kk0, 0);
+            ldtrip(kk0 + 8, 0);
+            dotrip(kk0 + 4, 1);
+          }
+          // hand the tiles to their 4-wave owners through C (lower tile positions)
+#pragma unroll
+          for (int sl = 0; sl < 5; ++sl) {
+            const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr] = acc3[sl][r];
+          }
+        };
+        WAVE_DISPATCH3(tile_schur);
+        part_q += 2.0 * qacc;
+        yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
+        yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
+        if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv < 2) y[16 * (wv + 3) + lr] = yacc1; }
+      }
+      const double qq = block_sum(part_q, red);   // (also the barrier that publishes y, the tiles in C and the chain's output)
+      int fail = s_flag[0];
       if (tid == 0) st.phase_clk[6] = clock64();
       for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < 80) ? y[cd] : 0.0);   // reduced rhs
-      // regularise: diag += mu dhat^2
-      auto tile_reg = [&](auto W_) {
+      mfma_d4 acc[4];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) acc[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      auto tile_load = [&](auto W_) {
         constexpr int WV = decltype(W_)::value;
 #pragma unroll
         for (int sl = 0; sl < NTILE(WV); ++sl) {
           const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-          if (I != J) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (lk + 4 * r == lr) acc[sl][r] += mu * dh2[16 * I + lr];
+          for (int r = 0; r < 4; ++r) {
+            acc[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+            if (I == J && lk + 4 * r == lr) acc[sl][r] += mu * dh2[16 * I + lr];   // regularise: diag += mu dhat^2
+          }
         }
       };
-      WAVE_DISPATCH(tile_reg);
-      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
-      __syncthreads();
-      // ---- P8: block elimination of the speed/leg-bias part, frames F-1 .. 0 ----
-      int fail = 0;
-      for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bval(F - 1, e / 80, e % 80);
-      for (int k = F - 1; k >= 0; --k) {
-        if (k > 0)
-          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bkm1[e] = Bval(k - 1, e / 80, e % 80);
-        lds_barrier();
-        if (tid < 64) {
-          const int f = chol13_wave(Ad + k * 169, Lk);
-          if (tid == 0) { s_flag[0] = f; if (f) st.pad[0] = 100 + k; }
-        }
-        lds_barrier();
-        fail |= s_flag[0];
-        // T = Lk^-1 [A_{k,k-1} | B_k | rhs_k]: one thread per column (13 + 80 + 1); threads 96..108: columns of Lk^-1
-        if (tid < 94) {
-          double cl[13];
+      WAVE_DISPATCH(tile_load);
+      __syncthreads();   // tmp (reduced rhs) complete
+      // ---- T(k) = [T_B(k) | t_g(k)] = M_k [B_k | rhs_k] - G_k T(k+1): the 80 + 1 columns are independent, so each wave
+      //      carries its 16-column tiles (wave w: tiles w and w + 4; tile 5 = rhs column) through all frames without any
+      //      barrier. The previous result is already in B-operand layout: register kk of a lane is row 4 kk + l / 16. ----
+      {
+        const int X0 = wv, X1 = wv + 4;
+        mfma_d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+        for (int k = F - 1; k >= 0; --k) {
+          mfma_d4 n0 = {0.0, 0.0, 0.0, 0.0}, n1 = {0.0, 0.0, 0.0, 0.0};
+          double am[4], ag[4];
 #pragma unroll
-          for (int i = 0; i < 13; ++i) {
-            double v = (tid < 13) ? ((k > 0) ? Ao[(k - 1) * 169 + i * 13 + tid] : 0.0) : (tid < 93 ? Bk[i * 80 + (tid - 13)] : tmp[CD_B0 + 13 * k + i]);
-#pragma unroll
-            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
-            cl[i] = v / Lk[i * 13 + i];
+          for (int kk = 0; kk < 4; ++kk) {
+            const int q = 4 * kk + lk;
+            const bool in = (lr < 13) && (q < 13);
+            const int idx = k * 169 + min(lr, 12) * 13 + min(q, 12);
+            const double m = Mk[idx], gg = Gk[idx];
+            am[kk] = in ? m : 0.0;
+            ag[kk] = (in && k < F - 1) ? -gg : 0.0;
           }
-#pragma unroll
-          for (int i = 0; i < 13; ++i) T[i * 96 + tid] = cl[i];
-        } else if (tid >= 96 && tid < 109) {
-          const int c = tid - 96;
-          double cl[13];
-#pragma unroll
-          for (int i = 0; i < 13; ++i) {
-            double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
-            cl[i] = v / Lk[i * 13 + i];
-          }
-#pragma unroll
-          for (int i = 0; i < 13; ++i) Lkm[k * 169 + i * 13 + c] = cl[i];   // Lk^-1 (lower), used by the back-substitution
-        }
-        lds_barrier();
-        for (int e = tid; e < 13 * 96; e += SOLVE_THREADS) Tm[k * 13 * 96 + e] = T[e];
-        if (k > 0) {
-          for (int e = tid; e < 169; e += SOLVE_THREADS) {
-            const int i = e / 13, j = e % 13;
-            double sacc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + j];
-            Ad[(k - 1) * 169 + e] -= sacc;
-          }
-          for (int e = tid; e < 1040; e += SOLVE_THREADS) {
-            const int i = e / 80, j = e % 80;
-            double sacc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + i] * T[q * 96 + 13 + j];
-            Bkm1[e] -= sacc;
-          }
-          if (tid < 13) {
-            double sacc = 0.0;
-            for (int q = 0; q < 13; ++q) sacc += T[q * 96 + tid] * T[q * 96 + 93];
-            tmp[CD_B0 + 13 * (k - 1) + tid] -= sacc;
-          }
-        }
-        // C -= T_P^T T_P (rank 13, padded to 16) on the matrix cores
-        auto tile_rank13 = [&](auto W_) {
-          constexpr int WV = decltype(W_)::value;
-          double opT[4][5];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const int q = 4 * kk + lk, qc = min(q, 12);
-#pragma unroll
-            for (int X = 0; X < 5; ++X) { const double v = T[qc * 96 + 13 + 16 * X + lr]; opT[kk][X] = (q < 13) ? v : 0.0; }
+            double b0 = Bval(k, qc, 16 * X0 + lr);
+            b0 = (q < 13) ? b0 : 0.0;
+            n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b0, n0, 0, 0, 0);
+            if (X1 < 6) {
+              double b1 = (X1 < 5) ? Bval(k, qc, 16 * min(X1, 4) + lr) : ((lr == 0) ? tmp[CD_B0 + 13 * k + qc] : 0.0);
+              b1 = (q < 13) ? b1 : 0.0;
+              n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b1, n1, 0, 0, 0);
+            }
           }
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
+          for (int kk = 0; kk < 4; ++kk) {
+            n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t0[kk], n0, 0, 0, 0);
+            if (X1 < 6) n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t1[kk], n1, 0, 0, 0);
+          }
+          t0 = n0; t1 = n1;
 #pragma unroll
-            for (int sl = 0; sl < NTILE(WV); ++sl) {
-              const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-              acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opT[kk][I], opT[kk][J], acc[sl], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            if (row < 13) {
+              Tm[k * 13 * 96 + row * 96 + 13 + 16 * X0 + lr] = n0[r];
+              if (X1 < 5) Tm[k * 13 * 96 + row * 96 + 13 + 16 * X1 + lr] = n1[r];
+              else if (X1 == 5 && lr == 0) Tm[k * 13 * 96 + row * 96 + 93] = n1[r];
             }
-        };
-        WAVE_DISPATCH(tile_rank13);
-        if (tid >= 64 && tid < 64 + 80) {
-          const int i = tid - 64;
-          double sacc = 0.0;
-          for (int q = 0; q < 13; ++q) sacc += T[q * 96 + 13 + i] * T[q * 96 + 93];
-          tmp[i] -= sacc;
+          }
         }
-        lds_barrier();
-        if (k > 0)
-          for (int e = tid; e < 1040; e += SOLVE_THREADS) Bk[e] = Bkm1[e];
       }
+      __syncthreads();   // T in global memory is read by every wave below
+      // ---- C -= sum_k T_B(k)^T T_B(k) (rank 143) on the matrix cores, rhs_P -= sum_k T_B(k)^T t_g(k); operands from Tm ----
+      {
+        double yr0 = 0.0, yr1 = 0.0;
+        auto tile_rank = [&](auto W_) {
+          constexpr int WV = decltype(W_)::value;
+          for (int k = 0; k < F; ++k) {
+            double opT[4][5], tg[4];
+            const double *Tk = Tm + (size_t)k * 13 * 96;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int qc = min(4 * kk + lk, 12);
+              tg[kk] = Tk[qc * 96 + 93];
+#pragma unroll
+              for (int X = 0; X < 5; ++X) opT[kk][X] = Tk[qc * 96 + 13 + 16 * X + lr];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const bool in = 4 * kk + lk < 13;
+#pragma unroll
+              for (int X = 0; X < 5; ++X) opT[kk][X] = in ? opT[kk][X] : 0.0;
+#pragma unroll
+              for (int sl = 0; sl < NTILE(WV); ++sl) {
+                const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opT[kk][I], opT[kk][J], acc[sl], 0, 0, 0);
+              }
+              yr0 += opT[kk][WV] * tg[kk];
+              if (WV == 0) yr1 += opT[kk][4] * tg[kk];
+            }
+          }
+        };
+        WAVE_DISPATCH(tile_rank);
+        yr0 += __shfl_xor(yr0, 16, 64); yr0 += __shfl_xor(yr0, 32, 64);
+        yr1 += __shfl_xor(yr1, 16, 64); yr1 += __shfl_xor(yr1, 32, 64);
+        if (lk == 0) { tmp[16 * wv + lr] -= yr0; if (wv == 0) tmp[64 + lr] -= yr1; }
+      }
+      lds_barrier();
       if (tid == 0) st.phase_clk[7] = clock64();
       // ---- dense Cholesky of the 80x80 reduced pose system: register tiles, pivot column broadcast through LDS,
       //      reciprocal square root of the pivot (one Newton step on v_rsq_f64) instead of sqrt + 80 divisions ----
