@@ -679,9 +679,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
     }
     __syncthreads();
     for (int i = tid; i < pn; i += SOLVE_THREADS) inv_pmap[pmap[i]] = (short)i;
-    int kb = -1;   // frame whose speed/leg-bias block the prior touches
-    for (int i = 0; i < pn; ++i)
-      if (pmap[i] >= CD_B0) { kb = (pmap[i] - CD_B0) / 13; break; }
+    const int kb = wm.pad;   // frame whose speed/leg-bias block the prior touches (-1: none), resolved when the batch is packed
     __syncthreads();
 
     // B_k(i, p): speed/leg-bias (frame k, local row i) x pose-part coupling, gathered from the IMU Grams and the prior
@@ -724,100 +722,160 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       __syncthreads();
       const double mu = st.mu;
       if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-      if (tid == 0) { st.phase_clk[1] = clock64(); st.phase_clk[2] = st.phase_clk[1]; st.phase_clk[3] = st.phase_clk[1]; }
+      if (tid == 0) st.phase_clk[1] = clock64();
       // ---- assembly: barrier-free scatter with LDS FP64 atomics (ds_add_f64); every Gram entry of every slot is an
       //      independent coalesced load + 1-2 atomic adds, so the L2 latency overlaps across entries ----
-      for (int e = tid; e < 80 * CLD; e += SOLVE_THREADS) C[e] = 0.0;
-      for (int e = tid; e < 11 * 169 + 10 * 169; e += SOLVE_THREADS) Ad[e] = 0.0;   // Ad and Ao are contiguous
+      // start from the prior's pre-assembled image (all zeros without a prior): coalesced copies instead of zero fill + scatter
+      {
+        const double *pd = b.prior_dense + (size_t)win * PD_N;
+        // C and Ad are contiguous in LDS and in the image: 8339 doubles = 33 per thread, all loads in flight at once
+        double pv[33];
+#pragma unroll
+        for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; pv[u] = pd[min(e, PD_BP - 1)]; }
+        double bpv[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; bpv[u] = pd[PD_BP + min(e, 13 * 80 - 1)]; }
+#pragma unroll
+        for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < PD_BP) C[e] = pv[u]; }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < 13 * 80) Bp[e] = bpv[u]; }
+        for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) Ao[e] = 0.0;
+      }
       for (int e = tid; e < CD_N; e += SOLVE_THREADS) g[e] = 0.0;
-      if (pn > 0 && tid < wm.prior_nb)
-        prior_dx(x + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid],
-                 b.prior_bsize[win * 40 + tid], S + b.prior_bidx[win * 40 + tid]);
       __syncthreads();
+      if (tid == 0) st.phase_clk[2] = clock64();
       {
         auto ladd = [](double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-        // visual Gram slots -> C, g
+        // pose-block entries: only the lower tile positions are consumed (tiles I >= J); entries inside a diagonal tile
+        // are mirrored
+        auto addC = [&](int pa, int pb, double v) {
+          const int hi = max(pa, pb), lo = min(pa, pb);
+          ladd(&C[hi * CLD + lo], v);
+          if (hi != lo && (hi >> 4) == (lo >> 4)) ladd(&C[lo * CLD + hi], v);
+        };
+        // visual Gram slots -> C, g. A thread keeps one packed entry (a, bc) and walks the window's (s, t) slots. The target
+        // index is affine in (s, j = s + t), so the walk is branch-free: 16 coalesced loads are issued, then 16-32 ds_add_f64.
         const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
-        const int nvis = wm.n_gram * VILO_GRAM;
-#pragma unroll 4
-        for (int idx = tid; idx < nvis; idx += SOLVE_THREADS) {
-          const double v = gs[idx];
-          const int sl = idx / VILO_GRAM, e = idx - sl * VILO_GRAM;
-          const int s = slot_st[sl] & 255, t = slot_st[sl] >> 8, j = s + t;
-          const int a = tab26[e] & 255, bc = tab26[e] >> 8;
-          if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;   // OneFrameTwoCam has no pose_j columns
-          const int pa = a < 6 ? 6 * s + a : (a < 12 ? 6 * j + (a - 6) : (a < 18 ? CD_EX0 + a - 12 : (a < 24 ? CD_EX1 + a - 18 : CD_TD)));
-          if (bc == 25) { if (a < 25) ladd(&g[pa], v); }
-          else {
-            const int pb = bc < 6 ? 6 * s + bc : (bc < 12 ? 6 * j + (bc - 6) : (bc < 18 ? CD_EX0 + bc - 12 : (bc < 24 ? CD_EX1 + bc - 18 : CD_TD)));
-            ladd(&C[pa * CLD + pb], v);
-            if (pa != pb) ladd(&C[pb * CLD + pa], v);
+        const int ns = wm.n_gram;
+        // IMU Gram entries of this thread (entries tid, tid + 256, ... of the 780, all 10 factors): loads issued first, they
+        // are consumed after the visual walk
+        double vi[4][10];
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const int e = min(tid + SOLVE_THREADS * p4, 779);
+#pragma unroll
+          for (int k = 0; k < 10; ++k) vi[p4][k] = igram[min(k, F - 2) * 780 + e];
+        }
+        // entries tid and tid + 256 of the 351 visual ones, 16 slots per trip: 32 loads in flight per thread
+        int da[2], db[2];
+        int cas[2], caj[2], ca0v[2], cbs[2], cbj[2], cb0v[2];
+        bool cisg[2], cdead[2], cuj[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = tid + SOLVE_THREADS * h, ec = min(e, VILO_GRAM - 1);
+          const int a = tab26[ec] & 255, bc = tab26[ec] >> 8;
+          da[h] = a; db[h] = bc;
+          cisg[h] = (bc == 25); cdead[h] = (cisg[h] && a == 25) || e >= VILO_GRAM;   // r^T r is not needed
+          cuj[h] = (a >= 6 && a < 12) || (bc >= 6 && bc < 12);
+          cas[h] = a < 6 ? 6 : 0; caj[h] = (a >= 6 && a < 12) ? 6 : 0;
+          ca0v[h] = a < 6 ? a : (a < 12 ? a - 6 : (a < 18 ? CD_EX0 + a - 12 : (a < 24 ? CD_EX1 + a - 18 : CD_TD)));
+          cbs[h] = bc < 6 ? 6 : 0; cbj[h] = (bc >= 6 && bc < 12) ? 6 : 0;
+          cb0v[h] = bc < 6 ? bc : (bc < 12 ? bc - 6 : (bc < 18 ? CD_EX0 + bc - 12 : (bc < 24 ? CD_EX1 + bc - 18 : CD_TD)));
+        }
+        for (int sl0 = 0; sl0 < ns; sl0 += 16) {
+          double v[2][16];
+          int sv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int slc = min(sl0 + u, ns - 1);
+            sv[u] = slot_st[slc];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[h][u] = gs[(size_t)slc * VILO_GRAM + min(tid + SOLVE_THREADS * h, VILO_GRAM - 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int s_ = sv[u] & 255, t_ = sv[u] >> 8, j_ = s_ + t_;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bool on = (sl0 + u < ns) && !(t_ == 0 && cuj[h]) && !cdead[h];   // OneFrameTwoCam has no pose_j columns
+              if (h == 1 && tid >= VILO_GRAM - SOLVE_THREADS) continue;
+              const double vv = on ? v[h][u] : 0.0;
+              const int pa = cas[h] * s_ + caj[h] * j_ + ca0v[h], pb = cisg[h] ? pa : cbs[h] * s_ + cbj[h] * j_ + cb0v[h];
+              const int hi = max(pa, pb), lo = min(pa, pb);
+              double *tgt = cisg[h] ? &g[pa] : &C[hi * CLD + lo];
+              ladd(tgt, vv);
+              if (!cisg[h] && hi != lo && (hi >> 4) == (lo >> 4)) ladd(&C[lo * CLD + hi], vv);
+            }
           }
         }
-        // IMULegFactor Grams (39x39 packed, column 38 = residual): P x P -> C, B x B -> Ad / Ao, gradient
-        const int nimu = (F - 1) * 780;
-#pragma unroll 4
-        for (int idx = tid; idx < nimu; idx += SOLVE_THREADS) {
-          const double v = igram[idx];
-          const int k = idx / 780, e = idx - k * 780;
+        if (tid == 0) st.phase_clk[13] = clock64();
+        // IMULegFactor Grams (39x39 packed, column 38 = residual): P x P -> C, B x B -> Ad / Ao, gradient. The target address
+        // of a packed entry is affine in the factor number k.
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const int e = tid + SOLVE_THREADS * p4;
+          if (e >= 780) continue;
           const int a = tab39[e] & 255, bc = tab39[e] >> 8;
-          if (bc == 38) { if (a < 38) ladd(&g[imu_col_cd(k, a)], v); continue; }
-          const int ca = imu_col_cd(k, a), cb = imu_col_cd(k, bc);
-          if (ca < CD_B0 && cb < CD_B0) {
-            ladd(&C[ca * CLD + cb], v);
-            if (ca != cb) ladd(&C[cb * CLD + ca], v);
-          } else if (ca >= CD_B0 && cb >= CD_B0) {
-            const int ka = (ca - CD_B0) / 13, ra = (ca - CD_B0) % 13, kc = (cb - CD_B0) / 13, rc = (cb - CD_B0) % 13;
-            if (ka == kc) { ladd(&Ad[ka * 169 + ra * 13 + rc], v); if (ra != rc) ladd(&Ad[ka * 169 + rc * 13 + ra], v); }
-            else ladd(&Ao[ka * 169 + rc * 13 + ra], v);   // a < bc => ka = k, kc = k + 1: rows frame k+1, cols frame k
+          // camera dim of local column c of factor k: c0 + ck * k
+          auto c0of = [](int c) { return c < 6 ? c : (c < 19 ? CD_B0 + (c - 6) : (c < 25 ? 6 + (c - 19) : CD_B0 + 13 + (c - 25))); };
+          auto ckof = [](int c) { return (c < 6 || (c >= 19 && c < 25)) ? 6 : 13; };
+          const bool aP = (a < 6) || (a >= 19 && a < 25), bP = (bc < 6) || (bc >= 19 && bc < 25);
+          const int ca0 = c0of(a), cak = ckof(a), cb0 = c0of(min(bc, 37)), cbk = ckof(min(bc, 37));
+          // kind: 0 skip, 1 gradient, 2 pose x pose (C), 3 same-frame bias block (Ad), 4 cross-frame bias block (Ao)
+          int kind = 0;
+          if (a < 38) {
+            if (bc == 38) kind = 1;
+            else if (aP && bP) kind = 2;
+            else if (!aP && !bP) kind = ((a < 19) == (bc < 19)) ? 3 : 4;
+          }
+          const int ra = (ca0 - CD_B0) % 13, rc = (cb0 - CD_B0) % 13;   // local rows inside the 13-blocks (kinds 3, 4)
+          const int fa = (a < 19) ? 0 : 1;                              // frame offset of the bias block of a (kinds 3, 4)
+#pragma unroll
+          for (int k = 0; k < 10; ++k) {
+            const double vv = (k < F - 1 && kind != 0) ? vi[p4][k] : 0.0;
+            const int ca = ca0 + cak * k, cb = cb0 + cbk * k;
+            double *tgt = &g[ca];
+            double *mir = nullptr;
+            if (kind == 2) { tgt = &C[cb * CLD + ca]; if (ca != cb && (ca >> 4) == (cb >> 4)) mir = &C[ca * CLD + cb]; }
+            else if (kind == 3) { tgt = &Ad[(k + fa) * 169 + ra * 13 + rc]; if (ra != rc) mir = &Ad[(k + fa) * 169 + rc * 13 + ra]; }
+            else if (kind == 4) tgt = &Ao[k * 169 + rc * 13 + ra];   // rows frame k+1, cols frame k
+            ladd(tgt, vv);
+            if (mir) ladd(mir, vv);
           }
         }
-        // marginalisation prior: H += J0^T J0, g += J0^T (r0 + J0 dx)
-        if (pn > 0) {
-          const double *b0 = b.prior_b0 + (size_t)win * 96;
-          const double *dx = S;
-          for (int i = tid; i < pn; i += SOLVE_THREADS) {
-            double sacc = b0[i];
-#pragma unroll 8
-            for (int q = 0; q < pn; ++q) sacc += Hp[(size_t)q * pn + i] * dx[q];
-            ladd(&g[pmap[i]], sacc);
+        if (tid == 0) st.phase_clk[14] = clock64();
+        // marginalisation prior gradient: g += J0^T (r0 + J0 dx) = b0 + H dx. H dx at the current point was formed by
+        // k_accept when it evaluated this point's cost (b.prior_hd), so no 86 x 86 product here.
+        if (tid < pn) ladd(&g[pmap[tid]], b.prior_b0[(size_t)win * 96 + tid] + b.prior_hd[(size_t)win * 96 + tid]);
+        if (tid == 0) st.phase_clk[15] = clock64();
+        if (tid < 13 * 18) {
+          const int i = tid / 18, sl = tid % 18, df = sl / 6, c = sl % 6;
+          // entry (frame k, row i, pose slot df): from factor k (pose_k / pose_{k+1} columns x bias_k rows) and from factor
+          // k - 1 (pose_{k-1} / pose_k columns x bias_k rows); packed index per source fixed per thread, factor walked
+          const int e1 = (df == 1) ? tri39(c, 6 + i) : tri39(6 + i, 19 + c);     // factor k     (df = 1: f = k, df = 2: f = k + 1)
+          const int e2 = (df == 0) ? tri39(c, 25 + i) : tri39(19 + c, 25 + i);   // factor k - 1 (df = 0: f = k - 1, df = 1: f = k)
+          double v1[11], v2[11];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            v1[k] = igram[min(max(k, 0), F - 2) * 780 + e1];
+            v2[k] = igram[min(max(k - 1, 0), F - 2) * 780 + e2];
           }
-#pragma unroll 4
-          for (int e = tid; e < pn * pn; e += SOLVE_THREADS) {
-            const double v = Hp[e];
-            const int i = e / pn, q = e - i * pn;
-            const int ci = pmap[i], cq = pmap[q];
-            if (ci < CD_B0 && cq < CD_B0) ladd(&C[ci * CLD + cq], v);
-            else if (ci >= CD_B0 && cq >= CD_B0) ladd(&Ad[((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13], v);
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            const int f = k + df - 1;
+            const bool ok = (k < F) && (f >= 0) && (f < F);
+            const bool u1 = ok && (k + 1 < F) && (df >= 1);
+            const bool u2 = ok && (k > 0) && (df <= 1);
+            Bs[(k * 13 + i) * 18 + sl] = (u1 ? v1[k] : 0.0) + (u2 ? v2[k] : 0.0);
           }
-        }
-        // speed/leg-bias x pose coupling (IMU factors) and the prior's rows for frame kb: one writer per entry
-        for (int e = tid; e < 11 * 13 * 18; e += SOLVE_THREADS) {
-          const int k = e / 234, i = (e % 234) / 18, sl = e % 18, df = sl / 6, c = sl % 6, f = k + df - 1;
-          double v = 0.0;
-          if (k < F && f >= 0 && f < F) {
-            if (k + 1 < F) {
-              if (f == k) v += igram[k * 780 + tri39(c, 6 + i)];
-              else if (f == k + 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
-            }
-            if (k > 0) {
-              if (f == k - 1) v += igram[(k - 1) * 780 + tri39(c, 25 + i)];
-              else if (f == k) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
-            }
-          }
-          Bs[e] = v;
-        }
-        for (int e = tid; e < 13 * 80; e += SOLVE_THREADS) {
-          double v = 0.0;
-          if (kb >= 0) { const int p1 = inv_pmap[CD_B0 + 13 * kb + e / 80], p2 = inv_pmap[e % 80]; if (p1 >= 0 && p2 >= 0) v = Hp[(size_t)p1 * pn + p2]; }
-          Bp[e] = v;
         }
       }
       __syncthreads();
+      if (tid == 0) st.phase_clk[3] = clock64();
       // constant dims -> identity rows / cols
-      for (int e = tid; e < 80 * 80; e += SOLVE_THREADS) {
-        const int i = e / 80, j = e % 80;
-        if (act[i] == 0.0 || act[j] == 0.0) C[i * CLD + j] = (i == j) ? 1.0 : 0.0;
+      if (tid < 80 && act[tid] == 0.0) {   // few dims are inactive (padding, constant extrinsics / td): one thread per such dim
+        for (int j = 0; j < 80; ++j) { C[tid * CLD + j] = 0.0; C[j * CLD + tid] = 0.0; }
+        C[tid * CLD + tid] = 1.0;
       }
       for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) {
         const int k = e / 169, i = (e % 169) / 13, j = e % 13;
@@ -1379,7 +1437,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   part = 0.0;
   for (int k = tid; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
   const double imu = block_sum(part, red);
-  double pri = 0.0;
+  double pri = 0.0, my_hd = 0.0;   // my_hd: row tid of H dx at the candidate (becomes the gradient term when accepted)
   if (wm.prior_n > 0) {
     const int n = wm.prior_n;
     if (tid < wm.prior_nb)
@@ -1388,10 +1446,12 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
     __syncthreads();
     const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
     part = 0.0;
-    for (int i = tid; i < n; i += 128) {
+    if (tid < n) {   // n <= 96 < 128: one row per thread
       double sacc = 0.0;
-      for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + i] * dxs[q];
-      part += dxs[i] * (sacc + 2.0 * b0[i]);
+#pragma unroll 16
+      for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + tid] * dxs[q];
+      part = dxs[tid] * (sacc + 2.0 * b0[tid]);
+      my_hd = sacc;
     }
     pri = block_sum(part, red) + b.prior_c0[win];
   }
@@ -1402,6 +1462,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
       st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
       st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
     }
+    if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
     return;
   }
   // ambient-space norms for ParameterToleranceReached
@@ -1448,6 +1509,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   }
   __syncthreads();
   if (accept_s) {
+    if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
     for (int e = tid; e < XSTRIDE; e += 128) x[e] = xc[e];
     for (int l = tid; l < wm.L; l += 128) b.lam[wm.lm_off + l] = b.lamc[wm.lm_off + l];
   }

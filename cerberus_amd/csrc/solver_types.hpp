@@ -21,6 +21,14 @@
 #define CD_B0 80
 #define CD_N 224  // 80 + 143 = 223, padded
 
+// prior pre-assembled once per batch into the solver's LDS image: pose block (80 x 81 padded rows), speed/leg-bias
+// diagonal blocks (11 x 13 x 13) and the 13 x 80 coupling rows of the frame the prior touches
+#define PD_CLD 81
+#define PD_C 0
+#define PD_AD (80 * PD_CLD)
+#define PD_BP (PD_AD + 11 * 169)
+#define PD_N (PD_BP + 13 * 80)
+
 #define CONST_LB 1
 #define CONST_EX 2
 #define CONST_TD 4
@@ -98,6 +106,8 @@ struct BatchDev {
   double *imu_cost;           // [W][10]
   // prior
   double *prior_H, *prior_b0, *prior_c0, *prior_x0;   // [W][96*96], [W][96], [W], [W][280]
+  double *prior_dense;        // [W][PD_N]
+  double *prior_hd;           // [W][96] H dx at the current point (written by k_accept)
   int *prior_map, *prior_bsize, *prior_bidx, *prior_bxoff, *prior_bstate;  // [W][96], [W][40] x4
   // camera-side vectors [W][CD_N]
   double *cam_g, *cam_dh2, *cam_y, *cam_scale;

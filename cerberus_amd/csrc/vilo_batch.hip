@@ -81,6 +81,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<unsigned char> flags;
   std::vector<vilo_preint> pre((size_t)W * 10);
   std::vector<double> pH((size_t)W * 96 * 96, 0.0), pb0((size_t)W * 96, 0.0), pc0(W, 0.0), px0((size_t)W * 280, 0.0);
+  std::vector<double> pdense((size_t)W * PD_N, 0.0);
   std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
   int lm_total = 0, gram_total = 0;
   bt->lm_off_host.resize(W);
@@ -100,7 +101,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     const int F = d.n_frames, L = d.n_landmarks;
     WinMeta &wm = wins[w];
     memset(&wm, 0, sizeof(wm));
-    wm.n_frames = F; wm.L = L; wm.use_leg = d.use_leg;
+    wm.n_frames = F; wm.L = L; wm.use_leg = d.use_leg; wm.pad = -1;
     wm.lm_off = lm_total; wm.chunk_off = (int)chunks.size(); wm.gram_off = gram_total;
     wm.const_mask = (d.leg_bias_const ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
     bt->lm_off_host[w] = lm_total;
@@ -179,6 +180,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         for (int c = 0; c < gs; ++c) px0[(size_t)w * 280 + xo + c] = p.x0[xo + c];
         xo += gs;
       }
+      wm.pad = bframe;
       double *H = &pH[(size_t)w * 96 * 96], *b0 = &pb0[(size_t)w * 96];
       for (int i = 0; i < n; ++i) {
         for (int j = 0; j <= i; ++j) {
@@ -194,6 +196,16 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
       double c0 = 0.0;
       for (int r = 0; r < n; ++r) c0 += p.r0[r] * p.r0[r];
       pc0[w] = c0;
+      double *pd = &pdense[(size_t)w * PD_N];
+      const int *pm = &pmap[(size_t)w * 96];
+      for (int i = 0; i < n; ++i)
+        for (int q = 0; q < n; ++q) {
+          const int ci = pm[i], cq = pm[q];
+          const double v = H[(size_t)i * n + q];
+          if (ci < CD_B0 && cq < CD_B0) pd[PD_C + ci * PD_CLD + cq] += v;
+          else if (ci >= CD_B0 && cq >= CD_B0) pd[PD_AD + ((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13] += v;
+          else if (ci >= CD_B0 && cq < CD_B0) pd[PD_BP + ((ci - CD_B0) % 13) * 80 + cq] += v;
+        }
     }
   }
   BatchDev &D = bt->d;
@@ -226,6 +238,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
   TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
+  TRYB(dev_upload(ctx, bt, &D.prior_dense, pdense));
+  TRYB(dev_alloc(ctx, bt, &D.prior_hd, (size_t)W * 96));
   TRYB(dev_upload(ctx, bt, &D.prior_b0, pb0));
   TRYB(dev_upload(ctx, bt, &D.prior_c0, pc0));
   TRYB(dev_upload(ctx, bt, &D.prior_x0, px0));

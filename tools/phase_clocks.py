@@ -17,7 +17,7 @@ ctx.preintegrate_windows(ws)
 b = api.Batch(ctx, ws)
 opts = api.default_solve_opts(True, 3)
 b.solve(opts)
-names = ["tables", "(mu loop)", "-", "-", "assembly+mask+tile", "P5/P6 scaling+q", "landmark Schur", "regularise+B elimination", "Cholesky 80",
+names = ["tables", "tables", "prior image copy", "Gram scatter (LDS atomics)", "masks + tile load", "P5/P6 scaling+q", "landmark Schur || bias chain", "T recurrence + rank-143", "Cholesky 80",
          "triangular solves", "B back-sub", "landmark back-sub+norms", "dogleg+candidate"]
 acc = np.zeros(13)
 vis = np.zeros(5)
@@ -35,5 +35,7 @@ for i in range(1, 13):
     if names[i] != "-":
         print("  %-28s %10.0f" % (names[i], acc[i]))
 print("  %-28s %10.0f" % ("total", acc[1:].sum()))
+c2 = b.fetch(12, 0).view(np.int64)
+print("scatter sub-phases (window 0, wave 0): visual %d  imu %d  prior-g %d  Bs %d" % (c2[13]-c2[2], c2[14]-c2[13], c2[15]-c2[14], c2[3]-c2[15]))
 print("k_visual_linearize first chunk: total %.0f  proj %.0f  gram %.0f  (n=%.1f kmax=%.1f)" % tuple(vis))
 print("k_imu_linearize factor 0: raw %.0f  whiten %.0f  gram %.0f" % tuple(imu))
