@@ -620,7 +620,7 @@ template <int N> struct IC { static constexpr int value = N; };
 
 __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ unsigned short tab26[352], tab39[784], slot_st[512];
+  __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
   __shared__ int s_flag[4];
   const int win = blockIdx.x;
@@ -660,22 +660,10 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       act[cd] = a;
       inv_pmap[cd] = -1;
     }
-    for (int e = tid; e < 784; e += SOLVE_THREADS) {
-      if (e < VILO_GRAM) { int a = 0, rem = e; while (rem >= 26 - a) { rem -= 26 - a; ++a; } tab26[e] = (unsigned short)(a | ((a + rem) << 8)); }
-      if (e < 780) { int a = 0, rem = e; while (rem >= 39 - a) { rem -= 39 - a; ++a; } tab39[e] = (unsigned short)(a | ((a + rem) << 8)); }
-    }
-    // slot table (s, t) of the window's Gram slots: chunk metas read in parallel, prefix by thread 0 from LDS
-    if (tid < wm.n_chunks && tid < 256) {
+    // chunk table (s, kmax, first Gram slot) of the window
+    if (tid < wm.n_chunks && tid < 64) {
       const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
-      red[tid] = (double)(cm.s | (cm.kmax << 8));
-    }
-    lds_barrier();
-    if (tid == 0) {
-      int sl = 0;
-      for (int ch = 0; ch < wm.n_chunks && ch < 256; ++ch) {
-        const int v = (int)red[ch], cs = v & 255, km = v >> 8;
-        for (int t = 0; t < km && sl < 512; ++t) slot_st[sl++] = (unsigned short)(cs | (t << 8));
-      }
+      chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
     }
     __syncthreads();
     for (int i = tid; i < pn; i += SOLVE_THREADS) inv_pmap[pmap[i]] = (short)i;
@@ -741,112 +729,145 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
         for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < 13 * 80) Bp[e] = bpv[u]; }
         for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) Ao[e] = 0.0;
       }
-      for (int e = tid; e < CD_N; e += SOLVE_THREADS) g[e] = 0.0;
+      // gradient starts from the prior's b0 + H dx (H dx at the current point was formed by k_accept when it evaluated this
+      // point's cost), gathered through the inverse prior map so that every g entry has one writer
+      for (int e = tid; e < CD_N; e += SOLVE_THREADS) {
+        const int pi = inv_pmap[e];
+        g[e] = (pn > 0 && pi >= 0) ? b.prior_b0[(size_t)win * 96 + pi] + b.prior_hd[(size_t)win * 96 + pi] : 0.0;
+      }
       __syncthreads();
       if (tid == 0) st.phase_clk[2] = clock64();
       {
-        auto ladd = [](double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-        // pose-block entries: only the lower tile positions are consumed (tiles I >= J); entries inside a diagonal tile
-        // are mirrored
-        auto addC = [&](int pa, int pb, double v) {
-          const int hi = max(pa, pb), lo = min(pa, pb);
-          ladd(&C[hi * CLD + lo], v);
-          if (hi != lo && (hi >> 4) == (lo >> 4)) ladd(&C[lo * CLD + hi], v);
+        // Plain (non-atomic) read-modify-write scatter: the work is split so that every target of C / g / Ad / Ao has exactly
+        // one owner thread. Two packed Gram entries can hit the same target only if they are "twins" (the same local pair
+        // taken once in the pose_s block and once in the pose_j block; for IMU factors once in the frame-i half and once in
+        // the frame-j half of the previous factor), so a thread owns an entry together with its twin.
+        auto rmw = [&](double *base, int hi, int lo, double v) {   // lower position + mirror inside a diagonal 16-block
+          base[hi * CLD + lo] += v;
+          if (hi != lo && (hi >> 4) == (lo >> 4)) base[lo * CLD + hi] += v;
         };
-        // visual Gram slots -> C, g. A thread keeps one packed entry (a, bc) and walks the window's (s, t) slots. The target
-        // index is affine in (s, j = s + t), so the walk is branch-free: 16 coalesced loads are issued, then 16-32 ds_add_f64.
         const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
         const int ns = wm.n_gram;
-        // IMU Gram entries of this thread (entries tid, tid + 256, ... of the 780, all 10 factors): loads issued first, they
-        // are consumed after the visual walk
-        double vi[4][10];
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
-          const int e = min(tid + SOLVE_THREADS * p4, 779);
-#pragma unroll
-          for (int k = 0; k < 10; ++k) vi[p4][k] = igram[min(k, F - 2) * 780 + e];
-        }
-        // entries tid and tid + 256 of the 351 visual ones, 16 slots per trip: 32 loads in flight per thread
-        int da[2], db[2];
-        int cas[2], caj[2], ca0v[2], cbs[2], cbj[2], cb0v[2];
-        bool cisg[2], cdead[2], cuj[2];
+        // ---- IMU loads first (consumed after the visual walk): groups tid and tid + 256 of the 336 ----
+        // classes: I1 pose_i x pose_i (21, twin +19), I2 bias_i x bias_i (91, twin +19), I3 gradient (19, twin +19),
+        //          I4 pose_i x pose_j (36), I5 bias_i x bias_j (169)
+        int ia[2], ib[2], icls[2];
+        double vim[2][10], vit[2][10];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int e = tid + SOLVE_THREADS * h, ec = min(e, VILO_GRAM - 1);
-          const int a = tab26[ec] & 255, bc = tab26[ec] >> 8;
-          da[h] = a; db[h] = bc;
-          cisg[h] = (bc == 25); cdead[h] = (cisg[h] && a == 25) || e >= VILO_GRAM;   // r^T r is not needed
-          cuj[h] = (a >= 6 && a < 12) || (bc >= 6 && bc < 12);
-          cas[h] = a < 6 ? 6 : 0; caj[h] = (a >= 6 && a < 12) ? 6 : 0;
-          ca0v[h] = a < 6 ? a : (a < 12 ? a - 6 : (a < 18 ? CD_EX0 + a - 12 : (a < 24 ? CD_EX1 + a - 18 : CD_TD)));
-          cbs[h] = bc < 6 ? 6 : 0; cbj[h] = (bc >= 6 && bc < 12) ? 6 : 0;
-          cb0v[h] = bc < 6 ? bc : (bc < 12 ? bc - 6 : (bc < 18 ? CD_EX0 + bc - 12 : (bc < 24 ? CD_EX1 + bc - 18 : CD_TD)));
+          int gid = tid + SOLVE_THREADS * h, a = 0, bc = 0, cls = 0;
+          if (gid < 21) { cls = 1; int rem = gid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+          else if (gid < 112) { cls = 2; int rem = gid - 21; while (rem >= 13 - a) { rem -= 13 - a; ++a; } bc = 6 + a + rem; a += 6; }
+          else if (gid < 131) { cls = 3; a = gid - 112; bc = 38; }
+          else if (gid < 167) { cls = 4; a = (gid - 131) / 6; bc = 19 + (gid - 131) % 6; }
+          else if (gid < 336) { cls = 5; a = 6 + (gid - 167) / 13; bc = 25 + (gid - 167) % 13; }
+          ia[h] = a; ib[h] = bc; icls[h] = cls;
+          const int e1 = tri39(a, bc), e2 = (cls >= 1 && cls <= 3) ? tri39(a + 19, cls == 3 ? 38 : bc + 19) : e1;
+#pragma unroll
+          for (int k = 0; k < 10; ++k) { vim[h][k] = igram[min(k, F - 2) * 780 + e1]; vit[h][k] = igram[min(k, F - 2) * 780 + e2]; }
         }
-        for (int sl0 = 0; sl0 < ns; sl0 += 16) {
-          double v[2][16];
-          int sv[16];
+        // ---- visual Gram slots: 246 owner groups, one per thread ----
+        // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
+        // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
+        {
+          int a = 0, bc = 0, cls = 0;
+          if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+          else if (tid < 57) { cls = 2; a = (tid - 21) / 6; bc = 6 + (tid - 21) % 6; }
+          else if (tid < 141) { cls = 3; a = (tid - 57) / 14; bc = 12 + (tid - 57) % 14; }
+          else if (tid < 246) { cls = 4; int rem = tid - 141; while (rem >= 14 - a) { rem -= 14 - a; ++a; } bc = 12 + a + rem; a += 12; }
+          const bool isg = (bc == 25), dead = (cls == 0) || (a == 25);
+          const int e1 = tri26(min(a, 25), bc), e2 = (cls == 1) ? tri26(a + 6, bc + 6) : (cls == 3 ? tri26(a + 6, bc) : e1);
+          auto restcd = [](int c) { return c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD); };
+          const int rb = (bc >= 12 && bc < 25) ? restcd(bc) : 0, ra_ = (a >= 12 && a < 25) ? restcd(a) : 0;
+          // Walk the window's chunks (fixed s, t = 0 .. kmax-1), two per trip = 44 loads in flight. Per chunk:
+          //  stage 1: the entry's own target depends on s only (V1, V3, V4): sum over t in a register, one read-modify-write
+          //  stage 2: the j-dependent target (twin of V1 / V3, the entry itself for V2): the kmax - 1 targets of a chunk are
+          //           distinct, so their reads are batched before their writes (no dependent LDS round trip per slot)
+          const int nch = min(wm.n_chunks, 64);
+          double *const gb = g;
+          for (int ch0 = 0; ch0 < nch; ch0 += 2) {
+            double v1[2][11], v2[2][11];
+            int cs2[2], km2[2];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int slc = min(sl0 + u, ns - 1);
-            sv[u] = slot_st[slc];
+            for (int c2 = 0; c2 < 2; ++c2) {
+              const unsigned ct = chunk_tab[min(ch0 + c2, nch - 1)];
+              cs2[c2] = ct & 255; km2[c2] = (ct >> 8) & 255;
+              const int sl0 = ct >> 16;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) v[h][u] = gs[(size_t)slc * VILO_GRAM + min(tid + SOLVE_THREADS * h, VILO_GRAM - 1)];
-          }
+              for (int t = 0; t < 11; ++t) {
+                const int tc = min(t, km2[c2] - 1);
+                v1[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
+                v2[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
+              }
+            }
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int s_ = sv[u] & 255, t_ = sv[u] >> 8, j_ = s_ + t_;
+            for (int c2 = 0; c2 < 2; ++c2) {
+              if (ch0 + c2 >= nch) continue;
+              const int s_ = cs2[c2], km = km2[c2];
+              // stage 1
+              if (cls != 2 && !dead) {
+                double sum = 0.0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const bool on = (sl0 + u < ns) && !(t_ == 0 && cuj[h]) && !cdead[h];   // OneFrameTwoCam has no pose_j columns
-              if (h == 1 && tid >= VILO_GRAM - SOLVE_THREADS) continue;
-              const double vv = on ? v[h][u] : 0.0;
-              const int pa = cas[h] * s_ + caj[h] * j_ + ca0v[h], pb = cisg[h] ? pa : cbs[h] * s_ + cbj[h] * j_ + cb0v[h];
-              const int hi = max(pa, pb), lo = min(pa, pb);
-              double *tgt = cisg[h] ? &g[pa] : &C[hi * CLD + lo];
-              ladd(tgt, vv);
-              if (!cisg[h] && hi != lo && (hi >> 4) == (lo >> 4)) ladd(&C[lo * CLD + hi], vv);
+                for (int t = 0; t < 11; ++t) sum += (t < km) ? v1[c2][t] : 0.0;
+                if (isg) gb[cls == 4 ? ra_ : 6 * s_ + a] += sum;
+                else if (cls == 1) rmw(C, 6 * s_ + bc, 6 * s_ + a, sum);
+                else if (cls == 3) rmw(C, rb, 6 * s_ + a, sum);
+                else rmw(C, rb, ra_, sum);
+              }
+              // stage 2
+              if (cls >= 1 && cls <= 3) {
+                double *pt[11], *pm[11];
+                double o1[11], o2[11];
+#pragma unroll
+                for (int t = 1; t < 11; ++t) {
+                  const int j_ = s_ + t;
+                  int hi, lo;
+                  if (cls == 1) { hi = 6 * j_ + bc; lo = 6 * j_ + a; }
+                  else if (cls == 2) { hi = 6 * j_ + (bc - 6); lo = 6 * s_ + a; }
+                  else { hi = rb; lo = 6 * j_ + a; }
+                  const bool ong = (cls == 3) && isg;
+                  pt[t] = ong ? &gb[6 * j_ + a] : &C[hi * CLD + lo];
+                  pm[t] = (!ong && hi != lo && (hi >> 4) == (lo >> 4)) ? &C[lo * CLD + hi] : nullptr;
+                }
+#pragma unroll
+                for (int t = 1; t < 11; ++t) {
+                  if (t < km) { o1[t] = *pt[t]; if (pm[t]) o2[t] = *pm[t]; }
+                }
+#pragma unroll
+                for (int t = 1; t < 11; ++t) {
+                  if (t < km) {
+                    const double val = (cls == 2) ? v1[c2][t] : v2[c2][t];
+                    *pt[t] = o1[t] + val;
+                    if (pm[t]) *pm[t] = o2[t] + val;
+                  }
+                }
+              }
             }
           }
         }
         if (tid == 0) st.phase_clk[13] = clock64();
-        // IMULegFactor Grams (39x39 packed, column 38 = residual): P x P -> C, B x B -> Ad / Ao, gradient. The target address
-        // of a packed entry is affine in the factor number k.
+        __syncthreads();   // the IMU owners below are different threads
 #pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
-          const int e = tid + SOLVE_THREADS * p4;
-          if (e >= 780) continue;
-          const int a = tab39[e] & 255, bc = tab39[e] >> 8;
-          // camera dim of local column c of factor k: c0 + ck * k
-          auto c0of = [](int c) { return c < 6 ? c : (c < 19 ? CD_B0 + (c - 6) : (c < 25 ? 6 + (c - 19) : CD_B0 + 13 + (c - 25))); };
-          auto ckof = [](int c) { return (c < 6 || (c >= 19 && c < 25)) ? 6 : 13; };
-          const bool aP = (a < 6) || (a >= 19 && a < 25), bP = (bc < 6) || (bc >= 19 && bc < 25);
-          const int ca0 = c0of(a), cak = ckof(a), cb0 = c0of(min(bc, 37)), cbk = ckof(min(bc, 37));
-          // kind: 0 skip, 1 gradient, 2 pose x pose (C), 3 same-frame bias block (Ad), 4 cross-frame bias block (Ao)
-          int kind = 0;
-          if (a < 38) {
-            if (bc == 38) kind = 1;
-            else if (aP && bP) kind = 2;
-            else if (!aP && !bP) kind = ((a < 19) == (bc < 19)) ? 3 : 4;
-          }
-          const int ra = (ca0 - CD_B0) % 13, rc = (cb0 - CD_B0) % 13;   // local rows inside the 13-blocks (kinds 3, 4)
-          const int fa = (a < 19) ? 0 : 1;                              // frame offset of the bias block of a (kinds 3, 4)
+        for (int h = 0; h < 2; ++h) {
+          const int a = ia[h], bc = ib[h], cls = icls[h];
+          if (cls == 0) continue;
 #pragma unroll
           for (int k = 0; k < 10; ++k) {
-            const double vv = (k < F - 1 && kind != 0) ? vi[p4][k] : 0.0;
-            const int ca = ca0 + cak * k, cb = cb0 + cbk * k;
-            double *tgt = &g[ca];
-            double *mir = nullptr;
-            if (kind == 2) { tgt = &C[cb * CLD + ca]; if (ca != cb && (ca >> 4) == (cb >> 4)) mir = &C[ca * CLD + cb]; }
-            else if (kind == 3) { tgt = &Ad[(k + fa) * 169 + ra * 13 + rc]; if (ra != rc) mir = &Ad[(k + fa) * 169 + rc * 13 + ra]; }
-            else if (kind == 4) tgt = &Ao[k * 169 + rc * 13 + ra];   // rows frame k+1, cols frame k
-            ladd(tgt, vv);
-            if (mir) ladd(mir, vv);
+            if (k >= F - 1) continue;
+            const double vm = vim[h][k], vt = vit[h][k];
+            if (cls == 1) { rmw(C, 6 * k + bc, 6 * k + a, vm); rmw(C, 6 * (k + 1) + bc, 6 * (k + 1) + a, vt); }
+            else if (cls == 2) {
+              const int ra = a - 6, rc = bc - 6;
+              Ad[k * 169 + ra * 13 + rc] += vm; Ad[(k + 1) * 169 + ra * 13 + rc] += vt;
+              if (ra != rc) { Ad[k * 169 + rc * 13 + ra] += vm; Ad[(k + 1) * 169 + rc * 13 + ra] += vt; }
+            } else if (cls == 3) {
+              const int c0 = a < 6 ? a : CD_B0 + (a - 6), ck = a < 6 ? 6 : 13;
+              g[c0 + ck * k] += vm; g[c0 + ck * (k + 1)] += vt;
+            } else if (cls == 4) rmw(C, 6 * (k + 1) + (bc - 19), 6 * k + a, vm);
+            else Ao[k * 169 + (bc - 25) * 13 + (a - 6)] += vm;   // rows frame k+1, cols frame k
           }
         }
         if (tid == 0) st.phase_clk[14] = clock64();
-        // marginalisation prior gradient: g += J0^T (r0 + J0 dx) = b0 + H dx. H dx at the current point was formed by
-        // k_accept when it evaluated this point's cost (b.prior_hd), so no 86 x 86 product here.
-        if (tid < pn) ladd(&g[pmap[tid]], b.prior_b0[(size_t)win * 96 + tid] + b.prior_hd[(size_t)win * 96 + tid]);
         if (tid == 0) st.phase_clk[15] = clock64();
         if (tid < 13 * 18) {
           const int i = tid / 18, sl = tid % 18, df = sl / 6, c = sl % 6;
