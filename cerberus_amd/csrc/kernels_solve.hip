@@ -83,6 +83,7 @@ __device__ double block_max(double v, double *red) {
 // =================================================================================================
 // k_visual_linearize
 // =================================================================================================
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #define XLANE 54  // LDS stride per lane: 2 rows x 26 cols + 2 pad; even so that every row starts 16-byte aligned (ds_read_b128)
 
 __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) {
@@ -100,22 +101,12 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
   const int li = cm.lm_local + lane;
 
-  // Gram ownership: lane owns one 8-wide segment (row a, columns b0 .. b0+7) of the upper triangle, b0 even so that the
-  // segment is read with four ds_read_b128 (which reach full LDS rate from one wave per SIMD; ds_read_b64 reaches a
-  // fifth). 56 segments cover the 351 entries; the few columns left of the diagonal / right of column 25 are computed
-  // and dropped.
-  int seg_a = 0, seg_b0 = 0;
-  bool seg_on = false;
-  {
-    int cnt = 0;
-    for (int a = 0; a < 26; ++a) {
-      const int bs = a & ~1, nseg = (26 - bs + 7) / 8;
-      for (int q = 0; q < nseg; ++q) {
-        if (cnt == lane) { seg_a = a; seg_b0 = bs + 8 * q; seg_on = true; }
-        ++cnt;
-      }
-    }
-  }
+  // Gram of a (start frame, t) slot on the FP64 matrix cores: X^T X with X = the 2 n corrected Jacobian rows (26 columns,
+  // padded to 32) as three 16 x 16 tiles (0,0), (0,1), (1,1). One k-step = 4 rows = 2 landmarks; lane (lr, lk) supplies
+  // X[row 4 kk + lk][lr] (tile column 0) and X[..][16 + lr] (tile column 1), which serve as A and B operands alike.
+  const int lr = lane & 15, lk = lane >> 4;
+  const int xoff = (lk >> 1) * XLANE + (lk & 1) * 26 + lr;
+  const bool c1on = lr < 10;   // columns 26 .. 31 of the second tile column do not exist
   if (active)
     for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
@@ -159,8 +150,7 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
 #pragma unroll
       for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
     }
-    double acc[8];
-    for (int m = 0; m < 8; ++m) acc[m] = 0.0;
+    mfma_d4 G00 = {0.0, 0.0, 0.0, 0.0}, G01 = G00, G11 = G00;
     double wj[6];
     for (int c = 0; c < 6; ++c) wj[c] = 0.0;
 
@@ -213,49 +203,35 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
       }
       lds_barrier();
       { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
-      // rows of lanes >= n are zero (those lanes store zeros above) and the pad rows behind lane 63 are zeroed once, so
-      // the row count is rounded up to 8; software pipeline: the LDS reads of the next 4 rows are in flight while the
-      // FMAs of the current 4 rows issue
-      const int nrows = (2 * n + 7) & ~7;
-      double xa0[4], xa1[4];
-      double2 xb0[4][4], xb1[4][4];
-      auto ld4 = [&](int row, double *xa, double2 (*xb)[4]) {
+      // rows of lanes >= n are zero (those lanes store zeros above), so the k-step count is rounded up to a multiple of 4
+      // (rows 128 .. are the zero pad lanes): 8 LDS reads in flight, then 12 MFMAs
+      const int nks = ((2 * n + 3) >> 2), nks4 = (nks + 3) & ~3;
+      for (int kk0 = 0; kk0 < nks4; kk0 += 4) {
+        double a0[4], a1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int base = ((row + u) >> 1) * XLANE + ((row + u) & 1) * 26;
-          xa[u] = X[base + seg_a];
-          const double2 *p = reinterpret_cast<const double2 *>(&X[base + seg_b0]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xb[u][i] = p[i];
+          const double *xr = &X[2 * (kk0 + u) * XLANE + xoff];
+          a0[u] = xr[0];
+          a1[u] = xr[16];
         }
-      };
-      auto fma4 = [&](const double *xa, const double2 (*xb)[4]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { acc[2 * i] += xa[u] * xb[u][i].x; acc[2 * i + 1] += xa[u] * xb[u][i].y; }
-      };
-      ld4(0, xa0, xb0);
-      for (int row = 0; row < nrows; row += 8) {
-        ld4(row + 4, xa1, xb1);
-        fma4(xa0, xb0);
-        ld4(row + 8, xa0, xb0);   // rows 128 .. 135 are the zero pad
-        fma4(xa1, xb1);
-        // pin the issue order (the scheduler otherwise hoists all 36 reads above the 64 FMAs and waits for all of them):
-        // 18 LDS reads (16 b128 + 2 read2_b64) in flight behind each group of 32 FMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+        for (int u = 0; u < 4; ++u) {
+          const double b1 = c1on ? a1[u] : 0.0;
+          G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], G00, 0, 0, 0);
+          G01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1, G01, 0, 0, 0);
+          G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, G11, 0, 0, 0);
+        }
       }
       lds_barrier();
       c_gram += clock64() - c_a;
     }
     double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int bc = seg_b0 + m;
-      if (seg_on && bc >= seg_a && bc < 26) gs[tri26(seg_a, bc)] = acc[m];
+    for (int r = 0; r < 4; ++r) {
+      const int row = lk + 4 * r;
+      if (row <= lr) gs[tri26(row, lr)] = G00[r];
+      if (c1on) gs[tri26(row, 16 + lr)] = G01[r];
+      if (c1on && row < 10 && row <= lr) gs[tri26(16 + row, 16 + lr)] = G11[r];
     }
     if (active && t > 0 && (fl & 1))
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
@@ -361,7 +337,6 @@ __global__ void __launch_bounds__(64) k_imu_raw(BatchDev b, double g_norm) {
 // Operand layout of the instruction: A(16 x 4): lane l holds A[l % 16][l / 16]; B(4 x 16): lane l holds B[l / 16][l % 16];
 // C/D(16 x 16): register r of lane l is C[(l / 16) + 4 r][l % 16].
 #define IW_JS 48   // LDS row stride of Jw (conflict-free operand reads of the Gram pass)
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(64) k_imu_whiten(BatchDev b) {
   __shared__ double Jw[32 * IW_JS];
