@@ -593,763 +593,832 @@ template <int N> struct IC { static constexpr int value = N; };
 #define NTILE(WV) ((WV) == 3 ? 3 : 4)
 #define WAVE_DISPATCH3(fn) do { if (wv == 0) fn(IC<0>{}); else if (wv == 1) fn(IC<1>{}); else if (wv == 2) fn(IC<2>{}); } while (0)
 
-__global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ unsigned chunk_tab[64];
-  __shared__ short inv_pmap[CD_N];
-  __shared__ int s_flag[4];
-  const int win = blockIdx.x;
-  SolverState &st = b.st[win];
-  if (st.done) return;
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = tid & 15, lk = (tid >> 4) & 3;   // wave (uniform), MFMA lane coordinates
-  const WinMeta wm = b.win[win];
-  double *C = lds + LDS_C, *Ad = lds + LDS_AD, *Ao = lds + LDS_AO, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y;
-  double *tmp = lds + LDS_TMP, *act = lds + LDS_ACT, *Lk = lds + LDS_LK, *S = lds + LDS_S, *red = lds + LDS_RED, *col = lds + LDS_COL;
-  double *Bk = S, *Bkm1 = S + 1040, *T = S + 2080, *Bs = lds + LDS_BS, *Bp = lds + LDS_BP;
-  double *Tm = b.Tm + (size_t)win * 11 * 13 * 96, *Lkm = b.Lk + (size_t)win * 11 * 169;
-  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
-  double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
-  double *cam_scale = b.cam_scale + (size_t)win * CD_N;
-  const int L = wm.L, F = wm.n_frames;
-  const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
-  const double *igram = b.imu_gram + (size_t)win * 10 * 780;
-  const int pn = wm.prior_n;
-  const double *Hp = b.prior_H + (size_t)win * 96 * 96;
-  const int *pmap = b.prior_map + (size_t)win * 96;
+// ---------------------------------------------------------------------------------------------------------------------
+// k_build_solve is one workgroup per window; its phases are separate __noinline__ functions that communicate through
+// LDS only (the matrix image in the dynamic LDS block, scalars and tables in KCtx). Keeping the phases apart bounds the
+// live ranges: as one function the kernel spilled ~200 doubles per lane to scratch and every small loop paid for it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct KCtx {
+  double *x, *xc, *Tm, *Lkm, *cam_g, *cam_dh2, *cam_y, *cam_scale, *lm_E, *lm_g, *lm_dh2, *lm_scale, *lm_einv, *lm_y;
+  const double *wl, *igram, *gs, *pd, *pb0, *phd, *Hp;
+  const int *pmap;
+  const ChunkMeta *chunks;
+  SolverState *st;
+  int win, F, L, pn, kb, n_chunks, n_gram, const_mask, gram_off;
+  double mu, gnorm2, gmax, qq, gnnorm2, gy;
+  SolveParams sp;
+  short inv_pmap[CD_N];
+  unsigned chunk_tab[64];
+  int s_flag[4];
+};
+extern __shared__ __attribute__((aligned(16))) double lds[];
+__shared__ KCtx kc;
 
-  if (st.need_lin) {
-    if (tid == 0) st.phase_clk[0] = clock64();
-    // ---- tables ----
-    for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-      double a = 1.0;
-      if (cd >= CD_EX0 && cd < CD_TD && (wm.const_mask & CONST_EX)) a = 0.0;
-      if (cd == CD_TD && (wm.const_mask & CONST_TD)) a = 0.0;
-      if (cd == 79 || cd >= CD_B0 + 143) a = 0.0;
-      if (cd < 66 && cd / 6 >= F) a = 0.0;
-      if (cd >= CD_B0 && cd < CD_B0 + 143) {
-        const int k = (cd - CD_B0) / 13, c = (cd - CD_B0) % 13;
-        if (k >= F) a = 0.0;
-        if (c >= 9 && (wm.const_mask & CONST_LB)) a = 0.0;
-      }
-      act[cd] = a;
-      inv_pmap[cd] = -1;
+#define KB_LOCALS                                                                                                         \
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;                                                              \
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = tid & 15, lk = (tid >> 4) & 3;                             \
+  (void)ty; (void)tx; (void)wv; (void)lr; (void)lk;                                                                       \
+  double *C = lds + LDS_C, *Ad = lds + LDS_AD, *Ao = lds + LDS_AO, *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y; \
+  double *tmp = lds + LDS_TMP, *act = lds + LDS_ACT, *Lk = lds + LDS_LK, *S = lds + LDS_S, *red = lds + LDS_RED, *col = lds + LDS_COL; \
+  double *Bs = lds + LDS_BS, *Bp = lds + LDS_BP;                                                                          \
+  (void)C; (void)Ad; (void)Ao; (void)g; (void)dh2; (void)y; (void)tmp; (void)act; (void)Lk; (void)S; (void)red; (void)col; (void)Bs; (void)Bp; \
+  SolverState &st = *kc.st;                                                                                               \
+  const SolveParams &sp = kc.sp;                                                                                          \
+  const int win = kc.win, F = kc.F, L = kc.L, pn = kc.pn, kb = kc.kb;                                                     \
+  (void)win; (void)F; (void)L; (void)pn; (void)kb; (void)sp;                                                              \
+  short *inv_pmap = kc.inv_pmap; unsigned *chunk_tab = kc.chunk_tab; int *s_flag = kc.s_flag;                             \
+  (void)inv_pmap; (void)chunk_tab; (void)s_flag;                                                                          \
+  auto Bval = [&](int k, int i, int p) -> double {                                                                        \
+    if (act[CD_B0 + 13 * k + i] == 0.0 || act[p] == 0.0) return 0.0;                                                      \
+    double v = 0.0;                                                                                                       \
+    if (p < 66) {                                                                                                         \
+      const int f = p / 6, df = f - k + 1;                                                                                \
+      if (df >= 0 && df <= 2) v = Bs[(k * 13 + i) * 18 + 6 * df + (p - 6 * f)];                                           \
+    }                                                                                                                     \
+    if (k == kb) v += Bp[i * 80 + p];                                                                                     \
+    return v;                                                                                                             \
+  };                                                                                                                      \
+  (void)Bval;
+
+__device__ __noinline__ void ph_tables() {
+  KB_LOCALS
+  const WinMeta wm_c = {kc.F, kc.L, kc.n_chunks, 0, 0, 0, kc.const_mask, kc.pn, kc.gram_off, kc.n_gram, 0, kc.kb};
+  const WinMeta &wm = wm_c; const int *pmap = kc.pmap; const ChunkMeta *chunkp = kc.chunks;
+  // ---- tables ----
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+    double a = 1.0;
+    if (cd >= CD_EX0 && cd < CD_TD && (wm.const_mask & CONST_EX)) a = 0.0;
+    if (cd == CD_TD && (wm.const_mask & CONST_TD)) a = 0.0;
+    if (cd == 79 || cd >= CD_B0 + 143) a = 0.0;
+    if (cd < 66 && cd / 6 >= F) a = 0.0;
+    if (cd >= CD_B0 && cd < CD_B0 + 143) {
+      const int k = (cd - CD_B0) / 13, c = (cd - CD_B0) % 13;
+      if (k >= F) a = 0.0;
+      if (c >= 9 && (wm.const_mask & CONST_LB)) a = 0.0;
     }
-    // chunk table (s, kmax, first Gram slot) of the window
-    if (tid < wm.n_chunks && tid < 64) {
-      const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
-      chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
+    act[cd] = a;
+    inv_pmap[cd] = -1;
+  }
+  // chunk table (s, kmax, first Gram slot) of the window
+  if (tid < wm.n_chunks && tid < 64) {
+    const ChunkMeta cm = chunkp[tid];
+    chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
+  }
+  __syncthreads();
+  for (int i = tid; i < pn; i += SOLVE_THREADS) inv_pmap[pmap[i]] = (short)i;
+  __syncthreads();
+
+}
+
+__device__ __noinline__ void ph_assemble() {
+  KB_LOCALS
+  const double *igram = kc.igram; (void)igram;
+  //      independent coalesced load + 1-2 atomic adds, so the L2 latency overlaps across entries ----
+  // start from the prior's pre-assembled image (all zeros without a prior): coalesced copies instead of zero fill + scatter
+  {
+    const double *pd = kc.pd;
+    // C and Ad are contiguous in LDS and in the image: 8339 doubles = 33 per thread, all loads in flight at once
+    double pv[33];
+#pragma unroll
+    for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; pv[u] = pd[min(e, PD_BP - 1)]; }
+    double bpv[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; bpv[u] = pd[PD_BP + min(e, 13 * 80 - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < PD_BP) C[e] = pv[u]; }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < 13 * 80) Bp[e] = bpv[u]; }
+    for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) Ao[e] = 0.0;
+  }
+  // gradient starts from the prior's b0 + H dx (H dx at the current point was formed by k_accept when it evaluated this
+  // point's cost), gathered through the inverse prior map so that every g entry has one writer
+  for (int e = tid; e < CD_N; e += SOLVE_THREADS) {
+    const int pi = inv_pmap[e];
+    g[e] = (pn > 0 && pi >= 0) ? kc.pb0[pi] + kc.phd[pi] : 0.0;
+  }
+  __syncthreads();
+  if (tid == 0) st.phase_clk[2] = clock64();
+  {
+    // Plain (non-atomic) read-modify-write scatter: the work is split so that every target of C / g / Ad / Ao has exactly
+    // one owner thread. Two packed Gram entries can hit the same target only if they are "twins" (the same local pair
+    // taken once in the pose_s block and once in the pose_j block; for IMU factors once in the frame-i half and once in
+    // the frame-j half of the previous factor), so a thread owns an entry together with its twin.
+    auto rmw = [&](double *base, int hi, int lo, double v) {   // lower position + mirror inside a diagonal 16-block
+      base[hi * CLD + lo] += v;
+      if (hi != lo && (hi >> 4) == (lo >> 4)) base[lo * CLD + hi] += v;
+    };
+    const double *gs = kc.gs;
+    const int ns = kc.n_gram;
+    // ---- IMU loads first (consumed after the visual walk): groups tid and tid + 256 of the 336 ----
+    // classes: I1 pose_i x pose_i (21, twin +19), I2 bias_i x bias_i (91, twin +19), I3 gradient (19, twin +19),
+    //          I4 pose_i x pose_j (36), I5 bias_i x bias_j (169)
+    int ia[2], ib[2], icls[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int gid = tid + SOLVE_THREADS * h, a = 0, bc = 0, cls = 0;
+      if (gid < 21) { cls = 1; int rem = gid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+      else if (gid < 112) { cls = 2; int rem = gid - 21; while (rem >= 13 - a) { rem -= 13 - a; ++a; } bc = 6 + a + rem; a += 6; }
+      else if (gid < 131) { cls = 3; a = gid - 112; bc = 38; }
+      else if (gid < 167) { cls = 4; a = (gid - 131) / 6; bc = 19 + (gid - 131) % 6; }
+      else if (gid < 336) { cls = 5; a = 6 + (gid - 167) / 13; bc = 25 + (gid - 167) % 13; }
+      ia[h] = a; ib[h] = bc; icls[h] = cls;
     }
-    __syncthreads();
-    for (int i = tid; i < pn; i += SOLVE_THREADS) inv_pmap[pmap[i]] = (short)i;
-    const int kb = wm.pad;   // frame whose speed/leg-bias block the prior touches (-1: none), resolved when the batch is packed
-    __syncthreads();
-
-    // B_k(i, p): speed/leg-bias (frame k, local row i) x pose-part coupling, gathered from the IMU Grams and the prior
-#ifdef VILO_BVAL_GATHER
-    auto Bval = [&](int k, int i, int p) -> double {
-      if (act[CD_B0 + 13 * k + i] == 0.0 || act[p] == 0.0) return 0.0;
-      double v = 0.0;
-      if (p < 66) {
-        const int f = p / 6, c = p - 6 * f;
-        if (k + 1 < F) {
-          if (f == k) v += igram[k * 780 + tri39(c, 6 + i)];
-          else if (f == k + 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
+    // ---- visual Gram slots: 246 owner groups, one per thread ----
+    // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
+    // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
+    {
+      int a = 0, bc = 0, cls = 0;
+      if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+      else if (tid < 57) { cls = 2; a = (tid - 21) / 6; bc = 6 + (tid - 21) % 6; }
+      else if (tid < 141) { cls = 3; a = (tid - 57) / 14; bc = 12 + (tid - 57) % 14; }
+      else if (tid < 246) { cls = 4; int rem = tid - 141; while (rem >= 14 - a) { rem -= 14 - a; ++a; } bc = 12 + a + rem; a += 12; }
+      const bool isg = (bc == 25), dead = (cls == 0) || (a == 25);
+      const int e1 = tri26(min(a, 25), bc), e2 = (cls == 1) ? tri26(a + 6, bc + 6) : (cls == 3 ? tri26(a + 6, bc) : e1);
+      auto restcd = [](int c) { return c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD); };
+      const int rb = (bc >= 12 && bc < 25) ? restcd(bc) : 0, ra_ = (a >= 12 && a < 25) ? restcd(a) : 0;
+      // Walk the window's chunks (fixed s, t = 0 .. kmax-1), two per trip = 44 loads in flight. Per chunk:
+      //  stage 1: the entry's own target depends on s only (V1, V3, V4): sum over t in a register, one read-modify-write
+      //  stage 2: the j-dependent target (twin of V1 / V3, the entry itself for V2): the kmax - 1 targets of a chunk are
+      //           distinct, so their reads are batched before their writes (no dependent LDS round trip per slot)
+      const int nch = min(kc.n_chunks, 64);
+      double *const gb = g;
+      for (int ch0 = 0; ch0 < nch; ch0 += 2) {
+        double v1[2][11], v2[2][11];
+        int cs2[2], km2[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const unsigned ct = chunk_tab[min(ch0 + c2, nch - 1)];
+          cs2[c2] = ct & 255; km2[c2] = (ct >> 8) & 255;
+          const int sl0 = ct >> 16;
+#pragma unroll
+          for (int t = 0; t < 11; ++t) {
+            const int tc = min(t, km2[c2] - 1);
+            v1[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
+            v2[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
+          }
         }
-        if (k > 0) {
-          if (f == k - 1) v += igram[(k - 1) * 780 + tri39(c, 25 + i)];
-          else if (f == k) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
-        }
-      }
-      if (k == kb) {
-        const int pi = inv_pmap[CD_B0 + 13 * k + i], pp = inv_pmap[p];
-        if (pi >= 0 && pp >= 0) v += Hp[(size_t)pi * pn + pp];
-      }
-      return v;
-    };
-#else
-    auto Bval = [&](int k, int i, int p) -> double {
-      if (act[CD_B0 + 13 * k + i] == 0.0 || act[p] == 0.0) return 0.0;
-      double v = 0.0;
-      if (p < 66) {
-        const int f = p / 6, df = f - k + 1;
-        if (df >= 0 && df <= 2) v = Bs[(k * 13 + i) * 18 + 6 * df + (p - 6 * f)];
-      }
-      if (k == kb) v += Bp[i * 80 + p];
-      return v;
-    };
-#endif
-
-    bool solved = false;
-    while (!solved) {
-      __syncthreads();
-      const double mu = st.mu;
-      if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-      if (tid == 0) st.phase_clk[1] = clock64();
-      // ---- assembly: barrier-free scatter with LDS FP64 atomics (ds_add_f64); every Gram entry of every slot is an
-      //      independent coalesced load + 1-2 atomic adds, so the L2 latency overlaps across entries ----
-      // start from the prior's pre-assembled image (all zeros without a prior): coalesced copies instead of zero fill + scatter
-      {
-        const double *pd = b.prior_dense + (size_t)win * PD_N;
-        // C and Ad are contiguous in LDS and in the image: 8339 doubles = 33 per thread, all loads in flight at once
-        double pv[33];
 #pragma unroll
-        for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; pv[u] = pd[min(e, PD_BP - 1)]; }
-        double bpv[5];
+        for (int c2 = 0; c2 < 2; ++c2) {
+          if (ch0 + c2 >= nch) continue;
+          const int s_ = cs2[c2], km = km2[c2];
+          // stage 1
+          if (cls != 2 && !dead) {
+            double sum = 0.0;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; bpv[u] = pd[PD_BP + min(e, 13 * 80 - 1)]; }
+            for (int t = 0; t < 11; ++t) sum += (t < km) ? v1[c2][t] : 0.0;
+            if (isg) gb[cls == 4 ? ra_ : 6 * s_ + a] += sum;
+            else if (cls == 1) rmw(C, 6 * s_ + bc, 6 * s_ + a, sum);
+            else if (cls == 3) rmw(C, rb, 6 * s_ + a, sum);
+            else rmw(C, rb, ra_, sum);
+          }
+          // stage 2
+          if (cls >= 1 && cls <= 3) {
+            double *pt[11], *pm[11];
+            double o1[11], o2[11];
 #pragma unroll
-        for (int u = 0; u < 33; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < PD_BP) C[e] = pv[u]; }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) { const int e = tid + SOLVE_THREADS * u; if (e < 13 * 80) Bp[e] = bpv[u]; }
-        for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) Ao[e] = 0.0;
-      }
-      // gradient starts from the prior's b0 + H dx (H dx at the current point was formed by k_accept when it evaluated this
-      // point's cost), gathered through the inverse prior map so that every g entry has one writer
-      for (int e = tid; e < CD_N; e += SOLVE_THREADS) {
-        const int pi = inv_pmap[e];
-        g[e] = (pn > 0 && pi >= 0) ? b.prior_b0[(size_t)win * 96 + pi] + b.prior_hd[(size_t)win * 96 + pi] : 0.0;
-      }
-      __syncthreads();
-      if (tid == 0) st.phase_clk[2] = clock64();
-      {
-        // Plain (non-atomic) read-modify-write scatter: the work is split so that every target of C / g / Ad / Ao has exactly
-        // one owner thread. Two packed Gram entries can hit the same target only if they are "twins" (the same local pair
-        // taken once in the pose_s block and once in the pose_j block; for IMU factors once in the frame-i half and once in
-        // the frame-j half of the previous factor), so a thread owns an entry together with its twin.
-        auto rmw = [&](double *base, int hi, int lo, double v) {   // lower position + mirror inside a diagonal 16-block
-          base[hi * CLD + lo] += v;
-          if (hi != lo && (hi >> 4) == (lo >> 4)) base[lo * CLD + hi] += v;
-        };
-        const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
-        const int ns = wm.n_gram;
-        // ---- IMU loads first (consumed after the visual walk): groups tid and tid + 256 of the 336 ----
-        // classes: I1 pose_i x pose_i (21, twin +19), I2 bias_i x bias_i (91, twin +19), I3 gradient (19, twin +19),
-        //          I4 pose_i x pose_j (36), I5 bias_i x bias_j (169)
-        int ia[2], ib[2], icls[2];
-        double vim[2][10], vit[2][10];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int gid = tid + SOLVE_THREADS * h, a = 0, bc = 0, cls = 0;
-          if (gid < 21) { cls = 1; int rem = gid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
-          else if (gid < 112) { cls = 2; int rem = gid - 21; while (rem >= 13 - a) { rem -= 13 - a; ++a; } bc = 6 + a + rem; a += 6; }
-          else if (gid < 131) { cls = 3; a = gid - 112; bc = 38; }
-          else if (gid < 167) { cls = 4; a = (gid - 131) / 6; bc = 19 + (gid - 131) % 6; }
-          else if (gid < 336) { cls = 5; a = 6 + (gid - 167) / 13; bc = 25 + (gid - 167) % 13; }
-          ia[h] = a; ib[h] = bc; icls[h] = cls;
-          const int e1 = tri39(a, bc), e2 = (cls >= 1 && cls <= 3) ? tri39(a + 19, cls == 3 ? 38 : bc + 19) : e1;
-#pragma unroll
-          for (int k = 0; k < 10; ++k) { vim[h][k] = igram[min(k, F - 2) * 780 + e1]; vit[h][k] = igram[min(k, F - 2) * 780 + e2]; }
-        }
-        // ---- visual Gram slots: 246 owner groups, one per thread ----
-        // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
-        // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
-        {
-          int a = 0, bc = 0, cls = 0;
-          if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
-          else if (tid < 57) { cls = 2; a = (tid - 21) / 6; bc = 6 + (tid - 21) % 6; }
-          else if (tid < 141) { cls = 3; a = (tid - 57) / 14; bc = 12 + (tid - 57) % 14; }
-          else if (tid < 246) { cls = 4; int rem = tid - 141; while (rem >= 14 - a) { rem -= 14 - a; ++a; } bc = 12 + a + rem; a += 12; }
-          const bool isg = (bc == 25), dead = (cls == 0) || (a == 25);
-          const int e1 = tri26(min(a, 25), bc), e2 = (cls == 1) ? tri26(a + 6, bc + 6) : (cls == 3 ? tri26(a + 6, bc) : e1);
-          auto restcd = [](int c) { return c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD); };
-          const int rb = (bc >= 12 && bc < 25) ? restcd(bc) : 0, ra_ = (a >= 12 && a < 25) ? restcd(a) : 0;
-          // Walk the window's chunks (fixed s, t = 0 .. kmax-1), two per trip = 44 loads in flight. Per chunk:
-          //  stage 1: the entry's own target depends on s only (V1, V3, V4): sum over t in a register, one read-modify-write
-          //  stage 2: the j-dependent target (twin of V1 / V3, the entry itself for V2): the kmax - 1 targets of a chunk are
-          //           distinct, so their reads are batched before their writes (no dependent LDS round trip per slot)
-          const int nch = min(wm.n_chunks, 64);
-          double *const gb = g;
-          for (int ch0 = 0; ch0 < nch; ch0 += 2) {
-            double v1[2][11], v2[2][11];
-            int cs2[2], km2[2];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-              const unsigned ct = chunk_tab[min(ch0 + c2, nch - 1)];
-              cs2[c2] = ct & 255; km2[c2] = (ct >> 8) & 255;
-              const int sl0 = ct >> 16;
-#pragma unroll
-              for (int t = 0; t < 11; ++t) {
-                const int tc = min(t, km2[c2] - 1);
-                v1[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
-                v2[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
-              }
+            for (int t = 1; t < 11; ++t) {
+              const int j_ = s_ + t;
+              int hi, lo;
+              if (cls == 1) { hi = 6 * j_ + bc; lo = 6 * j_ + a; }
+              else if (cls == 2) { hi = 6 * j_ + (bc - 6); lo = 6 * s_ + a; }
+              else { hi = rb; lo = 6 * j_ + a; }
+              const bool ong = (cls == 3) && isg;
+              pt[t] = ong ? &gb[6 * j_ + a] : &C[hi * CLD + lo];
+              pm[t] = (!ong && hi != lo && (hi >> 4) == (lo >> 4)) ? &C[lo * CLD + hi] : nullptr;
             }
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-              if (ch0 + c2 >= nch) continue;
-              const int s_ = cs2[c2], km = km2[c2];
-              // stage 1
-              if (cls != 2 && !dead) {
-                double sum = 0.0;
+            for (int t = 1; t < 11; ++t) {
+              if (t < km) { o1[t] = *pt[t]; if (pm[t]) o2[t] = *pm[t]; }
+            }
 #pragma unroll
-                for (int t = 0; t < 11; ++t) sum += (t < km) ? v1[c2][t] : 0.0;
-                if (isg) gb[cls == 4 ? ra_ : 6 * s_ + a] += sum;
-                else if (cls == 1) rmw(C, 6 * s_ + bc, 6 * s_ + a, sum);
-                else if (cls == 3) rmw(C, rb, 6 * s_ + a, sum);
-                else rmw(C, rb, ra_, sum);
-              }
-              // stage 2
-              if (cls >= 1 && cls <= 3) {
-                double *pt[11], *pm[11];
-                double o1[11], o2[11];
-#pragma unroll
-                for (int t = 1; t < 11; ++t) {
-                  const int j_ = s_ + t;
-                  int hi, lo;
-                  if (cls == 1) { hi = 6 * j_ + bc; lo = 6 * j_ + a; }
-                  else if (cls == 2) { hi = 6 * j_ + (bc - 6); lo = 6 * s_ + a; }
-                  else { hi = rb; lo = 6 * j_ + a; }
-                  const bool ong = (cls == 3) && isg;
-                  pt[t] = ong ? &gb[6 * j_ + a] : &C[hi * CLD + lo];
-                  pm[t] = (!ong && hi != lo && (hi >> 4) == (lo >> 4)) ? &C[lo * CLD + hi] : nullptr;
-                }
-#pragma unroll
-                for (int t = 1; t < 11; ++t) {
-                  if (t < km) { o1[t] = *pt[t]; if (pm[t]) o2[t] = *pm[t]; }
-                }
-#pragma unroll
-                for (int t = 1; t < 11; ++t) {
-                  if (t < km) {
-                    const double val = (cls == 2) ? v1[c2][t] : v2[c2][t];
-                    *pt[t] = o1[t] + val;
-                    if (pm[t]) *pm[t] = o2[t] + val;
-                  }
-                }
+            for (int t = 1; t < 11; ++t) {
+              if (t < km) {
+                const double val = (cls == 2) ? v1[c2][t] : v2[c2][t];
+                *pt[t] = o1[t] + val;
+                if (pm[t]) *pm[t] = o2[t] + val;
               }
             }
           }
         }
-        if (tid == 0) st.phase_clk[13] = clock64();
-        __syncthreads();   // the IMU owners below are different threads
+      }
+    }
+    if (tid == 0) st.phase_clk[13] = clock64();
+    double vim[2][10], vit[2][10];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int a = ia[h], bc = ib[h], cls = icls[h];
-          if (cls == 0) continue;
+    for (int h = 0; h < 2; ++h) {
+      const int a = ia[h], bc = ib[h], cls = icls[h];
+      const int e1 = tri39(a, bc), e2 = (cls >= 1 && cls <= 3) ? tri39(a + 19, cls == 3 ? 38 : bc + 19) : e1;
 #pragma unroll
-          for (int k = 0; k < 10; ++k) {
-            if (k >= F - 1) continue;
-            const double vm = vim[h][k], vt = vit[h][k];
-            if (cls == 1) { rmw(C, 6 * k + bc, 6 * k + a, vm); rmw(C, 6 * (k + 1) + bc, 6 * (k + 1) + a, vt); }
-            else if (cls == 2) {
-              const int ra = a - 6, rc = bc - 6;
-              Ad[k * 169 + ra * 13 + rc] += vm; Ad[(k + 1) * 169 + ra * 13 + rc] += vt;
-              if (ra != rc) { Ad[k * 169 + rc * 13 + ra] += vm; Ad[(k + 1) * 169 + rc * 13 + ra] += vt; }
-            } else if (cls == 3) {
-              const int c0 = a < 6 ? a : CD_B0 + (a - 6), ck = a < 6 ? 6 : 13;
-              g[c0 + ck * k] += vm; g[c0 + ck * (k + 1)] += vt;
-            } else if (cls == 4) rmw(C, 6 * (k + 1) + (bc - 19), 6 * k + a, vm);
-            else Ao[k * 169 + (bc - 25) * 13 + (a - 6)] += vm;   // rows frame k+1, cols frame k
-          }
+      for (int k = 0; k < 10; ++k) { vim[h][k] = igram[min(k, F - 2) * 780 + e1]; vit[h][k] = igram[min(k, F - 2) * 780 + e2]; }
+    }
+    __syncthreads();   // the IMU owners below are different threads
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int a = ia[h], bc = ib[h], cls = icls[h];
+      if (cls == 0) continue;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        if (k >= F - 1) continue;
+        const double vm = vim[h][k], vt = vit[h][k];
+        if (cls == 1) { rmw(C, 6 * k + bc, 6 * k + a, vm); rmw(C, 6 * (k + 1) + bc, 6 * (k + 1) + a, vt); }
+        else if (cls == 2) {
+          const int ra = a - 6, rc = bc - 6;
+          Ad[k * 169 + ra * 13 + rc] += vm; Ad[(k + 1) * 169 + ra * 13 + rc] += vt;
+          if (ra != rc) { Ad[k * 169 + rc * 13 + ra] += vm; Ad[(k + 1) * 169 + rc * 13 + ra] += vt; }
+        } else if (cls == 3) {
+          const int c0 = a < 6 ? a : CD_B0 + (a - 6), ck = a < 6 ? 6 : 13;
+          g[c0 + ck * k] += vm; g[c0 + ck * (k + 1)] += vt;
+        } else if (cls == 4) rmw(C, 6 * (k + 1) + (bc - 19), 6 * k + a, vm);
+        else Ao[k * 169 + (bc - 25) * 13 + (a - 6)] += vm;   // rows frame k+1, cols frame k
+      }
+    }
+    if (tid == 0) st.phase_clk[14] = clock64();
+    if (tid == 0) st.phase_clk[15] = clock64();
+    if (tid < 13 * 18) {
+      const int i = tid / 18, sl = tid % 18, df = sl / 6, c = sl % 6;
+      // entry (frame k, row i, pose slot df): from factor k (pose_k / pose_{k+1} columns x bias_k rows) and from factor
+      // k - 1 (pose_{k-1} / pose_k columns x bias_k rows); packed index per source fixed per thread, factor walked
+      const int e1 = (df == 1) ? tri39(c, 6 + i) : tri39(6 + i, 19 + c);     // factor k     (df = 1: f = k, df = 2: f = k + 1)
+      const int e2 = (df == 0) ? tri39(c, 25 + i) : tri39(19 + c, 25 + i);   // factor k - 1 (df = 0: f = k - 1, df = 1: f = k)
+      double v1[11], v2[11];
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        v1[k] = igram[min(max(k, 0), F - 2) * 780 + e1];
+        v2[k] = igram[min(max(k - 1, 0), F - 2) * 780 + e2];
+      }
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const int f = k + df - 1;
+        const bool ok = (k < F) && (f >= 0) && (f < F);
+        const bool u1 = ok && (k + 1 < F) && (df >= 1);
+        const bool u2 = ok && (k > 0) && (df <= 1);
+        Bs[(k * 13 + i) * 18 + sl] = (u1 ? v1[k] : 0.0) + (u2 ? v2[k] : 0.0);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) st.phase_clk[3] = clock64();
+  // constant dims -> identity rows / cols
+  if (tid < 80 && act[tid] == 0.0) {   // few dims are inactive (padding, constant extrinsics / td): one thread per such dim
+    for (int j = 0; j < 80; ++j) { C[tid * CLD + j] = 0.0; C[j * CLD + tid] = 0.0; }
+    C[tid * CLD + tid] = 1.0;
+  }
+  for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) {
+    const int k = e / 169, i = (e % 169) / 13, j = e % 13;
+    if (act[CD_B0 + 13 * k + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ad[e] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) {
+    const int k = e / 169, i = (e % 169) / 13, j = e % 13;
+    if (act[CD_B0 + 13 * (k + 1) + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ao[e] = 0.0;
+  }
+  for (int e = tid; e < CD_N; e += SOLVE_THREADS)
+    if (act[e] == 0.0) g[e] = 0.0;
+  if (tid == 0) st.phase_clk[21] = clock64();
+  if ((tid & 63) == 0 && tid > 0) st.phase_clk[32 + (tid >> 6)] = clock64();
+  __syncthreads();
+  if (tid == 0) st.phase_clk[22] = clock64();
+}
+
+__device__ __noinline__ int ph_scale_schur_chain() {
+  KB_LOCALS
+  const double mu = kc.mu;
+  double *cam_scale = kc.cam_scale, *Tm = kc.Tm, *Lkm = kc.Lkm;
+  const double *wl = kc.wl;
+  double *lm_E_ = kc.lm_E, *lm_g_ = kc.lm_g, *lm_dh2_ = kc.lm_dh2, *lm_scale_ = kc.lm_scale, *lm_einv_ = kc.lm_einv, *lm_y_ = kc.lm_y;
+  // During q and the landmark Schur pass the 15 lower tiles belong to waves 0..2 (tile t -> wave t % 3, 5 each) while
+  // wave 3 runs the block-tridiagonal Cholesky chain of the speed/leg-bias part; afterwards they are redistributed over
+  // all four waves (tile t -> wave t % 4) through LDS.
+  mfma_d4 acc3[5];
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) acc3[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  auto tile_load3 = [&](auto W_) {
+    constexpr int WV = decltype(W_)::value;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc3[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+    }
+  };
+  WAVE_DISPATCH3(tile_load3);
+  if (tid == 0) st.phase_clk[23] = clock64();
+  if (tid < 80) y[tid] = C[tid * CLD + tid];
+  __syncthreads();
+  if (tid == 0) st.phase_clk[4] = clock64();
+  // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+    double hii = 1.0;
+    if (cd < CD_B0) hii = y[cd];
+    else if (cd < CD_B0 + 143) hii = Ad[((cd - CD_B0) / 13) * 169 + ((cd - CD_B0) % 13) * 14];
+    if (act[cd] != 0.0) {
+      double sc;
+      if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
+      else sc = cam_scale[cd];
+      const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
+      dh2[cd] = d2 / (sc * sc);
+      tmp[cd] = g[cd] / dh2[cd];
+    } else {
+      dh2[cd] = 1.0;
+      tmp[cd] = 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) st.phase_clk[27] = clock64();
+  // camera part of |D^-1 g|^2, max|g|, q = v^T H v (before regularisation / Schur)
+  double part_gn = 0.0, part_q = 0.0, part_gmax = 0.0;
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+    part_gn += g[cd] * tmp[cd];
+    part_gmax = fmax(part_gmax, fabs(g[cd]));
+  }
+  auto tile_q = [&](auto W_) {
+    constexpr int WV = decltype(W_)::value;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
+      const double vc = tmp[16 * J + lr], sym = (I == J) ? 1.0 : 2.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part_q += sym * tmp[16 * I + lk + 4 * r] * acc3[sl][r] * vc;
+    }
+  };
+  WAVE_DISPATCH3(tile_q);
+  if (tid == 0) st.phase_clk[28] = clock64();
+  if (tid >= 96 && tid < 96 + 143) {
+    const int e = tid - 96, k = e / 13, i = e % 13;
+    if (k < F) {
+      const double vi = tmp[CD_B0 + e];
+      double sacc = 0.0;
+      for (int j = 0; j < 13; ++j) sacc += Ad[k * 169 + i * 13 + j] * tmp[CD_B0 + 13 * k + j];
+      double cross = 0.0;
+      if (k > 0)
+        for (int j = 0; j < 13; ++j) cross += Ao[(k - 1) * 169 + i * 13 + j] * tmp[CD_B0 + 13 * (k - 1) + j];
+      // coupling rows: the IMU part spans poses k-1 .. k+1 (Bs), the prior part (frame kb only) is a plain dot product
+      double bp = 0.0;
+      if (act[CD_B0 + 13 * k + i] != 0.0) {
+#pragma unroll
+        for (int sl = 0; sl < 18; ++sl) {
+          const int f = k + sl / 6 - 1, pc = min(max(6 * f + sl % 6, 0), 65);
+          bp += (f >= 0 && f < F) ? Bs[(k * 13 + i) * 18 + sl] * act[pc] * tmp[pc] : 0.0;
         }
-        if (tid == 0) st.phase_clk[14] = clock64();
-        if (tid == 0) st.phase_clk[15] = clock64();
-        if (tid < 13 * 18) {
-          const int i = tid / 18, sl = tid % 18, df = sl / 6, c = sl % 6;
-          // entry (frame k, row i, pose slot df): from factor k (pose_k / pose_{k+1} columns x bias_k rows) and from factor
-          // k - 1 (pose_{k-1} / pose_k columns x bias_k rows); packed index per source fixed per thread, factor walked
-          const int e1 = (df == 1) ? tri39(c, 6 + i) : tri39(6 + i, 19 + c);     // factor k     (df = 1: f = k, df = 2: f = k + 1)
-          const int e2 = (df == 0) ? tri39(c, 25 + i) : tri39(19 + c, 25 + i);   // factor k - 1 (df = 0: f = k - 1, df = 1: f = k)
-          double v1[11], v2[11];
-#pragma unroll
-          for (int k = 0; k < 11; ++k) {
-            v1[k] = igram[min(max(k, 0), F - 2) * 780 + e1];
-            v2[k] = igram[min(max(k - 1, 0), F - 2) * 780 + e2];
-          }
-#pragma unroll
-          for (int k = 0; k < 11; ++k) {
-            const int f = k + df - 1;
-            const bool ok = (k < F) && (f >= 0) && (f < F);
-            const bool u1 = ok && (k + 1 < F) && (df >= 1);
-            const bool u2 = ok && (k > 0) && (df <= 1);
-            Bs[(k * 13 + i) * 18 + sl] = (u1 ? v1[k] : 0.0) + (u2 ? v2[k] : 0.0);
-          }
+        if (k == kb) {
+#pragma unroll 16
+          for (int p = 0; p < 80; ++p) bp += Bp[i * 80 + p] * act[p] * tmp[p];
         }
       }
-      __syncthreads();
-      if (tid == 0) st.phase_clk[3] = clock64();
-      // constant dims -> identity rows / cols
-      if (tid < 80 && act[tid] == 0.0) {   // few dims are inactive (padding, constant extrinsics / td): one thread per such dim
-        for (int j = 0; j < 80; ++j) { C[tid * CLD + j] = 0.0; C[j * CLD + tid] = 0.0; }
-        C[tid * CLD + tid] = 1.0;
-      }
-      for (int e = tid; e < 11 * 169; e += SOLVE_THREADS) {
-        const int k = e / 169, i = (e % 169) / 13, j = e % 13;
-        if (act[CD_B0 + 13 * k + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ad[e] = (i == j) ? 1.0 : 0.0;
-      }
-      for (int e = tid; e < 10 * 169; e += SOLVE_THREADS) {
-        const int k = e / 169, i = (e % 169) / 13, j = e % 13;
-        if (act[CD_B0 + 13 * (k + 1) + i] == 0.0 || act[CD_B0 + 13 * k + j] == 0.0) Ao[e] = 0.0;
-      }
-      for (int e = tid; e < CD_N; e += SOLVE_THREADS)
-        if (act[e] == 0.0) g[e] = 0.0;
-      __syncthreads();
-      // During q and the landmark Schur pass the 15 lower tiles belong to waves 0..2 (tile t -> wave t % 3, 5 each) while
-      // wave 3 runs the block-tridiagonal Cholesky chain of the speed/leg-bias part; afterwards they are redistributed over
-      // all four waves (tile t -> wave t % 4) through LDS.
-      mfma_d4 acc3[5];
+      part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
+    }
+  }
+  if (tid == 96) st.phase_clk[29] = clock64();
+  // ---- P6: landmarks pass 1 ----
+  double *lm_E = lm_E_, *lm_g = lm_g_, *lm_dh2 = lm_dh2_, *lm_scale = lm_scale_, *lm_einv = lm_einv_, *lm_y = lm_y_;
+  for (int l = tid; l < L; l += SOLVE_THREADS) {
+    const double E = lm_E[l], gl = lm_g[l];
+    double sc;
+    if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
+    else sc = lm_scale[l];
+    const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
+    lm_dh2[l] = d2;
+    const double vl = gl / d2;
+    part_q += E * vl * vl;   // the cross term 2 vl w_l^T v is accumulated in the Schur pass below
+    lm_y[l] = vl;            // (scratch until the back-substitution overwrites it)
+    part_gn += gl * vl;
+    part_gmax = fmax(part_gmax, fabs(gl));
+    lm_einv[l] = 1.0 / (E + mu * d2);
+  }
+  if (tid == 0) st.phase_clk[30] = clock64();
+  const double gnorm2 = block_sum(part_gn, red);
+  const double gmax = block_max(part_gmax, red);
+  if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
+    if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
+    return 1;
+  }
+  if (tid == 0) st.phase_clk[5] = clock64();
+  // regularise the speed/leg-bias diagonal blocks (the pose part is regularised after the tile redistribution)
+  for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
+  if (tid == 0) { s_flag[0] = 0; }
+  __syncthreads();   // also: lm_einv / lm_y written above are read through global memory below
+  double *Mk = S, *Gk = S + 1859, *TA1 = S + 3718, *rinvk = S + 3887, *TA0 = col;
+  double actv[5], vv[5], yacc0 = 0.0, yacc1 = 0.0, qacc = 0.0;
 #pragma unroll
-      for (int sl = 0; sl < 5; ++sl) acc3[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-      auto tile_load3 = [&](auto W_) {
-        constexpr int WV = decltype(W_)::value;
+  for (int X = 0; X < 5; ++X) { actv[X] = act[16 * X + lr]; vv[X] = tmp[16 * X + lr]; }
+  if (wv == 3) {
+    // ---- block-tridiagonal Cholesky chain of the speed/leg-bias part (13x13 blocks, frames F-1 .. 0), one wave, no
+    //      workgroup barriers:  S_k = A_kk - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,
+    //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
+    //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
+    const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
+    double *TAcur = TA0, *TAprev = TA1;
+    for (int k = F - 1; k >= 0; --k) {
+      const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
+      if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c < 13 && grp < 3) {
+        double cl[13];
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) {
-          const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
+        for (int i = 0; i < 13; ++i) {
+          double v;
+          if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
+          else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
+          else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc3[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+          for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
+          cl[i] = v * rinvk[i];
         }
-      };
-      WAVE_DISPATCH3(tile_load3);
-      if (tid < 80) y[tid] = C[tid * CLD + tid];
-      __syncthreads();
-      if (tid == 0) st.phase_clk[4] = clock64();
-      // ---- P5: Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g ----
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-        double hii = 1.0;
-        if (cd < CD_B0) hii = y[cd];
-        else if (cd < CD_B0 + 143) hii = Ad[((cd - CD_B0) / 13) * 169 + ((cd - CD_B0) % 13) * 14];
-        if (act[cd] != 0.0) {
-          double sc;
-          if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
-          else sc = cam_scale[cd];
-          const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
-          dh2[cd] = d2 / (sc * sc);
-          tmp[cd] = g[cd] / dh2[cd];
+        if (grp == 0) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
+        } else if (grp == 1) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) { Mk[k * 169 + i * 13 + c] = cl[i]; Lkm[k * 169 + i * 13 + c] = cl[i]; }
         } else {
-          dh2[cd] = 1.0;
-          tmp[cd] = 0.0;
+#pragma unroll
+          for (int i = 0; i < 13; ++i) Gk[k * 169 + i * 13 + c] = cl[i];
         }
       }
-      __syncthreads();
-      // camera part of |D^-1 g|^2, max|g|, q = v^T H v (before regularisation / Schur)
-      double part_gn = 0.0, part_q = 0.0, part_gmax = 0.0;
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-        part_gn += g[cd] * tmp[cd];
-        part_gmax = fmax(part_gmax, fabs(g[cd]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k > 0) {
+        for (int e = lane; e < 169; e += 64) {
+          const int i = e / 13, j = e - 13 * i;
+          double sacc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
+          Ad[(k - 1) * 169 + e] -= sacc;
+        }
       }
-      auto tile_q = [&](auto W_) {
-        constexpr int WV = decltype(W_)::value;
+      double *sw = TAcur; TAcur = TAprev; TAprev = sw;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    // ---- Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One
+    //      k-step = 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles
+    //      (X, .) and as B of tiles (., X): 5 row-coalesced global loads and 5 MFMAs per k-step per wave, no LDS. The same
+    //      operands give rhs_P -= sum_l w_l g_l / (...) and the 2 vl w_l^T v term of q.
+    const int nks = (L + 3) >> 2;
+    auto tile_schur = [&](auto W_) {
+      constexpr int WV = decltype(W_)::value;
+      double opb[2][4][5], eb[2][4], gb[2][4], db[2][4];
+      auto ldtrip = [&](int kk0, int bsel) {
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) {
-          const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
-          const double vc = tmp[16 * J + lr], sym = (I == J) ? 1.0 : 2.0;
+        for (int u = 0; u < 4; ++u) {
+          const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
+          eb[bsel][u] = lm_einv[lc]; gb[bsel][u] = lm_g[lc]; db[bsel][u] = lm_y[lc];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) part_q += sym * tmp[16 * I + lk + 4 * r] * acc3[sl][r] * vc;
+          for (int X = 0; X < 5; ++X) opb[bsel][u][X] = wl[(size_t)(16 * X + lr) * L + lc];
         }
       };
-      WAVE_DISPATCH3(tile_q);
-      if (tid >= 96 && tid < 96 + 143) {
-        const int e = tid - 96, k = e / 13, i = e % 13;
-        if (k < F) {
-          const double vi = tmp[CD_B0 + e];
-          double sacc = 0.0;
-          for (int j = 0; j < 13; ++j) sacc += Ad[k * 169 + i * 13 + j] * tmp[CD_B0 + 13 * k + j];
-          double cross = 0.0;
-          if (k > 0)
-            for (int j = 0; j < 13; ++j) cross += Ao[(k - 1) * 169 + i * 13 + j] * tmp[CD_B0 + 13 * (k - 1) + j];
-          double bp = 0.0;
-          if (k == kb) {
-            for (int p = 0; p < VILO_NPU; ++p) bp += Bval(k, i, p) * tmp[p];
-          } else {
-            const int p0 = 6 * (k > 0 ? k - 1 : 0), p1 = 6 * (k + 2 < F ? k + 2 : F);
-            for (int p = p0; p < p1; ++p) bp += Bval(k, i, p) * tmp[p];
-          }
-          part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
-        }
-      }
-      // ---- P6: landmarks pass 1 ----
-      double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off;
-      double *lm_scale = b.lm_scale + wm.lm_off, *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
-      for (int l = tid; l < L; l += SOLVE_THREADS) {
-        const double E = lm_E[l], gl = lm_g[l];
-        double sc;
-        if (!st.scale_ready) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
-        else sc = lm_scale[l];
-        const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
-        lm_dh2[l] = d2;
-        const double vl = gl / d2;
-        part_q += E * vl * vl;   // the cross term 2 vl w_l^T v is accumulated in the Schur pass below
-        lm_y[l] = vl;            // (scratch until the back-substitution overwrites it)
-        part_gn += gl * vl;
-        part_gmax = fmax(part_gmax, fabs(gl));
-        lm_einv[l] = 1.0 / (E + mu * d2);
-      }
-      const double gnorm2 = block_sum(part_gn, red);
-      const double gmax = block_max(part_gmax, red);
-      if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
-        if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
-        return;
-      }
-      if (tid == 0) st.phase_clk[5] = clock64();
-      // regularise the speed/leg-bias diagonal blocks (the pose part is regularised after the tile redistribution)
-      for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
-      if (tid == 0) { s_flag[0] = 0; }
-      __syncthreads();   // also: lm_einv / lm_y written above are read through global memory below
-      double *Mk = S, *Gk = S + 1859, *TA1 = S + 3718, *rinvk = S + 3887, *TA0 = col;
-      double actv[5], vv[5], yacc0 = 0.0, yacc1 = 0.0, qacc = 0.0;
+      auto dotrip = [&](int kk0, int bsel) {
 #pragma unroll
-      for (int X = 0; X < 5; ++X) { actv[X] = act[16 * X + lr]; vv[X] = tmp[16 * X + lr]; }
-      if (wv == 3) {
-        // ---- block-tridiagonal Cholesky chain of the speed/leg-bias part (13x13 blocks, frames F-1 .. 0), one wave, no
-        //      workgroup barriers:  S_k = A_kk - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,
-        //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
-        //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
-        const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
-        double *TAcur = TA0, *TAprev = TA1;
-        for (int k = F - 1; k >= 0; --k) {
-          const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
-          if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (c < 13 && grp < 3) {
-            double cl[13];
+        for (int u = 0; u < 4; ++u) {
+          const int l = 4 * (kk0 + u) + lk;
+          const double ei = (l < L) ? eb[bsel][u] : 0.0, ge = gb[bsel][u] * ei, vl = (l < L) ? db[bsel][u] : 0.0;
+          double op[5];
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-              double v;
-              if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
-              else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
-              else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
-#pragma unroll
-              for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
-              cl[i] = v * rinvk[i];
-            }
-            if (grp == 0) {
-#pragma unroll
-              for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
-            } else if (grp == 1) {
-#pragma unroll
-              for (int i = 0; i < 13; ++i) { Mk[k * 169 + i * 13 + c] = cl[i]; Lkm[k * 169 + i * 13 + c] = cl[i]; }
-            } else {
-#pragma unroll
-              for (int i = 0; i < 13; ++i) Gk[k * 169 + i * 13 + c] = cl[i];
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (k > 0) {
-            for (int e = lane; e < 169; e += 64) {
-              const int i = e / 13, j = e - 13 * i;
-              double sacc = 0.0;
-#pragma unroll
-              for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
-              Ad[(k - 1) * 169 + e] -= sacc;
-            }
-          }
-          double *sw = TAcur; TAcur = TAprev; TAprev = sw;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      } else {
-        // ---- Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One
-        //      k-step = 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles
-        //      (X, .) and as B of tiles (., X): 5 row-coalesced global loads and 5 MFMAs per k-step per wave, no LDS. The same
-        //      operands give rhs_P -= sum_l w_l g_l / (...) and the 2 vl w_l^T v term of q.
-        const int nks = (L + 3) >> 2;
-        auto tile_schur = [&](auto W_) {
-          constexpr int WV = decltype(W_)::value;
-          double opb[2][4][5], eb[2][4], gb[2][4], db[2][4];
-          auto ldtrip = [&](int kk0, int bsel) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
-              eb[bsel][u] = lm_einv[lc]; gb[bsel][u] = lm_g[lc]; db[bsel][u] = lm_y[lc];
-#pragma unroll
-              for (int X = 0; X < 5; ++X) opb[bsel][u][X] = wl[(size_t)(16 * X + lr) * L + lc];
-            }
-          };
-          auto dotrip = [&](int kk0, int bsel) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int l = 4 * (kk0 + u) + lk;
-              const double ei = (l < L) ? eb[bsel][u] : 0.0, ge = gb[bsel][u] * ei, vl = (l < L) ? db[bsel][u] : 0.0;
-              double op[5];
-#pragma unroll
-              for (int X = 0; X < 5; ++X) op[X] = opb[bsel][u][X] * actv[X];
-#pragma unroll
-              for (int sl = 0; sl < 5; ++sl) {
-                const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
-                acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc3[sl], 0, 0, 0);
-              }
-              yacc0 += op[WV] * ge; qacc += op[WV] * vv[WV] * vl;
-              if (WV < 2) { yacc1 += op[WV + 3] * ge; qacc += op[WV + 3] * vv[WV + 3] * vl; }
-            }
-          };
-          // 4 k-steps (16 landmarks) per trip, the next trip's 32 loads in flight behind the current trip's 20 MFMAs;
-          // landmarks past L are clamped to a valid address and masked through their 1 / (E + mu d2) factor
-          ldtrip(0, 0);
-          for (int kk0 = 0; kk0 < nks; kk0 += 8) {
-            ldtrip(kk0 + 4, 1);
-            dotrip(kk0, 0);
-            ldtrip(kk0 + 8, 0);
-            dotrip(kk0 + 4, 1);
-          }
-          // hand the tiles to their 4-wave owners through C (lower tile positions)
+          for (int X = 0; X < 5; ++X) op[X] = opb[bsel][u][X] * actv[X];
 #pragma unroll
           for (int sl = 0; sl < 5; ++sl) {
             const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr] = acc3[sl][r];
+            acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc3[sl], 0, 0, 0);
           }
-        };
-        WAVE_DISPATCH3(tile_schur);
-        part_q += 2.0 * qacc;
-        yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
-        yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
-        if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv < 2) y[16 * (wv + 3) + lr] = yacc1; }
-      }
-      const double qq = block_sum(part_q, red);   // (also the barrier that publishes y, the tiles in C and the chain's output)
-      int fail = s_flag[0];
-      if (tid == 0) st.phase_clk[6] = clock64();
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < 80) ? y[cd] : 0.0);   // reduced rhs
-      mfma_d4 acc[4];
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) acc[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-      auto tile_load = [&](auto W_) {
-        constexpr int WV = decltype(W_)::value;
-#pragma unroll
-        for (int sl = 0; sl < NTILE(WV); ++sl) {
-          const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
-            if (I == J && lk + 4 * r == lr) acc[sl][r] += mu * dh2[16 * I + lr];   // regularise: diag += mu dhat^2
-          }
+          yacc0 += op[WV] * ge; qacc += op[WV] * vv[WV] * vl;
+          if (WV < 2) { yacc1 += op[WV + 3] * ge; qacc += op[WV + 3] * vv[WV + 3] * vl; }
         }
       };
-      WAVE_DISPATCH(tile_load);
-      __syncthreads();   // tmp (reduced rhs) complete
-      // ---- T(k) = [T_B(k) | t_g(k)] = M_k [B_k | rhs_k] - G_k T(k+1): the 80 + 1 columns are independent, so each wave
-      //      carries its 16-column tiles (wave w: tiles w and w + 4; tile 5 = rhs column) through all frames without any
-      //      barrier. The previous result is already in B-operand layout: register kk of a lane is row 4 kk + l / 16. ----
-      {
-        const int X0 = wv, X1 = wv + 4;
-        mfma_d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
-        for (int k = F - 1; k >= 0; --k) {
-          mfma_d4 n0 = {0.0, 0.0, 0.0, 0.0}, n1 = {0.0, 0.0, 0.0, 0.0};
-          double am[4], ag[4];
+      // 4 k-steps (16 landmarks) per trip, the next trip's 32 loads in flight behind the current trip's 20 MFMAs;
+      // landmarks past L are clamped to a valid address and masked through their 1 / (E + mu d2) factor
+      ldtrip(0, 0);
+      for (int kk0 = 0; kk0 < nks; kk0 += 8) {
+        ldtrip(kk0 + 4, 1);
+        dotrip(kk0, 0);
+        ldtrip(kk0 + 8, 0);
+        dotrip(kk0 + 4, 1);
+      }
+      // hand the tiles to their 4-wave owners through C (lower tile positions)
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int q = 4 * kk + lk;
-            const bool in = (lr < 13) && (q < 13);
-            const int idx = k * 169 + min(lr, 12) * 13 + min(q, 12);
-            const double m = Mk[idx], gg = Gk[idx];
-            am[kk] = in ? m : 0.0;
-            ag[kk] = (in && k < F - 1) ? -gg : 0.0;
-          }
+      for (int sl = 0; sl < 5; ++sl) {
+        const int I = c_tileI[WV + 3 * sl], J = c_tileJ[WV + 3 * sl];
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int q = 4 * kk + lk, qc = min(q, 12);
-            double b0 = Bval(k, qc, 16 * X0 + lr);
-            b0 = (q < 13) ? b0 : 0.0;
-            n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b0, n0, 0, 0, 0);
-            if (X1 < 6) {
-              double b1 = (X1 < 5) ? Bval(k, qc, 16 * min(X1, 4) + lr) : ((lr == 0) ? tmp[CD_B0 + 13 * k + qc] : 0.0);
-              b1 = (q < 13) ? b1 : 0.0;
-              n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b1, n1, 0, 0, 0);
-            }
-          }
+        for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr] = acc3[sl][r];
+      }
+    };
+    WAVE_DISPATCH3(tile_schur);
+    part_q += 2.0 * qacc;
+    yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
+    yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
+    if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv < 2) y[16 * (wv + 3) + lr] = yacc1; }
+  }
+  const double qq = block_sum(part_q, red);   // (also the barrier that publishes y, the tiles in C and the chain's output)
+  if (tid == 0) { kc.gnorm2 = gnorm2; kc.gmax = gmax; kc.qq = qq; }
+  return 0;
+}
+
+__device__ __noinline__ void ph_elim_chol() {
+  KB_LOCALS
+  const double mu = kc.mu;
+  double *Tm = kc.Tm;
+  double *Mk = S, *Gk = S + 1859;
+  if (tid == 0) st.phase_clk[6] = clock64();
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) tmp[cd] = g[cd] - ((cd < 80) ? y[cd] : 0.0);   // reduced rhs
+  mfma_d4 acc[4];
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t0[kk], n0, 0, 0, 0);
-            if (X1 < 6) n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t1[kk], n1, 0, 0, 0);
-          }
-          t0 = n0; t1 = n1;
+  for (int sl = 0; sl < 4; ++sl) acc[sl] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  auto tile_load = [&](auto W_) {
+    constexpr int WV = decltype(W_)::value;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = lk + 4 * r;
-            if (row < 13) {
-              Tm[k * 13 * 96 + row * 96 + 13 + 16 * X0 + lr] = n0[r];
-              if (X1 < 5) Tm[k * 13 * 96 + row * 96 + 13 + 16 * X1 + lr] = n1[r];
-              else if (X1 == 5 && lr == 0) Tm[k * 13 * 96 + row * 96 + 93] = n1[r];
-            }
-          }
+    for (int sl = 0; sl < NTILE(WV); ++sl) {
+      const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[sl][r] = C[(16 * I + lk + 4 * r) * CLD + 16 * J + lr];
+        if (I == J && lk + 4 * r == lr) acc[sl][r] += mu * dh2[16 * I + lr];   // regularise: diag += mu dhat^2
+      }
+    }
+  };
+  WAVE_DISPATCH(tile_load);
+  __syncthreads();   // tmp (reduced rhs) complete
+  // ---- T(k) = [T_B(k) | t_g(k)] = M_k [B_k | rhs_k] - G_k T(k+1): the 80 + 1 columns are independent, so each wave
+  //      carries its 16-column tiles (wave w: tiles w and w + 4; tile 5 = rhs column) through all frames without any
+  //      barrier. The previous result is already in B-operand layout: register kk of a lane is row 4 kk + l / 16. ----
+  {
+    const int X0 = wv, X1 = wv + 4;
+    mfma_d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k = F - 1; k >= 0; --k) {
+      mfma_d4 n0 = {0.0, 0.0, 0.0, 0.0}, n1 = {0.0, 0.0, 0.0, 0.0};
+      double am[4], ag[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int q = 4 * kk + lk;
+        const bool in = (lr < 13) && (q < 13);
+        const int idx = k * 169 + min(lr, 12) * 13 + min(q, 12);
+        const double m = Mk[idx], gg = Gk[idx];
+        am[kk] = in ? m : 0.0;
+        ag[kk] = (in && k < F - 1) ? -gg : 0.0;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int q = 4 * kk + lk, qc = min(q, 12);
+        double b0 = Bval(k, qc, 16 * X0 + lr);
+        b0 = (q < 13) ? b0 : 0.0;
+        n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b0, n0, 0, 0, 0);
+        if (X1 < 6) {
+          double b1 = (X1 < 5) ? Bval(k, qc, 16 * min(X1, 4) + lr) : ((lr == 0) ? tmp[CD_B0 + 13 * k + qc] : 0.0);
+          b1 = (q < 13) ? b1 : 0.0;
+          n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b1, n1, 0, 0, 0);
         }
       }
-      __syncthreads();   // T in global memory is read by every wave below
-      // ---- C -= sum_k T_B(k)^T T_B(k) (rank 143) on the matrix cores, rhs_P -= sum_k T_B(k)^T t_g(k); operands from Tm ----
-      {
-        double yr0 = 0.0, yr1 = 0.0;
-        auto tile_rank = [&](auto W_) {
-          constexpr int WV = decltype(W_)::value;
-          for (int k = 0; k < F; ++k) {
-            double opT[4][5], tg[4];
-            const double *Tk = Tm + (size_t)k * 13 * 96;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int qc = min(4 * kk + lk, 12);
-              tg[kk] = Tk[qc * 96 + 93];
+      for (int kk = 0; kk < 4; ++kk) {
+        n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t0[kk], n0, 0, 0, 0);
+        if (X1 < 6) n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t1[kk], n1, 0, 0, 0);
+      }
+      t0 = n0; t1 = n1;
 #pragma unroll
-              for (int X = 0; X < 5; ++X) opT[kk][X] = Tk[qc * 96 + 13 + 16 * X + lr];
-            }
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk + 4 * r;
+        if (row < 13) {
+          Tm[k * 13 * 96 + row * 96 + 13 + 16 * X0 + lr] = n0[r];
+          if (X1 < 5) Tm[k * 13 * 96 + row * 96 + 13 + 16 * X1 + lr] = n1[r];
+          else if (X1 == 5 && lr == 0) Tm[k * 13 * 96 + row * 96 + 93] = n1[r];
+        }
+      }
+    }
+  }
+  __syncthreads();   // T in global memory is read by every wave below
+  // ---- C -= sum_k T_B(k)^T T_B(k) (rank 143) on the matrix cores, rhs_P -= sum_k T_B(k)^T t_g(k); operands from Tm ----
+  {
+    double yr0 = 0.0, yr1 = 0.0;
+    auto tile_rank = [&](auto W_) {
+      constexpr int WV = decltype(W_)::value;
+      for (int k = 0; k < F; ++k) {
+        double opT[4][5], tg[4];
+        const double *Tk = Tm + (size_t)k * 13 * 96;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const bool in = 4 * kk + lk < 13;
+        for (int kk = 0; kk < 4; ++kk) {
+          const int qc = min(4 * kk + lk, 12);
+          tg[kk] = Tk[qc * 96 + 93];
 #pragma unroll
-              for (int X = 0; X < 5; ++X) opT[kk][X] = in ? opT[kk][X] : 0.0;
+          for (int X = 0; X < 5; ++X) opT[kk][X] = Tk[qc * 96 + 13 + 16 * X + lr];
+        }
 #pragma unroll
-              for (int sl = 0; sl < NTILE(WV); ++sl) {
-                const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opT[kk][I], opT[kk][J], acc[sl], 0, 0, 0);
-              }
-              yr0 += opT[kk][WV] * tg[kk];
-              if (WV == 0) yr1 += opT[kk][4] * tg[kk];
-            }
+        for (int kk = 0; kk < 4; ++kk) {
+          const bool in = 4 * kk + lk < 13;
+#pragma unroll
+          for (int X = 0; X < 5; ++X) opT[kk][X] = in ? opT[kk][X] : 0.0;
+#pragma unroll
+          for (int sl = 0; sl < NTILE(WV); ++sl) {
+            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opT[kk][I], opT[kk][J], acc[sl], 0, 0, 0);
           }
-        };
-        WAVE_DISPATCH(tile_rank);
-        yr0 += __shfl_xor(yr0, 16, 64); yr0 += __shfl_xor(yr0, 32, 64);
-        yr1 += __shfl_xor(yr1, 16, 64); yr1 += __shfl_xor(yr1, 32, 64);
-        if (lk == 0) { tmp[16 * wv + lr] -= yr0; if (wv == 0) tmp[64 + lr] -= yr1; }
+          yr0 += opT[kk][WV] * tg[kk];
+          if (WV == 0) yr1 += opT[kk][4] * tg[kk];
+        }
+      }
+    };
+    WAVE_DISPATCH(tile_rank);
+    yr0 += __shfl_xor(yr0, 16, 64); yr0 += __shfl_xor(yr0, 32, 64);
+    yr1 += __shfl_xor(yr1, 16, 64); yr1 += __shfl_xor(yr1, 32, 64);
+    if (lk == 0) { tmp[16 * wv + lr] -= yr0; if (wv == 0) tmp[64 + lr] -= yr1; }
+  }
+  lds_barrier();
+  if (tid == 0) st.phase_clk[7] = clock64();
+  // ---- dense Cholesky of the 80x80 reduced pose system: register tiles, pivot column broadcast through LDS,
+  //      reciprocal square root of the pivot (one Newton step on v_rsq_f64) instead of sqrt + 80 divisions ----
+  // ---- dense Cholesky of the 80x80 reduced pose system, blocked by 16: diagonal tile by one wave (registers +
+  //      v_readlane), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores;
+  //      2 workgroup barriers per block column (10 in total). L is left in C (lower triangle) for the solves ----
+  double *P16 = S, *D16 = S + 1100, *LI16 = S + 1400;
+  auto tile_chol = [&](auto W_) {
+    constexpr int WV = decltype(W_)::value;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+#pragma unroll
+      for (int sl = 0; sl < NTILE(WV); ++sl) {
+        const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+        if (I == j && J == j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[sl][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int f16 = chol16_wave(D16, C + (16 * j) * CLD + 16 * j, CLD, LI16);
+          if (f16 && (tid & 63) == 0) { if (st.pad[1] == 0) st.pad[1] = 1000 + 16 * j; s_flag[1] = 1; }
+        }
       }
       lds_barrier();
-      if (tid == 0) st.phase_clk[7] = clock64();
-      // ---- dense Cholesky of the 80x80 reduced pose system: register tiles, pivot column broadcast through LDS,
-      //      reciprocal square root of the pivot (one Newton step on v_rsq_f64) instead of sqrt + 80 divisions ----
-      // ---- dense Cholesky of the 80x80 reduced pose system, blocked by 16: diagonal tile by one wave (registers +
-      //      v_readlane), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores;
-      //      2 workgroup barriers per block column (10 in total). L is left in C (lower triangle) for the solves ----
-      double *P16 = S, *D16 = S + 1100, *LI16 = S + 1400;
-      auto tile_chol = [&](auto W_) {
-        constexpr int WV = decltype(W_)::value;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+      for (int sl = 0; sl < NTILE(WV); ++sl) {
+        const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+        if (J == j && I > j) {
+          double *Pt = P16 + (I - j - 1) * 272;
 #pragma unroll
-          for (int sl = 0; sl < NTILE(WV); ++sl) {
-            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-            if (I == j && J == j) {
+          for (int r = 0; r < 4; ++r) Pt[(lk + 4 * r) * 17 + lr] = acc[sl][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[sl][r];
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              const int f16 = chol16_wave(D16, C + (16 * j) * CLD + 16 * j, CLD, LI16);
-              if (f16 && (tid & 63) == 0) { if (st.pad[1] == 0) st.pad[1] = 1000 + 16 * j; s_flag[1] = 1; }
-            }
-          }
-          lds_barrier();
+          for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[lr * 17 + 4 * kk + lk], LI16[lr * 17 + 4 * kk + lk], nacc, 0, 0, 0);
+          acc[sl] = nacc;
 #pragma unroll
-          for (int sl = 0; sl < NTILE(WV); ++sl) {
-            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-            if (J == j && I > j) {
-              double *Pt = P16 + (I - j - 1) * 272;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) Pt[(lk + 4 * r) * 17 + lr] = acc[sl][r];
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[lr * 17 + 4 * kk + lk], LI16[lr * 17 + 4 * kk + lk], nacc, 0, 0, 0);
-              acc[sl] = nacc;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * j + lr] = nacc[r];
-            }
-          }
-          lds_barrier();
-#pragma unroll
-          for (int sl = 0; sl < NTILE(WV); ++sl) {
-            const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
-            if (J > j) {
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk)
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-C[(16 * I + lr) * CLD + 16 * j + 4 * kk + lk], C[(16 * J + lr) * CLD + 16 * j + 4 * kk + lk], acc[sl], 0, 0, 0);
-            }
-          }
+          for (int r = 0; r < 4; ++r) C[(16 * I + lk + 4 * r) * CLD + 16 * j + lr] = nacc[r];
         }
-      };
-      WAVE_DISPATCH(tile_chol);
+      }
       lds_barrier();
-      fail |= s_flag[1];
+#pragma unroll
+      for (int sl = 0; sl < NTILE(WV); ++sl) {
+        const int I = c_tileI[WV + 4 * sl], J = c_tileJ[WV + 4 * sl];
+        if (J > j) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-C[(16 * I + lr) * CLD + 16 * j + 4 * kk + lk], C[(16 * J + lr) * CLD + 16 * j + 4 * kk + lk], acc[sl], 0, 0, 0);
+        }
+      }
+    }
+  };
+  WAVE_DISPATCH(tile_chol);
+  lds_barrier();
+}
+
+__device__ __noinline__ void ph_solve() {
+  KB_LOCALS
+  double *Tm = kc.Tm, *Lkm = kc.Lkm;
+  const double *wl = kc.wl;
+  double *lm_g = kc.lm_g, *lm_dh2 = kc.lm_dh2, *lm_einv = kc.lm_einv, *lm_y = kc.lm_y;
+  // ---- triangular solves L L^T yP = rhs by wave 0 (lane owns rows lane and lane + 64); pivots by v_readlane ----
+  if (tid < 80) col[tid] = 1.0 / C[tid * CLD + tid];
+  lds_barrier();
+  if (tid < 64) {
+    const int lane = tid;
+    double b0 = tmp[lane], b1 = lane < 16 ? tmp[lane + 64] : 0.0;
+    for (int j = 0; j < 80; ++j) {
+      const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
+      if (lane > j) b0 -= C[lane * CLD + j] * yj;
+      if (lane < 16 && lane + 64 > j) b1 -= C[(lane + 64) * CLD + j] * yj;
+      if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+    }
+    for (int j = 79; j >= 0; --j) {
+      const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
+      if (lane < j) b0 -= C[j * CLD + lane] * yj;
+      if (lane < 16 && lane + 64 < j) b1 -= C[j * CLD + lane + 64] * yj;
+      if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+    }
+    y[lane] = b0;
+    if (lane < 16) y[lane + 64] = b1;
+  }
+  __syncthreads();   // also orders the Tm / Lkm global stores of the elimination before the loads below
+  if (tid == 0) st.phase_clk[9] = clock64();
+  // ---- back-substitution of the B part: u_k = t_g - T_B yP (parallel), then the chain over frames:
+  //      y_k = L_k^-T (u_k - T_A y_{k-1}) with L_k^-1 precomputed, one LDS round trip per frame (wave 0) ----
+  double *U = S;               // [11][13]
+  double *TA = S + 160;        // [11][169]  T_A blocks
+  double *LI = C;              // [11][169]  L_k^-1 blocks (the pose factor is no longer needed)
+  if (tid < 143) {
+    const int k = tid / 13, i = tid % 13;
+    if (k < F) {
+      const double *trow = Tm + (size_t)k * 13 * 96 + i * 96;
+      double sacc = trow[93];
+#pragma unroll 16
+      for (int q = 0; q < 80; ++q) sacc -= trow[13 + q] * y[q];
+      U[k * 13 + i] = sacc;
+    }
+  }
+  for (int e = tid; e < F * 169; e += SOLVE_THREADS) {
+    const int k = e / 169, r = (e % 169) / 13, c = e % 13;
+    TA[e] = Tm[(size_t)k * 13 * 96 + r * 96 + c];
+    LI[e] = Lkm[e];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid, row = lane < 13 ? lane : 0;
+    double *rb = col;   // rhs broadcast buffer
+    for (int k = 0; k < F; ++k) {
+      double rhs = U[k * 13 + row];
+      if (k > 0) {
+#pragma unroll
+        for (int q = 0; q < 13; ++q) rhs -= TA[k * 169 + row * 13 + q] * y[CD_B0 + 13 * (k - 1) + q];
+      }
+      if (lane < 13) rb[lane] = rhs;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double yk = 0.0;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) yk += LI[k * 169 + q * 13 + row] * rb[q];   // (L^-T rhs)_row = sum_q Linv[q][row] rhs[q]
+      if (lane < 13) y[CD_B0 + 13 * k + lane] = yk;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (tid == 0) st.phase_clk[10] = clock64();
+  // ---- P9: landmarks pass 2 (back-substitution) + norms ----
+  double part_gnn = 0.0, part_gy = 0.0;
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+    if (act[cd] == 0.0) y[cd] = 0.0;
+  }
+  __syncthreads();
+  for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
+    part_gnn += dh2[cd] * y[cd] * y[cd] * act[cd];
+    part_gy += g[cd] * y[cd];
+  }
+  for (int l = tid; l < L; l += SOLVE_THREADS) {
+    double tl = 0.0;
+#pragma unroll 16
+    for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * y[a];
+    const double yl = (lm_g[l] - tl) * lm_einv[l];
+    lm_y[l] = yl;
+    part_gnn += lm_dh2[l] * yl * yl;
+    part_gy += lm_g[l] * yl;
+  }
+  const double gnnorm2 = block_sum(part_gnn, red);
+  const double gy = block_sum(part_gy, red);
+  if (tid == 0) { kc.gnnorm2 = gnnorm2; kc.gy = gy; }
+}
+
+__global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, SolveParams sp_in) {
+  const int win = blockIdx.x;
+  SolverState &st = b.st[win];
+  if (st.done) return;
+  const int tid = threadIdx.x;
+  double *g = lds + LDS_G, *dh2 = lds + LDS_DH2, *y = lds + LDS_Y, *tmp = lds + LDS_TMP;
+  const WinMeta wm = b.win[win];
+  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
+  double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
+  if (tid == 0) {
+    kc.x = x; kc.xc = xc;
+    kc.Tm = b.Tm + (size_t)win * 11 * 13 * 96; kc.Lkm = b.Lk + (size_t)win * 11 * 169;
+    kc.cam_g = cam_g; kc.cam_dh2 = cam_dh2; kc.cam_y = cam_y; kc.cam_scale = b.cam_scale + (size_t)win * CD_N;
+    kc.lm_E = b.lm_E + wm.lm_off; kc.lm_g = b.lm_g + wm.lm_off; kc.lm_dh2 = b.lm_dh2 + wm.lm_off;
+    kc.lm_scale = b.lm_scale + wm.lm_off; kc.lm_einv = b.lm_einv + wm.lm_off; kc.lm_y = b.lm_y + wm.lm_off;
+    kc.wl = b.lm_w + 80 * (size_t)wm.lm_off; kc.igram = b.imu_gram + (size_t)win * 10 * 780;
+    kc.gs = b.gram + (size_t)wm.gram_off * VILO_GRAM; kc.pd = b.prior_dense + (size_t)win * PD_N;
+    kc.pb0 = b.prior_b0 + (size_t)win * 96; kc.phd = b.prior_hd + (size_t)win * 96; kc.Hp = b.prior_H + (size_t)win * 96 * 96;
+    kc.pmap = b.prior_map + (size_t)win * 96; kc.chunks = b.chunk + wm.chunk_off; kc.st = &st;
+    kc.win = win; kc.F = wm.n_frames; kc.L = wm.L; kc.pn = wm.prior_n; kc.kb = wm.pad; kc.n_chunks = wm.n_chunks;
+    kc.n_gram = wm.n_gram; kc.const_mask = wm.const_mask; kc.gram_off = wm.gram_off;
+    kc.sp = sp_in;
+  }
+  __syncthreads();
+  const SolveParams &sp = kc.sp;
+
+  if (st.need_lin) {
+    if (tid == 0) st.phase_clk[0] = clock64();
+    ph_tables();
+    bool solved = false;
+    while (!solved) {
+      __syncthreads();
+      if (tid == 0) { kc.mu = st.mu; kc.s_flag[0] = 0; kc.s_flag[1] = 0; st.phase_clk[1] = clock64(); }
+      __syncthreads();
+      ph_assemble();
+      if (ph_scale_schur_chain()) return;
+      ph_elim_chol();
+      const int fail = kc.s_flag[0] | kc.s_flag[1];
       if (fail) {
         // DoglegStrategy::ComputeGaussNewtonStep: mu *= 10 and retry while mu < max_mu (1.0)
         __syncthreads();
-        if (tid == 0) { st.mu *= 10.0; s_flag[0] = 0; s_flag[1] = 0; }
+        if (tid == 0) { st.mu *= 10.0; }
         __syncthreads();
         if (!(st.mu < 1.0)) {
-          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = qq; st.gmax = gmax; st.scale_ready = 1; }
+          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = kc.gnorm2; st.q = kc.qq; st.gmax = kc.gmax; st.scale_ready = 1; }
           return;
         }
         continue;
       }
       if (tid == 0) st.phase_clk[8] = clock64();
-      // ---- triangular solves L L^T yP = rhs by wave 0 (lane owns rows lane and lane + 64); pivots by v_readlane ----
-      if (tid < 80) col[tid] = 1.0 / C[tid * CLD + tid];
-      lds_barrier();
-      if (tid < 64) {
-        const int lane = tid;
-        double b0 = tmp[lane], b1 = lane < 16 ? tmp[lane + 64] : 0.0;
-        for (int j = 0; j < 80; ++j) {
-          const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
-          if (lane > j) b0 -= C[lane * CLD + j] * yj;
-          if (lane < 16 && lane + 64 > j) b1 -= C[(lane + 64) * CLD + j] * yj;
-          if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
-        }
-        for (int j = 79; j >= 0; --j) {
-          const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
-          if (lane < j) b0 -= C[j * CLD + lane] * yj;
-          if (lane < 16 && lane + 64 < j) b1 -= C[j * CLD + lane + 64] * yj;
-          if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
-        }
-        y[lane] = b0;
-        if (lane < 16) y[lane + 64] = b1;
-      }
-      __syncthreads();   // also orders the Tm / Lkm global stores of the elimination before the loads below
-      if (tid == 0) st.phase_clk[9] = clock64();
-      // ---- back-substitution of the B part: u_k = t_g - T_B yP (parallel), then the chain over frames:
-      //      y_k = L_k^-T (u_k - T_A y_{k-1}) with L_k^-1 precomputed, one LDS round trip per frame (wave 0) ----
-      double *U = S;               // [11][13]
-      double *TA = S + 160;        // [11][169]  T_A blocks
-      double *LI = C;              // [11][169]  L_k^-1 blocks (the pose factor is no longer needed)
-      if (tid < 143) {
-        const int k = tid / 13, i = tid % 13;
-        if (k < F) {
-          const double *trow = Tm + (size_t)k * 13 * 96 + i * 96;
-          double sacc = trow[93];
-#pragma unroll 16
-          for (int q = 0; q < 80; ++q) sacc -= trow[13 + q] * y[q];
-          U[k * 13 + i] = sacc;
-        }
-      }
-      for (int e = tid; e < F * 169; e += SOLVE_THREADS) {
-        const int k = e / 169, r = (e % 169) / 13, c = e % 13;
-        TA[e] = Tm[(size_t)k * 13 * 96 + r * 96 + c];
-        LI[e] = Lkm[e];
-      }
+      ph_solve();
       __syncthreads();
-      if (tid < 64) {
-        const int lane = tid, row = lane < 13 ? lane : 0;
-        double *rb = col;   // rhs broadcast buffer
-        for (int k = 0; k < F; ++k) {
-          double rhs = U[k * 13 + row];
-          if (k > 0) {
-#pragma unroll
-            for (int q = 0; q < 13; ++q) rhs -= TA[k * 169 + row * 13 + q] * y[CD_B0 + 13 * (k - 1) + q];
-          }
-          if (lane < 13) rb[lane] = rhs;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          double yk = 0.0;
-#pragma unroll
-          for (int q = 0; q < 13; ++q) yk += LI[k * 169 + q * 13 + row] * rb[q];   // (L^-T rhs)_row = sum_q Linv[q][row] rhs[q]
-          if (lane < 13) y[CD_B0 + 13 * k + lane] = yk;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      }
-      __syncthreads();
-      if (tid == 0) st.phase_clk[10] = clock64();
-      // ---- P9: landmarks pass 2 (back-substitution) + norms ----
-      double part_gnn = 0.0, part_gy = 0.0;
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-        if (act[cd] == 0.0) y[cd] = 0.0;
-      }
-      __syncthreads();
-      for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
-        part_gnn += dh2[cd] * y[cd] * y[cd] * act[cd];
-        part_gy += g[cd] * y[cd];
-      }
-      for (int l = tid; l < L; l += SOLVE_THREADS) {
-        double tl = 0.0;
-#pragma unroll 16
-        for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * y[a];
-        const double yl = (lm_g[l] - tl) * lm_einv[l];
-        lm_y[l] = yl;
-        part_gnn += lm_dh2[l] * yl * yl;
-        part_gy += lm_g[l] * yl;
-      }
-      const double gnnorm2 = block_sum(part_gnn, red);
-      const double gy = block_sum(part_gy, red);
+      const double gnnorm2 = kc.gnnorm2, gy = kc.gy;
       if (!(isfinite(gnnorm2) && isfinite(gy))) {   // IsArrayValid(gauss_newton_step_) failed
         if (tid == 0) st.mu *= 10.0;
         __syncthreads();
@@ -1361,8 +1430,8 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
       }
       for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) { cam_g[cd] = g[cd]; cam_dh2[cd] = dh2[cd]; cam_y[cd] = y[cd]; }
       if (tid == 0) {
-        st.gnorm2 = gnorm2; st.gnnorm2 = gnnorm2; st.gdotgn = -gy; st.q = qq; st.gmax = gmax;
-        st.alpha = gnorm2 / qq;
+        st.gnorm2 = kc.gnorm2; st.gnnorm2 = gnnorm2; st.gdotgn = -gy; st.q = kc.qq; st.gmax = kc.gmax;
+        st.alpha = kc.gnorm2 / kc.qq;
         st.scale_ready = 1;
         st.lin_fail = 0;
       }
@@ -1373,6 +1442,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_build_solve(BatchDev b, Solve
     for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) { g[cd] = cam_g[cd]; dh2[cd] = cam_dh2[cd]; y[cd] = cam_y[cd]; }
     __syncthreads();
   }
+
   if (tid == 0) st.phase_clk[11] = clock64();
   // ---- P11: dogleg step for the current radius, candidate camera state ----
   if (tid == 0) {

@@ -79,7 +79,7 @@ struct SolverState {
   int pad[3];
   double cost_trace[64];
   double radius_trace[64];
-  long long phase_clk[32];   // shader-clock stamps (last linearisation), profiling aid: 0..12 k_build_solve, 16..21 k_visual_linearize (first chunk), 24..27 k_imu_linearize (k = 0)
+  long long phase_clk[48];   // shader-clock stamps (last linearisation), profiling aid: 0..12 k_build_solve, 16..21 k_visual_linearize (first chunk), 24..27 k_imu_linearize (k = 0)
 };
 
 struct BatchDev {
