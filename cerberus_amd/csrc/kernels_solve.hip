@@ -879,6 +879,65 @@ __device__ __noinline__ void ph_assemble() {
   if (tid == 0) st.phase_clk[22] = clock64();
 }
 
+// Block-tridiagonal Cholesky chain of the speed/leg-bias part (wave 3 only, concurrent with the landmark Schur pass).
+__device__ __noinline__ void ph_bias_chain() {
+  KB_LOCALS
+  double *Tm = kc.Tm, *Lkm = kc.Lkm;
+  double *Mk = S, *Gk = S + 1859, *TA1 = S + 3718, *rinvk = S + 3887, *TA0 = col;
+  {
+    // ---- block-tridiagonal Cholesky chain of the speed/leg-bias part (13x13 blocks, frames F-1 .. 0), one wave, no
+    //      workgroup barriers:  S_k = A_kk - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,
+    //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
+    //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
+    const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
+    double *TAcur = TA0, *TAprev = TA1;
+    for (int k = F - 1; k >= 0; --k) {
+      if (k == 5 && lane == 0) st.phase_clk[36] = clock64();
+      const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
+      if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k == 5 && lane == 0) st.phase_clk[37] = clock64();
+      if (c < 13 && grp < 3) {
+        double cl[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+          double v;
+          if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
+          else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
+          else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
+#pragma unroll
+          for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
+          cl[i] = v * rinvk[i];
+        }
+        if (grp == 0) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
+        } else if (grp == 1) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) { Mk[k * 169 + i * 13 + c] = cl[i]; Lkm[k * 169 + i * 13 + c] = cl[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) Gk[k * 169 + i * 13 + c] = cl[i];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k == 5 && lane == 0) st.phase_clk[38] = clock64();
+      if (k > 0) {
+        for (int e = lane; e < 169; e += 64) {
+          const int i = e / 13, j = e - 13 * i;
+          double sacc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
+          Ad[(k - 1) * 169 + e] -= sacc;
+        }
+      }
+      double *sw = TAcur; TAcur = TAprev; TAprev = sw;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k == 5 && lane == 0) st.phase_clk[39] = clock64();
+    }
+  }
+}
+
 __device__ __noinline__ int ph_scale_schur_chain() {
   KB_LOCALS
   const double mu = kc.mu;
@@ -1001,52 +1060,7 @@ __device__ __noinline__ int ph_scale_schur_chain() {
 #pragma unroll
   for (int X = 0; X < 5; ++X) { actv[X] = act[16 * X + lr]; vv[X] = tmp[16 * X + lr]; }
   if (wv == 3) {
-    // ---- block-tridiagonal Cholesky chain of the speed/leg-bias part (13x13 blocks, frames F-1 .. 0), one wave, no
-    //      workgroup barriers:  S_k = A_kk - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,
-    //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
-    //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
-    const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
-    double *TAcur = TA0, *TAprev = TA1;
-    for (int k = F - 1; k >= 0; --k) {
-      const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
-      if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (c < 13 && grp < 3) {
-        double cl[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-          double v;
-          if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
-          else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
-          else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
-#pragma unroll
-          for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
-          cl[i] = v * rinvk[i];
-        }
-        if (grp == 0) {
-#pragma unroll
-          for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
-        } else if (grp == 1) {
-#pragma unroll
-          for (int i = 0; i < 13; ++i) { Mk[k * 169 + i * 13 + c] = cl[i]; Lkm[k * 169 + i * 13 + c] = cl[i]; }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 13; ++i) Gk[k * 169 + i * 13 + c] = cl[i];
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (k > 0) {
-        for (int e = lane; e < 169; e += 64) {
-          const int i = e / 13, j = e - 13 * i;
-          double sacc = 0.0;
-#pragma unroll
-          for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
-          Ad[(k - 1) * 169 + e] -= sacc;
-        }
-      }
-      double *sw = TAcur; TAcur = TAprev; TAprev = sw;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    ph_bias_chain();
   } else {
     // ---- Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One
     //      k-step = 4 landmarks; the operand of tile row X (lane: w[16 X + l % 16][4 kk + l / 16]) serves as A of tiles
@@ -1105,6 +1119,7 @@ __device__ __noinline__ int ph_scale_schur_chain() {
     yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
     if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv < 2) y[16 * (wv + 3) + lr] = yacc1; }
   }
+  if (tid == 0) st.phase_clk[40] = clock64();
   const double qq = block_sum(part_q, red);   // (also the barrier that publishes y, the tiles in C and the chain's output)
   if (tid == 0) { kc.gnorm2 = gnorm2; kc.gmax = gmax; kc.qq = qq; }
   return 0;

@@ -39,5 +39,7 @@ c2 = b.fetch(12, 0).view(np.int64)
 print("scatter sub-phases (window 0, wave 0): visual %d  imu %d  prior-g %d  Bs %d" % (c2[13]-c2[2], c2[14]-c2[13], c2[15]-c2[14], c2[3]-c2[15]))
 print("masks: loops %d  barrier %d  tile_load3 %d  diag+barrier %d | P5 %d  q tiles %d  q bias part(t96) %d  P6 loop %d  block sums %d" % (c2[21]-c2[3], c2[22]-c2[21], c2[23]-c2[22], c2[4]-c2[23], c2[27]-c2[4], c2[28]-c2[27], c2[29]-c2[28], c2[30]-c2[29], c2[5]-c2[30]))
 print("mask-phase arrival of waves 1..3 relative to wave 0: %d %d %d" % (c2[33]-c2[21], c2[34]-c2[21], c2[35]-c2[21]))
+print("Schur pass alone (wave 0, from block sums to its end): %d" % (c2[40]-c2[5]))
+print("bias chain frame 5: chol13 %d  substitutions %d  S update %d" % (c2[37]-c2[36], c2[38]-c2[37], c2[39]-c2[38]))
 print("k_visual_linearize first chunk: total %.0f  proj %.0f  gram %.0f  (n=%.1f kmax=%.1f)" % tuple(vis))
 print("k_imu_linearize factor 0: raw %.0f  whiten %.0f  gram %.0f" % tuple(imu))
