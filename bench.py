@@ -29,6 +29,19 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
     return 88 * sum_k + 16 * L + 8 * (20 * F + 15 + L) + 10 * 8696 + 8 * (n_prior * n_prior + n_prior + 98) + 8 * (20 * F + 15 + L)
 
 
+def algorithmic_flops_build_solve(L, F=11, n_prior=86):
+    """FP64 flops of one k_build_solve launch per window: landmark Schur complement on the lower
+    triangle (L rank-1 updates of the 80x80 block), the speed/leg-bias elimination (13x13 block chain, coupling rows,
+    rank-143 update), the 80x80 Cholesky and the solves. 1 FMA = 2 flops."""
+    tri = 80 * 81 // 2
+    schur = 2 * L * tri + 2 * L * 80 * 3            # rank-1 updates + rhs / q / back-substitution products
+    chain = F * (13 ** 3 // 3 + 3 * 13 ** 3)       # chol13 + three 13x13 triangular solves / products per frame
+    coupling = F * 2 * (2 * 13 * 13 * 81)          # T(k) = M_k [B_k | rhs] - G_k T(k+1)
+    rank = 2 * 13 * F * tri                        # C -= sum_k T_B^T T_B
+    chol = 80 ** 3 // 3 + 2 * 80 * 80
+    return schur + 2 * chain + coupling + rank + chol
+
+
 def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
     """The oracle (CPU restatement of the reference path, scalar FP64, 1 thread) on windows of the same workload."""
     import numpy as np  # noqa: F401
@@ -133,7 +146,7 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh: separate
         # FETCH_SIZE / WRITE_SIZE runs, calibrated on a known 1 GiB copy); only valid for the profiled configuration
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v3.json")
+        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v4.json")
         if os.path.exists(pmc_file) and W == 1024 and args.landmarks == 200:
             try:
                 traffic = json.load(open(pmc_file))["hbm_bytes_per_dispatch"].get(dom)
@@ -149,9 +162,15 @@ def main():
                        "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": "profiles/round1_pmc_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "traffic": traffic, "traffic_source": "profiles/round1_pmc_v4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
                          "algorithmic_bytes_per_window_iteration": b_alg,
-                         "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9},
+                         "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9,
+                         # the same kernel against the FP64 matrix-core ceiling (78.6 TFLOP/s = half the 157.3 TF f32 MFMA rate
+                         # of MI355X_MICROARCH.md): SURVEY 8(d) prices the path in bytes, but at ~40 flop/B the FP64 units bound it
+                         "fp64": {"bound": "mfma", "achieved": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 if dom == "k_build_solve" else None,
+                                  "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 / 78.6 if dom == "k_build_solve" else None,
+                                  "algorithmic_flops_per_window": algorithmic_flops_build_solve(args.landmarks)}},
             "kernels": kern,
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }

@@ -7,8 +7,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KNOWN = ("k_visual_linearize", "k_imu_linearize", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
-         "k_preint_imu_leg", "k_prepare_preint", "k_calib_copy", "k_marginalize")
+KNOWN = ("k_visual_linearize", "k_imu_raw", "k_imu_whiten", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
+         "k_preint_imu_leg", "k_prepare_preint", "k_sqrt_transpose", "k_calib_copy", "k_marginalize")
 
 
 def short(name):
