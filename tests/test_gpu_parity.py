@@ -217,10 +217,10 @@ def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
     sb = ctx.solve_windows(ws, opts)
     for w1, s1 in zip(singles, sb):
         s = ctx.solve_windows([w1], opts)[0]
-        np.testing.assert_allclose(s.final_cost, s1.final_cost, rtol=1e-9)   # LDS-atomic assembly: summation order varies
+        assert s.final_cost == s1.final_cost    # no atomics anywhere on the path: a window's result does not depend on its batch
     for w_b, w_s in zip(ws, singles):
         for a, bb in zip(w_b.state_arrays(), w_s.state_arrays()):
-            np.testing.assert_allclose(a, bb, rtol=0, atol=1e-9 * max(1.0, np.abs(bb).max()))
+            np.testing.assert_array_equal(a, bb)
     # and against the oracle for the ragged ones
     for spec, w_b in zip(specs[1:], ws[1:]):
         w_o = _fresh(cfg, ocfg, **spec)
