@@ -1293,51 +1293,90 @@ __device__ __noinline__ void ph_solve() {
   double *Tm = kc.Tm, *Lkm = kc.Lkm;
   const double *wl = kc.wl;
   double *lm_g = kc.lm_g, *lm_dh2 = kc.lm_dh2, *lm_einv = kc.lm_einv, *lm_y = kc.lm_y;
-  // ---- triangular solves L L^T yP = rhs by wave 0 (lane owns rows lane and lane + 64); pivots by v_readlane ----
+  double *U = S;               // [11][13]
+  double *TA = S + 160;        // [11][169]  T_A blocks
+  double *LI = S + 2048;       // [11][169]  L_k^-1 blocks
   if (tid < 80) col[tid] = 1.0 / C[tid * CLD + tid];
   lds_barrier();
-  if (tid < 64) {
+  // ---- phase A: wave 0 solves L L^T yP = rhs (lane owns rows lane and lane + 64; pivots by v_readlane; the factor is
+  //      read in blocks of 16 columns into registers so that the 160 dependent steps touch no memory); meanwhile waves
+  //      1..3 stage T_A / L_k^-1 in LDS and fetch their rows of T_B (consumed in phase B) ----
+  double trow[81];
+  const int urow = tid - 64;   // (frame, row) of the coupling block handled by this thread in phase B
+  if (wv == 0) {
     const int lane = tid;
     double b0 = tmp[lane], b1 = lane < 16 ? tmp[lane + 64] : 0.0;
-    for (int j = 0; j < 80; ++j) {
-      const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
-      if (lane > j) b0 -= C[lane * CLD + j] * yj;
-      if (lane < 16 && lane + 64 > j) b1 -= C[(lane + 64) * CLD + j] * yj;
-      if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+    const int r1 = min(lane + 64, 79);
+#pragma unroll
+    for (int jb = 0; jb < 5; ++jb) {
+      double l0[16], l1[16], ri[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) { l0[jj] = C[lane * CLD + 16 * jb + jj]; l1[jj] = C[r1 * CLD + 16 * jb + jj]; ri[jj] = col[16 * jb + jj]; }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * jb + jj;
+        const double yj = readlane_d((jb < 4) ? b0 : b1, j & 63) * ri[jj];
+        if (jb < 4 && lane > j) b0 -= l0[jj] * yj;
+        if (lane < 16 && lane + 64 > j) b1 -= l1[jj] * yj;
+        if (lane == (j & 63)) { if (jb < 4) b0 = yj; else b1 = yj; }
+      }
     }
-    for (int j = 79; j >= 0; --j) {
-      const double yj = readlane_d((j < 64) ? b0 : b1, j & 63) * col[j];
-      if (lane < j) b0 -= C[j * CLD + lane] * yj;
-      if (lane < 16 && lane + 64 < j) b1 -= C[j * CLD + lane + 64] * yj;
-      if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+#pragma unroll
+    for (int jb = 4; jb >= 0; --jb) {
+      double c0[16], c1[16], ri[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) { c0[jj] = C[(16 * jb + jj) * CLD + lane]; c1[jj] = C[(16 * jb + jj) * CLD + r1]; ri[jj] = col[16 * jb + jj]; }
+#pragma unroll
+      for (int jj = 15; jj >= 0; --jj) {
+        const int j = 16 * jb + jj;
+        const double yj = readlane_d((jb < 4) ? b0 : b1, j & 63) * ri[jj];
+        if (lane < j) b0 -= c0[jj] * yj;
+        if (lane < 16 && lane + 64 < j) b1 -= c1[jj] * yj;
+        if (lane == (j & 63)) { if (jb < 4) b0 = yj; else b1 = yj; }
+      }
     }
     y[lane] = b0;
     if (lane < 16) y[lane + 64] = b1;
-  }
-  __syncthreads();   // also orders the Tm / Lkm global stores of the elimination before the loads below
-  if (tid == 0) st.phase_clk[9] = clock64();
-  // ---- back-substitution of the B part: u_k = t_g - T_B yP (parallel), then the chain over frames:
-  //      y_k = L_k^-T (u_k - T_A y_{k-1}) with L_k^-1 precomputed, one LDS round trip per frame (wave 0) ----
-  double *U = S;               // [11][13]
-  double *TA = S + 160;        // [11][169]  T_A blocks
-  double *LI = C;              // [11][169]  L_k^-1 blocks (the pose factor is no longer needed)
-  if (tid < 143) {
-    const int k = tid / 13, i = tid % 13;
-    if (k < F) {
-      const double *trow = Tm + (size_t)k * 13 * 96 + i * 96;
-      double sacc = trow[93];
-#pragma unroll 16
-      for (int q = 0; q < 80; ++q) sacc -= trow[13 + q] * y[q];
-      U[k * 13 + i] = sacc;
+  } else {
+    // (the elimination's global stores of T / L^-1 were ordered by the barriers at the end of ph_elim_chol)
+    for (int e = tid - 64; e < F * 169; e += SOLVE_THREADS - 64) {
+      const int k = e / 169, r = (e % 169) / 13, c = e % 13;
+      TA[e] = Tm[(size_t)k * 13 * 96 + r * 96 + c];
+      LI[e] = Lkm[e];
+    }
+    if (urow < 13 * F) {
+      const double *tr = Tm + (size_t)(urow / 13) * 13 * 96 + (urow % 13) * 96 + 13;
+#pragma unroll
+      for (int q = 0; q < 81; ++q) trow[q] = tr[q];   // T_B row (80) and t_g (column 93 = tr[80])
     }
   }
-  for (int e = tid; e < F * 169; e += SOLVE_THREADS) {
-    const int k = e / 169, r = (e % 169) / 13, c = e % 13;
-    TA[e] = Tm[(size_t)k * 13 * 96 + r * 96 + c];
-    LI[e] = Lkm[e];
+  __syncthreads();
+  if (tid == 0) st.phase_clk[9] = clock64();
+  // ---- phase B: u_k = t_g - T_B yP ----
+  if (wv != 0 && urow < 13 * F) {
+    double sacc = trow[80];
+#pragma unroll
+    for (int q = 0; q < 80; ++q) sacc -= trow[q] * y[q];
+    U[urow] = sacc;
   }
   __syncthreads();
-  if (tid < 64) {
+  // ---- phase C: wave 0 runs the chain over frames y_k = L_k^-T (u_k - T_A y_{k-1}) (one LDS round trip per frame); waves
+  //      1..3 back-substitute the landmarks (they only need yP): all 80 coupling entries of a landmark in flight at once ----
+  double part_gnn = 0.0, part_gy = 0.0;
+  auto landmark = [&](int l) {
+    double wcol[80];
+#pragma unroll
+    for (int a = 0; a < 80; ++a) wcol[a] = wl[(size_t)a * L + l];
+    const double gl = lm_g[l], ei = lm_einv[l], d2 = lm_dh2[l];
+    double tl = 0.0;
+#pragma unroll
+    for (int a = 0; a < VILO_NPU; ++a) tl += wcol[a] * act[a] * y[a];
+    const double yl = (gl - tl) * ei;
+    lm_y[l] = yl;
+    part_gnn += d2 * yl * yl;
+    part_gy += gl * yl;
+  };
+  if (wv == 0) {
     const int lane = tid, row = lane < 13 ? lane : 0;
     double *rb = col;   // rhs broadcast buffer
     for (int k = 0; k < F; ++k) {
@@ -1354,11 +1393,13 @@ __device__ __noinline__ void ph_solve() {
       if (lane < 13) y[CD_B0 + 13 * k + lane] = yk;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    for (int l = 192 + tid; l < L; l += SOLVE_THREADS) landmark(l);
+  } else {
+    for (int l = tid - 64; l < L; l += SOLVE_THREADS) landmark(l);
   }
   __syncthreads();
   if (tid == 0) st.phase_clk[10] = clock64();
-  // ---- P9: landmarks pass 2 (back-substitution) + norms ----
-  double part_gnn = 0.0, part_gy = 0.0;
+  // ---- camera part of the norms ----
   for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
     if (act[cd] == 0.0) y[cd] = 0.0;
   }
@@ -1366,15 +1407,6 @@ __device__ __noinline__ void ph_solve() {
   for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
     part_gnn += dh2[cd] * y[cd] * y[cd] * act[cd];
     part_gy += g[cd] * y[cd];
-  }
-  for (int l = tid; l < L; l += SOLVE_THREADS) {
-    double tl = 0.0;
-#pragma unroll 16
-    for (int a = 0; a < VILO_NPU; ++a) tl += wl[(size_t)a * L + l] * act[a] * y[a];
-    const double yl = (lm_g[l] - tl) * lm_einv[l];
-    lm_y[l] = yl;
-    part_gnn += lm_dh2[l] * yl * yl;
-    part_gy += lm_g[l] * yl;
   }
   const double gnnorm2 = block_sum(part_gnn, red);
   const double gy = block_sum(part_gy, red);
