@@ -605,6 +605,7 @@ struct KCtx {
   const ChunkMeta *chunks;
   SolverState *st;
   int win, F, L, pn, kb, n_chunks, n_gram, const_mask, gram_off;
+  int chain_k;   // lowest frame whose M_k / G_k the bias chain has published (producer: wave 3, consumers: waves 0..2)
   double mu, gnorm2, gmax, qq, gnnorm2, gy;
   SolveParams sp;
   short inv_pmap[CD_N];
@@ -890,25 +891,44 @@ __device__ __noinline__ void ph_bias_chain() {
     //      T_A(k) = M_k A_{k,k-1},  G_k = M_k T_A(k+1)^T.  Three groups of 13 lanes run the same forward substitution on
     //      different right-hand sides (columns of A_{k,k-1}, of I and of T_A(k+1)^T).
     const int lane = tid & 63, grp = lane >> 4, c = lane & 15;
+    const int row = c < 13 ? c : 0;
     double *TAcur = TA0, *TAprev = TA1;
     for (int k = F - 1; k >= 0; --k) {
       if (k == 5 && lane == 0) st.phase_clk[36] = clock64();
-      const int f13 = chol13_wave(Ad + k * 169, Lk, rinvk);
+      // right-looking 13x13 Cholesky: lane i (of every 16-lane group) keeps row i of S_k; after step j the updates of the
+      // remaining columns are independent FMAs; column j of L is broadcast with v_readlane
+      double a[13], l[13];
+#pragma unroll
+      for (int j = 0; j < 13; ++j) { a[j] = Ad[k * 169 + row * 13 + j]; l[j] = 0.0; }
+      double myrinv = 1.0;
+      int f13 = 0;
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        double piv = readlane_d(a[j], j);
+        if (!(piv > 0.0) || !isfinite(piv)) { f13 = 1; piv = 1.0; }
+        const double rinv = rsqrt(piv);
+        const double lj = (c == j) ? piv * rinv : (c > j ? a[j] * rinv : 0.0);
+        l[j] = lj;
+        if (c == j) myrinv = rinv;
+#pragma unroll
+        for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
+      }
       if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (k == 5 && lane == 0) st.phase_clk[37] = clock64();
+      // forward substitutions L x = rhs with L(i, q) = register l[q] of lane i: T_A(k) columns (group 0), L^-1 columns
+      // (group 1), G_k columns (group 2)
+      double cl[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        double v;
+        if (grp == 0) v = (k > 0) ? Ao[max(k - 1, 0) * 169 + i * 13 + row] : 0.0;
+        else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
+        else v = (k < F - 1) ? TAprev[row * 13 + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < i; ++q) v -= readlane_d(l[q], i) * cl[q];
+        cl[i] = v * readlane_d(myrinv, i);
+      }
       if (c < 13 && grp < 3) {
-        double cl[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-          double v;
-          if (grp == 0) v = (k > 0) ? Ao[(k - 1) * 169 + i * 13 + c] : 0.0;
-          else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
-          else v = (k < F - 1) ? TAprev[c * 13 + i] : 0.0;
-#pragma unroll
-          for (int q = 0; q < i; ++q) v -= Lk[i * 13 + q] * cl[q];
-          cl[i] = v * rinvk[i];
-        }
         if (grp == 0) {
 #pragma unroll
           for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; Tm[k * 13 * 96 + i * 96 + c] = cl[i]; }
@@ -921,6 +941,7 @@ __device__ __noinline__ void ph_bias_chain() {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *(volatile int *)&kc.chain_k = k;   // M_k / G_k of frame k are visible: the T recurrence may consume them
       if (k == 5 && lane == 0) st.phase_clk[38] = clock64();
       if (k > 0) {
         for (int e = lane; e < 169; e += 64) {
@@ -1053,7 +1074,7 @@ __device__ __noinline__ int ph_scale_schur_chain() {
   if (tid == 0) st.phase_clk[5] = clock64();
   // regularise the speed/leg-bias diagonal blocks (the pose part is regularised after the tile redistribution)
   for (int e = tid; e < 11 * 13; e += SOLVE_THREADS) Ad[(e / 13) * 169 + (e % 13) * 14] += mu * dh2[CD_B0 + e];
-  if (tid == 0) { s_flag[0] = 0; }
+  if (tid == 0) { s_flag[0] = 0; *(volatile int *)&kc.chain_k = F; }
   __syncthreads();   // also: lm_einv / lm_y written above are read through global memory below
   double *Mk = S, *Gk = S + 1859, *TA1 = S + 3718, *rinvk = S + 3887, *TA0 = col;
   double actv[5], vv[5], yacc0 = 0.0, yacc1 = 0.0, qacc = 0.0;
@@ -1118,8 +1139,57 @@ __device__ __noinline__ int ph_scale_schur_chain() {
     yacc0 += __shfl_xor(yacc0, 16, 64); yacc0 += __shfl_xor(yacc0, 32, 64);
     yacc1 += __shfl_xor(yacc1, 16, 64); yacc1 += __shfl_xor(yacc1, 32, 64);
     if (lk == 0) { y[16 * wv + lr] = yacc0; if (wv < 2) y[16 * (wv + 3) + lr] = yacc1; }
+    if (tid == 0) st.phase_clk[40] = clock64();
+    // ---- T(k) = [T_B(k) | t_g(k)] = M_k [B_k | rhs_k] - G_k T(k+1): the 80 + 1 columns are independent, so each wave
+    //      carries its 16-column tiles (wave w < 3: tiles w and w + 3; tile 5 = rhs column) through all frames without any
+    //      barrier. The previous result is already in B-operand layout: register kk of a lane is row 4 kk + l / 16. ----
+      {
+      const int X0 = wv, X1 = wv + 3;
+      mfma_d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+      for (int k = F - 1; k >= 0; --k) {
+        while (*(volatile int *)&kc.chain_k > k) __builtin_amdgcn_s_sleep(4);   // frame k published by the chain (wave 3)
+        asm volatile("" ::: "memory");
+        mfma_d4 n0 = {0.0, 0.0, 0.0, 0.0}, n1 = {0.0, 0.0, 0.0, 0.0};
+        double am[4], ag[4];
+  #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int q = 4 * kk + lk;
+          const bool in = (lr < 13) && (q < 13);
+          const int idx = k * 169 + min(lr, 12) * 13 + min(q, 12);
+          const double m = Mk[idx], gg = Gk[idx];
+          am[kk] = in ? m : 0.0;
+          ag[kk] = (in && k < F - 1) ? -gg : 0.0;
+        }
+  #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int q = 4 * kk + lk, qc = min(q, 12);
+          double b0 = Bval(k, qc, 16 * X0 + lr);
+          b0 = (q < 13) ? b0 : 0.0;
+          n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b0, n0, 0, 0, 0);
+          if (X1 < 6) {
+            double b1 = (X1 < 5) ? Bval(k, qc, 16 * min(X1, 4) + lr) : ((lr == 0) ? g[CD_B0 + 13 * k + qc] : 0.0);
+            b1 = (q < 13) ? b1 : 0.0;
+            n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b1, n1, 0, 0, 0);
+          }
+        }
+  #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t0[kk], n0, 0, 0, 0);
+          if (X1 < 6) n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t1[kk], n1, 0, 0, 0);
+        }
+        t0 = n0; t1 = n1;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = lk + 4 * r;
+          if (row < 13) {
+            Tm[k * 13 * 96 + row * 96 + 13 + 16 * X0 + lr] = n0[r];
+            if (X1 < 5) Tm[k * 13 * 96 + row * 96 + 13 + 16 * X1 + lr] = n1[r];
+            else if (X1 == 5 && lr == 0) Tm[k * 13 * 96 + row * 96 + 93] = n1[r];
+          }
+        }
+      }
+    }
   }
-  if (tid == 0) st.phase_clk[40] = clock64();
   const double qq = block_sum(part_q, red);   // (also the barrier that publishes y, the tiles in C and the chain's output)
   if (tid == 0) { kc.gnorm2 = gnorm2; kc.gmax = gmax; kc.qq = qq; }
   return 0;
@@ -1149,53 +1219,6 @@ __device__ __noinline__ void ph_elim_chol() {
   };
   WAVE_DISPATCH(tile_load);
   __syncthreads();   // tmp (reduced rhs) complete
-  // ---- T(k) = [T_B(k) | t_g(k)] = M_k [B_k | rhs_k] - G_k T(k+1): the 80 + 1 columns are independent, so each wave
-  //      carries its 16-column tiles (wave w: tiles w and w + 4; tile 5 = rhs column) through all frames without any
-  //      barrier. The previous result is already in B-operand layout: register kk of a lane is row 4 kk + l / 16. ----
-  {
-    const int X0 = wv, X1 = wv + 4;
-    mfma_d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
-    for (int k = F - 1; k >= 0; --k) {
-      mfma_d4 n0 = {0.0, 0.0, 0.0, 0.0}, n1 = {0.0, 0.0, 0.0, 0.0};
-      double am[4], ag[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int q = 4 * kk + lk;
-        const bool in = (lr < 13) && (q < 13);
-        const int idx = k * 169 + min(lr, 12) * 13 + min(q, 12);
-        const double m = Mk[idx], gg = Gk[idx];
-        am[kk] = in ? m : 0.0;
-        ag[kk] = (in && k < F - 1) ? -gg : 0.0;
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int q = 4 * kk + lk, qc = min(q, 12);
-        double b0 = Bval(k, qc, 16 * X0 + lr);
-        b0 = (q < 13) ? b0 : 0.0;
-        n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b0, n0, 0, 0, 0);
-        if (X1 < 6) {
-          double b1 = (X1 < 5) ? Bval(k, qc, 16 * min(X1, 4) + lr) : ((lr == 0) ? tmp[CD_B0 + 13 * k + qc] : 0.0);
-          b1 = (q < 13) ? b1 : 0.0;
-          n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], b1, n1, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t0[kk], n0, 0, 0, 0);
-        if (X1 < 6) n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[kk], t1[kk], n1, 0, 0, 0);
-      }
-      t0 = n0; t1 = n1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lk + 4 * r;
-        if (row < 13) {
-          Tm[k * 13 * 96 + row * 96 + 13 + 16 * X0 + lr] = n0[r];
-          if (X1 < 5) Tm[k * 13 * 96 + row * 96 + 13 + 16 * X1 + lr] = n1[r];
-          else if (X1 == 5 && lr == 0) Tm[k * 13 * 96 + row * 96 + 93] = n1[r];
-        }
-      }
-    }
-  }
   __syncthreads();   // T in global memory is read by every wave below
   // ---- C -= sum_k T_B(k)^T T_B(k) (rank 143) on the matrix cores, rhs_P -= sum_k T_B(k)^T t_g(k); operands from Tm ----
   {
