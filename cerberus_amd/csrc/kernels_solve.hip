@@ -915,18 +915,32 @@ __device__ __noinline__ void ph_bias_chain() {
       }
       if (f13 && lane == 0) { s_flag[0] = 1; st.pad[0] = 100 + k; }
       if (k == 5 && lane == 0) st.phase_clk[37] = clock64();
-      // forward substitutions L x = rhs with L(i, q) = register l[q] of lane i: T_A(k) columns (group 0), L^-1 columns
-      // (group 1), G_k columns (group 2)
+      // forward substitutions L x = rhs: T_A(k) columns (group 0), L^-1 columns (group 1), G_k columns (group 2). L goes
+      // through LDS once and is read back (broadcast) into registers BEFORE the dependent chain, so the 78 dependent FMAs
+      // of a lane wait on nothing but each other
+      if (lane < 13) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) Lk[lane * 13 + j] = l[j];
+        rinvk[lane] = myrinv;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double Lr[78], rv[13], rhs[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        rv[i] = rinvk[i];
+#pragma unroll
+        for (int q = 0; q < i; ++q) Lr[(i * (i - 1)) / 2 + q] = Lk[i * 13 + q];
+        if (grp == 0) rhs[i] = (k > 0) ? Ao[max(k - 1, 0) * 169 + i * 13 + row] : 0.0;
+        else if (grp == 1) rhs[i] = (i == c) ? 1.0 : 0.0;
+        else rhs[i] = (k < F - 1) ? TAprev[row * 13 + i] : 0.0;
+      }
       double cl[13];
 #pragma unroll
       for (int i = 0; i < 13; ++i) {
-        double v;
-        if (grp == 0) v = (k > 0) ? Ao[max(k - 1, 0) * 169 + i * 13 + row] : 0.0;
-        else if (grp == 1) v = (i == c) ? 1.0 : 0.0;
-        else v = (k < F - 1) ? TAprev[row * 13 + i] : 0.0;
+        double v = rhs[i];
 #pragma unroll
-        for (int q = 0; q < i; ++q) v -= readlane_d(l[q], i) * cl[q];
-        cl[i] = v * readlane_d(myrinv, i);
+        for (int q = 0; q < i; ++q) v -= Lr[(i * (i - 1)) / 2 + q] * cl[q];
+        cl[i] = v * rv[i];
       }
       if (c < 13 && grp < 3) {
         if (grp == 0) {
