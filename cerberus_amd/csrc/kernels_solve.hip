@@ -546,34 +546,44 @@ __device__ int chol13_wave(const double *A, double *Lout, double *rinv_out) {
 __device__ int chol16_wave(const double *A, double *Ldst, int ldl, double *Linv) {
   const int lane = threadIdx.x & 63;
   const int row = lane & 15;
-  double a[16], l[16];
+  double a[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { a[j] = A[row * 17 + j]; l[j] = 0.0; }
+  for (int j = 0; j < 16; ++j) a[j] = A[row * 17 + j];
   int fail = 0;
   double myrinv = 1.0;
+  // right-looking: after column j is scaled, the updates of the remaining columns are independent FMAs
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    double s = a[j];
-#pragma unroll
-    for (int q = 0; q < j; ++q) s -= l[q] * readlane_d(l[q], j);
-    double piv = readlane_d(s, j);
+    double piv = readlane_d(a[j], j);
     if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
-    const double rinv = rsqrt(piv), ljj = piv * rinv;
-    l[j] = (lane == j) ? ljj : (lane > j ? s * rinv : 0.0);
-    if (lane == j) myrinv = rinv;
+    const double rinv = rsqrt(piv);
+    const double lj = (row == j) ? piv * rinv : (row > j ? a[j] * rinv : 0.0);
+    a[j] = lj;
+    if (row == j) myrinv = rinv;
+#pragma unroll
+    for (int q = j + 1; q < 16; ++q) a[q] -= lj * readlane_d(lj, q);
   }
   if (lane < 16) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) Ldst[lane * ldl + j] = l[j];
+    for (int j = 0; j < 16; ++j) Ldst[lane * ldl + j] = a[j];
+    Linv[16 * 17 + lane] = myrinv;   // (scratch row behind the 16 x 17 block)
   }
-  // column c = lane of L^-1 by forward substitution; L(i, q) is register l[q] of lane i
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // column c = lane of L^-1 by forward substitution; L is read back (broadcast) into registers before the dependent chain
+  double Lr[120], rv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    rv[i] = Linv[16 * 17 + i];
+#pragma unroll
+    for (int q = 0; q < i; ++q) Lr[(i * (i - 1)) / 2 + q] = Ldst[i * ldl + q];
+  }
   double cl[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     double v = (i == row) ? 1.0 : 0.0;
 #pragma unroll
-    for (int q = 0; q < i; ++q) v -= readlane_d(l[q], i) * cl[q];
-    cl[i] = v * readlane_d(myrinv, i);
+    for (int q = 0; q < i; ++q) v -= Lr[(i * (i - 1)) / 2 + q] * cl[q];
+    cl[i] = v * rv[i];
   }
   if (lane < 16) {
 #pragma unroll
