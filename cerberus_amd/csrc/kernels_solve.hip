@@ -86,24 +86,51 @@ __device__ double block_max(double v, double *red) {
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #define XLANE 54  // LDS stride per lane: 2 rows x 26 cols + 2 pad; even so that every row starts 16-byte aligned (ds_read_b128)
 
+// Per-lane view of a packed wave (WaveMeta): which chunk (start frame) a lane belongs to.
+struct LaneSeg {
+  int seg, s, gi, li;   // segment (-1: padding lane), start frame, global / window-local landmark index
+  bool active;
+};
+__device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkMeta *chunks, int lane, int cs[4], int cn[4], int ckm[4], int cgo[4]) {
+  LaneSeg ls;
+  ls.seg = -1; ls.s = 0; ls.gi = 0; ls.li = 0; ls.active = false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    cs[g] = 0; cn[g] = 0; ckm[g] = 0; cgo[g] = 0;
+    if (g < wv.nseg) {
+      const ChunkMeta cm = chunks[wv.seg_chunk[g]];
+      cs[g] = cm.s; cn[g] = cm.n; ckm[g] = cm.kmax; cgo[g] = cm.gram_off;
+      const int i = lane - wv.seg_lane0[g];
+      if (i >= 0 && i < cm.n) { ls.seg = g; ls.s = cm.s; ls.gi = cm.lm_off + i; ls.li = cm.lm_local + i; ls.active = true; }
+    }
+  }
+  return ls;
+}
+
 __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) {
   __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
-  const ChunkMeta cm = b.chunk[blockIdx.x];
-  SolverState &st = b.st[cm.win];
+  __shared__ double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
+  const WaveMeta wv = b.wave[blockIdx.x];
+  SolverState &st = b.st[wv.win];
   if (st.done || !st.need_lin) return;
-  const WinMeta wm = b.win[cm.win];
+  const WinMeta wm = b.win[wv.win];
   const int lane = threadIdx.x;
-  const bool active = lane < cm.n;
-  const int n = cm.n, L = wm.L, s = cm.s;
-  const bool prof = (blockIdx.x == (unsigned)wm.chunk_off) && lane == 0;
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
+  const bool active = ls.active;
+  const int n = wv.n_lanes, L = wm.L, s = ls.s;
+  const bool prof = (blockIdx.x == (unsigned)wm.wave_off) && lane == 0;
   long long c_proj = 0, c_gram = 0, c_t0 = clock64(), c_a = 0;
-  const double *x = b.x + (size_t)cm.win * XSTRIDE;
+  const double *xg = b.x + (size_t)wv.win * XSTRIDE;
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
-  const int li = cm.lm_local + lane;
+  const int li = ls.li;
+  for (int e = lane; e < XSTRIDE; e += 64) xs[e] = xg[e];
+  const double *x = xs;
 
   // Gram of a (start frame, t) slot on the FP64 matrix cores: X^T X with X = the 2 n corrected Jacobian rows (26 columns,
   // padded to 32) as three 16 x 16 tiles (0,0), (0,1), (1,1). One k-step = 4 rows = 2 landmarks; lane (lr, lk) supplies
   // X[row 4 kk + lk][lr] (tile column 0) and X[..][16 + lr] (tile column 1), which serve as A and B operands alike.
+  // Every segment of the wave (its own start frame) accumulates into its own three tiles.
   const int lr = lane & 15, lk = lane >> 4;
   const int xoff = (lk >> 1) * XLANE + (lk & 1) * 26 + lr;
   const bool c1on = lr < 10;   // columns 26 .. 31 of the second tile column do not exist
@@ -111,15 +138,17 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
     for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
 
-  const double *obs = b.obs + cm.obs_off;
-  const unsigned char *flg = b.flags + cm.flag_off;
+  const double *obs = b.obs + wv.obs_off;
+  const unsigned char *flg = b.flags + wv.flag_off;
   double o12[12];
   double lam = 1.0;
+  for (int c = 0; c < 12; ++c) o12[c] = 0.0;
   if (active) {
-    lam = b.lam[cm.lm_off + lane];
+    lam = b.lam[ls.gi];
     o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
     o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
   }
+  lds_barrier();
   const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
   const double td = x[XO_TD];
 
@@ -137,26 +166,28 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
 #pragma unroll
     for (int c = 0; c < 11; ++c) on[c] = obs[(size_t)c * n + lane];
   }
-  for (int t = 0; t < cm.kmax; ++t) {
-    const int j = s + t;
+  for (int t = 0; t < wv.kmax; ++t) {
+    const int j = min(s + t, VILO_MAX_FRAMES - 1);
     const unsigned char fl = fl_next;
     const double *pose_j = x + XO_POSE + 7 * j;
     double ob[11];
 #pragma unroll
     for (int c = 0; c < 11; ++c) ob[c] = on[c];
-    if (active && t + 1 < cm.kmax) {
+    if (active && t + 1 < wv.kmax) {
       fl_next = flg[(size_t)(t + 1) * n + lane];
       const double *obn = obs + (size_t)(t + 1) * 11 * n;
 #pragma unroll
       for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
     }
-    mfma_d4 G00 = {0.0, 0.0, 0.0, 0.0}, G01 = G00, G11 = G00;
+    mfma_d4 G00[4], G01[4], G11[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { G00[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G01[g] = G00[g]; G11[g] = G00[g]; }
     double wj[6];
     for (int c = 0; c < 6; ++c) wj[c] = 0.0;
 
     for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
-      const bool produce = (fl & 1) && (cam == 0 || (fl & 2));
+      const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
       double *xr0 = &X[lane * XLANE], *xr1 = xr0 + 26;
       c_a = clock64();
       if (produce) {
@@ -203,42 +234,50 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
       }
       lds_barrier();
       { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
-      // rows of lanes >= n are zero (those lanes store zeros above), so the k-step count is rounded up to a multiple of 4
-      // (rows 128 .. are the zero pad lanes): 8 LDS reads in flight, then 12 MFMAs
-      const int nks = ((2 * n + 3) >> 2), nks4 = (nks + 3) & ~3;
-      for (int kk0 = 0; kk0 < nks4; kk0 += 4) {
-        double a0[4], a1[4];
+      // rows of padding / unobserved lanes are zero, and every segment spans a multiple of 8 lanes = 4 k-steps:
+      // 8 LDS reads in flight, then 12 MFMAs per trip
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double *xr = &X[2 * (kk0 + u) * XLANE + xoff];
-          a0[u] = xr[0];
-          a1[u] = xr[16];
-        }
+      for (int g = 0; g < 4; ++g) {
+        if (g >= wv.nseg || t >= ckm[g]) continue;
+        const int k0 = wv.seg_lane0[g] >> 1, k1 = k0 + (((cn[g] + 7) & ~7) >> 1);
+        for (int kk0 = k0; kk0 < k1; kk0 += 4) {
+          double a0[4], a1[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double b1 = c1on ? a1[u] : 0.0;
-          G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], G00, 0, 0, 0);
-          G01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1, G01, 0, 0, 0);
-          G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, G11, 0, 0, 0);
+          for (int u = 0; u < 4; ++u) {
+            const double *xr = &X[2 * (kk0 + u) * XLANE + xoff];
+            a0[u] = xr[0];
+            a1[u] = xr[16];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double b1 = c1on ? a1[u] : 0.0;
+            G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], G00[g], 0, 0, 0);
+            G01[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1, G01[g], 0, 0, 0);
+            G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, G11[g], 0, 0, 0);
+          }
         }
       }
       lds_barrier();
       c_gram += clock64() - c_a;
     }
-    double *gs = b.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = lk + 4 * r;
-      if (row <= lr) gs[tri26(row, lr)] = G00[r];
-      if (c1on) gs[tri26(row, 16 + lr)] = G01[r];
-      if (c1on && row < 10 && row <= lr) gs[tri26(16 + row, 16 + lr)] = G11[r];
+    for (int g = 0; g < 4; ++g) {
+      if (g >= wv.nseg || t >= ckm[g]) continue;
+      double *gs = b.gram + (size_t)(cgo[g] + t) * VILO_GRAM;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk + 4 * r;
+        if (row <= lr) gs[tri26(row, lr)] = G00[g][r];
+        if (c1on) gs[tri26(row, 16 + lr)] = G01[g][r];
+        if (c1on && row < 10 && row <= lr) gs[tri26(16 + row, 16 + lr)] = G11[g][r];
+      }
     }
     if (active && t > 0 && (fl & 1))
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
   }
   if (active) {
-    b.lm_E[cm.lm_off + lane] = E;
-    b.lm_g[cm.lm_off + lane] = gl;
+    b.lm_E[ls.gi] = E;
+    b.lm_g[ls.gi] = gl;
     for (int c = 0; c < 6; ++c) {
       wbase[(size_t)(6 * s + c) * L + li] = wc_s[c];
       wbase[(size_t)(CD_EX0 + c) * L + li] = wc_e0[c];
@@ -248,24 +287,26 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   }
   const double csum = wave_sum(active ? cost : 0.0);
   if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
-  if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = cm.n; st.phase_clk[20] = cm.kmax; }
+  if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = wv.n_lanes; st.phase_clk[20] = wv.kmax; }
 }
 
 // Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
 // Also forms the candidate inverse depth: lambda_c = lambda - a * g_l / dhat_l^2 - b * y_l.
 __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, double huber_a, int init_mode) {
-  const ChunkMeta cm = b.chunk[blockIdx.x];
-  const SolverState &st = b.st[cm.win];
+  const WaveMeta wv = b.wave[blockIdx.x];
+  const SolverState &st = b.st[wv.win];
   if (st.done || (!init_mode && !st.step_valid)) return;
   const int lane = threadIdx.x;
-  const bool active = lane < cm.n;
-  const int n = cm.n, s = cm.s;
-  const double *x = b.xc + (size_t)cm.win * XSTRIDE;
-  const double *obs = b.obs + cm.obs_off;
-  const unsigned char *flg = b.flags + cm.flag_off;
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
+  const bool active = ls.active;
+  const int n = wv.n_lanes, s = ls.s;
+  const double *x = b.xc + (size_t)wv.win * XSTRIDE;
+  const double *obs = b.obs + wv.obs_off;
+  const unsigned char *flg = b.flags + wv.flag_off;
   double cost = 0.0;
   if (active) {
-    const int gi = cm.lm_off + lane;
+    const int gi = ls.gi;
     double lam = b.lam[gi];
     if (!init_mode) lam += -st.coef_a * b.lm_g[gi] / b.lm_dh2[gi] - st.coef_b * b.lm_y[gi];
     b.lamc[gi] = lam;
@@ -274,7 +315,7 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
     o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
     const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
     const double td = x[XO_TD];
-    for (int t = 0; t < cm.kmax; ++t) {
+    for (int t = 0; t < wv.kmax; ++t) {
       const unsigned char fl = flg[(size_t)t * n + lane];
       if (!(fl & 1)) continue;
       const double *pose_j = x + XO_POSE + 7 * (s + t);
@@ -653,7 +694,7 @@ __shared__ KCtx kc;
 
 __device__ __noinline__ void ph_tables() {
   KB_LOCALS
-  const WinMeta wm_c = {kc.F, kc.L, kc.n_chunks, 0, 0, 0, kc.const_mask, kc.pn, kc.gram_off, kc.n_gram, 0, kc.kb};
+  const WinMeta wm_c = {kc.F, kc.L, kc.n_chunks, 0, 0, 0, kc.const_mask, kc.pn, kc.gram_off, kc.n_gram, 0, kc.kb, 0, 0};
   const WinMeta &wm = wm_c; const int *pmap = kc.pmap; const ChunkMeta *chunkp = kc.chunks;
   // ---- tables ----
   for (int cd = tid; cd < CD_N; cd += SOLVE_THREADS) {
@@ -1592,7 +1633,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   }
   // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2)
   double part = 0.0;
-  for (int c = tid; c < wm.n_chunks; c += 128) part += b.chunk_cost[wm.chunk_off + c];
+  for (int c = tid; c < wm.n_waves; c += 128) part += b.chunk_cost[wm.wave_off + c];
   const double vis = block_sum(part, red);
   part = 0.0;
   for (int k = tid; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
@@ -1725,7 +1766,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   // IterationZero: cost at the initial point
   VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
   P0(3);
-  hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 1);
+  hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 1);
   P1();
   P0(4);
   hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
@@ -1736,7 +1777,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   ap.init_mode = 0;
   for (int it = 0; it < o->max_num_iterations; ++it) {
     P0(0);
-    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha);
+    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
     P1();
     P0(7);
     hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn);
@@ -1748,7 +1789,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
     P1();
     P0(3);
-    hipLaunchKernelGGL(k_visual_cost, dim3(b.n_chunks), dim3(64), 0, s, b, sq, ha, 0);
+    hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 0);
     P1();
     P0(4);
     hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 0);
@@ -1765,7 +1806,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
 int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4);
-  hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_chunks), dim3(64), 0, ctx->stream, b, sq, ha);
+  hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, ctx->stream, b, sq, ha);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn);
   hipLaunchKernelGGL(k_imu_whiten, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
   VILO_HIP(hipGetLastError());

@@ -42,7 +42,9 @@ struct WinMeta {
   int gram_off;    // first Gram slot
   int n_gram;
   int prior_nb;
-  int pad;
+  int pad;         // frame whose speed/leg-bias block the prior touches (-1: none)
+  int wave_off;    // first packed visual wave
+  int n_waves;
 };
 
 // One wave-sized chunk of the landmarks of a window that share a start frame.
@@ -52,8 +54,18 @@ struct ChunkMeta {
   int lm_local;             // index inside the window
   int gram_off;             // global Gram slot of t = 0 (kmax slots)
   int pad;
-  long long obs_off;        // doubles: layout [t][11][n]
-  long long flag_off;       // bytes:   layout [t][n]  bit0 valid, bit1 stereo
+  long long obs_off;        // (unused: observations are stored per packed wave, see WaveMeta)
+  long long flag_off;
+};
+
+// One wave of the visual kernels: up to 4 chunks (different start frames) packed side by side, each starting at a lane
+// that is a multiple of 8 (the MFMA Gram pass walks 8 landmarks per trip); observations are stored per wave.
+struct WaveMeta {
+  int win, nseg, n_lanes, kmax;   // n_lanes: multiple of 8, <= 64; kmax: max over the segments
+  int seg_chunk[4];               // global chunk index
+  int seg_lane0[4];
+  long long obs_off;              // doubles: layout [t][11][n_lanes]
+  long long flag_off;             // bytes:   layout [t][n_lanes]  bit0 valid, bit1 stereo
 };
 
 // Trust-region / dogleg state per window (Ceres 1.14 TrustRegionMinimizer + DoglegStrategy members).
@@ -83,9 +95,10 @@ struct SolverState {
 };
 
 struct BatchDev {
-  int W, n_chunks, n_lm, n_gram;
+  int W, n_chunks, n_lm, n_gram, n_waves;
   WinMeta *win;
   ChunkMeta *chunk;
+  WaveMeta *wave;
   double *obs;
   unsigned char *flags;
   // states

@@ -77,6 +77,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   memset(&bt->d, 0, sizeof(BatchDev));
   std::vector<WinMeta> wins(W);
   std::vector<ChunkMeta> chunks;
+  std::vector<WaveMeta> waves;
+  std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
   std::vector<double> obs, x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<unsigned char> flags;
   std::vector<vilo_preint> pre((size_t)W * 10);
@@ -133,28 +135,53 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
           kmax = std::max(kmax, K);
         }
         cm.kmax = kmax;
-        cm.obs_off = (long long)obs.size();
-        cm.flag_off = (long long)flags.size();
         cm.gram_off = gram_total;
         gram_total += kmax;
-        obs.resize(obs.size() + (size_t)kmax * 11 * n, 0.0);
-        flags.resize(flags.size() + (size_t)kmax * n, 0);
         for (int i = 0; i < n; ++i) {
           const int l = ids[c0 + i];
-          const int o0 = d.lm_obs_offset[l], K = d.lm_obs_offset[l + 1] - o0;
-          for (int t = 0; t < K; ++t) {
-            for (int f = 0; f < 11; ++f) obs[cm.obs_off + ((size_t)t * 11 + f) * n + i] = d.obs[(size_t)(o0 + t) * 11 + f];
-            flags[cm.flag_off + (size_t)t * n + i] = (unsigned char)(1 | (d.obs_is_stereo[o0 + t] ? 2 : 0));
-          }
           bt->perm_host.push_back(l);
           lam0.push_back(s.inv_depth[l]);
         }
+        chunk_ids.push_back(std::vector<int>(ids.begin() + c0, ids.begin() + c0 + n));
         local += n;
         chunks.push_back(cm);
       }
     }
     if (local != L) { ctx->err = "landmark start_frame outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
     wm.n_chunks = (int)chunks.size() - wm.chunk_off;
+    // pack the window's chunks into waves: consecutive chunks side by side, each at a lane multiple of 8, <= 4 per wave
+    wm.wave_off = (int)waves.size();
+    for (int c = wm.chunk_off; c < (int)chunks.size();) {
+      WaveMeta wv;
+      memset(&wv, 0, sizeof(wv));
+      wv.win = w;
+      int lanes = 0;
+      while (c < (int)chunks.size() && wv.nseg < 4) {
+        const int pad = (chunks[c].n + 7) & ~7;
+        if (lanes + pad > 64) break;
+        wv.seg_chunk[wv.nseg] = c; wv.seg_lane0[wv.nseg] = lanes;
+        wv.kmax = std::max(wv.kmax, chunks[c].kmax);
+        lanes += pad; ++wv.nseg; ++c;
+      }
+      wv.n_lanes = lanes;
+      wv.obs_off = (long long)obs.size();
+      wv.flag_off = (long long)flags.size();
+      obs.resize(obs.size() + (size_t)wv.kmax * 11 * lanes, 0.0);
+      flags.resize(flags.size() + (size_t)wv.kmax * lanes, 0);
+      for (int g = 0; g < wv.nseg; ++g) {
+        const std::vector<int> &ids = chunk_ids[wv.seg_chunk[g]];
+        for (size_t i = 0; i < ids.size(); ++i) {
+          const int l = ids[i], lane = wv.seg_lane0[g] + (int)i;
+          const int o0 = d.lm_obs_offset[l], K = d.lm_obs_offset[l + 1] - o0;
+          for (int t = 0; t < K; ++t) {
+            for (int f = 0; f < 11; ++f) obs[wv.obs_off + ((size_t)t * 11 + f) * lanes + lane] = d.obs[(size_t)(o0 + t) * 11 + f];
+            flags[wv.flag_off + (size_t)t * lanes + lane] = (unsigned char)(1 | (d.obs_is_stereo[o0 + t] ? 2 : 0));
+          }
+        }
+      }
+      waves.push_back(wv);
+    }
+    wm.n_waves = (int)waves.size() - wm.wave_off;
     wm.n_gram = gram_total - wm.gram_off;
     lm_total += L;
     for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k];
@@ -209,9 +236,10 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     }
   }
   BatchDev &D = bt->d;
-  D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total;
+  D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
   TRYB(dev_upload(ctx, bt, &D.win, wins));
   TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
+  TRYB(dev_upload(ctx, bt, &D.wave, waves));
   TRYB(dev_upload(ctx, bt, &D.obs, obs));
   TRYB(dev_upload(ctx, bt, &D.flags, flags));
   TRYB(dev_upload(ctx, bt, &D.x0, x0));
