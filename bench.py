@@ -170,11 +170,14 @@ def main():
                          "fp64": {"bound": "mfma", "achieved": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 if dom == "k_build_solve" else None,
                                   "peak": 78.6, "unit": "TFLOP/s",
                                   "frac": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 / 78.6 if dom == "k_build_solve" else None,
-                                  "algorithmic_flops_per_window": algorithmic_flops_build_solve(args.landmarks)}},
+                                  "algorithmic_flops_per_window": algorithmic_flops_build_solve(args.landmarks),
+                                  # 13.7 Mflop per window-iteration at config 2 for the WHOLE iteration (all kernels)
+                                  "whole_iteration_tflops": (13.7e6 * W / (iter_ms * 1e-3) / 1e12) if args.landmarks == 200 else None,
+                                  "whole_iteration_frac": (13.7e6 * W / (iter_ms * 1e-3) / 1e12 / 78.6) if args.landmarks == 200 else None}},
             "kernels": kern,
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
-        if args.single_window_latency:
+        if args.single_window_latency or world == 1:   # absolute rate of ONE window on one GPU
             b1 = api.Batch(ctx, windows[:1])
             lib.vilo_set_profiling(ctx.h, 0)
             for _ in range(3):
