@@ -82,7 +82,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; VILO_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box
+        dist.init_process_group(os.environ.get("VILO_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
     import numpy as np
@@ -118,7 +120,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -157,7 +159,7 @@ def main():
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (500 Hz), "
+            "config": {"workload": ("BASELINE configs[1]" if args.landmarks == 200 else "BASELINE configs[2]-sized") + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (500 Hz), "
                                    "%d independent windows per GPU, %d fixed dogleg iterations per step" % (args.landmarks, W, ITERS),
                        "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
