@@ -71,7 +71,8 @@ def main():
     ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU")
     ap.add_argument("--landmarks", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window")
+    ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
+    ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +149,7 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh: separate
         # FETCH_SIZE / WRITE_SIZE runs, calibrated on a known 1 GiB copy); only valid for the profiled configuration
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v4.json")
+        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v5.json")
         if os.path.exists(pmc_file) and W == 1024 and args.landmarks == 200:
             try:
                 traffic = json.load(open(pmc_file))["hbm_bytes_per_dispatch"].get(dom)
@@ -164,7 +165,7 @@ def main():
                        "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": "profiles/round1_pmc_v4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "traffic": traffic, "traffic_source": "profiles/round1_pmc_v5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9,
                          # the same kernel against the FP64 matrix-core ceiling (78.6 TFLOP/s = half the 157.3 TF f32 MFMA rate
@@ -179,7 +180,7 @@ def main():
             "kernels": kern,
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
-        if args.single_window_latency or world == 1:   # absolute rate of ONE window on one GPU
+        if (args.single_window_latency or world == 1) and not args.no_single_window:   # absolute rate of ONE window on one GPU
             b1 = api.Batch(ctx, windows[:1])
             lib.vilo_set_profiling(ctx.h, 0)
             for _ in range(3):
