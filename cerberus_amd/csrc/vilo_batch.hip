@@ -209,17 +209,20 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
       }
       wm.pad = bframe;
       double *H = &pH[(size_t)w * 96 * 96], *b0 = &pb0[(size_t)w * 96];
-      for (int i = 0; i < n; ++i) {
-        for (int j = 0; j <= i; ++j) {
-          double sacc = 0.0;
-          for (int r = 0; r < n; ++r) sacc += p.J0[(size_t)r * n + i] * p.J0[(size_t)r * n + j];
-          H[(size_t)i * n + j] = sacc;
-          H[(size_t)j * n + i] = sacc;
+      // H = J0^T J0 and b0 = J0^T r0 as sums of row outer products: unit-stride inner loops (this is the bulk of the
+      // host-side packing time of a batch)
+      for (int r = 0; r < n; ++r) {
+        const double *jr = p.J0 + (size_t)r * n;
+        const double rr = p.r0[r];
+        for (int i = 0; i < n; ++i) {
+          const double ji = jr[i];
+          double *hi = H + (size_t)i * n;
+          for (int j = 0; j <= i; ++j) hi[j] += ji * jr[j];
+          b0[i] += ji * rr;
         }
-        double sb = 0.0;
-        for (int r = 0; r < n; ++r) sb += p.J0[(size_t)r * n + i] * p.r0[r];
-        b0[i] = sb;
       }
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) H[(size_t)j * n + i] = H[(size_t)i * n + j];
       double c0 = 0.0;
       for (int r = 0; r < n; ++r) c0 += p.r0[r] * p.r0[r];
       pc0[w] = c0;
