@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(64) k_imu_raw(BatchDev b, double g_norm) {
   if (f >= b.W * 10) return;
   const int win = f / 10, k = f % 10;
   const SolverState &st = b.st[win];
-  if (st.done || !st.need_lin) return;
+  if (st.done || !st.need_lin || b.imu_skip[f]) return;
   const PreintPrepared &pp = b.prep[f];
   const double *x = b.x + (size_t)win * XSTRIDE;
   double *raw = b.imu_raw + (size_t)f * IMU_LIN_STRIDE;
@@ -385,6 +385,11 @@ __global__ void __launch_bounds__(64) k_imu_whiten(BatchDev b) {
   SolverState &st = b.st[win];
   if (st.done || !st.need_lin) return;
   const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+  if (b.imu_skip[f]) {   // no factor for this interval: it contributes nothing to the normal equations
+    for (int e = lane; e < IMU_LIN_STRIDE; e += 64) b.imu_lin[(size_t)f * IMU_LIN_STRIDE + e] = 0.0;
+    for (int e = lane; e < 780; e += 64) b.imu_gram[(size_t)f * 780 + e] = 0.0;
+    return;
+  }
   const bool prof = (f % 10 == 0 && lane == 0);
   const long long c0 = clock64();
   const double *U = b.prep[f].sqrt_info;
@@ -456,6 +461,7 @@ __global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int 
   const int win = f / 10, k = f % 10;
   const SolverState &st = b.st[win];
   if (st.done || (!init_mode && !st.step_valid)) return;
+  if (b.imu_skip[f]) { b.imu_cost[f] = 0.0; return; }
   const PreintPrepared &pp = b.prep[f];
   const double *x = b.xc + (size_t)win * XSTRIDE;
   double r[31];

@@ -117,6 +117,7 @@ struct BatchDev {
   double *imu_lin;            // [W][10][31*39]  whitened J (31x38) | whitened r (col 38)
   double *imu_gram;           // [W][10][780]    packed upper triangle of [J | r]^T [J | r]
   double *imu_cost;           // [W][10]
+  unsigned char *imu_skip;    // [W][10] 1: no factor for this interval (sum_dt > 10 s, estimator.cpp:1118,1164) or interval beyond the window
   // prior
   double *prior_H, *prior_b0, *prior_c0, *prior_x0;   // [W][96*96], [W][96], [W], [W][280]
   double *prior_dense;        // [W][PD_N]

@@ -84,6 +84,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<vilo_preint> pre((size_t)W * 10);
   std::vector<double> pH((size_t)W * 96 * 96, 0.0), pb0((size_t)W * 96, 0.0), pc0(W, 0.0), px0((size_t)W * 280, 0.0);
   std::vector<double> pdense((size_t)W * PD_N, 0.0);
+  std::vector<unsigned char> iskip((size_t)W * 10, 0);
   std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
   int lm_total = 0, gram_total = 0;
   bt->lm_off_host.resize(W);
@@ -185,6 +186,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     wm.n_gram = gram_total - wm.gram_off;
     lm_total += L;
     for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k];
+    for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !(d.preint[k].sum_dt > 10.0)) ? 0 : 1;
     // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
     if (d.prior && d.prior->valid && d.prior->n > 0) {
       const vilo_prior &p = *d.prior;
@@ -268,6 +270,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   if (hipMemset(D.imu_raw, 0, sizeof(double) * (size_t)W * 10 * 31 * 39) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
+  TRYB(dev_upload(ctx, bt, &D.imu_skip, iskip));
   TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
   TRYB(dev_upload(ctx, bt, &D.prior_dense, pdense));
   TRYB(dev_alloc(ctx, bt, &D.prior_hd, (size_t)W * 96));

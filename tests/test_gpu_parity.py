@@ -193,6 +193,21 @@ def test_solve_parity(ctx, cfg, ocfg, iters):
         assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
 
 
+def test_solve_skips_long_intervals(ctx, cfg, ocfg):
+    """estimator.cpp:1118 / :1164: no IMU(-leg) factor for an interval with sum_dt > 10 s."""
+    from cerberus_amd import api
+    w_g = _fresh(cfg, ocfg, n_landmarks=40, seed=13)
+    w_o = _fresh(cfg, ocfg, n_landmarks=40, seed=13)
+    for w in (w_g, w_o):
+        w.preint[4, 0] = 11.0   # sum_dt of interval (4, 5)
+    summ = ctx.solve_windows([w_g], api.default_solve_opts(True, 4))[0]
+    osum = O.solve_window(ocfg, w_o, O.default_opts(True, 4))
+    assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
 def test_solve_config2_window_and_tolerances(ctx, cfg, ocfg):
     """Full-size config-2 window (200 landmarks), Ceres termination rules enabled."""
     from cerberus_amd import api
