@@ -208,6 +208,38 @@ def test_solve_skips_long_intervals(ctx, cfg, ocfg):
         assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
 
 
+def _truncate(w, F):
+    """First F frames of a synthetic window (the reference solves such windows while frame_count < WINDOW_SIZE: no prior
+    yet, leg biases constant, estimator.cpp:1074-1082)."""
+    keep = [l for l in range(w.L) if w.lm_start_frame[l] + 2 <= F]   # at least two observations left
+    obs, st, off, sf = [], [], [0], []
+    for l in keep:
+        o0, o1 = w.lm_obs_offset[l], w.lm_obs_offset[l + 1]
+        K = min(o1 - o0, F - w.lm_start_frame[l])
+        obs.append(w.obs[o0:o0 + K]); st.append(w.obs_is_stereo[o0:o0 + K]); off.append(off[-1] + K); sf.append(w.lm_start_frame[l])
+    w.L, w.n_obs = len(keep), off[-1]
+    w.lm_start_frame = np.array(sf, np.int32); w.lm_obs_offset = np.array(off, np.int32)
+    w.obs = np.ascontiguousarray(np.concatenate(obs)); w.obs_is_stereo = np.ascontiguousarray(np.concatenate(st))
+    w.inv_depth = np.ascontiguousarray(w.inv_depth[keep])
+    w.F = F
+    w.prior.struct.valid = 0
+    w.leg_bias_const = 1
+    return w
+
+
+@pytest.mark.parametrize("F", [4, 8])
+def test_solve_partial_window(ctx, cfg, ocfg, F):
+    from cerberus_amd import api
+    w_g = _truncate(_fresh(cfg, ocfg, n_landmarks=60, seed=17), F)
+    w_o = _truncate(_fresh(cfg, ocfg, n_landmarks=60, seed=17), F)
+    summ = ctx.solve_windows([w_g], api.default_solve_opts(True, 4))[0]
+    osum = O.solve_window(ocfg, w_o, O.default_opts(True, 4))
+    assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a[:F] - bb[:F]).max() < 1e-6 * max(1.0, np.abs(bb[:F]).max()) if a.shape[0] == 11 else np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
 def test_solve_config2_window_and_tolerances(ctx, cfg, ocfg):
     """Full-size config-2 window (200 landmarks), Ceres termination rules enabled."""
     from cerberus_amd import api
