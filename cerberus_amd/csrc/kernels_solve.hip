@@ -20,16 +20,9 @@ using namespace vilo;
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but leaves global loads in flight
 // (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
-#ifdef VILO_SAFE_BARRIER
-__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
-#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 // broadcast lane `src` (wave-uniform index) of a double through SGPRs (v_readlane): a few cycles, no LDS round trip
 __device__ __forceinline__ double readlane_d(double v, int src) {
-#ifdef VILO_SHFL
-  return __shfl(v, src, 64);
-#endif
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src);
   hi = __builtin_amdgcn_readlane(hi, src);
@@ -552,7 +545,7 @@ __device__ __forceinline__ int imu_col_cd(int k, int c) {
 #define LDS_BS (LDS_LK + 176)          /* [11][13][18]: B_k x (pose_{k-1}, pose_k, pose_{k+1}) from the IMU factors */
 #define LDS_BP (LDS_BS + 11 * 13 * 18)  /* [13][80]: prior rows of the frame whose speed/leg-bias it touches */
 #define LDS_S (LDS_BP + 13 * 80)
-#define LDS_S_SIZE 4096          /* union: landmark chunk w[32][81] + einv[64]  |  Bk[1040] Bkm1[1040] T[13*96]  |  back-sub blocks */
+#define LDS_S_SIZE 4096          /* union: M_k / G_k / T_A of the bias chain  |  diagonal / panel tiles of the Cholesky  |  back-substitution blocks */
 #define LDS_RED (LDS_S + LDS_S_SIZE)
 #define LDS_COL (LDS_RED + SOLVE_THREADS)
 #define LDS_TOTAL (LDS_COL + 176)
@@ -731,7 +724,7 @@ __device__ __noinline__ void ph_tables() {
 __device__ __noinline__ void ph_assemble() {
   KB_LOCALS
   const double *igram = kc.igram; (void)igram;
-  //      independent coalesced load + 1-2 atomic adds, so the L2 latency overlaps across entries ----
+  // ---- assembly of the window's normal equations in LDS (no atomics: every target has one owner thread) ----
   // start from the prior's pre-assembled image (all zeros without a prior): coalesced copies instead of zero fill + scatter
   {
     const double *pd = kc.pd;

@@ -126,7 +126,7 @@ struct BatchDev {
   // camera-side vectors [W][CD_N]
   double *cam_g, *cam_dh2, *cam_y, *cam_scale;
   // block scratch
-  double *A_diag, *A_off, *Bm, *Tm, *Lk;   // [W][11][169], [W][10][169], [W][11][13*80], [W][11][13*96], [W][11][169]
+  double *Tm, *Lk;            // [W][11][13*96] T_k = [T_A | T_B | t_g], [W][11][169] L_k^-1
   SolverState *st;
   int *status;
 };

@@ -286,9 +286,6 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_alloc(ctx, bt, &D.cam_dh2, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_y, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_scale, (size_t)W * CD_N));
-  TRYB(dev_alloc(ctx, bt, &D.A_diag, (size_t)W * 11 * 169));
-  TRYB(dev_alloc(ctx, bt, &D.A_off, (size_t)W * 10 * 169));
-  TRYB(dev_alloc(ctx, bt, &D.Bm, (size_t)W * 11 * 1040));
   TRYB(dev_alloc(ctx, bt, &D.Tm, (size_t)W * 11 * 13 * 96));
   TRYB(dev_alloc(ctx, bt, &D.Lk, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));

@@ -17,7 +17,7 @@ ctx.preintegrate_windows(ws)
 b = api.Batch(ctx, ws)
 opts = api.default_solve_opts(True, 3)
 b.solve(opts)
-names = ["tables", "tables", "prior image copy", "Gram scatter (LDS atomics)", "masks + tile load", "P5/P6 scaling+q", "landmark Schur || bias chain", "T recurrence + rank-143", "Cholesky 80",
+names = ["tables", "tables", "prior image copy", "Gram scatter (owner-computes)", "masks + tile load", "P5/P6 scaling+q", "landmark Schur || bias chain", "T recurrence + rank-143", "Cholesky 80",
          "triangular solves", "B back-sub", "landmark back-sub+norms", "dogleg+candidate"]
 acc = np.zeros(13)
 vis = np.zeros(5)
