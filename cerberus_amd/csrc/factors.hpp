@@ -292,7 +292,7 @@ VD void imu_leg_raw(const PreintHead &P, double g_norm, const double *pose_i, co
 // Classic IMU factor before whitening. Residual order P0 R3 V6 BA9 BG12; local columns
 // [pose_i 0..5 | sb_i 6..14 | pose_j 15..20 | sb_j 21..29]. Uses the P,R,V,BA,BG parts of PreintHead.
 VD void imu_raw(const PreintHead &P, double g_norm, const double *pose_i, const double *sb_i, const double *pose_j,
-                const double *sb_j, double *r, bool want_jac, double *J, int ld) {
+                const double *sb_j, double *r, bool want_jac, double *J, int ld, int cj = 15) {
   const v3 G = mk3(0, 0, g_norm);
   const v3 Pi = ld3(pose_i), Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
   const v3 Pj = ld3(pose_j), Vj = ld3(sb_j), Baj = ld3(sb_j + 3), Bgj = ld3(sb_j + 6);
@@ -333,11 +333,12 @@ VD void imu_raw(const PreintHead &P, double g_norm, const double *pose_i, const 
   put(6, 12, -dv_dbg);
   put(9, 9, nI3);
   put(12, 12, nI3);
-  put(0, 15, RiT);
-  put(3, 18, Qleft33(qmul(qmul(qinv(cq), Qi_inv), Qj)));
-  put(6, 21, RiT);
-  put(9, 24, I3);
-  put(12, 27, I3);
+  // frame-j blocks start at column cj (15 in the factor's own layout; 19 inside the solver's 38-column IMU-leg layout)
+  put(0, cj, RiT);
+  put(3, cj + 3, Qleft33(qmul(qmul(qinv(cq), Qi_inv), Qj)));
+  put(6, cj + 6, RiT);
+  put(9, cj + 9, I3);
+  put(12, cj + 12, I3);
 }
 
 // dx of one kept block of the prior (marginalization_factor.cpp:357-377); size = global size (7 -> 6 local).

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
     for (int e = tid; e < M.n_drop_lm * 80; e += MT) {
       const int li = e / 80, a = e % 80;
       const int l = drop_lm[(size_t)win * max_l0 + li];
-      const int row = 19 + li;
+      const int row = M.m - M.n_drop_lm + li;   // landmarks follow the dropped frame-0 dims (19 with leg biases, 15 without)
       if (a == 79) {
         A[(size_t)row * T + row] += bd.lm_E[wm.lm_off + l];
         bv[row] += bd.lm_g[wm.lm_off + l];
@@ -405,9 +405,10 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
       for (int k = 0; k < d.prior->n_blocks; ++k) mark(d.prior->block_id[k]);
     std::vector<int> dropped_ids;
     if (mode == 0) {
-      M.has_imu = d.preint[0].sum_dt < 10.0 ? 1 : 0;
+      const int nkind = d.use_leg ? 3 : 2;   // pose, speed/bias (, leg bias)
+      M.has_imu = (d.use_leg ? d.preint[0].sum_dt : d.preint_imu[0].sum_dt) < 10.0 ? 1 : 0;
       if (M.has_imu)
-        for (int kind = 0; kind < 3; ++kind) { mark(kind * 16 + 0); mark(kind * 16 + 1); }
+        for (int kind = 0; kind < nkind; ++kind) { mark(kind * 16 + 0); mark(kind * 16 + 1); }
       int L; const int *perm = vilo_batch_perm(bt, w, &L);
       for (int i = 0; i < L; ++i) {
         const int l = perm[i];
@@ -449,7 +450,7 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
       for (int c = 0; c < ls; ++c) M.cdmap[cd + c] = pos + c;
       pos += ls;
     }
-    if (mode == 0 && pos != 19 && M.n_drop_lm > 0) { vilo_batch_destroy(ctx, bt); ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
+    if (mode == 0 && pos != (d.use_leg ? 19 : 15) && M.n_drop_lm > 0) { vilo_batch_destroy(ctx, bt); ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
     pos += M.n_drop_lm;
     M.m = pos;
     std::vector<int> kept;

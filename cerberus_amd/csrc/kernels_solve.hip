@@ -359,10 +359,18 @@ __global__ void __launch_bounds__(64) k_imu_raw(BatchDev b, double g_norm) {
   const double *x = b.x + (size_t)win * XSTRIDE;
   double *raw = b.imu_raw + (size_t)f * IMU_LIN_STRIDE;
   double r[31];
-  imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-              x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, raw, 39);
+  if (b.win[win].use_leg) {
+    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, raw, 39);
 #pragma unroll
-  for (int i = 0; i < 31; ++i) raw[i * 39 + 38] = r[i];
+    for (int i = 0; i < 31; ++i) raw[i * 39 + 38] = r[i];
+  } else {
+    // plain IMUFactor (estimator.cpp:1160-1171) inside the same 31 x 39 layout: rows 0..14, the frame-j blocks at column 19,
+    // leg-bias columns and rows 15..30 stay zero (sqrt_info is embedded accordingly, k_embed_sqrt15)
+    imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, true, raw, 39, 19);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) raw[i * 39 + 38] = r[i];
+  }
 }
 
 // Stage 2: one wave per factor, both products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
@@ -458,8 +466,14 @@ __global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int 
   const PreintPrepared &pp = b.prep[f];
   const double *x = b.xc + (size_t)win * XSTRIDE;
   double r[31];
-  imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-              x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
+  if (b.win[win].use_leg) {
+    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
+  } else {
+#pragma unroll
+    for (int i = 15; i < 31; ++i) r[i] = 0.0;
+    imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, false, nullptr, 0);
+  }
   const double *ut = b.sqrtT + f;
   double c = 0.0;
   int e = 0;
@@ -471,6 +485,24 @@ __global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm, int 
     c += sacc * sacc;
   }
   b.imu_cost[f] = c;
+}
+
+// use_leg == 0: the 15 x 15 sqrt_info of an IMUFactor (leading 225 doubles, row stride 15) re-laid out as the leading block of a
+// 31 x 31 matrix (row stride 31, zeros elsewhere) so that the IMU-leg kernels can be used unchanged
+__global__ void __launch_bounds__(256) k_embed_sqrt15(BatchDev b) {
+  __shared__ double t[225];
+  PreintPrepared &pp = b.prep[blockIdx.x];
+  for (int e = threadIdx.x; e < 225; e += 256) t[e] = pp.sqrt_info[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 31 * 31; e += 256) {
+    const int i = e / 31, q = e - 31 * i;
+    pp.sqrt_info[e] = (i < 15 && q < 15) ? t[i * 15 + q] : 0.0;
+  }
+}
+int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b) {
+  hipLaunchKernelGGL(k_embed_sqrt15, dim3(b.W * 10), dim3(256), 0, ctx->stream, b);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
 }
 
 // entry-major transpose of the upper triangles of sqrt_info (once per batch)

@@ -81,7 +81,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
   std::vector<double> obs, x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<unsigned char> flags;
-  std::vector<vilo_preint> pre((size_t)W * 10);
+  std::vector<vilo_preint> pre(in[0].use_leg ? (size_t)W * 10 : 1);
+  std::vector<vilo_preint_imu> pre_imu(in[0].use_leg ? 1 : (size_t)W * 10);
   std::vector<double> pH((size_t)W * 96 * 96, 0.0), pb0((size_t)W * 96, 0.0), pc0(W, 0.0), px0((size_t)W * 280, 0.0);
   std::vector<double> pdense((size_t)W * PD_N, 0.0);
   std::vector<unsigned char> iskip((size_t)W * 10, 0);
@@ -97,8 +98,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     if (d.n_frames < 2 || d.n_frames > VILO_MAX_FRAMES || d.n_landmarks < 0 || d.n_landmarks > VILO_NUM_OF_F) {
       ctx->err = "window sizes out of range"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
-    if (!d.use_leg) { ctx->err = "solver supports the IMU-leg factor path (use_leg = 1)"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
-    if (!d.preint || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
+    if ((d.use_leg != 0) != (in[0].use_leg != 0)) { ctx->err = "all windows of a batch must use the same IMU factor kind (use_leg)"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    if (!d.use_leg && !d.preint_imu) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+    if ((d.use_leg && !d.preint) || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
       vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
     const int F = d.n_frames, L = d.n_landmarks;
@@ -106,7 +108,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     memset(&wm, 0, sizeof(wm));
     wm.n_frames = F; wm.L = L; wm.use_leg = d.use_leg; wm.pad = -1;
     wm.lm_off = lm_total; wm.chunk_off = (int)chunks.size(); wm.gram_off = gram_total;
-    wm.const_mask = (d.leg_bias_const ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
+    // use_leg == 0: the leg-bias blocks are not part of the problem (estimator.cpp:1071-1072): masked like constant blocks
+    wm.const_mask = ((d.leg_bias_const || !d.use_leg) ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
     bt->lm_off_host[w] = lm_total;
     bt->L_host[w] = L;
     // states (vector2double layout)
@@ -185,8 +188,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     wm.n_waves = (int)waves.size() - wm.wave_off;
     wm.n_gram = gram_total - wm.gram_off;
     lm_total += L;
-    for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k];
-    for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !(d.preint[k].sum_dt > 10.0)) ? 0 : 1;
+    if (d.use_leg) { for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k]; }
+    else { for (int k = 0; k + 1 < F; ++k) pre_imu[(size_t)w * 10 + k] = d.preint_imu[k]; }
+    for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !((d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt) > 10.0)) ? 0 : 1;
     // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
     if (d.prior && d.prior->valid && d.prior->n > 0) {
       const vilo_prior &p = *d.prior;
@@ -296,11 +300,15 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   // hoist sqrt_info = chol(cov^-1)^T out of the iteration loop (the reference recomputes it on every
   // IMULegFactor::Evaluate, imu_leg_factor.cpp:197-198)
   {
-    vilo_preint *d_pre = nullptr;
-    if (hipMalloc((void **)&d_pre, sizeof(vilo_preint) * (size_t)W * 10) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    const bool leg = in[0].use_leg != 0;
+    void *d_pre = nullptr;
+    const size_t bytes = (leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu)) * (size_t)W * 10;
+    if (hipMalloc(&d_pre, bytes) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
     int rc = VILO_OK;
-    if (hipMemcpy(d_pre, pre.data(), sizeof(vilo_preint) * (size_t)W * 10, hipMemcpyHostToDevice) != hipSuccess) rc = VILO_ERR_HIP;
-    if (rc == VILO_OK) rc = vilo_launch_prepare_preint(ctx, W * 10, d_pre, D.prep, D.status);
+    if (hipMemcpy(d_pre, leg ? (const void *)pre.data() : (const void *)pre_imu.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = VILO_ERR_HIP;
+    if (rc == VILO_OK) rc = leg ? vilo_launch_prepare_preint(ctx, W * 10, (const vilo_preint *)d_pre, D.prep, D.status)
+                                : vilo_launch_prepare_preint_imu(ctx, W * 10, (const vilo_preint_imu *)d_pre, D.prep, D.status);
+    if (rc == VILO_OK && !leg) rc = vilo_launch_embed_sqrt15(ctx, D);
     if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
     if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
     (void)hipFree(d_pre);

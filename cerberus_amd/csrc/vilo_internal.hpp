@@ -74,3 +74,4 @@ int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, P
 int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status);
 struct BatchDev;
 int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b);
+int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b);

@@ -337,6 +337,50 @@ def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
         assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
 
 
+def _vins(cfg, ocfg, **kw):
+    """USE_LEG = 0 (config/a1_config/hardware_a1_vins_config.yaml): IMUFactor instead of IMULegFactor, no leg-bias blocks."""
+    w = _fresh(cfg, ocfg, with_prior=False, **kw)
+    w.use_leg = 0
+    return w
+
+
+def test_solve_without_leg_factors(ctx, cfg, ocfg):
+    from cerberus_amd import api
+    w_g, w_o = _vins(cfg, ocfg, n_landmarks=40, seed=51), _vins(cfg, ocfg, n_landmarks=40, seed=51)
+    lb0 = w_g.leg_bias.copy()
+    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 5))[0]
+    so = O.solve_window(ocfg, w_o, O.default_opts(True, 5))
+    assert sg.iterations == so.iterations and sg.num_successful == so.num_successful
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+    np.testing.assert_array_equal(w_g.leg_bias, lb0)   # not part of the problem
+
+
+def test_marginalize_and_next_solve_without_leg_factors(ctx, cfg, ocfg):
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w0 = _vins(cfg, ocfg, n_landmarks=50, seed=61)
+    pg, po = PriorData(), PriorData()
+    ctx.marginalize(w0, 0, pg)
+    rc, m, A, bvec = O.marginalize(ocfg, w0, 0, po, want_A=True)
+    assert rc == 0 and pg.struct.valid == 1 and pg.blocks() == po.blocks()
+    n = pg.n
+    assert n == po.n
+    Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+    Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+    assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max()
+    assert np.abs(Jg.T @ pg.r0[:n] - Jo.T @ po.r0[:n]).max() < 1e-6 * np.abs(Jo.T @ po.r0[:n]).max()
+    w_g, w_o = _vins(cfg, ocfg, n_landmarks=50, seed=62), _vins(cfg, ocfg, n_landmarks=50, seed=62)
+    for w in (w_g, w_o):
+        w.prior = pg.copy()
+    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 5))[0]
+    so = O.solve_window(ocfg, w_o, O.default_opts(True, 5))
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+
+
 def test_gauge_fix(ctx, cfg, ocfg):
     from cerberus_amd import api
     w_g = _fresh(cfg, ocfg, n_landmarks=30, seed=41)
