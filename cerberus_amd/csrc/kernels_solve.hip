@@ -1797,7 +1797,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   // IterationZero: cost at the initial point
   VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
   P0(3);
-  hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 1);
+  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 1);
   P1();
   P0(4);
   hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
@@ -1808,7 +1808,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   ap.init_mode = 0;
   for (int it = 0; it < o->max_num_iterations; ++it) {
     P0(0);
-    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
+    if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
     P1();
     P0(7);
     hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn);
@@ -1820,7 +1820,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
     P1();
     P0(3);
-    hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 0);
+    if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 0);
     P1();
     P0(4);
     hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 0);
@@ -1837,7 +1837,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
 int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4);
-  hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, ctx->stream, b, sq, ha);
+  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, ctx->stream, b, sq, ha);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn);
   hipLaunchKernelGGL(k_imu_whiten, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
   VILO_HIP(hipGetLastError());

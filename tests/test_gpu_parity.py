@@ -381,6 +381,27 @@ def test_marginalize_and_next_solve_without_leg_factors(ctx, cfg, ocfg):
         assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
 
 
+@pytest.mark.parametrize("with_prior", [True, False])
+def test_solve_window_without_landmarks(ctx, cfg, ocfg, with_prior):
+    """Empty visual input (no feature has 4 observations yet): IMU-leg factors (+ prior) only."""
+    from cerberus_amd import api
+
+    def mk():
+        w = _fresh(cfg, ocfg, n_landmarks=1, seed=77, with_prior=with_prior)
+        w.L, w.n_obs = 0, 0
+        w.lm_start_frame = np.zeros(0, np.int32); w.lm_obs_offset = np.zeros(1, np.int32)
+        w.obs = np.zeros((0, 11)); w.obs_is_stereo = np.zeros(0, np.uint8); w.inv_depth = np.zeros(0)
+        return w
+    w_g, w_o = mk(), mk()
+    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 4))[0]
+    so = O.solve_window(ocfg, w_o, O.default_opts(True, 4))
+    assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        if a.size:
+            assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max())
+
+
 def test_gauge_fix(ctx, cfg, ocfg):
     from cerberus_amd import api
     w_g = _fresh(cfg, ocfg, n_landmarks=30, seed=41)
