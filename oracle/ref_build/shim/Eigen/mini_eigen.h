@@ -257,6 +257,7 @@ template <class Derived> class MatrixBase {
   // ---- dense solvers
   PlainObject inverse() const;
   Scalar determinant() const;
+  template <class Dummy = void> auto jacobiSvd(unsigned flags = 0) const;
 };
 
 // ---------------------------------------------------------------------------------------------------- Matrix
@@ -761,6 +762,48 @@ template <class M> class SelfAdjointEigenSolver {
   const M &eigenvectors() const { return v_; }
   ComputationInfo info() const { return info_; }
 };
+
+enum { ComputeFullU = 0x04, ComputeThinU = 0x08, ComputeFullV = 0x10, ComputeThinV = 0x20 };
+// Singular values (descending) and right singular vectors by one-sided Jacobi (Hestenes) on the columns of A.
+template <class M> class JacobiSVD {
+  typedef typename M::Scalar Scalar;
+  Matrix<Scalar, Dynamic, Dynamic> v_;
+  Matrix<Scalar, Dynamic, 1> s_;
+
+ public:
+  JacobiSVD() {}
+  template <class O> explicit JacobiSVD(const MatrixBase<O> &a, unsigned = 0) { compute(a); }
+  template <class O> JacobiSVD &compute(const MatrixBase<O> &A, unsigned = 0) {
+    const Index m = A.rows(), n = A.cols();
+    Matrix<Scalar, Dynamic, Dynamic> U(A), V = Matrix<Scalar, Dynamic, Dynamic>::Identity(n, n);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      Scalar off(0);
+      for (Index p = 0; p < n - 1; ++p)
+        for (Index q = p + 1; q < n; ++q) {
+          Scalar al(0), be(0), ga(0);
+          for (Index i = 0; i < m; ++i) { al += U.ref(i, p) * U.ref(i, p); be += U.ref(i, q) * U.ref(i, q); ga += U.ref(i, p) * U.ref(i, q); }
+          if (ga == Scalar(0)) continue;
+          off = std::max(off, std::abs(ga) / std::sqrt(al * be + std::numeric_limits<Scalar>::min()));
+          const Scalar zeta = (be - al) / (Scalar(2) * ga);
+          const Scalar t = (zeta >= Scalar(0) ? Scalar(1) : Scalar(-1)) / (std::abs(zeta) + std::sqrt(Scalar(1) + zeta * zeta));
+          const Scalar c = Scalar(1) / std::sqrt(Scalar(1) + t * t), sn = c * t;
+          for (Index i = 0; i < m; ++i) { const Scalar up = U.ref(i, p), uq = U.ref(i, q); U.ref(i, p) = c * up - sn * uq; U.ref(i, q) = sn * up + c * uq; }
+          for (Index i = 0; i < n; ++i) { const Scalar vp = V.ref(i, p), vq = V.ref(i, q); V.ref(i, p) = c * vp - sn * vq; V.ref(i, q) = sn * vp + c * vq; }
+        }
+      if (off < Scalar(1e-15)) break;
+    }
+    std::vector<Scalar> sv((size_t)n);
+    std::vector<Index> order((size_t)n);
+    for (Index j = 0; j < n; ++j) { Scalar s2(0); for (Index i = 0; i < m; ++i) s2 += U.ref(i, j) * U.ref(i, j); sv[(size_t)j] = std::sqrt(s2); order[(size_t)j] = j; }
+    std::sort(order.begin(), order.end(), [&](Index a, Index b) { return sv[(size_t)a] > sv[(size_t)b]; });
+    v_.resize(n, n); s_.resize(n);
+    for (Index j = 0; j < n; ++j) { s_(j) = sv[(size_t)order[(size_t)j]]; for (Index i = 0; i < n; ++i) v_.ref(i, j) = V.ref(i, order[(size_t)j]); }
+    return *this;
+  }
+  const Matrix<Scalar, Dynamic, Dynamic> &matrixV() const { return v_; }
+  const Matrix<Scalar, Dynamic, 1> &singularValues() const { return s_; }
+};
+template <class D> template <class Dummy> auto MatrixBase<D>::jacobiSvd(unsigned flags) const { return JacobiSVD<PlainObject>(*this, flags); }
 
 // ---------------------------------------------------------------------------------------------------- Quaternion
 namespace internal {

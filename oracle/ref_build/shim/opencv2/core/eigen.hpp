@@ -1,2 +1,2 @@
-// TEST INFRASTRUCTURE: empty stand-in (the factor sources include it through parameters.h but use nothing from it).
 #pragma once
+#include "../opencv.hpp"

@@ -3,7 +3,12 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <list>
+#include <map>
+#include <queue>
+#include <set>
 #include <string>
+#include <vector>
 #define ROS_INFO(...) ((void)0)
 #define ROS_DEBUG(...) ((void)0)
 #define ROS_WARN(...) ((void)0)
