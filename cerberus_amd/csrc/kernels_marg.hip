@@ -109,7 +109,9 @@ struct MargWin {
   int m, n;             // dropped / kept local dims
   int n_drop_lm;        // landmarks among the dropped dims (they follow the 19 frame-0 dims; mode 0)
   int mode;
-  int has_imu, prior_n, pad0, pad1;
+  int has_imu, prior_n;
+  int general;          // 1: this window goes through the global-memory eigen path (set by the host from k_marginalize_lds' verdict)
+  int pad1;
   long long scratch_off;  // doubles into the scratch arena
   int cdmap[CD_N];      // camera dim -> index in [dropped | kept] ordering, -1 if absent
 };
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
   const MargWin &M = mw[win];
   const WinMeta wm = bd.win[win];
   const int m = M.m, n = M.n, T = m + n;
-  if (m == 0 || n == 0) return;
+  if (m == 0 || n == 0 || !M.general) return;
   double *A = scratch + M.scratch_off, *bv = A + (size_t)T * T, *Amm = bv + T, *Vm = Amm + (size_t)m * m, *Ainv = Vm + (size_t)m * m;
   double *tmp = Ainv + (size_t)m * m, *Ar = tmp + (size_t)n * m, *V2 = Ar + (size_t)n * n, *br = V2 + (size_t)n * n;
   const double *x = bd.x + (size_t)win * XSTRIDE;
@@ -272,6 +274,336 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
 }
 
 // double2vector gauge fix + re-pack (estimator.cpp:903-957, 848-873)
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-resident marginalisation (the path every well-conditioned window takes).
+//
+// MarginalizationInfo::marginalize inverts Amm through an eigen-decomposition with eigenvalues <= eps = 1e-8 dropped
+// (marginalization_factor.cpp:281-286). When every eigenvalue of Amm exceeds eps that pseudo-inverse IS the inverse, and the
+// Schur complement can be formed by elimination in the order the block structure suggests: the dropped landmarks first (their
+// block of Amm is diagonal: an inverse depth only couples to camera-side blocks), then the <= 19 dense dims of frame 0 by a
+// Cholesky factorisation. The kernel certifies "lambda_min(Amm) > eps" by factorising Amm - eps I the same way (all pivots
+// positive) and hands the window to k_marginalize (global-memory Jacobi on the full Amm) when the certificate fails.
+// The second decomposition (A' -> J0 = sqrt(S) V^T, marginalization_factor.cpp:297-305) needs eigenvectors and a rank decision
+// (A' always carries the 4 unobservable gauge directions): parallel cyclic Jacobi as before, but on LDS-resident A' and V.
+#define MGT 1024
+constexpr int MG_NMAX = VILO_MAX_PRIOR_DIM;       // 96
+constexpr int MG_LD = MG_NMAX + 1;                // odd leading dimension: column walks spread over the LDS banks
+constexpr int MG_TMAX = 19 + MG_NMAX;             // dense dropped dims + kept dims
+constexpr int MG_TILE = 32;                       // landmarks per elimination tile
+constexpr int MG_R0 = 2 * MG_NMAX * MG_LD;        // 18624 doubles: A1 (TMAX^2 = 13225) + tile (TMAX * 32), later A' | V
+constexpr int MG_TILE_OFF = 13312;
+constexpr int MG_SMALL = MG_TMAX + 3 * MG_TILE + 19 * 19 + 2 * 48 + 19 + MG_NMAX + 8;
+constexpr int MG_LDS_DOUBLES = MG_R0 + MG_SMALL;
+static_assert(MG_TILE_OFF >= MG_TMAX * MG_TMAX && MG_TILE_OFF + MG_TMAX * MG_TILE <= MG_R0, "LDS plan");
+static_assert(MG_LDS_DOUBLES * 8 + 2 * 48 * 4 + 2 * 80 * 4 + 96 * 8 + 64 * 8 + 64 <= 160 * 1024, "LDS budget");
+
+// in-place Cholesky of the leading d x d block (lower triangle) of M; all threads call. *fail is set when a pivot is not positive.
+__device__ void chol_lds(double *M, int ld, int d, int *fail) {
+  const int tid = threadIdx.x;
+  for (int k = 0; k < d; ++k) {
+    if (tid == 0) {
+      const double p = M[k * ld + k];
+      if (!(p > 0.0)) { *fail = 1; M[k * ld + k] = 1.0; } else M[k * ld + k] = sqrt(p);
+    }
+    __syncthreads();
+    if (tid > k && tid < d) M[tid * ld + k] /= M[k * ld + k];
+    __syncthreads();
+    for (int e = tid; e < d * d; e += MGT) {
+      const int i = e / d, j = e % d;
+      if (j > k && i >= j) M[i * ld + j] -= M[i * ld + k] * M[j * ld + k];
+    }
+    __syncthreads();
+  }
+}
+
+// sum over the workgroup: wave shuffles, then one LDS slot per wave
+__device__ double blk_sum_w(double v, double *wsum /*LDS [MGT/64]*/) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) wsum[tid >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int i = 0; i < MGT / 64; ++i) r += wsum[i];
+  return r;
+}
+
+// Two-sided cyclic Jacobi on LDS-resident A, V (ne x ne with ne even: an odd problem is padded by a decoupled zero row/column).
+// diag(A) = eigenvalues, columns of V = eigenvectors. Round-robin pairing gives ne/2 disjoint rotations per step; each 2x2 block
+// A[{p_a,q_a}][{p_b,q_b}] is rotated from both sides in one pass (read once, written once), V from the right.
+__device__ void jacobi_eigh_lds(double *A, double *V, int n, int ld, double *cs, int *pq, double *wsum) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ne = (n + 1) & ~1, half = ne / 2;
+  for (int e = tid; e < ne * ld; e += MGT) {
+    const int i = e / ld, j = e % ld;
+    if (j < ne) {
+      V[e] = (i == j) ? 1.0 : 0.0;
+      if (i >= n || j >= n) A[e] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (int i = wv; i < n; i += MGT / 64)
+      for (int j = lane; j < n; j += 64) {
+        const double v = A[i * ld + j];
+        if (i == j) dg += v * v; else if (j > i) off += v * v;
+      }
+    off = blk_sum_w(off, wsum);
+    dg = blk_sum_w(dg, wsum);
+    if (off <= 1e-60 || off <= 1e-32 * dg) break;
+    for (int step = 0; step < ne - 1; ++step) {
+      if (tid < half) {
+        // circle method: position tid plays position ne-1-tid; the player at position k is (k == ne-1) ? ne-1 : (k + step) % (ne-1)
+        const int ka = tid, kb = ne - 1 - tid;
+        int p = (ka + step) % (ne - 1);
+        int q = (kb == ne - 1) ? ne - 1 : (kb + step) % (ne - 1);
+        if (p > q) { const int t_ = p; p = q; q = t_; }
+        double c = 1.0, sn = 0.0;
+        const double apq = A[p * ld + q];
+        if (apq != 0.0) {
+          const double app = A[p * ld + p], aqq = A[q * ld + q];
+          const double tau = (aqq - app) / (2.0 * apq);
+          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          c = 1.0 / sqrt(1.0 + t * t);
+          sn = t * c;
+        }
+        pq[2 * tid] = p; pq[2 * tid + 1] = q;
+        cs[2 * tid] = c; cs[2 * tid + 1] = sn;
+      }
+      __syncthreads();
+      // A <- J^T A J, block (a, b) = rows {p_a, q_a} x columns {p_b, q_b}
+      if (lane < half) {
+        const int pb = pq[2 * lane], qb = pq[2 * lane + 1];
+        const double cb = cs[2 * lane], sb = cs[2 * lane + 1];
+        for (int a = wv; a < half; a += MGT / 64) {
+          const int pa = pq[2 * a], qa = pq[2 * a + 1];
+          const double ca = cs[2 * a], sa = cs[2 * a + 1];
+          const double x00 = A[pa * ld + pb], x01 = A[pa * ld + qb], x10 = A[qa * ld + pb], x11 = A[qa * ld + qb];
+          const double r00 = ca * x00 - sa * x10, r01 = ca * x01 - sa * x11;   // rows: J_a^T
+          const double r10 = sa * x00 + ca * x10, r11 = sa * x01 + ca * x11;
+          A[pa * ld + pb] = cb * r00 - sb * r01; A[pa * ld + qb] = sb * r00 + cb * r01;   // columns: J_b
+          A[qa * ld + pb] = cb * r10 - sb * r11; A[qa * ld + qb] = sb * r10 + cb * r11;
+        }
+        // V <- V J
+        for (int k = wv; k < ne; k += MGT / 64) {
+          const double vkp = V[k * ld + pb], vkq = V[k * ld + qb];
+          V[k * ld + pb] = cb * vkp - sb * vkq;
+          V[k * ld + qb] = sb * vkp + cb * vkq;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const MargWin *mw, const int *drop_lm, int max_l0, double *J0_out,
+                                                         double *r0_out, int *status, int *need_general, long long *clk /* [W][8] or null */) {
+  extern __shared__ double ml[];
+  double *A1 = ml, *tile = ml + MG_TILE_OFF;
+  double *b1 = ml + MG_R0, *dinv = b1 + MG_TMAX, *deps = dinv + MG_TILE, *gl = deps + MG_TILE, *Ce = gl + MG_TILE, *cs = Ce + 19 * 19;
+  double *yb = cs + 2 * 48, *br = yb + 19;
+  __shared__ double wsum[MGT / 64];
+  __shared__ int pq[2 * 48];
+  __shared__ int act_a[80], act_t[80];
+  __shared__ int n_act, fail;
+  __shared__ double dx[VILO_MAX_PRIOR_DIM];
+  const int win = blockIdx.x, tid = threadIdx.x;
+  const MargWin &M = mw[win];
+  const WinMeta wm = bd.win[win];
+  const int m = M.m, n = M.n, L0 = M.n_drop_lm, md = m - L0, T = md + n;
+  if (m == 0 || n == 0) return;
+  if (T > MG_TMAX || n > MG_NMAX || md > 19) { if (tid == 0) need_general[win] = 1; return; }
+  const double eps = 1e-8;
+  const double *x = bd.x + (size_t)win * XSTRIDE;
+  auto stamp = [&](int i) { if (clk && tid == 0) clk[win * 8 + i] = (long long)__builtin_readcyclecounter(); };
+  stamp(0);
+  // index of a camera dim in [dense dropped | kept], -1 if absent
+  auto loc = [&](int ci) { const int i = M.cdmap[ci]; return i < 0 ? -1 : (i < md ? i : i - L0); };
+  for (int e = tid; e < T * T; e += MGT) A1[e] = 0.0;
+  for (int e = tid; e < T; e += MGT) b1[e] = 0.0;
+  if (tid == 0) { n_act = 0; fail = 0; }
+  __syncthreads();
+  auto add = [&](int ci, int cj, double v) {
+    const int i = loc(ci), j = loc(cj);
+    if (i >= 0 && j >= 0) A1[i * T + j] += v;
+  };
+  // ---- prior factor (marginalization_factor.cpp:347-395 evaluated at the current state): J^T J = H, J^T r = b0 + H dx ----
+  if (M.prior_n > 0) {
+    const int pn = M.prior_n;
+    const double *Hp = bd.prior_H + (size_t)win * 96 * 96, *b0 = bd.prior_b0 + (size_t)win * 96;
+    const int *pmap = bd.prior_map + (size_t)win * 96;
+    if (tid < wm.prior_nb)
+      prior_dx(x + bd.prior_bstate[win * 40 + tid], bd.prior_x0 + (size_t)win * 280 + bd.prior_bxoff[win * 40 + tid],
+               bd.prior_bsize[win * 40 + tid], dx + bd.prior_bidx[win * 40 + tid]);
+    __syncthreads();
+    for (int e = tid; e < pn * pn; e += MGT) add(pmap[e / pn], pmap[e % pn], Hp[e]);
+    for (int i = tid; i < pn; i += MGT) {
+      double sacc = b0[i];
+      for (int q = 0; q < pn; ++q) sacc += Hp[(size_t)q * pn + i] * dx[q];
+      const int t = loc(pmap[i]);
+      if (t >= 0) b1[t] += sacc;
+    }
+    __syncthreads();
+  }
+  if (M.mode == 0) {
+    // ---- IMULegFactor / IMUFactor between frames 0 and 1: whitened [J | r] staged through LDS ----
+    if (M.has_imu) {
+      const double *lin = bd.imu_lin + (size_t)win * 10 * 31 * 39;
+      for (int e = tid; e < 31 * 39; e += MGT) tile[e] = lin[e];
+      __syncthreads();
+      for (int e = tid; e < 39 * 39; e += MGT) {
+        const int a = e / 39, c = e % 39;
+        if (a == 38) continue;
+        double sacc = 0.0;
+        for (int i = 0; i < 31; ++i) sacc += tile[i * 39 + a] * tile[i * 39 + c];
+        auto cdof = [](int cc) { return cc < 6 ? cc : (cc < 19 ? CD_B0 + (cc - 6) : (cc < 25 ? 6 + (cc - 19) : CD_B0 + 13 + (cc - 25))); };
+        if (c == 38) { const int t = loc(cdof(a)); if (t >= 0) b1[t] += sacc; }
+        else add(cdof(a), cdof(c), sacc);
+      }
+      __syncthreads();
+    }
+    // ---- visual factors of the landmarks that start in frame 0: camera-side Gram slots of the s = 0 chunks ----
+    for (int ch = 0; ch < wm.n_chunks; ++ch) {
+      const ChunkMeta cm = bd.chunk[wm.chunk_off + ch];
+      if (cm.s != 0) continue;
+      for (int t = 0; t < cm.kmax; ++t) {
+        const double *gs = bd.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
+        for (int e = tid; e < VILO_GRAM; e += MGT) {
+          int a = 0, rem = e;
+          while (rem >= 26 - a) { rem -= 26 - a; ++a; }
+          const int bc = a + rem;
+          if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;
+          auto cdof = [&](int c) { return c < 6 ? c : (c < 12 ? 6 * t + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
+          const double v = gs[e];
+          if (bc == 25) { if (a < 25) { const int q = loc(cdof(a)); if (q >= 0) b1[q] += v; } }
+          else {
+            add(cdof(a), cdof(bc), v);
+            if (cdof(a) != cdof(bc)) add(cdof(bc), cdof(a), v);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  stamp(1);
+  // ---- certificate copy: C - eps I (dense dropped block before the landmarks are folded in) ----
+  for (int e = tid; e < md * md; e += MGT) Ce[e] = A1[(e / md) * T + e % md] - ((e / md == e % md) ? eps : 0.0);
+  // camera dims that exist in this problem (rows of the landmark coupling W)
+  if (tid == 0) {
+    int k = 0;
+    for (int a = 0; a < 79; ++a) { const int t = loc(a); if (t >= 0) { act_a[k] = a; act_t[k] = t; ++k; } }
+    n_act = k;
+  }
+  __syncthreads();
+  // ---- eliminate the dropped landmarks: A1 -= W D^-1 W^T, b1 -= W D^-1 g, tile by tile ----
+  if (L0 > 0) {
+    const int na = n_act;
+    const double *wl = bd.lm_w + 80 * (size_t)wm.lm_off;
+    for (int l0 = 0; l0 < L0; l0 += MG_TILE) {
+      const int nl = min(MG_TILE, L0 - l0);
+      if (tid < nl) {
+        const int l = drop_lm[(size_t)win * max_l0 + l0 + tid];
+        const double D = bd.lm_E[wm.lm_off + l];
+        if (!(D - eps > 0.0)) fail = 1;
+        dinv[tid] = 1.0 / D; deps[tid] = 1.0 / (D - eps); gl[tid] = bd.lm_g[wm.lm_off + l];
+      }
+      for (int e = tid; e < na * MG_TILE; e += MGT) {
+        const int k = e / MG_TILE, j = e % MG_TILE;
+        tile[e] = (j < nl) ? wl[(size_t)act_a[k] * wm.L + drop_lm[(size_t)win * max_l0 + l0 + j]] : 0.0;
+      }
+      __syncthreads();
+      for (int e = tid; e < na * (na + 1) / 2; e += MGT) {
+        int k1 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((k1 + 1) * (k1 + 2) / 2 <= e) ++k1;
+        while (k1 * (k1 + 1) / 2 > e) --k1;
+        const int k2 = e - k1 * (k1 + 1) / 2;
+        double sacc = 0.0, se = 0.0;
+        const int t1 = act_t[k1], t2 = act_t[k2];
+        const bool cert = t1 < md && t2 < md;
+        for (int j = 0; j < nl; ++j) {
+          const double ww = tile[k1 * MG_TILE + j] * tile[k2 * MG_TILE + j];
+          sacc += ww * dinv[j];
+          if (cert) se += ww * deps[j];
+        }
+        A1[t1 * T + t2] -= sacc;
+        if (t1 != t2) A1[t2 * T + t1] -= sacc;
+        if (cert) { Ce[t1 * md + t2] -= se; if (t1 != t2) Ce[t2 * md + t1] -= se; }
+      }
+      if (tid < na) {
+        double sacc = 0.0;
+        for (int j = 0; j < nl; ++j) sacc += tile[tid * MG_TILE + j] * gl[j] * dinv[j];
+        b1[act_t[tid]] -= sacc;
+      }
+      __syncthreads();
+    }
+  }
+  stamp(2);
+  // ---- certificate: Amm - eps I positive definite <=> Cholesky of its landmark-reduced dense block has positive pivots ----
+  chol_lds(Ce, md, md, &fail);
+  if (fail) { if (tid == 0) need_general[win] = 1; return; }
+  // ---- eliminate the dense dropped dims: A' = Arr - Arm C^-1 Amr with C = L L^T ----
+  chol_lds(A1, T, md, &fail);
+  if (fail) { if (tid == 0) need_general[win] = 1; return; }
+  stamp(3);
+  double *Y = tile;   // md x n, Y = L^-1 A1[0:md, md:T]
+  if (tid <= n) {
+    for (int i = 0; i < md; ++i) {
+      double sacc = (tid < n) ? 0.5 * (A1[i * T + md + tid] + A1[(md + tid) * T + i]) : b1[i];
+      for (int k = 0; k < i; ++k) sacc -= A1[i * T + k] * ((tid < n) ? Y[k * n + tid] : yb[k]);
+      sacc /= A1[i * T + i];
+      if (tid < n) Y[i * n + tid] = sacc; else yb[i] = sacc;
+    }
+  }
+  __syncthreads();
+  // A' (lower triangle, mirrored: SelfAdjointEigenSolver reads the lower triangle) into registers, then compact to ld = MG_LD
+  constexpr int PER = (MG_NMAX * MG_NMAX + MGT - 1) / MGT;
+  double keep[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + u * MGT;
+    keep[u] = 0.0;
+    if (e < n * n) {
+      int i = e / n, j = e % n;
+      if (j > i) { const int t_ = i; i = j; j = t_; }
+      double sacc = A1[(md + i) * T + md + j];
+      for (int k = 0; k < md; ++k) sacc -= Y[k * n + i] * Y[k * n + j];
+      keep[u] = sacc;
+    }
+  }
+  if (tid < n) {
+    double sacc = b1[md + tid];
+    for (int k = 0; k < md; ++k) sacc -= Y[k * n + tid] * yb[k];
+    br[tid] = sacc;
+  }
+  __syncthreads();
+  double *Ar = ml, *V2 = ml + MG_NMAX * MG_LD;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + u * MGT;
+    if (e < n * n) Ar[(e / n) * MG_LD + e % n] = keep[u];
+  }
+  __syncthreads();
+  stamp(4);
+  jacobi_eigh_lds(Ar, V2, n, MG_LD, cs, pq, wsum);
+  stamp(5);
+  double *J0 = J0_out + (size_t)win * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, *r0 = r0_out + (size_t)win * VILO_MAX_PRIOR_DIM;
+  for (int e = tid; e < n * n; e += MGT) {
+    const int i = e / n, j = e % n;
+    const double S = Ar[i * MG_LD + i];
+    J0[e] = (S > eps) ? sqrt(S) * V2[j * MG_LD + i] : 0.0;
+  }
+  for (int i = tid; i < n; i += MGT) {
+    const double S = Ar[i * MG_LD + i];
+    double sacc = 0.0;
+    for (int j = 0; j < n; ++j) sacc += V2[j * MG_LD + i] * br[j];
+    r0[i] = (S > eps) ? sqrt(1.0 / S) * sacc : 0.0;
+    if (!isfinite(r0[i])) *status = 1;
+  }
+  stamp(6);
+}
+
 __device__ v3 R2ypr_deg(const m3 &R) {
   const v3 nn = mk3(R.a[0], R.a[3], R.a[6]), o = mk3(R.a[1], R.a[4], R.a[7]), a = mk3(R.a[2], R.a[5], R.a[8]);
   const double y = atan2(nn.y, nn.x);
@@ -341,6 +673,9 @@ __global__ void k_gauge_fix(int W, int F, const double *before_pose0 /*[W][7]*/,
 
 }  // namespace
 
+extern "C" double vilo_last_marginalize_ms(const vilo_ctx *ctx) { return ctx ? ctx->last_marg_ms : 0.0; }
+extern "C" int vilo_debug_marg_general_count(const vilo_ctx *ctx) { return ctx ? ctx->marg_general_count : 0; }
+
 extern "C" int vilo_gauge_fix(vilo_ctx *ctx, int W, const vilo_window_state *before, vilo_window_state *after, int F) {
   if (!ctx || W <= 0 || !before || !after || F < 1 || F > VILO_MAX_FRAMES) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
@@ -388,6 +723,7 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
   std::vector<std::vector<int>> kept_ids(W), kept_cd(W), kept_gs(W), kept_soff(W);
   int max_l0 = 1;
   std::vector<std::vector<int>> drops(W);
+  std::vector<char> keep_prior(W, 0);
   size_t scratch_total = 0;
   for (int w = 0; w < W; ++w) {
     const vilo_window_desc &d = in[w];
@@ -430,7 +766,9 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
         if (std::find(present.begin(), present.end(), kind * 16) != present.end()) dropped_ids.push_back(kind * 16);
     } else {
       if (!has_prior || std::find(present.begin(), present.end(), VILO_BLK_POSE * 16 + (WS - 1)) == present.end()) {
-        out[w].valid = 0; M.m = 0; M.n = 0;
+        // estimator.cpp:1379-1380: nothing is marginalised and last_marginalization_info stays as it is
+        keep_prior[w] = has_prior ? 1 : 0;
+        M.m = 0; M.n = 0;
         continue;
       }
       dropped_ids.push_back(VILO_BLK_POSE * 16 + (WS - 1));
@@ -465,30 +803,72 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
     }
     M.n = pos - M.m;
     if (M.n > VILO_MAX_PRIOR_DIM || (int)kept.size() > VILO_MAX_PRIOR_BLOCKS || M.m > 1200) { vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
-    M.scratch_off = (long long)scratch_total;
-    const size_t T = (size_t)M.m + M.n;
-    scratch_total += T * T + T + 3 * (size_t)M.m * M.m + (size_t)M.n * M.m + 3 * (size_t)M.n * M.n + 2 * M.n + 64;
   }
   std::vector<int> drop_flat((size_t)W * max_l0, 0);
   for (int w = 0; w < W; ++w)
     for (size_t i = 0; i < drops[w].size(); ++i) drop_flat[(size_t)w * max_l0 + i] = drops[w][i];
-  DevBuf d_mw, d_drop, d_scr, d_J0, d_r0, d_status;
+  DevBuf d_mw, d_drop, d_scr, d_J0, d_r0, d_status, d_general, d_clk;
+  const bool want_clk = getenv("VILO_MARG_CLOCKS") != nullptr;
+  if (want_clk && d_clk.alloc(sizeof(long long) * 8 * W) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   auto fail = [&](int code) { vilo_batch_destroy(ctx, bt); return code; };
   if (d_mw.alloc(sizeof(MargWin) * W) != hipSuccess || d_drop.alloc(sizeof(int) * drop_flat.size()) != hipSuccess ||
-      d_scr.alloc(sizeof(double) * std::max<size_t>(1, scratch_total)) != hipSuccess ||
       d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
-      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int)) != hipSuccess)
+      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int)) != hipSuccess ||
+      d_general.alloc(sizeof(int) * W) != hipSuccess)
     return fail(VILO_ERR_HIP);
   if (hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_drop.p, drop_flat.data(), sizeof(int) * drop_flat.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(d_status.p, 0, sizeof(int)) != hipSuccess)
+      hipMemset(d_status.p, 0, sizeof(int)) != hipSuccess || hipMemset(d_general.p, 0, sizeof(int) * W) != hipSuccess)
     return fail(VILO_ERR_HIP);
   // preMarginalize: evaluate the factors at the current state (marginalization_factor.cpp:119-138)
+  (void)hipEventRecord(ctx->ev0, ctx->stream);
   rc = vilo_marg_linearize(ctx, bd);
   if (rc != VILO_OK) return fail(rc);
-  hipLaunchKernelGGL(k_marginalize, dim3(W), dim3(MT), 0, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_scr.as<double>(),
-                     d_J0.as<double>(), d_r0.as<double>(), d_status.as<int>());
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize launch failed"; return fail(VILO_ERR_HIP); }
+  static bool attr_set = false;
+  const size_t lds_bytes = (size_t)MG_LDS_DOUBLES * sizeof(double);
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_marginalize_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return fail(VILO_ERR_HIP);
+    attr_set = true;
+  }
+  const bool force_general = getenv("VILO_MARG_GENERAL") != nullptr;   // test hook: every window through the global-memory eigen path
+  std::vector<int> general(W, force_general ? 1 : 0);
+  if (!force_general) {
+    hipLaunchKernelGGL(k_marginalize_lds, dim3(W), dim3(MGT), lds_bytes, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_J0.as<double>(),
+                       d_r0.as<double>(), d_status.as<int>(), d_general.as<int>(), want_clk ? d_clk.as<long long>() : nullptr);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize_lds launch failed"; return fail(VILO_ERR_HIP); }
+    if (hipMemcpy(general.data(), d_general.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+    if (want_clk) {
+      long long c[8];
+      if (hipMemcpy(c, d_clk.p, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[k_marginalize_lds] window 0 cycles: assemble %lld, landmarks %lld, cholesky %lld, schur %lld, jacobi %lld, output %lld\n", c[1] - c[0],
+                c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[6] - c[5]);
+    }
+  }
+  ctx->marg_general_count = 0;
+  for (int w = 0; w < W; ++w)
+    if (general[w] && mws[w].m > 0 && mws[w].n > 0) { mws[w].general = 1; ++ctx->marg_general_count; }
+  if (ctx->marg_general_count > 0) {
+    // rank-deficient Amm (or an over-sized problem): thresholded eigen pseudo-inverse of the full Amm in global memory
+    scratch_total = 0;
+    for (int w = 0; w < W; ++w) {
+      MargWin &M = mws[w];
+      if (!M.general) continue;
+      M.scratch_off = (long long)scratch_total;
+      const size_t T = (size_t)M.m + M.n;
+      scratch_total += T * T + T + 3 * (size_t)M.m * M.m + (size_t)M.n * M.m + 3 * (size_t)M.n * M.n + 2 * M.n + 64;
+    }
+    if (d_scr.alloc(sizeof(double) * std::max<size_t>(1, scratch_total)) != hipSuccess ||
+        hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(VILO_ERR_HIP);
+    hipLaunchKernelGGL(k_marginalize, dim3(W), dim3(MT), 0, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_scr.as<double>(),
+                       d_J0.as<double>(), d_r0.as<double>(), d_status.as<int>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize launch failed"; return fail(VILO_ERR_HIP); }
+  }
+  float marg_ms = 0.f;
+  if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
+      hipEventElapsedTime(&marg_ms, ctx->ev0, ctx->ev1) != hipSuccess)
+    return fail(VILO_ERR_HIP);
+  ctx->last_marg_ms = marg_ms;
   std::vector<double> J0((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM), r0((size_t)W * VILO_MAX_PRIOR_DIM);
   int status = 0;
   if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -498,6 +878,18 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
     vilo_prior &p = out[w];
+    if (keep_prior[w]) {
+      const vilo_prior &q = *in[w].prior;
+      if (&p != &q) {
+        int sum_g = 0;
+        for (int k = 0; k < q.n_blocks; ++k) { p.block_id[k] = q.block_id[k]; p.block_size[k] = q.block_size[k]; p.block_idx[k] = q.block_idx[k]; sum_g += q.block_size[k]; }
+        p.n = q.n; p.n_blocks = q.n_blocks; p.valid = 1;
+        memmove(p.x0, q.x0, sizeof(double) * sum_g);
+        memmove(p.J0, q.J0, sizeof(double) * (size_t)q.n * q.n);
+        memmove(p.r0, q.r0, sizeof(double) * q.n);
+      }
+      continue;
+    }
     if (M.m == 0 || M.n == 0) { p.valid = 0; continue; }
     const int WS = in[w].n_frames - 1;
     p.n = M.n; p.n_blocks = (int)kept_ids[w].size(); p.valid = 1;

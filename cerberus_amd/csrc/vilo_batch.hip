@@ -4,6 +4,7 @@
 //   problem build  estimator.cpp:1059-1216 (which residual blocks exist; here: landmark-major chunk tables)
 //   double2vector  estimator.cpp:903-1003  (gauge fix: vilo_gauge_fix)
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "solver_types.hpp"
@@ -75,6 +76,10 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   vilo_batch *bt = new vilo_batch();
   bt->W = W;
   memset(&bt->d, 0, sizeof(BatchDev));
+  const bool timing = getenv("VILO_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_prior = 0.0;
   std::vector<WinMeta> wins(W);
   std::vector<ChunkMeta> chunks;
   std::vector<WaveMeta> waves;
@@ -214,6 +219,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         xo += gs;
       }
       wm.pad = bframe;
+      const double t_p0 = now();
       double *H = &pH[(size_t)w * 96 * 96], *b0 = &pb0[(size_t)w * 96];
       // H = J0^T J0 and b0 = J0^T r0 as sums of row outer products: unit-stride inner loops (this is the bulk of the
       // host-side packing time of a batch)
@@ -242,8 +248,10 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
           else if (ci >= CD_B0 && cq >= CD_B0) pd[PD_AD + ((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13] += v;
           else if (ci >= CD_B0 && cq < CD_B0) pd[PD_BP + ((ci - CD_B0) % 13) * 80 + cq] += v;
         }
+      t_prior += now() - t_p0;
     }
   }
+  const double t_packed = now();
   BatchDev &D = bt->d;
   D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
   TRYB(dev_upload(ctx, bt, &D.win, wins));
@@ -297,6 +305,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
     vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP;
   }
+  const double t_uploaded = now();
   // hoist sqrt_info = chol(cov^-1)^T out of the iteration loop (the reference recomputes it on every
   // IMULegFactor::Evaluate, imu_leg_factor.cpp:197-198)
   {
@@ -314,8 +323,12 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     (void)hipFree(d_pre);
     if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
   }
+  const double t_prep = now();
   int rc = vilo_batch_reset(ctx, bt);
   if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
+  if (timing)
+    fprintf(stderr, "[vilo_batch_create] W=%d pack %.2f ms (prior H %.2f) alloc+upload %.2f ms preint %.2f ms reset %.2f ms\n", W, t_packed - t_begin, t_prior,
+            t_uploaded - t_packed, t_prep - t_uploaded, now() - t_prep);
   *out = bt;
   return VILO_OK;
 }

@@ -25,6 +25,8 @@ struct vilo_ctx {
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   double last_solve_ms;
+  double last_marg_ms = 0.0;       // GPU time of the last vilo_marginalize (linearisation + marginalisation kernels)
+  int marg_general_count = 0;      // windows of the last vilo_marginalize that took the global-memory eigen path
   std::string err;
   vilo_config *d_cfg;
   // per-kernel HIP-event timing of the solve pipeline (vilo_set_profiling)

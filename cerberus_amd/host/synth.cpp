@@ -4,6 +4,8 @@
 // Estimator::processIMULeg (estimator.cpp:590-653). No oracle code, no GPU.
 #include <string.h>
 
+#include <map>
+#include <set>
 #include <vector>
 
 #include "../../include/vilo_synth.h"
@@ -357,5 +359,143 @@ extern "C" int vilo_synth_window(const vilo_config *cfg, const vilo_synth_params
       for (int i = 0; i < n; ++i) pr_->r0[i] = 0.3 * rng.normal();
     }
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// continuous stream (see vilo_synth.h)
+struct vilo_synth_stream {
+  vilo_config cfg;
+  vilo_synth_stream_params p;
+  Rng rng;
+  int k = 0;   // next image index
+  double lc_true[4];
+  v3 ba, bg;
+  m3 ric;
+  v3 tic0, tic1;
+  double td;
+  struct Tracked { double l[2], r[2]; bool has_r; };
+  std::map<int, Tracked> tracked;
+  std::set<int> used;
+  explicit vilo_synth_stream(uint64_t seed) : rng(seed) {}
+};
+
+namespace {
+// landmark i of slab k (x in [10k, 10k+10))
+v3 cloud_point(uint64_t seed, int slab, int i) {
+  Rng r(seed * 0x2545F4914F6CDD1Dull + (uint64_t)(slab + 1000) * 7919ull + (uint64_t)i * 104729ull);
+  r.next();
+  return mk3(10.0 * slab + r.uni(0, 10.0), r.uni(-6.0, 6.0), r.uni(-0.2, 3.0));
+}
+}  // namespace
+
+extern "C" void vilo_synth_stream_default_params(vilo_synth_stream_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->seed = 20260925ull;
+  p->imu_rate_hz = 500.0; p->frame_rate_hz = 15.0; p->pixel_noise = 0.5; p->t0 = 0.0;
+  p->cloud_per_10m = 400; p->max_features = 150; p->drop_prob = 0.02; p->stereo_prob = 0.9;
+}
+
+extern "C" vilo_synth_stream *vilo_synth_stream_create(const vilo_config *cfg, const vilo_synth_stream_params *p) {
+  vilo_synth_stream *s = new vilo_synth_stream(p->seed * 0x9E3779B97F4A7C15ull + 777);
+  s->cfg = *cfg; s->p = *p;
+  s->ric.a[0] = 0; s->ric.a[1] = 0; s->ric.a[2] = 1; s->ric.a[3] = -1; s->ric.a[4] = 0; s->ric.a[5] = 0; s->ric.a[6] = 0; s->ric.a[7] = -1; s->ric.a[8] = 0;
+  s->tic0 = mk3(0.10076, 0.025, 0.1114); s->tic1 = mk3(0.10076, -0.025, 0.1114);
+  s->td = 0.0;
+  s->ba = mk3(0.05, -0.03, 0.02); s->bg = mk3(0.002, -0.001, 0.0015);
+  for (int j = 0; j < 4; ++j) s->lc_true[j] = 0.21 + 0.003 * s->rng.normal();
+  return s;
+}
+extern "C" void vilo_synth_stream_destroy(vilo_synth_stream *s) { delete s; }
+extern "C" void vilo_synth_stream_extrinsics(const vilo_synth_stream *s, double *tic, double *ric, double *td) {
+  st3(tic, s->tic0); st3(tic + 3, s->tic1);
+  for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < 9; ++i) ric[9 * c + i] = s->ric.a[i];
+  *td = s->td;
+}
+
+extern "C" int vilo_synth_stream_next(vilo_synth_stream *s, vilo_sample *samples, int max_samples, int *n_samples, int *ids, double *obs11,
+                                      uint8_t *stereo, int max_features, int *n_features, double *header, double *truth) {
+  const double DT = 1.0 / s->p.frame_rate_hz, h = 1.0 / s->p.imu_rate_hz;
+  const double t = s->p.t0 + s->k * DT;
+  // --- samples ---
+  int ns = 0;
+  if (s->k == 0) {
+    if (max_samples < 1) return -1;
+    make_sample(&s->cfg, t, 0.0, s->lc_true, s->ba, s->bg, s->rng, &samples[ns++]);
+  } else {
+    const double tp = t - DT;
+    int n_full = (int)floor(DT / h + 1e-9);
+    double last_dt = DT - n_full * h;
+    if (last_dt < 1e-9) { last_dt = h; n_full -= 1; }
+    if (max_samples < n_full + 1) return -1;
+    for (int i = 1; i <= n_full; ++i) make_sample(&s->cfg, tp + i * h, h, s->lc_true, s->ba, s->bg, s->rng, &samples[ns++]);
+    make_sample(&s->cfg, t, last_dt, s->lc_true, s->ba, s->bg, s->rng, &samples[ns++]);
+  }
+  *n_samples = ns;
+  // --- features ---
+  const BodyState b = body_at(t);
+  const double pn = s->p.pixel_noise / s->cfg.focal_length;
+  auto project = [&](const v3 &Pw, double l[2], double r[2], bool &in_r) {
+    const v3 pb = tr(b.R) * (Pw - b.p);
+    const v3 c0 = tr(s->ric) * (pb - s->tic0), c1 = tr(s->ric) * (pb - s->tic1);
+    if (c0.z < 1.0 || c0.z > 20.0) return false;
+    l[0] = c0.x / c0.z; l[1] = c0.y / c0.z;
+    if (fabs(l[0]) > 0.7 || fabs(l[1]) > 0.55) return false;
+    r[0] = c1.x / c1.z; r[1] = c1.y / c1.z;
+    in_r = fabs(r[0]) <= 0.7 && fabs(r[1]) <= 0.55;
+    return true;
+  };
+  const int per = s->p.cloud_per_10m;
+  auto point_of = [&](int id) { return cloud_point(s->p.seed, id / per - 1000, id % per); };
+  std::map<int, vilo_synth_stream::Tracked> next;
+  int nf = 0;
+  auto emit = [&](int id, const double l[2], const double r[2], bool has_r, const vilo_synth_stream::Tracked *prev) {
+    double *ob = obs11 + 11 * (size_t)nf;
+    ob[0] = l[0]; ob[1] = l[1]; ob[2] = 1.0;
+    ob[3] = has_r ? r[0] : 0.0; ob[4] = has_r ? r[1] : 0.0; ob[5] = has_r ? 1.0 : 0.0;
+    ob[6] = prev ? (l[0] - prev->l[0]) / DT : 0.0; ob[7] = prev ? (l[1] - prev->l[1]) / DT : 0.0;
+    ob[8] = (prev && prev->has_r && has_r) ? (r[0] - prev->r[0]) / DT : 0.0;
+    ob[9] = (prev && prev->has_r && has_r) ? (r[1] - prev->r[1]) / DT : 0.0;
+    ob[10] = s->td;
+    ids[nf] = id; stereo[nf] = has_r ? 1 : 0;
+    ++nf;
+    vilo_synth_stream::Tracked tr_;
+    tr_.l[0] = l[0]; tr_.l[1] = l[1]; tr_.r[0] = r[0]; tr_.r[1] = r[1]; tr_.has_r = has_r;
+    next[id] = tr_;
+  };
+  for (auto &kv : s->tracked) {
+    double l[2], r[2];
+    bool in_r = false;
+    if (s->rng.uni() < s->p.drop_prob) continue;
+    if (!project(point_of(kv.first), l, r, in_r)) continue;
+    if (nf >= max_features) return -1;
+    for (int c = 0; c < 2; ++c) { l[c] += pn * s->rng.normal(); r[c] += pn * s->rng.normal(); }
+    emit(kv.first, l, r, in_r && s->rng.uni() < s->p.stereo_prob, &kv.second);
+  }
+  const int slab0 = (int)floor((b.p.x + 0.5) / 10.0), slab1 = (int)floor((b.p.x + 21.0) / 10.0);
+  for (int sl = slab0; sl <= slab1 && nf < s->p.max_features; ++sl)
+    for (int i = 0; i < per && nf < s->p.max_features; ++i) {
+      const int id = (sl + 1000) * per + i;
+      if (s->used.count(id)) continue;
+      double l[2], r[2];
+      bool in_r = false;
+      if (!project(cloud_point(s->p.seed, sl, i), l, r, in_r)) continue;
+      if (nf >= max_features) return -1;
+      for (int c = 0; c < 2; ++c) { l[c] += pn * s->rng.normal(); r[c] += pn * s->rng.normal(); }
+      s->used.insert(id);
+      emit(id, l, r, in_r && s->rng.uni() < s->p.stereo_prob, nullptr);
+    }
+  s->tracked.swap(next);
+  *n_features = nf;
+  *header = t;
+  if (truth) {
+    const quat q = quat_from_R(b.R);
+    st3(truth, b.p);
+    truth[3] = q.x; truth[4] = q.y; truth[5] = q.z; truth[6] = q.w;
+    st3(truth + 7, b.v); st3(truth + 10, s->ba); st3(truth + 13, s->bg);
+    for (int j = 0; j < 4; ++j) truth[16 + j] = s->lc_true[j];
+  }
+  ++s->k;
   return 0;
 }

@@ -1,0 +1,534 @@
+// See vilo_sliding_window.h. Host bookkeeping only: every factor evaluation, the trust-region solve, preintegration and the
+// marginalisation run in libvilo_gpu.so.
+#include "vilo_sliding_window.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vilo_window_io.h"
+#include "../csrc/vilo_math.hpp"
+
+namespace vilo {
+namespace {
+
+// Eigen::Quaterniond(Matrix3d) (the branch structure of Eigen's quaternion-from-rotation-matrix)
+quat quat_from_R(const m3 &m) {
+  quat q;
+  double t = m.a[0] + m.a[4] + m.a[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m.a[7] - m.a[5]) * t; q.y = (m.a[2] - m.a[6]) * t; q.z = (m.a[3] - m.a[1]) * t;
+  } else {
+    int i = 0;
+    if (m.a[4] > m.a[0]) i = 1;
+    if (m.a[8] > m.a[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m.a[4 * i] - m.a[4 * j] - m.a[4 * k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m.a[3 * k + j] - m.a[3 * j + k]) * t;
+    v[j] = (m.a[3 * j + i] + m.a[3 * i + j]) * t;
+    v[k] = (m.a[3 * k + i] + m.a[3 * i + k]) * t;
+    q.x = v[0]; q.y = v[1]; q.z = v[2];
+  }
+  return q;
+}
+// Utility::R2ypr (utility.h:83-98), degrees
+v3 R2ypr(const m3 &R) {
+  const double y = std::atan2(R.a[3], R.a[0]);
+  const double p = std::atan2(-R.a[6], R.a[0] * std::cos(y) + R.a[3] * std::sin(y));
+  const double r = std::atan2(R.a[2] * std::sin(y) - R.a[5] * std::cos(y), -R.a[1] * std::sin(y) + R.a[4] * std::cos(y));
+  return mk3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+// Utility::ypr2R (utility.h:100-126)
+m3 ypr2R(const v3 &ypr) {
+  const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+  m3 Rz = m3_eye(), Ry = m3_eye(), Rx = m3_eye();
+  Rz.a[0] = std::cos(y); Rz.a[1] = -std::sin(y); Rz.a[3] = std::sin(y); Rz.a[4] = std::cos(y);
+  Ry.a[0] = std::cos(p); Ry.a[2] = std::sin(p); Ry.a[6] = -std::sin(p); Ry.a[8] = std::cos(p);
+  Rx.a[4] = std::cos(r); Rx.a[5] = -std::sin(r); Rx.a[7] = std::sin(r); Rx.a[8] = std::cos(r);
+  return Rz * Ry * Rx;
+}
+// Utility::g2R (utility.cpp:12-22) with Eigen's Quaternion::FromTwoVectors for the non-antiparallel case
+m3 g2R(const v3 &gv) {
+  const v3 a = gv * (1.0 / norm(gv)), b = mk3(0, 0, 1.0);
+  const double c = dot(a, b);
+  quat q;
+  if (c < -1.0 + 1e-12) {
+    q = mkq(0.0, 1.0, 0.0, 0.0);   // half turn about any axis perpendicular to gravity
+  } else {
+    const v3 axis = cross(a, b);
+    const double s = std::sqrt((1.0 + c) * 2.0);
+    q = mkq(0.5 * s, axis.x / s, axis.y / s, axis.z / s);
+  }
+  m3 R0 = qR(q);
+  const double yaw = R2ypr(R0).x;
+  return ypr2R(mk3(-yaw, 0, 0)) * R0;
+}
+inline void st_m3(double *p, const m3 &m) { for (int i = 0; i < 9; ++i) p[i] = m.a[i]; }
+inline void cp(double *d, const double *s, int n) { std::memcpy(d, s, sizeof(double) * n); }
+template <int N> inline void swp(double (&a)[N], double (&b)[N]) { for (int i = 0; i < N; ++i) std::swap(a[i], b[i]); }
+
+}  // namespace
+
+SlidingWindow::PriorStore::PriorStore() : x0(7 * VILO_MAX_PRIOR_BLOCKS), J0((size_t)VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM), r0(VILO_MAX_PRIOR_DIM) {
+  std::memset(&p, 0, sizeof(p));
+  bind();
+}
+
+SlidingWindow::SlidingWindow(vilo_ctx *ctx, const vilo_config &cfg, const SlidingWindowOptions &opt)
+    : f_manager(opt.features), ctx_(ctx), cfg_(cfg), opt_(opt), pre_(NF), pre_imu_(NF) {
+  clearState();
+  g[0] = 0; g[1] = 0; g[2] = cfg.g_norm;
+}
+
+void SlidingWindow::clearState() {
+  const m3 I = m3_eye();
+  for (int i = 0; i < NF; ++i) {
+    st_m3(Rs[i], I);
+    for (int k = 0; k < 3; ++k) Ps[i][k] = Vs[i][k] = Bas[i][k] = Bgs[i][k] = 0.0;
+    for (int k = 0; k < 4; ++k) Rho[i][k] = 0.21;   // VILO_LOWER_LEG_LENGTH (estimator.cpp:167-170, yaml lower_leg_length)
+    Headers[i] = 0.0;
+    buf_[i].clear();
+    dirty_[i] = false;
+    std::memset(lin_[i], 0, sizeof lin_[i]);
+  }
+  for (int c = 0; c < 2; ++c) {
+    st_m3(ric[c], I);
+    tic[c][0] = tic[c][1] = tic[c][2] = 0.0;
+  }
+  first_imu = false; init_first_pose_flag = false;
+  sum_of_back = sum_of_front = 0; frame_count = 0; solver_flag = INITIAL; open_ex_estimation = 0;
+  prior_[0].p.valid = prior_[1].p.valid = 0; cur_prior_ = 0; pending_ = 0; n_optimizations = 0;
+  std::memset(&last_sample, 0, sizeof last_sample);
+  std::memset(&last_summary, 0, sizeof last_summary);
+  f_manager.clearState();
+}
+
+void SlidingWindow::setExtrinsics(const double *t, const double *r, double td_) {
+  cp(&tic[0][0], t, 6);
+  cp(&ric[0][0], r, 18);
+  td = td_;
+}
+
+void SlidingWindow::initFirstPose(const double p[3], const double R[9]) {
+  cp(Ps[0], p, 3);
+  cp(Rs[0], R, 9);
+  init_first_pose_flag = true;
+}
+
+void SlidingWindow::initFirstIMUPose(const vilo_sample *s, int n) {
+  init_first_pose_flag = true;
+  v3 aver = mk3(0, 0, 0);
+  for (int i = 0; i < n; ++i) aver = aver + ld3(s[i].acc);
+  aver = aver * (1.0 / n);
+  st_m3(Rs[0], g2R(aver));
+}
+
+void SlidingWindow::startInterval(int j) {
+  buf_[j].assign(1, last_sample);
+  cp(lin_[j], Bas[j], 3); cp(lin_[j] + 3, Bgs[j], 3); cp(lin_[j] + 6, Rho[j], 4);
+  dirty_[j] = true;
+}
+
+void SlidingWindow::processIMULeg(const vilo_sample &s) {
+  if (!first_imu) {
+    first_imu = true;
+    last_sample = s;
+  }
+  if (buf_[frame_count].empty()) startInterval(frame_count);
+  if (frame_count != 0) {
+    const int j = frame_count;
+    buf_[j].push_back(s);
+    dirty_[j] = true;
+    // mid-point propagation of the newest frame (estimator.cpp:634-641)
+    const double dt = s.dt;
+    const v3 gv = ld3(g), ba = ld3(Bas[j]), bg = ld3(Bgs[j]);
+    m3 R = ld_m3_rowmajor(Rs[j]);
+    const v3 un_acc_0 = R * (ld3(last_sample.acc) - ba) - gv;
+    const v3 un_gyr = (ld3(last_sample.gyr) + ld3(s.gyr)) * 0.5 - bg;
+    R = R * qR(deltaQ(un_gyr * dt));
+    const v3 un_acc_1 = R * (ld3(s.acc) - ba) - gv;
+    const v3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+    const v3 P = ld3(Ps[j]) + ld3(Vs[j]) * dt + un_acc * (0.5 * dt * dt);
+    const v3 V = ld3(Vs[j]) + un_acc * dt;
+    st_m3(Rs[j], R); st3(Ps[j], P); st3(Vs[j], V);
+  }
+  last_sample = s;
+}
+
+void SlidingWindow::vector2double() {
+  para_Pose.resize(7 * NF); para_SpeedBias.resize(9 * NF); para_LegBias.resize(4 * NF); para_Ex_Pose.resize(14); para_Td.resize(1);
+  for (int i = 0; i < NF; ++i) {
+    double *p = &para_Pose[7 * i];
+    cp(p, Ps[i], 3);
+    const quat q = quat_from_R(ld_m3_rowmajor(Rs[i]));
+    p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+    double *sb = &para_SpeedBias[9 * i];
+    cp(sb, Vs[i], 3); cp(sb + 3, Bas[i], 3); cp(sb + 6, Bgs[i], 3);
+    cp(&para_LegBias[4 * i], Rho[i], 4);
+  }
+  for (int c = 0; c < 2; ++c) {
+    double *p = &para_Ex_Pose[7 * c];
+    cp(p, tic[c], 3);
+    const quat q = quat_from_R(ld_m3_rowmajor(ric[c]));
+    p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+  }
+  para_Feature.assign(std::max(1, f_manager.featureCount()), 0.0);
+  f_manager.depthVector(para_Feature.data());
+  para_Td[0] = td;
+}
+
+void SlidingWindow::double2vector() {
+  // the yaw / position re-anchoring itself (estimator.cpp:905-957) ran in vilo_gauge_fix on para_*; unpack
+  for (int i = 0; i < NF; ++i) {
+    const double *p = &para_Pose[7 * i];
+    cp(Ps[i], p, 3);
+    st_m3(Rs[i], qR(qnormalized(ldq_pose(p))));
+    const double *sb = &para_SpeedBias[9 * i];
+    cp(Vs[i], sb, 3); cp(Bas[i], sb + 3, 3); cp(Bgs[i], sb + 6, 3);
+    if (opt_.use_leg) cp(Rho[i], &para_LegBias[4 * i], 4);
+  }
+  for (int c = 0; c < 2; ++c) {
+    const double *p = &para_Ex_Pose[7 * c];
+    cp(tic[c], p, 3);
+    st_m3(ric[c], qR(qnormalized(ldq_pose(p))));
+  }
+  if (f_manager.featureCount() > 0) f_manager.setDepth(para_Feature.data());
+  td = para_Td[0];
+}
+
+void SlidingWindow::fillDesc() {
+  std::memset(&desc_, 0, sizeof desc_);
+  f_manager.fill(&desc_, &lm_start_, &lm_off_, &obs_, &stereo_);
+  desc_.n_frames = frame_count + 1;
+  desc_.use_leg = opt_.use_leg;
+  desc_.preint = opt_.use_leg ? &pre_[1] : nullptr;
+  desc_.preint_imu = opt_.use_leg ? nullptr : &pre_imu_[1];
+  desc_.prior = hasPrior() ? &prior_[cur_prior_].p : nullptr;
+  // SetParameterBlockConstant decisions, estimator.cpp:1074-1106
+  desc_.leg_bias_const = (opt_.use_leg && !opt_.optimize_leg_bias) || frame_count < WS;
+  const double v0 = norm(ld3(Vs[0]));
+  if ((opt_.estimate_extrinsic && frame_count == WS && v0 > 0.2) || open_ex_estimation) {
+    open_ex_estimation = 1;
+    desc_.ex_const = 0;
+  } else {
+    desc_.ex_const = 1;
+  }
+  desc_.td_const = (!opt_.estimate_td || v0 < 0.2) ? 1 : 0;
+  state_.pose = para_Pose.data(); state_.speed_bias = para_SpeedBias.data(); state_.leg_bias = para_LegBias.data();
+  state_.ex_pose = para_Ex_Pose.data(); state_.td = para_Td.data(); state_.inv_depth = para_Feature.data();
+}
+
+bool SlidingWindow::beginImage(double header, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
+  marginalization_flag = f_manager.addFrame(frame_count, n, ids, obs11, stereo, td) ? MARGIN_OLD : MARGIN_SECOND_NEW;
+  Headers[frame_count] = header;
+  pending_ = 0;
+  if (solver_flag == INITIAL) {
+    f_manager.triangulate(&Ps[0][0], &Rs[0][0], &tic[0][0], &ric[0][0]);
+    if (frame_count == WS) {
+      // il_pre_integrations[i]->repropagate(Zero, Bgs[i], rho_i) (estimator.cpp:752-760)
+      for (int i = 0; i < NF; ++i) {
+        lin_[i][0] = lin_[i][1] = lin_[i][2] = 0.0;
+        cp(lin_[i] + 3, Bgs[i], 3); cp(lin_[i] + 6, Rho[i], 4);
+        dirty_[i] = true;
+      }
+      pending_ = 1;
+      return true;
+    }
+    // estimator.cpp:789-802
+    ++frame_count;
+    const int prev = frame_count - 1;
+    cp(Ps[frame_count], Ps[prev], 3); cp(Vs[frame_count], Vs[prev], 3); cp(Rs[frame_count], Rs[prev], 9);
+    cp(Bas[frame_count], Bas[prev], 3); cp(Bgs[frame_count], Bgs[prev], 3); cp(Rho[frame_count], Rho[prev], 4);
+    return false;
+  }
+  f_manager.triangulate(&Ps[0][0], &Rs[0][0], &tic[0][0], &ric[0][0]);
+  pending_ = 2;
+  return true;
+}
+
+void SlidingWindow::endImage() {
+  if (pending_ == 1) {
+    solver_flag = NON_LINEAR;
+    slideWindow();
+  } else if (pending_ == 2) {
+    std::vector<int> remove_ids;
+    outliersRejection(&remove_ids);
+    f_manager.removeOutlier(remove_ids.data(), (int)remove_ids.size());
+    slideWindow();
+    f_manager.removeFailures();
+  }
+  pending_ = 0;
+}
+
+int SlidingWindow::processImage(double header, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
+  int rc = VILO_OK;
+  if (beginImage(header, n, ids, obs11, stereo)) {
+    SlidingWindow *self = this;
+    rc = optimizeBatch(ctx_, &self, 1);
+  }
+  if (rc == VILO_OK) endImage();
+  return rc;
+}
+
+int SlidingWindow::dump(const vilo_window_state &before) const {
+  char path[1024];
+  std::snprintf(path, sizeof path, "%s/win_%05d.bin", opt_.dump_dir.c_str(), n_optimizations);
+  const double ref_summary[4] = {(double)last_summary.iterations, last_summary.initial_cost, last_summary.final_cost, (double)last_summary.termination};
+  return vilo_window_write(path, &cfg_, &desc_, &before, &state_, ref_summary, marginalization_flag);
+}
+
+int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n) {
+  if (n <= 0) return VILO_OK;
+  const int use_leg = ws[0]->opt_.use_leg;
+  for (int w = 0; w < n; ++w)
+    if (ws[w]->opt_.use_leg != use_leg || ws[w]->pending_ == 0 || ws[w]->frame_count != WS) return VILO_ERR_BAD_ARG;
+  // 1. preintegration of the intervals whose samples or linearisation point changed: one device call for the whole fleet
+  {
+    std::vector<vilo_sample> samples;
+    std::vector<int32_t> offsets(1, 0);
+    std::vector<double> lin;
+    std::vector<std::pair<int, int>> which;
+    for (int w = 0; w < n; ++w)
+      for (int j = 1; j <= WS; ++j) {
+        SlidingWindow &s = *ws[w];
+        if (!s.dirty_[j]) continue;
+        samples.insert(samples.end(), s.buf_[j].begin(), s.buf_[j].end());
+        offsets.push_back((int32_t)samples.size());
+        if (use_leg) lin.insert(lin.end(), s.lin_[j], s.lin_[j] + 10);
+        else lin.insert(lin.end(), s.lin_[j], s.lin_[j] + 6);
+        which.push_back({w, j});
+      }
+    if (!which.empty()) {
+      int rc;
+      if (use_leg) {
+        std::vector<vilo_preint> out(which.size());
+        rc = vilo_preintegrate(ctx, (int)which.size(), samples.data(), offsets.data(), lin.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_[which[k].second] = out[k];
+      } else {
+        std::vector<vilo_preint_imu> out(which.size());
+        rc = vilo_preintegrate_imu(ctx, (int)which.size(), samples.data(), offsets.data(), lin.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_imu_[which[k].second] = out[k];
+      }
+      for (auto &wj : which) ws[wj.first]->dirty_[wj.second] = false;
+    }
+  }
+  // 2. vector2double + the problem description
+  std::vector<vilo_window_desc> descs(n);
+  std::vector<vilo_window_state> states(n), befores(n);
+  std::vector<std::vector<double>> keep(n);   // pre-solve copies: Rs[0]/Ps[0] for the gauge fix, everything for the dump
+  std::vector<vilo_solve_summary> sums(n);
+  for (int w = 0; w < n; ++w) {
+    SlidingWindow &s = *ws[w];
+    s.vector2double();
+    s.fillDesc();
+    descs[w] = s.desc_; states[w] = s.state_;
+    std::vector<double> &k = keep[w];
+    k.insert(k.end(), s.para_Pose.begin(), s.para_Pose.end());
+    k.insert(k.end(), s.para_SpeedBias.begin(), s.para_SpeedBias.end());
+    k.insert(k.end(), s.para_LegBias.begin(), s.para_LegBias.end());
+    k.insert(k.end(), s.para_Ex_Pose.begin(), s.para_Ex_Pose.end());
+    k.insert(k.end(), s.para_Td.begin(), s.para_Td.end());
+    k.insert(k.end(), s.para_Feature.begin(), s.para_Feature.end());
+    double *b = k.data();
+    befores[w].pose = b; b += 7 * NF;
+    befores[w].speed_bias = b; b += 9 * NF;
+    befores[w].leg_bias = b; b += 4 * NF;
+    befores[w].ex_pose = b; b += 14;
+    befores[w].td = b; b += 1;
+    befores[w].inv_depth = b;
+  }
+  // 3. ceres::Solve (estimator.cpp:1236) and double2vector (:1240)
+  int rc = vilo_solve_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, sums.data());
+  if (rc != VILO_OK) return rc;
+  rc = vilo_gauge_fix(ctx, n, befores.data(), states.data(), NF);
+  if (rc != VILO_OK) return rc;
+  for (int w = 0; w < n; ++w) {
+    SlidingWindow &s = *ws[w];
+    s.last_summary = sums[w];
+    s.double2vector();
+    // marginalisation linearises at vector2double() of the unpacked state (estimator.cpp:1252 / :1384)
+    s.vector2double();
+    s.state_.inv_depth = s.para_Feature.data();
+    states[w] = s.state_;
+    if (!s.opt_.dump_dir.empty() && s.dump(befores[w]) != 0) return VILO_ERR_BAD_ARG;
+    ++s.n_optimizations;
+  }
+  // 4. marginalisation (estimator.cpp:1247-1455), one device call per flag value present in the fleet
+  for (int mode = 0; mode < 2; ++mode) {
+    std::vector<int> idx;
+    for (int w = 0; w < n; ++w)
+      if (ws[w]->marginalization_flag == mode) idx.push_back(w);
+    if (idx.empty()) continue;
+    std::vector<vilo_window_desc> d(idx.size());
+    std::vector<vilo_window_state> st(idx.size());
+    std::vector<vilo_prior> out(idx.size());
+    for (size_t k = 0; k < idx.size(); ++k) {
+      SlidingWindow &s = *ws[idx[k]];
+      d[k] = descs[idx[k]]; st[k] = states[idx[k]];
+      PriorStore &nx = s.prior_[1 - s.cur_prior_];
+      nx.bind();
+      out[k] = nx.p;
+    }
+    rc = vilo_marginalize(ctx, (int)idx.size(), d.data(), st.data(), mode, out.data());
+    if (rc != VILO_OK) return rc;
+    for (size_t k = 0; k < idx.size(); ++k) {
+      SlidingWindow &s = *ws[idx[k]];
+      s.prior_[1 - s.cur_prior_].p = out[k];
+      s.prior_[1 - s.cur_prior_].bind();
+      s.cur_prior_ = 1 - s.cur_prior_;
+    }
+  }
+  return VILO_OK;
+}
+
+void SlidingWindow::outliersRejection(std::vector<int> *remove_ids) const {
+  const m3 r0 = ld_m3_rowmajor(ric[0]), r1 = ld_m3_rowmajor(ric[1]);
+  const v3 t0 = ld3(tic[0]), t1 = ld3(tic[1]);
+  auto reproj = [&](int i, int j, const m3 &ricj, const v3 &ticj, double depth, const v3 &uvi, const double *uvj) {
+    const m3 Ri = ld_m3_rowmajor(Rs[i]), Rj = ld_m3_rowmajor(Rs[j]);
+    const v3 pts_w = Ri * (r0 * (uvi * depth) + t0) + ld3(Ps[i]);
+    const v3 pc = tr(ricj) * (tr(Rj) * (pts_w - ld3(Ps[j])) - ticj);
+    const double rx = pc.x / pc.z - uvj[0], ry = pc.y / pc.z - uvj[1];
+    return std::sqrt(rx * rx + ry * ry);
+  };
+  for (const Track &t : f_manager.tracks) {
+    if (t.obs.size() < 4) continue;
+    double err = 0;
+    int cnt = 0;
+    const int imu_i = t.start_frame;
+    int imu_j = imu_i - 1;
+    const v3 pts_i = ld3(t.obs[0].point);
+    const double depth = t.estimated_depth;
+    for (const Observation &o : t.obs) {
+      ++imu_j;
+      if (imu_i != imu_j) { err += reproj(imu_i, imu_j, r0, t0, depth, pts_i, o.point); ++cnt; }
+      if (f_manager.cfg.stereo && o.is_stereo) { err += reproj(imu_i, imu_j, r1, t1, depth, pts_i, o.point_right); ++cnt; }
+    }
+    if (err / cnt * f_manager.cfg.focal_length > 3) remove_ids->push_back(t.feature_id);
+  }
+}
+
+void SlidingWindow::slideWindow() {
+  if (frame_count != WS) return;
+  if (marginalization_flag == MARGIN_OLD) {
+    cp(back_R0_, Rs[0], 9); cp(back_P0_, Ps[0], 3);
+    for (int i = 0; i < WS; ++i) {
+      std::swap(Headers[i], Headers[i + 1]);
+      swp(Rs[i], Rs[i + 1]); swp(Ps[i], Ps[i + 1]); swp(Vs[i], Vs[i + 1]); swp(Bas[i], Bas[i + 1]); swp(Bgs[i], Bgs[i + 1]);
+      swp(Rho[i], Rho[i + 1]);
+      buf_[i].swap(buf_[i + 1]);
+      swp(lin_[i], lin_[i + 1]);
+      std::swap(pre_[i], pre_[i + 1]);
+      std::swap(pre_imu_[i], pre_imu_[i + 1]);
+      std::swap(dirty_[i], dirty_[i + 1]);
+    }
+    Headers[WS] = Headers[WS - 1];
+    cp(Ps[WS], Ps[WS - 1], 3); cp(Rs[WS], Rs[WS - 1], 9); cp(Vs[WS], Vs[WS - 1], 3); cp(Bas[WS], Bas[WS - 1], 3);
+    cp(Bgs[WS], Bgs[WS - 1], 3); cp(Rho[WS], Rho[WS - 1], 4);
+    startInterval(WS);
+    slideWindowOld();
+  } else {
+    Headers[WS - 1] = Headers[WS];
+    cp(Ps[WS - 1], Ps[WS], 3); cp(Rs[WS - 1], Rs[WS], 9);
+    // the newest interval is appended to the one before it (estimator.cpp:1581-1599); its constructor sample is not a push
+    buf_[WS - 1].insert(buf_[WS - 1].end(), buf_[WS].begin() + 1, buf_[WS].end());
+    dirty_[WS - 1] = true;
+    cp(Vs[WS - 1], Vs[WS], 3); cp(Bas[WS - 1], Bas[WS], 3); cp(Bgs[WS - 1], Bgs[WS], 3); cp(Rho[WS - 1], Rho[WS], 4);
+    startInterval(WS);
+    slideWindowNew();
+  }
+}
+
+void SlidingWindow::slideWindowNew() {
+  ++sum_of_front;
+  f_manager.removeFront(frame_count);
+}
+
+void SlidingWindow::slideWindowOld() {
+  ++sum_of_back;
+  if (solver_flag == NON_LINEAR) {
+    const m3 bR = ld_m3_rowmajor(back_R0_), R0n = ld_m3_rowmajor(Rs[0]), r0 = ld_m3_rowmajor(ric[0]);
+    double mR[9], nR[9], mP[3], nP[3];
+    st_m3(mR, bR * r0); st_m3(nR, R0n * r0);
+    st3(mP, ld3(back_P0_) + bR * ld3(tic[0]));
+    st3(nP, ld3(Ps[0]) + R0n * ld3(tic[0]));
+    f_manager.removeBackShiftDepth(mR, mP, nR, nP);
+  } else {
+    f_manager.removeBack();
+  }
+}
+
+}  // namespace vilo
+
+extern "C" {
+using vilo::SlidingWindow;
+void *vilo_sw_create(vilo_ctx *ctx, const vilo_config *cfg, const vilo_sw_options *o) {
+  vilo::SlidingWindowOptions opt;
+  if (o) {
+    opt.use_leg = o->use_leg; opt.optimize_leg_bias = o->optimize_leg_bias; opt.estimate_extrinsic = o->estimate_extrinsic;
+    opt.estimate_td = o->estimate_td;
+    if (o->max_num_iterations > 0) opt.solve.max_num_iterations = o->max_num_iterations;
+    opt.solve.fixed_iterations = o->fixed_iterations;
+    if (o->dump_dir) opt.dump_dir = o->dump_dir;
+  }
+  opt.features.focal_length = cfg->focal_length;
+  return new SlidingWindow(ctx, *cfg, opt);
+}
+void vilo_sw_destroy(void *h) { delete (SlidingWindow *)h; }
+void vilo_sw_set_extrinsics(void *h, const double *t, const double *r, double td) { ((SlidingWindow *)h)->setExtrinsics(t, r, td); }
+void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v) {
+  SlidingWindow *s = (SlidingWindow *)h;
+  s->initFirstPose(p, R);
+  if (v) s->setInitialVelocity(v);
+}
+void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *s, int n) { ((SlidingWindow *)h)->initFirstIMUPose(s, n); }
+void vilo_sw_process_samples(void *h, const vilo_sample *s, int n) {
+  for (int i = 0; i < n; ++i) ((SlidingWindow *)h)->processIMULeg(s[i]);
+}
+int vilo_sw_process_image(void *h, double header, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
+  return ((SlidingWindow *)h)->processImage(header, n, ids, obs11, stereo);
+}
+int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int W, const double *headers, const int *off, const int *ids, const double *obs11,
+                           const uint8_t *stereo) {
+  std::vector<SlidingWindow *> due;
+  for (int w = 0; w < W; ++w) {
+    SlidingWindow *s = (SlidingWindow *)hs[w];
+    if (s->beginImage(headers[w], off[w + 1] - off[w], ids + off[w], obs11 + 11 * (size_t)off[w], stereo + off[w])) due.push_back(s);
+  }
+  const int rc = SlidingWindow::optimizeBatch(ctx, due.data(), (int)due.size());
+  if (rc != VILO_OK) return rc;
+  for (int w = 0; w < W; ++w) ((SlidingWindow *)hs[w])->endImage();
+  return VILO_OK;
+}
+void vilo_sw_get_state(void *h, int *flags, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, double *Rho, double *tic, double *ric,
+                       double *td) {
+  const SlidingWindow *s = (const SlidingWindow *)h;
+  if (flags) {
+    flags[0] = s->frame_count; flags[1] = s->solver_flag; flags[2] = s->marginalization_flag; flags[3] = s->n_optimizations;
+    flags[4] = s->f_manager.featureCount(); flags[5] = s->hasPrior() ? s->prior().n : 0;
+  }
+  const int NF = SlidingWindow::NF;
+  if (Ps) std::memcpy(Ps, s->Ps, sizeof(double) * 3 * NF);
+  if (Rs) std::memcpy(Rs, s->Rs, sizeof(double) * 9 * NF);
+  if (Vs) std::memcpy(Vs, s->Vs, sizeof(double) * 3 * NF);
+  if (Bas) std::memcpy(Bas, s->Bas, sizeof(double) * 3 * NF);
+  if (Bgs) std::memcpy(Bgs, s->Bgs, sizeof(double) * 3 * NF);
+  if (Rho) std::memcpy(Rho, s->Rho, sizeof(double) * 4 * NF);
+  if (tic) std::memcpy(tic, s->tic, sizeof(double) * 6);
+  if (ric) std::memcpy(ric, s->ric, sizeof(double) * 18);
+  if (td) *td = s->td;
+}
+int vilo_sw_last_summary(void *h, vilo_solve_summary *out) {
+  *out = ((SlidingWindow *)h)->last_summary;
+  return 0;
+}
+}

@@ -232,11 +232,20 @@ int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before
 
 /* ---- marginalisation half (estimator.cpp:1247-1455; MarginalizationInfo::{preMarginalize,marginalize,
  * getParameterBlocks} marginalization_factor.cpp:119-333). mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW.
- * out->x0/J0/r0 must point at caller buffers of >= 7*VILO_MAX_PRIOR_BLOCKS, VILO_MAX_PRIOR_DIM^2, VILO_MAX_PRIOR_DIM doubles. */
+ * out->x0/J0/r0 must point at caller buffers of >= 7*VILO_MAX_PRIOR_BLOCKS, VILO_MAX_PRIOR_DIM^2, VILO_MAX_PRIOR_DIM doubles.
+ * MARGIN_SECOND_NEW with a prior that does not hold para_Pose[WINDOW_SIZE-1] marginalises nothing and hands the
+ * incoming prior back unchanged (estimator.cpp:1379-1380); without any prior out->valid = 0. */
 int vilo_marginalize(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
                      int mode, vilo_prior *out);
 
+/* GPU time (HIP events on ctx's stream) of the kernels of the last vilo_marginalize: linearisation + marginalisation. */
+double vilo_last_marginalize_ms(const vilo_ctx *ctx);
+
 /* ---- measurement / test hooks (no counterpart in the reference) -------------------------------------- */
+/* Windows of the last vilo_marginalize whose Amm was not certified positive definite beyond eps = 1e-8 and therefore went
+ * through the eigen-thresholded pseudo-inverse of the full Amm (marginalization_factor.cpp:281-286) instead of block
+ * elimination. The environment variable VILO_MARG_GENERAL=1 forces every window down that path. */
+int vilo_debug_marg_general_count(const vilo_ctx *ctx);
 /* Per-kernel GPU time of the solve pipeline, HIP events on ctx's stream. kinds: see vilo_kernel_name(). */
 void vilo_set_profiling(vilo_ctx *ctx, int on);
 int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n);

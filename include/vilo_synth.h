@@ -52,6 +52,31 @@ typedef struct {
 
 int vilo_synth_window(const vilo_config *cfg, const vilo_synth_params *p, vilo_synth_out *out);
 
+/* ---- a continuous sensor stream of one robot (input side of Estimator::processMeasurements, estimator.cpp:400-521) ----
+ * Same trajectory, gait, sensor noise and extrinsics as vilo_synth_window; images at frame_rate_hz looking at a static
+ * landmark cloud laid out along the path, with a feature-tracker stand-in (tracks persist while the point stays in both
+ * fields of view, never re-use an id, at most max_features per image, optical-flow velocity by finite differences). */
+typedef struct {
+  uint64_t seed;
+  double imu_rate_hz, frame_rate_hz, pixel_noise;
+  double t0;               /* trajectory time of the first image: different robots of a fleet use different phases */
+  int32_t cloud_per_10m;   /* landmarks per 10 m slab of the corridor */
+  int32_t max_features;    /* MAX_CNT of the tracker (yaml max_cnt) */
+  double drop_prob;        /* per image probability of losing a track */
+  double stereo_prob;      /* probability that a visible right-camera match is reported */
+} vilo_synth_stream_params;
+typedef struct vilo_synth_stream vilo_synth_stream;
+void vilo_synth_stream_default_params(vilo_synth_stream_params *p);
+vilo_synth_stream *vilo_synth_stream_create(const vilo_config *cfg, const vilo_synth_stream_params *p);
+void vilo_synth_stream_destroy(vilo_synth_stream *s);
+/* tic [2][3], ric [2][9] row-major, td */
+void vilo_synth_stream_extrinsics(const vilo_synth_stream *s, double *tic, double *ric, double *td);
+/* Next image: the samples between the previous image and this one (dt as estimator.cpp:456-462 computes it; the first
+ * call returns the single sample at t0), the tracked features (obs rows in vilo_window_desc::obs order) and the true
+ * state at the image time: truth[20] = p(3) q(xyzw) v(3) ba(3) bg(3) rho(4). Returns 0, or -1 when a buffer is too small. */
+int vilo_synth_stream_next(vilo_synth_stream *s, vilo_sample *samples, int max_samples, int *n_samples, int *ids, double *obs11,
+                           uint8_t *stereo, int max_features, int *n_features, double *header, double *truth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,7 +194,12 @@ double eval_block(const Problem &P, RBlock &b, bool want_jac, bool ref_sqrt_info
   const double *par[ORC_MAX_PRIOR_BLOCKS];
   const int np = (int)b.params.size();
   for (int k = 0; k < np; ++k) par[k] = P.params[b.params[k]].ptr;
-  b.r.assign(b.nres, 0.0);
+  // A cost-only evaluation (the candidate point of a trust-region step) must not touch the residuals of the linearisation
+  // point: Ceres keeps residuals_ at x and evaluates the candidate with residuals == NULL (trust_region_minimizer.cc,
+  // ComputeCandidatePointAndEvaluateCost), and model_cost_change of the step after a REJECTED candidate is formed from them.
+  std::vector<double> r_local;
+  std::vector<double> &r_out = want_jac ? b.r : r_local;
+  r_out.assign(b.nres, 0.0);
   std::vector<std::vector<double>> Jg(np);
   double *jp[ORC_MAX_PRIOR_BLOCKS];
   for (int k = 0; k < np; ++k) {
@@ -208,15 +213,15 @@ double eval_block(const Problem &P, RBlock &b, bool want_jac, bool ref_sqrt_info
   double **jac = want_jac ? jp : nullptr;
   (void)ref_sqrt_info;
   switch (b.kind) {
-    case 0: orc_eval_prior(P.w->prior, par, b.r.data(), jac); break;
-    case 1: orc_eval_imu_leg(P.cfg, &P.w->preint[b.aux], par, b.r.data(), jac); break;
-    case 2: orc_eval_imu(P.cfg, &P.w->preint_imu[b.aux], par, b.r.data(), jac); break;
-    case 3: orc_eval_proj2f1c(P.cfg, b.obs12, par, b.r.data(), jac); break;
-    case 4: orc_eval_proj2f2c(P.cfg, b.obs12, par, b.r.data(), jac); break;
-    default: orc_eval_proj1f2c(P.cfg, b.obs12, par, b.r.data(), jac); break;
+    case 0: orc_eval_prior(P.w->prior, par, r_out.data(), jac); break;
+    case 1: orc_eval_imu_leg(P.cfg, &P.w->preint[b.aux], par, r_out.data(), jac); break;
+    case 2: orc_eval_imu(P.cfg, &P.w->preint_imu[b.aux], par, r_out.data(), jac); break;
+    case 3: orc_eval_proj2f1c(P.cfg, b.obs12, par, r_out.data(), jac); break;
+    case 4: orc_eval_proj2f2c(P.cfg, b.obs12, par, r_out.data(), jac); break;
+    default: orc_eval_proj1f2c(P.cfg, b.obs12, par, r_out.data(), jac); break;
   }
   double sq = 0;
-  for (int i = 0; i < b.nres; ++i) sq += b.r[i] * b.r[i];
+  for (int i = 0; i < b.nres; ++i) sq += r_out[i] * r_out[i];
   double cost2 = sq;
   double alpha_sq_norm = 0.0, sqrt_rho1 = 1.0, residual_scaling = 1.0;
   if (b.loss) {
@@ -242,17 +247,17 @@ double eval_block(const Problem &P, RBlock &b, bool want_jac, bool ref_sqrt_info
       for (int c = 0; c < p.lsize; ++c) {
         double rTJ = 0;
         if (b.loss && alpha_sq_norm != 0.0)
-          for (int i = 0; i < b.nres; ++i) rTJ += b.r[i] * Jg[k][(size_t)i * p.gsize + c];
+          for (int i = 0; i < b.nres; ++i) rTJ += r_out[i] * Jg[k][(size_t)i * p.gsize + c];
         for (int i = 0; i < b.nres; ++i) {
           double v = Jg[k][(size_t)i * p.gsize + c];
-          if (b.loss) v = sqrt_rho1 * (v - alpha_sq_norm * b.r[i] * rTJ);
+          if (b.loss) v = sqrt_rho1 * (v - alpha_sq_norm * r_out[i] * rTJ);
           b.J[k][(size_t)i * p.lsize + c] = v;
         }
       }
     }
   }
   if (b.loss)
-    for (int i = 0; i < b.nres; ++i) b.r[i] *= residual_scaling;
+    for (int i = 0; i < b.nres; ++i) r_out[i] *= residual_scaling;
   return cost2;
 }
 
@@ -600,9 +605,11 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
     if (converged) {
       scatter_x(P, R, x);  // the candidate is NOT applied on convergence
       termination = 1;
+      --iter;  // Ceres returns before this iteration's summary is pushed: Summary::iterations holds the completed ones only
       break;
     }
     const double relative_decrease = (x_cost - candidate_cost) / model_cost_change;
+    if (getenv("ORC_TRACE")) fprintf(stderr, "[orc] it %d x_cost %.15g cand %.15g model %.15g rd %.15g step_norm %.15g radius %.15g\n", iter, x_cost, candidate_cost, model_cost_change, relative_decrease, dogleg_step_norm, radius);
     if (relative_decrease > o->min_relative_decrease) {
       // HandleSuccessfulStep
       x = candidate_x;

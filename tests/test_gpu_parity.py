@@ -319,6 +319,29 @@ def test_marginalize(ctx, cfg, ocfg, mode):
     assert np.abs(Ag - As).max() < 1e-6 * np.abs(As).max()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_marginalize_block_elimination_equals_the_eigen_pseudo_inverse_path(ctx, cfg, ocfg, mode, monkeypatch):
+    """k_marginalize_lds eliminates landmarks, then the dense frame-0 dims by Cholesky, after certifying lambda_min(Amm) > eps;
+    k_marginalize (the fallback for rank-deficient Amm) forms the eps-thresholded eigen pseudo-inverse of the full Amm as
+    marginalization_factor.cpp:281-286 does. On a well-conditioned window both give the same prior information."""
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w = _fresh(cfg, ocfg, n_landmarks=60, seed=23)
+    pf, pg = PriorData(), PriorData()
+    ctx.marginalize(w, mode, pf)
+    assert api.lib().vilo_debug_marg_general_count(ctx.h) == 0
+    monkeypatch.setenv("VILO_MARG_GENERAL", "1")
+    ctx.marginalize(w, mode, pg)
+    assert api.lib().vilo_debug_marg_general_count(ctx.h) == 1
+    assert pf.blocks() == pg.blocks() and pf.n == pg.n
+    Jf, Jg = pf.J0_matrix(), pg.J0_matrix()
+    Af, Ag = Jf.T @ Jf, Jg.T @ Jg
+    assert np.abs(Af - Ag).max() < 1e-6 * np.abs(Ag).max()
+    bf, bg = Jf.T @ pf.r0[:pf.n], Jg.T @ pg.r0[:pg.n]
+    assert np.abs(bf - bg).max() < 1e-6 * np.abs(bg).max()
+    np.testing.assert_allclose(pf.r0[:pf.n] @ pf.r0[:pf.n], pg.r0[:pg.n] @ pg.r0[:pg.n], rtol=1e-6)
+
+
 def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
     """Prior produced by GPU marginalisation of one window drives the solve of the next (GPU vs oracle)."""
     from cerberus_amd import api

@@ -22,4 +22,7 @@ for mode in (0, 1):
         t0 = time.perf_counter()
         rc = api.lib().vilo_marginalize(ctx.h, W, descs, states, mode, priors)
         dt = time.perf_counter() - t0
-    print("mode %d: rc %d, %d windows in %.1f ms = %.3f ms per window (n = %d)" % (mode, rc, W, 1e3 * dt, 1e3 * dt / W, priors[0].n))
+    L = api.lib()
+    L.vilo_last_marginalize_ms.restype = C.c_double
+    print("mode %d: rc %d, %d windows in %.1f ms = %.3f ms per window (n = %d); kernels %.2f ms, %d windows on the general eigen path"
+          % (mode, rc, W, 1e3 * dt, 1e3 * dt / W, priors[0].n, L.vilo_last_marginalize_ms(ctx.h), L.vilo_debug_marg_general_count(ctx.h)))
