@@ -636,12 +636,8 @@ __device__ quat quat_from_R_dev(const m3 &m) {
   return q;
 }
 
-__global__ void k_gauge_fix(int W, int F, const double *before_pose0 /*[W][7]*/, double *pose /*[W][F][7]*/, double *sb /*[W][F][9]*/,
-                            double *ex /*[W][2][7]*/) {
-  const int w = blockIdx.x, t = threadIdx.x;
-  if (w >= W) return;
-  const double *bp = before_pose0 + 7 * w;
-  double *pw = pose + (size_t)w * F * 7, *sw = sb + (size_t)w * F * 9;
+__device__ void k_gauge_fix_body(int F, const double *bp /*[7]*/, double *pw /*[F][7]*/, double *sw /*[F][9]*/, double *exw /*[2][7]*/) {
+  const int t = threadIdx.x;
   const m3 Rs0 = qR(ldq_pose(bp));
   const m3 R00 = qR(ldq_pose(pw));
   const v3 o0 = R2ypr_deg(Rs0), o00 = R2ypr_deg(R00);
@@ -664,14 +660,35 @@ __global__ void k_gauge_fix(int W, int F, const double *before_pose0 /*[W][7]*/,
   } else {
     __syncthreads();
     if (t < F + 2) {
-      double *pp = ex + (size_t)w * 14 + 7 * (t - F);
+      double *pp = exw + 7 * (t - F);
       const quat q = quat_from_R_dev(qR(qnormalized(ldq_pose(pp))));
       pp[3] = q.x; pp[4] = q.y; pp[5] = q.z; pp[6] = q.w;
     }
   }
 }
 
+__global__ void k_gauge_fix(int W, int F, const double *before_pose0 /*[W][7]*/, double *pose /*[W][F][7]*/, double *sb /*[W][F][9]*/,
+                            double *ex /*[W][2][7]*/) {
+  const int w = blockIdx.x;
+  if (w >= W) return;
+  k_gauge_fix_body(F, before_pose0 + 7 * w, pose + (size_t)w * F * 7, sb + (size_t)w * F * 9, ex + (size_t)w * 14);
+}
+
+// the same on the state block of a device-resident batch (pose [F][7] at XO_POSE, speed/bias [F][9] at XO_SB, extrinsics at XO_EX);
+// Rs[0] / Ps[0] of before the solve come from the batch's uploaded initial states
+__global__ void k_gauge_fix_x(BatchDev b) {
+  const int w = blockIdx.x;
+  double *x = b.x + (size_t)w * XSTRIDE;
+  k_gauge_fix_body(b.win[w].n_frames, b.x0 + (size_t)w * XSTRIDE + XO_POSE, x + XO_POSE, x + XO_SB, x + XO_EX);
+}
+
 }  // namespace
+
+int vilo_gauge_fix_batch(vilo_ctx *ctx, BatchDev &bd) {
+  hipLaunchKernelGGL(k_gauge_fix_x, dim3(bd.W), dim3(64), 0, ctx->stream, bd);
+  VILO_HIP(hipGetLastError());
+  return VILO_OK;
+}
 
 extern "C" double vilo_last_marginalize_ms(const vilo_ctx *ctx) { return ctx ? ctx->last_marg_ms : 0.0; }
 extern "C" int vilo_debug_marg_general_count(const vilo_ctx *ctx) { return ctx ? ctx->marg_general_count : 0; }
@@ -711,25 +728,26 @@ struct vilo_batch;
 BatchDev *vilo_batch_dev(vilo_batch *bt);
 const int *vilo_batch_perm(vilo_batch *bt, int win, int *L);
 
-extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *state, int mode,
-                                vilo_prior *out) {
-  if (!ctx || W <= 0 || !in || !state || !out || (mode != 0 && mode != 1)) return VILO_ERR_BAD_ARG;
-  VILO_HIP(hipSetDevice(ctx->device));
-  vilo_batch *bt = nullptr;
-  int rc = vilo_batch_create(ctx, W, in, state, &bt);
-  if (rc != VILO_OK) return rc;
+// Marginalisation of every window of an existing batch at its current device state (b.x, b.lam). `state` holds the same
+// values on the host (they become keep_block_data of the new prior); modes[w]: 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW, < 0 skip
+// (out[w] untouched). The batch is left alive.
+static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_window_desc *in, const vilo_window_state *state, const int *modes,
+                             vilo_prior *out) {
+  int rc = VILO_OK;
   BatchDev &bd = *vilo_batch_dev(bt);
   std::vector<MargWin> mws(W);
   std::vector<std::vector<int>> kept_ids(W), kept_cd(W), kept_gs(W), kept_soff(W);
   int max_l0 = 1;
   std::vector<std::vector<int>> drops(W);
-  std::vector<char> keep_prior(W, 0);
+  std::vector<char> keep_prior(W, 0), skip(W, 0);
   size_t scratch_total = 0;
   for (int w = 0; w < W; ++w) {
     const vilo_window_desc &d = in[w];
     MargWin &M = mws[w];
     memset(&M, 0, sizeof(M));
     for (int i = 0; i < CD_N; ++i) M.cdmap[i] = -1;
+    const int mode = modes[w];
+    if (mode < 0) { M.m = 0; M.n = 0; M.mode = 0; skip[w] = 1; continue; }
     M.mode = mode;
     const int F = d.n_frames, WS = F - 1;
     const bool has_prior = d.prior && d.prior->valid && d.prior->n > 0;
@@ -788,7 +806,7 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
       for (int c = 0; c < ls; ++c) M.cdmap[cd + c] = pos + c;
       pos += ls;
     }
-    if (mode == 0 && pos != (d.use_leg ? 19 : 15) && M.n_drop_lm > 0) { vilo_batch_destroy(ctx, bt); ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
+    if (mode == 0 && pos != (d.use_leg ? 19 : 15) && M.n_drop_lm > 0) { ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
     pos += M.n_drop_lm;
     M.m = pos;
     std::vector<int> kept;
@@ -802,15 +820,15 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
       pos += ls;
     }
     M.n = pos - M.m;
-    if (M.n > VILO_MAX_PRIOR_DIM || (int)kept.size() > VILO_MAX_PRIOR_BLOCKS || M.m > 1200) { vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    if (M.n > VILO_MAX_PRIOR_DIM || (int)kept.size() > VILO_MAX_PRIOR_BLOCKS || M.m > 1200) { return VILO_ERR_UNSUPPORTED; }
   }
   std::vector<int> drop_flat((size_t)W * max_l0, 0);
   for (int w = 0; w < W; ++w)
     for (size_t i = 0; i < drops[w].size(); ++i) drop_flat[(size_t)w * max_l0 + i] = drops[w][i];
   DevBuf d_mw, d_drop, d_scr, d_J0, d_r0, d_status, d_general, d_clk;
   const bool want_clk = getenv("VILO_MARG_CLOCKS") != nullptr;
-  if (want_clk && d_clk.alloc(sizeof(long long) * 8 * W) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
-  auto fail = [&](int code) { vilo_batch_destroy(ctx, bt); return code; };
+  if (want_clk && d_clk.alloc(sizeof(long long) * 8 * W) != hipSuccess) { return VILO_ERR_HIP; }
+  auto fail = [&](int code) { return code; };
   if (d_mw.alloc(sizeof(MargWin) * W) != hipSuccess || d_drop.alloc(sizeof(int) * drop_flat.size()) != hipSuccess ||
       d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
       d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int)) != hipSuccess ||
@@ -877,6 +895,8 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
     return fail(VILO_ERR_HIP);
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
+    if (skip[w]) continue;
+    const int mode = modes[w];
     vilo_prior &p = out[w];
     if (keep_prior[w]) {
       const vilo_prior &q = *in[w].prior;
@@ -913,7 +933,42 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
       p.r0[i] = r0[(size_t)w * VILO_MAX_PRIOR_DIM + i];
     }
   }
-  vilo_batch_destroy(ctx, bt);
   if (status) { ctx->err = "non-finite marginalisation result"; return VILO_ERR_NUMERIC; }
   return VILO_OK;
+}
+
+extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *state, int mode,
+                                vilo_prior *out) {
+  if (!ctx || W <= 0 || !in || !state || !out || (mode != 0 && mode != 1)) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_batch *bt = nullptr;
+  int rc = vilo_batch_create(ctx, W, in, state, &bt);
+  if (rc != VILO_OK) return rc;
+  std::vector<int> modes(W, mode);
+  rc = marginalize_batch(ctx, bt, W, in, state, modes.data(), out);
+  vilo_batch_destroy(ctx, bt);
+  return rc;
+}
+
+// Estimator::optimization() (estimator.cpp:1054-1458) as one call on one device-resident batch: ceres::Solve, double2vector's
+// gauge fix, then the marginalisation linearised at that result.
+extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
+                                     const int *marginalization_flag, vilo_prior *next_prior, vilo_solve_summary *summaries) {
+  if (!ctx || W <= 0 || !in || !inout || !opts) return VILO_ERR_BAD_ARG;
+  if (marginalization_flag && !next_prior) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_batch *bt = nullptr;
+  int rc = vilo_batch_create(ctx, W, in, inout, &bt);
+  if (rc != VILO_OK) return rc;
+  rc = vilo_batch_solve(ctx, bt, opts);
+  if (rc == VILO_OK) rc = vilo_gauge_fix_batch(ctx, *vilo_batch_dev(bt));
+  if (rc == VILO_OK) rc = vilo_batch_download(ctx, bt, inout, summaries);
+  if (rc == VILO_OK && marginalization_flag) {
+    // the reference only marginalises full windows (estimator.cpp:1243-1244)
+    std::vector<int> modes(W);
+    for (int w = 0; w < W; ++w) modes[w] = (in[w].n_frames == VILO_MAX_FRAMES) ? marginalization_flag[w] : -1;
+    rc = marginalize_batch(ctx, bt, W, in, inout, modes.data(), next_prior);
+  }
+  vilo_batch_destroy(ctx, bt);
+  return rc;
 }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <memory>
 
 #include "solver_types.hpp"
 
@@ -40,6 +41,44 @@ int dev_upload(vilo_ctx *ctx, vilo_batch *bt, T **p, const std::vector<T> &h) {
   return VILO_OK;
 }
 #define TRYB(x) do { int rc_ = (x); if (rc_ != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc_; } } while (0)
+
+
+// MarginalizationFactor (marginalization_factor.cpp:335-395) in normal-equation form, per window: H = J0^T J0 (n x n, ld n),
+// b0 = J0^T r0, c0 = r0^T r0, and H scattered into the solver's pre-assembled camera image (PD_* layout).
+__global__ void __launch_bounds__(256) k_prior_pack(int W, const WinMeta *win, const double *J0s /*[W][96*96], n x n packed*/,
+                                                    const double *r0s /*[W][96]*/, const int *pmap /*[W][96]*/, double *H /*[W][96*96]*/,
+                                                    double *b0 /*[W][96]*/, double *c0 /*[W]*/, double *pdense /*[W][PD_N], zeroed*/) {
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int n = win[w].prior_n;
+  if (n <= 0) return;
+  const double *J = J0s + (size_t)w * 96 * 96, *r = r0s + (size_t)w * 96;
+  const int *pm = pmap + (size_t)w * 96;
+  double *Hw = H + (size_t)w * 96 * 96, *pd = pdense + (size_t)w * PD_N;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    if (j > i) continue;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += J[(size_t)k * n + i] * J[(size_t)k * n + j];
+    Hw[(size_t)i * n + j] = s;
+    Hw[(size_t)j * n + i] = s;
+    for (int rep = 0; rep < (i == j ? 1 : 2); ++rep) {
+      const int ci = rep ? pm[j] : pm[i], cq = rep ? pm[i] : pm[j];
+      if (ci < CD_B0 && cq < CD_B0) pd[PD_C + ci * PD_CLD + cq] = s;
+      else if (ci >= CD_B0 && cq >= CD_B0) pd[PD_AD + ((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13] = s;
+      else if (ci >= CD_B0 && cq < CD_B0) pd[PD_BP + ((ci - CD_B0) % 13) * 80 + cq] = s;
+    }
+  }
+  for (int i = tid; i < n; i += 256) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += J[(size_t)k * n + i] * r[k];
+    b0[(size_t)w * 96 + i] = s;
+  }
+  if (tid == 0) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += r[k] * r[k];
+    c0[w] = s;
+  }
+}
 
 // camera dim of the first local dim of a prior block id; -1 if unsupported
 int prior_block_cd(int id, int *state_off) {
@@ -86,16 +125,15 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
   std::vector<double> obs, x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<unsigned char> flags;
-  std::vector<vilo_preint> pre(in[0].use_leg ? (size_t)W * 10 : 1);
-  std::vector<vilo_preint_imu> pre_imu(in[0].use_leg ? 1 : (size_t)W * 10);
-  std::vector<double> pH((size_t)W * 96 * 96, 0.0), pb0((size_t)W * 96, 0.0), pc0(W, 0.0), px0((size_t)W * 280, 0.0);
-  std::vector<double> pdense((size_t)W * PD_N, 0.0);
+  std::vector<double> px0((size_t)W * 280, 0.0);
+  // J0 / r0 of the priors, packed n x n per window, staged for k_prior_pack (uninitialised storage: only n x n of a slot is read)
+  std::unique_ptr<double[]> pJ(new double[(size_t)W * 96 * 96]), pr0(new double[(size_t)W * 96]);
+  bool any_prior = false;
   std::vector<unsigned char> iskip((size_t)W * 10, 0);
   std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
   int lm_total = 0, gram_total = 0;
   bt->lm_off_host.resize(W);
   bt->L_host.resize(W);
-  memset(pre.data(), 0, pre.size() * sizeof(vilo_preint));
 
   for (int w = 0; w < W; ++w) {
     const vilo_window_desc &d = in[w];
@@ -193,8 +231,6 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     wm.n_waves = (int)waves.size() - wm.wave_off;
     wm.n_gram = gram_total - wm.gram_off;
     lm_total += L;
-    if (d.use_leg) { for (int k = 0; k + 1 < F; ++k) pre[(size_t)w * 10 + k] = d.preint[k]; }
-    else { for (int k = 0; k + 1 < F; ++k) pre_imu[(size_t)w * 10 + k] = d.preint_imu[k]; }
     for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !((d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt) > 10.0)) ? 0 : 1;
     // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
     if (d.prior && d.prior->valid && d.prior->n > 0) {
@@ -220,34 +256,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
       }
       wm.pad = bframe;
       const double t_p0 = now();
-      double *H = &pH[(size_t)w * 96 * 96], *b0 = &pb0[(size_t)w * 96];
-      // H = J0^T J0 and b0 = J0^T r0 as sums of row outer products: unit-stride inner loops (this is the bulk of the
-      // host-side packing time of a batch)
-      for (int r = 0; r < n; ++r) {
-        const double *jr = p.J0 + (size_t)r * n;
-        const double rr = p.r0[r];
-        for (int i = 0; i < n; ++i) {
-          const double ji = jr[i];
-          double *hi = H + (size_t)i * n;
-          for (int j = 0; j <= i; ++j) hi[j] += ji * jr[j];
-          b0[i] += ji * rr;
-        }
-      }
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < i; ++j) H[(size_t)j * n + i] = H[(size_t)i * n + j];
-      double c0 = 0.0;
-      for (int r = 0; r < n; ++r) c0 += p.r0[r] * p.r0[r];
-      pc0[w] = c0;
-      double *pd = &pdense[(size_t)w * PD_N];
-      const int *pm = &pmap[(size_t)w * 96];
-      for (int i = 0; i < n; ++i)
-        for (int q = 0; q < n; ++q) {
-          const int ci = pm[i], cq = pm[q];
-          const double v = H[(size_t)i * n + q];
-          if (ci < CD_B0 && cq < CD_B0) pd[PD_C + ci * PD_CLD + cq] += v;
-          else if (ci >= CD_B0 && cq >= CD_B0) pd[PD_AD + ((ci - CD_B0) / 13) * 169 + ((ci - CD_B0) % 13) * 13 + (cq - CD_B0) % 13] += v;
-          else if (ci >= CD_B0 && cq < CD_B0) pd[PD_BP + ((ci - CD_B0) % 13) * 80 + cq] += v;
-        }
+      memcpy(pJ.get() + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
+      memcpy(pr0.get() + (size_t)w * 96, p.r0, sizeof(double) * n);
+      any_prior = true;
       t_prior += now() - t_p0;
     }
   }
@@ -283,13 +294,17 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
   TRYB(dev_upload(ctx, bt, &D.imu_skip, iskip));
-  TRYB(dev_upload(ctx, bt, &D.prior_H, pH));
-  TRYB(dev_upload(ctx, bt, &D.prior_dense, pdense));
+  TRYB(dev_alloc(ctx, bt, &D.prior_H, (size_t)W * 96 * 96));
+  TRYB(dev_alloc(ctx, bt, &D.prior_dense, (size_t)W * PD_N));
   TRYB(dev_alloc(ctx, bt, &D.prior_hd, (size_t)W * 96));
-  TRYB(dev_upload(ctx, bt, &D.prior_b0, pb0));
-  TRYB(dev_upload(ctx, bt, &D.prior_c0, pc0));
+  TRYB(dev_alloc(ctx, bt, &D.prior_b0, (size_t)W * 96));
+  TRYB(dev_alloc(ctx, bt, &D.prior_c0, (size_t)W));
   TRYB(dev_upload(ctx, bt, &D.prior_x0, px0));
   TRYB(dev_upload(ctx, bt, &D.prior_map, pmap));
+  if (hipMemsetAsync(D.prior_dense, 0, sizeof(double) * (size_t)W * PD_N, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(D.prior_b0, 0, sizeof(double) * (size_t)W * 96, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(D.prior_c0, 0, sizeof(double) * (size_t)W, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(D.prior_H, 0, sizeof(double) * (size_t)W * 96 * 96, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   TRYB(dev_upload(ctx, bt, &D.prior_bsize, pbs));
   TRYB(dev_upload(ctx, bt, &D.prior_bidx, pbi));
   TRYB(dev_upload(ctx, bt, &D.prior_bxoff, pbx));
@@ -305,16 +320,35 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
     vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP;
   }
+  if (any_prior) {
+    double *d_J = nullptr, *d_r = nullptr;
+    if (hipMalloc((void **)&d_J, sizeof(double) * (size_t)W * 96 * 96) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    bt->allocs.push_back(d_J);
+    if (hipMalloc((void **)&d_r, sizeof(double) * (size_t)W * 96) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    bt->allocs.push_back(d_r);
+    if (hipMemcpyAsync(d_J, pJ.get(), sizeof(double) * (size_t)W * 96 * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_r, pr0.get(), sizeof(double) * (size_t)W * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
+    if (hipGetLastError() != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+  }
   const double t_uploaded = now();
   // hoist sqrt_info = chol(cov^-1)^T out of the iteration loop (the reference recomputes it on every
   // IMULegFactor::Evaluate, imu_leg_factor.cpp:197-198)
   {
     const bool leg = in[0].use_leg != 0;
     void *d_pre = nullptr;
-    const size_t bytes = (leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu)) * (size_t)W * 10;
+    const size_t rec = leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu);
+    const size_t bytes = rec * (size_t)W * 10;
     if (hipMalloc(&d_pre, bytes) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
     int rc = VILO_OK;
-    if (hipMemcpy(d_pre, leg ? (const void *)pre.data() : (const void *)pre_imu.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = VILO_ERR_HIP;
+    // records go from the caller's arrays straight to the device (a staged host copy of W x 156 KB costs more than the W copies)
+    bool partial = false;
+    for (int w = 0; w < W; ++w) partial = partial || in[w].n_frames < VILO_MAX_FRAMES;
+    if (partial && hipMemsetAsync(d_pre, 0, bytes, ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    for (int w = 0; w < W && rc == VILO_OK; ++w) {
+      const void *src = leg ? (const void *)in[w].preint : (const void *)in[w].preint_imu;
+      if (hipMemcpyAsync((char *)d_pre + rec * (size_t)w * 10, src, rec * (size_t)(in[w].n_frames - 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    }
     if (rc == VILO_OK) rc = leg ? vilo_launch_prepare_preint(ctx, W * 10, (const vilo_preint *)d_pre, D.prep, D.status)
                                 : vilo_launch_prepare_preint_imu(ctx, W * 10, (const vilo_preint_imu *)d_pre, D.prep, D.status);
     if (rc == VILO_OK && !leg) rc = vilo_launch_embed_sqrt15(ctx, D);

@@ -3,6 +3,7 @@
 #include "vilo_sliding_window.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -284,8 +285,15 @@ int SlidingWindow::dump(const vilo_window_state &before) const {
   return vilo_window_write(path, &cfg_, &desc_, &before, &state_, ref_summary, marginalization_flag);
 }
 
+double now_ms_public();
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n) {
   if (n <= 0) return VILO_OK;
+  const bool timing = getenv("VILO_HOST_TIMING") != nullptr;
+  const double t0 = now_ms();
   const int use_leg = ws[0]->opt_.use_leg;
   for (int w = 0; w < n; ++w)
     if (ws[w]->opt_.use_leg != use_leg || ws[w]->pending_ == 0 || ws[w]->frame_count != WS) return VILO_ERR_BAD_ARG;
@@ -321,10 +329,11 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
       for (auto &wj : which) ws[wj.first]->dirty_[wj.second] = false;
     }
   }
+  const double t1 = now_ms();
   // 2. vector2double + the problem description
   std::vector<vilo_window_desc> descs(n);
   std::vector<vilo_window_state> states(n), befores(n);
-  std::vector<std::vector<double>> keep(n);   // pre-solve copies: Rs[0]/Ps[0] for the gauge fix, everything for the dump
+  std::vector<std::vector<double>> keep(n);   // pre-solve copies (the dump's `before`)
   std::vector<vilo_solve_summary> sums(n);
   for (int w = 0; w < n; ++w) {
     SlidingWindow &s = *ws[w];
@@ -346,47 +355,34 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
     befores[w].td = b; b += 1;
     befores[w].inv_depth = b;
   }
-  // 3. ceres::Solve (estimator.cpp:1236) and double2vector (:1240)
-  int rc = vilo_solve_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, sums.data());
+  // 3. Estimator::optimization() from ceres::Solve on (estimator.cpp:1236-1455) in one device call: solve, double2vector's gauge
+  //    fix, marginalisation at the result — one packing of the batch, no host round trip between the halves
+  const double t2 = now_ms();
+  std::vector<int> flags(n);
+  std::vector<vilo_prior> next(n);
+  for (int w = 0; w < n; ++w) {
+    SlidingWindow &s = *ws[w];
+    flags[w] = s.marginalization_flag;
+    PriorStore &nx = s.prior_[1 - s.cur_prior_];
+    nx.bind();
+    next[w] = nx.p;
+  }
+  int rc = vilo_optimize_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), next.data(), sums.data());
   if (rc != VILO_OK) return rc;
-  rc = vilo_gauge_fix(ctx, n, befores.data(), states.data(), NF);
-  if (rc != VILO_OK) return rc;
+  const double t3 = now_ms();
   for (int w = 0; w < n; ++w) {
     SlidingWindow &s = *ws[w];
     s.last_summary = sums[w];
-    s.double2vector();
-    // marginalisation linearises at vector2double() of the unpacked state (estimator.cpp:1252 / :1384)
-    s.vector2double();
-    s.state_.inv_depth = s.para_Feature.data();
-    states[w] = s.state_;
     if (!s.opt_.dump_dir.empty() && s.dump(befores[w]) != 0) return VILO_ERR_BAD_ARG;
+    s.double2vector();
+    s.prior_[1 - s.cur_prior_].p = next[w];
+    s.prior_[1 - s.cur_prior_].bind();
+    s.cur_prior_ = 1 - s.cur_prior_;
     ++s.n_optimizations;
   }
-  // 4. marginalisation (estimator.cpp:1247-1455), one device call per flag value present in the fleet
-  for (int mode = 0; mode < 2; ++mode) {
-    std::vector<int> idx;
-    for (int w = 0; w < n; ++w)
-      if (ws[w]->marginalization_flag == mode) idx.push_back(w);
-    if (idx.empty()) continue;
-    std::vector<vilo_window_desc> d(idx.size());
-    std::vector<vilo_window_state> st(idx.size());
-    std::vector<vilo_prior> out(idx.size());
-    for (size_t k = 0; k < idx.size(); ++k) {
-      SlidingWindow &s = *ws[idx[k]];
-      d[k] = descs[idx[k]]; st[k] = states[idx[k]];
-      PriorStore &nx = s.prior_[1 - s.cur_prior_];
-      nx.bind();
-      out[k] = nx.p;
-    }
-    rc = vilo_marginalize(ctx, (int)idx.size(), d.data(), st.data(), mode, out.data());
-    if (rc != VILO_OK) return rc;
-    for (size_t k = 0; k < idx.size(); ++k) {
-      SlidingWindow &s = *ws[idx[k]];
-      s.prior_[1 - s.cur_prior_].p = out[k];
-      s.prior_[1 - s.cur_prior_].bind();
-      s.cur_prior_ = 1 - s.cur_prior_;
-    }
-  }
+  if (timing)
+    fprintf(stderr, "[optimizeBatch] n=%d preintegrate %.2f ms, vector2double+tables %.2f ms, vilo_optimize_windows %.2f ms, double2vector %.2f ms\n", n, t1 - t0,
+            t2 - t1, t3 - t2, now_ms() - t3);
   return VILO_OK;
 }
 
@@ -467,6 +463,8 @@ void SlidingWindow::slideWindowOld() {
   }
 }
 
+double now_ms_public() { return now_ms(); }
+
 }  // namespace vilo
 
 extern "C" {
@@ -500,13 +498,18 @@ int vilo_sw_process_image(void *h, double header, int n, const int *ids, const d
 int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int W, const double *headers, const int *off, const int *ids, const double *obs11,
                            const uint8_t *stereo) {
   std::vector<SlidingWindow *> due;
+  const double t0 = vilo::now_ms_public();
   for (int w = 0; w < W; ++w) {
     SlidingWindow *s = (SlidingWindow *)hs[w];
     if (s->beginImage(headers[w], off[w + 1] - off[w], ids + off[w], obs11 + 11 * (size_t)off[w], stereo + off[w])) due.push_back(s);
   }
+  const double t1 = vilo::now_ms_public();
   const int rc = SlidingWindow::optimizeBatch(ctx, due.data(), (int)due.size());
   if (rc != VILO_OK) return rc;
+  const double t2 = vilo::now_ms_public();
   for (int w = 0; w < W; ++w) ((SlidingWindow *)hs[w])->endImage();
+  if (getenv("VILO_HOST_TIMING"))
+    fprintf(stderr, "[vilo_sw_process_images] W=%d beginImage %.2f ms, optimizeBatch %.2f ms, endImage %.2f ms\n", W, t1 - t0, t2 - t1, vilo::now_ms_public() - t2);
   return VILO_OK;
 }
 void vilo_sw_get_state(void *h, int *flags, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, double *Rho, double *tic, double *ric,

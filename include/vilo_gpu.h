@@ -238,6 +238,15 @@ int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before
 int vilo_marginalize(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
                      int mode, vilo_prior *out);
 
+/* ---- Estimator::optimization() as ONE call (estimator.cpp:1054-1458): solve, double2vector gauge fix, marginalisation
+ * linearised at that result, all on one device-resident batch (one packing, no host round trip between the halves).
+ * inout: states, replaced by the gauge-fixed result. marginalization_flag: [n_windows] 0 MARGIN_OLD / 1 MARGIN_SECOND_NEW
+ * (estimator.h:64-68), or NULL to skip the marginalisation; windows with n_frames < WINDOW_SIZE + 1 are not marginalised
+ * (estimator.cpp:1243) and their next_prior entry is left untouched. next_prior: [n_windows], buffers as for vilo_marginalize. */
+int vilo_optimize_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                          const vilo_solve_opts *opts, const int *marginalization_flag, vilo_prior *next_prior,
+                          vilo_solve_summary *summaries);
+
 /* GPU time (HIP events on ctx's stream) of the kernels of the last vilo_marginalize: linearisation + marginalisation. */
 double vilo_last_marginalize_ms(const vilo_ctx *ctx);
 
