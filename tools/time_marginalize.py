@@ -4,7 +4,8 @@ import ctypes as C
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cerberus_amd import api, synth, _ctypes as T  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
