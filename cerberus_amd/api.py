@@ -98,6 +98,41 @@ class Batch:
             pass
 
 
+class PreintStreams:
+    """vilo_preint_streams: device-resident IMULegIntegrationBase objects updated by push_back as samples arrive."""
+
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, n
+        self.h = C.c_void_p()
+        ctx._check(lib().vilo_preint_streams_create(ctx.h, n, C.byref(self.h)))
+
+    def reset(self, ids, first, lin):
+        ids, first, lin = np.ascontiguousarray(ids, np.int32), _c(first), _c(lin)
+        self.ctx._check(lib().vilo_preint_streams_reset(self.ctx.h, self.h, len(ids), T.iptr(ids), C.cast(first.ctypes.data, C.POINTER(T.Sample)), _p(lin)))
+
+    def push(self, ids, samples, offsets):
+        ids, samples, offsets = np.ascontiguousarray(ids, np.int32), _c(samples), np.ascontiguousarray(offsets, np.int32)
+        self.ctx._check(lib().vilo_preint_streams_push(self.ctx.h, self.h, len(ids), T.iptr(ids), C.cast(samples.ctypes.data, C.POINTER(T.Sample)),
+                                                       T.iptr(offsets)))
+
+    def read(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        out = np.zeros((len(ids), T.PREINT_DOUBLES))
+        self.ctx._check(lib().vilo_preint_streams_read(self.ctx.h, self.h, len(ids), T.iptr(ids), C.cast(out.ctypes.data, C.POINTER(T.Preint))))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vilo_preint_streams_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, cfg, device=0):
         self.cfg = cfg

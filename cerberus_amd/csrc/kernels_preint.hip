@@ -56,21 +56,29 @@ struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
   double f[3], J[9], v[3], g[3], h[9];
 };
 
+// A device-resident IMULegIntegrationBase (imu_leg_integration_base.h:73-128): public state, the previous sample
+// (acc_0, gyr_0, phi_0, dphi_0, c_0) and the contact-type-2 force filter
+struct PreintStream {
+  vilo_preint rec;
+  vilo_sample last;
+  double ff_min[4], ff_max[4], ff_win[20], ff_var[4];
+  int ff_idx[4];
+  int n_pushed, pad;
+};
+
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
-                                                       const double *lin, vilo_preint *out) {
+// One IMULegIntegrationBase, batch form (STREAM = false: constructor + every push_back of the interval, state starts at the
+// identity) or streaming form (STREAM = true: the object lives in HBM between calls, this call push_back()s the new samples).
+// Both run the same arithmetic in the same order: pushing an interval in pieces gives bitwise the batch result.
+template <bool STREAM>
+__device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
+                                    PreintStream *st) {
   __shared__ double Fm[31 * 31], Vm[31 * 46], nd[46];
   __shared__ double Jm[31 * 32], Pm[31 * 32], Qm[31 * 32];
   __shared__ LegTerms lt[8];
-  __shared__ double ubuf[64];   // uniform scratch written by lane 0: R0 (9) R1 (9) dq (4) rq (4) misc
-  __shared__ int cflag[4];
-  const int f = blockIdx.x;
-  if (f >= n) return;
-  const vilo_config &cfg = *cfgp;
   const int lane = threadIdx.x;
-  const int s_begin = offsets[f], s_end = offsets[f + 1];
-  const double *ln = lin + 10 * f;
+  if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
   const v3 ba = ld3(ln), bg = ld3(ln + 3);
   double rho[4] = {ln[6], ln[7], ln[8], ln[9]};
   // state (uniform; kept redundantly in every lane's registers, updated identically)
@@ -84,14 +92,27 @@ __global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config 
   int ff_idx[4] = {0, 0, 0, 0};
   for (int j = 0; j < 4; ++j)
     for (int k = 0; k < 5; ++k) ff_win[j][k] = 0.0;
-  for (int e = lane; e < 31 * 32; e += 64) { Jm[e] = ((e / 32) == (e % 32)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  if (STREAM) {
+    const vilo_preint &r = st->rec;
+    dp = ld3(r.delta_p); dv = ld3(r.delta_v);
+    dq = mkq(r.delta_q[3], r.delta_q[0], r.delta_q[1], r.delta_q[2]);
+    for (int j = 0; j < 4; ++j) eps[j] = ld3(r.delta_eps + 3 * j);
+    sum_dt = r.sum_dt;
+    for (int j = 0; j < 4; ++j) {
+      ff_min[j] = st->ff_min[j]; ff_max[j] = st->ff_max[j]; ff_var[j] = st->ff_var[j]; ff_idx[j] = st->ff_idx[j];
+      for (int k = 0; k < 5; ++k) ff_win[j][k] = st->ff_win[5 * j + k];
+    }
+    for (int e = lane; e < 31 * 31; e += 64) { Jm[(e / 31) * 32 + (e % 31)] = r.jacobian[e]; Pm[(e / 31) * 32 + (e % 31)] = r.covariance[e]; }
+  } else {
+    for (int e = lane; e < 31 * 32; e += 64) { Jm[e] = ((e / 32) == (e % 32)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  }
   __syncthreads();
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
 
-  for (int si = s_begin + 1; si < s_end; ++si) {
-    const vilo_sample &s0 = samples[si - 1], &s1 = samples[si];
+  for (int si = STREAM ? s_begin : s_begin + 1; si < s_end; ++si) {
+    const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
     const double dt = s1.dt;
     const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
     // IMU midpoint update (:152-160)
@@ -253,18 +274,69 @@ __global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config 
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
     sum_dt += dt;
   }
-  vilo_preint &o = out[f];
+  vilo_preint &o = *outp;
   if (lane == 0) {
     o.sum_dt = sum_dt;
     st3(o.delta_p, dp); st3(o.delta_v, dv);
     o.delta_q[0] = dq.x; o.delta_q[1] = dq.y; o.delta_q[2] = dq.z; o.delta_q[3] = dq.w;
     for (int j = 0; j < 4; ++j) { st3(o.delta_eps + 3 * j, eps[j]); o.lin_rho[j] = rho[j]; }
     st3(o.lin_ba, ba); st3(o.lin_bg, bg);
+    if (STREAM && s_end > s_begin) {
+      st->last = samples[s_end - 1];
+      st->n_pushed += s_end - s_begin;
+      for (int j = 0; j < 4; ++j) {
+        st->ff_min[j] = ff_min[j]; st->ff_max[j] = ff_max[j]; st->ff_var[j] = ff_var[j]; st->ff_idx[j] = ff_idx[j];
+        for (int k = 0; k < 5; ++k) st->ff_win[5 * j + k] = ff_win[j][k];
+      }
+    }
   }
   for (int e = lane; e < 31 * 31; e += 64) {
     o.jacobian[e] = Jm[(e / 31) * 32 + (e % 31)];
     o.covariance[e] = Pm[(e / 31) * 32 + (e % 31)];
   }
+}
+
+__global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
+                                                       const double *lin, vilo_preint *out) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  preint_imu_leg_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 10 * f, out + f, nullptr);
+}
+
+// push_back() on device-resident objects: workgroup k appends samples[offsets[k] .. offsets[k+1]) to stream ids[k]
+__global__ void __launch_bounds__(64) k_preint_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
+                                                           PreintStream *streams) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  PreintStream *st = streams + ids[f];
+  preint_imu_leg_body<true>(*cfgp, samples, offsets[f], offsets[f + 1], nullptr, &st->rec, st);
+}
+
+// IMULegIntegrationBase{acc_0, gyr_0, phi_0, dphi_0, c_0, ba, bg, rho} (imu_leg_integration_base.cpp:7-42)
+__global__ void __launch_bounds__(64) k_preint_stream_reset(int n, const int *ids, const vilo_sample *first, const double *lin, PreintStream *streams) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  PreintStream &st = streams[ids[f]];
+  vilo_preint &r = st.rec;
+  for (int e = lane; e < 31 * 31; e += 64) { r.jacobian[e] = (e / 31 == e % 31) ? 1.0 : 0.0; r.covariance[e] = 0.0; }
+  if (lane == 0) {
+    r.sum_dt = 0.0;
+    for (int k = 0; k < 3; ++k) { r.delta_p[k] = 0.0; r.delta_v[k] = 0.0; r.delta_q[k] = 0.0; r.lin_ba[k] = lin[10 * f + k]; r.lin_bg[k] = lin[10 * f + 3 + k]; }
+    r.delta_q[3] = 1.0;
+    for (int k = 0; k < 12; ++k) r.delta_eps[k] = 0.0;
+    for (int k = 0; k < 4; ++k) { r.lin_rho[k] = lin[10 * f + 6 + k]; st.ff_min[k] = st.ff_max[k] = st.ff_var[k] = 0.0; st.ff_idx[k] = 0; }
+    for (int k = 0; k < 20; ++k) st.ff_win[k] = 0.0;
+    st.last = first[f];
+    st.n_pushed = 0;
+  }
+}
+
+__global__ void k_preint_stream_gather(int n, const int *ids, const PreintStream *streams, vilo_preint *out) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const double *src = (const double *)&streams[ids[f]].rec;
+  double *dst = (double *)(out + f);
+  for (int e = threadIdx.x; e < (int)(sizeof(vilo_preint) / sizeof(double)); e += blockDim.x) dst[e] = src[e];
 }
 
 __global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
@@ -381,4 +453,91 @@ extern "C" int vilo_preintegrate(vilo_ctx *ctx, int n, const vilo_sample *sample
 extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
                                      vilo_preint_imu *out) {
   return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu);
+}
+
+// ---- device-resident, incrementally updated preintegration (the reference's push_back as samples arrive, estimator.cpp:619-626) ----
+struct vilo_preint_streams {
+  int n, device;
+  PreintStream *d;
+};
+
+extern "C" int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **out) {
+  if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_preint_streams *s = new vilo_preint_streams();
+  s->n = n; s->d = nullptr; s->device = ctx->device;
+  if (hipMalloc((void **)&s->d, sizeof(PreintStream) * (size_t)n) != hipSuccess || hipMemset(s->d, 0, sizeof(PreintStream) * (size_t)n) != hipSuccess) {
+    if (s->d) (void)hipFree(s->d);
+    delete s;
+    ctx->err = "vilo_preint_streams_create: allocation failed";
+    return VILO_ERR_HIP;
+  }
+  *out = s;
+  return VILO_OK;
+}
+extern "C" void vilo_preint_streams_destroy(vilo_ctx *ctx, vilo_preint_streams *s) {
+  if (!s) return;
+  (void)ctx;   // may already be gone when a host object releases its pool late
+  (void)hipSetDevice(s->device);
+  if (s->d) (void)hipFree(s->d);
+  delete s;
+}
+static int check_ids(const vilo_preint_streams *s, int n, const int32_t *ids) {
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] < 0 || ids[i] >= s->n) return VILO_ERR_BAD_ARG;
+    for (int j = 0; j < i; ++j)
+      if (ids[j] == ids[i]) return VILO_ERR_BAD_ARG;   // two workgroups would update one object
+  }
+  return VILO_OK;
+}
+extern "C" int vilo_preint_streams_reset(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, const vilo_sample *first, const double *lin) {
+  if (!ctx || !s || n < 0 || (n && (!ids || !first || !lin))) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  if (check_ids(s, n, ids) != VILO_OK) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  DevBuf d_i, d_f, d_l;
+  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_f.alloc(sizeof(vilo_sample) * (size_t)n)); VILO_HIP(d_l.alloc(sizeof(double) * 10 * (size_t)n));
+  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_f.p, first, sizeof(vilo_sample) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * 10 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_preint_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->d);
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, const vilo_sample *samples,
+                                        const int32_t *offsets) {
+  if (!ctx || !s || n < 0 || (n && (!ids || !samples || !offsets))) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  if (check_ids(s, n, ids) != VILO_OK) return VILO_ERR_BAD_ARG;
+  for (int i = 0; i < n; ++i)
+    if (offsets[i + 1] < offsets[i]) return VILO_ERR_BAD_ARG;
+  const int ns = offsets[n] - offsets[0];
+  if (ns == 0) return VILO_OK;
+  VILO_HIP(hipSetDevice(ctx->device));
+  DevBuf d_i, d_s, d_o;
+  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_s.alloc(sizeof(vilo_sample) * (size_t)offsets[n])); VILO_HIP(d_o.alloc(sizeof(int) * (size_t)(n + 1)));
+  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice, ctx->stream));
+  VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
+                     d_i.as<int>(), s->d);
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+extern "C" int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, vilo_preint *out) {
+  if (!ctx || !s || n < 0 || (n && (!ids || !out))) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= s->n) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  DevBuf d_i, d_out;
+  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_out.alloc(sizeof(vilo_preint) * (size_t)n));
+  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_i.as<int>(), (const PreintStream *)s->d, d_out.as<vilo_preint>());
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(vilo_preint) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
 }

@@ -88,6 +88,20 @@ SlidingWindow::SlidingWindow(vilo_ctx *ctx, const vilo_config &cfg, const Slidin
   g[0] = 0; g[1] = 0; g[2] = cfg.g_norm;
 }
 
+SlidingWindow::~SlidingWindow() {
+  if (own_pool_ && pool_) vilo_preint_streams_destroy(ctx_, pool_);
+}
+
+void SlidingWindow::attachStreams(vilo_preint_streams *pool, int base_id) {
+  if (own_pool_ && pool_) vilo_preint_streams_destroy(ctx_, pool_);
+  pool_ = pool; own_pool_ = false;
+  for (int j = 0; j < NF; ++j) {
+    sid_[j] = base_id + j;
+    need_reset_[j] = !buf_[j].empty();
+    pushed_[j] = 0;
+  }
+}
+
 void SlidingWindow::clearState() {
   const m3 I = m3_eye();
   for (int i = 0; i < NF; ++i) {
@@ -97,6 +111,9 @@ void SlidingWindow::clearState() {
     Headers[i] = 0.0;
     buf_[i].clear();
     dirty_[i] = false;
+    if (!pool_) sid_[i] = i;
+    pushed_[i] = 0;
+    need_reset_[i] = false;
     std::memset(lin_[i], 0, sizeof lin_[i]);
   }
   for (int c = 0; c < 2; ++c) {
@@ -135,6 +152,7 @@ void SlidingWindow::startInterval(int j) {
   buf_[j].assign(1, last_sample);
   cp(lin_[j], Bas[j], 3); cp(lin_[j] + 3, Bgs[j], 3); cp(lin_[j] + 6, Rho[j], 4);
   dirty_[j] = true;
+  need_reset_[j] = true; pushed_[j] = 0;
 }
 
 void SlidingWindow::processIMULeg(const vilo_sample &s) {
@@ -238,6 +256,7 @@ bool SlidingWindow::beginImage(double header, int n, const int *ids, const doubl
         lin_[i][0] = lin_[i][1] = lin_[i][2] = 0.0;
         cp(lin_[i] + 3, Bgs[i], 3); cp(lin_[i] + 6, Rho[i], 4);
         dirty_[i] = true;
+        need_reset_[i] = true; pushed_[i] = 0;   // repropagate = constructor + every buffered push_back again
       }
       pending_ = 1;
       return true;
@@ -297,8 +316,55 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   const int use_leg = ws[0]->opt_.use_leg;
   for (int w = 0; w < n; ++w)
     if (ws[w]->opt_.use_leg != use_leg || ws[w]->pending_ == 0 || ws[w]->frame_count != WS) return VILO_ERR_BAD_ARG;
-  // 1. preintegration of the intervals whose samples or linearisation point changed: one device call for the whole fleet
-  {
+  // 1. preintegration of the intervals whose samples or linearisation point changed: one device call sequence for the whole fleet
+  bool streaming = use_leg && ws[0]->opt_.streaming_preintegration;
+  if (streaming) {
+    // robots without a pool get one of their own; a fleet shares one pool (then every robot is served by the same three calls)
+    for (int w = 0; w < n; ++w)
+      if (!ws[w]->pool_) {
+        int rc = vilo_preint_streams_create(ctx, NF, &ws[w]->pool_);
+        if (rc != VILO_OK) return rc;
+        ws[w]->own_pool_ = true;
+        for (int j = 0; j < NF; ++j) { ws[w]->sid_[j] = j; ws[w]->need_reset_[j] = !ws[w]->buf_[j].empty(); ws[w]->pushed_[j] = 0; }
+      }
+    for (int w0 = 0; w0 < n;) {
+      int w1 = w0 + 1;
+      while (w1 < n && ws[w1]->pool_ == ws[w0]->pool_) ++w1;
+      vilo_preint_streams *pool = ws[w0]->pool_;
+      std::vector<int32_t> rid, pid, gid, offsets(1, 0);
+      std::vector<vilo_sample> first, samples;
+      std::vector<double> lin;
+      std::vector<std::pair<int, int>> which;
+      for (int w = w0; w < w1; ++w) {
+        SlidingWindow &s = *ws[w];
+        for (int j = 1; j <= WS; ++j) {
+          if (s.buf_[j].empty()) continue;
+          if (s.need_reset_[j]) {
+            rid.push_back(s.sid_[j]); first.push_back(s.buf_[j][0]); lin.insert(lin.end(), s.lin_[j], s.lin_[j] + 10);
+            s.need_reset_[j] = false; s.pushed_[j] = 0;
+          }
+          const int have = (int)s.buf_[j].size() - 1;
+          if (s.pushed_[j] < have) {
+            pid.push_back(s.sid_[j]);
+            samples.insert(samples.end(), s.buf_[j].begin() + 1 + s.pushed_[j], s.buf_[j].end());
+            offsets.push_back((int32_t)samples.size());
+            s.pushed_[j] = have;
+          }
+          if (s.dirty_[j]) { gid.push_back(s.sid_[j]); which.push_back({w, j}); }
+        }
+      }
+      int rc = vilo_preint_streams_reset(ctx, pool, (int)rid.size(), rid.data(), first.data(), lin.data());
+      if (rc == VILO_OK) rc = vilo_preint_streams_push(ctx, pool, (int)pid.size(), pid.data(), samples.data(), offsets.data());
+      std::vector<vilo_preint> out(gid.size());
+      if (rc == VILO_OK) rc = vilo_preint_streams_read(ctx, pool, (int)gid.size(), gid.data(), out.data());
+      if (rc != VILO_OK) return rc;
+      for (size_t k = 0; k < which.size(); ++k) {
+        ws[which[k].first]->pre_[which[k].second] = out[k];
+        ws[which[k].first]->dirty_[which[k].second] = false;
+      }
+      w0 = w1;
+    }
+  } else {
     std::vector<vilo_sample> samples;
     std::vector<int32_t> offsets(1, 0);
     std::vector<double> lin;
@@ -426,6 +492,7 @@ void SlidingWindow::slideWindow() {
       std::swap(pre_[i], pre_[i + 1]);
       std::swap(pre_imu_[i], pre_imu_[i + 1]);
       std::swap(dirty_[i], dirty_[i + 1]);
+      std::swap(sid_[i], sid_[i + 1]); std::swap(pushed_[i], pushed_[i + 1]); std::swap(need_reset_[i], need_reset_[i + 1]);
     }
     Headers[WS] = Headers[WS - 1];
     cp(Ps[WS], Ps[WS - 1], 3); cp(Rs[WS], Rs[WS - 1], 9); cp(Vs[WS], Vs[WS - 1], 3); cp(Bas[WS], Bas[WS - 1], 3);
@@ -477,11 +544,13 @@ void *vilo_sw_create(vilo_ctx *ctx, const vilo_config *cfg, const vilo_sw_option
     if (o->max_num_iterations > 0) opt.solve.max_num_iterations = o->max_num_iterations;
     opt.solve.fixed_iterations = o->fixed_iterations;
     if (o->dump_dir) opt.dump_dir = o->dump_dir;
+    opt.streaming_preintegration = o->streaming_preintegration;
   }
   opt.features.focal_length = cfg->focal_length;
   return new SlidingWindow(ctx, *cfg, opt);
 }
 void vilo_sw_destroy(void *h) { delete (SlidingWindow *)h; }
+void vilo_sw_attach_streams(void *h, vilo_preint_streams *pool, int base_id) { ((SlidingWindow *)h)->attachStreams(pool, base_id); }
 void vilo_sw_set_extrinsics(void *h, const double *t, const double *r, double td) { ((SlidingWindow *)h)->setExtrinsics(t, r, td); }
 void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v) {
   SlidingWindow *s = (SlidingWindow *)h;

@@ -33,6 +33,7 @@ namespace vilo {
 
 struct SlidingWindowOptions {
   int use_leg = 1;             // USE_LEG: IMULegFactor (1) or IMUFactor (0)
+  int streaming_preintegration = 1;   // 1: intervals live on the device and are push_back()ed (USE_LEG); 0: re-integrate changed intervals
   int optimize_leg_bias = 1;   // OPTIMIZE_LEG_BIAS (estimator.cpp:1074)
   int estimate_extrinsic = 0;  // ESTIMATE_EXTRINSIC (estimator.cpp:1092)
   int estimate_td = 0;         // ESTIMATE_TD (estimator.cpp:1105)
@@ -49,10 +50,19 @@ class SlidingWindow {
   enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };   // estimator.h:64-68
 
   SlidingWindow(vilo_ctx *ctx, const vilo_config &cfg, const SlidingWindowOptions &opt);
+  ~SlidingWindow();
+  SlidingWindow(const SlidingWindow &) = delete;
+  SlidingWindow &operator=(const SlidingWindow &) = delete;
   void clearState();                                                                   // estimator.cpp:24-110
   void setExtrinsics(const double *tic2x3, const double *ric2x9, double td);           // setParameter :112-174
   void initFirstPose(const double p[3], const double R[9]);
   void initFirstIMUPose(const vilo_sample *samples, int n);
+  // Device-resident preintegration objects (vilo_preint_streams, include/vilo_gpu.h) for the window's intervals: slot j of the
+  // window uses one of the NF objects base_id .. base_id + NF - 1 of `pool`, so an interval is integrated once, sample by sample,
+  // however often MARGIN_SECOND_NEW merges the newest interval into it (the reference's push_back, estimator.cpp:1581-1599;
+  // without a pool a changed interval is re-integrated from its buffer). Robots of a fleet share one pool, one push per image.
+  // USE_LEG only. Without a call the window creates a pool of its own on first use.
+  void attachStreams(vilo_preint_streams *pool, int base_id);
   void setInitialVelocity(const double v[3]) { for (int i = 0; i < 3; ++i) Vs[0][i] = v[i]; }   // the reference starts at rest
   void processIMULeg(const vilo_sample &s);   // s.dt as computed at estimator.cpp:456-462
 
@@ -109,6 +119,12 @@ class SlidingWindow {
   std::vector<vilo_preint> pre_;
   std::vector<vilo_preint_imu> pre_imu_;
   bool dirty_[NF];
+  // streaming preintegration: object id of each slot, samples of buf_[j] (after element 0) already pushed, constructor pending
+  vilo_preint_streams *pool_ = nullptr;
+  bool own_pool_ = false;
+  int sid_[NF];
+  int pushed_[NF];
+  bool need_reset_[NF];
   PriorStore prior_[2];
   int cur_prior_ = 0;
   int pending_ = 0;   // 0 none, 1 first optimisation (INITIAL), 2 steady state
@@ -129,9 +145,12 @@ typedef struct {
   int32_t use_leg, optimize_leg_bias, estimate_extrinsic, estimate_td;
   int32_t max_num_iterations, fixed_iterations;
   const char *dump_dir;   // may be NULL
+  int32_t streaming_preintegration, pad;
 } vilo_sw_options;
 void *vilo_sw_create(vilo_ctx *ctx, const vilo_config *cfg, const vilo_sw_options *opt);
 void vilo_sw_destroy(void *h);
+// share one pool of device-resident preintegration objects among the robots of a fleet: robot k uses ids 11*k .. 11*k + 10
+void vilo_sw_attach_streams(void *h, vilo_preint_streams *pool, int base_id);
 void vilo_sw_set_extrinsics(void *h, const double *tic2x3, const double *ric2x9, double td);
 void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v /* may be NULL */);
 void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *samples, int n);

@@ -15,7 +15,8 @@ MAX_SAMPLES, MAX_FEATURES = 256, 512
 
 class SwOptions(C.Structure):
     _fields_ = [("use_leg", C.c_int32), ("optimize_leg_bias", C.c_int32), ("estimate_extrinsic", C.c_int32), ("estimate_td", C.c_int32),
-                ("max_num_iterations", C.c_int32), ("fixed_iterations", C.c_int32), ("dump_dir", C.c_char_p)]
+                ("max_num_iterations", C.c_int32), ("fixed_iterations", C.c_int32), ("dump_dir", C.c_char_p),
+                ("streaming_preintegration", C.c_int32), ("pad", C.c_int32)]
 
 
 class StreamParams(C.Structure):
@@ -38,6 +39,7 @@ def host_lib():
         _host.vilo_sw_create.restype = C.c_void_p
         _host.vilo_sw_create.argtypes = [C.c_void_p, C.POINTER(T.Config), C.POINTER(SwOptions)]
         _host.vilo_sw_destroy.argtypes = [C.c_void_p]
+        _host.vilo_sw_attach_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _host.vilo_sw_set_extrinsics.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, C.c_double]
         _host.vilo_sw_init_first_pose.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, T.c_double_p]
         _host.vilo_sw_process_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -99,11 +101,17 @@ class SlidingWindow:
     """vilo::SlidingWindow behind its C entry points."""
 
     def __init__(self, ctx, cfg, use_leg=1, optimize_leg_bias=1, estimate_extrinsic=0, estimate_td=0, max_num_iterations=0, fixed_iterations=0,
-                 dump_dir=None):
+                 dump_dir=None, streaming_preintegration=1):
         self.H, self.ctx = host_lib(), ctx
         self._dump = dump_dir.encode() if dump_dir else None
-        o = SwOptions(use_leg, optimize_leg_bias, estimate_extrinsic, estimate_td, max_num_iterations, fixed_iterations, self._dump)
-        self.h = C.c_void_p(self.H.vilo_sw_create(ctx.h, C.byref(cfg), C.byref(o)))
+        o = SwOptions(use_leg, optimize_leg_bias, estimate_extrinsic, estimate_td, max_num_iterations, fixed_iterations, self._dump,
+                      streaming_preintegration, 0)
+        self.h = C.c_void_p(self.H.vilo_sw_create(ctx.h if ctx is not None else None, C.byref(cfg), C.byref(o)))
+
+    def attach_streams(self, pool, base_id):
+        """pool: api.PreintStreams shared by a fleet; this robot uses objects base_id .. base_id + 10"""
+        self._pool = pool
+        self.H.vilo_sw_attach_streams(self.h, pool.h, base_id)
 
     def set_extrinsics(self, tic, ric, td):
         self.H.vilo_sw_set_extrinsics(self.h, _dp(np.ascontiguousarray(tic)), _dp(np.ascontiguousarray(ric)), td)
@@ -140,6 +148,56 @@ class SlidingWindow:
     def __del__(self):
         if getattr(self, "h", None):
             self.H.vilo_sw_destroy(self.h)
+            self.h = None
+
+
+class MeasurementProcessor:
+    """vilo::MeasurementProcessor (cerberus_amd/host/vilo_sensor_buffer.h): timestamped IMU / leg messages and feature frames
+    in, processIMULeg / processImage calls out, as Estimator::processMeasurements does (estimator.cpp:400-521)."""
+
+    def __init__(self, sliding_window):
+        self.H, self.sw = host_lib(), sliding_window
+        self.H.vilo_mp_create.restype = C.c_void_p
+        self.H.vilo_mp_create.argtypes = [C.c_void_p]
+        self.H.vilo_mp_destroy.argtypes = [C.c_void_p]
+        self.H.vilo_mp_input_imu.argtypes = [C.c_void_p, C.c_double, T.c_double_p, T.c_double_p]
+        self.H.vilo_mp_input_leg.argtypes = [C.c_void_p, C.c_double, T.c_double_p, T.c_double_p, T.c_double_p]
+        self.H.vilo_mp_input_feature.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.H.vilo_mp_queue_size.argtypes = [C.c_void_p]
+        self.H.vilo_mp_process.argtypes = [C.c_void_p]
+        self.H.vilo_mp_last_interval.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.h = C.c_void_p(self.H.vilo_mp_create(sliding_window.h))
+
+    def input_sample(self, t, sample):
+        """sample: one row of the Stream's sample array (dt ignored: the processor derives it from the stamps)"""
+        s = np.ascontiguousarray(sample, np.float64)
+        self.H.vilo_mp_input_imu(self.h, t, _dp(s[1:4]), _dp(s[4:7]))
+        self.H.vilo_mp_input_leg(self.h, t, _dp(s[7:19]), _dp(s[19:31]), _dp(s[31:35]))
+
+    def input_feature(self, t, ids, obs, stereo):
+        ids, obs, stereo = np.ascontiguousarray(ids, np.int32), np.ascontiguousarray(obs), np.ascontiguousarray(stereo, np.uint8)
+        rc = self.H.vilo_mp_input_feature(self.h, t, len(ids), ids.ctypes.data, obs.ctypes.data, stereo.ctypes.data)
+        if rc < 0:
+            raise RuntimeError("vilo_mp_input_feature failed: %d" % rc)
+        return rc
+
+    def process(self):
+        rc = self.H.vilo_mp_process(self.h)
+        if rc < 0:
+            raise RuntimeError("vilo_mp_process failed: %d" % rc)
+        return rc
+
+    def queue_size(self):
+        return self.H.vilo_mp_queue_size(self.h)
+
+    def last_interval(self):
+        out = np.zeros((MAX_SAMPLES, T.SAMPLE_DOUBLES))
+        n = self.H.vilo_mp_last_interval(self.h, out.ctypes.data, MAX_SAMPLES)
+        return out[:n].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.H.vilo_mp_destroy(self.h)
             self.h = None
 
 

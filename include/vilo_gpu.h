@@ -211,6 +211,22 @@ int vilo_preintegrate(vilo_ctx *ctx, int n_intervals, const vilo_sample *samples
 int vilo_preintegrate_imu(vilo_ctx *ctx, int n_intervals, const vilo_sample *samples, const int32_t *offsets,
                           const double *lin, vilo_preint_imu *out);
 
+/* ---- the same objects kept on the device and updated as samples arrive: IMULegIntegrationBase::push_back per IMU/leg
+ * message (Estimator::processIMULeg, estimator.cpp:619-626) instead of re-integrating an interval. A pool of n objects;
+ * pushing an interval in pieces gives bitwise the result of vilo_preintegrate on the whole interval. ---------------------- */
+typedef struct vilo_preint_streams vilo_preint_streams;
+int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **pool);
+void vilo_preint_streams_destroy(vilo_ctx *ctx, vilo_preint_streams *pool);
+/* new IMULegIntegrationBase{acc_0, gyr_0, phi_0, dphi_0, c_0, ba, bg, rho} (imu_leg_integration_base.cpp:7-42) for the
+ * objects ids[0..n): first[k] holds the constructor's measurement, lin [n][10] = ba bg rho. ids must be distinct. */
+int vilo_preint_streams_reset(vilo_ctx *ctx, vilo_preint_streams *pool, int n, const int32_t *ids, const vilo_sample *first,
+                              const double *lin);
+/* push_back (imu_leg_integration_base.cpp:44-60): object ids[k] receives samples[offsets[k] .. offsets[k+1]) in order. */
+int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *pool, int n, const int32_t *ids, const vilo_sample *samples,
+                             const int32_t *offsets);
+/* the public state of the objects ids[0..n) (what IMULegFactor reads) */
+int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *pool, int n, const int32_t *ids, vilo_preint *out);
+
 /* ---- Estimator::optimization(), solve half (estimator.cpp:1054-1245) --------------------------------
  * Synchronous; n_windows = 1 reproduces the reference call. States are updated in place with the
  * solver result (double2vector's gauge fix is vilo_gauge_fix below). */

@@ -101,6 +101,79 @@ def test_preintegrate(ctx, ocfg, small_window):
         assert _rel(out_i[k][17:], w.preint_imu[k][17:]) < 1e-10
 
 
+@pytest.fixture(scope="module")
+def ctx_force(cfg):
+    """contact_sensor_type 2 (config/go1_config/hardware_go1_vilo_config.yaml:30): foot forces instead of contact flags"""
+    import copy
+    from cerberus_amd import api
+    c2 = copy.copy(cfg)
+    c2.contact_sensor_type = 2
+    c = api.Context(c2, 0)
+    yield c
+    c.close()
+
+
+def _force_samples(samples, seed=0):
+    rng = np.random.default_rng(seed)
+    s = np.array(samples, copy=True)
+    s[:, 31:35] = 15.0 + 140.0 * s[:, 31:35] + 4.0 * rng.normal(size=s[:, 31:35].shape)
+    return s
+
+
+def test_preintegrate_contact_sensor_type_2(ctx_force, ocfg, small_window):
+    """imu_leg_integration_base.cpp:195-229, 300-317 on the device against the oracle (which tests/test_oracle_vs_reference.py
+    pins against the reference's own imu_leg_integration_base.cpp for this model)."""
+    import copy
+    w = small_window
+    o2 = copy.copy(ocfg)
+    o2.contact_sensor_type = 2
+    smp = _force_samples(w.samples, 3)
+    out = ctx_force.preintegrate(smp, w.sample_offsets, w.lin)
+    for k in range(10):
+        a0, a1 = w.sample_offsets[k], w.sample_offsets[k + 1]
+        b = O.preintegrate_imu_leg(o2, smp[a0:a1], w.lin[k])
+        a = out[k]
+        np.testing.assert_allclose(a[:33], b[:33], rtol=1e-12, atol=1e-14)
+        assert _rel(a[33:33 + 961], b[33:33 + 961]) < 1e-11
+        assert _rel(a[33 + 961:], b[33 + 961:]) < 1e-10
+    assert _rel(out[0][33 + 961:], w.preint[0][33 + 961:]) > 1e-3   # not the flag-based noise model
+
+
+@pytest.mark.parametrize("force", [False, True])
+def test_streaming_preintegration_equals_the_batch_bitwise(ctx, ctx_force, small_window, force):
+    """vilo_preint_streams_*: IMULegIntegrationBase objects resident in HBM, push_back()ed in arbitrary pieces (as
+    Estimator::processIMULeg does per message, estimator.cpp:619-626), against vilo_preintegrate on the whole interval."""
+    from cerberus_amd import api
+    c = ctx_force if force else ctx
+    w = small_window
+    smp = _force_samples(w.samples, 5) if force else w.samples
+    batch = c.preintegrate(smp, w.sample_offsets, w.lin)
+    rng = np.random.default_rng(11)
+    pool = api.PreintStreams(c, 16)
+    ids = rng.permutation(16)[:10]
+    first = np.stack([smp[w.sample_offsets[k]] for k in range(10)])
+    pool.reset(ids, first, w.lin)
+    np.testing.assert_array_equal(pool.read(ids)[:, 0], 0.0)                         # sum_dt of a fresh object
+    cursor = [int(w.sample_offsets[k]) + 1 for k in range(10)]                        # element 0 is the constructor's measurement
+    while any(cursor[k] < w.sample_offsets[k + 1] for k in range(10)):
+        sel, chunks = [], []
+        for k in range(10):
+            left = int(w.sample_offsets[k + 1]) - cursor[k]
+            if left and rng.random() < 0.7:
+                n = int(rng.integers(1, min(left, 9) + 1))
+                sel.append(k); chunks.append(smp[cursor[k]:cursor[k] + n]); cursor[k] += n
+        if not sel:
+            continue
+        off = np.concatenate([[0], np.cumsum([len(ch) for ch in chunks])])
+        pool.push(ids[sel], np.concatenate(chunks), off)
+    np.testing.assert_array_equal(pool.read(ids), batch)
+    # a reset object starts over; the others keep their state
+    pool.reset(ids[:1], first[:1], w.lin[:1])
+    again = pool.read(ids)
+    assert again[0, 0] == 0.0 and np.array_equal(again[1:], batch[1:])
+    pool.close()
+
+
 def _cd_to_oracle(cd, F=11):
     if cd < 66:
         return 19 * (cd // 6) + cd % 6

@@ -57,6 +57,36 @@ def test_preintegration_imu_leg(cfg, window):
         np.testing.assert_allclose(po["cov"], pr["cov"], rtol=1e-9, atol=1e-18 + 1e-12 * np.abs(pr["cov"]).max())
 
 
+def force_samples(samples, seed=0):
+    """contact flags {0, 1} of the synthetic gait -> foot forces in newtons, as contact_sensor_type 2 reads them"""
+    rng = np.random.default_rng(seed)
+    s = np.array(samples, copy=True)
+    s[:, 31:35] = 15.0 + 140.0 * s[:, 31:35] + 4.0 * rng.normal(size=s[:, 31:35].shape)
+    return s
+
+
+def test_preintegration_contact_sensor_type_2(window):
+    """Force-based contact model (imu_leg_integration_base.cpp:195-229, 300-317; go1 configs): adaptive min/max force
+    tracker, logistic flag truncated to an integer, 5-sample force variance and the three-term velocity noise."""
+    import copy
+    cfg2 = copy.copy(O.default_config())
+    cfg2.contact_sensor_type = 2
+    w = window
+    for k in range(w.F - 1):
+        a, b = w.sample_offsets[k], w.sample_offsets[k + 1]
+        smp = force_samples(w.samples[a:b], seed=k)
+        po = _split(O.preintegrate_imu_leg(cfg2, smp, w.lin[k]))
+        with R.as_oracle():
+            pr = _split(O.preintegrate_imu_leg(cfg2, smp, w.lin[k]))
+        for f in ("sum_dt", "dp", "dq", "dv", "de", "lin"):
+            np.testing.assert_allclose(po[f], pr[f], rtol=1e-12, atol=1e-14, err_msg=f)
+        np.testing.assert_allclose(po["jac"], pr["jac"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(po["cov"], pr["cov"], rtol=1e-9, atol=1e-18 + 1e-12 * np.abs(pr["cov"]).max())
+        # the model is really different from the flag-based one
+        p0 = _split(O.preintegrate_imu_leg(O.default_config(), w.samples[a:b], w.lin[k]))
+        assert np.abs(po["cov"] - p0["cov"]).max() > 1e-3 * np.abs(p0["cov"]).max()
+
+
 def test_preintegration_imu(cfg, window):
     w = window
     for k in (0, 4, 9):

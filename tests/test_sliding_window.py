@@ -181,16 +181,31 @@ def test_replay_without_leg_factors(ctx, cfg, ocfg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_streaming_and_batch_preintegration_give_the_same_replay(ctx, cfg):
+    """Intervals kept on the device and push_back()ed (default) against re-integration of every changed interval from its sample
+    buffer: bitwise the same estimate, including the MARGIN_SECOND_NEW merges of the newest interval into the one before."""
+    a = _run(ctx, cfg, 22, seed=31)[1]
+    b = _run(ctx, cfg, 22, seed=31, streaming_preintegration=0)[1]
+    assert {st["marginalization_flag"] for _, st in a[10:]} == {0, 1}
+    for (_, sa), (_, sb) in zip(a, b):
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "Rho"):
+            np.testing.assert_array_equal(sa[key], sb[key])
+
+
+@pytest.mark.gpu
 def test_fleet_in_lockstep_equals_robots_one_by_one(ctx, cfg):
     """process_images batches the solve and the marginalisation of every robot that is due into one device call each; the
     result per robot is bitwise what the robot gets alone."""
     from cerberus_amd import sequence
     R, N = 3, 16
     alone = [_run(ctx, cfg, N, seed=200 + r, t0=0.4 * r)[1][-1][1] for r in range(R)]
+    from cerberus_amd import api
     streams = [sequence.Stream(cfg, seed=200 + r, t0=0.4 * r) for r in range(R)]
     robots = [sequence.SlidingWindow(ctx, cfg) for _ in range(R)]
-    for s, w in zip(streams, robots):
+    pool = api.PreintStreams(ctx, 11 * R)     # one pool of device-resident preintegration objects for the fleet
+    for r, (s, w) in enumerate(zip(streams, robots)):
         w.set_extrinsics(*s.extrinsics())
+        w.attach_streams(pool, 11 * r)
     for k in range(N):
         frames = [s.next() for s in streams]
         for w, f in zip(robots, frames):
