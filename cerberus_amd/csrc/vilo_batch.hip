@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <thread>
 
 #include "solver_types.hpp"
 
@@ -38,6 +39,13 @@ int dev_upload(vilo_ctx *ctx, vilo_batch *bt, T **p, const std::vector<T> &h) {
   int rc = dev_alloc(ctx, bt, p, h.size());
   if (rc != VILO_OK) return rc;
   if (!h.empty()) VILO_HIP(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return VILO_OK;
+}
+template <class T>
+int dev_upload_raw(vilo_ctx *ctx, vilo_batch *bt, T **p, const T *h, size_t n) {
+  int rc = dev_alloc(ctx, bt, p, n);
+  if (rc != VILO_OK) return rc;
+  if (n) VILO_HIP(hipMemcpy(*p, h, n * sizeof(T), hipMemcpyHostToDevice));
   return VILO_OK;
 }
 #define TRYB(x) do { int rc_ = (x); if (rc_ != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc_; } } while (0)
@@ -123,8 +131,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<ChunkMeta> chunks;
   std::vector<WaveMeta> waves;
   std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
-  std::vector<double> obs, x0((size_t)W * XSTRIDE, 0.0), lam0;
-  std::vector<unsigned char> flags;
+  std::vector<double> x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<double> px0((size_t)W * 280, 0.0);
   // J0 / r0 of the priors, packed n x n per window, staged for k_prior_pack (uninitialised storage: only n x n of a slot is read)
   std::unique_ptr<double[]> pJ(new double[(size_t)W * 96 * 96]), pr0(new double[(size_t)W * 96]);
@@ -132,9 +139,11 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<unsigned char> iskip((size_t)W * 10, 0);
   std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
   int lm_total = 0, gram_total = 0;
+  size_t obs_total = 0, flags_total = 0;
   bt->lm_off_host.resize(W);
   bt->L_host.resize(W);
 
+  // ---- pass 1 (serial, light): validation, chunk / wave tables and every offset ----
   for (int w = 0; w < W; ++w) {
     const vilo_window_desc &d = in[w];
     const vilo_window_state &s = init[w];
@@ -155,14 +164,6 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     wm.const_mask = ((d.leg_bias_const || !d.use_leg) ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
     bt->lm_off_host[w] = lm_total;
     bt->L_host[w] = L;
-    // states (vector2double layout)
-    double *xw = &x0[(size_t)w * XSTRIDE];
-    memcpy(xw + XO_POSE, s.pose, sizeof(double) * 7 * F);
-    memcpy(xw + XO_SB, s.speed_bias, sizeof(double) * 9 * F);
-    memcpy(xw + XO_LB, s.leg_bias, sizeof(double) * 4 * F);
-    for (int k = F; k < VILO_MAX_FRAMES; ++k) xw[XO_POSE + 7 * k + 6] = 1.0;
-    memcpy(xw + XO_EX, s.ex_pose, sizeof(double) * 14);
-    xw[XO_TD] = s.td[0];
     // landmark chunks: group by start frame, <= 64 per chunk, list order preserved inside a group
     int local = 0;
     for (int sf = 0; sf < F; ++sf) {
@@ -211,42 +212,71 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         lanes += pad; ++wv.nseg; ++c;
       }
       wv.n_lanes = lanes;
-      wv.obs_off = (long long)obs.size();
-      wv.flag_off = (long long)flags.size();
-      obs.resize(obs.size() + (size_t)wv.kmax * 11 * lanes, 0.0);
-      flags.resize(flags.size() + (size_t)wv.kmax * lanes, 0);
+      wv.obs_off = (long long)obs_total;
+      wv.flag_off = (long long)flags_total;
+      obs_total += (size_t)wv.kmax * 11 * lanes;
+      flags_total += (size_t)wv.kmax * lanes;
+      waves.push_back(wv);
+    }
+    wm.n_waves = (int)waves.size() - wm.wave_off;
+    wm.n_gram = gram_total - wm.gram_off;
+    lm_total += L;
+    if (d.prior && d.prior->valid && d.prior->n > 0) {
+      if (d.prior->n > VILO_MAX_PRIOR_DIM || d.prior->n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+      any_prior = true;
+    }
+  }
+  // ---- pass 2 (one host thread per slice of windows): the heavy copies — wave-packed observation image, states, prior staging ----
+  std::unique_ptr<double[]> obs(new double[std::max<size_t>(1, obs_total)]);
+  std::unique_ptr<unsigned char[]> flags(new unsigned char[std::max<size_t>(1, flags_total)]);
+  std::vector<int> win_err(W, 0);
+  auto fill_window = [&](int w) {
+    const vilo_window_desc &d = in[w];
+    const vilo_window_state &s = init[w];
+    WinMeta &wm = wins[w];
+    const int F = d.n_frames;
+    // states (vector2double layout)
+    double *xw = &x0[(size_t)w * XSTRIDE];
+    memcpy(xw + XO_POSE, s.pose, sizeof(double) * 7 * F);
+    memcpy(xw + XO_SB, s.speed_bias, sizeof(double) * 9 * F);
+    memcpy(xw + XO_LB, s.leg_bias, sizeof(double) * 4 * F);
+    for (int k = F; k < VILO_MAX_FRAMES; ++k) xw[XO_POSE + 7 * k + 6] = 1.0;
+    memcpy(xw + XO_EX, s.ex_pose, sizeof(double) * 14);
+    xw[XO_TD] = s.td[0];
+    for (int wi = wm.wave_off; wi < wm.wave_off + wm.n_waves; ++wi) {
+      const WaveMeta &wv = waves[wi];
+      const int lanes = wv.n_lanes;
+      double *ob = obs.get() + wv.obs_off;
+      unsigned char *fl = flags.get() + wv.flag_off;
+      memset(ob, 0, sizeof(double) * (size_t)wv.kmax * 11 * lanes);
+      memset(fl, 0, (size_t)wv.kmax * lanes);
       for (int g = 0; g < wv.nseg; ++g) {
         const std::vector<int> &ids = chunk_ids[wv.seg_chunk[g]];
         for (size_t i = 0; i < ids.size(); ++i) {
           const int l = ids[i], lane = wv.seg_lane0[g] + (int)i;
           const int o0 = d.lm_obs_offset[l], K = d.lm_obs_offset[l + 1] - o0;
           for (int t = 0; t < K; ++t) {
-            for (int f = 0; f < 11; ++f) obs[wv.obs_off + ((size_t)t * 11 + f) * lanes + lane] = d.obs[(size_t)(o0 + t) * 11 + f];
-            flags[wv.flag_off + (size_t)t * lanes + lane] = (unsigned char)(1 | (d.obs_is_stereo[o0 + t] ? 2 : 0));
+            for (int f = 0; f < 11; ++f) ob[((size_t)t * 11 + f) * lanes + lane] = d.obs[(size_t)(o0 + t) * 11 + f];
+            fl[(size_t)t * lanes + lane] = (unsigned char)(1 | (d.obs_is_stereo[o0 + t] ? 2 : 0));
           }
         }
       }
-      waves.push_back(wv);
     }
-    wm.n_waves = (int)waves.size() - wm.wave_off;
-    wm.n_gram = gram_total - wm.gram_off;
-    lm_total += L;
     for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !((d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt) > 10.0)) ? 0 : 1;
-    // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
+    // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): block tables here, H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0 in k_prior_pack
     if (d.prior && d.prior->valid && d.prior->n > 0) {
       const vilo_prior &p = *d.prior;
       const int n = p.n;
-      if (n > VILO_MAX_PRIOR_DIM || p.n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
       wm.prior_n = n; wm.prior_nb = p.n_blocks;
       int xo = 0, bframe = -1;
       for (int k = 0; k < p.n_blocks; ++k) {
         int soff = 0;
         const int cd = prior_block_cd(p.block_id[k], &soff);
         const int gs = p.block_size[k], ls = gs == 7 ? 6 : gs;
-        if (cd < 0 || p.block_idx[k] < 0 || p.block_idx[k] + ls > n) { ctx->err = "unsupported prior block"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+        if (cd < 0 || p.block_idx[k] < 0 || p.block_idx[k] + ls > n) { win_err[w] = 1; return; }
         if (cd >= CD_B0) {
           const int fr = (cd - CD_B0) / 13;
-          if (bframe >= 0 && bframe != fr) { ctx->err = "prior couples speed/leg biases of two frames"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+          if (bframe >= 0 && bframe != fr) { win_err[w] = 2; return; }
           bframe = fr;
         }
         pbs[(size_t)w * 40 + k] = gs; pbi[(size_t)w * 40 + k] = p.block_idx[k]; pbx[(size_t)w * 40 + k] = xo; pbst[(size_t)w * 40 + k] = soff;
@@ -255,21 +285,36 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         xo += gs;
       }
       wm.pad = bframe;
-      const double t_p0 = now();
       memcpy(pJ.get() + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
       memcpy(pr0.get() + (size_t)w * 96, p.r0, sizeof(double) * n);
-      any_prior = true;
-      t_prior += now() - t_p0;
+    }
+  };
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min({hw > 0 ? hw : 1, 16, W / 8}));
+    if (nt <= 1) {
+      for (int w = 0; w < W; ++w) fill_window(w);
+    } else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] { for (int w = t; w < W; w += nt) fill_window(w); });
+      for (auto &x : th) x.join();
     }
   }
+  for (int w = 0; w < W; ++w)
+    if (win_err[w]) {
+      ctx->err = win_err[w] == 1 ? "unsupported prior block" : "prior couples speed/leg biases of two frames";
+      vilo_batch_destroy(ctx, bt);
+      return VILO_ERR_UNSUPPORTED;
+    }
   const double t_packed = now();
   BatchDev &D = bt->d;
   D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
   TRYB(dev_upload(ctx, bt, &D.win, wins));
   TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
   TRYB(dev_upload(ctx, bt, &D.wave, waves));
-  TRYB(dev_upload(ctx, bt, &D.obs, obs));
-  TRYB(dev_upload(ctx, bt, &D.flags, flags));
+  TRYB(dev_upload_raw(ctx, bt, &D.obs, obs.get(), obs_total));
+  TRYB(dev_upload_raw(ctx, bt, &D.flags, flags.get(), flags_total));
   TRYB(dev_upload(ctx, bt, &D.x0, x0));
   TRYB(dev_upload(ctx, bt, &D.lam0, lam0));
   TRYB(dev_upload(ctx, bt, &D.lm_perm, bt->perm_host));
@@ -361,7 +406,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   int rc = vilo_batch_reset(ctx, bt);
   if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
   if (timing)
-    fprintf(stderr, "[vilo_batch_create] W=%d pack %.2f ms (prior H %.2f) alloc+upload %.2f ms preint %.2f ms reset %.2f ms\n", W, t_packed - t_begin, t_prior,
+    fprintf(stderr, "[vilo_batch_create] W=%d pack %.2f ms (prior staging %.2f) alloc+upload %.2f ms preint %.2f ms reset %.2f ms\n", W, t_packed - t_begin, t_prior,
             t_uploaded - t_packed, t_prep - t_uploaded, now() - t_prep);
   *out = bt;
   return VILO_OK;

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 #include "../../include/vilo_window_io.h"
 #include "../csrc/vilo_math.hpp"
@@ -305,7 +307,21 @@ int SlidingWindow::dump(const vilo_window_state &before) const {
 }
 
 double now_ms_public();
+void parallel_for_public(int n, const std::function<void(int)> &fn);
 namespace {
+// robots are independent: host bookkeeping of a fleet runs on a few threads
+void parallel_for(int n, const std::function<void(int)> &fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int nt = std::max(1, std::min({hw > 0 ? hw : 1, 16, n / 4}));
+  if (nt <= 1) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (int i = t; i < n; i += nt) fn(i); });
+  for (auto &x : th) x.join();
+}
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
@@ -401,7 +417,7 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   std::vector<vilo_window_state> states(n), befores(n);
   std::vector<std::vector<double>> keep(n);   // pre-solve copies (the dump's `before`)
   std::vector<vilo_solve_summary> sums(n);
-  for (int w = 0; w < n; ++w) {
+  parallel_for(n, [&](int w) {
     SlidingWindow &s = *ws[w];
     s.vector2double();
     s.fillDesc();
@@ -420,7 +436,7 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
     befores[w].ex_pose = b; b += 14;
     befores[w].td = b; b += 1;
     befores[w].inv_depth = b;
-  }
+  });
   // 3. Estimator::optimization() from ceres::Solve on (estimator.cpp:1236-1455) in one device call: solve, double2vector's gauge
   //    fix, marginalisation at the result — one packing of the batch, no host round trip between the halves
   const double t2 = now_ms();
@@ -436,16 +452,19 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   int rc = vilo_optimize_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), next.data(), sums.data());
   if (rc != VILO_OK) return rc;
   const double t3 = now_ms();
-  for (int w = 0; w < n; ++w) {
+  std::vector<int> dump_rc(n, 0);
+  parallel_for(n, [&](int w) {
     SlidingWindow &s = *ws[w];
     s.last_summary = sums[w];
-    if (!s.opt_.dump_dir.empty() && s.dump(befores[w]) != 0) return VILO_ERR_BAD_ARG;
+    if (!s.opt_.dump_dir.empty()) dump_rc[w] = s.dump(befores[w]);
     s.double2vector();
     s.prior_[1 - s.cur_prior_].p = next[w];
     s.prior_[1 - s.cur_prior_].bind();
     s.cur_prior_ = 1 - s.cur_prior_;
     ++s.n_optimizations;
-  }
+  });
+  for (int w = 0; w < n; ++w)
+    if (dump_rc[w] != 0) return VILO_ERR_BAD_ARG;
   if (timing)
     fprintf(stderr, "[optimizeBatch] n=%d preintegrate %.2f ms, vector2double+tables %.2f ms, vilo_optimize_windows %.2f ms, double2vector %.2f ms\n", n, t1 - t0,
             t2 - t1, t3 - t2, now_ms() - t3);
@@ -489,11 +508,12 @@ void SlidingWindow::slideWindow() {
       swp(Rho[i], Rho[i + 1]);
       buf_[i].swap(buf_[i + 1]);
       swp(lin_[i], lin_[i + 1]);
-      std::swap(pre_[i], pre_[i + 1]);
-      std::swap(pre_imu_[i], pre_imu_[i + 1]);
       std::swap(dirty_[i], dirty_[i + 1]);
       std::swap(sid_[i], sid_[i + 1]); std::swap(pushed_[i], pushed_[i + 1]); std::swap(need_reset_[i], need_reset_[i + 1]);
     }
+    // il_pre_integrations / pre_integrations: the same pointer swap chain as one rotation of the record arrays
+    if (opt_.use_leg) std::rotate(pre_.begin(), pre_.begin() + 1, pre_.end());
+    else std::rotate(pre_imu_.begin(), pre_imu_.begin() + 1, pre_imu_.end());
     Headers[WS] = Headers[WS - 1];
     cp(Ps[WS], Ps[WS - 1], 3); cp(Rs[WS], Rs[WS - 1], 9); cp(Vs[WS], Vs[WS - 1], 3); cp(Bas[WS], Bas[WS - 1], 3);
     cp(Bgs[WS], Bgs[WS - 1], 3); cp(Rho[WS], Rho[WS - 1], 4);
@@ -531,6 +551,7 @@ void SlidingWindow::slideWindowOld() {
 }
 
 double now_ms_public() { return now_ms(); }
+void parallel_for_public(int n, const std::function<void(int)> &fn) { parallel_for(n, fn); }
 
 }  // namespace vilo
 
@@ -568,15 +589,18 @@ int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int W, const double *
                            const uint8_t *stereo) {
   std::vector<SlidingWindow *> due;
   const double t0 = vilo::now_ms_public();
-  for (int w = 0; w < W; ++w) {
+  std::vector<char> is_due(W, 0);
+  vilo::parallel_for_public(W, [&](int w) {
     SlidingWindow *s = (SlidingWindow *)hs[w];
-    if (s->beginImage(headers[w], off[w + 1] - off[w], ids + off[w], obs11 + 11 * (size_t)off[w], stereo + off[w])) due.push_back(s);
-  }
+    is_due[w] = s->beginImage(headers[w], off[w + 1] - off[w], ids + off[w], obs11 + 11 * (size_t)off[w], stereo + off[w]) ? 1 : 0;
+  });
+  for (int w = 0; w < W; ++w)
+    if (is_due[w]) due.push_back((SlidingWindow *)hs[w]);
   const double t1 = vilo::now_ms_public();
   const int rc = SlidingWindow::optimizeBatch(ctx, due.data(), (int)due.size());
   if (rc != VILO_OK) return rc;
   const double t2 = vilo::now_ms_public();
-  for (int w = 0; w < W; ++w) ((SlidingWindow *)hs[w])->endImage();
+  vilo::parallel_for_public(W, [&](int w) { ((SlidingWindow *)hs[w])->endImage(); });
   if (getenv("VILO_HOST_TIMING"))
     fprintf(stderr, "[vilo_sw_process_images] W=%d beginImage %.2f ms, optimizeBatch %.2f ms, endImage %.2f ms\n", W, t1 - t0, t2 - t1, vilo::now_ms_public() - t2);
   return VILO_OK;
