@@ -63,6 +63,59 @@ def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
             "sample": "%d synthetic config-2 windows x %d iterations, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s" % (n_win, ITERS, t_total)}
 
 
+def _all_cores_child(k, n_landmarks, t_end, q):
+    from cerberus_amd import synth
+    from oracle import oracle_py as O
+    cfg = synth.default_config()
+    ocfg = O.config_from(cfg)
+    opts = O.default_opts(fixed_iterations=True, max_num_iterations=ITERS)
+    opts.recompute_sqrt_info = 1
+    w = synth.make_window(cfg, n_landmarks=n_landmarks, seed=778000 + k % 16)
+    O.fill_preint(ocfg, w)
+    init = w.clone_state()
+    n = 0
+    t0 = time.time()
+    while time.time() < t_end:
+        w.set_state([a.copy() for a in init])
+        n += O.solve_window(ocfg, w, opts).iterations
+    q.put((n, t0, time.time()))
+
+
+def cpu_all_cores_main(n_landmarks, budget_s):
+    """Runs in a fresh interpreter (no torch / HIP state to fork): one process per core, one window each."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # a container's CPU quota, not the visible CPU count, is what "every core" means (cgroup v2 cpu.max = "quota period")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    t_end = time.time() + 3.0 + budget_s          # 3 s for every child to build its window
+    ps = [ctx.Process(target=_all_cores_child, args=(k, n_landmarks, t_end, q)) for k in range(cores)]
+    for p_ in ps:
+        p_.start()
+    res = [q.get() for _ in ps]
+    for p_ in ps:
+        p_.join()
+    n_it = sum(r[0] for r in res)
+    span = max(r[2] for r in res) - min(r[1] for r in res)
+    print(json.dumps({"value": n_it / span, "unit": "GN iters/s", "cores": cores, "kind": "port",
+                      "sample": "one config-2 window per process, %d processes, %d iterations in %.1f s wall, oracle/liboracle.so" % (cores, n_it, span)}))
+
+
+def cpu_baseline_all_cores(n_landmarks, budget_s=6.0):
+    """SURVEY §8(d) "all-cores mode": one window per core, every core of the box (own process each: the oracle's allocator
+    traffic serialises threads of one process)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores", str(n_landmarks), str(budget_s)], capture_output=True, text=True,
+                       timeout=120)
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +245,10 @@ def main():
             b1.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks)
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks)
+            except Exception as e:   # the single-thread number above is the contract; this one is extra information
+                out["cpu_baseline_all_cores"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
@@ -200,6 +257,10 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
 
+
+if __name__ == "__main__" and len(sys.argv) >= 2 and sys.argv[1] == "--cpu-all-cores":
+    cpu_all_cores_main(int(sys.argv[2]), float(sys.argv[3]))
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
