@@ -1693,6 +1693,9 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
     if (tid == 0) {
       st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
       st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
+      // a non-finite evaluation at the initial point: ceres::Solve fails in IterationZero ("Residual and Jacobian evaluation
+      // failed", ResidualBlock::Evaluate's IsArrayValid) and leaves the parameters alone; this window is done, the others go on
+      if (!(cand < 1.7976931348623157e308)) { st.done = 1; st.termination = 2; }
     }
     if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
     return;

@@ -479,6 +479,13 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
   gather_x(P, R, x);
   double x_norm = vnorm(x);
   double x_cost = evaluate(P, true);
+  if (!std::isfinite(x_cost)) {
+    // ResidualBlock::Evaluate rejects non-finite residuals / Jacobians (IsArrayValid): TrustRegionMinimizer::IterationZero
+    // fails with "Residual and Jacobian evaluation failed", termination FAILURE, parameters untouched
+    sum->initial_cost = sum->final_cost = x_cost;
+    sum->termination = 2;
+    return -1;
+  }
   std::vector<double> scale(n, 1.0), ones(n, 1.0), g_unscaled, sqn;
   if (o->jacobi_scaling) {
     JT_r_and_colnorm(P, R, ones, g_unscaled, sqn);

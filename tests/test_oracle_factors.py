@@ -265,3 +265,16 @@ def test_prior_eval(ocfg, small_window):
         ls = 6 if size == 7 else size
         np.testing.assert_array_equal(J[:, :ls], J0[:, idx:idx + ls])
         np.testing.assert_allclose(J[:, :ls], Jn, atol=2e-2 * np.abs(J0).max())  # dtheta=2vec(dq) is first order
+
+
+def test_non_finite_start_fails_like_ceres(cfg, ocfg):
+    """IterationZero with a non-finite evaluation: FAILURE, parameters untouched (the device side: tests/test_error_paths.py)."""
+    from cerberus_amd import synth
+    w = synth.make_window(cfg, n_landmarks=20, seed=3)
+    O.fill_preint(ocfg, w)
+    w.state_arrays()[0][4, 1] = np.nan
+    before = w.clone_state()
+    with pytest.raises(FloatingPointError):
+        O.solve_window(ocfg, w, O.default_opts(True, 3))
+    for a, b in zip(w.state_arrays(), before):
+        np.testing.assert_array_equal(a, b)
