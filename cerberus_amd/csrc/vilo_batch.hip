@@ -20,6 +20,12 @@ struct vilo_batch {
   std::vector<int> perm_host;       // device order -> original landmark index (per window, concatenated)
   std::vector<int> L_host;
   int W;
+  // the launch sequence of one solve (5 + 7 x max_num_iterations kernels) as a hipGraph, captured when the same resident batch is
+  // solved a second time with the same options (vilo_batch_reset + vilo_batch_solve loops: replays, Monte-Carlo seeds, bench)
+  hipGraphExec_t gexec = nullptr;
+  vilo_solve_opts gopts;
+  int n_solves = 0;
+  bool graph_failed = false;
 };
 
 namespace {
@@ -112,6 +118,7 @@ const int *vilo_batch_perm(vilo_batch *bt, int win, int *L) {
 extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
   if (!bt) return;
   if (ctx) (void)hipSetDevice(ctx->device);
+  if (bt->gexec) (void)hipGraphExecDestroy(bt->gexec);
   for (void *p : bt->allocs) (void)hipFree(p);
   delete bt;
 }
@@ -425,9 +432,29 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   if (!ctx || !bt || !opts) return VILO_ERR_BAD_ARG;
   if (opts->max_num_iterations < 0 || opts->max_num_iterations > 63) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
+  int rc = VILO_OK;
+  const bool want_graph = !ctx->profile && !bt->graph_failed && bt->n_solves >= 1 && getenv("VILO_NO_GRAPH") == nullptr;
+  if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0)) {
+    if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      rc = vilo_solve_launch(ctx, bt->d, opts);
+      const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+      if (rc != VILO_OK || e != hipSuccess || !g || hipGraphInstantiate(&bt->gexec, g, nullptr, nullptr, 0) != hipSuccess) bt->gexec = nullptr;
+      if (g) (void)hipGraphDestroy(g);
+    }
+    if (!bt->gexec) { bt->graph_failed = true; (void)hipGetLastError(); ctx->err.clear(); }
+    else bt->gopts = *opts;
+    rc = VILO_OK;
+  }
   VILO_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = vilo_solve_launch(ctx, bt->d, opts);
-  if (rc != VILO_OK) return rc;
+  if (want_graph && bt->gexec) {
+    VILO_HIP(hipGraphLaunch(bt->gexec, ctx->stream));
+  } else {
+    rc = vilo_solve_launch(ctx, bt->d, opts);
+    if (rc != VILO_OK) return rc;
+  }
+  ++bt->n_solves;
   VILO_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   VILO_HIP(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;

@@ -15,7 +15,10 @@
  * oracle/ref_build/; tests/test_oracle_vs_reference.py) and against the outputs frozen from that
  * build (tests/golden/reference_vectors.npz; tests/test_golden.py). The Ceres trust-region
  * trajectory (orc_solve_window) is "PARITY UNPINNED": restated from the published Ceres 1.14
- * algorithm only, no Ceres build is available here.
+ * algorithm only, no Ceres build is available here. (It has one independent check: the HIP path implements the same
+ * algorithm separately, and replaying a sensor stream through both found — and fixed — a deviation of THIS file from
+ * Ceres after rejected steps; tests/golden/seq_window_rejected_steps.vwin keeps that case.) The force-based contact model
+ * (contact_sensor_type 2) of the preintegration is pinned against the reference too.
  */
 #ifndef VILO_ORACLE_H
 #define VILO_ORACLE_H
