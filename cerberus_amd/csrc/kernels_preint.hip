@@ -47,6 +47,55 @@ __device__ void jac_cov_update(const double *Fm, const double *Vm, const double 
   __syncthreads();
 }
 
+// The same update for the 31-dim IMU-leg state on the FP64 matrix cores: all four products are 32 x 32 (x 32 or x 48) GEMMs of
+// zero-padded LDS matrices, 2 x 2 output tiles of v_mfma_f64_16x16x4 (lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16] of a
+// 4-deep k-step and owns C[(l / 16) + 4 r][l % 16], r = 0..3). One wave, 144 MFMAs per sample instead of ~4300 LDS-fed FMAs per lane.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int FLD = 33;   // leading dimension of the 32 x 32 matrices (odd: rows land in different LDS banks)
+constexpr int VLD = 49;   // of the 32 x 48 noise Jacobian
+
+// C(32 x 32) = A(32 x 4 KS) * op(B): row-major A (lda), B given as Bt = B^T row-major (ldb) when BT, else B row-major
+template <int KS, bool BT>
+__device__ __forceinline__ void gemm32(const double *A, int lda, const double *B, int ldb, const double *kscale, mfma_d4 acc[4]) {
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 4 * kk + lk;
+    double a0 = A[lr * lda + k], a1 = A[(16 + lr) * lda + k];
+    if (kscale) { const double sc = kscale[k]; a0 *= sc; a1 *= sc; }
+    const double b0 = BT ? B[lr * ldb + k] : B[k * ldb + lr];
+    const double b1 = BT ? B[(16 + lr) * ldb + k] : B[k * ldb + 16 + lr];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[3], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]) {
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr] = acc[t][r];
+}
+// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468)
+__device__ void jac_cov_update_mfma(const double *Fm, const double *Vm, const double *nd, double *Jm, double *Pm, double *Qm) {
+  const mfma_d4 z = {0.0, 0.0, 0.0, 0.0};
+  mfma_d4 accJ[4] = {z, z, z, z}, accQ[4] = {z, z, z, z};
+  gemm32<8, false>(Fm, FLD, Jm, FLD, nullptr, accJ);   // F J
+  gemm32<8, false>(Fm, FLD, Pm, FLD, nullptr, accQ);   // Q = F P
+  __syncthreads();
+  store32(Jm, FLD, accJ);
+  store32(Qm, FLD, accQ);
+  __syncthreads();
+  mfma_d4 accP[4] = {z, z, z, z};
+  gemm32<8, true>(Qm, FLD, Fm, FLD, nullptr, accP);    // Q F^T
+  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accP);        // + V N V^T
+  __syncthreads();
+  store32(Pm, FLD, accP);
+  __syncthreads();
+}
+
 __device__ inline void put33(double *M, int ld, int r0, int c0, const m3 &A) {
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) M[(r0 + a) * ld + c0 + b] = A.a[3 * a + b];
@@ -74,8 +123,10 @@ struct PreintStream {
 template <bool STREAM>
 __device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
                                     PreintStream *st) {
-  __shared__ double Fm[31 * 31], Vm[31 * 46], nd[46];
-  __shared__ double Jm[31 * 32], Pm[31 * 32], Qm[31 * 32];
+  // padded to 32 rows (48 noise columns) with odd leading dimensions: rows / columns 31 and noise 46, 47 stay zero, so the FP64
+  // MFMA tiles of jac_cov_update_mfma need no masks
+  __shared__ double Fm[32 * FLD], Vm[32 * VLD], nd[48];
+  __shared__ double Jm[32 * FLD], Pm[32 * FLD], Qm[32 * FLD];
   __shared__ LegTerms lt[8];
   const int lane = threadIdx.x;
   if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
@@ -102,9 +153,11 @@ __device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *s
       ff_min[j] = st->ff_min[j]; ff_max[j] = st->ff_max[j]; ff_var[j] = st->ff_var[j]; ff_idx[j] = st->ff_idx[j];
       for (int k = 0; k < 5; ++k) ff_win[j][k] = st->ff_win[5 * j + k];
     }
-    for (int e = lane; e < 31 * 31; e += 64) { Jm[(e / 31) * 32 + (e % 31)] = r.jacobian[e]; Pm[(e / 31) * 32 + (e % 31)] = r.covariance[e]; }
+    for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = 0.0; Pm[e] = 0.0; }
+    __syncthreads();
+    for (int e = lane; e < 31 * 31; e += 64) { Jm[(e / 31) * FLD + (e % 31)] = r.jacobian[e]; Pm[(e / 31) * FLD + (e % 31)] = r.covariance[e]; }
   } else {
-    for (int e = lane; e < 31 * 32; e += 64) { Jm[e] = ((e / 32) == (e % 32)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+    for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = ((e / FLD) == (e % FLD) && e / FLD < 31) ? 1.0 : 0.0; Pm[e] = 0.0; }
   }
   __syncthreads();
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
@@ -171,8 +224,9 @@ __device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *s
       st3(lt[lane].f, k.f); st3(lt[lane].v, v); st3(lt[lane].g, g);
       for (int q = 0; q < 9; ++q) { lt[lane].J[q] = k.J.a[q]; lt[lane].h[q] = h.a[q]; }
     }
-    for (int e = lane; e < 31 * 31; e += 64) Fm[e] = 0.0;
-    for (int e = lane; e < 31 * 46; e += 64) Vm[e] = 0.0;
+    for (int e = lane; e < 32 * FLD; e += 64) Fm[e] = 0.0;
+    for (int e = lane; e < 32 * VLD; e += 64) Vm[e] = 0.0;
+    if (lane >= 46 && lane < 48) nd[lane] = 0.0;
     __syncthreads();
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
@@ -219,56 +273,56 @@ __device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *s
     const m3 kappa_7 = I3 - Rwx * dt;
     if (lane == 0) {
       const m3 kappa_1 = (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * kappa_7) * (-0.5 * dt);
-      put33(Fm, 31, 0, 0, I3);
-      put33(Fm, 31, 0, 3, kappa_1 * (0.5 * dt));
-      put33(Fm, 31, 0, 6, I3 * dt);
-      put33(Fm, 31, 0, 21, (R0 + R1) * (-0.25 * dt * dt));
-      put33(Fm, 31, 0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
-      put33(Fm, 31, 3, 3, kappa_7);
-      put33(Fm, 31, 3, 24, I3 * (-1.0 * dt));
-      put33(Fm, 31, 6, 3, kappa_1);
-      put33(Fm, 31, 6, 6, I3);
-      put33(Fm, 31, 6, 21, (R0 + R1) * (-0.5 * dt));
-      put33(Fm, 31, 6, 24, (R1 * Ra1) * (0.5 * dt * dt));
+      put33(Fm, FLD, 0, 0, I3);
+      put33(Fm, FLD, 0, 3, kappa_1 * (0.5 * dt));
+      put33(Fm, FLD, 0, 6, I3 * dt);
+      put33(Fm, FLD, 0, 21, (R0 + R1) * (-0.25 * dt * dt));
+      put33(Fm, FLD, 0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
+      put33(Fm, FLD, 3, 3, kappa_7);
+      put33(Fm, FLD, 3, 24, I3 * (-1.0 * dt));
+      put33(Fm, FLD, 6, 3, kappa_1);
+      put33(Fm, FLD, 6, 6, I3);
+      put33(Fm, FLD, 6, 21, (R0 + R1) * (-0.5 * dt));
+      put33(Fm, FLD, 6, 24, (R1 * Ra1) * (0.5 * dt * dt));
       const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt);
-      put33(Vm, 46, 0, 0, R0 * (0.25 * dt * dt));
-      put33(Vm, 46, 0, 3, VpG);
-      put33(Vm, 46, 0, 6, R1 * (0.25 * dt * dt));
-      put33(Vm, 46, 0, 9, VpG);
-      put33(Vm, 46, 3, 3, I3 * (0.5 * dt));
-      put33(Vm, 46, 3, 9, I3 * (0.5 * dt));
+      put33(Vm, VLD, 0, 0, R0 * (0.25 * dt * dt));
+      put33(Vm, VLD, 0, 3, VpG);
+      put33(Vm, VLD, 0, 6, R1 * (0.25 * dt * dt));
+      put33(Vm, VLD, 0, 9, VpG);
+      put33(Vm, VLD, 3, 3, I3 * (0.5 * dt));
+      put33(Vm, VLD, 3, 9, I3 * (0.5 * dt));
       const m3 VvG = (R1 * Ra1) * (-0.5 * dt * 0.5 * dt);
-      put33(Vm, 46, 6, 0, R0 * (0.5 * dt));
-      put33(Vm, 46, 6, 3, VvG);
-      put33(Vm, 46, 6, 6, R1 * (0.5 * dt));
-      put33(Vm, 46, 6, 9, VvG);
+      put33(Vm, VLD, 6, 0, R0 * (0.5 * dt));
+      put33(Vm, VLD, 6, 3, VvG);
+      put33(Vm, VLD, 6, 6, R1 * (0.5 * dt));
+      put33(Vm, VLD, 6, 9, VvG);
     } else if (lane >= 1 && lane <= 4) {
       const int j = lane - 1, e = 9 + 3 * j;
       const v3 vi = ld3(lt[2 * j].v), vi1 = ld3(lt[2 * j + 1].v), fi = ld3(lt[2 * j].f), fi1 = ld3(lt[2 * j + 1].f);
       const m3 Ji = ld_m3_rowmajor(lt[2 * j].J), Ji1 = ld_m3_rowmajor(lt[2 * j + 1].J);
       const m3 hi = ld_m3_rowmajor(lt[2 * j].h), hi1 = ld_m3_rowmajor(lt[2 * j + 1].h);
       const v3 gi = ld3(lt[2 * j].g), gi1 = ld3(lt[2 * j + 1].g);
-      put33(Fm, 31, e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
-      put33(Fm, 31, e, e, I3);
-      put33(Fm, 31, e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(pbr + Rbr * fi) + R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
+      put33(Fm, FLD, e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
+      put33(Fm, FLD, e, e, I3);
+      put33(Fm, FLD, e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(pbr + Rbr * fi) + R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
       const v3 gsum = (gi + gi1) * (0.5 * dt);
-      Fm[(e + 0) * 31 + 27 + j] = gsum.x; Fm[(e + 1) * 31 + 27 + j] = gsum.y; Fm[(e + 2) * 31 + 27 + j] = gsum.z;
-      put33(Vm, 46, e, 3, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R0 * skew(pbr + Rbr * fi)) * (0.5 * dt));
-      put33(Vm, 46, e, 9, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
-      put33(Vm, 46, e, 18, hi * (-0.5 * dt));
-      put33(Vm, 46, e, 21, hi1 * (-0.5 * dt));
-      put33(Vm, 46, e, 24, (R0 * Rbr * Ji) * (-0.5 * dt));
-      put33(Vm, 46, e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
-      put33(Vm, 46, e, 30 + 3 * j, I3 * (-dt));
+      Fm[(e + 0) * FLD + 27 + j] = gsum.x; Fm[(e + 1) * FLD + 27 + j] = gsum.y; Fm[(e + 2) * FLD + 27 + j] = gsum.z;
+      put33(Vm, VLD, e, 3, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R0 * skew(pbr + Rbr * fi)) * (0.5 * dt));
+      put33(Vm, VLD, e, 9, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
+      put33(Vm, VLD, e, 18, hi * (-0.5 * dt));
+      put33(Vm, VLD, e, 21, hi1 * (-0.5 * dt));
+      put33(Vm, VLD, e, 24, (R0 * Rbr * Ji) * (-0.5 * dt));
+      put33(Vm, VLD, e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
+      put33(Vm, VLD, e, 30 + 3 * j, I3 * (-dt));
     } else if (lane == 5) {
-      put33(Fm, 31, 21, 21, I3);
-      put33(Fm, 31, 24, 24, I3);
-      for (int j = 0; j < 4; ++j) { Fm[(27 + j) * 31 + 27 + j] = 1.0; Vm[(27 + j) * 46 + 42 + j] = -dt; }
-      put33(Vm, 46, 21, 12, I3 * (-dt));
-      put33(Vm, 46, 24, 15, I3 * (-dt));
+      put33(Fm, FLD, 21, 21, I3);
+      put33(Fm, FLD, 24, 24, I3);
+      for (int j = 0; j < 4; ++j) { Fm[(27 + j) * FLD + 27 + j] = 1.0; Vm[(27 + j) * VLD + 42 + j] = -dt; }
+      put33(Vm, VLD, 21, 12, I3 * (-dt));
+      put33(Vm, VLD, 24, 15, I3 * (-dt));
     }
     __syncthreads();
-    jac_cov_update<31, 46>(Fm, Vm, nd, Jm, Pm, Qm);
+    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, Qm);
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
@@ -291,8 +345,8 @@ __device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *s
     }
   }
   for (int e = lane; e < 31 * 31; e += 64) {
-    o.jacobian[e] = Jm[(e / 31) * 32 + (e % 31)];
-    o.covariance[e] = Pm[(e / 31) * 32 + (e % 31)];
+    o.jacobian[e] = Jm[(e / 31) * FLD + (e % 31)];
+    o.covariance[e] = Pm[(e / 31) * FLD + (e % 31)];
   }
 }
 
