@@ -10,6 +10,7 @@
 //   * eigen-decomposes A' and emits J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b' (:297-305).
 // Address-keyed bookkeeping (addr_shift, estimator.cpp:1358-1370) is replaced by integer block ids.
 #include <algorithm>
+#include <chrono>
 
 #include "solver_types.hpp"
 
@@ -957,18 +958,28 @@ extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_des
   if (!ctx || W <= 0 || !in || !inout || !opts) return VILO_ERR_BAD_ARG;
   if (marginalization_flag && !next_prior) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
+  const bool timing = getenv("VILO_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   vilo_batch *bt = nullptr;
   int rc = vilo_batch_create(ctx, W, in, inout, &bt);
   if (rc != VILO_OK) return rc;
+  const double t1 = now();
   rc = vilo_batch_solve(ctx, bt, opts);
+  const double t2 = now();
   if (rc == VILO_OK) rc = vilo_gauge_fix_batch(ctx, *vilo_batch_dev(bt));
   if (rc == VILO_OK) rc = vilo_batch_download(ctx, bt, inout, summaries);
+  const double t3 = now();
   if (rc == VILO_OK && marginalization_flag) {
     // the reference only marginalises full windows (estimator.cpp:1243-1244)
     std::vector<int> modes(W);
     for (int w = 0; w < W; ++w) modes[w] = (in[w].n_frames == VILO_MAX_FRAMES) ? marginalization_flag[w] : -1;
     rc = marginalize_batch(ctx, bt, W, in, inout, modes.data(), next_prior);
   }
+  const double t4 = now();
   vilo_batch_destroy(ctx, bt);
+  if (timing)
+    fprintf(stderr, "[vilo_optimize_windows] W=%d create %.2f ms, solve %.2f ms, gauge fix + download %.2f ms, marginalise %.2f ms (kernels %.2f), destroy %.2f ms\n", W,
+            t1 - t0, t2 - t1, t3 - t2, t4 - t3, ctx->last_marg_ms, now() - t4);
   return rc;
 }

@@ -15,7 +15,9 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o);
 
 struct vilo_batch {
   BatchDev d;
-  std::vector<void *> allocs;
+  std::vector<std::pair<void *, size_t>> chunks_dev;   // arena chunks (from / back to ctx->pool_free)
+  char *cur = nullptr;
+  size_t cur_left = 0;
   std::vector<int> lm_off_host;     // per window
   std::vector<int> perm_host;       // device order -> original landmark index (per window, concatenated)
   std::vector<int> L_host;
@@ -30,15 +32,37 @@ struct vilo_batch {
 
 namespace {
 
+// bump allocation out of 64 MB (or larger) arena chunks; chunks are recycled through the context's free list
+int dev_alloc_bytes(vilo_ctx *ctx, vilo_batch *bt, void **p, size_t bytes) {
+  *p = nullptr;
+  bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  if (bt->cur_left < bytes) {
+    const size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool_free.size(); ++i)
+      if (ctx->pool_free[i].second >= bytes && (best < 0 || ctx->pool_free[i].second < ctx->pool_free[best].second)) best = i;
+    std::pair<void *, size_t> ch;
+    if (best >= 0) {
+      ch = ctx->pool_free[best];
+      ctx->pool_free.erase(ctx->pool_free.begin() + best);
+    } else {
+      void *q = nullptr;
+      VILO_HIP(hipMalloc(&q, want));
+      ch = {q, want};
+    }
+    bt->chunks_dev.push_back(ch);
+    bt->cur = (char *)ch.first; bt->cur_left = ch.second;
+  }
+  *p = bt->cur;
+  bt->cur += bytes; bt->cur_left -= bytes;
+  return VILO_OK;
+}
 template <class T>
 int dev_alloc(vilo_ctx *ctx, vilo_batch *bt, T **p, size_t n) {
-  *p = nullptr;
-  if (n == 0) n = 1;
   void *q = nullptr;
-  VILO_HIP(hipMalloc(&q, n * sizeof(T)));
-  bt->allocs.push_back(q);
+  int rc = dev_alloc_bytes(ctx, bt, &q, std::max<size_t>(n, 1) * sizeof(T));
   *p = (T *)q;
-  return VILO_OK;
+  return rc;
 }
 template <class T>
 int dev_upload(vilo_ctx *ctx, vilo_batch *bt, T **p, const std::vector<T> &h) {
@@ -119,7 +143,12 @@ extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
   if (!bt) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   if (bt->gexec) (void)hipGraphExecDestroy(bt->gexec);
-  for (void *p : bt->allocs) (void)hipFree(p);
+  if (ctx) {
+    (void)hipStreamSynchronize(ctx->stream);   // nothing of this batch may still be running when its memory is handed on
+    for (auto &c : bt->chunks_dev) ctx->pool_free.push_back(c);
+  } else {
+    for (auto &c : bt->chunks_dev) (void)hipFree(c.first);
+  }
   delete bt;
 }
 
@@ -141,7 +170,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   std::vector<double> x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<double> px0((size_t)W * 280, 0.0);
   // J0 / r0 of the priors, packed n x n per window, staged for k_prior_pack (uninitialised storage: only n x n of a slot is read)
-  std::unique_ptr<double[]> pJ(new double[(size_t)W * 96 * 96]), pr0(new double[(size_t)W * 96]);
+  double *pJ = (double *)vilo_host_stage(ctx, 0, sizeof(double) * (size_t)W * 96 * 96), *pr0 = (double *)vilo_host_stage(ctx, 1, sizeof(double) * (size_t)W * 96);
   bool any_prior = false;
   std::vector<unsigned char> iskip((size_t)W * 10, 0);
   std::vector<int> pmap((size_t)W * 96, 0), pbs((size_t)W * 40, 0), pbi((size_t)W * 40, 0), pbx((size_t)W * 40, 0), pbst((size_t)W * 40, 0);
@@ -234,8 +263,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     }
   }
   // ---- pass 2 (one host thread per slice of windows): the heavy copies — wave-packed observation image, states, prior staging ----
-  std::unique_ptr<double[]> obs(new double[std::max<size_t>(1, obs_total)]);
-  std::unique_ptr<unsigned char[]> flags(new unsigned char[std::max<size_t>(1, flags_total)]);
+  double *obs = (double *)vilo_host_stage(ctx, 2, sizeof(double) * std::max<size_t>(1, obs_total));
+  unsigned char *flags = (unsigned char *)vilo_host_stage(ctx, 3, std::max<size_t>(1, flags_total));
+  if (!pJ || !pr0 || !obs || !flags) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   std::vector<int> win_err(W, 0);
   auto fill_window = [&](int w) {
     const vilo_window_desc &d = in[w];
@@ -253,8 +283,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     for (int wi = wm.wave_off; wi < wm.wave_off + wm.n_waves; ++wi) {
       const WaveMeta &wv = waves[wi];
       const int lanes = wv.n_lanes;
-      double *ob = obs.get() + wv.obs_off;
-      unsigned char *fl = flags.get() + wv.flag_off;
+      double *ob = obs + wv.obs_off;
+      unsigned char *fl = flags + wv.flag_off;
       memset(ob, 0, sizeof(double) * (size_t)wv.kmax * 11 * lanes);
       memset(fl, 0, (size_t)wv.kmax * lanes);
       for (int g = 0; g < wv.nseg; ++g) {
@@ -292,8 +322,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         xo += gs;
       }
       wm.pad = bframe;
-      memcpy(pJ.get() + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
-      memcpy(pr0.get() + (size_t)w * 96, p.r0, sizeof(double) * n);
+      memcpy(pJ + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
+      memcpy(pr0 + (size_t)w * 96, p.r0, sizeof(double) * n);
     }
   };
   {
@@ -320,8 +350,8 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   TRYB(dev_upload(ctx, bt, &D.win, wins));
   TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
   TRYB(dev_upload(ctx, bt, &D.wave, waves));
-  TRYB(dev_upload_raw(ctx, bt, &D.obs, obs.get(), obs_total));
-  TRYB(dev_upload_raw(ctx, bt, &D.flags, flags.get(), flags_total));
+  TRYB(dev_upload_raw(ctx, bt, &D.obs, obs, obs_total));
+  TRYB(dev_upload_raw(ctx, bt, &D.flags, flags, flags_total));
   TRYB(dev_upload(ctx, bt, &D.x0, x0));
   TRYB(dev_upload(ctx, bt, &D.lam0, lam0));
   TRYB(dev_upload(ctx, bt, &D.lm_perm, bt->perm_host));
@@ -374,12 +404,10 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
   }
   if (any_prior) {
     double *d_J = nullptr, *d_r = nullptr;
-    if (hipMalloc((void **)&d_J, sizeof(double) * (size_t)W * 96 * 96) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
-    bt->allocs.push_back(d_J);
-    if (hipMalloc((void **)&d_r, sizeof(double) * (size_t)W * 96) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
-    bt->allocs.push_back(d_r);
-    if (hipMemcpyAsync(d_J, pJ.get(), sizeof(double) * (size_t)W * 96 * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(d_r, pr0.get(), sizeof(double) * (size_t)W * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    TRYB(dev_alloc(ctx, bt, &d_J, (size_t)W * 96 * 96));
+    TRYB(dev_alloc(ctx, bt, &d_r, (size_t)W * 96));
+    if (hipMemcpyAsync(d_J, pJ, sizeof(double) * (size_t)W * 96 * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_r, pr0, sizeof(double) * (size_t)W * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
     hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
     if (hipGetLastError() != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   }
@@ -391,7 +419,7 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     void *d_pre = nullptr;
     const size_t rec = leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu);
     const size_t bytes = rec * (size_t)W * 10;
-    if (hipMalloc(&d_pre, bytes) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    if (dev_alloc_bytes(ctx, bt, &d_pre, bytes) != VILO_OK) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }   // arena: lives as long as the batch
     int rc = VILO_OK;
     // records go from the caller's arrays straight to the device (a staged host copy of W x 156 KB costs more than the W copies)
     bool partial = false;
@@ -406,7 +434,6 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     if (rc == VILO_OK && !leg) rc = vilo_launch_embed_sqrt15(ctx, D);
     if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
     if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
-    (void)hipFree(d_pre);
     if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
   }
   const double t_prep = now();

@@ -69,6 +69,8 @@ extern "C" void vilo_destroy(vilo_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
+  for (auto &c : ctx->pool_free) (void)hipFree(c.first);
+  for (auto &h : ctx->host_stage) free(h.first);
   for (hipEvent_t e : ctx->pev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vilo_gpu.h"
@@ -25,6 +26,11 @@ struct vilo_ctx {
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   double last_solve_ms;
+  // device memory pool: batches are built and torn down once per image in a replay; their arena chunks come from and return to
+  // this free list (grow-only, released by vilo_destroy) instead of ~65 hipMalloc / hipFree per batch
+  std::vector<std::pair<void *, size_t>> pool_free;
+  // reusable host staging (grow-only): the wave-packed observation image and the prior staging of vilo_batch_create
+  std::vector<std::pair<void *, size_t>> host_stage;
   double last_marg_ms = 0.0;       // GPU time of the last vilo_marginalize (linearisation + marginalisation kernels)
   int marg_general_count = 0;      // windows of the last vilo_marginalize that took the global-memory eigen path
   std::string err;
@@ -37,6 +43,18 @@ struct vilo_ctx {
   long long kernel_launches[8];
 };
 #define VILO_NKERNEL 8
+
+// grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified)
+inline void *vilo_host_stage(vilo_ctx *ctx, int slot, size_t bytes) {
+  if ((int)ctx->host_stage.size() <= slot) ctx->host_stage.resize(slot + 1, {nullptr, 0});
+  auto &hs = ctx->host_stage[slot];
+  if (hs.second < bytes) {
+    free(hs.first);
+    hs.second = bytes + bytes / 4;
+    hs.first = malloc(hs.second);
+  }
+  return hs.first;
+}
 
 
 #define VILO_HIP(call)                                                                                   \
