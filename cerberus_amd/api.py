@@ -133,6 +133,37 @@ class PreintStreams:
             pass
 
 
+class PriorPool:
+    """vilo_prior_pool: last_marginalization_info objects whose J0 / r0 stay on the device between frames."""
+
+    def __init__(self, ctx, n_slots):
+        self.ctx, self.n = ctx, n_slots
+        self.h = C.c_void_p()
+        ctx._check(lib().vilo_prior_pool_create(ctx.h, n_slots, C.byref(self.h)))
+
+    def upload(self, slot, prior):
+        self.ctx._check(lib().vilo_prior_pool_upload(self.ctx.h, self.h, slot, C.byref(prior.struct) if prior is not None else None))
+
+    def download(self, slot, prior_out):
+        prior_out.rebind()
+        self.ctx._check(lib().vilo_prior_pool_download(self.ctx.h, self.h, slot, C.byref(prior_out.struct)))
+        return prior_out
+
+    def dim(self, slot):
+        return lib().vilo_prior_pool_dim(self.h, slot)
+
+    def close(self):
+        if self.h:
+            lib().vilo_prior_pool_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, cfg, device=0):
         self.cfg = cfg

@@ -605,6 +605,25 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   stamp(6);
 }
 
+// new priors of pooled windows: device to device into their slot (n x n packed, ld n); src >= 0: the unchanged prior moves
+// from slot src to slot dst (MARGIN_SECOND_NEW with nothing to drop)
+__global__ void __launch_bounds__(256) k_prior_scatter(int W, const MargWin *mw, const int *dst, const int *src, const double *J0, const double *r0, double *pJ,
+                                                       double *pr) {
+  const int w = blockIdx.x;
+  if (w >= W || dst[w] < 0) return;
+  double *dj = pJ + (size_t)dst[w] * 96 * 96, *dr = pr + (size_t)dst[w] * 96;
+  if (src[w] >= 0) {
+    const double *sj = pJ + (size_t)src[w] * 96 * 96, *sr = pr + (size_t)src[w] * 96;
+    for (int e = threadIdx.x; e < 96 * 96; e += 256) dj[e] = sj[e];
+    for (int e = threadIdx.x; e < 96; e += 256) dr[e] = sr[e];
+    return;
+  }
+  const int n = mw[w].n;
+  const double *sj = J0 + (size_t)w * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, *sr = r0 + (size_t)w * VILO_MAX_PRIOR_DIM;
+  for (int e = threadIdx.x; e < n * n; e += 256) dj[e] = sj[e];
+  for (int e = threadIdx.x; e < n; e += 256) dr[e] = sr[e];
+}
+
 __device__ v3 R2ypr_deg(const m3 &R) {
   const v3 nn = mk3(R.a[0], R.a[3], R.a[6]), o = mk3(R.a[1], R.a[4], R.a[7]), a = mk3(R.a[2], R.a[5], R.a[8]);
   const double y = atan2(nn.y, nn.x);
@@ -732,8 +751,8 @@ const int *vilo_batch_perm(vilo_batch *bt, int win, int *L);
 // Marginalisation of every window of an existing batch at its current device state (b.x, b.lam). `state` holds the same
 // values on the host (they become keep_block_data of the new prior); modes[w]: 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW, < 0 skip
 // (out[w] untouched). The batch is left alive.
-static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_window_desc *in, const vilo_window_state *state, const int *modes,
-                             vilo_prior *out) {
+static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, const vilo_window_state *state,
+                             const int *modes, vilo_prior *out) {
   int rc = VILO_OK;
   BatchDev &bd = *vilo_batch_dev(bt);
   std::vector<MargWin> mws(W);
@@ -751,17 +770,19 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     if (mode < 0) { M.m = 0; M.n = 0; M.mode = 0; skip[w] = 1; continue; }
     M.mode = mode;
     const int F = d.n_frames, WS = F - 1;
-    const bool has_prior = d.prior && d.prior->valid && d.prior->n > 0;
-    M.prior_n = has_prior ? d.prior->n : 0;
+    const vilo_resident_refs *rf = refs ? refs + w : nullptr;
+    const vilo_prior *prw = vilo_win_prior(d, rf);
+    const bool has_prior = prw && prw->valid && prw->n > 0;
+    M.prior_n = has_prior ? prw->n : 0;
     // which camera blocks take part (id = kind*16 + index), in the oracle's canonical order
     std::vector<int> present;   // block ids
     auto mark = [&](int id) { if (std::find(present.begin(), present.end(), id) == present.end()) present.push_back(id); };
     if (has_prior)
-      for (int k = 0; k < d.prior->n_blocks; ++k) mark(d.prior->block_id[k]);
+      for (int k = 0; k < prw->n_blocks; ++k) mark(prw->block_id[k]);
     std::vector<int> dropped_ids;
     if (mode == 0) {
       const int nkind = d.use_leg ? 3 : 2;   // pose, speed/bias (, leg bias)
-      M.has_imu = (d.use_leg ? d.preint[0].sum_dt : d.preint_imu[0].sum_dt) < 10.0 ? 1 : 0;
+      M.has_imu = vilo_win_sum_dt(d, rf, 0) < 10.0 ? 1 : 0;
       if (M.has_imu)
         for (int kind = 0; kind < nkind; ++kind) { mark(kind * 16 + 0); mark(kind * 16 + 1); }
       int L; const int *perm = vilo_batch_perm(bt, w, &L);
@@ -888,30 +909,60 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       hipEventElapsedTime(&marg_ms, ctx->ev0, ctx->ev1) != hipSuccess)
     return fail(VILO_ERR_HIP);
   ctx->last_marg_ms = marg_ms;
-  std::vector<double> J0((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM), r0((size_t)W * VILO_MAX_PRIOR_DIM);
+  // windows with a prior pool leave J0 / r0 on the device (slot next_prior_slot); only their kept-block bookkeeping is host side
+  std::vector<int> dst_slot(W, -1), src_slot(W, -1);
+  bool any_host = false;
+  for (int w = 0; w < W; ++w) {
+    if (skip[w]) continue;
+    if (refs && refs[w].prior_pool) {
+      vilo_prior_pool *pl = refs[w].prior_pool;
+      if (refs[w].next_prior_slot < 0 || refs[w].next_prior_slot >= pl->n) return VILO_ERR_BAD_ARG;
+      if (keep_prior[w]) { if (refs[w].prior_slot != refs[w].next_prior_slot) src_slot[w] = refs[w].prior_slot; else continue; }
+      dst_slot[w] = refs[w].next_prior_slot;
+    } else {
+      any_host = true;
+    }
+  }
+  if (refs && refs[0].prior_pool) {
+    DevBuf d_dst, d_src;
+    if (d_dst.alloc(sizeof(int) * W) != hipSuccess || d_src.alloc(sizeof(int) * W) != hipSuccess ||
+        hipMemcpy(d_dst.p, dst_slot.data(), sizeof(int) * W, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_src.p, src_slot.data(), sizeof(int) * W, hipMemcpyHostToDevice) != hipSuccess)
+      return VILO_ERR_HIP;
+    hipLaunchKernelGGL(k_prior_scatter, dim3(W), dim3(256), 0, ctx->stream, W, d_mw.as<MargWin>(), d_dst.as<int>(), d_src.as<int>(), d_J0.as<double>(), d_r0.as<double>(),
+                       refs[0].prior_pool->dJ, refs[0].prior_pool->dr);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return VILO_ERR_HIP;
+  }
+  std::vector<double> J0, r0((size_t)W * VILO_MAX_PRIOR_DIM);
   int status = 0;
-  if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-    return fail(VILO_ERR_HIP);
+  if (any_host) {
+    J0.resize((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM);
+    if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(VILO_ERR_HIP);
+  }
+  if (hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
     if (skip[w]) continue;
     const int mode = modes[w];
-    vilo_prior &p = out[w];
+    const bool pooled = refs && refs[w].prior_pool;
+    vilo_prior &p = pooled ? refs[w].prior_pool->meta[refs[w].next_prior_slot] : out[w];
     if (keep_prior[w]) {
-      const vilo_prior &q = *in[w].prior;
+      const vilo_prior &q = *vilo_win_prior(in[w], refs ? refs + w : nullptr);
       if (&p != &q) {
         int sum_g = 0;
         for (int k = 0; k < q.n_blocks; ++k) { p.block_id[k] = q.block_id[k]; p.block_size[k] = q.block_size[k]; p.block_idx[k] = q.block_idx[k]; sum_g += q.block_size[k]; }
         p.n = q.n; p.n_blocks = q.n_blocks; p.valid = 1;
         memmove(p.x0, q.x0, sizeof(double) * sum_g);
-        memmove(p.J0, q.J0, sizeof(double) * (size_t)q.n * q.n);
-        memmove(p.r0, q.r0, sizeof(double) * q.n);
+        if (!pooled) {
+          memmove(p.J0, q.J0, sizeof(double) * (size_t)q.n * q.n);
+          memmove(p.r0, q.r0, sizeof(double) * q.n);
+        }
       }
       continue;
     }
-    if (M.m == 0 || M.n == 0) { p.valid = 0; continue; }
+    if (M.m == 0 || M.n == 0) { p.valid = 0; p.n = 0; continue; }
     const int WS = in[w].n_frames - 1;
     p.n = M.n; p.n_blocks = (int)kept_ids[w].size(); p.valid = 1;
     int xo = 0;
@@ -929,6 +980,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       for (int c = 0; c < kept_gs[w][k]; ++c) p.x0[xo + c] = src[c];
       xo += kept_gs[w][k];
     }
+    if (pooled) continue;
     for (int i = 0; i < M.n; ++i) {
       for (int j = 0; j < M.n; ++j) p.J0[(size_t)i * M.n + j] = J0[(size_t)w * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM + (size_t)i * M.n + j];
       p.r0[i] = r0[(size_t)w * VILO_MAX_PRIOR_DIM + i];
@@ -946,23 +998,27 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
   int rc = vilo_batch_create(ctx, W, in, state, &bt);
   if (rc != VILO_OK) return rc;
   std::vector<int> modes(W, mode);
-  rc = marginalize_batch(ctx, bt, W, in, state, modes.data(), out);
+  rc = marginalize_batch(ctx, bt, W, in, nullptr, state, modes.data(), out);
   vilo_batch_destroy(ctx, bt);
   return rc;
 }
 
 // Estimator::optimization() (estimator.cpp:1054-1458) as one call on one device-resident batch: ceres::Solve, double2vector's
 // gauge fix, then the marginalisation linearised at that result.
-extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
-                                     const int *marginalization_flag, vilo_prior *next_prior, vilo_solve_summary *summaries) {
+extern "C" int vilo_optimize_windows_resident(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, vilo_window_state *inout,
+                                              const vilo_solve_opts *opts, const int *marginalization_flag, vilo_prior *next_prior,
+                                              vilo_solve_summary *summaries) {
   if (!ctx || W <= 0 || !in || !inout || !opts) return VILO_ERR_BAD_ARG;
-  if (marginalization_flag && !next_prior) return VILO_ERR_BAD_ARG;
+  if (marginalization_flag && !next_prior) {
+    for (int w = 0; w < W; ++w)
+      if (!refs || !refs[w].prior_pool) return VILO_ERR_BAD_ARG;
+  }
   VILO_HIP(hipSetDevice(ctx->device));
   const bool timing = getenv("VILO_HOST_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   vilo_batch *bt = nullptr;
-  int rc = vilo_batch_create(ctx, W, in, inout, &bt);
+  int rc = vilo_batch_create_refs(ctx, W, in, refs, inout, &bt);
   if (rc != VILO_OK) return rc;
   const double t1 = now();
   rc = vilo_batch_solve(ctx, bt, opts);
@@ -974,7 +1030,7 @@ extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_des
     // the reference only marginalises full windows (estimator.cpp:1243-1244)
     std::vector<int> modes(W);
     for (int w = 0; w < W; ++w) modes[w] = (in[w].n_frames == VILO_MAX_FRAMES) ? marginalization_flag[w] : -1;
-    rc = marginalize_batch(ctx, bt, W, in, inout, modes.data(), next_prior);
+    rc = marginalize_batch(ctx, bt, W, in, refs, inout, modes.data(), next_prior);
   }
   const double t4 = now();
   vilo_batch_destroy(ctx, bt);
@@ -982,4 +1038,79 @@ extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_des
     fprintf(stderr, "[vilo_optimize_windows] W=%d create %.2f ms, solve %.2f ms, gauge fix + download %.2f ms, marginalise %.2f ms (kernels %.2f), destroy %.2f ms\n", W,
             t1 - t0, t2 - t1, t3 - t2, t4 - t3, ctx->last_marg_ms, now() - t4);
   return rc;
+}
+
+// Estimator::optimization() (estimator.cpp:1054-1458) as one call on one device-resident batch: ceres::Solve, double2vector's
+// gauge fix, then the marginalisation linearised at that result.
+extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
+                                     const int *marginalization_flag, vilo_prior *next_prior, vilo_solve_summary *summaries) {
+  if (marginalization_flag && !next_prior) return VILO_ERR_BAD_ARG;
+  return vilo_optimize_windows_resident(ctx, W, in, nullptr, inout, opts, marginalization_flag, next_prior, summaries);
+}
+
+// ---- prior pool ----
+extern "C" int vilo_prior_pool_create(vilo_ctx *ctx, int n, vilo_prior_pool **out) {
+  if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  vilo_prior_pool *pl = new vilo_prior_pool();
+  pl->n = n; pl->device = ctx->device; pl->dJ = pl->dr = nullptr;
+  if (hipMalloc((void **)&pl->dJ, sizeof(double) * (size_t)n * 96 * 96) != hipSuccess || hipMalloc((void **)&pl->dr, sizeof(double) * (size_t)n * 96) != hipSuccess) {
+    if (pl->dJ) (void)hipFree(pl->dJ);
+    delete pl;
+    ctx->err = "vilo_prior_pool_create: allocation failed";
+    return VILO_ERR_HIP;
+  }
+  pl->meta.resize(n);
+  pl->x0_store.assign((size_t)n * 7 * VILO_MAX_PRIOR_BLOCKS, 0.0);
+  for (int i = 0; i < n; ++i) {
+    memset(&pl->meta[i], 0, sizeof(vilo_prior));
+    pl->meta[i].x0 = &pl->x0_store[(size_t)i * 7 * VILO_MAX_PRIOR_BLOCKS];
+  }
+  *out = pl;
+  return VILO_OK;
+}
+extern "C" void vilo_prior_pool_destroy(vilo_ctx *ctx, vilo_prior_pool *pl) {
+  if (!pl) return;
+  (void)ctx;
+  (void)hipSetDevice(pl->device);
+  (void)hipFree(pl->dJ);
+  (void)hipFree(pl->dr);
+  delete pl;
+}
+extern "C" int vilo_prior_pool_dim(const vilo_prior_pool *pl, int slot) {
+  if (!pl || slot < 0 || slot >= pl->n || !pl->meta[slot].valid) return 0;
+  return pl->meta[slot].n;
+}
+extern "C" int vilo_prior_pool_upload(vilo_ctx *ctx, vilo_prior_pool *pl, int slot, const vilo_prior *p) {
+  if (!ctx || !pl || slot < 0 || slot >= pl->n) return VILO_ERR_BAD_ARG;
+  vilo_prior &m = pl->meta[slot];
+  if (!p || !p->valid || p->n <= 0) { m.valid = 0; m.n = 0; m.n_blocks = 0; return VILO_OK; }
+  if (p->n > VILO_MAX_PRIOR_DIM || p->n_blocks > VILO_MAX_PRIOR_BLOCKS || !p->x0 || !p->J0 || !p->r0) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  double *x0 = m.x0;
+  m = *p;
+  m.x0 = x0; m.J0 = nullptr; m.r0 = nullptr;
+  int sum_g = 0;
+  for (int k = 0; k < p->n_blocks; ++k) sum_g += p->block_size[k];
+  memcpy(m.x0, p->x0, sizeof(double) * sum_g);
+  VILO_HIP(hipMemcpy(pl->dJ + (size_t)slot * 96 * 96, p->J0, sizeof(double) * (size_t)p->n * p->n, hipMemcpyHostToDevice));
+  VILO_HIP(hipMemcpy(pl->dr + (size_t)slot * 96, p->r0, sizeof(double) * p->n, hipMemcpyHostToDevice));
+  return VILO_OK;
+}
+extern "C" int vilo_prior_pool_download(vilo_ctx *ctx, vilo_prior_pool *pl, int slot, vilo_prior *out) {
+  if (!ctx || !pl || !out || slot < 0 || slot >= pl->n) return VILO_ERR_BAD_ARG;
+  const vilo_prior &m = pl->meta[slot];
+  double *x0 = out->x0, *J0 = out->J0, *r0 = out->r0;
+  if (!m.valid || m.n <= 0) { out->valid = 0; out->n = 0; out->n_blocks = 0; return VILO_OK; }
+  if (!x0 || !J0 || !r0) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  *out = m;
+  out->x0 = x0; out->J0 = J0; out->r0 = r0;
+  int sum_g = 0;
+  for (int k = 0; k < m.n_blocks; ++k) sum_g += m.block_size[k];
+  memcpy(x0, m.x0, sizeof(double) * sum_g);
+  VILO_HIP(hipMemcpy(J0, pl->dJ + (size_t)slot * 96 * 96, sizeof(double) * (size_t)m.n * m.n, hipMemcpyDeviceToHost));
+  VILO_HIP(hipMemcpy(r0, pl->dr + (size_t)slot * 96, sizeof(double) * m.n, hipMemcpyDeviceToHost));
+  return VILO_OK;
 }

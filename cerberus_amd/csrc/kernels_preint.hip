@@ -7,6 +7,16 @@
 
 using namespace vilo;
 
+// A device-resident IMULegIntegrationBase (imu_leg_integration_base.h:73-128): public state, the previous sample
+// (acc_0, gyr_0, phi_0, dphi_0, c_0) and the contact-type-2 force filter
+struct PreintStream {
+  vilo_preint rec;
+  vilo_sample last;
+  double ff_min[4], ff_max[4], ff_win[20], ff_var[4];
+  int ff_idx[4];
+  int n_pushed, pad;
+};
+
 namespace {
 
 // jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (:467-468 / integration_base.h:136-137)
@@ -105,15 +115,6 @@ struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
   double f[3], J[9], v[3], g[3], h[9];
 };
 
-// A device-resident IMULegIntegrationBase (imu_leg_integration_base.h:73-128): public state, the previous sample
-// (acc_0, gyr_0, phi_0, dphi_0, c_0) and the contact-type-2 force filter
-struct PreintStream {
-  vilo_preint rec;
-  vilo_sample last;
-  double ff_min[4], ff_max[4], ff_win[20], ff_var[4];
-  int ff_idx[4];
-  int n_pushed, pad;
-};
 
 }  // namespace
 
@@ -385,11 +386,11 @@ __global__ void __launch_bounds__(64) k_preint_stream_reset(int n, const int *id
   }
 }
 
-__global__ void k_preint_stream_gather(int n, const int *ids, const PreintStream *streams, vilo_preint *out) {
+__global__ void k_preint_stream_gather(int n, const int *ids, const int *dst_idx /* null: f */, const PreintStream *streams, vilo_preint *out) {
   const int f = blockIdx.x;
   if (f >= n) return;
   const double *src = (const double *)&streams[ids[f]].rec;
-  double *dst = (double *)(out + f);
+  double *dst = (double *)(out + (dst_idx ? dst_idx[f] : f));
   for (int e = threadIdx.x; e < (int)(sizeof(vilo_preint) / sizeof(double)); e += blockDim.x) dst[e] = src[e];
 }
 
@@ -510,10 +511,6 @@ extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *sa
 }
 
 // ---- device-resident, incrementally updated preintegration (the reference's push_back as samples arrive, estimator.cpp:619-626) ----
-struct vilo_preint_streams {
-  int n, device;
-  PreintStream *d;
-};
 
 extern "C" int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **out) {
   if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
@@ -589,9 +586,16 @@ extern "C" int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *s, i
   DevBuf d_i, d_out;
   VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_out.alloc(sizeof(vilo_preint) * (size_t)n));
   VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_i.as<int>(), (const PreintStream *)s->d, d_out.as<vilo_preint>());
+  hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_i.as<int>(), (const int *)nullptr, (const PreintStream *)s->d, d_out.as<vilo_preint>());
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(vilo_preint) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
+
+// records of device-resident objects straight into a batch's record array (device to device): d_ids / d_dst are device arrays
+int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, vilo_preint *d_out) {
+  hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_ids, d_dst, (const PreintStream *)pool->d, d_out);
+  VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

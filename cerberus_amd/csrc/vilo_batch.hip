@@ -81,6 +81,16 @@ int dev_upload_raw(vilo_ctx *ctx, vilo_batch *bt, T **p, const T *h, size_t n) {
 #define TRYB(x) do { int rc_ = (x); if (rc_ != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc_; } } while (0)
 
 
+// J0 / r0 of the windows whose prior lives in a pool slot: device-to-device into the staging k_prior_pack reads
+__global__ void __launch_bounds__(256) k_prior_gather(int W, const WinMeta *win, const int *slot, const double *pJ, const double *pr, double *J0s, double *r0s) {
+  const int w = blockIdx.x;
+  if (w >= W || slot[w] < 0) return;
+  const int n = win[w].prior_n;
+  const double *sj = pJ + (size_t)slot[w] * 96 * 96, *sr = pr + (size_t)slot[w] * 96;
+  for (int e = threadIdx.x; e < n * n; e += 256) J0s[(size_t)w * 96 * 96 + e] = sj[e];
+  for (int e = threadIdx.x; e < n; e += 256) r0s[(size_t)w * 96 + e] = sr[e];
+}
+
 // MarginalizationFactor (marginalization_factor.cpp:335-395) in normal-equation form, per window: H = J0^T J0 (n x n, ld n),
 // b0 = J0^T r0, c0 = r0^T r0, and H scattered into the solver's pre-assembled camera image (PD_* layout).
 __global__ void __launch_bounds__(256) k_prior_pack(int W, const WinMeta *win, const double *J0s /*[W][96*96], n x n packed*/,
@@ -152,7 +162,14 @@ extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
   delete bt;
 }
 
+int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, vilo_preint *d_out);
+
 extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *init, vilo_batch **out) {
+  return vilo_batch_create_refs(ctx, W, in, nullptr, init, out);
+}
+
+// refs (optional, [W]): device-resident preintegration objects / prior slots instead of the host records of the descs
+int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, const vilo_window_state *init, vilo_batch **out) {
   if (!ctx || !in || !init || !out || W <= 0) return VILO_ERR_BAD_ARG;
   *out = nullptr;
   VILO_HIP(hipSetDevice(ctx->device));
@@ -188,7 +205,12 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     }
     if ((d.use_leg != 0) != (in[0].use_leg != 0)) { ctx->err = "all windows of a batch must use the same IMU factor kind (use_leg)"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
     if (!d.use_leg && !d.preint_imu) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
-    if ((d.use_leg && !d.preint) || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
+    const vilo_resident_refs *rf = refs ? refs + w : nullptr;
+    if (rf && rf->preint_pool && (!d.use_leg || !rf->preint_ids || !rf->preint_sum_dt || rf->preint_pool != refs[0].preint_pool)) {
+      ctx->err = "resident preintegration: IMU-leg windows only, one pool per batch"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED;
+    }
+    if (rf && rf->prior_pool && rf->prior_pool != refs[0].prior_pool) { ctx->err = "one prior pool per batch"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    if ((d.use_leg && !d.preint && !(rf && rf->preint_pool)) || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
       vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
     const int F = d.n_frames, L = d.n_landmarks;
@@ -257,8 +279,9 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     wm.n_waves = (int)waves.size() - wm.wave_off;
     wm.n_gram = gram_total - wm.gram_off;
     lm_total += L;
-    if (d.prior && d.prior->valid && d.prior->n > 0) {
-      if (d.prior->n > VILO_MAX_PRIOR_DIM || d.prior->n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+    const vilo_prior *pr = vilo_win_prior(d, rf);
+    if (pr && pr->valid && pr->n > 0) {
+      if (pr->n > VILO_MAX_PRIOR_DIM || pr->n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
       any_prior = true;
     }
   }
@@ -299,10 +322,12 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         }
       }
     }
-    for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !((d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt) > 10.0)) ? 0 : 1;
+    const vilo_resident_refs *rf = refs ? refs + w : nullptr;
+    for (int k = 0; k < 10; ++k) iskip[(size_t)w * 10 + k] = (k + 1 < F && !(vilo_win_sum_dt(d, rf, k) > 10.0)) ? 0 : 1;
     // prior (MarginalizationFactor, marginalization_factor.cpp:335-395): block tables here, H = J0^T J0, b0 = J0^T r0, c0 = r0^T r0 in k_prior_pack
-    if (d.prior && d.prior->valid && d.prior->n > 0) {
-      const vilo_prior &p = *d.prior;
+    const vilo_prior *pr = vilo_win_prior(d, rf);
+    if (pr && pr->valid && pr->n > 0) {
+      const vilo_prior &p = *pr;
       const int n = p.n;
       wm.prior_n = n; wm.prior_nb = p.n_blocks;
       int xo = 0, bframe = -1;
@@ -322,8 +347,10 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
         xo += gs;
       }
       wm.pad = bframe;
-      memcpy(pJ + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
-      memcpy(pr0 + (size_t)w * 96, p.r0, sizeof(double) * n);
+      if (p.J0) {   // a pool slot keeps J0 / r0 on the device: gathered there, below
+        memcpy(pJ + (size_t)w * 96 * 96, p.J0, sizeof(double) * (size_t)n * n);
+        memcpy(pr0 + (size_t)w * 96, p.r0, sizeof(double) * n);
+      }
     }
   };
   {
@@ -408,6 +435,14 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     TRYB(dev_alloc(ctx, bt, &d_r, (size_t)W * 96));
     if (hipMemcpyAsync(d_J, pJ, sizeof(double) * (size_t)W * 96 * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(d_r, pr0, sizeof(double) * (size_t)W * 96, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+    if (refs && refs[0].prior_pool) {
+      std::vector<int> slot(W, -1);
+      for (int w = 0; w < W; ++w)
+        if (refs[w].prior_pool && refs[w].prior_slot >= 0 && refs[w].prior_slot < refs[w].prior_pool->n && wins[w].prior_n > 0) slot[w] = refs[w].prior_slot;
+      int *d_slot = nullptr;
+      TRYB(dev_upload(ctx, bt, &d_slot, slot));
+      hipLaunchKernelGGL(k_prior_gather, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_slot, refs[0].prior_pool->dJ, refs[0].prior_pool->dr, d_J, d_r);
+    }
     hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
     if (hipGetLastError() != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   }
@@ -425,9 +460,24 @@ extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *i
     bool partial = false;
     for (int w = 0; w < W; ++w) partial = partial || in[w].n_frames < VILO_MAX_FRAMES;
     if (partial && hipMemsetAsync(d_pre, 0, bytes, ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    std::vector<int> g_ids, g_dst;
     for (int w = 0; w < W && rc == VILO_OK; ++w) {
+      if (refs && refs[w].preint_pool) {
+        for (int k = 0; k + 1 < in[w].n_frames; ++k) {
+          const int id = refs[w].preint_ids[k];
+          if (id < 0 || id >= refs[w].preint_pool->n) { rc = VILO_ERR_BAD_ARG; break; }
+          g_ids.push_back(id); g_dst.push_back(w * 10 + k);
+        }
+        continue;
+      }
       const void *src = leg ? (const void *)in[w].preint : (const void *)in[w].preint_imu;
       if (hipMemcpyAsync((char *)d_pre + rec * (size_t)w * 10, src, rec * (size_t)(in[w].n_frames - 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    }
+    if (rc == VILO_OK && !g_ids.empty()) {
+      int *d_gi = nullptr, *d_gd = nullptr;
+      rc = dev_upload(ctx, bt, &d_gi, g_ids);
+      if (rc == VILO_OK) rc = dev_upload(ctx, bt, &d_gd, g_dst);
+      if (rc == VILO_OK) rc = vilo_launch_preint_gather(ctx, refs[0].preint_pool, (int)g_ids.size(), d_gi, d_gd, (vilo_preint *)d_pre);
     }
     if (rc == VILO_OK) rc = leg ? vilo_launch_prepare_preint(ctx, W * 10, (const vilo_preint *)d_pre, D.prep, D.status)
                                 : vilo_launch_prepare_preint_imu(ctx, W * 10, (const vilo_preint_imu *)d_pre, D.prep, D.status);

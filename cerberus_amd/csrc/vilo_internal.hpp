@@ -95,3 +95,27 @@ int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *
 struct BatchDev;
 int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b);
 int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b);
+
+// ---- device-resident hand-over objects (include/vilo_gpu.h) ----
+struct vilo_prior_pool {
+  int n, device;
+  double *dJ, *dr;                 // [n][96*96] (n x n packed, ld n), [n][96]
+  std::vector<vilo_prior> meta;    // host mirror: n, blocks, x0 -> x0_store; J0 = r0 = nullptr (device only)
+  std::vector<double> x0_store;    // [n][7 * VILO_MAX_PRIOR_BLOCKS]
+};
+struct PreintStream;
+struct vilo_preint_streams {
+  int n, device;
+  PreintStream *d;
+};
+// the prior a window sees: the host struct of its desc, or the host mirror of its pool slot
+inline const vilo_prior *vilo_win_prior(const vilo_window_desc &d, const vilo_resident_refs *r) {
+  if (r && r->prior_pool) return (r->prior_slot >= 0 && r->prior_slot < r->prior_pool->n) ? &r->prior_pool->meta[r->prior_slot] : nullptr;
+  return d.prior;
+}
+inline double vilo_win_sum_dt(const vilo_window_desc &d, const vilo_resident_refs *r, int k) {
+  if (r && r->preint_pool) return r->preint_sum_dt[k];
+  return d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt;
+}
+struct vilo_batch;
+int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, const vilo_window_state *init, vilo_batch **out);

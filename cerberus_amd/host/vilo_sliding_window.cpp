@@ -86,12 +86,24 @@ SlidingWindow::PriorStore::PriorStore() : x0(7 * VILO_MAX_PRIOR_BLOCKS), J0((siz
 
 SlidingWindow::SlidingWindow(vilo_ctx *ctx, const vilo_config &cfg, const SlidingWindowOptions &opt)
     : f_manager(opt.features), ctx_(ctx), cfg_(cfg), opt_(opt), pre_(NF), pre_imu_(NF) {
+  resident_ = opt.resident && opt.use_leg && opt.streaming_preintegration && opt.dump_dir.empty();
   clearState();
   g[0] = 0; g[1] = 0; g[2] = cfg.g_norm;
 }
 
 SlidingWindow::~SlidingWindow() {
   if (own_pool_ && pool_) vilo_preint_streams_destroy(ctx_, pool_);
+  if (own_ppool_ && ppool_) vilo_prior_pool_destroy(ctx_, ppool_);
+}
+
+void SlidingWindow::attachPriorPool(vilo_prior_pool *pool, int base_slot) {
+  if (own_ppool_ && ppool_) vilo_prior_pool_destroy(ctx_, ppool_);
+  ppool_ = pool; own_ppool_ = false; pslot_base_ = base_slot;
+}
+
+int SlidingWindow::priorDim() const {
+  if (resident_) return ppool_ ? vilo_prior_pool_dim(ppool_, pslot_base_ + cur_prior_) : 0;
+  return prior_[cur_prior_].p.valid ? prior_[cur_prior_].p.n : 0;
 }
 
 void SlidingWindow::attachStreams(vilo_preint_streams *pool, int base_id) {
@@ -116,6 +128,7 @@ void SlidingWindow::clearState() {
     if (!pool_) sid_[i] = i;
     pushed_[i] = 0;
     need_reset_[i] = false;
+    sum_dt_[i] = 0.0;
     std::memset(lin_[i], 0, sizeof lin_[i]);
   }
   for (int c = 0; c < 2; ++c) {
@@ -124,7 +137,8 @@ void SlidingWindow::clearState() {
   }
   first_imu = false; init_first_pose_flag = false;
   sum_of_back = sum_of_front = 0; frame_count = 0; solver_flag = INITIAL; open_ex_estimation = 0;
-  prior_[0].p.valid = prior_[1].p.valid = 0; cur_prior_ = 0; pending_ = 0; n_optimizations = 0;
+  prior_[0].p.valid = prior_[1].p.valid = 0; cur_prior_ = 0;
+  if (ppool_) { vilo_prior_pool_upload(ctx_, ppool_, pslot_base_, nullptr); vilo_prior_pool_upload(ctx_, ppool_, pslot_base_ + 1, nullptr); } pending_ = 0; n_optimizations = 0;
   std::memset(&last_sample, 0, sizeof last_sample);
   std::memset(&last_summary, 0, sizeof last_summary);
   f_manager.clearState();
@@ -155,6 +169,7 @@ void SlidingWindow::startInterval(int j) {
   cp(lin_[j], Bas[j], 3); cp(lin_[j] + 3, Bgs[j], 3); cp(lin_[j] + 6, Rho[j], 4);
   dirty_[j] = true;
   need_reset_[j] = true; pushed_[j] = 0;
+  sum_dt_[j] = 0.0;
 }
 
 void SlidingWindow::processIMULeg(const vilo_sample &s) {
@@ -167,6 +182,7 @@ void SlidingWindow::processIMULeg(const vilo_sample &s) {
     const int j = frame_count;
     buf_[j].push_back(s);
     dirty_[j] = true;
+    sum_dt_[j] += s.dt;
     // mid-point propagation of the newest frame (estimator.cpp:634-641)
     const double dt = s.dt;
     const v3 gv = ld3(g), ba = ld3(Bas[j]), bg = ld3(Bgs[j]);
@@ -231,7 +247,8 @@ void SlidingWindow::fillDesc() {
   desc_.use_leg = opt_.use_leg;
   desc_.preint = opt_.use_leg ? &pre_[1] : nullptr;
   desc_.preint_imu = opt_.use_leg ? nullptr : &pre_imu_[1];
-  desc_.prior = hasPrior() ? &prior_[cur_prior_].p : nullptr;
+  desc_.prior = (!resident_ && hasPrior()) ? &prior_[cur_prior_].p : nullptr;
+  if (resident_) { desc_.preint = nullptr; }
   // SetParameterBlockConstant decisions, estimator.cpp:1074-1106
   desc_.leg_bias_const = (opt_.use_leg && !opt_.optimize_leg_bias) || frame_count < WS;
   const double v0 = norm(ld3(Vs[0]));
@@ -259,6 +276,8 @@ bool SlidingWindow::beginImage(double header, int n, const int *ids, const doubl
         cp(lin_[i] + 3, Bgs[i], 3); cp(lin_[i] + 6, Rho[i], 4);
         dirty_[i] = true;
         need_reset_[i] = true; pushed_[i] = 0;   // repropagate = constructor + every buffered push_back again
+        sum_dt_[i] = 0.0;
+        for (size_t q = 1; q < buf_[i].size(); ++q) sum_dt_[i] += buf_[i][q].dt;
       }
       pending_ = 1;
       return true;
@@ -334,15 +353,40 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
     if (ws[w]->opt_.use_leg != use_leg || ws[w]->pending_ == 0 || ws[w]->frame_count != WS) return VILO_ERR_BAD_ARG;
   // 1. preintegration of the intervals whose samples or linearisation point changed: one device call sequence for the whole fleet
   bool streaming = use_leg && ws[0]->opt_.streaming_preintegration;
-  if (streaming) {
-    // robots without a pool get one of their own; a fleet shares one pool (then every robot is served by the same three calls)
-    for (int w = 0; w < n; ++w)
-      if (!ws[w]->pool_) {
-        int rc = vilo_preint_streams_create(ctx, NF, &ws[w]->pool_);
+  // robots without pools get their own; a fleet shares pools (then every robot is served by the same few device calls)
+  for (int w = 0; w < n; ++w) {
+    SlidingWindow &s = *ws[w];
+    if (s.opt_.use_leg && s.opt_.streaming_preintegration && !s.pool_) {
+      int rc = vilo_preint_streams_create(ctx, NF, &s.pool_);
+      if (rc != VILO_OK) return rc;
+      s.own_pool_ = true;
+      for (int j = 0; j < NF; ++j) { s.sid_[j] = j; s.need_reset_[j] = !s.buf_[j].empty(); s.pushed_[j] = 0; }
+    }
+    if (s.resident_ && !s.ppool_) {
+      int rc = vilo_prior_pool_create(ctx, 2, &s.ppool_);
+      if (rc != VILO_OK) return rc;
+      s.own_ppool_ = true; s.pslot_base_ = 0;
+    }
+  }
+  // one call serves windows of one kind only (same options, same pools): split a mixed fleet
+  auto same_kind = [](const SlidingWindow &a, const SlidingWindow &b) {
+    return a.resident_ == b.resident_ && a.pool_ == b.pool_ && a.ppool_ == b.ppool_ && a.opt_.streaming_preintegration == b.opt_.streaming_preintegration;
+  };
+  for (int w = 1; w < n; ++w)
+    if (!same_kind(*ws[w], *ws[0])) {
+      std::vector<SlidingWindow *> rest(ws, ws + n), grp;
+      while (!rest.empty()) {
+        grp.clear();
+        std::vector<SlidingWindow *> other;
+        for (SlidingWindow *x : rest) (same_kind(*x, *rest[0]) ? grp : other).push_back(x);
+        const int rc = optimizeBatch(ctx, grp.data(), (int)grp.size());
         if (rc != VILO_OK) return rc;
-        ws[w]->own_pool_ = true;
-        for (int j = 0; j < NF; ++j) { ws[w]->sid_[j] = j; ws[w]->need_reset_[j] = !ws[w]->buf_[j].empty(); ws[w]->pushed_[j] = 0; }
+        rest.swap(other);
       }
+      return VILO_OK;
+    }
+  const bool resident = ws[0]->resident_;
+  if (streaming) {
     for (int w0 = 0; w0 < n;) {
       int w1 = w0 + 1;
       while (w1 < n && ws[w1]->pool_ == ws[w0]->pool_) ++w1;
@@ -366,7 +410,8 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
             offsets.push_back((int32_t)samples.size());
             s.pushed_[j] = have;
           }
-          if (s.dirty_[j]) { gid.push_back(s.sid_[j]); which.push_back({w, j}); }
+          if (s.dirty_[j] && !resident) { gid.push_back(s.sid_[j]); which.push_back({w, j}); }
+          if (resident) s.dirty_[j] = false;
         }
       }
       int rc = vilo_preint_streams_reset(ctx, pool, (int)rid.size(), rid.data(), first.data(), lin.data());
@@ -442,14 +487,22 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   const double t2 = now_ms();
   std::vector<int> flags(n);
   std::vector<vilo_prior> next(n);
+  std::vector<vilo_resident_refs> refs(resident ? n : 0);
   for (int w = 0; w < n; ++w) {
     SlidingWindow &s = *ws[w];
     flags[w] = s.marginalization_flag;
+    if (resident) {
+      vilo_resident_refs &r = refs[w];
+      r.preint_pool = s.pool_; r.preint_ids = &s.sid_[1]; r.preint_sum_dt = &s.sum_dt_[1];
+      r.prior_pool = s.ppool_; r.prior_slot = s.pslot_base_ + s.cur_prior_; r.next_prior_slot = s.pslot_base_ + 1 - s.cur_prior_;
+      continue;
+    }
     PriorStore &nx = s.prior_[1 - s.cur_prior_];
     nx.bind();
     next[w] = nx.p;
   }
-  int rc = vilo_optimize_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), next.data(), sums.data());
+  int rc = resident ? vilo_optimize_windows_resident(ctx, n, descs.data(), refs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), nullptr, sums.data())
+                    : vilo_optimize_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), next.data(), sums.data());
   if (rc != VILO_OK) return rc;
   const double t3 = now_ms();
   std::vector<int> dump_rc(n, 0);
@@ -458,8 +511,10 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
     s.last_summary = sums[w];
     if (!s.opt_.dump_dir.empty()) dump_rc[w] = s.dump(befores[w]);
     s.double2vector();
-    s.prior_[1 - s.cur_prior_].p = next[w];
-    s.prior_[1 - s.cur_prior_].bind();
+    if (!resident) {
+      s.prior_[1 - s.cur_prior_].p = next[w];
+      s.prior_[1 - s.cur_prior_].bind();
+    }
     s.cur_prior_ = 1 - s.cur_prior_;
     ++s.n_optimizations;
   });
@@ -510,6 +565,7 @@ void SlidingWindow::slideWindow() {
       swp(lin_[i], lin_[i + 1]);
       std::swap(dirty_[i], dirty_[i + 1]);
       std::swap(sid_[i], sid_[i + 1]); std::swap(pushed_[i], pushed_[i + 1]); std::swap(need_reset_[i], need_reset_[i + 1]);
+      std::swap(sum_dt_[i], sum_dt_[i + 1]);
     }
     // il_pre_integrations / pre_integrations: the same pointer swap chain as one rotation of the record arrays
     if (opt_.use_leg) std::rotate(pre_.begin(), pre_.begin() + 1, pre_.end());
@@ -524,6 +580,7 @@ void SlidingWindow::slideWindow() {
     cp(Ps[WS - 1], Ps[WS], 3); cp(Rs[WS - 1], Rs[WS], 9);
     // the newest interval is appended to the one before it (estimator.cpp:1581-1599); its constructor sample is not a push
     buf_[WS - 1].insert(buf_[WS - 1].end(), buf_[WS].begin() + 1, buf_[WS].end());
+    for (size_t q = 1; q < buf_[WS].size(); ++q) sum_dt_[WS - 1] += buf_[WS][q].dt;
     dirty_[WS - 1] = true;
     cp(Vs[WS - 1], Vs[WS], 3); cp(Bas[WS - 1], Bas[WS], 3); cp(Bgs[WS - 1], Bgs[WS], 3); cp(Rho[WS - 1], Rho[WS], 4);
     startInterval(WS);
@@ -566,12 +623,14 @@ void *vilo_sw_create(vilo_ctx *ctx, const vilo_config *cfg, const vilo_sw_option
     opt.solve.fixed_iterations = o->fixed_iterations;
     if (o->dump_dir) opt.dump_dir = o->dump_dir;
     opt.streaming_preintegration = o->streaming_preintegration;
+    opt.resident = o->resident;
   }
   opt.features.focal_length = cfg->focal_length;
   return new SlidingWindow(ctx, *cfg, opt);
 }
 void vilo_sw_destroy(void *h) { delete (SlidingWindow *)h; }
 void vilo_sw_attach_streams(void *h, vilo_preint_streams *pool, int base_id) { ((SlidingWindow *)h)->attachStreams(pool, base_id); }
+void vilo_sw_attach_prior_pool(void *h, vilo_prior_pool *pool, int base_slot) { ((SlidingWindow *)h)->attachPriorPool(pool, base_slot); }
 void vilo_sw_set_extrinsics(void *h, const double *t, const double *r, double td) { ((SlidingWindow *)h)->setExtrinsics(t, r, td); }
 void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v) {
   SlidingWindow *s = (SlidingWindow *)h;
@@ -610,7 +669,7 @@ void vilo_sw_get_state(void *h, int *flags, double *Ps, double *Rs, double *Vs, 
   const SlidingWindow *s = (const SlidingWindow *)h;
   if (flags) {
     flags[0] = s->frame_count; flags[1] = s->solver_flag; flags[2] = s->marginalization_flag; flags[3] = s->n_optimizations;
-    flags[4] = s->f_manager.featureCount(); flags[5] = s->hasPrior() ? s->prior().n : 0;
+    flags[4] = s->f_manager.featureCount(); flags[5] = s->priorDim();
   }
   const int NF = SlidingWindow::NF;
   if (Ps) std::memcpy(Ps, s->Ps, sizeof(double) * 3 * NF);

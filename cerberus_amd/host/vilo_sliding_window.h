@@ -33,6 +33,8 @@ namespace vilo {
 
 struct SlidingWindowOptions {
   int use_leg = 1;             // USE_LEG: IMULegFactor (1) or IMUFactor (0)
+  int resident = 1;            // 1 (with streaming preintegration, no dump): the prior and the preintegration records stay on the device
+                               //    between frames (vilo_prior_pool / vilo_preint_streams handles, vilo_optimize_windows_resident)
   int streaming_preintegration = 1;   // 1: intervals live on the device and are push_back()ed (USE_LEG); 0: re-integrate changed intervals
   int optimize_leg_bias = 1;   // OPTIMIZE_LEG_BIAS (estimator.cpp:1074)
   int estimate_extrinsic = 0;  // ESTIMATE_EXTRINSIC (estimator.cpp:1092)
@@ -63,6 +65,8 @@ class SlidingWindow {
   // without a pool a changed interval is re-integrated from its buffer). Robots of a fleet share one pool, one push per image.
   // USE_LEG only. Without a call the window creates a pool of its own on first use.
   void attachStreams(vilo_preint_streams *pool, int base_id);
+  // The same for the marginalisation prior: this robot uses slots base_slot and base_slot + 1 of `pool` alternately.
+  void attachPriorPool(vilo_prior_pool *pool, int base_slot);
   void setInitialVelocity(const double v[3]) { for (int i = 0; i < 3; ++i) Vs[0][i] = v[i]; }   // the reference starts at rest
   void processIMULeg(const vilo_sample &s);   // s.dt as computed at estimator.cpp:456-462
 
@@ -92,8 +96,8 @@ class SlidingWindow {
   std::vector<double> para_Pose, para_SpeedBias, para_LegBias, para_Ex_Pose, para_Td, para_Feature;
   vilo_solve_summary last_summary;
   int n_optimizations = 0;
-  bool hasPrior() const { return prior_[cur_prior_].p.valid != 0; }
-  const vilo_prior &prior() const { return prior_[cur_prior_].p; }
+  int priorDim() const;   // n of last_marginalization_info, 0: none
+  bool hasPrior() const { return priorDim() > 0; }
   int intervalSamples(int j) const { return (int)buf_[j].size(); }
 
  private:
@@ -122,6 +126,11 @@ class SlidingWindow {
   // streaming preintegration: object id of each slot, samples of buf_[j] (after element 0) already pushed, constructor pending
   vilo_preint_streams *pool_ = nullptr;
   bool own_pool_ = false;
+  vilo_prior_pool *ppool_ = nullptr;
+  bool own_ppool_ = false;
+  int pslot_base_ = 0;
+  bool resident_ = false;
+  double sum_dt_[NF];   // host copy of each interval's sum_dt (the 10 s rule of estimator.cpp:1118 needs it without a device read)
   int sid_[NF];
   int pushed_[NF];
   bool need_reset_[NF];
@@ -145,12 +154,13 @@ typedef struct {
   int32_t use_leg, optimize_leg_bias, estimate_extrinsic, estimate_td;
   int32_t max_num_iterations, fixed_iterations;
   const char *dump_dir;   // may be NULL
-  int32_t streaming_preintegration, pad;
+  int32_t streaming_preintegration, resident;
 } vilo_sw_options;
 void *vilo_sw_create(vilo_ctx *ctx, const vilo_config *cfg, const vilo_sw_options *opt);
 void vilo_sw_destroy(void *h);
 // share one pool of device-resident preintegration objects among the robots of a fleet: robot k uses ids 11*k .. 11*k + 10
 void vilo_sw_attach_streams(void *h, vilo_preint_streams *pool, int base_id);
+void vilo_sw_attach_prior_pool(void *h, vilo_prior_pool *pool, int base_slot);   // robot k: slots 2*k, 2*k + 1
 void vilo_sw_set_extrinsics(void *h, const double *tic2x3, const double *ric2x9, double td);
 void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v /* may be NULL */);
 void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *samples, int n);

@@ -16,7 +16,7 @@ MAX_SAMPLES, MAX_FEATURES = 256, 512
 class SwOptions(C.Structure):
     _fields_ = [("use_leg", C.c_int32), ("optimize_leg_bias", C.c_int32), ("estimate_extrinsic", C.c_int32), ("estimate_td", C.c_int32),
                 ("max_num_iterations", C.c_int32), ("fixed_iterations", C.c_int32), ("dump_dir", C.c_char_p),
-                ("streaming_preintegration", C.c_int32), ("pad", C.c_int32)]
+                ("streaming_preintegration", C.c_int32), ("resident", C.c_int32)]
 
 
 class StreamParams(C.Structure):
@@ -40,6 +40,7 @@ def host_lib():
         _host.vilo_sw_create.argtypes = [C.c_void_p, C.POINTER(T.Config), C.POINTER(SwOptions)]
         _host.vilo_sw_destroy.argtypes = [C.c_void_p]
         _host.vilo_sw_attach_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _host.vilo_sw_attach_prior_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _host.vilo_sw_set_extrinsics.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, C.c_double]
         _host.vilo_sw_init_first_pose.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, T.c_double_p]
         _host.vilo_sw_process_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -101,17 +102,22 @@ class SlidingWindow:
     """vilo::SlidingWindow behind its C entry points."""
 
     def __init__(self, ctx, cfg, use_leg=1, optimize_leg_bias=1, estimate_extrinsic=0, estimate_td=0, max_num_iterations=0, fixed_iterations=0,
-                 dump_dir=None, streaming_preintegration=1):
+                 dump_dir=None, streaming_preintegration=1, resident=1):
         self.H, self.ctx = host_lib(), ctx
         self._dump = dump_dir.encode() if dump_dir else None
         o = SwOptions(use_leg, optimize_leg_bias, estimate_extrinsic, estimate_td, max_num_iterations, fixed_iterations, self._dump,
-                      streaming_preintegration, 0)
+                      streaming_preintegration, resident)
         self.h = C.c_void_p(self.H.vilo_sw_create(ctx.h if ctx is not None else None, C.byref(cfg), C.byref(o)))
 
     def attach_streams(self, pool, base_id):
         """pool: api.PreintStreams shared by a fleet; this robot uses objects base_id .. base_id + 10"""
         self._pool = pool
         self.H.vilo_sw_attach_streams(self.h, pool.h, base_id)
+
+    def attach_prior_pool(self, pool, base_slot):
+        """pool: api.PriorPool shared by a fleet; this robot alternates between slots base_slot and base_slot + 1"""
+        self._ppool = pool
+        self.H.vilo_sw_attach_prior_pool(self.h, pool.h, base_slot)
 
     def set_extrinsics(self, tic, ric, td):
         self.H.vilo_sw_set_extrinsics(self.h, _dp(np.ascontiguousarray(tic)), _dp(np.ascontiguousarray(ric)), td)

@@ -263,6 +263,32 @@ int vilo_optimize_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *
                           const vilo_solve_opts *opts, const int *marginalization_flag, vilo_prior *next_prior,
                           vilo_solve_summary *summaries);
 
+/* ---- device-resident hand-over between frames ("a device-resident prior") ----------------------------
+ * last_marginalization_info objects kept in HBM: slot = {n, kept blocks, keep_block_data on the host; linearized_jacobians and
+ * linearized_residuals on the device}. A window then names the slot its prior comes from and the slot the next prior goes to,
+ * and the preintegration objects (vilo_preint_streams) its IMU factors read, instead of carrying 74 KB of J0 and 156 KB of
+ * records through host memory in both directions every frame. */
+typedef struct vilo_prior_pool vilo_prior_pool;
+int vilo_prior_pool_create(vilo_ctx *ctx, int n_slots, vilo_prior_pool **pool);
+void vilo_prior_pool_destroy(vilo_ctx *ctx, vilo_prior_pool *pool);
+int vilo_prior_pool_upload(vilo_ctx *ctx, vilo_prior_pool *pool, int slot, const vilo_prior *prior);   /* NULL / !valid: empties the slot */
+int vilo_prior_pool_download(vilo_ctx *ctx, vilo_prior_pool *pool, int slot, vilo_prior *out);        /* buffers as for vilo_marginalize */
+int vilo_prior_pool_dim(const vilo_prior_pool *pool, int slot);   /* n of the slot, 0: no prior */
+
+typedef struct {
+  vilo_preint_streams *preint_pool;   /* NULL: the window's vilo_window_desc::preint records are used */
+  const int32_t *preint_ids;          /* [n_frames - 1] object of interval k (frames k -> k+1) */
+  const double *preint_sum_dt;        /* [n_frames - 1] their sum_dt, host side (intervals above 10 s carry no factor, estimator.cpp:1118) */
+  vilo_prior_pool *prior_pool;        /* NULL: vilo_window_desc::prior / the next_prior argument are used */
+  int32_t prior_slot;                 /* < 0: no prior */
+  int32_t next_prior_slot;            /* where vilo_optimize_windows_resident leaves the new last_marginalization_info */
+} vilo_resident_refs;
+
+/* vilo_optimize_windows with per-window device handles (refs[w]); next_prior may be NULL when every window names a prior pool. */
+int vilo_optimize_windows_resident(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_resident_refs *refs,
+                                   vilo_window_state *inout, const vilo_solve_opts *opts, const int *marginalization_flag,
+                                   vilo_prior *next_prior, vilo_solve_summary *summaries);
+
 /* GPU time (HIP events on ctx's stream) of the kernels of the last vilo_marginalize: linearisation + marginalisation. */
 double vilo_last_marginalize_ms(const vilo_ctx *ctx);
 

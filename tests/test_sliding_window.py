@@ -193,6 +193,40 @@ def test_streaming_and_batch_preintegration_give_the_same_replay(ctx, cfg):
 
 
 @pytest.mark.gpu
+def test_resident_prior_equals_the_host_carried_one(ctx, cfg):
+    """Default: the prior (vilo_prior_pool slot) and the preintegration records (vilo_preint_streams objects) never leave the device
+    between frames. resident=0 carries both through host memory every frame (vilo_optimize_windows). Same estimate, bit for bit, and
+    the slot the manager points at holds the prior the host path ends with."""
+    from cerberus_amd import api, sequence
+    from cerberus_amd.synth import PriorData
+    a = _run(ctx, cfg, 20, seed=41)
+    b = _run(ctx, cfg, 20, seed=41, resident=0)
+    for (_, sa), (_, sb) in zip(a[1], b[1]):
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "Rho"):
+            np.testing.assert_array_equal(sa[key], sb[key])
+        assert sa["prior_n"] == sb["prior_n"]
+    # an explicit pool: download the final prior and compare with a host-side marginalisation of the same window? the host path's
+    # prior is internal to the manager, so check the pool round trip instead: upload -> download is the identity
+    pool = api.PriorPool(ctx, 2)
+    w = synth_window_with_prior(cfg)
+    pool.upload(1, w.prior)
+    assert pool.dim(1) == w.prior.n and pool.dim(0) == 0
+    back = pool.download(1, PriorData())
+    assert back.blocks() == w.prior.blocks()
+    np.testing.assert_array_equal(back.J0_matrix(), w.prior.J0_matrix())
+    np.testing.assert_array_equal(back.r0[:back.n], w.prior.r0[:w.prior.n])
+    np.testing.assert_array_equal(back.x0[:7 * 40], w.prior.x0[:7 * 40])
+    pool.upload(1, None)
+    assert pool.dim(1) == 0
+    pool.close()
+
+
+def synth_window_with_prior(cfg):
+    from cerberus_amd import synth
+    return synth.make_window(cfg, n_landmarks=20, seed=77)
+
+
+@pytest.mark.gpu
 def test_fleet_in_lockstep_equals_robots_one_by_one(ctx, cfg):
     """process_images batches the solve and the marginalisation of every robot that is due into one device call each; the
     result per robot is bitwise what the robot gets alone."""
@@ -203,9 +237,11 @@ def test_fleet_in_lockstep_equals_robots_one_by_one(ctx, cfg):
     streams = [sequence.Stream(cfg, seed=200 + r, t0=0.4 * r) for r in range(R)]
     robots = [sequence.SlidingWindow(ctx, cfg) for _ in range(R)]
     pool = api.PreintStreams(ctx, 11 * R)     # one pool of device-resident preintegration objects for the fleet
+    priors = api.PriorPool(ctx, 2 * R)        # and one of device-resident priors (two slots per robot)
     for r, (s, w) in enumerate(zip(streams, robots)):
         w.set_extrinsics(*s.extrinsics())
         w.attach_streams(pool, 11 * r)
+        w.attach_prior_pool(priors, 2 * r)
     for k in range(N):
         frames = [s.next() for s in streams]
         for w, f in zip(robots, frames):

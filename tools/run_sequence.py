@@ -27,10 +27,12 @@ def main():
         os.makedirs(a.dump, exist_ok=True)
     robots = [sequence.SlidingWindow(ctx, cfg, use_leg=0 if a.no_leg else 1, dump_dir=a.dump if r == 0 else None) for r in range(a.robots)]
     pool = api.PreintStreams(ctx, 11 * a.robots) if not a.no_leg else None
+    priors = api.PriorPool(ctx, 2 * a.robots) if not a.no_leg else None
     for r, (s, w) in enumerate(zip(streams, robots)):
         w.set_extrinsics(*s.extrinsics())
         if pool:
             w.attach_streams(pool, 11 * r)
+            w.attach_prior_pool(priors, 2 * r)
     t_img = []
     for k in range(a.images):
         frames = [s.next() for s in streams]
