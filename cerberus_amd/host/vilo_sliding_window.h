@@ -8,9 +8,10 @@
 //   initFirstIMUPose :524-544, initFirstPose :546-552                initFirstIMUPose, initFirstPose
 //   processImage :655-846                                            beginImage -> optimizeBatch -> endImage   (processImage = all three)
 //   vector2double :848-901, double2vector :903-1003                  vector2double, double2vector (gauge fix through vilo_gauge_fix)
-//   optimization :1054-1458                                          optimizeBatch: vilo_optimize_windows (solve + gauge fix + marginalisation
-//                                                                    on one device-resident batch), any number of windows per call
-//                                                                    (independent robots share one launch sequence)
+//   optimization :1054-1458                                          optimizeBatch: vilo_optimize_windows[_resident] (solve + gauge fix +
+//                                                                    marginalisation on one device batch; by default the prior and the
+//                                                                    preintegration records stay in HBM between frames), any number of
+//                                                                    windows per call (independent robots share one launch sequence)
 //   slideWindow :1460-1678                                           slideWindow (MARGIN_OLD / MARGIN_SECOND_NEW incl. sample-buffer merge)
 //   outliersRejection :1741-1798, reprojectionError :1729-1739       outliersRejection
 //
