@@ -415,6 +415,67 @@ def test_marginalize_block_elimination_equals_the_eigen_pseudo_inverse_path(ctx,
     np.testing.assert_allclose(pf.r0[:pf.n] @ pf.r0[:pf.n], pg.r0[:pg.n] @ pg.r0[:pg.n], rtol=1e-6)
 
 
+def test_marginalize_many_dropped_landmarks(ctx, cfg, ocfg):
+    """700 landmarks, 100 of them anchored in frame 0: the landmark elimination of k_marginalize_lds walks four 32-wide tiles."""
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w = _fresh(cfg, ocfg, n_landmarks=700, seed=29)
+    assert int((w.lm_start_frame == 0).sum()) == 100
+    pg, po = PriorData(), PriorData()
+    ctx.marginalize(w, 0, pg)
+    assert api.lib().vilo_debug_marg_general_count(ctx.h) == 0
+    rc, m, _, _ = O.marginalize(ocfg, w, 0, po)
+    assert rc == 0 and m == 119 and pg.blocks() == po.blocks() and pg.n == po.n == 86
+    Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+    Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+    assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max()
+    bg, bo = Jg.T @ pg.r0[:86], Jo.T @ po.r0[:86]
+    assert np.abs(bg - bo).max() < 1e-6 * np.abs(bo).max()
+
+
+def test_optimize_windows_is_solve_plus_gauge_fix_plus_marginalize(ctx, cfg, ocfg):
+    """vilo_optimize_windows (one device batch) against the three separate entry points, and against the oracle's chain."""
+    import ctypes as C
+    from cerberus_amd import api, _ctypes as T
+    from cerberus_amd.synth import PriorData
+    opts = api.default_solve_opts(True, 5)
+    ws = [_fresh(cfg, ocfg, n_landmarks=50, seed=60 + i) for i in range(3)]
+    ref = [_fresh(cfg, ocfg, n_landmarks=50, seed=60 + i) for i in range(3)]
+    flags = [0, 1, 0]
+    # separate calls
+    p_sep = [PriorData() for _ in ref]
+    for w, f, p in zip(ref, flags, p_sep):
+        before = w.clone_state()
+        ctx.solve_windows([w], opts)
+        ctx.gauge_fix(before, w)
+        ctx.marginalize(w, f, p)
+    # one call
+    W = len(ws)
+    descs = (T.WindowDesc * W)(); states = (T.WindowState * W)(); summ = (T.SolveSummary * W)(); priors = (T.Prior * W)()
+    p_one = [PriorData() for _ in ws]
+    for i, w in enumerate(ws):
+        descs[i], states[i] = w.desc(T)
+        priors[i] = p_one[i].struct
+    fl = (C.c_int * W)(*flags)
+    ctx._check(api.lib().vilo_optimize_windows(ctx.h, W, descs, states, C.byref(opts), fl, priors, summ))
+    for i in range(W):
+        for a, b in zip(ws[i].state_arrays(), ref[i].state_arrays()):
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())     # the gauge fix runs on the batch's state block
+        p_one[i].struct = priors[i]
+        assert p_one[i].blocks() == p_sep[i].blocks()
+        Ja, Jb = p_one[i].J0_matrix(), p_sep[i].J0_matrix()
+        assert np.abs(Ja.T @ Ja - Jb.T @ Jb).max() < 1e-9 * np.abs(Jb.T @ Jb).max()
+    # the oracle's chain on the first window
+    wo = _fresh(cfg, ocfg, n_landmarks=50, seed=60)
+    before = wo.clone_state()
+    O.solve_window(ocfg, wo, O.default_opts(True, 5))
+    O.gauge_fix(before, wo)
+    po = PriorData()
+    assert O.marginalize(ocfg, wo, 0, po)[0] == 0
+    Jg, Jo = p_one[0].J0_matrix(), po.J0_matrix()
+    assert np.abs(Jg.T @ Jg - Jo.T @ Jo).max() < 1e-6 * np.abs(Jo.T @ Jo).max()
+
+
 def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
     """Prior produced by GPU marginalisation of one window drives the solve of the next (GPU vs oracle)."""
     from cerberus_amd import api
