@@ -172,3 +172,44 @@ def test_gpu_marginalization_vs_reference(ctx, gwin, mode):
     np.testing.assert_allclose(H, G["marg%d_H" % mode], rtol=0, atol=tol * np.abs(G["marg%d_H" % mode]).max())
     np.testing.assert_allclose(b, G["marg%d_b" % mode], rtol=0, atol=tol * np.abs(G["marg%d_b" % mode]).max())
     np.testing.assert_array_equal(x0, G["marg%d_x0" % mode])
+
+
+# ------------------------------------------------------------------------------ force-based contact model (contact_sensor_type 2)
+GF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preint_force_model.npz"))
+
+
+def _force_inputs(gwin):
+    from test_oracle_vs_reference import force_samples
+    return force_samples(gwin.samples, seed=int(GF["force_seed"]))
+
+
+def _check_force_records(pre, rt_state, rt_jac, rt_cov):
+    ref = GF["preint"]
+    np.testing.assert_allclose(pre[:, :33], ref[:, :33], rtol=rt_state, atol=1e-13)
+    np.testing.assert_allclose(pre[:, 33:994], ref[:, 33:994], rtol=rt_jac, atol=1e-11)
+    for k in range(ref.shape[0]):
+        cov = ref[k, 994:]
+        np.testing.assert_allclose(pre[k, 994:], cov, rtol=rt_cov, atol=1e-11 * np.abs(cov).max())
+
+
+def test_oracle_force_model_preintegration(gwin):
+    """tests/golden/preint_force_model.npz: the reference's IMULegIntegrationBase with contact_sensor_type 2
+    (imu_leg_integration_base.cpp:195-229, 300-317), frozen by tests/golden/make_golden_rank3.py."""
+    import copy
+    cfg2 = copy.copy(O.default_config())
+    cfg2.contact_sensor_type = 2
+    w, smp = gwin, _force_inputs(gwin)
+    pre = np.array([O.preintegrate_imu_leg(cfg2, smp[w.sample_offsets[k]:w.sample_offsets[k + 1]], w.lin[k]) for k in range(w.F - 1)])
+    _check_force_records(pre, 1e-12, 1e-10, 1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_force_model_preintegration_vs_reference(gwin):
+    import copy
+    from cerberus_amd import api
+    c2 = copy.copy(synth.default_config())
+    c2.contact_sensor_type = 2
+    c = api.Context(c2, 0)
+    w, smp = gwin, _force_inputs(gwin)
+    _check_force_records(c.preintegrate(smp, w.sample_offsets, w.lin), 1e-11, 1e-9, 1e-8)
+    c.close()
