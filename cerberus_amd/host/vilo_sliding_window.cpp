@@ -243,6 +243,12 @@ void SlidingWindow::double2vector() {
 void SlidingWindow::fillDesc() {
   std::memset(&desc_, 0, sizeof desc_);
   f_manager.fill(&desc_, &lm_start_, &lm_off_, &obs_, &stereo_);
+  // para_Feature has NUM_OF_F rows (estimator.h:196, parameters.h:24): the reference relies on the tracker's MAX_CNT to stay below
+  // it; here the features beyond the first NUM_OF_F of the list are left out of the problem (their depths stay as triangulated)
+  if (desc_.n_landmarks > VILO_NUM_OF_F) {
+    desc_.n_landmarks = VILO_NUM_OF_F;
+    desc_.n_obs = lm_off_[VILO_NUM_OF_F];
+  }
   desc_.n_frames = frame_count + 1;
   desc_.use_leg = opt_.use_leg;
   desc_.preint = opt_.use_leg ? &pre_[1] : nullptr;

@@ -72,10 +72,11 @@ class Stream:
         for k, v in kw.items():
             setattr(self.p, k, v)
         self.h = C.c_void_p(L.vilo_synth_stream_create(C.byref(cfg), C.byref(self.p)))
+        self.max_feat = max(MAX_FEATURES, int(self.p.max_features) + 64)
         self.samples = np.zeros((MAX_SAMPLES, T.SAMPLE_DOUBLES))
-        self.ids = np.zeros(MAX_FEATURES, np.int32)
-        self.obs = np.zeros((MAX_FEATURES, 11))
-        self.stereo = np.zeros(MAX_FEATURES, np.uint8)
+        self.ids = np.zeros(self.max_feat, np.int32)
+        self.obs = np.zeros((self.max_feat, 11))
+        self.stereo = np.zeros(self.max_feat, np.uint8)
         self.truth = np.zeros(20)
 
     def extrinsics(self):
@@ -86,7 +87,7 @@ class Stream:
     def next(self):
         ns, nf, hd = C.c_int(), C.c_int(), C.c_double()
         rc = self.L.vilo_synth_stream_next(self.h, self.samples.ctypes.data, MAX_SAMPLES, C.byref(ns), self.ids.ctypes.data, self.obs.ctypes.data,
-                                           self.stereo.ctypes.data, MAX_FEATURES, C.byref(nf), C.byref(hd), self.truth.ctypes.data)
+                                           self.stereo.ctypes.data, self.max_feat, C.byref(nf), C.byref(hd), self.truth.ctypes.data)
         if rc != 0:
             raise RuntimeError("vilo_synth_stream_next: buffer too small")
         return dict(header=hd.value, samples=self.samples[:ns.value].copy(), ids=self.ids[:nf.value].copy(), obs=self.obs[:nf.value].copy(),

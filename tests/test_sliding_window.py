@@ -227,6 +227,27 @@ def synth_window_with_prior(cfg):
 
 
 @pytest.mark.gpu
+def test_more_features_than_para_feature_rows(ctx, cfg):
+    """para_Feature has NUM_OF_F = 1000 rows (parameters.h:24); the reference depends on the tracker's MAX_CNT to stay below. A
+    denser scene than that must not break the manager: the first 1000 features of the list are optimised, the rest keep their
+    triangulated depth."""
+    from cerberus_amd import sequence
+    stream = sequence.Stream(cfg, seed=3, cloud_per_10m=4000, max_features=900, drop_prob=0.01)
+    sw = sequence.SlidingWindow(ctx, cfg)
+    sw.set_extrinsics(*stream.extrinsics())
+    most = 0
+    for k in range(26):
+        f = stream.next()
+        sequence.feed(sw, f, k == 0)
+        sw.process_image(f["header"], f["ids"], f["obs"], f["stereo"])
+        st = sw.state()
+        most = max(most, st["feature_count"])
+        if k >= 10:
+            assert np.linalg.norm(st["Ps"][9] - f["truth"][0:3]) < 0.02, k
+    assert most > 1000
+
+
+@pytest.mark.gpu
 def test_fleet_in_lockstep_equals_robots_one_by_one(ctx, cfg):
     """process_images batches the solve and the marginalisation of every robot that is due into one device call each; the
     result per robot is bitwise what the robot gets alone."""
