@@ -227,6 +227,29 @@ def synth_window_with_prior(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", [dict(max_features=0), dict(max_features=8), dict(stereo_prob=0.0), dict(drop_prob=0.4),
+                                   dict(frame_rate_hz=60.0), dict(frame_rate_hz=5.0), dict(imu_rate_hz=200.0)],
+                         ids=["no-features", "8-features", "mono-only", "short-tracks", "60Hz-images", "5Hz-images", "200Hz-imu"])
+def test_replay_survives_degenerate_scenes(ctx, cfg, scene):
+    """Windows without landmarks (prior of 19 dims: pose / speed-bias / leg-bias of one frame), without stereo matches, with tracks
+    too short to enter the problem, with no parallax between images (every frame MARGIN_SECOND_NEW, the newest interval merged into
+    the one before it again and again) or with long intervals: the estimate stays finite and near the truth (legs + IMU carry it)."""
+    from cerberus_amd import sequence
+    stream = sequence.Stream(cfg, seed=11, **scene)
+    sw = sequence.SlidingWindow(ctx, cfg)
+    sw.set_extrinsics(*stream.extrinsics())
+    n = 70 if scene.get("frame_rate_hz") == 60.0 else 30
+    for k in range(n):
+        f = stream.next()
+        sequence.feed(sw, f, k == 0)
+        sw.process_image(f["header"], f["ids"], f["obs"], f["stereo"])
+        st = sw.state()
+        if k >= 10:
+            assert np.isfinite(st["Ps"]).all() and np.linalg.norm(st["Ps"][9] - f["truth"][0:3]) < 0.05, k
+    assert st["n_optimizations"] == n - 10 and st["prior_n"] >= 19
+
+
+@pytest.mark.gpu
 def test_more_features_than_para_feature_rows(ctx, cfg):
     """para_Feature has NUM_OF_F = 1000 rows (parameters.h:24); the reference depends on the tracker's MAX_CNT to stay below. A
     denser scene than that must not break the manager: the first 1000 features of the list are optimised, the rest keep their
