@@ -101,10 +101,10 @@ class Batch:
 class PreintStreams:
     """vilo_preint_streams: device-resident IMULegIntegrationBase objects updated by push_back as samples arrive."""
 
-    def __init__(self, ctx, n):
-        self.ctx, self.n = ctx, n
+    def __init__(self, ctx, n, imu_only=False):
+        self.ctx, self.n, self.imu_only = ctx, n, imu_only
         self.h = C.c_void_p()
-        ctx._check(lib().vilo_preint_streams_create(ctx.h, n, C.byref(self.h)))
+        ctx._check((lib().vilo_preint_streams_create_imu if imu_only else lib().vilo_preint_streams_create)(ctx.h, n, C.byref(self.h)))
 
     def reset(self, ids, first, lin):
         ids, first, lin = np.ascontiguousarray(ids, np.int32), _c(first), _c(lin)
@@ -117,6 +117,10 @@ class PreintStreams:
 
     def read(self, ids):
         ids = np.ascontiguousarray(ids, np.int32)
+        if self.imu_only:
+            out = np.zeros((len(ids), T.PREINT_IMU_DOUBLES))
+            self.ctx._check(lib().vilo_preint_streams_read_imu(self.ctx.h, self.h, len(ids), T.iptr(ids), C.cast(out.ctypes.data, C.POINTER(T.PreintImu))))
+            return out
         out = np.zeros((len(ids), T.PREINT_DOUBLES))
         self.ctx._check(lib().vilo_preint_streams_read(self.ctx.h, self.h, len(ids), T.iptr(ids), C.cast(out.ctypes.data, C.POINTER(T.Preint))))
         return out

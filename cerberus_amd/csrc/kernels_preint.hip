@@ -17,6 +17,13 @@ struct PreintStream {
   int n_pushed, pad;
 };
 
+// the same for an IntegrationBase (integration_base.h:201-220), the USE_LEG = 0 configurations
+struct PreintImuStream {
+  vilo_preint_imu rec;
+  vilo_sample last;
+  int n_pushed, pad;
+};
+
 namespace {
 
 // jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (:467-468 / integration_base.h:136-137)
@@ -394,28 +401,36 @@ __global__ void k_preint_stream_gather(int n, const int *ids, const int *dst_idx
   for (int e = threadIdx.x; e < (int)(sizeof(vilo_preint) / sizeof(double)); e += blockDim.x) dst[e] = src[e];
 }
 
-__global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
-                                                   const double *lin, vilo_preint_imu *out) {
+template <bool STREAM>
+__device__ void preint_imu_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint_imu *outp,
+                                PreintImuStream *st) {
   __shared__ double Fm[15 * 15], Vm[15 * 18], nd[18];
   __shared__ double Jm[15 * 16], Pm[15 * 16], Qm[15 * 16];
-  const int f = blockIdx.x;
-  if (f >= n) return;
-  const vilo_config &cfg = *cfgp;
   const int lane = threadIdx.x;
-  const int s_begin = offsets[f], s_end = offsets[f + 1];
-  const v3 ba = ld3(lin + 6 * f), bg = ld3(lin + 6 * f + 3);
+  if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) are consecutive in vilo_preint_imu
+  const v3 ba = ld3(ln), bg = ld3(ln + 3);
   v3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
   quat dq = mkq(1, 0, 0, 0);
   double sum_dt = 0.0;
-  for (int e = lane; e < 15 * 16; e += 64) { Jm[e] = ((e / 16) == (e % 16)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  if (STREAM) {
+    const vilo_preint_imu &r = st->rec;
+    dp = ld3(r.delta_p); dv = ld3(r.delta_v);
+    dq = mkq(r.delta_q[3], r.delta_q[0], r.delta_q[1], r.delta_q[2]);
+    sum_dt = r.sum_dt;
+    for (int e = lane; e < 15 * 16; e += 64) { Jm[e] = 0.0; Pm[e] = 0.0; }
+    __syncthreads();
+    for (int e = lane; e < 15 * 15; e += 64) { Jm[(e / 15) * 16 + (e % 15)] = r.jacobian[e]; Pm[(e / 15) * 16 + (e % 15)] = r.covariance[e]; }
+  } else {
+    for (int e = lane; e < 15 * 16; e += 64) { Jm[e] = ((e / 16) == (e % 16)) ? 1.0 : 0.0; Pm[e] = 0.0; }
+  }
   if (lane < 18) {   // integration_base.h:31-37 (ACC_N on all axes)
     const int blk = lane / 3;
     nd[lane] = (blk == 0 || blk == 2) ? cfg.acc_n * cfg.acc_n : (blk == 1 || blk == 3) ? cfg.gyr_n * cfg.gyr_n : (blk == 4) ? cfg.acc_w * cfg.acc_w : cfg.gyr_w * cfg.gyr_w;
   }
   __syncthreads();
   const m3 I3 = m3_eye();
-  for (int si = s_begin + 1; si < s_end; ++si) {
-    const vilo_sample &s0 = samples[si - 1], &s1 = samples[si];
+  for (int si = STREAM ? s_begin : s_begin + 1; si < s_end; ++si) {
+    const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
     const double dt = s1.dt;
     const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
     const v3 un_acc_0 = qrot(dq, acc_0 - ba);
@@ -463,17 +478,54 @@ __global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfg
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     sum_dt += dt;
   }
-  vilo_preint_imu &o = out[f];
+  vilo_preint_imu &o = *outp;
   if (lane == 0) {
     o.sum_dt = sum_dt;
     st3(o.delta_p, dp); st3(o.delta_v, dv);
     o.delta_q[0] = dq.x; o.delta_q[1] = dq.y; o.delta_q[2] = dq.z; o.delta_q[3] = dq.w;
     st3(o.lin_ba, ba); st3(o.lin_bg, bg);
+    if (STREAM && s_end > s_begin) { st->last = samples[s_end - 1]; st->n_pushed += s_end - s_begin; }
   }
   for (int e = lane; e < 15 * 15; e += 64) {
     o.jacobian[e] = Jm[(e / 15) * 16 + (e % 15)];
     o.covariance[e] = Pm[(e / 15) * 16 + (e % 15)];
   }
+}
+
+__global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
+                                                   const double *lin, vilo_preint_imu *out) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  preint_imu_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 6 * f, out + f, nullptr);
+}
+__global__ void __launch_bounds__(64) k_preint_imu_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
+                                                               PreintImuStream *streams) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  PreintImuStream *st = streams + ids[f];
+  preint_imu_body<true>(*cfgp, samples, offsets[f], offsets[f + 1], nullptr, &st->rec, st);
+}
+// new IntegrationBase{acc_0, gyr_0, ba, bg} (integration_base.h:18-40)
+__global__ void __launch_bounds__(64) k_preint_imu_stream_reset(int n, const int *ids, const vilo_sample *first, const double *lin, PreintImuStream *streams) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  PreintImuStream &st = streams[ids[f]];
+  vilo_preint_imu &r = st.rec;
+  for (int e = lane; e < 15 * 15; e += 64) { r.jacobian[e] = (e / 15 == e % 15) ? 1.0 : 0.0; r.covariance[e] = 0.0; }
+  if (lane == 0) {
+    r.sum_dt = 0.0;
+    for (int k = 0; k < 3; ++k) { r.delta_p[k] = 0.0; r.delta_v[k] = 0.0; r.delta_q[k] = 0.0; r.lin_ba[k] = lin[6 * f + k]; r.lin_bg[k] = lin[6 * f + 3 + k]; }
+    r.delta_q[3] = 1.0;
+    st.last = first[f];
+    st.n_pushed = 0;
+  }
+}
+__global__ void k_preint_imu_stream_gather(int n, const int *ids, const int *dst_idx, const PreintImuStream *streams, vilo_preint_imu *out) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const double *src = (const double *)&streams[ids[f]].rec;
+  double *dst = (double *)(out + (dst_idx ? dst_idx[f] : f));
+  for (int e = threadIdx.x; e < (int)(sizeof(vilo_preint_imu) / sizeof(double)); e += blockDim.x) dst[e] = src[e];
 }
 
 template <class OUT, class KERNEL>
@@ -512,25 +564,38 @@ extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *sa
 
 // ---- device-resident, incrementally updated preintegration (the reference's push_back as samples arrive, estimator.cpp:619-626) ----
 
-extern "C" int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **out) {
-  if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
-  VILO_HIP(hipSetDevice(ctx->device));
+static int streams_create(vilo_ctx *ctx, int n, int kind, vilo_preint_streams **out) {
   vilo_preint_streams *s = new vilo_preint_streams();
-  s->n = n; s->d = nullptr; s->device = ctx->device;
-  if (hipMalloc((void **)&s->d, sizeof(PreintStream) * (size_t)n) != hipSuccess || hipMemset(s->d, 0, sizeof(PreintStream) * (size_t)n) != hipSuccess) {
-    if (s->d) (void)hipFree(s->d);
+  s->n = n; s->d = nullptr; s->di = nullptr; s->device = ctx->device; s->kind = kind;
+  void *q = nullptr;
+  const size_t bytes = (kind ? sizeof(PreintImuStream) : sizeof(PreintStream)) * (size_t)n;
+  if (hipMalloc(&q, bytes) != hipSuccess || hipMemset(q, 0, bytes) != hipSuccess) {
+    if (q) (void)hipFree(q);
     delete s;
     ctx->err = "vilo_preint_streams_create: allocation failed";
     return VILO_ERR_HIP;
   }
+  if (kind) s->di = (PreintImuStream *)q; else s->d = (PreintStream *)q;
   *out = s;
   return VILO_OK;
+}
+
+extern "C" int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **out) {
+  if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  return streams_create(ctx, n, 0, out);
+}
+extern "C" int vilo_preint_streams_create_imu(vilo_ctx *ctx, int n, vilo_preint_streams **out) {
+  if (!ctx || n <= 0 || !out) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  return streams_create(ctx, n, 1, out);
 }
 extern "C" void vilo_preint_streams_destroy(vilo_ctx *ctx, vilo_preint_streams *s) {
   if (!s) return;
   (void)ctx;   // may already be gone when a host object releases its pool late
   (void)hipSetDevice(s->device);
   if (s->d) (void)hipFree(s->d);
+  if (s->di) (void)hipFree(s->di);
   delete s;
 }
 static int check_ids(const vilo_preint_streams *s, int n, const int32_t *ids) {
@@ -546,12 +611,14 @@ extern "C" int vilo_preint_streams_reset(vilo_ctx *ctx, vilo_preint_streams *s, 
   if (n == 0) return VILO_OK;
   if (check_ids(s, n, ids) != VILO_OK) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
+  const int lw = s->kind ? 6 : 10;
   DevBuf d_i, d_f, d_l;
-  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_f.alloc(sizeof(vilo_sample) * (size_t)n)); VILO_HIP(d_l.alloc(sizeof(double) * 10 * (size_t)n));
+  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_f.alloc(sizeof(vilo_sample) * (size_t)n)); VILO_HIP(d_l.alloc(sizeof(double) * lw * (size_t)n));
   VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_f.p, first, sizeof(vilo_sample) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * 10 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_preint_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->d);
+  VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * lw * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if (s->kind) hipLaunchKernelGGL(k_preint_imu_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->di);
+  else hipLaunchKernelGGL(k_preint_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->d);
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipStreamSynchronize(ctx->stream));
   return VILO_OK;
@@ -571,14 +638,33 @@ extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, i
   VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
-                     d_i.as<int>(), s->d);
+  if (s->kind)
+    hipLaunchKernelGGL(k_preint_imu_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
+                       d_i.as<int>(), s->di);
+  else
+    hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
+                       d_i.as<int>(), s->d);
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipStreamSynchronize(ctx->stream));
   return VILO_OK;
 }
+extern "C" int vilo_preint_streams_read_imu(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, vilo_preint_imu *out) {
+  if (!ctx || !s || !s->kind || n < 0 || (n && (!ids || !out))) return VILO_ERR_BAD_ARG;
+  if (n == 0) return VILO_OK;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= s->n) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  DevBuf d_i, d_out;
+  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_out.alloc(sizeof(vilo_preint_imu) * (size_t)n));
+  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_preint_imu_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_i.as<int>(), (const int *)nullptr, (const PreintImuStream *)s->di, d_out.as<vilo_preint_imu>());
+  VILO_HIP(hipGetLastError());
+  VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(vilo_preint_imu) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  return VILO_OK;
+}
 extern "C" int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, vilo_preint *out) {
-  if (!ctx || !s || n < 0 || (n && (!ids || !out))) return VILO_ERR_BAD_ARG;
+  if (!ctx || !s || s->kind || n < 0 || (n && (!ids || !out))) return VILO_ERR_BAD_ARG;
   if (n == 0) return VILO_OK;
   for (int i = 0; i < n; ++i)
     if (ids[i] < 0 || ids[i] >= s->n) return VILO_ERR_BAD_ARG;
@@ -594,8 +680,9 @@ extern "C" int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *s, i
 }
 
 // records of device-resident objects straight into a batch's record array (device to device): d_ids / d_dst are device arrays
-int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, vilo_preint *d_out) {
-  hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_ids, d_dst, (const PreintStream *)pool->d, d_out);
+int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, void *d_out) {
+  if (pool->kind) hipLaunchKernelGGL(k_preint_imu_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_ids, d_dst, (const PreintImuStream *)pool->di, (vilo_preint_imu *)d_out);
+  else hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_ids, d_dst, (const PreintStream *)pool->d, (vilo_preint *)d_out);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

@@ -162,7 +162,7 @@ extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
   delete bt;
 }
 
-int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, vilo_preint *d_out);
+int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, void *d_out);
 
 extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *init, vilo_batch **out) {
   return vilo_batch_create_refs(ctx, W, in, nullptr, init, out);
@@ -204,12 +204,12 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       ctx->err = "window sizes out of range"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
     if ((d.use_leg != 0) != (in[0].use_leg != 0)) { ctx->err = "all windows of a batch must use the same IMU factor kind (use_leg)"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
-    if (!d.use_leg && !d.preint_imu) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
     const vilo_resident_refs *rf = refs ? refs + w : nullptr;
-    if (rf && rf->preint_pool && (!d.use_leg || !rf->preint_ids || !rf->preint_sum_dt || rf->preint_pool != refs[0].preint_pool)) {
-      ctx->err = "resident preintegration: IMU-leg windows only, one pool per batch"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED;
+    if (rf && rf->preint_pool && ((d.use_leg != 0) == (rf->preint_pool->kind != 0) || !rf->preint_ids || !rf->preint_sum_dt || rf->preint_pool != refs[0].preint_pool)) {
+      ctx->err = "resident preintegration: pool kind must match use_leg, one pool per batch"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED;
     }
     if (rf && rf->prior_pool && rf->prior_pool != refs[0].prior_pool) { ctx->err = "one prior pool per batch"; vilo_batch_destroy(ctx, bt); return VILO_ERR_UNSUPPORTED; }
+    if (!d.use_leg && !d.preint_imu && !(rf && rf->preint_pool)) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
     if ((d.use_leg && !d.preint && !(rf && rf->preint_pool)) || !s.pose || !s.speed_bias || !s.leg_bias || !s.ex_pose || !s.td || (d.n_landmarks && (!s.inv_depth || !d.lm_start_frame || !d.lm_obs_offset || !d.obs || !d.obs_is_stereo))) {
       vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
@@ -477,7 +477,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       int *d_gi = nullptr, *d_gd = nullptr;
       rc = dev_upload(ctx, bt, &d_gi, g_ids);
       if (rc == VILO_OK) rc = dev_upload(ctx, bt, &d_gd, g_dst);
-      if (rc == VILO_OK) rc = vilo_launch_preint_gather(ctx, refs[0].preint_pool, (int)g_ids.size(), d_gi, d_gd, (vilo_preint *)d_pre);
+      if (rc == VILO_OK) rc = vilo_launch_preint_gather(ctx, refs[0].preint_pool, (int)g_ids.size(), d_gi, d_gd, d_pre);
     }
     if (rc == VILO_OK) rc = leg ? vilo_launch_prepare_preint(ctx, W * 10, (const vilo_preint *)d_pre, D.prep, D.status)
                                 : vilo_launch_prepare_preint_imu(ctx, W * 10, (const vilo_preint_imu *)d_pre, D.prep, D.status);

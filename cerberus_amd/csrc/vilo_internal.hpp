@@ -104,9 +104,11 @@ struct vilo_prior_pool {
   std::vector<double> x0_store;    // [n][7 * VILO_MAX_PRIOR_BLOCKS]
 };
 struct PreintStream;
+struct PreintImuStream;
 struct vilo_preint_streams {
-  int n, device;
+  int n, device, kind;   // kind 0: IMULegIntegrationBase objects (d), 1: IntegrationBase objects (di)
   PreintStream *d;
+  PreintImuStream *di;
 };
 // the prior a window sees: the host struct of its desc, or the host mirror of its pool slot
 inline const vilo_prior *vilo_win_prior(const vilo_window_desc &d, const vilo_resident_refs *r) {

@@ -86,7 +86,7 @@ SlidingWindow::PriorStore::PriorStore() : x0(7 * VILO_MAX_PRIOR_BLOCKS), J0((siz
 
 SlidingWindow::SlidingWindow(vilo_ctx *ctx, const vilo_config &cfg, const SlidingWindowOptions &opt)
     : f_manager(opt.features), ctx_(ctx), cfg_(cfg), opt_(opt), pre_(NF), pre_imu_(NF) {
-  resident_ = opt.resident && opt.use_leg && opt.streaming_preintegration && opt.dump_dir.empty();
+  resident_ = opt.resident && opt.streaming_preintegration && opt.dump_dir.empty();
   clearState();
   g[0] = 0; g[1] = 0; g[2] = cfg.g_norm;
 }
@@ -254,7 +254,7 @@ void SlidingWindow::fillDesc() {
   desc_.preint = opt_.use_leg ? &pre_[1] : nullptr;
   desc_.preint_imu = opt_.use_leg ? nullptr : &pre_imu_[1];
   desc_.prior = (!resident_ && hasPrior()) ? &prior_[cur_prior_].p : nullptr;
-  if (resident_) { desc_.preint = nullptr; }
+  if (resident_) { desc_.preint = nullptr; desc_.preint_imu = nullptr; }
   // SetParameterBlockConstant decisions, estimator.cpp:1074-1106
   desc_.leg_bias_const = (opt_.use_leg && !opt_.optimize_leg_bias) || frame_count < WS;
   const double v0 = norm(ld3(Vs[0]));
@@ -358,12 +358,12 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   for (int w = 0; w < n; ++w)
     if (ws[w]->opt_.use_leg != use_leg || ws[w]->pending_ == 0 || ws[w]->frame_count != WS) return VILO_ERR_BAD_ARG;
   // 1. preintegration of the intervals whose samples or linearisation point changed: one device call sequence for the whole fleet
-  bool streaming = use_leg && ws[0]->opt_.streaming_preintegration;
+  bool streaming = ws[0]->opt_.streaming_preintegration != 0;
   // robots without pools get their own; a fleet shares pools (then every robot is served by the same few device calls)
   for (int w = 0; w < n; ++w) {
     SlidingWindow &s = *ws[w];
-    if (s.opt_.use_leg && s.opt_.streaming_preintegration && !s.pool_) {
-      int rc = vilo_preint_streams_create(ctx, NF, &s.pool_);
+    if (s.opt_.streaming_preintegration && !s.pool_) {
+      int rc = s.opt_.use_leg ? vilo_preint_streams_create(ctx, NF, &s.pool_) : vilo_preint_streams_create_imu(ctx, NF, &s.pool_);
       if (rc != VILO_OK) return rc;
       s.own_pool_ = true;
       for (int j = 0; j < NF; ++j) { s.sid_[j] = j; s.need_reset_[j] = !s.buf_[j].empty(); s.pushed_[j] = 0; }
@@ -406,7 +406,7 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
         for (int j = 1; j <= WS; ++j) {
           if (s.buf_[j].empty()) continue;
           if (s.need_reset_[j]) {
-            rid.push_back(s.sid_[j]); first.push_back(s.buf_[j][0]); lin.insert(lin.end(), s.lin_[j], s.lin_[j] + 10);
+            rid.push_back(s.sid_[j]); first.push_back(s.buf_[j][0]); lin.insert(lin.end(), s.lin_[j], s.lin_[j] + (use_leg ? 10 : 6));
             s.need_reset_[j] = false; s.pushed_[j] = 0;
           }
           const int have = (int)s.buf_[j].size() - 1;
@@ -422,13 +422,18 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
       }
       int rc = vilo_preint_streams_reset(ctx, pool, (int)rid.size(), rid.data(), first.data(), lin.data());
       if (rc == VILO_OK) rc = vilo_preint_streams_push(ctx, pool, (int)pid.size(), pid.data(), samples.data(), offsets.data());
-      std::vector<vilo_preint> out(gid.size());
-      if (rc == VILO_OK) rc = vilo_preint_streams_read(ctx, pool, (int)gid.size(), gid.data(), out.data());
-      if (rc != VILO_OK) return rc;
-      for (size_t k = 0; k < which.size(); ++k) {
-        ws[which[k].first]->pre_[which[k].second] = out[k];
-        ws[which[k].first]->dirty_[which[k].second] = false;
+      if (use_leg) {
+        std::vector<vilo_preint> out(gid.size());
+        if (rc == VILO_OK) rc = vilo_preint_streams_read(ctx, pool, (int)gid.size(), gid.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_[which[k].second] = out[k];
+      } else {
+        std::vector<vilo_preint_imu> out(gid.size());
+        if (rc == VILO_OK) rc = vilo_preint_streams_read_imu(ctx, pool, (int)gid.size(), gid.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_imu_[which[k].second] = out[k];
       }
+      for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->dirty_[which[k].second] = false;
       w0 = w1;
     }
   } else {

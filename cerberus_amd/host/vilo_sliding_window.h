@@ -36,7 +36,7 @@ struct SlidingWindowOptions {
   int use_leg = 1;             // USE_LEG: IMULegFactor (1) or IMUFactor (0)
   int resident = 1;            // 1 (with streaming preintegration, no dump): the prior and the preintegration records stay on the device
                                //    between frames (vilo_prior_pool / vilo_preint_streams handles, vilo_optimize_windows_resident)
-  int streaming_preintegration = 1;   // 1: intervals live on the device and are push_back()ed (USE_LEG); 0: re-integrate changed intervals
+  int streaming_preintegration = 1;   // 1: intervals live on the device and are push_back()ed; 0: re-integrate changed intervals
   int optimize_leg_bias = 1;   // OPTIMIZE_LEG_BIAS (estimator.cpp:1074)
   int estimate_extrinsic = 0;  // ESTIMATE_EXTRINSIC (estimator.cpp:1092)
   int estimate_td = 0;         // ESTIMATE_TD (estimator.cpp:1105)
@@ -64,7 +64,8 @@ class SlidingWindow {
   // window uses one of the NF objects base_id .. base_id + NF - 1 of `pool`, so an interval is integrated once, sample by sample,
   // however often MARGIN_SECOND_NEW merges the newest interval into it (the reference's push_back, estimator.cpp:1581-1599;
   // without a pool a changed interval is re-integrated from its buffer). Robots of a fleet share one pool, one push per image.
-  // USE_LEG only. Without a call the window creates a pool of its own on first use.
+  // The pool's kind must match USE_LEG (vilo_preint_streams_create / _create_imu). Without a call the window creates a pool of
+  // its own on first use.
   void attachStreams(vilo_preint_streams *pool, int base_id);
   // The same for the marginalisation prior: this robot uses slots base_slot and base_slot + 1 of `pool` alternately.
   void attachPriorPool(vilo_prior_pool *pool, int base_slot);

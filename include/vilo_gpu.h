@@ -216,6 +216,9 @@ int vilo_preintegrate_imu(vilo_ctx *ctx, int n_intervals, const vilo_sample *sam
  * pushing an interval in pieces gives bitwise the result of vilo_preintegrate on the whole interval. ---------------------- */
 typedef struct vilo_preint_streams vilo_preint_streams;
 int vilo_preint_streams_create(vilo_ctx *ctx, int n, vilo_preint_streams **pool);
+/* the same pool of IntegrationBase objects (integration_base.h) for USE_LEG = 0: reset takes lin [n][6] = ba bg, the leg fields
+ * of the samples are ignored, vilo_preint_streams_read_imu returns their state */
+int vilo_preint_streams_create_imu(vilo_ctx *ctx, int n, vilo_preint_streams **pool);
 void vilo_preint_streams_destroy(vilo_ctx *ctx, vilo_preint_streams *pool);
 /* new IMULegIntegrationBase{acc_0, gyr_0, phi_0, dphi_0, c_0, ba, bg, rho} (imu_leg_integration_base.cpp:7-42) for the
  * objects ids[0..n): first[k] holds the constructor's measurement, lin [n][10] = ba bg rho. ids must be distinct. */
@@ -226,6 +229,7 @@ int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *pool, int n, co
                              const int32_t *offsets);
 /* the public state of the objects ids[0..n) (what IMULegFactor reads) */
 int vilo_preint_streams_read(vilo_ctx *ctx, vilo_preint_streams *pool, int n, const int32_t *ids, vilo_preint *out);
+int vilo_preint_streams_read_imu(vilo_ctx *ctx, vilo_preint_streams *pool, int n, const int32_t *ids, vilo_preint_imu *out);
 
 /* ---- Estimator::optimization(), solve half (estimator.cpp:1054-1245) --------------------------------
  * Synchronous; n_windows = 1 reproduces the reference call. States are updated in place with the

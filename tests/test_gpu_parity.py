@@ -174,6 +174,29 @@ def test_streaming_preintegration_equals_the_batch_bitwise(ctx, ctx_force, small
     pool.close()
 
 
+def test_streaming_imu_only_preintegration_equals_the_batch_bitwise(ctx, small_window):
+    """IntegrationBase objects (USE_LEG = 0) kept on the device, pushed in pieces, against vilo_preintegrate_imu."""
+    from cerberus_amd import api
+    w = small_window
+    lin6 = np.ascontiguousarray(w.lin[:, :6])
+    batch = ctx.preintegrate_imu(w.samples, w.sample_offsets, lin6)
+    pool = api.PreintStreams(ctx, 10, imu_only=True)
+    ids = np.arange(10)
+    pool.reset(ids, np.stack([w.samples[w.sample_offsets[k]] for k in range(10)]), lin6)
+    for piece in range(3):   # thirds of every interval
+        chunks = []
+        for k in range(10):
+            a, b = int(w.sample_offsets[k]) + 1, int(w.sample_offsets[k + 1])
+            cut = [a, a + (b - a) // 3, a + 2 * (b - a) // 3, b]
+            chunks.append(w.samples[cut[piece]:cut[piece + 1]])
+        pool.push(ids, np.concatenate(chunks), np.concatenate([[0], np.cumsum([len(c) for c in chunks])]))
+    np.testing.assert_array_equal(pool.read(ids), batch)
+    leg_pool = api.PreintStreams(ctx, 2)
+    with pytest.raises(api.ViloError):   # kinds do not mix
+        api.Context._check(ctx, api.lib().vilo_preint_streams_read_imu(ctx.h, leg_pool.h, 0 + 1, api.T.iptr(np.zeros(1, np.int32)), None))
+    leg_pool.close(); pool.close()
+
+
 def _cd_to_oracle(cd, F=11):
     if cd < 66:
         return 19 * (cd // 6) + cd % 6

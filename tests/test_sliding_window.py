@@ -172,6 +172,11 @@ def test_every_dumped_window_replays_through_the_oracle(ctx, cfg, ocfg, tmp_path
 @pytest.mark.gpu
 def test_replay_without_leg_factors(ctx, cfg, ocfg, tmp_path):
     """USE_LEG = 0 (hardware_a1_vins_config.yaml): IMUFactor chain, no leg-bias blocks in the prior."""
+    res = _run(ctx, cfg, 18, seed=9, use_leg=0)[1]                      # streaming IntegrationBase objects, resident prior
+    host = _run(ctx, cfg, 18, seed=9, use_leg=0, resident=0, streaming_preintegration=0)[1]
+    for (_, sa), (_, sb) in zip(res, host):
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+            np.testing.assert_array_equal(sa[key], sb[key])
     sw, hist = _run(ctx, cfg, 18, seed=9, dump_dir=str(tmp_path), use_leg=0)
     st = hist[-1][1]
     assert st["n_optimizations"] == 8 and st["prior_n"] in (76, 82)

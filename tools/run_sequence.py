@@ -30,8 +30,8 @@ def main():
     if a.dump:
         os.makedirs(a.dump, exist_ok=True)
     robots = [sequence.SlidingWindow(ctx, cfg, use_leg=0 if a.no_leg else 1, dump_dir=a.dump if r == 0 else None) for r in range(a.robots)]
-    pool = api.PreintStreams(ctx, 11 * a.robots) if not a.no_leg else None
-    priors = api.PriorPool(ctx, 2 * a.robots) if not a.no_leg else None
+    pool = api.PreintStreams(ctx, 11 * a.robots, imu_only=a.no_leg)
+    priors = api.PriorPool(ctx, 2 * a.robots)
     for r, (s, w) in enumerate(zip(streams, robots)):
         w.set_extrinsics(*s.extrinsics())
         if pool:
