@@ -96,17 +96,22 @@ __global__ void __launch_bounds__(256) k_prior_gather(int W, const WinMeta *win,
 __global__ void __launch_bounds__(256) k_prior_pack(int W, const WinMeta *win, const double *J0s /*[W][96*96], n x n packed*/,
                                                     const double *r0s /*[W][96]*/, const int *pmap /*[W][96]*/, double *H /*[W][96*96]*/,
                                                     double *b0 /*[W][96]*/, double *c0 /*[W]*/, double *pdense /*[W][PD_N], zeroed*/) {
+  extern __shared__ double Jl[];   // J0 of the window (n x n) + r0 (n): read once from HBM, every product out of LDS
   const int w = blockIdx.x, tid = threadIdx.x;
   const int n = win[w].prior_n;
   if (n <= 0) return;
   const double *J = J0s + (size_t)w * 96 * 96, *r = r0s + (size_t)w * 96;
+  double *rl = Jl + 96 * 96;
+  for (int e = tid; e < n * n; e += 256) Jl[e] = J[e];
+  for (int e = tid; e < n; e += 256) rl[e] = r[e];
+  __syncthreads();
   const int *pm = pmap + (size_t)w * 96;
   double *Hw = H + (size_t)w * 96 * 96, *pd = pdense + (size_t)w * PD_N;
   for (int e = tid; e < n * n; e += 256) {
     const int i = e / n, j = e % n;
     if (j > i) continue;
     double s = 0.0;
-    for (int k = 0; k < n; ++k) s += J[(size_t)k * n + i] * J[(size_t)k * n + j];
+    for (int k = 0; k < n; ++k) s += Jl[k * n + i] * Jl[k * n + j];
     Hw[(size_t)i * n + j] = s;
     Hw[(size_t)j * n + i] = s;
     for (int rep = 0; rep < (i == j ? 1 : 2); ++rep) {
@@ -118,12 +123,12 @@ __global__ void __launch_bounds__(256) k_prior_pack(int W, const WinMeta *win, c
   }
   for (int i = tid; i < n; i += 256) {
     double s = 0.0;
-    for (int k = 0; k < n; ++k) s += J[(size_t)k * n + i] * r[k];
+    for (int k = 0; k < n; ++k) s += Jl[k * n + i] * rl[k];
     b0[(size_t)w * 96 + i] = s;
   }
   if (tid == 0) {
     double s = 0.0;
-    for (int k = 0; k < n; ++k) s += r[k] * r[k];
+    for (int k = 0; k < n; ++k) s += rl[k] * rl[k];
     c0[w] = s;
   }
 }
@@ -443,7 +448,15 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       TRYB(dev_upload(ctx, bt, &d_slot, slot));
       hipLaunchKernelGGL(k_prior_gather, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_slot, refs[0].prior_pool->dJ, refs[0].prior_pool->dr, d_J, d_r);
     }
-    hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
+    {
+      static bool pp_attr = false;
+      const size_t pp_lds = sizeof(double) * (96 * 96 + 96);
+      if (!pp_attr) {
+        if (hipFuncSetAttribute((const void *)k_prior_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+        pp_attr = true;
+      }
+      hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), pp_lds, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
+    }
     if (hipGetLastError() != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   }
   const double t_uploaded = now();
