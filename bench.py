@@ -243,6 +243,32 @@ def main():
                 b1.reset(); b1.solve(opts)
             out["single_window_iters_per_s"] = 20 * ITERS / (time.perf_counter() - t1)
             b1.close()
+        if world == 1 and not args.no_single_window:
+            # Two resident batches of the same size solved concurrently, each on its own context = HIP stream, one host thread each:
+            # the small kernels and the tails of the large ones of one batch run in the gaps of the other. Reported beside `value`,
+            # not as `value`: per-launch kernel durations (the roofline block above) are only meaningful without a co-runner.
+            try:
+                import threading
+                lib.vilo_set_profiling(ctx.h, 0)
+                ctx2 = api.Context(cfg, device=local_rank)
+                windows2 = [synth.make_window(cfg, n_landmarks=args.landmarks, seed=30260925 + i) for i in range(W)]
+                ctx2.preintegrate_windows(windows2)
+                batch2 = api.Batch(ctx2, windows2)
+
+                def run(b, n):
+                    for _ in range(n):
+                        b.reset(); b.solve(opts)
+                for b in (batch, batch2):
+                    run(b, 2)
+                t2 = time.perf_counter()
+                th = [threading.Thread(target=run, args=(b, args.steps)) for b in (batch, batch2)]
+                [t.start() for t in th]; [t.join() for t in th]
+                dt2 = time.perf_counter() - t2
+                out["two_streams"] = {"value": 2 * W * ITERS * args.steps / dt2, "unit": "GN window-iterations/s", "windows_per_gpu": 2 * W,
+                                      "note": "two batches of %d windows on two HIP streams, same kernels; not the headline value" % W}
+                batch2.close(); ctx2.close()
+            except Exception as e:
+                out["two_streams"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks)
             try:
