@@ -278,18 +278,21 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
     }
     wbase[(size_t)CD_TD * L + li] = wc_td;
   }
-  const double csum = wave_sum(active ? cost : 0.0);
-  if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
+  (void)cost;   // the cost at the linearisation point is k_visual_cost's job
   if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = wv.n_lanes; st.phase_clk[20] = wv.kmax; }
 }
 
 // Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
 // Also forms the candidate inverse depth: lambda_c = lambda - a * g_l / dhat_l^2 - b * y_l.
+// One workgroup per (packed wave, frame offset t): 33 k short waves instead of 3 k waves walking up to 11 frames each — the pass
+// is latency-bound, the frames of a landmark are independent here, and k_accept adds the per-(wave, t) partial sums.
 __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, double huber_a, int init_mode) {
   const WaveMeta wv = b.wave[blockIdx.x];
   const SolverState &st = b.st[wv.win];
   if (st.done || (!init_mode && !st.step_valid)) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, t = blockIdx.y;
+  double *cost_out = b.chunk_cost + (size_t)blockIdx.x * VILO_MAX_FRAMES + t;
+  if (t >= wv.kmax) { if (lane == 0) *cost_out = 0.0; return; }
   int cs[4], cn[4], ckm[4], cgo[4];
   const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
   const bool active = ls.active;
@@ -302,16 +305,15 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
     const int gi = ls.gi;
     double lam = b.lam[gi];
     if (!init_mode) lam += -st.coef_a * b.lm_g[gi] / b.lm_dh2[gi] - st.coef_b * b.lm_y[gi];
-    b.lamc[gi] = lam;
-    double o12[12];
-    o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
-    o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
-    const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
-    const double td = x[XO_TD];
-    for (int t = 0; t < wv.kmax; ++t) {
-      const unsigned char fl = flg[(size_t)t * n + lane];
-      if (!(fl & 1)) continue;
-      const double *pose_j = x + XO_POSE + 7 * (s + t);
+    if (t == 0) b.lamc[gi] = lam;
+    const unsigned char fl = flg[(size_t)t * n + lane];
+    if (fl & 1) {
+      double o12[12];
+      o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
+      o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
+      const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
+      const double td = x[XO_TD];
+      const double *pose_j = x + XO_POSE + 7 * min(s + t, VILO_MAX_FRAMES - 1);
       const double *ob = obs + (size_t)t * 11 * n;
       o12[11] = ob[(size_t)10 * n + lane];
       double r[2];
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
     }
   }
   const double csum = wave_sum(active ? cost : 0.0);
-  if (lane == 0) b.chunk_cost[blockIdx.x] = csum;
+  if (lane == 0) *cost_out = csum;
 }
 
 // =================================================================================================
@@ -1664,7 +1666,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   }
   // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2)
   double part = 0.0;
-  for (int c = tid; c < wm.n_waves; c += 128) part += b.chunk_cost[wm.wave_off + c];
+  for (int c = tid; c < wm.n_waves * VILO_MAX_FRAMES; c += 128) part += b.chunk_cost[(size_t)wm.wave_off * VILO_MAX_FRAMES + c];
   const double vis = block_sum(part, red);
   part = 0.0;
   for (int k = tid; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
@@ -1800,7 +1802,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   // IterationZero: cost at the initial point
   VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
   P0(3);
-  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 1);
+  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, 1);
   P1();
   P0(4);
   hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
@@ -1823,7 +1825,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
     P1();
     P0(3);
-    if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, 0);
+    if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, 0);
     P1();
     P0(4);
     hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 0);

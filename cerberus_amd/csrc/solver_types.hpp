@@ -109,7 +109,7 @@ struct BatchDev {
   double *lm_E, *lm_g, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
   double *lm_w;               // per window: [80][L] at 80 * lm_off
   double *gram;               // [n_gram][VILO_GRAM]
-  double *chunk_cost;         // [n_chunks]
+  double *chunk_cost;         // [n_waves][VILO_MAX_FRAMES] partial visual cost per (packed wave, frame offset)
   // IMU factors
   PreintPrepared *prep;       // [W][10]
   double *imu_raw;            // [W][10][31*39]  raw J (31x38) | raw r; zeros written once, non-zeros per linearisation

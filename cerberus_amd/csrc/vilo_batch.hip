@@ -399,7 +399,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.lm_einv, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_w, (size_t)lm_total * 80));
   TRYB(dev_alloc(ctx, bt, &D.gram, (size_t)gram_total * VILO_GRAM));
-  TRYB(dev_alloc(ctx, bt, &D.chunk_cost, chunks.size()));
+  TRYB(dev_alloc(ctx, bt, &D.chunk_cost, waves.size() * VILO_MAX_FRAMES));   // per (packed wave, frame offset) partial costs
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
   TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
   TRYB(dev_alloc(ctx, bt, &D.imu_raw, (size_t)W * 10 * 31 * 39));
