@@ -499,6 +499,40 @@ def test_optimize_windows_is_solve_plus_gauge_fix_plus_marginalize(ctx, cfg, ocf
     assert np.abs(Jg.T @ Jg - Jo.T @ Jo).max() < 1e-6 * np.abs(Jo.T @ Jo).max()
 
 
+def test_marginalize_config2_batch(ctx, cfg, ocfg):
+    """256 config-2 windows (200 landmarks) in one vilo_marginalize call, both flags: every window takes the LDS path, the
+    information matrices are symmetric positive semi-definite with the 4-dim gauge null space cut off at eps, and three of them agree
+    with the oracle."""
+    import ctypes as C
+    from cerberus_amd import api, synth, _ctypes as T
+    from cerberus_amd.synth import PriorData
+    W = 256
+    ws = [synth.make_window(cfg, n_landmarks=200, seed=900 + i) for i in range(W)]
+    ctx.preintegrate_windows(ws)
+    descs = (T.WindowDesc * W)(); states = (T.WindowState * W)(); priors = (T.Prior * W)()
+    outs = [PriorData() for _ in range(W)]
+    for i, w in enumerate(ws):
+        descs[i], states[i] = w.desc(T)
+        priors[i] = outs[i].struct
+    for mode, n_expect in ((0, 86), (1, 80)):
+        ctx._check(api.lib().vilo_marginalize(ctx.h, W, descs, states, mode, priors))
+        assert api.lib().vilo_debug_marg_general_count(ctx.h) == 0
+        for i in range(W):
+            outs[i].struct = priors[i]
+            assert priors[i].valid == 1 and priors[i].n == n_expect
+        for i in (0, 100, 255):
+            J = outs[i].J0_matrix()
+            A = J.T @ J
+            assert np.isfinite(J).all() and np.isfinite(outs[i].r0[:n_expect]).all()
+            ev = np.linalg.eigvalsh(A)
+            assert ev.min() > -1e-9 * ev.max() and (np.abs(J).sum(axis=1) == 0).sum() <= 6   # rows of dropped eigenvalues are zero
+            po = PriorData()
+            O.fill_preint(ocfg, ws[i])
+            assert O.marginalize(ocfg, ws[i], mode, po)[0] == 0
+            Jo = po.J0_matrix()
+            assert np.abs(A - Jo.T @ Jo).max() < 1e-5 * np.abs(Jo.T @ Jo).max()
+
+
 def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
     """Prior produced by GPU marginalisation of one window drives the solve of the next (GPU vs oracle)."""
     from cerberus_amd import api
