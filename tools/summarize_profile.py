@@ -25,7 +25,7 @@ def db(pattern):
 
 summary = {}
 con = db("trace/**/*.db")
-print("== rocprofv3 --kernel-trace --stats: python bench.py --steps 2 --warmup 1 --windows 1024")
+print("== rocprofv3 --kernel-trace --stats: python bench.py --steps 2 --warmup 1 (windows per GPU: see the grid of the k_build_solve dispatch below)")
 if con:
     ks = {}
     for name, calls, total, avg, pct in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
