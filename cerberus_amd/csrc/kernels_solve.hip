@@ -100,7 +100,13 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
   return ls;
 }
 
-__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) {
+// TPAR = false: one wave per packed wave walks all its frames (the throughput form: landmark-side sums stay in registers).
+// TPAR = true (small batches, b.lm_part != null): one wave per (packed wave, frame offset) so that a handful of windows still
+// fills the chip; every landmark-side term is written per (frame, camera) and k_visual_reduce adds the terms in the order the
+// walking form adds them — the two forms give bitwise the same linearisation.
+#define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
+template <bool TPAR>
+__device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a) {
   __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
   __shared__ double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
   const WaveMeta wv = b.wave[blockIdx.x];
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
   const bool active = ls.active;
   const int n = wv.n_lanes, L = wm.L, s = ls.s;
-  const bool prof = (blockIdx.x == (unsigned)wm.wave_off) && lane == 0;
+  const bool prof = !TPAR && (blockIdx.x == (unsigned)wm.wave_off) && lane == 0;
   long long c_proj = 0, c_gram = 0, c_t0 = clock64(), c_a = 0;
   const double *xg = b.x + (size_t)wv.win * XSTRIDE;
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   const int lr = lane & 15, lk = lane >> 4;
   const int xoff = (lk >> 1) * XLANE + (lk & 1) * 26 + lr;
   const bool c1on = lr < 10;   // columns 26 .. 31 of the second tile column do not exist
-  if (active)
+  if (!TPAR && active)   // TPAR: the host clears w before the launch (the frames of a landmark run in different workgroups)
     for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
 
@@ -159,14 +165,21 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
 #pragma unroll
     for (int c = 0; c < 11; ++c) on[c] = obs[(size_t)c * n + lane];
   }
-  for (int t = 0; t < wv.kmax; ++t) {
+  const int t_begin = TPAR ? (int)blockIdx.y : 0, t_end = TPAR ? min((int)blockIdx.y + 1, wv.kmax) : wv.kmax;
+  if (TPAR && t_begin > 0 && active && t_begin < wv.kmax) {   // this workgroup's frame instead of frame 0
+    fl_next = flg[(size_t)t_begin * n + lane];
+    const double *obn = obs + (size_t)t_begin * 11 * n;
+#pragma unroll
+    for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
+  }
+  for (int t = t_begin; t < t_end; ++t) {
     const int j = min(s + t, VILO_MAX_FRAMES - 1);
     const unsigned char fl = fl_next;
     const double *pose_j = x + XO_POSE + 7 * j;
     double ob[11];
 #pragma unroll
     for (int c = 0; c < 11; ++c) ob[c] = on[c];
-    if (active && t + 1 < wv.kmax) {
+    if (!TPAR && active && t + 1 < wv.kmax) {
       fl_next = flg[(size_t)(t + 1) * n + lane];
       const double *obn = obs + (size_t)(t + 1) * 11 * n;
 #pragma unroll
@@ -204,16 +217,27 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
         correct_col(cr, r[0], r[1], Jt[0], Jt[1]);
         r[0] *= cr.residual_scaling;
         r[1] *= cr.residual_scaling;
-        // landmark-side reductions (the e-block of Ceres' Schur eliminator)
-        E += Jl[0] * Jl[0] + Jl[1] * Jl[1];
-        gl += Jl[0] * r[0] + Jl[1] * r[1];
+        // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
+        double term[LM_NTERM];
+        term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
+        term[1] = Jl[0] * r[0] + Jl[1] * r[1];
         for (int c = 0; c < 6; ++c) {
-          wc_s[c] += Ji[c] * Jl[0] + Ji[6 + c] * Jl[1];
+          term[2 + c] = Ji[c] * Jl[0] + Ji[6 + c] * Jl[1];
+          term[8 + c] = Je0[c] * Jl[0] + Je0[6 + c] * Jl[1];
+          term[14 + c] = Je1[c] * Jl[0] + Je1[6 + c] * Jl[1];
           wj[c] += Jj[c] * Jl[0] + Jj[6 + c] * Jl[1];
-          wc_e0[c] += Je0[c] * Jl[0] + Je0[6 + c] * Jl[1];
-          wc_e1[c] += Je1[c] * Jl[0] + Je1[6 + c] * Jl[1];
         }
-        wc_td += Jt[0] * Jl[0] + Jt[1] * Jl[1];
+        term[20] = Jt[0] * Jl[0] + Jt[1] * Jl[1];
+        if (TPAR) {
+          double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
+#pragma unroll
+          for (int v = 0; v < LM_NTERM; ++v) pt[(size_t)v * b.n_lm] = term[v];
+        } else {
+          E += term[0];
+          gl += term[1];
+          for (int c = 0; c < 6; ++c) { wc_s[c] += term[2 + c]; wc_e0[c] += term[8 + c]; wc_e1[c] += term[14 + c]; }
+          wc_td += term[20];
+        }
         for (int c = 0; c < 6; ++c) {
           xr0[c] = Ji[c]; xr1[c] = Ji[6 + c];
           xr0[6 + c] = Jj[c]; xr1[6 + c] = Jj[6 + c];
@@ -268,7 +292,7 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
     if (active && t > 0 && (fl & 1))
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
   }
-  if (active) {
+  if (!TPAR && active) {
     b.lm_E[ls.gi] = E;
     b.lm_g[ls.gi] = gl;
     for (int c = 0; c < 6; ++c) {
@@ -280,6 +304,68 @@ __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, 
   }
   (void)cost;   // the cost at the linearisation point is k_visual_cost's job
   if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = wv.n_lanes; st.phase_clk[20] = wv.kmax; }
+}
+
+__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a) { visual_linearize_body<false>(b, sq, huber_a); }
+__global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double sq, double huber_a) { visual_linearize_body<true>(b, sq, huber_a); }
+
+// Second half of the TPAR form: per landmark, the (frame, camera) terms in the order the walking form adds them (frames ascending,
+// left camera before right; an unobserved factor contributed +0.0).
+__global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b) {
+  const WaveMeta wv = b.wave[blockIdx.x];
+  const SolverState &st = b.st[wv.win];
+  if (st.done || !st.need_lin) return;
+  const WinMeta wm = b.win[wv.win];
+  const int lane = threadIdx.x;
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
+  if (!ls.active) return;
+  double acc[LM_NTERM];
+#pragma unroll
+  for (int v = 0; v < LM_NTERM; ++v) acc[v] = 0.0;
+  for (int t = 0; t < wv.kmax; ++t)
+    for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
+      const double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
+#pragma unroll
+      for (int v = 0; v < LM_NTERM; ++v) acc[v] += pt[(size_t)v * b.n_lm];
+    }
+  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
+  const int L = wm.L, li = ls.li, s = ls.s;
+  b.lm_E[ls.gi] = acc[0];
+  b.lm_g[ls.gi] = acc[1];
+  for (int c = 0; c < 6; ++c) {
+    wbase[(size_t)(6 * s + c) * L + li] = acc[2 + c];
+    wbase[(size_t)(CD_EX0 + c) * L + li] = acc[8 + c];
+    wbase[(size_t)(CD_EX1 + c) * L + li] = acc[14 + c];
+  }
+  wbase[(size_t)CD_TD * L + li] = acc[20];
+}
+
+// First part of the TPAR form: what the walking form does before its frame loop — the coupling rows of the landmarks of every window
+// that is about to be re-linearised start from zero (windows that keep their linearisation after a rejected step are not touched).
+__global__ void __launch_bounds__(64) k_visual_clear(BatchDev b) {
+  const WaveMeta wv = b.wave[blockIdx.x];
+  const SolverState &st = b.st[wv.win];
+  if (st.done || !st.need_lin) return;
+  const WinMeta wm = b.win[wv.win];
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, threadIdx.x, cs, cn, ckm, cgo);
+  if (!ls.active) return;
+  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
+  for (int a = 0; a < 80; ++a) wbase[(size_t)a * wm.L + ls.li] = 0.0;
+}
+
+// both forms behind one call (kernel kind 0 of the profiling table)
+static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream_t s) {
+  if (b.n_waves <= 0) return;
+  if (b.lm_part) {
+    hipLaunchKernelGGL(k_visual_clear, dim3(b.n_waves), dim3(64), 0, s, b);
+    (void)hipMemsetAsync(b.lm_part, 0, sizeof(double) * (size_t)VILO_MAX_FRAMES * 2 * LM_NTERM * b.n_lm, s);
+    hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha);
+    hipLaunchKernelGGL(k_visual_reduce, dim3(b.n_waves), dim3(64), 0, s, b);
+  } else {
+    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
+  }
 }
 
 // Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
@@ -1813,7 +1899,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   ap.init_mode = 0;
   for (int it = 0; it < o->max_num_iterations; ++it) {
     P0(0);
-    if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
+    launch_visual_linearize(b, sq, ha, s);
     P1();
     P0(7);
     hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn);
@@ -1842,7 +1928,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
 int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4);
-  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, ctx->stream, b, sq, ha);
+  launch_visual_linearize(b, sq, ha, ctx->stream);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn);
   hipLaunchKernelGGL(k_imu_whiten, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
   VILO_HIP(hipGetLastError());

@@ -108,6 +108,8 @@ struct BatchDev {
   // landmark-side linearisation
   double *lm_E, *lm_g, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
   double *lm_w;               // per window: [80][L] at 80 * lm_off
+  double *lm_part;            // small batches only (else null): [11 frames][2 cameras][21 terms][n_lm] landmark-side terms of the
+                              // frame-parallel linearisation (k_visual_linearize_tpar / k_visual_reduce)
   double *gram;               // [n_gram][VILO_GRAM]
   double *chunk_cost;         // [n_waves][VILO_MAX_FRAMES] partial visual cost per (packed wave, frame offset)
   // IMU factors

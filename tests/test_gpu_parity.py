@@ -372,6 +372,23 @@ def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
             assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
 
 
+def test_small_and_large_batches_linearise_identically(ctx, cfg, ocfg):
+    """Up to 256 packed waves a batch is linearised frame-parallel (k_visual_linearize_tpar + k_visual_reduce: one workgroup per
+    (packed wave, frame) so that a few windows still fill the chip), above that by one wave per packed wave. Same window, both forms,
+    bit for bit — a robot gets the same answer alone and inside a fleet of any size."""
+    from cerberus_amd import api
+    opts = api.default_solve_opts(False, 12)
+    alone = [_fresh(cfg, ocfg, n_landmarks=60, seed=300 + i) for i in range(3)]
+    for w in alone:
+        ctx.solve_windows([w], opts)                                   # 2 packed waves: frame-parallel form
+    crowd = [_fresh(cfg, ocfg, n_landmarks=60, seed=300 + i) for i in range(3)] + \
+            [_fresh(cfg, ocfg, n_landmarks=60, seed=900 + i) for i in range(160)]   # > 256 packed waves: walking form
+    ctx.solve_windows(crowd, opts)
+    for w1, w2 in zip(alone, crowd[:3]):
+        for a, b in zip(w1.state_arrays(), w2.state_arrays()):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_size_independent_properties(ctx, cfg):
     """Config-2 sized batch: cost never increases along accepted steps, rejected steps leave the state
     untouched, and re-solving from the solution gains almost nothing."""
