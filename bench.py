@@ -202,10 +202,13 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh: separate
         # FETCH_SIZE / WRITE_SIZE runs, calibrated on a known 1 GiB copy); only valid for the profiled configuration
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", {1024: "round1_pmc_v5.json", 4096: "round1_pmc_v7.json"}.get(W, "none"))
+        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v8.json")   # profiled at 4096 windows per dispatch; traffic is per window
         if os.path.exists(pmc_file) and args.landmarks == 200:
             try:
-                traffic = json.load(open(pmc_file))["hbm_bytes_per_dispatch"].get(dom)
+                pmc = json.load(open(pmc_file))
+                traffic = pmc["hbm_bytes_per_dispatch"].get(dom)
+                if traffic is not None:
+                    traffic = traffic * W / pmc.get("windows_per_dispatch", 4096)
             except Exception:
                 traffic = None
         out = {
@@ -218,7 +221,7 @@ def main():
                        "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" % os.path.basename(pmc_file)) if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "traffic": traffic, "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; measured at 4096 windows per dispatch, scaled to this batch)" % os.path.basename(pmc_file)) if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9,
                          # the same kernel against the FP64 matrix-core ceiling (78.6 TFLOP/s = half the 157.3 TF f32 MFMA rate

@@ -1143,7 +1143,7 @@ __device__ __noinline__ void ph_bias_chain() {
   }
 }
 
-__device__ __noinline__ int ph_scale_schur_chain() {
+__device__ __forceinline__ int ph_scale_schur_chain() {
   KB_LOCALS
   const double mu = kc.mu;
   double *cam_scale = kc.cam_scale, *Tm = kc.Tm, *Lkm = kc.Lkm;
@@ -1495,7 +1495,7 @@ __device__ __noinline__ void ph_elim_chol() {
   lds_barrier();
 }
 
-__device__ __noinline__ void ph_solve() {
+__device__ __forceinline__ void ph_solve() {
   KB_LOCALS
   double *Tm = kc.Tm, *Lkm = kc.Lkm;
   const double *wl = kc.wl;
