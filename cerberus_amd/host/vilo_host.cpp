@@ -36,18 +36,12 @@ bool MarginalizationFactor::Evaluate(double const *const *p, double *r, double *
 
 int WindowSolver::optimization(const vilo_window_desc &window, vilo_window_state &state, int marginalization_flag, vilo_prior *next_prior,
                                vilo_solve_summary *summary) {
-  const int F = window.n_frames;
-  // keep Rs[0] / Ps[0] of the pre-solve state for the yaw / position gauge fix (estimator.cpp:905-915)
-  std::vector<double> pose0(state.pose, state.pose + 7);
-  vilo_window_state before = state;
-  before.pose = pose0.data();
+  // solve, double2vector's gauge fix (Rs[0] / Ps[0] of the pre-solve state, estimator.cpp:905-915) and the marginalisation at the
+  // result on one device-resident batch; the reference only marginalises full windows (estimator.cpp:1243)
   vilo_solve_summary local;
-  int rc = vilo_solve_windows(ctx, 1, &window, &state, &opts, summary ? summary : &local);
-  if (rc != 0) return rc;
-  rc = vilo_gauge_fix(ctx, 1, &before, &state, F);
-  if (rc != 0) return rc;
-  if (next_prior && F == VILO_MAX_FRAMES) rc = vilo_marginalize(ctx, 1, &window, &state, marginalization_flag, next_prior);
-  return rc;
+  const bool marg = next_prior && window.n_frames == VILO_MAX_FRAMES;
+  return vilo_optimize_windows(ctx, 1, &window, &state, &opts, marg ? &marginalization_flag : nullptr, marg ? next_prior : nullptr,
+                               summary ? summary : &local);
 }
 
 }  // namespace vilo
