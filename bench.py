@@ -222,6 +222,7 @@ def main():
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; measured at 4096 windows per dispatch, scaled to this batch)" % os.path.basename(pmc_file)) if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "rocprof_summary": "profiles/round1_rocprof_summary_v8.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)",
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9,
                          # the same kernel against the FP64 matrix-core ceiling (78.6 TFLOP/s = half the 157.3 TF f32 MFMA rate
