@@ -179,9 +179,9 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel GPU time over the timed region (HIP events on the solver's stream)
-    ms = (C.c_double * 8)()
-    launches = (C.c_longlong * 8)()
-    nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 8)
+    ms = (C.c_double * 16)()
+    launches = (C.c_longlong * 16)()
+    nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 16)
     lib.vilo_kernel_name.restype = C.c_char_p
     kern = {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]),
                                                "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}

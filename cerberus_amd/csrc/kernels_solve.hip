@@ -14,20 +14,9 @@
 //                       scaling, dogleg quantities, landmark Schur complement, block elimination, dense Cholesky,
 //                       back-substitution, dogleg step, candidate state.
 //   k_visual_cost / k_imu_cost / k_accept   trial-point cost and the trust-region accept/reject logic.
-#include "solver_types.hpp"
+#include "solve_common.hpp"
 
 using namespace vilo;
-
-// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but leaves global loads in flight
-// (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// broadcast lane `src` (wave-uniform index) of a double through SGPRs (v_readlane): a few cycles, no LDS round trip
-__device__ __forceinline__ double readlane_d(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src);
-  hi = __builtin_amdgcn_readlane(hi, src);
-  return __hiloint2double(hi, lo);
-}
 
 // inverse of the packed upper-triangle index: row a of entry e for an n x n matrix (start(a) = a (2n + 1 - a) / 2)
 __device__ __forceinline__ int tri_row(int e, int n) {
@@ -40,12 +29,16 @@ __device__ __forceinline__ int tri_row(int e, int n) {
   return a;
 }
 
-__device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
-
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
+// Block b of a launch runs on XCD b % 8 (observed dispatch order); the packed waves of a window differ in length (kmax 11 / 9 / 7 / 5
+// at config 2) and repeat with the window period, so the identity mapping hands every XCD waves of ONE length and the XCD with the
+// longest ones finishes 1.4x after the average. Rotating the position inside each group of 8 blocks by the group index gives every
+// XCD the same mix. A permutation of [0, n): groups of 8 map onto themselves, the ragged tail is left alone.
+__device__ __forceinline__ int xcd_balanced(int b, int n) {
+  const int q = b >> 3;
+  if (8 * q + 8 > n) return b;
+  return 8 * q + ((b + q) & 7);
 }
+
 
 // block-wide sum through LDS (all threads must call); red has blockDim.x entries
 __device__ double block_sum(double v, double *red) {
@@ -76,7 +69,6 @@ __device__ double block_max(double v, double *red) {
 // =================================================================================================
 // k_visual_linearize
 // =================================================================================================
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #define XLANE 54  // LDS stride per lane: 2 rows x 26 cols + 2 pad; even so that every row starts 16-byte aligned (ds_read_b128)
 
 // Per-lane view of a packed wave (WaveMeta): which chunk (start frame) a lane belongs to.
@@ -109,7 +101,8 @@ template <bool TPAR>
 __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a) {
   __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
   __shared__ double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
-  const WaveMeta wv = b.wave[blockIdx.x];
+  const int wave_id = b.wave_order[blockIdx.x];
+  const WaveMeta wv = b.wave[wave_id];
   SolverState &st = b.st[wv.win];
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[wv.win];
@@ -118,7 +111,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
   const bool active = ls.active;
   const int n = wv.n_lanes, L = wm.L, s = ls.s;
-  const bool prof = !TPAR && (blockIdx.x == (unsigned)wm.wave_off) && lane == 0;
+  const bool prof = !TPAR && (wave_id == wm.wave_off) && lane == 0;
   long long c_proj = 0, c_gram = 0, c_t0 = clock64(), c_a = 0;
   const double *xg = b.x + (size_t)wv.win * XSTRIDE;
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
@@ -373,11 +366,12 @@ static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream
 // One workgroup per (packed wave, frame offset t): 33 k short waves instead of 3 k waves walking up to 11 frames each — the pass
 // is latency-bound, the frames of a landmark are independent here, and k_accept adds the per-(wave, t) partial sums.
 __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, double huber_a, int init_mode) {
-  const WaveMeta wv = b.wave[blockIdx.x];
+  const int wave_id = xcd_balanced(blockIdx.x, gridDim.x);
+  const WaveMeta wv = b.wave[wave_id];
   const SolverState &st = b.st[wv.win];
   if (st.done || (!init_mode && !st.step_valid)) return;
   const int lane = threadIdx.x, t = blockIdx.y;
-  double *cost_out = b.chunk_cost + (size_t)blockIdx.x * VILO_MAX_FRAMES + t;
+  double *cost_out = b.chunk_cost + (size_t)wave_id * VILO_MAX_FRAMES + t;
   if (t >= wv.kmax) { if (lane == 0) *cost_out = 0.0; return; }
   int cs[4], cn[4], ckm[4], cgo[4];
   const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
@@ -430,7 +424,6 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
 // IMU-leg factors
 // =================================================================================================
 #define IMU_LIN_STRIDE (31 * 39)
-__device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
 #define IMU_NTRI 496   // upper triangle of the 31 x 31 sqrt_info
 
 // Stage 1 of the IMULegFactor linearisation: one THREAD per factor evaluates the raw residual and the 31 x 38 local
@@ -611,38 +604,6 @@ int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b) {
 // =================================================================================================
 // k_build_solve
 // =================================================================================================
-struct SolveParams {
-  double min_lm_diagonal, max_lm_diagonal;
-  double min_radius, gradient_tolerance;
-  int jacobi_scaling, fixed_iterations;
-};
-
-// DoglegStrategy::ComputeTraditionalDoglegStep in scalar form + TrustRegionMinimizer's model_cost_change.
-__device__ void dogleg_scalars(SolverState &s) {
-  const double gradient_norm = sqrt(s.gnorm2), gn_norm = sqrt(s.gnnorm2), radius = s.radius;
-  double a, bb, step_norm;
-  if (gn_norm <= radius) {
-    a = 0.0; bb = 1.0; step_norm = gn_norm;
-  } else if (gradient_norm * s.alpha >= radius) {
-    a = radius / gradient_norm; bb = 0.0; step_norm = radius;
-  } else {
-    const double b_dot_a = -s.alpha * s.gdotgn;
-    const double a_squared_norm = (s.alpha * gradient_norm) * (s.alpha * gradient_norm);
-    const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gn_norm * gn_norm;
-    const double c = b_dot_a - a_squared_norm;
-    const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
-    const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
-    a = s.alpha * (1.0 - beta); bb = beta;
-    step_norm = sqrt(fmax(0.0, a * a * s.gnorm2 - 2.0 * a * bb * s.gdotgn + bb * bb * s.gnnorm2));
-  }
-  s.coef_a = a; s.coef_b = bb; s.dogleg_step_norm = step_norm;
-  // -(J d)^T (r + J d / 2) with d = -a D^-2 g - b y, (H + mu D^2) y = g
-  const double gy = -s.gdotgn;
-  s.model_cost_change = a * s.gnorm2 + bb * gy -
-                        0.5 * (a * a * s.q + 2.0 * a * bb * (s.gnorm2 - s.mu * gy) + bb * bb * (gy - s.mu * s.gnnorm2));
-  s.step_valid = (s.model_cost_change > 0.0) ? 1 : 0;
-}
-
 // camera dim of column c (0..37) of IMULegFactor(k, k+1)'s local Jacobian
 __device__ __forceinline__ int imu_col_cd(int k, int c) {
   if (c < 6) return 6 * k + c;
@@ -1851,6 +1812,8 @@ __global__ void k_init_state(BatchDev b, double radius0) {
 // =================================================================================================
 // host-side launch sequence
 // =================================================================================================
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage);   // kernels_wave.hip
+
 int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipStream_t s = ctx->stream;
@@ -1869,6 +1832,9 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   ap.parameter_tolerance = o->parameter_tolerance; ap.max_num_iterations = o->max_num_iterations;
   ap.fixed_iterations = o->fixed_iterations; ap.init_mode = 1; ap.pad = 0;
   const int W = b.W;
+  // VILO_SOLVER=fourwave: the round-1 one-workgroup-per-window solver (k_build_solve) instead of k_assemble_pose + k_solve_wave
+  const char *solver_env = getenv("VILO_SOLVER");
+  const bool wave_solver = !(solver_env && strcmp(solver_env, "fourwave") == 0);
   int pidx = 0;
   ctx->pev_kind.clear();
   auto P0 = [&](int kind) {
@@ -1907,9 +1873,18 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     P0(1);
     hipLaunchKernelGGL(k_imu_whiten, dim3(W * 10), dim3(64), 0, s, b);
     P1();
-    P0(2);
-    hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
-    P1();
+    if (wave_solver) {
+      P0(8);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 0) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(9);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 1) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+    } else {
+      P0(2);
+      hipLaunchKernelGGL(k_build_solve, dim3(W), dim3(SOLVE_THREADS), lds_bytes, s, b, sp);
+      P1();
+    }
     P0(3);
     if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, 0);
     P1();

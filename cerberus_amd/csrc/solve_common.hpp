@@ -1,0 +1,73 @@
+// Small device helpers shared by the solver kernels (kernels_solve.hip: linearisation, cost, accept, the four-wave solver;
+// kernels_wave.hip: pose-system assembly and the single-wave solver).
+#pragma once
+#include "solver_types.hpp"
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but leaves global loads in flight
+// (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// single-wave workgroups: LDS writes of this wave are visible to its later reads once lgkmcnt has drained
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// broadcast lane `src` (wave-uniform index) of a double through SGPRs (v_readlane): a few cycles, no LDS round trip
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+__device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+__device__ __forceinline__ double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return __shfl(v, 0, 64);
+}
+
+struct SolveParams {
+  double min_lm_diagonal, max_lm_diagonal;
+  double min_radius, gradient_tolerance;
+  int jacobi_scaling, fixed_iterations;
+};
+
+// is camera dimension cd part of the problem (not a constant block, not beyond the window's frames, not padding)
+__device__ __forceinline__ bool cd_active(int cd, int F, int cmask) {
+  if (cd < 66) return cd < 6 * F;
+  if (cd < CD_TD) return !(cmask & CONST_EX);
+  if (cd == CD_TD) return !(cmask & CONST_TD);
+  if (cd < CD_B0 || cd >= CD_B0 + 143) return false;
+  const int e = cd - CD_B0, k = e / 13, c = e - 13 * k;
+  return k < F && !(c >= 9 && (cmask & CONST_LB));
+}
+
+// DoglegStrategy::ComputeTraditionalDoglegStep in scalar form + TrustRegionMinimizer's model_cost_change.
+__device__ __forceinline__ void dogleg_scalars(SolverState &s) {
+  const double gradient_norm = sqrt(s.gnorm2), gn_norm = sqrt(s.gnnorm2), radius = s.radius;
+  double a, bb, step_norm;
+  if (gn_norm <= radius) {
+    a = 0.0; bb = 1.0; step_norm = gn_norm;
+  } else if (gradient_norm * s.alpha >= radius) {
+    a = radius / gradient_norm; bb = 0.0; step_norm = radius;
+  } else {
+    const double b_dot_a = -s.alpha * s.gdotgn;
+    const double a_squared_norm = (s.alpha * gradient_norm) * (s.alpha * gradient_norm);
+    const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gn_norm * gn_norm;
+    const double c = b_dot_a - a_squared_norm;
+    const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+    const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
+    a = s.alpha * (1.0 - beta); bb = beta;
+    step_norm = sqrt(fmax(0.0, a * a * s.gnorm2 - 2.0 * a * bb * s.gdotgn + bb * bb * s.gnnorm2));
+  }
+  s.coef_a = a; s.coef_b = bb; s.dogleg_step_norm = step_norm;
+  // -(J d)^T (r + J d / 2) with d = -a D^-2 g - b y, (H + mu D^2) y = g
+  const double gy = -s.gdotgn;
+  s.model_cost_change = a * s.gnorm2 + bb * gy -
+                        0.5 * (a * a * s.q + 2.0 * a * bb * (s.gnorm2 - s.mu * gy) + bb * bb * (gy - s.mu * s.gnnorm2));
+  s.step_valid = (s.model_cost_change > 0.0) ? 1 : 0;
+}

@@ -99,6 +99,7 @@ struct BatchDev {
   WinMeta *win;
   ChunkMeta *chunk;
   WaveMeta *wave;
+  int *wave_order;            // launch order of the packed waves of k_visual_linearize: longest (kmax) first, equal lengths adjacent
   double *obs;
   unsigned char *flags;
   // states
@@ -129,6 +130,9 @@ struct BatchDev {
   double *cam_g, *cam_dh2, *cam_y, *cam_scale;
   // block scratch
   double *Tm, *Lk;            // [W][11][13*96] T_k = [T_A | T_B | t_g], [W][11][169] L_k^-1
+  double *TAg;                // [W][11][169] T_A(k) = L_k^-1 A_{k,k-1} (single-wave solver: kept for the back-substitution sweeps)
+  double *Cimg;               // [W][3840] assembled pose system: 15 lower 16 x 16 tiles in FP64-MFMA accumulator order (k_assemble_pose)
+  double *cam_gin;            // [W][CD_N] gradient at the linearisation point: complete for the pose system, prior part for the rest
   SolverState *st;
   int *status;
 };

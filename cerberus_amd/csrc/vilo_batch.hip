@@ -382,6 +382,26 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_upload(ctx, bt, &D.win, wins));
   TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
   TRYB(dev_upload(ctx, bt, &D.wave, waves));
+  {
+    // launch order of the packed waves: by decreasing number of frames walked. A single-wave workgroup can only start on the SIMD the
+    // dispatcher's cyclic pointer names, so waves of mixed length in flight on one CU leave SIMDs idle behind a long one (measured: 2.7
+    // instead of 4 resident waves per CU); with equal lengths adjacent they retire in launch order and the longest ones do not form the tail.
+    std::vector<int> order(waves.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    const char *wo_env = getenv("VILO_WAVE_ORDER");   // tuning aid: 0 = window order, 1 = by length, 2 = by length, groups rotated
+    const int wo = wo_env ? atoi(wo_env) : 1;
+    if (wo >= 1) std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return waves[a].kmax > waves[c].kmax; });
+    if (wo == 2) {
+      size_t g0 = 0; int gi = 0;
+      while (g0 < order.size()) {
+        size_t g1 = g0;
+        while (g1 < order.size() && waves[order[g1]].kmax == waves[order[g0]].kmax) ++g1;
+        if (g1 - g0 > 8) std::rotate(order.begin() + g0, order.begin() + g0 + (gi % 8), order.begin() + g1);
+        g0 = g1; ++gi;
+      }
+    }
+    TRYB(dev_upload(ctx, bt, &D.wave_order, order));
+  }
   TRYB(dev_upload_raw(ctx, bt, &D.obs, obs, obs_total));
   TRYB(dev_upload_raw(ctx, bt, &D.flags, flags, flags_total));
   TRYB(dev_upload(ctx, bt, &D.x0, x0));
@@ -434,6 +454,9 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.cam_scale, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.Tm, (size_t)W * 11 * 13 * 96));
   TRYB(dev_alloc(ctx, bt, &D.Lk, (size_t)W * 11 * 169));
+  TRYB(dev_alloc(ctx, bt, &D.TAg, (size_t)W * 11 * 169));
+  TRYB(dev_alloc(ctx, bt, &D.Cimg, (size_t)W * 3840));
+  TRYB(dev_alloc(ctx, bt, &D.cam_gin, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));
   TRYB(dev_alloc(ctx, bt, &D.status, 1));
   if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {

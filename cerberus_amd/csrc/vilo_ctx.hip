@@ -53,7 +53,7 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   ctx->last_solve_ms = 0.0;
   ctx->d_cfg = nullptr;
   ctx->profile = 0;
-  for (int i = 0; i < 8; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
+  for (int i = 0; i < VILO_NKERNEL; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
       hipEventCreate(&ctx->ev1) != hipSuccess || hipMalloc((void **)&ctx->d_cfg, sizeof(vilo_config)) != hipSuccess ||
       hipMemcpy(ctx->d_cfg, cfg, sizeof(vilo_config), hipMemcpyHostToDevice) != hipSuccess) {
@@ -86,14 +86,14 @@ extern "C" double vilo_last_solve_ms(const vilo_ctx *ctx) { return ctx ? ctx->la
 extern "C" void vilo_set_profiling(vilo_ctx *ctx, int on) {
   if (!ctx) return;
   ctx->profile = on;
-  for (int i = 0; i < 8; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
+  for (int i = 0; i < VILO_NKERNEL; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
 }
 extern "C" int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n) {
   if (!ctx || !ms || !launches) return VILO_ERR_BAD_ARG;
-  for (int i = 0; i < n && i < 8; ++i) { ms[i] = ctx->kernel_ms[i]; launches[i] = ctx->kernel_launches[i]; }
+  for (int i = 0; i < n && i < VILO_NKERNEL; ++i) { ms[i] = ctx->kernel_ms[i]; launches[i] = ctx->kernel_launches[i]; }
   return VILO_NKERNEL;
 }
 extern "C" const char *vilo_kernel_name(int kind) {
-  static const char *names[VILO_NKERNEL] = {"k_visual_linearize", "k_imu_whiten", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state", "k_imu_raw"};
+  static const char *names[VILO_NKERNEL] = {"k_visual_linearize", "k_imu_whiten", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state", "k_imu_raw", "k_assemble_pose", "k_solve_wave"};
   return (kind >= 0 && kind < VILO_NKERNEL) ? names[kind] : "";
 }

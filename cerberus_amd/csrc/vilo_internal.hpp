@@ -20,6 +20,7 @@
 #define VILO_GRAM 351      // packed upper triangle of the 26 x 26 per-(group, t) Gram matrix
 #define VILO_GCOLS 26      // [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td 1 | r 1]
 
+#define VILO_NKERNEL 10
 struct vilo_ctx {
   vilo_config cfg;
   int device;
@@ -39,10 +40,10 @@ struct vilo_ctx {
   int profile;
   std::vector<hipEvent_t> pev;      // event pool
   std::vector<int> pev_kind;        // kernel kind of interval i = [pev[2i], pev[2i+1]]
-  double kernel_ms[8];
-  long long kernel_launches[8];
+  double kernel_ms[VILO_NKERNEL];
+  long long kernel_launches[VILO_NKERNEL];
+  bool wave_attr_set = false;       // k_solve_wave's dynamic-LDS opt-in done on this context's device
 };
-#define VILO_NKERNEL 8
 
 // grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified)
 inline void *vilo_host_stage(vilo_ctx *ctx, int slot, size_t bytes) {
