@@ -1,10 +1,13 @@
 // Single-wave solver for gfx950: what ceres::Solve does per linearisation for Estimator::optimization()
 // (estimator.cpp:1221-1236; DENSE_SCHUR + traditional DOGLEG, Ceres 1.14 semantics), one WAVE per window.
 //
-//   k_assemble_pose   throughput kernel, one thread per entry of the window's 80 x 80 pose / extrinsic / td system: gathers the
+//   k_assemble        one 256-thread workgroup per window (five per CU): the camera-side normal equations of the window in the layouts
+//                     the solver streams. Pose / extrinsic / td system (80 x 80): owner-computes scatter (no atomics) of the
 //                     per-(start frame, t) Gram slots of k_visual_linearize, the pose blocks of the IMU factor Grams and the prior
-//                     image into 15 lower 16 x 16 tiles stored in FP64-MFMA accumulator order (one coalesced load per register in
-//                     the solver), plus the gradient of those 80 dimensions.
+//                     image into an LDS image of 15 lower 16 x 16 tiles, written out in FP64-MFMA accumulator order (one coalesced
+//                     load per register in the solver). Speed / leg-bias part: diagonal blocks A_kk, off-diagonal blocks (transposed),
+//                     IMU coupling blocks with poses k-1 .. k+1, prior coupling rows, the diagonal and the gradient — constant blocks
+//                     and absent frames already masked, so the solver has no index arithmetic in its loops.
 //   k_solve_wave      one 64-lane workgroup per window, 40 KB of LDS: four windows per CU, one per SIMD, no workgroup barriers and no
 //                     idle waves (the four-wave k_build_solve kept one wave of four busy through its serial phases).
 //                     Jacobi scaling / dogleg diagonal / q = |J D^-2 g|^2  ->  block-tridiagonal Cholesky chain of the speed / leg-bias
@@ -15,126 +18,207 @@
 
 using namespace vilo;
 
-// packed upper triangle of an IMU factor's 39 x 39 Gram [J | r]^T [J | r], any argument order
-__device__ __forceinline__ int ig_idx(int a, int b) { return a <= b ? tri39(a, b) : tri39(b, a); }
-
-// =================================================================================================
-// k_assemble_pose
-// =================================================================================================
-#define CIMG_N 3840   // 15 tiles x 4 registers x 64 lanes
 __device__ __forceinline__ int tile_index(int I, int J) { return (I * (I + 1)) / 2 + J; }   // I >= J
+__device__ constexpr int c_tI[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+__device__ constexpr int c_tJ[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 
-// local Gram column (12 .. 24) of a non-pose camera dimension (ex0 66..71, ex1 72..77, td 78)
-__device__ __forceinline__ int rest_col(int cd) { return 12 + (cd - CD_EX0); }
-
-// visual part of pose-system entry (hi, lo), hi >= lo, both < 79 (or the gradient: hi = -1): sums the window's Gram slots in chunk
-// order, t ascending — a fixed order, so a window gives bitwise the same system whatever batch it is solved in
-__device__ double visual_entry(const double *gs, const unsigned *chunk_tab, int nch, int hi, int lo) {
-  const bool grad = hi < 0;
-  const bool lo_pose = lo < 66;
-  const int fl = lo_pose ? lo / 6 : -1, il = lo_pose ? lo - 6 * fl : 0;
-  const bool hi_pose = !grad && hi < 66;
-  const int fh = hi_pose ? hi / 6 : -1, ih = hi_pose ? hi - 6 * fh : 0;
-  const int ch_ = grad ? 25 : (hi_pose ? 0 : rest_col(hi));   // local column of a non-pose hi (or r)
-  double sum = 0.0;
-  for (int c = 0; c < nch; ++c) {
-    const unsigned ct = chunk_tab[c];
-    const int s = ct & 255, km = (ct >> 8) & 255, sl0 = ct >> 16;
-    if (!lo_pose) {   // rest x rest (or rest x r): every slot of the window
-      const int e = tri26(rest_col(lo), ch_);
-      for (int t = 0; t < km; ++t) sum += gs[(size_t)(sl0 + t) * VILO_GRAM + e];
-    } else if (!hi_pose) {   // pose f x rest / r: as start pose in every slot of its own chunks, as pose j in slot f - s of earlier chunks
-      if (s == fl) {
-        const int e = tri26(il, ch_);
-        for (int t = 0; t < km; ++t) sum += gs[(size_t)(sl0 + t) * VILO_GRAM + e];
-      } else if (s < fl && fl - s < km) {
-        sum += gs[(size_t)(sl0 + fl - s) * VILO_GRAM + tri26(6 + il, ch_)];
-      }
-    } else if (fl == fh) {   // pose f x pose f
-      if (s == fl) {
-        const int e = tri26(il, ih);
-        for (int t = 0; t < km; ++t) sum += gs[(size_t)(sl0 + t) * VILO_GRAM + e];
-      } else if (s < fl && fl - s < km) {
-        sum += gs[(size_t)(sl0 + fl - s) * VILO_GRAM + tri26(6 + il, 6 + ih)];
-      }
-    } else {   // pose fl x pose fh, fl < fh: start pose fl, observed in frame fh
-      if (s == fl && fh - fl < km) sum += gs[(size_t)(sl0 + fh - fl) * VILO_GRAM + tri26(il, 6 + ih)];
-    }
-  }
-  return sum;
-}
-
-// IMU-factor part of pose-system entry (hi, lo) (pose x pose only; gradient: hi = -1)
-__device__ double imu_pose_entry(const double *igram, int F, int hi, int lo) {
-  if (lo >= 66) return 0.0;
-  const int fl = lo / 6, il = lo - 6 * fl;
-  double sum = 0.0;
-  if (hi < 0) {
-    if (fl < F - 1) sum += igram[fl * 780 + tri39(il, 38)];
-    if (fl >= 1 && fl < F) sum += igram[(fl - 1) * 780 + tri39(19 + il, 38)];
-    return sum;
-  }
-  if (hi >= 66) return 0.0;
-  const int fh = hi / 6, ih = hi - 6 * fh;
-  if (fh == fl) {
-    if (fl < F - 1) sum += igram[fl * 780 + tri39(il, ih)];
-    if (fl >= 1 && fl < F) sum += igram[(fl - 1) * 780 + tri39(19 + il, 19 + ih)];
-  } else if (fh == fl + 1 && fh < F) {
-    sum += igram[fl * 780 + tri39(il, 19 + ih)];
-  }
-  return sum;
+// =================================================================================================
+// k_assemble
+// =================================================================================================
+// position of pose-system entry (row, col) (tile row >= tile column) in the accumulator-order image: tile, register row >> 2, lane
+__device__ __forceinline__ int cimg_pos(int row, int col) {
+  const int rr = row & 15;
+  return 256 * tile_index(row >> 4, col >> 4) + 64 * (rr >> 2) + 16 * (rr & 3) + (col & 15);
 }
 
 #define ASM_THREADS 256
-#define ASM_BLOCKS_PER_WIN 16   // 16 x 256 = 4096 >= 3840 matrix entries + 224 gradient entries
 
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble_pose(BatchDev b) {
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b) {
+  __shared__ double Cl[CIMG_N];
+  __shared__ double gl[CD_N];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
-  const int win = blockIdx.x / ASM_BLOCKS_PER_WIN, part = blockIdx.x % ASM_BLOCKS_PER_WIN;
+  const int win = blockIdx.x, tid = threadIdx.x;
   const SolverState &st = b.st[win];
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[win];
-  const int tid = threadIdx.x, F = wm.n_frames, nch = min(wm.n_chunks, 64);
-  if (tid < nch) {
-    const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
-    chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
-  }
+  const int F = wm.n_frames, cmask = wm.const_mask, kb = wm.pad, pn = wm.prior_n;
   const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
   const double *igram = b.imu_gram + (size_t)win * 10 * 780;
   const double *pd = b.prior_dense + (size_t)win * PD_N;
-  const int idx = part * ASM_THREADS + tid;
-  if (idx >= CIMG_N) {
-    // gradient of the 224 camera dimensions: the prior's b0 + H dx for all of them (H dx of the current point was formed by k_accept),
-    // the visual and IMU parts for the pose system (the speed / leg-bias part adds its IMU terms in the solver)
-    for (int e = tid; e < CD_N; e += ASM_THREADS) inv_pmap[e] = -1;
-    __syncthreads();
-    if (tid < wm.prior_n) inv_pmap[b.prior_map[(size_t)win * 96 + tid]] = (short)tid;
-    __syncthreads();
-    const int cd = idx - CIMG_N;
-    if (cd < CD_N) {
-      const int pi = inv_pmap[cd];
-      double g = (wm.prior_n > 0 && pi >= 0) ? b.prior_b0[(size_t)win * 96 + pi] + b.prior_hd[(size_t)win * 96 + pi] : 0.0;
-      if (cd < VILO_NPU) g += visual_entry(gs, chunk_tab, nch, -1, cd) + imu_pose_entry(igram, F, -1, cd);
-      if (!cd_active(cd, F, wm.const_mask)) g = 0.0;
-      b.cam_gin[(size_t)win * CD_N + cd] = g;
-    }
-    return;
+  double *bimg = b.Bimg + (size_t)win * BI_N;
+
+  // ---- the pose system starts from the prior's pre-assembled image (zeros without a prior) ----
+  for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
+    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
+    Cl[idx] = pd[PD_C + max(row, col) * PD_CLD + min(row, col)];
+  }
+  for (int e = tid; e < CD_N; e += ASM_THREADS) inv_pmap[e] = -1;
+  if (tid < min(wm.n_chunks, 64)) {
+    const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
+    chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
   }
   __syncthreads();
-  const int tile = idx >> 8, r = (idx >> 6) & 3, lane = idx & 63, lr = lane & 15, lk = lane >> 4;
-  int I = 0;
-  while (tile_index(I + 1, 0) <= tile) ++I;
-  const int J = tile - tile_index(I, 0);
-  const int row = 16 * I + lk + 4 * r, col = 16 * J + lr;
-  const int hi = max(row, col), lo = min(row, col);
-  double v;
-  if (!cd_active(hi, F, wm.const_mask) || !cd_active(lo, F, wm.const_mask)) {
-    v = (hi == lo) ? 1.0 : 0.0;   // constant blocks / absent frames / padding: identity rows and columns
-  } else {
-    v = pd[PD_C + hi * PD_CLD + lo] + visual_entry(gs, chunk_tab, nch, hi, lo) + imu_pose_entry(igram, F, hi, lo);
+  if (tid < pn) inv_pmap[b.prior_map[(size_t)win * 96 + tid]] = (short)tid;
+  __syncthreads();
+  // gradient starts from the prior's b0 + H dx (H dx at the current point was formed by k_accept when it evaluated this point's cost)
+  for (int e = tid; e < CD_N; e += ASM_THREADS) {
+    const int pi = inv_pmap[e];
+    gl[e] = (pn > 0 && pi >= 0) ? b.prior_b0[(size_t)win * 96 + pi] + b.prior_hd[(size_t)win * 96 + pi] : 0.0;
   }
-  b.Cimg[(size_t)win * CIMG_N + idx] = v;
+  __syncthreads();
+
+  // ---- plain (non-atomic) read-modify-write scatter: every target has exactly one owner thread. Two packed Gram entries can hit the
+  //      same target only if they are "twins" (the same local pair taken once in the pose_s block and once in the pose_j block; for IMU
+  //      factors once in the frame-i half and once in the frame-j half of the previous factor), so a thread owns an entry and its twin ----
+  auto rmw = [&](int hi, int lo, double v) {   // lower position + mirror inside a diagonal tile
+    Cl[cimg_pos(hi, lo)] += v;
+    if (hi != lo && (hi >> 4) == (lo >> 4)) Cl[cimg_pos(lo, hi)] += v;
+  };
+  {
+    // visual Gram slots: 246 owner groups, one per thread
+    // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
+    // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
+    int a = 0, bc = 0, cls = 0;
+    if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+    else if (tid < 57) { cls = 2; a = (tid - 21) / 6; bc = 6 + (tid - 21) % 6; }
+    else if (tid < 141) { cls = 3; a = (tid - 57) / 14; bc = 12 + (tid - 57) % 14; }
+    else if (tid < 246) { cls = 4; int rem = tid - 141; while (rem >= 14 - a) { rem -= 14 - a; ++a; } bc = 12 + a + rem; a += 12; }
+    const bool isg = (bc == 25), dead = (cls == 0) || (a == 25);
+    const int e1 = tri26(min(a, 25), bc), e2 = (cls == 1) ? tri26(a + 6, bc + 6) : (cls == 3 ? tri26(a + 6, bc) : e1);
+    auto restcd = [](int c) { return c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD); };
+    const int rb = (bc >= 12 && bc < 25) ? restcd(bc) : 0, ra_ = (a >= 12 && a < 25) ? restcd(a) : 0;
+    // Walk the window's chunks (fixed s, t = 0 .. kmax-1), two per trip = 44 loads in flight. Per chunk:
+    //  stage 1: the entry's own target depends on s only (V1, V3, V4): sum over t in a register, one read-modify-write
+    //  stage 2: the j-dependent target (twin of V1 / V3, the entry itself for V2)
+    const int nch = min(wm.n_chunks, 64);
+    for (int ch0 = 0; ch0 < nch; ch0 += 2) {
+      double v1[2][11], v2[2][11];
+      int cs2[2], km2[2];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const unsigned ct = chunk_tab[min(ch0 + c2, nch - 1)];
+        cs2[c2] = ct & 255; km2[c2] = (ct >> 8) & 255;
+        const int sl0 = ct >> 16;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+          const int tc = min(t, km2[c2] - 1);
+          v1[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
+          v2[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
+        }
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        if (ch0 + c2 >= nch) continue;
+        const int s_ = cs2[c2], km = km2[c2];
+        if (cls != 2 && !dead) {
+          double sum = 0.0;
+#pragma unroll
+          for (int t = 0; t < 11; ++t) sum += (t < km) ? v1[c2][t] : 0.0;
+          if (isg) gl[cls == 4 ? ra_ : 6 * s_ + a] += sum;
+          else if (cls == 1) rmw(6 * s_ + bc, 6 * s_ + a, sum);
+          else if (cls == 3) rmw(rb, 6 * s_ + a, sum);
+          else rmw(rb, ra_, sum);
+        }
+        if (cls >= 1 && cls <= 3) {
+#pragma unroll
+          for (int t = 1; t < 11; ++t) {
+            if (t < km) {
+              const int j_ = s_ + t;
+              const double val = (cls == 2) ? v1[c2][t] : v2[c2][t];
+              if (cls == 3 && isg) gl[6 * j_ + a] += val;
+              else if (cls == 1) rmw(6 * j_ + bc, 6 * j_ + a, val);
+              else if (cls == 2) rmw(6 * j_ + (bc - 6), 6 * s_ + a, val);
+              else rmw(rb, 6 * j_ + a, val);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();   // the IMU owners below are different threads
+  {
+    // IMU factor Grams, pose part: I1 pose_i x pose_i (21, twin +19), I3 pose gradient (6, twin +19), I4 pose_i x pose_j (36)
+    int a = 0, bc = 0, cls = 0;
+    if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
+    else if (tid < 27) { cls = 3; a = tid - 21; bc = 38; }
+    else if (tid < 63) { cls = 4; a = (tid - 27) / 6; bc = 19 + (tid - 27) % 6; }
+    if (cls) {
+      const int e1 = tri39(a, bc), e2 = (cls == 4) ? e1 : tri39(a + 19, cls == 3 ? 38 : bc + 19);
+      double vm[10], vt[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { vm[k] = igram[min(k, F - 2) * 780 + e1]; vt[k] = igram[min(k, F - 2) * 780 + e2]; }
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        if (k >= F - 1) continue;
+        if (cls == 1) { rmw(6 * k + bc, 6 * k + a, vm[k]); rmw(6 * (k + 1) + bc, 6 * (k + 1) + a, vt[k]); }
+        else if (cls == 3) { gl[6 * k + a] += vm[k]; gl[6 * (k + 1) + a] += vt[k]; }
+        else rmw(6 * (k + 1) + (bc - 19), 6 * k + a, vm[k]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pose system out: constant blocks / absent frames / padding as identity rows and columns ----
+  for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
+    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
+    double v = Cl[idx];
+    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) v = (row == col) ? 1.0 : 0.0;
+    b.Cimg[(size_t)win * CIMG_N + idx] = v;
+    if (row == col) bimg[BI_DIAG + row] = v;
+  }
+  // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams ----
+  for (int e = tid; e < 11 * 169; e += ASM_THREADS) {   // A_kk: factor k (frame k is "i": columns 6..18), factor k - 1 ("j": 25..37), prior at frame kb
+    const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
+    double val;
+    if (!cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(CD_B0 + 13 * k + j, F, cmask)) {
+      val = (i == j) ? 1.0 : 0.0;
+    } else {
+      val = (k == kb) ? pd[PD_AD + e] : 0.0;
+      if (k < F - 1) val += igram[k * 780 + tri39(6 + min(i, j), 6 + max(i, j))];
+      if (k >= 1) val += igram[(k - 1) * 780 + tri39(25 + min(i, j), 25 + max(i, j))];
+    }
+    bimg[BI_AD + e] = val;
+    if (i == j) bimg[BI_DIAG + CD_B0 + 13 * k + i] = val;
+  }
+  for (int e = tid; e < 10 * 169; e += ASM_THREADS) {   // A_{k+1,k} transposed: [k][j = dimension of frame k][i = dimension of frame k + 1]
+    const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
+    double val = 0.0;
+    if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) val = igram[k * 780 + tri39(6 + j, 25 + i)];
+    bimg[BI_AOT + e] = val;
+  }
+  for (int e = tid; e < 11 * 13 * 18; e += ASM_THREADS) {   // coupling of dimension i of frame k with pose k - 1 + df, column c
+    const int k = e / 234, is = e - 234 * k, i = is / 18, s = is - 18 * i, df = s / 6, c = s - 6 * df, f = k - 1 + df;
+    double val = 0.0;
+    if (f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
+      if (df == 1) {
+        if (k < F - 1) val += igram[k * 780 + tri39(c, 6 + i)];
+        if (k >= 1) val += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
+      } else if (df == 2) {
+        if (k < F - 1) val += igram[k * 780 + tri39(6 + i, 19 + c)];
+      } else {
+        val += igram[(k - 1) * 780 + tri39(c, 25 + i)];   // (f >= 0 means k >= 1)
+      }
+    }
+    bimg[BI_BS + e] = val;
+  }
+  for (int e = tid; e < 13 * 80; e += ASM_THREADS) {   // prior rows of the frame whose speed / leg-bias block it touches
+    const int i = e / 80, p = e - 80 * i;
+    bimg[BI_BP + e] = (kb >= 0 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) ? pd[PD_BP + e] : 0.0;
+  }
+  // gradient: visual + IMU pose part + prior from the LDS vector; the speed / leg-bias dimensions add their IMU terms here
+  for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
+    double g = gl[cd];
+    if (cd >= CD_B0 && cd < CD_B0 + 143) {
+      const int k = (cd - CD_B0) / 13, i = (cd - CD_B0) - 13 * k;
+      if (k < F - 1) g += igram[k * 780 + tri39(6 + i, 38)];
+      if (k >= 1 && k < F) g += igram[(k - 1) * 780 + tri39(25 + i, 38)];
+    }
+    if (!cd_active(cd, F, cmask)) g = 0.0;
+    b.cam_gin[(size_t)win * CD_N + cd] = g;
+  }
+  if (tid == 0) { bimg[BI_DIAG + 79] = 1.0; bimg[BI_DIAG + 223] = 1.0; }
 }
 
 // =================================================================================================
@@ -149,18 +233,15 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble_pose(BatchDev b) {
 #define WS_V 4080
 #define WS_SCR 4160
 #define WS_TOTAL 5120
-// while the pose tiles live in registers (until the Cholesky) their LDS region holds the speed / leg-bias part
-#define WC_AD 0         // [11][169] diagonal blocks
-#define WC_AO 1859      // [10][169] rows frame k + 1, columns frame k
-#define WC_VB 3552      // [143] v = g / dhat^2 of the speed / leg-bias dimensions
-#define WC_DB 3696      // [143] dhat^2
+// while the pose tiles live in registers (until the Cholesky) their LDS region holds vectors of the speed / leg-bias part
+#define WC_VB 0         // [144] v = g / dhat^2
+#define WC_DB 144       // [144] dhat^2
+#define WC_GB 288       // [144] gradient
 // scratch during the chain
-#define WX_LM 0         // 13 x 13: L_k, then M_k = L_k^-1
+#define WX_LM 0         // 13 x 13: M_k = L_k^-1
 #define WX_TA0 176
 #define WX_TA1 352
-#define WX_RINV 528     // 16
-#define WX_SN 544       // 13 x 13: S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
-#define WX_GB 720       // [143] gradient of the speed / leg-bias dimensions
+#define WX_SN 528       // 13 x 13: S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
 // scratch during the Cholesky / solves
 #define WX_D16 0        // 16 x 17
 #define WX_LI16 272     // 16 x 17 + 16
@@ -169,34 +250,13 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble_pose(BatchDev b) {
 // back-substitution of the speed / leg-bias part (the factor in the C region is dead by then)
 #define WB_M 0          // [11][169]
 #define WB_TA 1859      // [11][169]
-#define WX_U 0          // [143]
-#define WX_YB 144       // [143]
+#define WX_U 0          // [144]
+#define WX_YB 144       // [144]
 #define WX_DEL 288      // [224] step of the camera dimensions
-#define WX_GB2 512      // [143] gradient of the speed / leg-bias dimensions (again: the Cholesky scratch overwrote WX_GB)
 
 extern "C" size_t vilo_solve_wave_lds_bytes() { return (size_t)WS_TOTAL * sizeof(double); }
 
 __device__ __forceinline__ int cswz(int t, int r, int c) { return WS_C + 256 * t + 16 * r + ((c + r) & 15); }
-
-// IMU + prior coupling of speed / leg-bias dimension i of frame k with pose-system column p (the B block of the arrow system).
-// Factor k (frames k, k + 1) has frame k as "i" (bias rows 6 + i) and factor k - 1 has it as "j" (bias rows 25 + i).
-__device__ __forceinline__ double b_coupling(const double *igram, const double *pd, int F, int kb, int cmask, int k, int i, int p) {
-  if (i >= 13 || p >= VILO_NPU || !cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(p, F, cmask)) return 0.0;
-  double v = 0.0;
-  if (p < 66) {
-    const int f = p / 6, c = p - 6 * f;
-    if (f == k) {
-      if (k < F - 1) v += igram[k * 780 + tri39(c, 6 + i)];
-      if (k >= 1) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
-    } else if (f == k + 1) {
-      if (k < F - 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
-    } else if (f == k - 1) {
-      v += igram[(k - 1) * 780 + tri39(c, 25 + i)];
-    }
-  }
-  if (k == kb) v += pd[PD_BP + i * 80 + p];
-  return v;
-}
 
 // 16 x 16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80 x 80 factorisation).
 // A: LDS 16 x 17 row-major in. Lane i (< 16, replicated in the four 16-lane groups) owns row i; pivots broadcast with v_readlane.
@@ -223,18 +283,19 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
   if (lane < 16) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) lds[cswz(t, lane, j)] = a[j];
-    Linv[16 * 17 + lane] = myrinv;
   }
-  // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers
-  double rv[16], cl[16];
+  // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers. (The copies are opaque to the
+  // compiler: it would otherwise recognise these broadcasts as the ones of the factorisation loop and keep all 120 alive in SGPRs.)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rv[i] = readlane_d(myrinv, i);
+  for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(a[j]));
+  double cl[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     double v = (i == row) ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < i; ++q) v -= readlane_d(a[q], i) * cl[q];   // L[i][q] lives in lane i, register q
-    cl[i] = v * rv[i];
+    cl[i] = v * readlane_d(myrinv, i);
+    __builtin_amdgcn_sched_barrier(0);   // keep the v_readlane results (SGPR pairs) of one row at a time: hoisted, they spill by the hundred
   }
   if (lane < 16) {
 #pragma unroll
@@ -252,9 +313,6 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
   const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
   const WinMeta wm = b.win[win];
   const int F = wm.n_frames, L = wm.L, kb = wm.pad, cmask = wm.const_mask;
-  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
-  double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
-  double *cam_scale = b.cam_scale + (size_t)win * CD_N;
   double *g = lds + WS_G, *dh2 = lds + WS_DH2, *y = lds + WS_Y, *v = lds + WS_V, *scr = lds + WS_SCR;
   // gradient, dogleg diagonal and Gauss-Newton step of the 143 speed / leg-bias dimensions: dimension lane + 64 m in register m
   double gBr[3], dBr[3], yBr[3];
@@ -263,152 +321,96 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
     if (lane == 0) st.phase_clk[0] = clock64();
     const double *Cimg = b.Cimg + (size_t)win * CIMG_N;
     const double *gin = b.cam_gin + (size_t)win * CD_N;
-    const double *igram = b.imu_gram + (size_t)win * 10 * 780;
-    const double *pd = b.prior_dense + (size_t)win * PD_N;
+    const double *bimg = b.Bimg + (size_t)win * BI_N;
     const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
     double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
            *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
     double *Mg = b.Lk + (size_t)win * 11 * 169, *TAg = b.TAg + (size_t)win * 11 * 169;
+    double *cam_scale = b.cam_scale + (size_t)win * CD_N;
     const bool first_scale = !st.scale_ready;
+    double mu = st.mu;
 
-    // ---- the speed / leg-bias part into LDS: diagonal blocks A_kk (IMU factors k and k - 1, prior at frame kb), off-diagonal blocks
-    //      A_{k+1,k}; constant / absent dimensions as identity rows ----
-    for (int e = lane; e < 11 * 169; e += 64) {
-      const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
-      double val;
-      if (!cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(CD_B0 + 13 * k + j, F, cmask)) {
-        val = (i == j) ? 1.0 : 0.0;
-      } else {
-        val = (k == kb) ? pd[PD_AD + e] : 0.0;
-        if (k < F - 1) val += igram[k * 780 + ig_idx(6 + i, 6 + j)];
-        if (k >= 1) val += igram[(k - 1) * 780 + ig_idx(25 + i, 25 + j)];
-      }
-      lds[WC_AD + e] = val;
-    }
-    for (int e = lane; e < 10 * 169; e += 64) {
-      const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;   // row: dimension i of frame k + 1, column: dimension j of frame k
-      double val = 0.0;
-      if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) val = igram[k * 780 + tri39(6 + j, 25 + i)];
-      lds[WC_AO + e] = val;
-    }
-    // gradient, Jacobi scaling (first linearisation), dogleg diagonal and v = D^-2 g of the speed / leg-bias dimensions
+    // ---- Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g: the 224 camera dimensions, then the landmarks ----
     double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
+    auto scale_dim = [&](int cd, double &ge, double &d, double &ve) {
+      ge = gin[cd]; d = 1.0; ve = 0.0;
+      if (cd_active(cd, F, cmask)) {
+        const double hii = bimg[BI_DIAG + cd];
+        double sc;
+        if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
+        else sc = cam_scale[cd];
+        const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
+        d = d2 / (sc * sc);
+        ve = ge / d;
+      }
+      part_gn += ge * ve;
+      part_gmax = fmax(part_gmax, fabs(ge));
+    };
+    for (int cd = lane; cd < 80; cd += 64) {
+      double ge, d, ve;
+      scale_dim(cd, ge, d, ve);
+      g[cd] = ge; dh2[cd] = d; v[cd] = ve;
+    }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const int e = lane + 64 * m;
       gBr[m] = 0.0; dBr[m] = 1.0; yBr[m] = 0.0;
-      if (e < 143) {
-        const int k = e / 13, i = e - 13 * k, cd = CD_B0 + e;
-        double hii = 1.0, ge = 0.0, d = 1.0, ve = 0.0;
-        if (cd_active(cd, F, cmask)) {
-          hii = (k == kb) ? pd[PD_AD + k * 169 + i * 14] : 0.0;
-          ge = gin[cd];
-          if (k < F - 1) { hii += igram[k * 780 + tri39(6 + i, 6 + i)]; ge += igram[k * 780 + tri39(6 + i, 38)]; }
-          if (k >= 1) { hii += igram[(k - 1) * 780 + tri39(25 + i, 25 + i)]; ge += igram[(k - 1) * 780 + tri39(25 + i, 38)]; }
-          double sc;
-          if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
-          else sc = cam_scale[cd];
-          const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
-          d = d2 / (sc * sc);
-          ve = ge / d;
-        }
-        gBr[m] = ge; dBr[m] = d;
-        lds[WC_VB + e] = ve;
-        lds[WC_DB + e] = d;
-        scr[WX_GB + e] = ge;
-        part_gn += ge * ve;
-        part_gmax = fmax(part_gmax, fabs(ge));
+      if (e < 144) {
+        double ve;
+        scale_dim(CD_B0 + e, gBr[m], dBr[m], ve);
+        lds[WC_VB + e] = ve; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m];
       }
     }
+    for (int l = lane; l < L; l += 64) {
+      const double E = lm_E[l], gl = lm_g[l];
+      double sc;
+      if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
+      else sc = lm_scale[l];
+      const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
+      lm_dh2[l] = d2;
+      const double vl = gl / d2;
+      part_q += E * vl * vl;   // the cross term 2 vl w_l^T v is accumulated in the Schur pass below
+      lm_y[l] = vl;            // (scratch until the back-substitution overwrites it)
+      part_gn += gl * vl;
+      part_gmax = fmax(part_gmax, fabs(gl));
+    }
+    const double gnorm2 = wave_sum(part_gn), gmax = wave_max(part_gmax);
+    if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
+      if (lane == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
+      return;
+    }
+    lds_fence();
 
-    bool solved = false;
-    bool have_q = false;
-    double gnorm2 = 0.0, gmax = 0.0, qq = 0.0, gnnorm2 = 0.0, gy = 0.0;
-    double mu = st.mu;
+    bool solved = false, have_q = false;
+    double qq = 0.0, gnnorm2 = 0.0, gy = 0.0;
+    const int lane_outer = lane;
     while (!solved) {
+      // The body almost never repeats (only when a factorisation fails and mu grows). The lane index is made opaque per trip so that the
+      // compiler does not hoist every lane-derived address of the body out of the "loop" and spill it across the whole kernel.
+      int lane = lane_outer;
+      asm volatile("" : "+v"(lane));
+      const int lr = lane & 15, lk = lane >> 4;
+      // per-lane constants of the coupling-block gathers: column 16 X + lr of the pose system is column oX of pose fX
+      int fX[5], oX[5];
+#pragma unroll
+      for (int X = 0; X < 5; ++X) { const int col = 16 * X + lr; fX[X] = col < 66 ? col / 6 : 99; oX[X] = col < 66 ? col - 6 * fX[X] : 0; }
       if (lane == 0) st.phase_clk[1] = clock64();
+      for (int l = lane; l < L; l += 64) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
       // ---- pose system: 15 lower tiles in accumulator order, one coalesced load per register ----
       mfma_d4 acc[15];
 #pragma unroll
       for (int t = 0; t < 15; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = Cimg[(t * 4 + r) * 64 + lane];
-      if (!have_q) {
-        // diagonal -> Jacobi scaling, dogleg diagonal, v = D^-2 g
+      if (!have_q) {   // q = v^T H v, pose tiles
 #pragma unroll
-        for (int I = 0; I < 5; ++I)
+        for (int t = 0; t < 15; ++t) {
+          const int I = c_tI[t], J = c_tJ[t];
+          const double vc = v[16 * J + lr] * ((I == J) ? 1.0 : 2.0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (lk + 4 * r == lr) y[16 * I + lr] = acc[tile_index(I, I)][r];
-        lds_fence();
-        for (int cd = lane; cd < 80; cd += 64) {
-          const double ge = gin[cd];
-          double d = 1.0, ve = 0.0;
-          if (cd_active(cd, F, cmask)) {
-            const double hii = y[cd];
-            double sc;
-            if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
-            else sc = cam_scale[cd];
-            const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
-            d = d2 / (sc * sc);
-            ve = ge / d;
-          }
-          g[cd] = ge; dh2[cd] = d; v[cd] = ve;
-          part_gn += ge * ve;
-          part_gmax = fmax(part_gmax, fabs(ge));
-        }
-        lds_fence();
-        // q = v^T H v: pose tiles
-#pragma unroll
-        for (int I = 0; I < 5; ++I)
-#pragma unroll
-          for (int J = 0; J <= I; ++J) {
-            const double vc = v[16 * J + lr], sym = (I == J) ? 1.0 : 2.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part_q += sym * v[16 * I + lk + 4 * r] * acc[tile_index(I, J)][r] * vc;
-          }
-        // speed / leg-bias rows: v_B^T (A_BB v_B + 2 B v_P), one lane per (frame, dimension)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const int e = lane + 64 * m;
-          if (e < 143) {
-            const int k = e / 13, i = e - 13 * k;
-            if (k < F) {
-              const double vi = lds[WC_VB + e];
-              double sacc = 0.0, cross = 0.0, bp = 0.0;
-              for (int j = 0; j < 13; ++j) sacc += lds[WC_AD + k * 169 + i * 13 + j] * lds[WC_VB + 13 * k + j];
-              if (k > 0)
-                for (int j = 0; j < 13; ++j) cross += lds[WC_AO + (k - 1) * 169 + i * 13 + j] * lds[WC_VB + 13 * (k - 1) + j];
-              if (vi != 0.0) {   // (an inactive dimension has v = 0 and no coupling)
-                const int p0 = (k == kb) ? 0 : max(0, 6 * (k - 1)), p1 = (k == kb) ? VILO_NPU : min(66, 6 * (k + 2));
-                for (int p = p0; p < p1; ++p) bp += b_coupling(igram, pd, F, kb, cmask, k, i, p) * v[p];
-              }
-              part_q += vi * (sacc + 2.0 * cross + 2.0 * bp);
-            }
-          }
-        }
-        // landmarks, pass 1
-        for (int l = lane; l < L; l += 64) {
-          const double E = lm_E[l], gl = lm_g[l];
-          double sc;
-          if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
-          else sc = lm_scale[l];
-          const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
-          lm_dh2[l] = d2;
-          const double vl = gl / d2;
-          part_q += E * vl * vl;   // the cross term 2 vl w_l^T v is accumulated in the Schur pass below
-          lm_y[l] = vl;            // (scratch until the back-substitution overwrites it)
-          part_gn += gl * vl;
-          part_gmax = fmax(part_gmax, fabs(gl));
-        }
-        gnorm2 = wave_sum(part_gn);
-        gmax = wave_max(part_gmax);
-        if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
-          if (lane == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
-          return;
+          for (int r = 0; r < 4; ++r) part_q += v[16 * I + lk + 4 * r] * acc[t][r] * vc;
         }
       }
-      for (int l = lane; l < L; l += 64) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
       if (lane == 0) st.phase_clk[2] = clock64();
 
       // ---- block-tridiagonal Cholesky chain of the speed / leg-bias part (13 x 13 blocks, frames F-1 .. 0):
@@ -421,35 +423,76 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       {
         const int grp = lk, c = lr;
         const int row = c < 13 ? c : 0;
-        double *LM = scr + WX_LM, *rinvk = scr + WX_RINV, *SN = scr + WX_SN, *GB = scr + WX_GB;
+        double *LM = scr + WX_LM, *SN = scr + WX_SN;
         double *TAcur = scr + WX_TA0, *TAprev = scr + WX_TA1;
+        const double *VB = lds + WC_VB, *DB = lds + WC_DB, *GB = lds + WC_GB;
         mfma_d4 T[5];
         double yr[5];
 #pragma unroll
         for (int X = 0; X < 5; ++X) { T[X] = mfma_d4{0.0, 0.0, 0.0, 0.0}; yr[X] = 0.0; }
         for (int k = F - 1; k >= 0; --k) {
+          // ---- this frame's blocks from the assembled image ----
           // [B_k | g_k] in accumulator order: row lk + 4 r (< 13), column 16 X + lr; column 79 carries the gradient
           mfma_d4 V[5];
-          const int x_lo = max(0, (6 * (k - 1)) >> 4), x_hi = min(4, (6 * (k + 2) - 1) >> 4);
 #pragma unroll
           for (int X = 0; X < 5; ++X) {
-            V[X] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-            if (k == kb || (X >= x_lo && X <= x_hi)) {
+            const int df = fX[X] - k + 1;
+            const bool on = df >= 0 && df <= 2;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) V[X][r] = b_coupling(igram, pd, F, kb, cmask, k, lk + 4 * r, 16 * X + lr);
+            for (int r = 0; r < 4; ++r) {
+              const int i = lk + 4 * r;
+              double val = (on && i < 13) ? bimg[BI_BS + (k * 13 + min(i, 12)) * 18 + 6 * min(max(df, 0), 2) + oX[X]] : 0.0;
+              if (k == kb && i < 13) val += bimg[BI_BP + i * 80 + 16 * X + lr];
+              V[X][r] = val;
             }
           }
           if (lr == 15) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) V[4][r] = (lk + 4 * r < 13) ? GB[13 * k + lk + 4 * r] : 0.0;
           }
-          // S_k (lane = row): first frame straight from A_kk, later frames from the update left by the previous step
-          double a[13], l[13];
-          const double *Ssrc = (k == F - 1) ? lds + WC_AD + k * 169 : SN;
+          // S_k (lane = row): the top frame straight from A_kk, later frames from the update left by the previous step
+          double a[13], l[13], rhs[13];
+          if (k == F - 1) {
 #pragma unroll
-          for (int j = 0; j < 13; ++j) { a[j] = Ssrc[row * 13 + j]; l[j] = 0.0; }
+            for (int j = 0; j < 13; ++j) a[j] = bimg[BI_AD + (k * 13 + row) * 13 + j];
+            if (!have_q) {   // v_k^T A_kk v_k of the top frame
+              double sacc = 0.0;
+#pragma unroll
+              for (int j = 0; j < 13; ++j) sacc += a[j] * VB[13 * k + j];
+              if (lane < 13) part_q += VB[13 * k + lane] * sacc;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 13; ++j) a[j] = SN[row * 13 + j];
+          }
+#pragma unroll
+          for (int i = 0; i < 13; ++i) rhs[i] = (k > 0) ? bimg[BI_AOT + (max(k - 1, 0) * 13 + row) * 13 + i] : 0.0;   // column `row` of A_{k,k-1}
+          double adn[3];   // A_{k-1,k-1}, entry lane + 64 m
+#pragma unroll
+          for (int m = 0; m < 3; ++m) adn[m] = (k > 0 && lane + 64 * m < 169) ? bimg[BI_AD + (k - 1) * 169 + lane + 64 * m] : 0.0;
+          if (!have_q && k > 0) {
+            // q: 2 v_k^T A_{k,k-1} v_{k-1} (lane = column of the off-diagonal block) and v_{k-1}^T A_{k-1,k-1} v_{k-1} (entry-parallel)
+            double sacc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) sacc += rhs[i] * VB[13 * k + i];
+            if (lane < 13) part_q += 2.0 * VB[13 * (k - 1) + lane] * sacc;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const int e = lane + 64 * m, i = e / 13, j = e - 13 * i;
+              if (e < 169) part_q += adn[m] * VB[13 * (k - 1) + i] * VB[13 * (k - 1) + j];
+            }
+          }
+          if (!have_q) {
+            // q: 2 v_k^T B_k v_P with the accumulator-order copy of B_k (column 79 is the gradient, not a coupling)
+#pragma unroll
+            for (int X = 0; X < 5; ++X) {
+              const double vp = (X == 4 && lr == 15) ? 0.0 : v[16 * X + lr];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part_q += 2.0 * V[X][r] * vp * ((lk + 4 * r < 13) ? VB[13 * k + min(lk + 4 * r, 12)] : 0.0);
+            }
+          }
           {
-            const double md = mu * lds[WC_DB + 13 * k + row];
+            const double md = mu * DB[13 * k + row];
 #pragma unroll
             for (int j = 0; j < 13; ++j) a[j] += (j == row) ? md : 0.0;
           }
@@ -466,19 +509,17 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
           }
           // forward substitutions L x = rhs: T_A(k) columns (group 0), L^-1 columns (group 1); L broadcast from the owning lanes
-          double rhs[13], cl[13], rv[13];
+          // (opaque copies: see chol16_tile)
+#pragma unroll
+          for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(l[j]));
+          double cl[13];
 #pragma unroll
           for (int i = 0; i < 13; ++i) {
-            rv[i] = readlane_d(myrinv, i);
-            if (grp == 0) rhs[i] = (k > 0) ? lds[WC_AO + max(k - 1, 0) * 169 + i * 13 + row] : 0.0;
-            else rhs[i] = (i == c) ? 1.0 : 0.0;
-          }
-#pragma unroll
-          for (int i = 0; i < 13; ++i) {
-            double vv = rhs[i];
+            double vv = (grp == 0) ? rhs[i] : ((i == c) ? 1.0 : 0.0);
 #pragma unroll
             for (int q = 0; q < i; ++q) vv -= readlane_d(l[q], i) * cl[q];
-            cl[i] = vv * rv[i];
+            cl[i] = vv * readlane_d(myrinv, i);
+            __builtin_amdgcn_sched_barrier(0);   // (one row's v_readlane results at a time)
           }
           if (c < 13 && grp < 2) {
             if (grp == 0) {
@@ -492,12 +533,15 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           lds_fence();
           // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
           if (k > 0) {
-            for (int e = lane; e < 169; e += 64) {
-              const int i = e / 13, j = e - 13 * i;
-              double sacc = 0.0;
 #pragma unroll
-              for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
-              SN[e] = lds[WC_AD + (k - 1) * 169 + e] - sacc;
+            for (int m = 0; m < 3; ++m) {
+              const int e = lane + 64 * m, i = e / 13, j = e - 13 * i;
+              if (e < 169) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
+                SN[e] = adn[m] - sacc;
+              }
             }
           }
           // V -= T_A(k+1)^T T(k+1);  T(k) = M_k V
@@ -533,14 +577,14 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           }
           // C -= T_B^T T_B, rhs_P -= T_B^T t_g
 #pragma unroll
-          for (int I = 0; I < 5; ++I)
+          for (int t = 0; t < 15; ++t) {
+            const int I = c_tI[t], J = c_tJ[t];
 #pragma unroll
-            for (int J = 0; J <= I; ++J)
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) {
-                const double opa = (I == 4) ? T4[kk] : T[I][kk], opb = (J == 4) ? T4[kk] : T[J][kk];
-                acc[tile_index(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opa, opb, acc[tile_index(I, J)], 0, 0, 0);
-              }
+            for (int kk = 0; kk < 4; ++kk) {
+              const double opa = (I == 4) ? T4[kk] : T[I][kk], opb = (J == 4) ? T4[kk] : T[J][kk];
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opa, opb, acc[t], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int X = 0; X < 5; ++X)
 #pragma unroll
@@ -591,10 +635,8 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
             for (int X = 0; X < 5; ++X) op[X] = opb[bsel][u][X] * actv[X];
 #pragma unroll
-            for (int I = 0; I < 5; ++I)
-#pragma unroll
-              for (int J = 0; J <= I; ++J)
-                acc[tile_index(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[I] * ei), op[J], acc[tile_index(I, J)], 0, 0, 0);
+            for (int t = 0; t < 15; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[c_tI[t]] * ei), op[c_tJ[t]], acc[t], 0, 0, 0);
 #pragma unroll
             for (int X = 0; X < 5; ++X) { yacc[X] += op[X] * ge; qacc += op[X] * vv[X] * vl; }
           }
@@ -682,6 +724,13 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           if (lane == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = qq; st.gmax = gmax; st.scale_ready = 1; }
           return;
         }
+        // the vectors of the speed / leg-bias part shared the C region with the factor: put them back
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int e = lane + 64 * m;
+          if (e < 144) { lds[WC_VB + e] = gBr[m] / dBr[m]; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
+        }
+        lds_fence();
         continue;
       }
       if (lane == 0) st.phase_clk[5] = clock64();
@@ -694,7 +743,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         lds_fence();
         double b0 = v[lane], b1 = lane < 16 ? v[lane + 64] : 0.0;
         const int I0 = lane >> 4;   // tile row of this lane's first row; its second row (lane + 64 < 80) is in tile row 4
-#pragma unroll
+#pragma unroll 1
         for (int jb = 0; jb < 5; ++jb) {
           double l0[16], l1[16], ri[16];
 #pragma unroll
@@ -712,7 +761,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             if (lane == (j & 63)) { if (jb < 4) b0 = yj; else b1 = yj; }
           }
         }
-#pragma unroll
+#pragma unroll 1
         for (int jb = 4; jb >= 0; --jb) {
           double c0[16], c1[16], ri[16];
 #pragma unroll
@@ -736,33 +785,52 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       lds_fence();
       if (lane == 0) st.phase_clk[6] = clock64();
 
-      // ---- back-substitution of the speed / leg-bias part: c_k = g_k - B_k yP, then the two block-bidiagonal sweeps
+      // ---- back-substitution of the speed / leg-bias part: c = g_B - B yP, then the two block-bidiagonal sweeps
       //        u_k = M_k (c_k - T_A(k+1)^T u_{k+1})   k = F-1 .. 0,      y_k = M_k^T (u_k - T_A(k) y_{k-1})   k = 0 .. F-1 ----
       double part_gnn = 0.0, part_gy = 0.0;
+      // (pointers of the second half are formed again from an opaque copy of the window index: carried across the Cholesky as SGPR
+      // pairs they push its v_readlane broadcasts into spill lanes)
+      int win_b = win, lmoff_b = wm.lm_off;
+      asm volatile("" : "+s"(win_b), "+s"(lmoff_b));
+      const double *bimg = b.Bimg + (size_t)win_b * BI_N;
+      const double *Mg = b.Lk + (size_t)win_b * 11 * 169, *TAg = b.TAg + (size_t)win_b * 11 * 169;
+      const double *wl = b.lm_w + 80 * (size_t)lmoff_b;
+      const double *lm_g = b.lm_g + lmoff_b, *lm_dh2 = b.lm_dh2 + lmoff_b, *lm_einv = b.lm_einv + lmoff_b;
+      double *lm_y = b.lm_y + lmoff_b;
       {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // M_k / T_A(k) written by this wave during the chain
         for (int e = lane; e < F * 169; e += 64) { lds[WB_M + e] = Mg[e]; lds[WB_TA + e] = TAg[e]; }
-        double *U = scr + WX_U, *YB = scr + WX_YB, *GB2 = scr + WX_GB2;
-        // c_k: lane (lr = dimension i, lk = quarter of the columns); the IMU part of B_k spans poses k-1 .. k+1, the prior part frame kb only
-        for (int k = 0; k < F; ++k) {
-          double sacc = 0.0;
-          if (lr < 13) {
-            const int p0 = (k == kb) ? 0 : max(0, 6 * (k - 1)), p1 = (k == kb) ? VILO_NPU : min(66, 6 * (k + 2));
-            for (int p = p0 + lk; p < p1; p += 4) sacc += b_coupling(igram, pd, F, kb, cmask, k, lr, p) * y[p];
+        double *U = scr + WX_U, *YB = scr + WX_YB;
+        // c: the IMU part of B_k spans poses k-1 .. k+1 (one dimension per lane and trip), the prior part frame kb only
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int e = lane + 64 * m;
+          if (e < 143) {
+            const int k = e / 13;
+            double sacc = gBr[m];
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+              const int p = 6 * (k - 1) + s;
+              sacc -= bimg[BI_BS + e * 18 + s] * y[min(max(p, 0), 79)];   // (blocks outside the window are zero in the image)
+            }
+            U[e] = sacc;
           }
+        }
+        lds_fence();
+        if (kb >= 0) {
+          double sacc = 0.0;
+          if (lr < 13)
+            for (int p = lk; p < VILO_NPU; p += 4) sacc += bimg[BI_BP + lr * 80 + p] * y[p];
           sacc += __shfl_xor(sacc, 16, 64);
           sacc += __shfl_xor(sacc, 32, 64);
-          if (lane < 13) U[13 * k + lane] = sacc;   // (B_k yP)_i
+          if (lane < 13) U[13 * kb + lane] -= sacc;
         }
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-          if (lane + 64 * m < 143) GB2[lane + 64 * m] = gBr[m];
         lds_fence();
         const int row = lr < 13 ? lr : 0;
         // forward sweep
         double unext = 0.0;   // u_{k+1}[row]
         for (int k = F - 1; k >= 0; --k) {
-          double s = GB2[13 * k + row] - U[13 * k + row];
+          double s = U[13 * k + row];
           if (k < F - 1) {
 #pragma unroll
             for (int q = 0; q < 13; ++q) s -= lds[WB_TA + (k + 1) * 169 + q * 13 + row] * readlane_d(unext, q);
@@ -794,7 +862,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         for (int m = 0; m < 3; ++m) {
           const int e = lane + 64 * m;
           yBr[m] = (e < 13 * F) ? YB[e] : 0.0;
-          part_gnn += dBr[m] * yBr[m] * yBr[m] * ((e < 143 && cd_active(CD_B0 + e, F, cmask)) ? 1.0 : 0.0);
+          part_gnn += dBr[m] * yBr[m] * yBr[m];   // (y is zero on inactive dimensions)
           part_gy += gBr[m] * yBr[m];
         }
       }
@@ -814,7 +882,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         part_gy += gl * yl;
       }
       for (int cd = lane; cd < 80; cd += 64) {
-        part_gnn += dh2[cd] * y[cd] * y[cd] * (cd_active(cd, F, cmask) ? 1.0 : 0.0);
+        part_gnn += dh2[cd] * y[cd] * y[cd];
         part_gy += g[cd] * y[cd];
       }
       gnnorm2 = wave_sum(part_gnn);
@@ -826,11 +894,20 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           if (lane == 0) { st.lin_fail = 1; st.step_valid = 0; st.scale_ready = 1; }
           return;
         }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int e = lane + 64 * m;
+          if (e < 144) { lds[WC_VB + e] = gBr[m] / dBr[m]; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
+        }
+        lds_fence();
         continue;
       }
       solved = true;
     }
     // keep the linearisation's vectors for the steps that reuse it after a rejected candidate
+    int win_c = win;
+    asm volatile("" : "+s"(win_c));
+    double *cam_g = b.cam_g + (size_t)win_c * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win_c * CD_N, *cam_y = b.cam_y + (size_t)win_c * CD_N;
     for (int cd = lane; cd < 80; cd += 64) { cam_g[cd] = g[cd]; cam_dh2[cd] = dh2[cd]; cam_y[cd] = y[cd]; }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -845,6 +922,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       st.phase_clk[8] = clock64();
     }
   } else {
+    const double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
     for (int cd = lane; cd < 80; cd += 64) { g[cd] = cam_g[cd]; dh2[cd] = cam_dh2[cd]; y[cd] = cam_y[cd]; }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -863,6 +941,10 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
   }
   ca = readlane_d(ca, 0); cb = readlane_d(cb, 0); go = __builtin_amdgcn_readlane(go, 0);
   if (!go) return;
+  int win_d = win;
+  asm volatile("" : "+s"(win_d));
+  const double *x = b.x + (size_t)win_d * XSTRIDE;
+  double *xc = b.xc + (size_t)win_d * XSTRIDE;
   double *del = scr + WX_DEL;
   for (int cd = lane; cd < 80; cd += 64) del[cd] = -ca * g[cd] / dh2[cd] - cb * y[cd];
 #pragma unroll
@@ -888,7 +970,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   const size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (stage == 0) {
-    hipLaunchKernelGGL(k_assemble_pose, dim3(b.W * ASM_BLOCKS_PER_WIN), dim3(ASM_THREADS), 0, s, b);
+    hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

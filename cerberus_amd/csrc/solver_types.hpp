@@ -29,6 +29,15 @@
 #define PD_BP (PD_AD + 11 * 169)
 #define PD_N (PD_BP + 13 * 80)
 
+// assembled camera-side system of a window as the single-wave solver streams it (k_assemble -> k_solve_wave)
+#define CIMG_N 3840     // pose system: 15 lower 16 x 16 tiles x 4 accumulator registers x 64 lanes
+#define BI_AD 0         // [11][13][13]  diagonal blocks A_kk of the speed / leg-bias part
+#define BI_AOT 1859     // [10][13][13]  A_{k+1,k} transposed: [k][dimension of frame k][dimension of frame k + 1]
+#define BI_BS 3549      // [11][13][18]  IMU coupling of frame k's dimensions with poses k-1, k, k+1
+#define BI_BP 6128      // [13][80]      prior coupling rows of the frame whose speed / leg-bias block the prior touches
+#define BI_DIAG 7168    // [CD_N]        diagonal of the camera-side Hessian
+#define BI_N 7392
+
 #define CONST_LB 1
 #define CONST_EX 2
 #define CONST_TD 4
@@ -132,7 +141,8 @@ struct BatchDev {
   double *Tm, *Lk;            // [W][11][13*96] T_k = [T_A | T_B | t_g], [W][11][169] L_k^-1
   double *TAg;                // [W][11][169] T_A(k) = L_k^-1 A_{k,k-1} (single-wave solver: kept for the back-substitution sweeps)
   double *Cimg;               // [W][3840] assembled pose system: 15 lower 16 x 16 tiles in FP64-MFMA accumulator order (k_assemble_pose)
-  double *cam_gin;            // [W][CD_N] gradient at the linearisation point: complete for the pose system, prior part for the rest
+  double *cam_gin;            // [W][CD_N] gradient at the linearisation point (k_assemble)
+  double *Bimg;               // [W][BI_N] speed / leg-bias part of the assembled system (BI_* layout)
   SolverState *st;
   int *status;
 };

@@ -457,6 +457,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.TAg, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.Cimg, (size_t)W * 3840));
   TRYB(dev_alloc(ctx, bt, &D.cam_gin, (size_t)W * CD_N));
+  TRYB(dev_alloc(ctx, bt, &D.Bimg, (size_t)W * BI_N));
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));
   TRYB(dev_alloc(ctx, bt, &D.status, 1));
   if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
