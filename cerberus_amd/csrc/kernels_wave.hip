@@ -33,9 +33,9 @@ __device__ __forceinline__ int cimg_pos(int row, int col) {
 
 #define ASM_THREADS 256
 
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b) {
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
   __shared__ double Cl[CIMG_N];
-  __shared__ double gl[CD_N];
+  __shared__ double gl[CD_N], hd[CD_N], vS[CD_N], red[12];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
   const int win = blockIdx.x, tid = threadIdx.x;
@@ -159,14 +159,60 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b) {
     }
   }
   __syncthreads();
-  // ---- pose system out: constant blocks / absent frames / padding as identity rows and columns ----
+  // ---- constant blocks / absent frames / padding as identity rows and columns; diagonal and gradient of all 224 camera dimensions ----
   for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
     const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
     const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
     double v = Cl[idx];
-    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) v = (row == col) ? 1.0 : 0.0;
+    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) { v = (row == col) ? 1.0 : 0.0; Cl[idx] = v; }
+    if (row == col) hd[row] = v;
+  }
+  for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
+    double g = gl[cd];
+    if (cd >= CD_B0) {
+      double h = 1.0;
+      if (cd < CD_B0 + 143 && cd_active(cd, F, cmask)) {
+        const int k = (cd - CD_B0) / 13, i = (cd - CD_B0) - 13 * k;
+        h = (k == kb) ? pd[PD_AD + k * 169 + i * 14] : 0.0;
+        if (k < F - 1) { h += igram[k * 780 + tri39(6 + i, 6 + i)]; g += igram[k * 780 + tri39(6 + i, 38)]; }
+        if (k >= 1) { h += igram[(k - 1) * 780 + tri39(25 + i, 25 + i)]; g += igram[(k - 1) * 780 + tri39(25 + i, 38)]; }
+      }
+      hd[cd] = h;
+    }
+    if (!cd_active(cd, F, cmask)) g = 0.0;
+    gl[cd] = g;
+    b.cam_gin[(size_t)win * CD_N + cd] = g;
+  }
+  __syncthreads();
+  // ---- Jacobi scaling 1 / (1 + sqrt(H_ii)) frozen at the first linearisation, dogleg diagonal clamp(diag, 1e-6, 1e32) in the scaled
+  //      space, v = D^-2 g (Ceres 1.14 TrustRegionMinimizer / DoglegStrategy) ----
+  double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
+  for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
+    double d = 1.0, ve = 0.0;
+    const double ge = gl[cd];
+    if (cd_active(cd, F, cmask)) {
+      double sc;
+      double *cs = b.cam_scale + (size_t)win * CD_N + cd;
+      if (!st.scale_ready) { sc = jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[cd])) : 1.0; *cs = sc; }
+      else sc = *cs;
+      const double d2 = fmin(fmax(sc * sc * hd[cd], min_lm_diagonal), max_lm_diagonal);
+      d = d2 / (sc * sc);
+      ve = ge / d;
+    }
+    vS[cd] = ve;
+    bimg[BI_DH2 + cd] = d;
+    bimg[BI_V + cd] = ve;
+    part_gn += ge * ve;
+    part_gmax = fmax(part_gmax, fabs(ge));
+  }
+  __syncthreads();
+  // ---- pose system out in accumulator order; q = v^T H v of the camera-side rows is summed while the blocks pass through registers ----
+  for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
+    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
+    const double v = Cl[idx];
     b.Cimg[(size_t)win * CIMG_N + idx] = v;
-    if (row == col) bimg[BI_DIAG + row] = v;
+    part_q += ((c_tI[t] == c_tJ[t]) ? 1.0 : 2.0) * vS[row] * v * vS[col];   // (a diagonal tile holds both triangles)
   }
   // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams ----
   for (int e = tid; e < 11 * 169; e += ASM_THREADS) {   // A_kk: factor k (frame k is "i": columns 6..18), factor k - 1 ("j": 25..37), prior at frame kb
@@ -180,18 +226,19 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b) {
       if (k >= 1) val += igram[(k - 1) * 780 + tri39(25 + min(i, j), 25 + max(i, j))];
     }
     bimg[BI_AD + e] = val;
-    if (i == j) bimg[BI_DIAG + CD_B0 + 13 * k + i] = val;
+    part_q += vS[CD_B0 + 13 * k + i] * val * vS[CD_B0 + 13 * k + j];
   }
   for (int e = tid; e < 10 * 169; e += ASM_THREADS) {   // A_{k+1,k} transposed: [k][j = dimension of frame k][i = dimension of frame k + 1]
     const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
     double val = 0.0;
     if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) val = igram[k * 780 + tri39(6 + j, 25 + i)];
     bimg[BI_AOT + e] = val;
+    part_q += 2.0 * vS[CD_B0 + 13 * (k + 1) + i] * val * vS[CD_B0 + 13 * k + j];
   }
-  for (int e = tid; e < 11 * 13 * 18; e += ASM_THREADS) {   // coupling of dimension i of frame k with pose k - 1 + df, column c
-    const int k = e / 234, is = e - 234 * k, i = is / 18, s = is - 18 * i, df = s / 6, c = s - 6 * df, f = k - 1 + df;
+  for (int e = tid; e < 11 * 16 * 18; e += ASM_THREADS) {   // coupling of dimension i of frame k with pose k - 1 + df, column c (rows 13..15: zero padding)
+    const int k = e / 288, is = e - 288 * k, i = is / 18, s = is - 18 * i, df = s / 6, c = s - 6 * df, f = k - 1 + df;
     double val = 0.0;
-    if (f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
+    if (i < 13 && f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
       if (df == 1) {
         if (k < F - 1) val += igram[k * 780 + tri39(c, 6 + i)];
         if (k >= 1) val += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
@@ -200,25 +247,28 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b) {
       } else {
         val += igram[(k - 1) * 780 + tri39(c, 25 + i)];   // (f >= 0 means k >= 1)
       }
+      part_q += 2.0 * vS[CD_B0 + 13 * k + i] * val * vS[6 * f + c];
     }
     bimg[BI_BS + e] = val;
   }
-  for (int e = tid; e < 13 * 80; e += ASM_THREADS) {   // prior rows of the frame whose speed / leg-bias block it touches
+  for (int e = tid; e < 16 * 80; e += ASM_THREADS) {   // prior rows of the frame whose speed / leg-bias block it touches (rows 13..15: zero padding)
     const int i = e / 80, p = e - 80 * i;
-    bimg[BI_BP + e] = (kb >= 0 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) ? pd[PD_BP + e] : 0.0;
-  }
-  // gradient: visual + IMU pose part + prior from the LDS vector; the speed / leg-bias dimensions add their IMU terms here
-  for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
-    double g = gl[cd];
-    if (cd >= CD_B0 && cd < CD_B0 + 143) {
-      const int k = (cd - CD_B0) / 13, i = (cd - CD_B0) - 13 * k;
-      if (k < F - 1) g += igram[k * 780 + tri39(6 + i, 38)];
-      if (k >= 1 && k < F) g += igram[(k - 1) * 780 + tri39(25 + i, 38)];
+    double val = 0.0;
+    if (kb >= 0 && i < 13 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) {
+      val = pd[PD_BP + e];
+      part_q += 2.0 * vS[CD_B0 + 13 * kb + i] * val * vS[p];
     }
-    if (!cd_active(cd, F, cmask)) g = 0.0;
-    b.cam_gin[(size_t)win * CD_N + cd] = g;
+    bimg[BI_BP + e] = val;
   }
-  if (tid == 0) { bimg[BI_DIAG + 79] = 1.0; bimg[BI_DIAG + 223] = 1.0; }
+  // camera-side sums of |D^-1 g|^2, max |g| and q (the landmarks add theirs in the solver): waves in fixed order
+  part_q = wave_sum(part_q); part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax);
+  if ((tid & 63) == 0) { red[tid >> 6] = part_q; red[4 + (tid >> 6)] = part_gn; red[8 + (tid >> 6)] = part_gmax; }
+  __syncthreads();
+  if (tid == 0) {
+    bimg[BI_SCAL + 0] = ((red[0] + red[1]) + red[2]) + red[3];
+    bimg[BI_SCAL + 1] = ((red[4] + red[5]) + red[6]) + red[7];
+    bimg[BI_SCAL + 2] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+  }
 }
 
 // =================================================================================================
@@ -261,7 +311,7 @@ __device__ __forceinline__ int cswz(int t, int r, int c) { return WS_C + 256 * t
 // 16 x 16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80 x 80 factorisation).
 // A: LDS 16 x 17 row-major in. Lane i (< 16, replicated in the four 16-lane groups) owns row i; pivots broadcast with v_readlane.
 // Writes L (lower, zeros above) into swizzled tile t of the C region and L^-1 (lower) to Linv (16 x 17). Returns 0 / 1 (not positive definite).
-__device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, double *Linv) {
+__device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, double *Linv, bool need_inv) {
   const int lane = threadIdx.x & 63;
   const int row = lane & 15;
   double a[16];
@@ -284,6 +334,7 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
 #pragma unroll
     for (int j = 0; j < 16; ++j) lds[cswz(t, lane, j)] = a[j];
   }
+  if (!need_inv) { lds_fence(); return fail; }   // (the last diagonal tile has no panel below it)
   // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers. (The copies are opaque to the
   // compiler: it would otherwise recognise these broadcasts as the ones of the factorisation loop and keep all 120 alive in SGPRs.)
 #pragma unroll
@@ -326,40 +377,18 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
     double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
            *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
     double *Mg = b.Lk + (size_t)win * 11 * 169, *TAg = b.TAg + (size_t)win * 11 * 169;
-    double *cam_scale = b.cam_scale + (size_t)win * CD_N;
     const bool first_scale = !st.scale_ready;
     double mu = st.mu;
 
-    // ---- Jacobi scaling (first linearisation), dogleg diagonal, v = D^-2 g: the 224 camera dimensions, then the landmarks ----
+    // ---- gradient, dogleg diagonal and v = D^-2 g of the camera dimensions come scaled from k_assemble (with their share of q, |D^-1 g|^2
+    //      and max |g|); the landmarks are scaled here ----
     double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
-    auto scale_dim = [&](int cd, double &ge, double &d, double &ve) {
-      ge = gin[cd]; d = 1.0; ve = 0.0;
-      if (cd_active(cd, F, cmask)) {
-        const double hii = bimg[BI_DIAG + cd];
-        double sc;
-        if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0; cam_scale[cd] = sc; }
-        else sc = cam_scale[cd];
-        const double d2 = fmin(fmax(sc * sc * hii, sp.min_lm_diagonal), sp.max_lm_diagonal);
-        d = d2 / (sc * sc);
-        ve = ge / d;
-      }
-      part_gn += ge * ve;
-      part_gmax = fmax(part_gmax, fabs(ge));
-    };
-    for (int cd = lane; cd < 80; cd += 64) {
-      double ge, d, ve;
-      scale_dim(cd, ge, d, ve);
-      g[cd] = ge; dh2[cd] = d; v[cd] = ve;
-    }
+    for (int cd = lane; cd < 80; cd += 64) { g[cd] = gin[cd]; dh2[cd] = bimg[BI_DH2 + cd]; v[cd] = bimg[BI_V + cd]; }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      const int e = lane + 64 * m;
-      gBr[m] = 0.0; dBr[m] = 1.0; yBr[m] = 0.0;
-      if (e < 144) {
-        double ve;
-        scale_dim(CD_B0 + e, gBr[m], dBr[m], ve);
-        lds[WC_VB + e] = ve; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m];
-      }
+      const int e = min(lane + 64 * m, 143);
+      gBr[m] = gin[CD_B0 + e]; dBr[m] = bimg[BI_DH2 + CD_B0 + e]; yBr[m] = 0.0;
+      if (lane + 64 * m < 144) { lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
     }
     for (int l = lane; l < L; l += 64) {
       const double E = lm_E[l], gl = lm_g[l];
@@ -374,7 +403,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       part_gn += gl * vl;
       part_gmax = fmax(part_gmax, fabs(gl));
     }
-    const double gnorm2 = wave_sum(part_gn), gmax = wave_max(part_gmax);
+    const double gnorm2 = bimg[BI_SCAL + 1] + wave_sum(part_gn), gmax = fmax(bimg[BI_SCAL + 2], wave_max(part_gmax));
     if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
       if (lane == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
       return;
@@ -402,15 +431,6 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       for (int t = 0; t < 15; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = Cimg[(t * 4 + r) * 64 + lane];
-      if (!have_q) {   // q = v^T H v, pose tiles
-#pragma unroll
-        for (int t = 0; t < 15; ++t) {
-          const int I = c_tI[t], J = c_tJ[t];
-          const double vc = v[16 * J + lr] * ((I == J) ? 1.0 : 2.0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part_q += v[16 * I + lk + 4 * r] * acc[t][r] * vc;
-        }
-      }
       if (lane == 0) st.phase_clk[2] = clock64();
 
       // ---- block-tridiagonal Cholesky chain of the speed / leg-bias part (13 x 13 blocks, frames F-1 .. 0):
@@ -425,72 +445,62 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         const int row = c < 13 ? c : 0;
         double *LM = scr + WX_LM, *SN = scr + WX_SN;
         double *TAcur = scr + WX_TA0, *TAprev = scr + WX_TA1;
-        const double *VB = lds + WC_VB, *DB = lds + WC_DB, *GB = lds + WC_GB;
+        const double *DB = lds + WC_DB, *GB = lds + WC_GB;
         mfma_d4 T[5];
         double yr[5];
 #pragma unroll
         for (int X = 0; X < 5; ++X) { T[X] = mfma_d4{0.0, 0.0, 0.0, 0.0}; yr[X] = 0.0; }
-        for (int k = F - 1; k >= 0; --k) {
-          // ---- this frame's blocks from the assembled image ----
-          // [B_k | g_k] in accumulator order: row lk + 4 r (< 13), column 16 X + lr; column 79 carries the gradient
-          mfma_d4 V[5];
+        // this frame's blocks come from the assembled image one frame ahead of their use (registers nV / nrhs / nadn)
+        auto load_blocks = [&](int k, mfma_d4 *Vn, double *rhsn, double *adnn) {
+          // [B_k | g_k] in accumulator order: row lk + 4 r, column 16 X + lr (zero rows 13..15 in the image); column 79 carries the gradient
 #pragma unroll
           for (int X = 0; X < 5; ++X) {
             const int df = fX[X] - k + 1;
             const bool on = df >= 0 && df <= 2;
+            const double *src = bimg + BI_BS + (k * 16 + lk) * 18 + 6 * min(max(df, 0), 2) + oX[X];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = lk + 4 * r;
-              double val = (on && i < 13) ? bimg[BI_BS + (k * 13 + min(i, 12)) * 18 + 6 * min(max(df, 0), 2) + oX[X]] : 0.0;
-              if (k == kb && i < 13) val += bimg[BI_BP + i * 80 + 16 * X + lr];
-              V[X][r] = val;
-            }
+            for (int r = 0; r < 4; ++r) Vn[X][r] = on ? src[72 * r] : 0.0;
           }
+          if (k == kb) {
+#pragma unroll
+            for (int X = 0; X < 5; ++X)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Vn[X][r] += bimg[BI_BP + (lk + 4 * r) * 80 + 16 * X + lr];
+          }
+#pragma unroll
+          for (int i = 0; i < 13; ++i) rhsn[i] = (k > 0) ? bimg[BI_AOT + (max(k - 1, 0) * 13 + row) * 13 + i] : 0.0;   // column `row` of A_{k,k-1}
+#pragma unroll
+          for (int m = 0; m < 3; ++m) adnn[m] = (k > 0 && lane + 64 * m < 169) ? bimg[BI_AD + max(k - 1, 0) * 169 + lane + 64 * m] : 0.0;   // A_{k-1,k-1}
+        };
+        mfma_d4 nV[5];
+        double nrhs[13], nadn[3];
+        load_blocks(F - 1, nV, nrhs, nadn);
+        int ei[3], ej[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { const int e = min(lane + 64 * m, 168); ei[m] = e / 13; ej[m] = e - 13 * ei[m]; }
+        for (int k = F - 1; k >= 0; --k) {
+          const int x_lo = (k <= kb) ? 0 : max(0, (6 * (k - 1)) >> 4);   // T(k) is zero left of pose k - 1 (dense from the prior's frame down)
+          mfma_d4 V[5];
+          double a[13], l[13], rhs[13], adn[3];
+#pragma unroll
+          for (int X = 0; X < 5; ++X) V[X] = nV[X];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) rhs[i] = nrhs[i];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) adn[m] = nadn[m];
           if (lr == 15) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) V[4][r] = (lk + 4 * r < 13) ? GB[13 * k + lk + 4 * r] : 0.0;
           }
           // S_k (lane = row): the top frame straight from A_kk, later frames from the update left by the previous step
-          double a[13], l[13], rhs[13];
           if (k == F - 1) {
 #pragma unroll
             for (int j = 0; j < 13; ++j) a[j] = bimg[BI_AD + (k * 13 + row) * 13 + j];
-            if (!have_q) {   // v_k^T A_kk v_k of the top frame
-              double sacc = 0.0;
-#pragma unroll
-              for (int j = 0; j < 13; ++j) sacc += a[j] * VB[13 * k + j];
-              if (lane < 13) part_q += VB[13 * k + lane] * sacc;
-            }
           } else {
 #pragma unroll
             for (int j = 0; j < 13; ++j) a[j] = SN[row * 13 + j];
           }
-#pragma unroll
-          for (int i = 0; i < 13; ++i) rhs[i] = (k > 0) ? bimg[BI_AOT + (max(k - 1, 0) * 13 + row) * 13 + i] : 0.0;   // column `row` of A_{k,k-1}
-          double adn[3];   // A_{k-1,k-1}, entry lane + 64 m
-#pragma unroll
-          for (int m = 0; m < 3; ++m) adn[m] = (k > 0 && lane + 64 * m < 169) ? bimg[BI_AD + (k - 1) * 169 + lane + 64 * m] : 0.0;
-          if (!have_q && k > 0) {
-            // q: 2 v_k^T A_{k,k-1} v_{k-1} (lane = column of the off-diagonal block) and v_{k-1}^T A_{k-1,k-1} v_{k-1} (entry-parallel)
-            double sacc = 0.0;
-#pragma unroll
-            for (int i = 0; i < 13; ++i) sacc += rhs[i] * VB[13 * k + i];
-            if (lane < 13) part_q += 2.0 * VB[13 * (k - 1) + lane] * sacc;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-              const int e = lane + 64 * m, i = e / 13, j = e - 13 * i;
-              if (e < 169) part_q += adn[m] * VB[13 * (k - 1) + i] * VB[13 * (k - 1) + j];
-            }
-          }
-          if (!have_q) {
-            // q: 2 v_k^T B_k v_P with the accumulator-order copy of B_k (column 79 is the gradient, not a coupling)
-#pragma unroll
-            for (int X = 0; X < 5; ++X) {
-              const double vp = (X == 4 && lr == 15) ? 0.0 : v[16 * X + lr];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) part_q += 2.0 * V[X][r] * vp * ((lk + 4 * r < 13) ? VB[13 * k + min(lk + 4 * r, 12)] : 0.0);
-            }
-          }
+          if (k == 5 && lane == 0) st.phase_clk[16] = clock64();
           {
             const double md = mu * DB[13 * k + row];
 #pragma unroll
@@ -508,6 +518,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
             for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
           }
+          if (k == 5 && lane == 0) st.phase_clk[17] = clock64();
           // forward substitutions L x = rhs: T_A(k) columns (group 0), L^-1 columns (group 1); L broadcast from the owning lanes
           // (opaque copies: see chol16_tile)
 #pragma unroll
@@ -531,15 +542,16 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             }
           }
           lds_fence();
+          if (k == 5 && lane == 0) st.phase_clk[18] = clock64();
           // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
           if (k > 0) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-              const int e = lane + 64 * m, i = e / 13, j = e - 13 * i;
+              const int e = lane + 64 * m;
               if (e < 169) {
                 double sacc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + i] * TAcur[q * 13 + j];
+                for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + ei[m]] * TAcur[q * 13 + ej[m]];
                 SN[e] = adn[m] - sacc;
               }
             }
@@ -554,19 +566,25 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             at[kk] = (in && k < F - 1) ? -ta : 0.0;
             am[kk] = in ? m : 0.0;
           }
+          if (k == 5 && lane == 0) st.phase_clk[19] = clock64();
           if (k < F - 1) {
 #pragma unroll
             for (int X = 0; X < 5; ++X)
+              if (X >= x_lo) {
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk) V[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], T[X][kk], V[X], 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) V[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], T[X][kk], V[X], 0, 0, 0);
+              }
           }
 #pragma unroll
-          for (int X = 0; X < 5; ++X) {
-            mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+          for (int X = 0; X < 5; ++X)
+            if (X >= x_lo) {
+              mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], V[X][kk], n, 0, 0, 0);
-            T[X] = n;
-          }
+              for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], V[X][kk], n, 0, 0, 0);
+              T[X] = n;
+            }
+          // the next frame's blocks: in flight behind the rank update below (V, rhs and adn of this frame are dead)
+          if (k > 0) load_blocks(k - 1, nV, nrhs, nadn);
           // t_g(k) (column 79) to every lane of its 16-lane row group; the pose system must not see it
           mfma_d4 T4 = T[4];
           double tg[4];
@@ -579,16 +597,19 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
           for (int t = 0; t < 15; ++t) {
             const int I = c_tI[t], J = c_tJ[t];
+            if (J >= x_lo) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const double opa = (I == 4) ? T4[kk] : T[I][kk], opb = (J == 4) ? T4[kk] : T[J][kk];
-              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opa, opb, acc[t], 0, 0, 0);
+              for (int kk = 0; kk < 4; ++kk) {
+                const double opa = (I == 4) ? T4[kk] : T[I][kk], opb = (J == 4) ? T4[kk] : T[J][kk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opa, opb, acc[t], 0, 0, 0);
+              }
             }
           }
 #pragma unroll
           for (int X = 0; X < 5; ++X)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) yr[X] += ((X == 4) ? T4[kk] : T[X][kk]) * tg[kk];
+          if (k == 5 && lane == 0) st.phase_clk[20] = clock64();
           double *sw = TAcur; TAcur = TAprev; TAprev = sw;
           lds_fence();
         }
@@ -654,7 +675,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
         if (!have_q) {
           part_q += 2.0 * qacc;
-          qq = wave_sum(part_q);
+          qq = bimg[BI_SCAL + 0] + wave_sum(part_q);
           have_q = true;
         }
 #pragma unroll
@@ -683,7 +704,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[tile_index(j, j)][r];
           lds_fence();
-          fail |= chol16_tile(lds, D16, tile_index(j, j), LI16);
+          fail |= chol16_tile(lds, D16, tile_index(j, j), LI16, j < 4);
           double li[4];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) li[kk] = LI16[lr * 17 + 4 * kk + lk];
@@ -728,7 +749,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
           const int e = lane + 64 * m;
-          if (e < 144) { lds[WC_VB + e] = gBr[m] / dBr[m]; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
+          if (e < 144) { lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
         }
         lds_fence();
         continue;
@@ -737,6 +758,17 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 
       // ---- L L^T yP = rhs: lane owns rows lane and lane + 64; pivots by v_readlane; the factor is read in blocks of 16 columns into
       //      registers so that the 160 dependent steps touch no memory ----
+      // M_k / T_A(k) of the chain (written to global memory by this wave) come back for the bias sweeps: the loads fly during the solves
+      double mreg[30], tareg[30];
+      {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double *Mg_ = b.Lk + (size_t)win * 11 * 169, *TAg_ = b.TAg + (size_t)win * 11 * 169;
+#pragma unroll
+        for (int u = 0; u < 30; ++u) {
+          const int e = min(lane + 64 * u, F * 169 - 1);
+          mreg[u] = Mg_[e]; tareg[u] = TAg_[e];
+        }
+      }
       {
         double *col = scr + WX_COL;
         for (int cd = lane; cd < 80; cd += 64) col[cd] = 1.0 / lds[cswz(tile_index(cd >> 4, cd >> 4), cd & 15, cd & 15)];
@@ -793,27 +825,33 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       int win_b = win, lmoff_b = wm.lm_off;
       asm volatile("" : "+s"(win_b), "+s"(lmoff_b));
       const double *bimg = b.Bimg + (size_t)win_b * BI_N;
-      const double *Mg = b.Lk + (size_t)win_b * 11 * 169, *TAg = b.TAg + (size_t)win_b * 11 * 169;
       const double *wl = b.lm_w + 80 * (size_t)lmoff_b;
       const double *lm_g = b.lm_g + lmoff_b, *lm_dh2 = b.lm_dh2 + lmoff_b, *lm_einv = b.lm_einv + lmoff_b;
       double *lm_y = b.lm_y + lmoff_b;
       {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // M_k / T_A(k) written by this wave during the chain
-        for (int e = lane; e < F * 169; e += 64) { lds[WB_M + e] = Mg[e]; lds[WB_TA + e] = TAg[e]; }
-        double *U = scr + WX_U, *YB = scr + WX_YB;
-        // c: the IMU part of B_k spans poses k-1 .. k+1 (one dimension per lane and trip), the prior part frame kb only
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const int e = lane + 64 * m;
-          if (e < 143) {
-            const int k = e / 13;
+        for (int u = 0; u < 30; ++u) {
+          const int e = lane + 64 * u;
+          if (e < 11 * 169) { lds[WB_M + e] = mreg[u]; lds[WB_TA + e] = tareg[u]; }
+        }
+        double *U = scr + WX_U, *YB = scr + WX_YB;
+        if (lane == 0) st.phase_clk[21] = clock64();
+        // c: the IMU part of B_k spans poses k-1 .. k+1 (one dimension per lane and trip), the prior part frame kb only
+        {
+          double bsv[3][18];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const int e = min(lane + 64 * m, 142), k = e / 13;
+#pragma unroll
+            for (int s = 0; s < 18; ++s) bsv[m][s] = bimg[BI_BS + (16 * k + (e - 13 * k)) * 18 + s];
+          }
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const int e = lane + 64 * m, k = min(e, 142) / 13;
             double sacc = gBr[m];
 #pragma unroll
-            for (int s = 0; s < 18; ++s) {
-              const int p = 6 * (k - 1) + s;
-              sacc -= bimg[BI_BS + e * 18 + s] * y[min(max(p, 0), 79)];   // (blocks outside the window are zero in the image)
-            }
-            U[e] = sacc;
+            for (int s = 0; s < 18; ++s) sacc -= bsv[m][s] * y[min(max(6 * (k - 1) + s, 0), 79)];   // (blocks outside the window are zero in the image)
+            if (e < 143) U[e] = sacc;
           }
         }
         lds_fence();
@@ -827,6 +865,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
         lds_fence();
         const int row = lr < 13 ? lr : 0;
+        if (lane == 0) st.phase_clk[22] = clock64();
         // forward sweep
         double unext = 0.0;   // u_{k+1}[row]
         for (int k = F - 1; k >= 0; --k) {
@@ -842,6 +881,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           unext = u;
         }
         lds_fence();
+        if (lane == 0) st.phase_clk[23] = clock64();
         // backward sweep
         double yprev = 0.0;
         for (int k = 0; k < F; ++k) {
@@ -897,7 +937,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
           const int e = lane + 64 * m;
-          if (e < 144) { lds[WC_VB + e] = gBr[m] / dBr[m]; lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
+          if (e < 144) { lds[WC_DB + e] = dBr[m]; lds[WC_GB + e] = gBr[m]; }
         }
         lds_fence();
         continue;
@@ -970,7 +1010,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   const size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (stage == 0) {
-    hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b);
+    hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -33,10 +33,13 @@
 #define CIMG_N 3840     // pose system: 15 lower 16 x 16 tiles x 4 accumulator registers x 64 lanes
 #define BI_AD 0         // [11][13][13]  diagonal blocks A_kk of the speed / leg-bias part
 #define BI_AOT 1859     // [10][13][13]  A_{k+1,k} transposed: [k][dimension of frame k][dimension of frame k + 1]
-#define BI_BS 3549      // [11][13][18]  IMU coupling of frame k's dimensions with poses k-1, k, k+1
-#define BI_BP 6128      // [13][80]      prior coupling rows of the frame whose speed / leg-bias block the prior touches
-#define BI_DIAG 7168    // [CD_N]        diagonal of the camera-side Hessian
-#define BI_N 7392
+#define BI_BS 3552      // [11][16][18]  IMU coupling of frame k's dimensions with poses k-1, k, k+1 (rows 13..15 zero)
+#define BI_BP 6720      // [16][80]      prior coupling rows of the frame whose speed / leg-bias block the prior touches (rows 13..15 zero)
+#define BI_DIAG 8000    // [CD_N]        diagonal of the camera-side Hessian
+#define BI_DH2 8224     // [CD_N]        dogleg diagonal dhat^2
+#define BI_V 8448       // [CD_N]        v = g / dhat^2
+#define BI_SCAL 8672    // [8]           camera-side sums: q = v^T H v, |D^-1 g|^2, max |g|
+#define BI_N 8704
 
 #define CONST_LB 1
 #define CONST_EX 2

@@ -27,3 +27,8 @@ print("k_solve_wave phases (cycles, mean over %d windows of %d):" % (len(sample)
 for n, a in zip(names, acc):
     print("  %-52s %10.0f" % (n, a))
 print("  %-52s %10.0f" % ("total", acc.sum()))
+c = b.fetch(12, 0).view(np.int64)
+print("chain, frame 5 (window 0): loads + S_k %d  chol13 %d  substitutions %d  S update + operands %d  MFMA (T, V, rank update) %d" %
+      (c[16] - c[16], c[17] - c[16], c[18] - c[17], c[19] - c[18], c[20] - c[19]))
+print("bias back-substitution (window 0): M / T_A copy %d  c = g - B yP %d  forward sweep %d  backward sweep %d" %
+      (c[21] - c[6], c[22] - c[21], c[23] - c[22], c[7] - c[23]))
