@@ -310,7 +310,8 @@ __device__ __forceinline__ int cswz(int t, int r, int c) { return WS_C + 256 * t
 
 // 16 x 16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80 x 80 factorisation).
 // A: LDS 16 x 17 row-major in. Lane i (< 16, replicated in the four 16-lane groups) owns row i; pivots broadcast with v_readlane.
-// Writes L (lower, zeros above) into swizzled tile t of the C region and L^-1 (lower) to Linv (16 x 17). Returns 0 / 1 (not positive definite).
+// Writes L^-1 (lower, zeros above) to Linv (16 x 17, for the panel products) and into swizzled tile t of the C region (for the triangular
+// solves: nothing reads L_jj itself again). Returns 0 / 1 (not positive definite).
 __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, double *Linv, bool need_inv) {
   const int lane = threadIdx.x & 63;
   const int row = lane & 15;
@@ -330,11 +331,7 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
 #pragma unroll
     for (int q = j + 1; q < 16; ++q) a[q] -= lj * readlane_d(lj, q);
   }
-  if (lane < 16) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) lds[cswz(t, lane, j)] = a[j];
-  }
-  if (!need_inv) { lds_fence(); return fail; }   // (the last diagonal tile has no panel below it)
+  (void)need_inv;
   // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers. (The copies are opaque to the
   // compiler: it would otherwise recognise these broadcasts as the ones of the factorisation loop and keep all 120 alive in SGPRs.)
 #pragma unroll
@@ -350,7 +347,11 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
   }
   if (lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Linv[i * 17 + lane] = (i >= lane) ? cl[i] : 0.0;
+    for (int i = 0; i < 16; ++i) {
+      const double li = (i >= lane) ? cl[i] : 0.0;
+      Linv[i * 17 + lane] = li;
+      lds[cswz(t, i, lane)] = li;
+    }
   }
   lds_fence();
   return fail;
@@ -756,8 +757,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       }
       if (lane == 0) st.phase_clk[5] = clock64();
 
-      // ---- L L^T yP = rhs: lane owns rows lane and lane + 64; pivots by v_readlane; the factor is read in blocks of 16 columns into
-      //      registers so that the 160 dependent steps touch no memory ----
+      // ---- L L^T yP = rhs ----
       // M_k / T_A(k) of the chain (written to global memory by this wave) come back for the bias sweeps: the loads fly during the solves
       double mreg[30], tareg[30];
       {
@@ -770,49 +770,43 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
       }
       {
-        double *col = scr + WX_COL;
-        for (int cd = lane; cd < 80; cd += 64) col[cd] = 1.0 / lds[cswz(tile_index(cd >> 4, cd >> 4), cd & 15, cd & 15)];
-        lds_fence();
-        double b0 = v[lane], b1 = lane < 16 ? v[lane + 64] : 0.0;
-        const int I0 = lane >> 4;   // tile row of this lane's first row; its second row (lane + 64 < 80) is in tile row 4
-#pragma unroll 1
-        for (int jb = 0; jb < 5; ++jb) {
-          double l0[16], l1[16], ri[16];
+        // Blockwise on the FP64 matrix cores, with the inverses of the diagonal tiles (kept in the factor's diagonal tiles):
+        //   forward   y_j = L_jj^-1 (b_j - sum_{i<j} L_ji y_i),   backward   x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i).
+        // A block vector lives in accumulator order, replicated over the 16 columns (register r of lane (lr, lk) = entry lk + 4 r), which
+        // is the B-operand order of the next product: the 2 x 60 MFMAs touch no memory but the factor's operand reads.
+        mfma_d4 yb[5];
 #pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            l0[jj] = (I0 >= jb) ? lds[cswz(tile_index(max(I0, jb), jb), lane & 15, jj)] : 0.0;
-            l1[jj] = lds[cswz(tile_index(4, jb), lane & 15, jj)];
-            ri[jj] = col[16 * jb + jj];
-          }
+        for (int j = 0; j < 5; ++j) {
+          mfma_d4 accv;
 #pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * jb + jj;
-            const double yj = readlane_d((jb < 4) ? b0 : b1, j & 63) * ri[jj];
-            if (jb < 4 && lane > j) b0 -= l0[jj] * yj;
-            if (lane < 16 && lane + 64 > j) b1 -= l1[jj] * yj;
-            if (lane == (j & 63)) { if (jb < 4) b0 = yj; else b1 = yj; }
-          }
+          for (int r = 0; r < 4; ++r) accv[r] = v[16 * j + lk + 4 * r];
+#pragma unroll
+          for (int i = 0; i < j; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds[cswz(tile_index(j, i), lr, 4 * kk + lk)], yb[i][kk], accv, 0, 0, 0);
+          mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[cswz(tile_index(j, j), lr, 4 * kk + lk)], accv[kk], n, 0, 0, 0);
+          yb[j] = n;
         }
-#pragma unroll 1
-        for (int jb = 4; jb >= 0; --jb) {
-          double c0[16], c1[16], ri[16];
 #pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            c0[jj] = (jb >= I0) ? lds[cswz(tile_index(jb, min(I0, jb)), jj, lane & 15)] : 0.0;   // L[16 jb + jj][lane]
-            c1[jj] = (jb == 4) ? lds[cswz(tile_index(4, 4), jj, lane & 15)] : 0.0;               // L[16 jb + jj][lane + 64]
-            ri[jj] = col[16 * jb + jj];
-          }
+        for (int j = 4; j >= 0; --j) {
+          mfma_d4 accv = yb[j];
 #pragma unroll
-          for (int jj = 15; jj >= 0; --jj) {
-            const int j = 16 * jb + jj;
-            const double yj = readlane_d((jb < 4) ? b0 : b1, j & 63) * ri[jj];
-            if (lane < j) b0 -= c0[jj] * yj;
-            if (lane < 16 && lane + 64 < j) b1 -= c1[jj] * yj;
-            if (lane == (j & 63)) { if (jb < 4) b0 = yj; else b1 = yj; }
-          }
+          for (int i = j + 1; i < 5; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds[cswz(tile_index(i, j), 4 * kk + lk, lr)], yb[i][kk], accv, 0, 0, 0);
+          mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[cswz(tile_index(j, j), 4 * kk + lk, lr)], accv[kk], n, 0, 0, 0);
+          yb[j] = n;
         }
-        y[lane] = cd_active(lane, F, cmask) ? b0 : 0.0;
-        if (lane < 16) y[lane + 64] = cd_active(lane + 64, F, cmask) ? b1 : 0.0;
+        if (lr == 0) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[16 * j + lk + 4 * r] = cd_active(16 * j + lk + 4 * r, F, cmask) ? yb[j][r] : 0.0;
+        }
       }
       lds_fence();
       if (lane == 0) st.phase_clk[6] = clock64();
