@@ -30,7 +30,7 @@ def lib():
         L = C.CDLL(path)
         L.vilo_last_error.restype = C.c_char_p
         L.vilo_last_solve_ms.restype = C.c_double
-        L.vilo_solve_lds_bytes.restype = C.c_size_t
+        L.vilo_solve_wave_lds_bytes.restype = C.c_size_t
         _lib = L
     return _lib
 

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
       const int row = M.m - M.n_drop_lm + li;   // landmarks follow the dropped frame-0 dims (19 with leg biases, 15 without)
       if (a == 79) {
         A[(size_t)row * T + row] += bd.lm_E[wm.lm_off + l];
-        bv[row] += bd.lm_g[wm.lm_off + l];
+        bv[row] += bd.lm_gbuf[0][wm.lm_off + l];
       } else {
         const int t = M.cdmap[a];
         const double v = wl[(size_t)a * wm.L + l];
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
         const int l = drop_lm[(size_t)win * max_l0 + l0 + tid];
         const double D = bd.lm_E[wm.lm_off + l];
         if (!(D - eps > 0.0)) fail = 1;
-        dinv[tid] = 1.0 / D; deps[tid] = 1.0 / (D - eps); gl[tid] = bd.lm_g[wm.lm_off + l];
+        dinv[tid] = 1.0 / D; deps[tid] = 1.0 / (D - eps); gl[tid] = bd.lm_gbuf[0][wm.lm_off + l];
       }
       for (int e = tid; e < na * MG_TILE; e += MGT) {
         const int k = e / MG_TILE, j = e % MG_TILE;

@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
     const double *gin = b.cam_gin + (size_t)win * CD_N;
     const double *bimg = b.Bimg + (size_t)win * BI_N;
     const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
-    double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_g + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
+    double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_gbuf[st.cur] + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
            *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
     double *Mg = b.Lk + (size_t)win * 11 * 169, *TAg = b.TAg + (size_t)win * 11 * 169;
     const bool first_scale = !st.scale_ready;
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       asm volatile("" : "+s"(win_b), "+s"(lmoff_b));
       const double *bimg = b.Bimg + (size_t)win_b * BI_N;
       const double *wl = b.lm_w + 80 * (size_t)lmoff_b;
-      const double *lm_g = b.lm_g + lmoff_b, *lm_dh2 = b.lm_dh2 + lmoff_b, *lm_einv = b.lm_einv + lmoff_b;
+      const double *lm_g = b.lm_gbuf[st.cur] + lmoff_b, *lm_dh2 = b.lm_dh2 + lmoff_b, *lm_einv = b.lm_einv + lmoff_b;
       double *lm_y = b.lm_y + lmoff_b;
       {
 #pragma unroll
@@ -974,11 +974,21 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
     else { dogleg_scalars(st); ca = st.coef_a; cb = st.coef_b; go = st.step_valid; }
   }
   ca = readlane_d(ca, 0); cb = readlane_d(cb, 0); go = __builtin_amdgcn_readlane(go, 0);
-  if (!go) return;
   int win_d = win;
   asm volatile("" : "+s"(win_d));
   const double *x = b.x + (size_t)win_d * XSTRIDE;
   double *xc = b.xc + (size_t)win_d * XSTRIDE;
+  {
+    // candidate inverse depths: lambda_c = lambda - a g_l / dhat_l^2 - b y_l (no valid step: the candidate is the current point, which
+    // the next pass linearises again — HandleInvalidStep in k_accept)
+    const double *lam = b.lam + wm.lm_off, *lmg = b.lm_gbuf[st.cur] + wm.lm_off, *lmd = b.lm_dh2 + wm.lm_off, *lmy = b.lm_y + wm.lm_off;
+    double *lamc = b.lamc + wm.lm_off;
+    for (int l = lane; l < L; l += 64) lamc[l] = go ? lam[l] - ca * lmg[l] / lmd[l] - cb * lmy[l] : lam[l];
+  }
+  if (!go) {
+    for (int e = lane; e < XSTRIDE; e += 64) xc[e] = x[e];
+    return;
+  }
   double *del = scr + WX_DEL;
   for (int cd = lane; cd < 80; cd += 64) del[cd] = -ca * g[cd] / dh2[cd] - cb * y[cd];
 #pragma unroll

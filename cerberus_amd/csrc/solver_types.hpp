@@ -100,7 +100,8 @@ struct SolverState {
   int scale_ready;    // Jacobi scaling computed (iteration 0)
   int num_invalid;
   int lin_fail;       // Cholesky failed for every mu < max_mu
-  int pad[3];
+  int cur;            // which landmark-gradient buffer belongs to the current linearisation
+  int pad[2];
   double cost_trace[64];
   double radius_trace[64];
   long long phase_clk[48];   // shader-clock stamps (last linearisation), profiling aid: 0..12 k_build_solve, 16..21 k_visual_linearize (first chunk), 24..27 k_imu_linearize (k = 0)
@@ -119,7 +120,8 @@ struct BatchDev {
   double *lam, *lamc, *lam0;  // [n_lm]
   int *lm_perm;               // device order -> original index within its window
   // landmark-side linearisation
-  double *lm_E, *lm_g, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
+  double *lm_E, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
+  double *lm_gbuf[2];         // [n_lm] x 2: landmark gradients of the current linearisation (SolverState::cur) and of the candidate's
   double *lm_w;               // per window: [80][L] at 80 * lm_off
   double *lm_part;            // small batches only (else null): [11 frames][2 cameras][21 terms][n_lm] landmark-side terms of the
                               // frame-parallel linearisation (k_visual_linearize_tpar / k_visual_reduce)

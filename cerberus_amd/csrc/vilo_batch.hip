@@ -412,7 +412,8 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.lam, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lamc, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_E, (size_t)lm_total));
-  TRYB(dev_alloc(ctx, bt, &D.lm_g, (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_gbuf[0], (size_t)lm_total));
+  TRYB(dev_alloc(ctx, bt, &D.lm_gbuf[1], (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_dh2, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_y, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_scale, (size_t)lm_total));
@@ -657,7 +658,11 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
   switch (what) {
     case 0: src = bt->d.gram + (size_t)wm.gram_off * VILO_GRAM; n = (size_t)wm.n_gram * VILO_GRAM; break;
     case 1: src = bt->d.lm_E + wm.lm_off; n = wm.L; break;
-    case 2: src = bt->d.lm_g + wm.lm_off; n = wm.L; break;
+    case 2: {
+      SolverState sst;
+      VILO_HIP(hipMemcpy(&sst, bt->d.st + win, sizeof(SolverState), hipMemcpyDeviceToHost));
+      src = bt->d.lm_gbuf[sst.cur & 1] + wm.lm_off; n = wm.L; break;
+    }
     case 3: src = bt->d.lm_w + 80 * (size_t)wm.lm_off; n = (size_t)80 * wm.L; break;
     case 4: src = bt->d.cam_g + (size_t)win * CD_N; n = CD_N; break;
     case 5: src = bt->d.cam_dh2 + (size_t)win * CD_N; n = CD_N; break;

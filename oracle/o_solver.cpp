@@ -584,7 +584,7 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
     }
     if (!step_is_valid) {
       // HandleInvalidStep + DoglegStrategy::StepIsInvalid
-      if (++num_consecutive_invalid > 5) { termination = 2; break; }
+      if (++num_consecutive_invalid >= 5) { termination = 2; break; }   // max_num_consecutive_invalid_steps = 5 (Ceres default): FAILURE on the 5th
       mu *= mu_increase;
       reuse = false;
       sum->cost_trace[iter] = x_cost;
