@@ -446,8 +446,9 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
 // The raw block never leaves the CU; the whitened one goes to HBM only for the marginalisation (mode 0).
 #define IW_JS 48   // LDS row stride of the block (conflict-free operand reads of the Gram pass)
 
-__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm, int mode) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_imu_linearize(BatchDev b, double g_norm, int mode) {
   __shared__ double R[32 * IW_JS];
+  __shared__ PreintHead headl;
   const int f = blockIdx.x, win = f / 10, k = f % 10;
   SolverState &st = b.st[win];
   if (lin_skip(st, mode)) return;
@@ -462,10 +463,34 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm,
   const bool prof = (k == 0 && lane == 0);
   const long long c0 = clock64();
   for (int e = lane; e < 32 * IW_JS; e += 64) R[e] = 0.0;
-  lds_fence();
   const PreintPrepared &pp = b.prep[f];
   const double *U = pp.sqrt_info;
-  // sqrt_info operands straight from global memory, in flight behind the raw evaluation: 12 A values per lane
+  // the 126 scalars of the preintegration record through LDS: two coalesced loads per lane instead of 126 broadcast loads held in registers
+  {
+    const double *hg = (const double *)&pp.head;
+    double *hl = (double *)&headl;
+    for (int e = lane; e < (int)(sizeof(PreintHead) / sizeof(double)); e += 64) hl[e] = hg[e];
+  }
+  lds_fence();
+  if (lane == 0) {
+    const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
+    double r[31];
+    if (b.win[win].use_leg) {
+      imu_leg_raw(headl, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                  x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, R, IW_JS);
+#pragma unroll
+      for (int i = 0; i < 31; ++i) R[i * IW_JS + 38] = r[i];
+    } else {
+      // plain IMUFactor (estimator.cpp:1160-1171) inside the same layout: rows 0..14, the frame-j blocks at column 19,
+      // leg-bias columns and rows 15..30 stay zero (sqrt_info is embedded accordingly, k_embed_sqrt15)
+      imu_raw(headl, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, true, R, IW_JS, 19);
+#pragma unroll
+      for (int i = 0; i < 15; ++i) R[i * IW_JS + 38] = r[i];
+    }
+  }
+  lds_fence();
+  const long long c1 = clock64();
+  // sqrt_info operands straight from global memory: 12 A values per lane
   double av[2][8];
 #pragma unroll
   for (int I = 0; I < 2; ++I)
@@ -474,24 +499,6 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, double g_norm,
       const int row = 16 * I + lr, q = 4 * kk + lk;
       av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
     }
-  if (lane == 0) {
-    const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
-    double r[31];
-    if (b.win[win].use_leg) {
-      imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-                  x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, R, IW_JS);
-#pragma unroll
-      for (int i = 0; i < 31; ++i) R[i * IW_JS + 38] = r[i];
-    } else {
-      // plain IMUFactor (estimator.cpp:1160-1171) inside the same layout: rows 0..14, the frame-j blocks at column 19,
-      // leg-bias columns and rows 15..30 stay zero (sqrt_info is embedded accordingly, k_embed_sqrt15)
-      imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, true, R, IW_JS, 19);
-#pragma unroll
-      for (int i = 0; i < 15; ++i) R[i * IW_JS + 38] = r[i];
-    }
-  }
-  lds_fence();
-  const long long c1 = clock64();
   double bv[8][3];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk)
