@@ -29,17 +29,33 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
     return 88 * sum_k + 16 * L + 8 * (20 * F + 15 + L) + 10 * 8696 + 8 * (n_prior * n_prior + n_prior + 98) + 8 * (20 * F + 15 + L)
 
 
-def algorithmic_flops_build_solve(L, F=11, n_prior=86):
-    """FP64 flops of one k_build_solve launch per window: landmark Schur complement on the lower
-    triangle (L rank-1 updates of the 80x80 block), the speed/leg-bias elimination (13x13 block chain, coupling rows,
-    rank-143 update), the 80x80 Cholesky and the solves. 1 FMA = 2 flops."""
-    tri = 80 * 81 // 2
-    schur = 2 * L * tri + 2 * L * 80 * 3            # rank-1 updates + rhs / q / back-substitution products
-    chain = F * (13 ** 3 // 3 + 3 * 13 ** 3)       # chol13 + three 13x13 triangular solves / products per frame
-    coupling = F * 2 * (2 * 13 * 13 * 81)          # T(k) = M_k [B_k | rhs] - G_k T(k+1)
-    rank = 2 * 13 * F * tri                        # C -= sum_k T_B^T T_B
-    chol = 80 ** 3 // 3 + 2 * 80 * 80
-    return schur + 2 * chain + coupling + rank + chol
+ALG_FLOPS_PER_WINDOW_ITERATION = {200: 13.7e6, 1000: 47.0e6}   # FP64 flops of one window-iteration (FMA = 2)
+ITERATION_KERNELS = ("k_visual_linearize", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")   # launched once per iteration
+
+
+def profile_evidence(W_run):
+    """Counter evidence of the committed rocprofv3 passes (tools/profile_gpu.sh, tools/profile_sq.sh; measured at 4096 windows per
+    dispatch): calibrated HBM bytes per dispatch and the matrix-core busy fraction per kernel. Per-window figures, so they scale."""
+    out = {"pmc": None, "mfma": None}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc.json")))
+        Wp = pmc.get("windows_per_dispatch", 4096)
+        out["pmc"] = {k: v * W_run / Wp for k, v in pmc["hbm_bytes_per_dispatch"].items()}
+        out["pmc_kernel_us"] = {k: v["avg_us"] for k, v in pmc["kernel_trace"].items()}
+    except Exception:
+        pass
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "round2_mfma.json")))
+        util = {}
+        for k, c in sq["kernels"].items():
+            us = (out.get("pmc_kernel_us") or {}).get(k)
+            if us and "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+                # busy cycles summed over the chip's 1024 SIMDs / (kernel cycles x 1024); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                util[k] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        out["mfma"] = util
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
@@ -122,7 +138,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=4096, help="independent windows per GPU")
+    ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
     ap.add_argument("--landmarks", type=int, default=200)
+    ap.add_argument("--rate", type=int, default=500, help="IMU / leg sample rate of the synthetic windows (Hz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
@@ -145,9 +163,24 @@ def main():
     from cerberus_amd import api, synth
     cfg = synth.default_config()
     ctx = api.Context(cfg, device=local_rank)
-    W = args.windows
+    if args.total_windows > 0:
+        # BASELINE configs[3] as stated: N_total independently seeded windows, window w -> GPU (w mod N)
+        assert args.total_windows % world == 0, "--total-windows must be a multiple of the number of ranks"
+        W = args.total_windows // world
+        ids = [rank + world * i for i in range(W)]
+        scaling = "strong"
+        workload = "BASELINE configs[3] (%d windows in total, window w on GPU w mod %d)" % (args.total_windows, world)
+    else:
+        W = args.windows
+        ids = [rank * W + i for i in range(W)]
+        scaling = "weak"
+        workload = "BASELINE configs[1]" if args.landmarks == 200 else "BASELINE configs[2]-sized"
     t0 = time.perf_counter()
-    windows = [synth.make_window(cfg, n_landmarks=args.landmarks, seed=20260925 + rank * W + i) for i in range(W)]
+    def mk(seed):
+        prm = synth.default_params(n_landmarks=args.landmarks, seed=seed)
+        prm.imu_rate_hz = float(args.rate)
+        return synth.make_window(cfg, params=prm)
+    windows = [mk(20260925 + g) for g in ids]
     ctx.preintegrate_windows(windows)   # K1 on the GPU: contact preintegration of all 10 * W intervals
     batch = api.Batch(ctx, windows)
     setup_s = time.perf_counter() - t0
@@ -169,6 +202,7 @@ def main():
     gpu_ms = 0.0
     for _ in range(args.steps):
         batch.reset()
+        batch.prepare()               # sqrt_info of the preintegration records: the reference pays it in every IMULegFactor::Evaluate
         gpu_ms += batch.solve(opts)   # returns after the stream has drained (HIP event)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -199,41 +233,36 @@ def main():
         dom_avg_s = kern[dom]["avg_ms"] * 1e-3
         achieved = b_alg * W / dom_avg_s / 1e9             # one launch of the dominant kernel covers W window-iterations
         iter_ms = sum(v["ms_total"] for v in kern.values()) / (args.steps * ITERS)
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh: separate
-        # FETCH_SIZE / WRITE_SIZE runs, calibrated on a known 1 GiB copy); only valid for the profiled configuration
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_v8.json")   # profiled at 4096 windows per dispatch; traffic is per window
-        if os.path.exists(pmc_file) and args.landmarks == 200:
-            try:
-                pmc = json.load(open(pmc_file))
-                traffic = pmc["hbm_bytes_per_dispatch"].get(dom)
-                if traffic is not None:
-                    traffic = traffic * W / pmc.get("windows_per_dispatch", 4096)
-            except Exception:
-                traffic = None
+        ev = profile_evidence(W) if args.landmarks == 200 else {"pmc": None, "mfma": None}
+        traffic = ev["pmc"].get(dom) if ev["pmc"] else None
+        it_traffic = sum(ev["pmc"].get(k, 0.0) for k in ITERATION_KERNELS) if ev["pmc"] else None
+        alg_flops = ALG_FLOPS_PER_WINDOW_ITERATION.get(args.landmarks)
         out = {
             "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput",
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]" if args.landmarks == 200 else "BASELINE configs[2]-sized") + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (500 Hz), "
-                                   "%d independent windows per GPU, %d fixed dogleg iterations per step" % (args.landmarks, W, ITERS),
-                       "windows_per_gpu": W, "iterations_per_step": ITERS, "observations_per_window": sum_k,
+            "config": {"workload": workload + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (%d Hz), "
+                                   "%d independent windows per GPU; one step = state reset + sqrt_info of the %d preintegration records + "
+                                   "%d fixed dogleg iterations" % (args.landmarks, args.rate, W, 10 * W, ITERS),
+                       "windows_per_gpu": W, "total_windows": W * world, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; measured at 4096 windows per dispatch, scaled to this batch)" % os.path.basename(pmc_file)) if traffic else None, "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
-                         "rocprof_summary": "profiles/round1_rocprof_summary_v8.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)",
+                         "traffic": traffic,
+                         "traffic_source": "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated on a 1 GiB copy; per-window figure scaled to this batch)" if traffic else None,
+                         "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
+                         "rocprof_summary": "profiles/round2_rocprof_summary.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)",
                          "algorithmic_bytes_per_window_iteration": b_alg,
-                         "whole_iteration_gbps": b_alg * W / (iter_ms * 1e-3) / 1e9,
-                         # the same kernel against the FP64 matrix-core ceiling (78.6 TFLOP/s = half the 157.3 TF f32 MFMA rate
-                         # of MI355X_MICROARCH.md): SURVEY 8(d) prices the path in bytes, but at ~40 flop/B the FP64 units bound it
-                         "fp64": {"bound": "mfma", "achieved": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 if dom == "k_build_solve" else None,
-                                  "peak": 78.6, "unit": "TFLOP/s",
-                                  "frac": algorithmic_flops_build_solve(args.landmarks) * W / dom_avg_s / 1e12 / 78.6 if dom == "k_build_solve" else None,
-                                  "algorithmic_flops_per_window": algorithmic_flops_build_solve(args.landmarks),
-                                  # 13.7 Mflop per window-iteration at config 2 for the WHOLE iteration (all kernels)
-                                  "whole_iteration_tflops": (13.7e6 * W / (iter_ms * 1e-3) / 1e12) if args.landmarks == 200 else None,
-                                  "whole_iteration_frac": (13.7e6 * W / (iter_ms * 1e-3) / 1e12 / 78.6) if args.landmarks == 200 else None}},
+                         "whole_iteration": {"gbps": b_alg * W / (iter_ms * 1e-3) / 1e9, "frac": b_alg * W / (iter_ms * 1e-3) / 1e9 / 8000.0,
+                                             "traffic_bytes_per_window_iteration": it_traffic / W if it_traffic else None,
+                                             "traffic_over_algorithmic": it_traffic / W / b_alg if it_traffic else None},
+                         # the same iteration against the FP64 ceiling (78.6 TFLOP/s, vector and matrix rate alike on gfx950): SURVEY 8(d) prices
+                         # the path in bytes, but at ~45 flop/B the FP64 units bound it
+                         "fp64": {"bound": "mfma", "peak": 78.6, "unit": "TFLOP/s", "algorithmic_flops_per_window_iteration": alg_flops,
+                                  "whole_iteration_tflops": alg_flops * W / (iter_ms * 1e-3) / 1e12 if alg_flops else None,
+                                  "whole_iteration_frac": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 78.6 if alg_flops else None,
+                                  "mfma_util": ev["mfma"],
+                                  "mfma_util_source": "profiles/round2_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" if ev["mfma"] else None}},
             "kernels": kern,
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }

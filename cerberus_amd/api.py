@@ -68,6 +68,10 @@ class Batch:
     def reset(self):
         self.ctx._check(lib().vilo_batch_reset(self.ctx.h, self.handle))
 
+    def prepare(self):
+        """sqrt_info of every preintegration record again (what the reference does per IMULegFactor::Evaluate), asynchronous."""
+        self.ctx._check(lib().vilo_batch_prepare(self.ctx.h, self.handle))
+
     def solve(self, opts):
         self.ctx._check(lib().vilo_batch_solve(self.ctx.h, self.handle, C.byref(opts)))
         return lib().vilo_last_solve_ms(self.ctx.h)

@@ -52,34 +52,36 @@ __device__ void sqrt_info_wave(const double *cov, double *U_out, double *R /*LDS
   for (int e = lane; e < N * N; e += 64) U_out[e] = Ub[(e / N) * LD + (e % N)];
 }
 
-__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status) {
+// skip (optional, [n]): records that carry no factor (interval beyond the window, sum_dt > 10 s) are left alone. per_record: the
+// "covariance not positive definite" flag goes to status[f] instead of status[0], so that a batch can fail the one window it concerns.
+__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
   __shared__ double R[31 * 32], Ub[31 * 32];
   const int f = blockIdx.x;
-  if (f >= n) return;
+  if (f >= n || (skip && skip[f])) return;
   const vilo_preint &p = pre[f];
   if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
-  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status);
+  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
 }
 
-__global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status) {
+__global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
   __shared__ double R[15 * 16], Ub[15 * 16];
   const int f = blockIdx.x;
-  if (f >= n) return;
+  if (f >= n || (skip && skip[f])) return;
   const vilo_preint_imu &p = pre[f];
   if (threadIdx.x == 0) fill_preint_head_imu(p, out[f].head);
   // 15x15 sqrt_info stored in the leading 225 doubles
-  sqrt_info_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status);
+  sqrt_info_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
 }
 
-int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status) {
+int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
-  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status);
+  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }
-int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status) {
+int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
-  hipLaunchKernelGGL(k_prepare_preint_imu, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status);
+  hipLaunchKernelGGL(k_prepare_preint_imu, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }
@@ -307,7 +309,7 @@ extern "C" int vilo_eval_imu_leg(vilo_ctx *ctx, int n, const vilo_preint *pre, c
   VILO_HIP(d_status.alloc(sizeof(int)));
   VILO_HIP(hipMemsetAsync(d_status.p, 0, sizeof(int), ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_pre.p, pre, sizeof(vilo_preint) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  TRY(vilo_launch_prepare_preint(ctx, n, d_pre.as<vilo_preint>(), d_prep.as<PreintPrepared>(), d_status.as<int>()));
+  TRY(vilo_launch_prepare_preint(ctx, n, d_pre.as<vilo_preint>(), d_prep.as<PreintPrepared>(), d_status.as<int>(), nullptr, 0));
   double *d_in[6], *d_r, *dJ[6];
   const double *h_in[6] = {pose_i, sb_i, lb_i, pose_j, sb_j, lb_j};
   const size_t gs[6] = {7, 9, 4, 7, 9, 4};
@@ -341,7 +343,7 @@ extern "C" int vilo_eval_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *pre, c
   VILO_HIP(d_status.alloc(sizeof(int)));
   VILO_HIP(hipMemsetAsync(d_status.p, 0, sizeof(int), ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_pre.p, pre, sizeof(vilo_preint_imu) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  TRY(vilo_launch_prepare_preint_imu(ctx, n, d_pre.as<vilo_preint_imu>(), d_prep.as<PreintPrepared>(), d_status.as<int>()));
+  TRY(vilo_launch_prepare_preint_imu(ctx, n, d_pre.as<vilo_preint_imu>(), d_prep.as<PreintPrepared>(), d_status.as<int>(), nullptr, 0));
   double *d_in[4], *d_r, *dJ[4];
   const double *h_in[4] = {pose_i, sb_i, pose_j, sb_j};
   const size_t gs[4] = {7, 9, 7, 9};

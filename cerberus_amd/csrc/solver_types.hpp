@@ -150,4 +150,5 @@ struct BatchDev {
   double *Bimg;               // [W][BI_N] speed / leg-bias part of the assembled system (BI_* layout)
   SolverState *st;
   int *status;
+  int *win_bad;               // [W] 1: a preintegration covariance of the window has no sqrt_info: the window fails alone (termination FAILURE)
 };

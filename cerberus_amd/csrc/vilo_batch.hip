@@ -28,6 +28,10 @@ struct vilo_batch {
   vilo_solve_opts gopts;
   int n_solves = 0;
   bool graph_failed = false;
+  // what vilo_batch_prepare needs to run the sqrt_info preparation again (the reference does it in every IMULegFactor::Evaluate)
+  void *d_pre = nullptr;
+  bool leg = true;
+  int *d_prep_bad = nullptr;   // [W * 10] covariance of this record not positive definite
 };
 
 namespace {
@@ -522,12 +526,19 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       if (rc == VILO_OK) rc = dev_upload(ctx, bt, &d_gd, g_dst);
       if (rc == VILO_OK) rc = vilo_launch_preint_gather(ctx, refs[0].preint_pool, (int)g_ids.size(), d_gi, d_gd, d_pre);
     }
-    if (rc == VILO_OK) rc = leg ? vilo_launch_prepare_preint(ctx, W * 10, (const vilo_preint *)d_pre, D.prep, D.status)
-                                : vilo_launch_prepare_preint_imu(ctx, W * 10, (const vilo_preint_imu *)d_pre, D.prep, D.status);
-    if (rc == VILO_OK && !leg) rc = vilo_launch_embed_sqrt15(ctx, D);
-    if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
-    if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
+    bt->d_pre = d_pre; bt->leg = leg;
+    if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->d_prep_bad, (size_t)W * 10);
+    if (rc == VILO_OK) rc = vilo_batch_prepare(ctx, bt);
+    // a covariance that is not positive definite has no sqrt_info: that window alone fails (termination FAILURE, like a non-finite
+    // IterationZero); the flag is looked at for live intervals only
+    std::vector<int> bad((size_t)W * 10, 0), winbad(W, 0);
+    if (rc == VILO_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                          hipMemcpy(bad.data(), bt->d_prep_bad, sizeof(int) * bad.size(), hipMemcpyDeviceToHost) != hipSuccess)) rc = VILO_ERR_HIP;
     if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
+    for (int w = 0; w < W; ++w)
+      for (int k = 0; k < 10; ++k)
+        if (!iskip[(size_t)w * 10 + k] && bad[(size_t)w * 10 + k]) winbad[w] = 1;
+    if (dev_upload(ctx, bt, &D.win_bad, winbad) != VILO_OK) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   }
   const double t_prep = now();
   int rc = vilo_batch_reset(ctx, bt);
@@ -537,6 +548,19 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
             t_uploaded - t_packed, t_prep - t_uploaded, now() - t_prep);
   *out = bt;
   return VILO_OK;
+}
+
+// sqrt_info = chol(cov^-1)^T of every live interval of the batch (asynchronous, on the context's stream)
+extern "C" int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *bt) {
+  if (!ctx || !bt || !bt->d_pre) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  BatchDev &D = bt->d;
+  VILO_HIP(hipMemsetAsync(bt->d_prep_bad, 0, sizeof(int) * (size_t)bt->W * 10, ctx->stream));
+  int rc = bt->leg ? vilo_launch_prepare_preint(ctx, bt->W * 10, (const vilo_preint *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1)
+                   : vilo_launch_prepare_preint_imu(ctx, bt->W * 10, (const vilo_preint_imu *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1);
+  if (rc == VILO_OK && !bt->leg) rc = vilo_launch_embed_sqrt15(ctx, D);
+  if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
+  return rc;
 }
 
 extern "C" int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *bt) {

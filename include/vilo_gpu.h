@@ -241,6 +241,9 @@ int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in,
 int vilo_batch_create(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *init,
                       vilo_batch **batch);
 int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *batch);  /* restore the uploaded initial states (device-side copy) */
+/* sqrt_info = LLT(cov^-1)^T of the batch's preintegration records again (asynchronous): vilo_batch_create runs it once; the reference
+ * recomputes it in every IMULegFactor::Evaluate (imu_leg_factor.cpp:197-198), a caller that replays a resident batch can charge it per solve */
+int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *batch);
 int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *batch, const vilo_solve_opts *opts);
 int vilo_batch_download(vilo_ctx *ctx, vilo_batch *batch, vilo_window_state *out, vilo_solve_summary *summaries);
 void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *batch);

@@ -3,10 +3,10 @@
 #   pass 1: --kernel-trace --stats              -> per-kernel average duration (must agree with bench.py's HIP events)
 #   pass 2: --pmc FETCH_SIZE  (+ kernel trace)  -> HBM read bytes per dispatch   (own pass: TCC has 4 slots, FETCH_SIZE takes 3)
 #   pass 3: --pmc WRITE_SIZE  (+ kernel trace)  -> HBM write bytes per dispatch
-# Each PMC pass also runs tools/calib_copy.py (2 GiB streamed at 8 B per lane) to calibrate the counters (MI355X_MICROARCH.md §HBM).
+# Each PMC pass also runs tools/calib_and_bench.py (k_calib_copy: 1 GiB read + 1 GiB written at 8 B per lane, 4 dispatches) to calibrate the counters (MI355X_MICROARCH.md §HBM).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KNOWN = ("k_visual_linearize", "k_imu_raw", "k_imu_whiten", "k_build_solve", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
+KNOWN = ("k_visual_linearize", "k_imu_linearize", "k_assemble", "k_solve_wave", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
          "k_preint_imu_leg", "k_prepare_preint", "k_sqrt_transpose", "k_calib_copy", "k_marginalize")
 
 
@@ -25,16 +25,16 @@ def db(pattern):
 
 summary = {}
 con = db("trace/**/*.db")
-print("== rocprofv3 --kernel-trace --stats: python bench.py --steps 2 --warmup 1 (windows per GPU: see the grid of the k_build_solve dispatch below)")
+print("== rocprofv3 --kernel-trace --stats: python bench.py --steps 2 --warmup 1 (windows per GPU = grid / 64 of the k_solve_wave dispatch below)")
 if con:
     ks = {}
     for name, calls, total, avg, pct in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         print("%-22s calls %5d  avg %10.1f us  total %10.3f ms  %5.1f%%" % (short(name), calls, avg, total / 1e3, pct))
         ks[short(name)] = {"calls": calls, "avg_us": avg, "total_ms": total / 1e3}
     summary["kernel_trace"] = ks
-    row = con.execute("select lds_size, vgpr_count, accum_vgpr_count, sgpr_count, workgroup_x, grid_x from kernels where name like '%k_build_solve%' limit 1").fetchone()
+    row = con.execute("select lds_size, vgpr_count, accum_vgpr_count, sgpr_count, workgroup_x, grid_x from kernels where name like '%k_solve_wave%' limit 1").fetchone()
     if row:
-        print("k_build_solve dispatch: lds %d B, vgpr %d, agpr %d, sgpr %d, workgroup %d, grid %d" % row)
+        print("k_solve_wave dispatch: lds %d B, vgpr %d, agpr %d, sgpr %d, workgroup %d, grid %d" % row)
 cal, per = {}, {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     con = db("pmc_%s/**/*.db" % cname)
