@@ -30,7 +30,7 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
 
 
 ALG_FLOPS_PER_WINDOW_ITERATION = {200: 13.7e6, 1000: 47.0e6}   # FP64 flops of one window-iteration (FMA = 2)
-ITERATION_KERNELS = ("k_visual_linearize", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")   # launched once per iteration
+ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")   # launched once per iteration
 
 
 def profile_evidence(W_run):

@@ -217,8 +217,9 @@ VD void fill_preint_head_imu(const PRE &p, PreintHead &h) {
     for (int a = 0; a < 3; ++a) h.dep_drho[j][a] = 0.0;
 }
 
+// Jacobian entry (row, col) goes to J[row * ld + col * cs] (cs = 1: row-major; cs = number of factors, ld = 39 cs: entry-major over a batch).
 VD void imu_leg_raw(const PreintHead &P, double g_norm, const double *pose_i, const double *sb_i, const double *lb_i,
-                    const double *pose_j, const double *sb_j, const double *lb_j, double *r, bool want_jac, double *J, int ld) {
+                    const double *pose_j, const double *sb_j, const double *lb_j, double *r, bool want_jac, double *J, int ld, int cs = 1) {
   const v3 G = mk3(0, 0, g_norm);
   const v3 Pi = ld3(pose_i), Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
   const v3 Pj = ld3(pose_j), Vj = ld3(sb_j), Baj = ld3(sb_j + 3), Bgj = ld3(sb_j + 6);
@@ -249,7 +250,7 @@ VD void imu_leg_raw(const PreintHead &P, double g_norm, const double *pose_i, co
 
   auto put = [&](int r0, int c0, const m3 &M) {
     for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) J[(r0 + a) * ld + c0 + b] = M.a[3 * a + b];
+      for (int b = 0; b < 3; ++b) J[(r0 + a) * ld + (c0 + b) * cs] = M.a[3 * a + b];
   };
   const m3 RiT = qR(Qi_inv);
   const m3 nRiT = -RiT;
@@ -274,8 +275,8 @@ VD void imu_leg_raw(const PreintHead &P, double g_norm, const double *pose_i, co
   put(24, 12, nI3);
   // legbias_i
   for (int j = 0; j < 4; ++j) {
-    for (int a = 0; a < 3; ++a) J[(9 + 3 * j + a) * ld + 15 + j] = -P.dep_drho[j][a];
-    J[(27 + j) * ld + 15 + j] = -1.0;
+    for (int a = 0; a < 3; ++a) J[(9 + 3 * j + a) * ld + (15 + j) * cs] = -P.dep_drho[j][a];
+    J[(27 + j) * ld + (15 + j) * cs] = -1.0;
   }
   // pose_j
   put(0, 19, RiT);
@@ -286,13 +287,13 @@ VD void imu_leg_raw(const PreintHead &P, double g_norm, const double *pose_i, co
   put(21, 28, I3);
   put(24, 31, I3);
   // legbias_j
-  for (int j = 0; j < 4; ++j) J[(27 + j) * ld + 34 + j] = 1.0;
+  for (int j = 0; j < 4; ++j) J[(27 + j) * ld + (34 + j) * cs] = 1.0;
 }
 
 // Classic IMU factor before whitening. Residual order P0 R3 V6 BA9 BG12; local columns
 // [pose_i 0..5 | sb_i 6..14 | pose_j 15..20 | sb_j 21..29]. Uses the P,R,V,BA,BG parts of PreintHead.
 VD void imu_raw(const PreintHead &P, double g_norm, const double *pose_i, const double *sb_i, const double *pose_j,
-                const double *sb_j, double *r, bool want_jac, double *J, int ld, int cj = 15) {
+                const double *sb_j, double *r, bool want_jac, double *J, int ld, int cj = 15, int cs = 1) {
   const v3 G = mk3(0, 0, g_norm);
   const v3 Pi = ld3(pose_i), Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
   const v3 Pj = ld3(pose_j), Vj = ld3(sb_j), Baj = ld3(sb_j + 3), Bgj = ld3(sb_j + 6);
@@ -315,7 +316,7 @@ VD void imu_raw(const PreintHead &P, double g_norm, const double *pose_i, const 
   if (!want_jac) return;
   auto put = [&](int r0, int c0, const m3 &M) {
     for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) J[(r0 + a) * ld + c0 + b] = M.a[3 * a + b];
+      for (int b = 0; b < 3; ++b) J[(r0 + a) * ld + (c0 + b) * cs] = M.a[3 * a + b];
   };
   const m3 RiT = qR(Qi_inv);
   const m3 nRiT = -RiT;

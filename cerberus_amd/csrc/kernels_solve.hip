@@ -437,112 +437,138 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
 #define IMU_LIN_STRIDE (31 * 39)
 #define IMU_NTRI 496   // upper triangle of the 31 x 31 sqrt_info
 
-// IMULegFactor linearisation (imu_leg_factor.cpp:173-386), one wave per factor:
-//   raw       residual + 31 x 38 local Jacobian by lane 0 (a scalar dependency chain) into a zero-filled 32 x 48 LDS block [J | r]
-//   whitening Jw = U [J | r]      (U = sqrt_info, upper triangular 31 x 31; 32 x 48 x 32 padded, zero blocks skipped)
-//   Gram      G  = Jw^T Jw        (39 x 39: the factor's J^T J, J^T r and r^T r = its cost; upper tiles only)
-// both products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64). Operand layout of the instruction: A(16 x 4): lane l holds
-// A[l % 16][l / 16]; B(4 x 16): lane l holds B[l / 16][l % 16]; C/D(16 x 16): register r of lane l is C[(l / 16) + 4 r][l % 16].
-// The raw block never leaves the CU; the whitened one goes to HBM only for the marginalisation (mode 0).
-#define IW_JS 48   // LDS row stride of the block (conflict-free operand reads of the Gram pass)
+// IMULegFactor linearisation (imu_leg_factor.cpp:173-386) in two kernels:
+//   k_imu_raw        one THREAD per factor (the code is a scalar dependency chain, so lanes = factors gives 64-way SIMD): raw residual and
+//                    31 x 38 local Jacobian, structural non-zeros only (the zeros are set once when the batch is created), stored
+//                    ENTRY-MAJOR over the batch — b.imu_raw[(row * 39 + col) * NF + f] — so that the 64 lanes of a store are 64 neighbours
+//   k_imu_linearize  one wave per factor, both products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//                      whitening Jw = U [J | r]   (U = sqrt_info, upper triangular 31 x 31; 32 x 48 x 32 padded, zero blocks skipped);
+//                                                 operands straight from global memory, only the structurally non-zero entries of [J | r]
+//                      Gram      G  = Jw^T Jw     (39 x 39: the factor's J^T J, J^T r and r^T r = its cost; upper tiles only)
+// Operand layout of the instruction: A(16 x 4): lane l holds A[l % 16][l / 16]; B(4 x 16): lane l holds B[l / 16][l % 16];
+// C/D(16 x 16): register r of lane l is C[(l / 16) + 4 r][l % 16]. The whitened block goes to HBM only for the marginalisation (mode 0).
+#define IW_JS 48   // LDS row stride of Jw (conflict-free operand reads of the Gram pass)
+// structural non-zeros of [J | r] (31 rows x 39 columns, bit c of entry r): union of the IMULegFactor and the embedded IMUFactor patterns
+__device__ constexpr unsigned long long c_imu_nz[31] = {
+    0x4000387fffULL, 0x4000387fffULL, 0x4000387fffULL, 0x4001c07038ULL, 0x4001c07038ULL, 0x4001c07038ULL, 0x400e007ff8ULL, 0x400e007ff8ULL,
+    0x400e007ff8ULL, 0x407038fe3fULL, 0x407038fe3fULL, 0x407038fe3fULL, 0x438039703fULL, 0x438039703fULL, 0x438039703fULL, 0x40003a703fULL,
+    0x40003a703fULL, 0x40003a703fULL, 0x40003c703fULL, 0x40003c703fULL, 0x40003c703fULL, 0x4070000e00ULL, 0x4070000e00ULL, 0x4070000e00ULL,
+    0x4380007000ULL, 0x4380007000ULL, 0x4380007000ULL, 0x4400008000ULL, 0x4800010000ULL, 0x5000020000ULL, 0x6000040000ULL};
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_imu_linearize(BatchDev b, double g_norm, int mode) {
-  __shared__ double R[32 * IW_JS];
-  __shared__ PreintHead headl;
-  const int f = blockIdx.x, win = f / 10, k = f % 10;
+__global__ void __launch_bounds__(64) k_imu_raw(BatchDev b, double g_norm, int mode) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NF = b.W * 10;
+  if (f >= NF) return;
+  const int win = f / 10, k = f % 10;
+  const SolverState &st = b.st[win];
+  if (lin_skip(st, mode) || b.imu_skip[f]) return;
+  const PreintPrepared &pp = b.prep[f];
+  const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
+  double *raw = b.imu_raw + f;
+  double r[31];
+  if (b.win[win].use_leg) {
+    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, raw, 39 * NF, NF);
+#pragma unroll
+    for (int i = 0; i < 31; ++i) raw[(size_t)(i * 39 + 38) * NF] = r[i];
+  } else {
+    // plain IMUFactor (estimator.cpp:1160-1171) inside the same 31 x 39 layout: rows 0..14, the frame-j blocks at column 19,
+    // leg-bias columns and rows 15..30 stay zero (sqrt_info is embedded accordingly, k_embed_sqrt15)
+    imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, true, raw, 39 * NF, 19, NF);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) raw[(size_t)(i * 39 + 38) * NF] = r[i];
+  }
+}
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+// One wave per PAIR of consecutive factors (2 p, 2 p + 1; the same window): a lane's 16-byte load of an entry-major raw entry brings
+// both factors' values, which halves the scattered 32-byte sectors the gather touches per factor.
+__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
+  __shared__ double Jw[32 * IW_JS];
+  const int f0 = 2 * blockIdx.x, win = f0 / 10;
   SolverState &st = b.st[win];
   if (lin_skip(st, mode)) return;
   const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-  double *gout = b.imu_gram + (size_t)f * 780;
-  if (b.imu_skip[f]) {   // no factor for this interval: it contributes nothing to the normal equations
-    if (mode == 0) for (int e = lane; e < IMU_LIN_STRIDE; e += 64) b.imu_lin[(size_t)f * IMU_LIN_STRIDE + e] = 0.0;
-    for (int e = lane; e < 780; e += 64) gout[e] = 0.0;
-    if (lane == 0) b.imu_cost[f] = 0.0;
-    return;
-  }
-  const bool prof = (k == 0 && lane == 0);
-  const long long c0 = clock64();
-  for (int e = lane; e < 32 * IW_JS; e += 64) R[e] = 0.0;
-  const PreintPrepared &pp = b.prep[f];
-  const double *U = pp.sqrt_info;
-  // the 126 scalars of the preintegration record through LDS: two coalesced loads per lane instead of 126 broadcast loads held in registers
+  const int NF = b.W * 10;
+  // [J | r] tiles of both factors: up to 24 B values per lane and factor (structural non-zeros only), all loads in flight at once
+  double bv[2][8][3];
   {
-    const double *hg = (const double *)&pp.head;
-    double *hl = (double *)&headl;
-    for (int e = lane; e < (int)(sizeof(PreintHead) / sizeof(double)); e += 64) hl[e] = hg[e];
-  }
-  lds_fence();
-  if (lane == 0) {
-    const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
-    double r[31];
-    if (b.win[win].use_leg) {
-      imu_leg_raw(headl, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-                  x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, true, R, IW_JS);
+    const dbl2 *raw2 = (const dbl2 *)(b.imu_raw + f0);
 #pragma unroll
-      for (int i = 0; i < 31; ++i) R[i * IW_JS + 38] = r[i];
-    } else {
-      // plain IMUFactor (estimator.cpp:1160-1171) inside the same layout: rows 0..14, the frame-j blocks at column 19,
-      // leg-bias columns and rows 15..30 stay zero (sqrt_info is embedded accordingly, k_embed_sqrt15)
-      imu_raw(headl, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, true, R, IW_JS, 19);
+    for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-      for (int i = 0; i < 15; ++i) R[i * IW_JS + 38] = r[i];
-    }
-  }
-  lds_fence();
-  const long long c1 = clock64();
-  // sqrt_info operands straight from global memory: 12 A values per lane
-  double av[2][8];
-#pragma unroll
-  for (int I = 0; I < 2; ++I)
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int row = 16 * I + lr, q = 4 * kk + lk;
-      av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
-    }
-  double bv[8][3];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-    for (int J = 0; J < 3; ++J) bv[kk][J] = R[(4 * kk + lk) * IW_JS + 16 * J + lr];
-  lds_fence();   // every operand of the whitening is in registers: the block is overwritten in place below
-  double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
-#pragma unroll
-  for (int I = 0; I < 2; ++I) {
-#pragma unroll
-    for (int J = 0; J < 3; ++J) {
-      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = (I == 0 ? 0 : 4); kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I][kk], bv[kk][J], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + lk + 4 * r, col = 16 * J + lr;
-        R[row * IW_JS + col] = acc[r];   // padding rows / columns come out as exact zeros
-        if (mode == 0 && row < 31 && col < 39) out[row * 39 + col] = acc[r];
+      for (int J = 0; J < 3; ++J) {
+        const int q = 4 * kk + lk, col = 16 * J + lr;
+        const bool nz = q < 31 && col < 39 && ((c_imu_nz[min(q, 30)] >> col) & 1ULL);
+        dbl2 v = {0.0, 0.0};
+        if (nz) v = raw2[((size_t)(q * 39 + col) * NF) >> 1];
+        bv[0][kk][J] = v[0]; bv[1][kk][J] = v[1];
       }
-    }
   }
-  lds_fence();
-  const long long c2 = clock64();
 #pragma unroll
-  for (int I = 0; I < 3; ++I) {
+  for (int h = 0; h < 2; ++h) {
+    const int f = f0 + h;
+    double *gout = b.imu_gram + (size_t)f * 780;
+    if (b.imu_skip[f]) {   // no factor for this interval: it contributes nothing to the normal equations
+      if (mode == 0) for (int e = lane; e < IMU_LIN_STRIDE; e += 64) b.imu_lin[(size_t)f * IMU_LIN_STRIDE + e] = 0.0;
+      for (int e = lane; e < 780; e += 64) gout[e] = 0.0;
+      if (lane == 0) b.imu_cost[f] = 0.0;
+      continue;
+    }
+    const bool prof = (f % 10 == 0 && lane == 0);
+    const long long c0 = clock64();
+    const double *U = b.prep[f].sqrt_info;
+    // sqrt_info operands straight from global memory: 12 A values per lane
+    double av[2][8];
 #pragma unroll
-    for (int J = I; J < 3; ++J) {
-      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int I = 0; I < 2; ++I)
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const double a_ = R[(4 * kk + lk) * IW_JS + 16 * I + lr];
-        const double b_ = R[(4 * kk + lk) * IW_JS + 16 * J + lr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc, 0, 0, 0);
+        const int row = 16 * I + lr, q = 4 * kk + lk;
+        av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
       }
+    const long long c1 = clock64();
+    double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
+    lds_fence();   // (the previous factor's Gram pass has read Jw)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = 16 * I + lk + 4 * r, bc = 16 * J + lr;
-        if (a <= bc && bc < 39) gout[tri39(a, bc)] = acc[r];
-        if (a == 38 && bc == 38) b.imu_cost[f] = acc[r];   // |sqrt_info r|^2
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+      for (int J = 0; J < 3; ++J) {
+        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = (I == 0 ? 0 : 4); kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I][kk], bv[h][kk][J], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lk + 4 * r, col = 16 * J + lr;
+          Jw[row * IW_JS + col] = acc[r];   // padding rows / columns come out as exact zeros
+          if (mode == 0 && row < 31 && col < 39) out[row * 39 + col] = acc[r];
+        }
       }
     }
+    lds_fence();
+    const long long c2 = clock64();
+#pragma unroll
+    for (int I = 0; I < 3; ++I) {
+#pragma unroll
+      for (int J = I; J < 3; ++J) {
+        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const double a_ = Jw[(4 * kk + lk) * IW_JS + 16 * I + lr];
+          const double b_ = Jw[(4 * kk + lk) * IW_JS + 16 * J + lr];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * I + lk + 4 * r, bc = 16 * J + lr;
+          if (a <= bc && bc < 39) gout[tri39(a, bc)] = acc[r];
+          if (a == 38 && bc == 38) b.imu_cost[f] = acc[r];   // |sqrt_info r|^2
+        }
+      }
+    }
+    if (prof) { const long long c3 = clock64(); st.phase_clk[24] = c1 - c0; st.phase_clk[25] = c2 - c1; st.phase_clk[26] = c3 - c2; }
   }
-  if (prof) { const long long c3 = clock64(); st.phase_clk[24] = c1 - c0; st.phase_clk[25] = c2 - c1; st.phase_clk[26] = c3 - c2; }
 }
 
 // residual-only at the candidate: one thread per factor; sqrt_info is read from its entry-major transpose
@@ -786,8 +812,11 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     P0(0);
     launch_visual_linearize(b, sq, ha, s, 1);
     P1();
+    P0(7);
+    hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
+    P1();
     P0(1);
-    hipLaunchKernelGGL(k_imu_linearize, dim3(W * 10), dim3(64), 0, s, b, gn, 1);
+    hipLaunchKernelGGL(k_imu_linearize, dim3(W * 5), dim3(64), 0, s, b, 1);
     P1();
     P0(5);
     hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
@@ -819,7 +848,8 @@ int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4, 0);
   launch_visual_linearize(b, sq, ha, ctx->stream, 0);
-  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, gn, 0);
+  hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn, 0);
+  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 5), dim3(64), 0, ctx->stream, b, 0);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

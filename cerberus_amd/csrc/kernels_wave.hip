@@ -214,51 +214,93 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
     b.Cimg[(size_t)win * CIMG_N + idx] = v;
     part_q += ((c_tI[t] == c_tJ[t]) ? 1.0 : 2.0) * vS[row] * v * vS[col];   // (a diagonal tile holds both triangles)
   }
-  // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams ----
-  for (int e = tid; e < 11 * 169; e += ASM_THREADS) {   // A_kk: factor k (frame k is "i": columns 6..18), factor k - 1 ("j": 25..37), prior at frame kb
-    const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
-    double val;
-    if (!cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(CD_B0 + 13 * k + j, F, cmask)) {
-      val = (i == j) ? 1.0 : 0.0;
-    } else {
-      val = (k == kb) ? pd[PD_AD + e] : 0.0;
-      if (k < F - 1) val += igram[k * 780 + tri39(6 + min(i, j), 6 + max(i, j))];
-      if (k >= 1) val += igram[(k - 1) * 780 + tri39(25 + min(i, j), 25 + max(i, j))];
-    }
-    bimg[BI_AD + e] = val;
-    part_q += vS[CD_B0 + 13 * k + i] * val * vS[CD_B0 + 13 * k + j];
-  }
-  for (int e = tid; e < 10 * 169; e += ASM_THREADS) {   // A_{k+1,k} transposed: [k][j = dimension of frame k][i = dimension of frame k + 1]
-    const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
-    double val = 0.0;
-    if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) val = igram[k * 780 + tri39(6 + j, 25 + i)];
-    bimg[BI_AOT + e] = val;
-    part_q += 2.0 * vS[CD_B0 + 13 * (k + 1) + i] * val * vS[CD_B0 + 13 * k + j];
-  }
-  for (int e = tid; e < 11 * 16 * 18; e += ASM_THREADS) {   // coupling of dimension i of frame k with pose k - 1 + df, column c (rows 13..15: zero padding)
-    const int k = e / 288, is = e - 288 * k, i = is / 18, s = is - 18 * i, df = s / 6, c = s - 6 * df, f = k - 1 + df;
-    double val = 0.0;
-    if (i < 13 && f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
-      if (df == 1) {
-        if (k < F - 1) val += igram[k * 780 + tri39(c, 6 + i)];
-        if (k >= 1) val += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
-      } else if (df == 2) {
-        if (k < F - 1) val += igram[k * 780 + tri39(6 + i, 19 + c)];
+  // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams. The loads of all trips of a block
+  //      kind are issued before the first store (values in registers): one memory round trip per kind instead of one per trip ----
+  {
+    double val[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // A_kk: factor k (frame k is "i": columns 6..18), factor k - 1 ("j": 25..37), prior at frame kb
+      const int e = min(tid + ASM_THREADS * u, 11 * 169 - 1);
+      const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
+      double v;
+      if (!cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(CD_B0 + 13 * k + j, F, cmask)) {
+        v = (i == j) ? 1.0 : 0.0;
       } else {
-        val += igram[(k - 1) * 780 + tri39(c, 25 + i)];   // (f >= 0 means k >= 1)
+        v = (k == kb) ? pd[PD_AD + e] : 0.0;
+        if (k < F - 1) v += igram[k * 780 + tri39(6 + min(i, j), 6 + max(i, j))];
+        if (k >= 1) v += igram[(k - 1) * 780 + tri39(25 + min(i, j), 25 + max(i, j))];
       }
-      part_q += 2.0 * vS[CD_B0 + 13 * k + i] * val * vS[6 * f + c];
+      val[u] = v;
     }
-    bimg[BI_BS + e] = val;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 11 * 169) {
+        const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
+        bimg[BI_AD + e] = val[u];
+        part_q += vS[CD_B0 + 13 * k + i] * val[u] * vS[CD_B0 + 13 * k + j];
+      }
+    }
   }
-  for (int e = tid; e < 16 * 80; e += ASM_THREADS) {   // prior rows of the frame whose speed / leg-bias block it touches (rows 13..15: zero padding)
-    const int i = e / 80, p = e - 80 * i;
-    double val = 0.0;
-    if (kb >= 0 && i < 13 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) {
-      val = pd[PD_BP + e];
-      part_q += 2.0 * vS[CD_B0 + 13 * kb + i] * val * vS[p];
+  {
+    double val[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {   // A_{k+1,k} transposed: [k][j = dimension of frame k][i = dimension of frame k + 1]
+      const int e = min(tid + ASM_THREADS * u, 10 * 169 - 1);
+      const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
+      double v = 0.0;
+      if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) v = igram[k * 780 + tri39(6 + j, 25 + i)];
+      val[u] = v;
     }
-    bimg[BI_BP + e] = val;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 10 * 169) {
+        const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
+        bimg[BI_AOT + e] = val[u];
+        part_q += 2.0 * vS[CD_B0 + 13 * (k + 1) + i] * val[u] * vS[CD_B0 + 13 * k + j];
+      }
+    }
+  }
+  {
+    double val[13];
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {   // coupling of dimension i of frame k with pose k - 1 + df, column c (rows 13..15: zero padding)
+      const int e = min(tid + ASM_THREADS * u, 11 * 288 - 1);
+      const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, df = sx / 6, c = sx - 6 * df, f = k - 1 + df;
+      double v = 0.0;
+      if (i < 13 && f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
+        if (df == 1) {
+          if (k < F - 1) v += igram[k * 780 + tri39(c, 6 + i)];
+          if (k >= 1) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
+        } else if (df == 2) {
+          if (k < F - 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
+        } else {
+          v += igram[(k - 1) * 780 + tri39(c, 25 + i)];   // (f >= 0 means k >= 1)
+        }
+      }
+      val[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 11 * 288) {
+        const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, f = k - 1 + sx / 6, c = sx % 6;
+        bimg[BI_BS + e] = val[u];
+        if (val[u] != 0.0) part_q += 2.0 * vS[CD_B0 + 13 * k + min(i, 12)] * val[u] * vS[min(max(6 * f + c, 0), 79)];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {   // prior rows of the frame whose speed / leg-bias block it touches (rows 13..15: zero padding)
+    const int e = tid + ASM_THREADS * u;
+    const int i = e / 80, p = e - 80 * i;
+    double v = 0.0;
+    if (kb >= 0 && i < 13 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) {
+      v = pd[PD_BP + e];
+      part_q += 2.0 * vS[CD_B0 + 13 * kb + i] * v * vS[p];
+    }
+    bimg[BI_BP + e] = v;
   }
   // camera-side sums of |D^-1 g|^2, max |g| and q (the landmarks add theirs in the solver): waves in fixed order
   part_q = wave_sum(part_q); part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax);
