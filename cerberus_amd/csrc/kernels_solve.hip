@@ -309,7 +309,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     if (TPAR) { if (lane == 0) cost_out[blockIdx.y] = csum; }
     else if (lane < VILO_MAX_FRAMES) cost_out[lane] = (lane == 0) ? csum : 0.0;
   }
-  if (prof) { st.phase_clk[16] = clock64() - c_t0; st.phase_clk[17] = c_proj; st.phase_clk[18] = c_gram; st.phase_clk[19] = wv.n_lanes; st.phase_clk[20] = wv.kmax; }
+  if (prof) { st.phase_clk[28] = clock64() - c_t0; st.phase_clk[29] = c_proj; st.phase_clk[30] = c_gram; st.phase_clk[31] = wv.n_lanes; st.phase_clk[32] = wv.kmax; }
 }
 
 __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false>(b, sq, huber_a, mode); }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
         }
       }
     }
-    if (prof) { const long long c3 = clock64(); st.phase_clk[24] = c1 - c0; st.phase_clk[25] = c2 - c1; st.phase_clk[26] = c3 - c2; }
+    if (prof) { const long long c3 = clock64(); st.phase_clk[33] = c1 - c0; st.phase_clk[34] = c2 - c1; st.phase_clk[35] = c3 - c2; }
   }
 }
 
