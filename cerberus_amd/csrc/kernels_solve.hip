@@ -132,8 +132,8 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const int lr = lane & 15, lk = lane >> 4;
   const int xoff = (lk >> 1) * XLANE + (lk & 1) * 26 + lr;
   const bool c1on = lr < 10;   // columns 26 .. 31 of the second tile column do not exist
-  if (!TPAR && active)   // TPAR: the host clears w before the launch (the frames of a landmark run in different workgroups)
-    for (int a = 0; a < 80; ++a) wbase[(size_t)a * L + li] = 0.0;
+  // (coupling rows w: every row of a landmark's column is written exactly once — the observed poses and the extrinsic / td rows with their
+  // sums, the rest with zeros at the end; TPAR: the host clears w before the launch, the frames of a landmark run in different workgroups)
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
 
   const double *obs = b.obs + wv.obs_off;
@@ -288,10 +288,19 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         if (c1on && row < 10 && row <= lr) gs[tri26(16 + row, 16 + lr)] = G11[g][r];
       }
     }
-    if (active && t > 0 && (fl & 1))
-      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
+    if (TPAR) {
+      if (active && t > 0 && (fl & 1))
+        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
+    } else if (active && t > 0 && s + t < VILO_MAX_FRAMES) {
+      const bool seen = fl & 1;
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = seen ? wj[c] : 0.0;
+    }
   }
   if (!TPAR && active) {
+    for (int f = 0; f < VILO_MAX_FRAMES; ++f)
+      if (f < s || f >= s + wv.kmax)
+        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
+    wbase[(size_t)79 * L + li] = 0.0;
     b.lm_E[ls.gi] = E;
     lm_g_out[ls.gi] = gl;
     for (int c = 0; c < 6; ++c) {
