@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       if (fail) {
         // DoglegStrategy::ComputeGaussNewtonStep: mu *= 10 and retry while mu < max_mu (1.0)
         mu *= 10.0;
-        if (lane == 0) st.mu = mu;
+        if (lane == 0) { st.mu = mu; st.pad[0]++; }   // (pad[0]: factorisation retries of this solve, read by the tests)
         if (!(mu < 1.0)) {
           if (lane == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = qq; st.gmax = gmax; st.scale_ready = 1; }
           return;
@@ -965,7 +965,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       gy = wave_sum(part_gy);
       if (!(isfinite(gnnorm2) && isfinite(gy))) {   // IsArrayValid(gauss_newton_step_) failed
         mu *= 10.0;
-        if (lane == 0) st.mu = mu;
+        if (lane == 0) { st.mu = mu; st.pad[0]++; }   // (pad[0]: factorisation retries of this solve, read by the tests)
         if (!(mu < 1.0)) {
           if (lane == 0) { st.lin_fail = 1; st.step_valid = 0; st.scale_ready = 1; }
           return;

@@ -466,6 +466,12 @@ extern "C" void orc_window_normal_eq(const orc_config *cfg, const orc_window *w,
 }
 
 // ceres::Solve with DENSE_SCHUR + DOGLEG (estimator.cpp:1221-1236); everything else Ceres defaults.
+// Which branches the last orc_solve_window took (test infrastructure for the parity tests that force them):
+// 0 Gauss-Newton step inside the radius, 1 Cauchy-limited step, 2 dogleg-interpolated step, 3 rejected steps, 4 longest run of rejected
+// steps, 5 invalid steps, 6 mu escalations (reduced system not positive definite), 7 accepted steps.
+static int g_branch[8];
+extern "C" void orc_last_branch_counts(int *out) { for (int i = 0; i < 8; ++i) out[i] = g_branch[i]; }
+
 extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_state *s, const orc_solve_opts *o,
                                 orc_summary *sum) {
   Problem P;
@@ -503,6 +509,8 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
   sum->initial_cost = x_cost;
   sum->cost_trace[0] = x_cost;
 
+  for (int i = 0; i < 8; ++i) g_branch[i] = 0;
+  int consecutive_rejected = 0;
   // DoglegStrategy state
   double radius = o->initial_trust_region_radius, mu = 1e-8;
   const double min_mu = 1e-8, max_mu = 1.0, mu_increase = 10.0;
@@ -545,6 +553,7 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
         for (int i = 0; i < n; ++i) Dlm[i] = diagonal[i] * std::sqrt(mu);
         std::vector<double> y;
         if (!schur_solve(H, gradient, Dlm, R.nc, R.nl, y)) {
+          ++g_branch[6];
           mu *= mu_increase;
           continue;
         }
@@ -559,12 +568,15 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
       // ComputeTraditionalDoglegStep
       const double gradient_norm = vnorm(dl_gradient), gauss_newton_norm = vnorm(gn_step);
       if (gauss_newton_norm <= radius) {
+        ++g_branch[0];
         step = gn_step;
         dogleg_step_norm = gauss_newton_norm;
       } else if (gradient_norm * alpha >= radius) {
+        ++g_branch[1];
         for (int i = 0; i < n; ++i) step[i] = -(radius / gradient_norm) * dl_gradient[i];
         dogleg_step_norm = radius;
       } else {
+        ++g_branch[2];
         const double b_dot_a = -alpha * vdot(dl_gradient, gn_step);
         const double a_squared_norm = std::pow(alpha * gradient_norm, 2.0);
         const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + std::pow(gauss_newton_norm, 2);
@@ -584,6 +596,7 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
     }
     if (!step_is_valid) {
       // HandleInvalidStep + DoglegStrategy::StepIsInvalid
+      ++g_branch[5];
       if (++num_consecutive_invalid >= 5) { termination = 2; break; }   // max_num_consecutive_invalid_steps = 5 (Ceres default): FAILURE on the 5th
       mu *= mu_increase;
       reuse = false;
@@ -629,11 +642,15 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
       mu = std::max(min_mu, 2.0 * mu / mu_increase);
       reuse = false;
       sum->num_successful++;
+      ++g_branch[7];
+      consecutive_rejected = 0;
     } else {
       // HandleUnsuccessfulStep + StepRejected
       scatter_x(P, R, x);
       radius *= 0.5;
       reuse = true;
+      ++g_branch[3];
+      g_branch[4] = std::max(g_branch[4], ++consecutive_rejected);
     }
     sum->cost_trace[iter] = x_cost;
     sum->radius_trace[iter] = radius;

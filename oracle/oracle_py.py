@@ -261,15 +261,22 @@ def window_normal_eq(cfg, w):
     return H, g, cost.value
 
 
-def solve_window(cfg, w, opts=None):
-    """In place on w's state arrays. Returns Summary."""
+def solve_window(cfg, w, opts=None, check=True):
+    """In place on w's state arrays. Returns Summary (check=False: also when the solve ended in FAILURE)."""
     opts = opts or default_opts()
     d, s = w.desc(_THIS)
     sm = Summary()
     rc = lib().orc_solve_window(C.byref(cfg), C.byref(d), C.byref(s), C.byref(opts), C.byref(sm))
-    if rc != 0:
+    if rc != 0 and check:
         raise FloatingPointError("orc_solve_window failed rc=%d" % rc)
     return sm
+
+
+def branch_counts():
+    """Branches the last solve_window took: [gn, cauchy, interpolated, rejected, longest rejected run, invalid, mu escalations, accepted]."""
+    out = (C.c_int * 8)()
+    lib().orc_last_branch_counts(out)
+    return list(out)
 
 
 def gauge_fix(before_arrays, w):
