@@ -828,7 +828,8 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       for (int c = 0; c < ls; ++c) M.cdmap[cd + c] = pos + c;
       pos += ls;
     }
-    if (mode == 0 && pos != (d.use_leg ? 19 : 15) && M.n_drop_lm > 0) { ctx->err = "MARGIN_OLD expects pose/speed-bias/leg-bias of frame 0"; return VILO_ERR_UNSUPPORTED; }
+    // (without an IMU factor on interval (0, 1) — sum_dt > 10 s — and without a prior on them, speed-bias / leg-bias of frame 0 are in no
+    // residual block and are not marginalised: the dense dropped part is the pose alone, as in MarginalizationInfo::addResidualBlockInfo)
     pos += M.n_drop_lm;
     M.m = pos;
     std::vector<int> kept;

@@ -455,6 +455,26 @@ def test_marginalize_block_elimination_equals_the_eigen_pseudo_inverse_path(ctx,
     np.testing.assert_allclose(pf.r0[:pf.n] @ pf.r0[:pf.n], pg.r0[:pg.n] @ pg.r0[:pg.n], rtol=1e-6)
 
 
+def test_marginalize_rank_deficient_block_takes_the_eigen_path(ctx, cfg, ocfg):
+    """A genuinely rank-deficient Amm (three zero eigenvalues, see conftest.rank_deficient_window): k_marginalize_lds cannot certify
+    lambda_min(Amm) > eps, the window goes to k_marginalize (eps-thresholded eigen pseudo-inverse, marginalization_factor.cpp:281-286),
+    and the prior it leaves is the oracle's (which tests/test_oracle_vs_reference.py pins against the compiled reference on this window)."""
+    from conftest import rank_deficient_window
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w = rank_deficient_window(cfg, ocfg)
+    pg, po = PriorData(), PriorData()
+    ctx.marginalize(w, 0, pg)
+    assert api.lib().vilo_debug_marg_general_count(ctx.h) == 1
+    rc, m, _, _ = O.marginalize(ocfg, w, 0, po)
+    assert rc == 0 and m == 7 and pg.blocks() == po.blocks() and pg.n == po.n == 19
+    Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+    Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+    assert np.abs(Ag - Ao).max() < 1e-8 * np.abs(Ao).max(), np.abs(Ag - Ao).max() / np.abs(Ao).max()
+    bg, bo = Jg.T @ pg.r0[:pg.n], Jo.T @ po.r0[:po.n]
+    assert np.abs(bg - bo).max() < 1e-8 * np.abs(bo).max(), np.abs(bg - bo).max() / np.abs(bo).max()
+
+
 def test_marginalize_many_dropped_landmarks(ctx, cfg, ocfg):
     """700 landmarks, 100 of them anchored in frame 0: the landmark elimination of k_marginalize_lds walks four 32-wide tiles."""
     from cerberus_amd import api

@@ -223,3 +223,26 @@ def test_marginalization(cfg, window, mode):
     for key in br:
         np.testing.assert_allclose(bo[key], br[key], rtol=0, atol=tol * bmax, err_msg=str(key))
         np.testing.assert_allclose(xo[key], xr[key], rtol=0, atol=0)
+
+
+def test_marginalization_of_a_rank_deficient_block(cfg):
+    """marginalization_factor.cpp:281-286: Amm is inverted through its eigen-decomposition with eigenvalues below eps set to zero. Window
+    without prior, without IMU factor on interval (0, 1) and with one two-observation landmark in frame 0: Amm (7 x 7) has three zero
+    eigenvalues. Reference and oracle agree on the prior they leave (here to 1e-9: nothing is ill-conditioned once the null space is cut)."""
+    from conftest import rank_deficient_window
+    w = rank_deficient_window(synth.default_config(), cfg)
+    po, pr = synth.PriorData(), synth.PriorData()
+    rc_o, m, A, _ = O.marginalize(cfg, w, 0, po, want_A=True)
+    assert rc_o == 0 and m == 7
+    ev = np.linalg.eigvalsh(0.5 * (A[:m, :m] + A[:m, :m].T))
+    assert (np.abs(ev) < 1e-8).sum() == 3 and ev[-1] > 1e4, ev
+    assert R.marginalize(cfg, w, 0, pr) == 0
+    assert po.struct.n == pr.struct.n == 19
+    Ho, bo, xo = R.prior_information(po)
+    Hr, br, xr = R.prior_information(pr)
+    hmax = max(np.abs(v).max() for v in Hr.values())
+    bmax = max(np.abs(v).max() for v in br.values())
+    for key in Hr:
+        np.testing.assert_allclose(Ho[key], Hr[key], rtol=0, atol=1e-9 * hmax, err_msg=str(key))
+    for key in br:
+        np.testing.assert_allclose(bo[key], br[key], rtol=0, atol=1e-9 * bmax, err_msg=str(key))
