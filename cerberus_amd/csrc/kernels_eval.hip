@@ -52,36 +52,100 @@ __device__ void sqrt_info_wave(const double *cov, double *U_out, double *R /*LDS
   for (int e = lane; e < N * N; e += 64) U_out[e] = Ub[(e / N) * LD + (e % N)];
 }
 
+// The reference's route taken literally (imu_leg_factor.cpp:197-198: LLT(covariance.inverse()).matrixL().transpose()): the inverse by
+// Gauss-Jordan elimination with partial pivoting (what Eigen's inverse() does for a 31 x 31 matrix up to the elimination order), then the
+// lower Cholesky factor of it, transposed. The covariance has a condition number of 1e13 .. 1e14, so this route carries ~1e-5 of relative
+// error that the default route (sqrt_info_wave: no inverse of the covariance is formed) does not; selectable with vilo_set_sqrt_info_mode.
+template <int N>
+__device__ void sqrt_info_literal_wave(const double *cov, double *U_out, double *A /*LDS N*(N+1)*/, double *B /*LDS N*(N+1)*/, int *status) {
+  const int lane = threadIdx.x;
+  const int LD = N + 1;
+  for (int e = lane; e < N * N; e += 64) {
+    const int i = e / N, j = e % N;
+    A[i * LD + j] = cov[e];
+    B[i * LD + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < N; ++j) {
+    // pivot: the largest |A[i][j]|, i >= j (ties: the lowest row)
+    double best = (lane >= j && lane < N) ? fabs(A[lane * LD + j]) : -1.0;
+    int bi = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_down(best, off, 64);
+      const int oi = __shfl_down(bi, off, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    const int p = __shfl(bi, 0, 64);
+    if (p != j && lane < N) {
+      double t = A[j * LD + lane]; A[j * LD + lane] = A[p * LD + lane]; A[p * LD + lane] = t;
+      t = B[j * LD + lane]; B[j * LD + lane] = B[p * LD + lane]; B[p * LD + lane] = t;
+    }
+    __syncthreads();
+    const double piv = A[j * LD + j];
+    if (lane == 0 && (!(fabs(piv) > 0.0) || !isfinite(piv))) *status = 1;
+    __syncthreads();
+    if (lane < N) { A[j * LD + lane] /= piv; B[j * LD + lane] /= piv; }
+    __syncthreads();
+    if (lane < N && lane != j) {   // lane = row
+      const double f = A[lane * LD + j];
+      for (int c = 0; c < N; ++c) { A[lane * LD + c] -= f * A[j * LD + c]; B[lane * LD + c] -= f * B[j * LD + c]; }
+    }
+    __syncthreads();
+  }
+  // lower Cholesky factor of the inverse (Eigen's LLT reads the lower triangle), in place in B
+  for (int j = 0; j < N; ++j) {
+    double sacc = 0.0;
+    if (lane >= j && lane < N) {
+      sacc = B[lane * LD + j];
+      for (int k = 0; k < j; ++k) sacc -= B[lane * LD + k] * B[j * LD + k];
+    }
+    __syncthreads();
+    if (lane == j) {
+      if (!(sacc > 0.0) || !isfinite(sacc)) { *status = 1; sacc = 1.0; }
+      B[j * LD + j] = sqrt(sacc);
+    }
+    __syncthreads();
+    if (lane > j && lane < N) B[lane * LD + j] = sacc / B[j * LD + j];
+    __syncthreads();
+  }
+  for (int e = lane; e < N * N; e += 64) {
+    const int i = e / N, j = e % N;
+    U_out[e] = (j >= i) ? B[j * LD + i] : 0.0;
+  }
+}
+
 // skip (optional, [n]): records that carry no factor (interval beyond the window, sum_dt > 10 s) are left alone. per_record: the
 // "covariance not positive definite" flag goes to status[f] instead of status[0], so that a batch can fail the one window it concerns.
-__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
+__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record, int literal) {
   __shared__ double R[31 * 32], Ub[31 * 32];
   const int f = blockIdx.x;
   if (f >= n || (skip && skip[f])) return;
   const vilo_preint &p = pre[f];
   if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
-  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
+  if (literal) sqrt_info_literal_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
+  else sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
 }
 
-__global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
+__global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record, int literal) {
   __shared__ double R[15 * 16], Ub[15 * 16];
   const int f = blockIdx.x;
   if (f >= n || (skip && skip[f])) return;
   const vilo_preint_imu &p = pre[f];
   if (threadIdx.x == 0) fill_preint_head_imu(p, out[f].head);
   // 15x15 sqrt_info stored in the leading 225 doubles
-  sqrt_info_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
+  if (literal) sqrt_info_literal_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
+  else sqrt_info_wave<15>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
 }
 
 int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
-  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
+  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record, ctx->sqrt_info_mode);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }
 int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
-  hipLaunchKernelGGL(k_prepare_preint_imu, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
+  hipLaunchKernelGGL(k_prepare_preint_imu, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record, ctx->sqrt_info_mode);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

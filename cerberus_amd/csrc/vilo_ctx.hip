@@ -83,6 +83,11 @@ extern "C" double vilo_last_solve_ms(const vilo_ctx *ctx) { return ctx ? ctx->la
 
 // Profiling hooks (not part of the reference interface): per-kernel GPU time of the solve pipeline measured with
 // HIP events on the stream the kernels are launched on.
+extern "C" int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode) {
+  if (!ctx || (mode != 0 && mode != 1)) return VILO_ERR_BAD_ARG;
+  ctx->sqrt_info_mode = mode;
+  return VILO_OK;
+}
 extern "C" void vilo_set_profiling(vilo_ctx *ctx, int on) {
   if (!ctx) return;
   ctx->profile = on;

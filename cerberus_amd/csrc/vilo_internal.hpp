@@ -42,6 +42,7 @@ struct vilo_ctx {
   std::vector<int> pev_kind;        // kernel kind of interval i = [pev[2i], pev[2i+1]]
   double kernel_ms[VILO_NKERNEL];
   long long kernel_launches[VILO_NKERNEL];
+  int sqrt_info_mode = 0;           // 0: Cholesky of the index-reversed covariance + triangular inverse; 1: the reference's inverse() + LLT, literally
   bool wave_attr_set = false;       // k_solve_wave's dynamic-LDS opt-in done on this context's device
 };
 

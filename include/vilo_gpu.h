@@ -305,6 +305,11 @@ double vilo_last_marginalize_ms(const vilo_ctx *ctx);
  * elimination. The environment variable VILO_MARG_GENERAL=1 forces every window down that path. */
 int vilo_debug_marg_general_count(const vilo_ctx *ctx);
 /* Per-kernel GPU time of the solve pipeline, HIP events on ctx's stream. kinds: see vilo_kernel_name(). */
+/* How sqrt_info = LLT(covariance.inverse()).matrixL().transpose() (imu_leg_factor.cpp:197-198, imu_factor.h) is computed for the batches and
+ * factor evaluations that follow. 0 (default): Cholesky of the index-reversed covariance and a triangular inverse — the same matrix without
+ * forming the inverse of a covariance whose condition number is 1e13..1e14. 1: the reference's route literally (inverse by pivoted Gauss-Jordan
+ * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
+int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
 void vilo_set_profiling(vilo_ctx *ctx, int on);
 int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n);
 const char *vilo_kernel_name(int kind);

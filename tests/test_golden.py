@@ -143,6 +143,36 @@ def test_gpu_imu_factors_vs_reference(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_literal_sqrt_info_route_vs_reference(ctx):
+    """vilo_set_sqrt_info_mode(1): inverse() + LLT as imu_leg_factor.cpp:197-198 writes it, on the device. Both routes are compared with
+    the outputs of the compiled reference (whose inverse / LLT are the test shim's): the whitened quantities agree to 1e-5 for the literal
+    route and 1e-6 for the default one — the covariance has a condition number of 1e13 .. 1e14 and the literal route squares the damage —
+    and the two device routes agree with each other to 1e-5 (the conditioning floor of the reference's own formula)."""
+    from cerberus_amd import api
+    P = _split(G["imu_params"], [7, 9, 4, 7, 9, 4])
+    r0, J0 = ctx.eval_imu_leg(G["preint"], P)
+    assert api.lib().vilo_set_sqrt_info_mode(ctx.h, 1) == 0
+    try:
+        r1, J1 = ctx.eval_imu_leg(G["preint"], P)
+    finally:
+        assert api.lib().vilo_set_sqrt_info_mode(ctx.h, 0) == 0
+    assert api.lib().vilo_set_sqrt_info_mode(ctx.h, 7) != 0
+    worst = 0.0
+    for k in range(r0.shape[0]):
+        Jl, Jd, Jr = np.hstack([J[k] for J in J1]), np.hstack([J[k] for J in J0]), G["imuleg_J"][k]
+        assert _rel(r1[k], G["imuleg_r"][k]) < 1e-5
+        assert _rel(Jl.T @ Jl, Jr.T @ Jr) < 1e-5
+        assert _rel(Jl.T @ r1[k], Jr.T @ G["imuleg_r"][k]) < 1e-5
+        worst = max(worst, _rel(Jl.T @ Jl, Jd.T @ Jd), _rel(r1[k], r0[k]))
+    assert 0.0 < worst < 1e-5, worst   # two different routes (not the same code twice), the same matrix up to conditioning
+    # the oracle's literal route (orc_sqrt_info mode 1) on the same covariances
+    for k in range(r0.shape[0]):
+        cov = G["preint"][k, 994:].reshape(31, 31)
+        U0, U1 = O.sqrt_info(cov, 0), O.sqrt_info(cov, 1)
+        assert _rel(U1.T @ U1, U0.T @ U0) < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_gpu_projection_vs_reference(ctx, kind):
     P = _split(G["proj%d_params" % kind], PROJ_SIZES[kind])
