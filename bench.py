@@ -211,6 +211,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # which windows each rank solved (first / last seed and a checksum of its first window's observations): shows the shards are disjoint
+        mine = torch.tensor([float(20260925 + ids[0]), float(20260925 + ids[-1]), float(windows[0].obs.sum())], dtype=torch.float64, device=t.device)
+        shards = [torch.zeros(3, dtype=torch.float64, device=t.device) for _ in range(world)]
+        dist.all_gather(shards, mine)
+        shard_info = [[int(x[0].item()), int(x[1].item()), float(x[2].item())] for x in shards]
+    else:
+        shard_info = [[20260925 + ids[0], 20260925 + ids[-1], float(windows[0].obs.sum())]]
 
     # per-kernel GPU time over the timed region (HIP events on the solver's stream)
     ms = (C.c_double * 16)()
@@ -246,7 +253,8 @@ def main():
                                    "%d independent windows per GPU; one step = state reset + sqrt_info of the %d preintegration records + "
                                    "%d fixed dogleg iterations" % (args.landmarks, args.rate, W, 10 * W, ITERS),
                        "windows_per_gpu": W, "total_windows": W * world, "iterations_per_step": ITERS, "observations_per_window": sum_k,
-                       "parallelism": "independent windows sharded over ranks, no collective"},
+                       "parallelism": "independent windows sharded over ranks, no collective",
+                       "shards": shard_info},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
                          "traffic_source": "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated on a 1 GiB copy; per-window figure scaled to this batch)" if traffic else None,

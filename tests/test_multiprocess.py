@@ -44,3 +44,37 @@ def test_two_rank_gloo_sharding(tmp_path):
     res = json.loads(line)
     assert res["max_time"] == 2.0          # max over ranks
     assert res["distinct"] == res["n"] == 6  # every rank solved different windows
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_py_itself_on_two_ranks_of_one_gpu():
+    """The real bench.py under torch.distributed.run with two ranks sharing the one GPU of the test box (VILO_BENCH_BACKEND=gloo,
+    local_rank % device_count): the N > 1 code path of the script the driver launches — rank-disjoint windows, barrier + max-over-ranks
+    timing, whole-job value."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", VILO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "64",
+                          "--no-cpu-baseline", "--no-single-window"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    W, it = d["config"]["windows_per_gpu"], d["config"]["iterations_per_step"]
+    assert W == 64 and d["config"]["total_windows"] == 128
+    assert abs(d["value"] - 2 * W * it / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    sh = d["config"]["shards"]
+    assert len(sh) == 2 and sh[0][1] < sh[1][0] and sh[0][2] != sh[1][2]   # disjoint seed ranges, different data
+    # BASELINE configs[3] mode: a fixed total, window w on rank w mod 2
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-windows", "64",
+                          "--no-cpu-baseline", "--no-single-window"], capture_output=True, text=True, timeout=900,
+                         env=dict(env, MASTER_PORT="29534"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["windows_per_gpu"] == 32 and d["config"]["total_windows"] == 64
+    assert abs(d["value"] - 64 * it / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    sh = d["config"]["shards"]
+    assert sh[0][0] + 1 == sh[1][0]   # interleaved: w mod 2
