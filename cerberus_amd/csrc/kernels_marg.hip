@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += V2[(size_t)j * n + i] * br[j];
     r0[i] = (S > eps) ? sqrt(1.0 / S) * s : 0.0;
-    if (!isfinite(r0[i])) *status = 1;
+    if (!isfinite(r0[i])) status[win] = 1;
   }
 }
 
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
     double sacc = 0.0;
     for (int j = 0; j < n; ++j) sacc += V2[j * MG_LD + i] * br[j];
     r0[i] = (S > eps) ? sqrt(1.0 / S) * sacc : 0.0;
-    if (!isfinite(r0[i])) *status = 1;
+    if (!isfinite(r0[i])) status[win] = 1;
   }
   stamp(6);
 }
@@ -854,22 +854,21 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   auto fail = [&](int code) { return code; };
   if (d_mw.alloc(sizeof(MargWin) * W) != hipSuccess || d_drop.alloc(sizeof(int) * drop_flat.size()) != hipSuccess ||
       d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
-      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int)) != hipSuccess ||
+      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int) * W) != hipSuccess ||
       d_general.alloc(sizeof(int) * W) != hipSuccess)
     return fail(VILO_ERR_HIP);
   if (hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_drop.p, drop_flat.data(), sizeof(int) * drop_flat.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(d_status.p, 0, sizeof(int)) != hipSuccess || hipMemset(d_general.p, 0, sizeof(int) * W) != hipSuccess)
+      hipMemset(d_status.p, 0, sizeof(int) * W) != hipSuccess || hipMemset(d_general.p, 0, sizeof(int) * W) != hipSuccess)
     return fail(VILO_ERR_HIP);
   // preMarginalize: evaluate the factors at the current state (marginalization_factor.cpp:119-138)
   (void)hipEventRecord(ctx->ev0, ctx->stream);
   rc = vilo_marg_linearize(ctx, bd);
   if (rc != VILO_OK) return fail(rc);
-  static bool attr_set = false;
   const size_t lds_bytes = (size_t)MG_LDS_DOUBLES * sizeof(double);
-  if (!attr_set) {
+  if (!ctx->marg_attr_set) {   // (per context = per device and host thread)
     if (hipFuncSetAttribute((const void *)k_marginalize_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return fail(VILO_ERR_HIP);
-    attr_set = true;
+    ctx->marg_attr_set = true;
   }
   const bool force_general = getenv("VILO_MARG_GENERAL") != nullptr;   // test hook: every window through the global-memory eigen path
   std::vector<int> general(W, force_general ? 1 : 0);
@@ -935,14 +934,15 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return VILO_ERR_HIP;
   }
   std::vector<double> J0, r0((size_t)W * VILO_MAX_PRIOR_DIM);
-  int status = 0;
+  std::vector<int> status(W, 0);
+  int any_bad = 0;
   if (any_host) {
     J0.resize((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM);
     if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(VILO_ERR_HIP);
   }
-  if (hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  if (hipMemcpy(status.data(), d_status.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
     if (skip[w]) continue;
@@ -964,6 +964,8 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       continue;
     }
     if (M.m == 0 || M.n == 0) { p.valid = 0; p.n = 0; continue; }
+    // a non-finite result concerns this window alone: it goes on without a prior, the others keep theirs (the call still reports it)
+    if (status[w]) { p.valid = 0; p.n = 0; any_bad = 1; continue; }
     const int WS = in[w].n_frames - 1;
     p.n = M.n; p.n_blocks = (int)kept_ids[w].size(); p.valid = 1;
     int xo = 0;
@@ -987,7 +989,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       p.r0[i] = r0[(size_t)w * VILO_MAX_PRIOR_DIM + i];
     }
   }
-  if (status) { ctx->err = "non-finite marginalisation result"; return VILO_ERR_NUMERIC; }
+  if (any_bad) { ctx->err = "non-finite marginalisation result (the windows concerned continue without a prior)"; return VILO_ERR_NUMERIC; }
   return VILO_OK;
 }
 

@@ -344,7 +344,14 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
         int soff = 0;
         const int cd = prior_block_cd(p.block_id[k], &soff);
         const int gs = p.block_size[k], ls = gs == 7 ? 6 : gs;
+        static const int kind_size[5] = {7, 9, 4, 7, 1};   // global sizes of VILO_BLK_POSE / SB / LB / EX / TD
+        const int kind = p.block_id[k] / 16;
+        if (p.block_id[k] < 0 || kind < 0 || kind > 4 || gs != kind_size[kind] || xo + gs > 280) { win_err[w] = 1; return; }
         if (cd < 0 || p.block_idx[k] < 0 || p.block_idx[k] + ls > n) { win_err[w] = 1; return; }
+        for (int q = 0; q < k; ++q) {   // local index ranges must not overlap
+          const int lq = p.block_size[q] == 7 ? 6 : p.block_size[q];
+          if (p.block_idx[k] < p.block_idx[q] + lq && p.block_idx[q] < p.block_idx[k] + ls) { win_err[w] = 1; return; }
+        }
         if (cd >= CD_B0) {
           const int fr = (cd - CD_B0) / 13;
           if (bframe >= 0 && bframe != fr) { win_err[w] = 2; return; }
@@ -483,11 +490,10 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       hipLaunchKernelGGL(k_prior_gather, dim3(W), dim3(256), 0, ctx->stream, W, D.win, d_slot, refs[0].prior_pool->dJ, refs[0].prior_pool->dr, d_J, d_r);
     }
     {
-      static bool pp_attr = false;
       const size_t pp_lds = sizeof(double) * (96 * 96 + 96);
-      if (!pp_attr) {
+      if (!ctx->prior_attr_set) {
         if (hipFuncSetAttribute((const void *)k_prior_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
-        pp_attr = true;
+        ctx->prior_attr_set = true;
       }
       hipLaunchKernelGGL(k_prior_pack, dim3(W), dim3(256), pp_lds, ctx->stream, W, D.win, d_J, d_r, D.prior_map, D.prior_H, D.prior_b0, D.prior_c0, D.prior_dense);
     }

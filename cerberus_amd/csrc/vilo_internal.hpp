@@ -43,7 +43,7 @@ struct vilo_ctx {
   double kernel_ms[VILO_NKERNEL];
   long long kernel_launches[VILO_NKERNEL];
   int sqrt_info_mode = 0;           // 0: Cholesky of the index-reversed covariance + triangular inverse; 1: the reference's inverse() + LLT, literally
-  bool wave_attr_set = false;       // k_solve_wave's dynamic-LDS opt-in done on this context's device
+  bool wave_attr_set = false, marg_attr_set = false, prior_attr_set = false;   // dynamic-LDS opt-ins done on this context's device       // k_solve_wave's dynamic-LDS opt-in done on this context's device
 };
 
 // grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified)

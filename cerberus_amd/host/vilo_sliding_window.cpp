@@ -320,7 +320,9 @@ int SlidingWindow::processImage(double header, int n, const int *ids, const doub
     SlidingWindow *self = this;
     rc = optimizeBatch(ctx_, &self, 1);
   }
-  if (rc == VILO_OK) endImage();
+  // VILO_ERR_NUMERIC is a per-window condition (a failed solve leaves the states alone, a non-finite marginalisation drops the prior): the
+  // window still slides, so that it stays usable; the code is passed on to the caller
+  if (rc == VILO_OK || rc == VILO_ERR_NUMERIC) endImage();
   return rc;
 }
 
@@ -378,6 +380,7 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   auto same_kind = [](const SlidingWindow &a, const SlidingWindow &b) {
     return a.resident_ == b.resident_ && a.pool_ == b.pool_ && a.ppool_ == b.ppool_ && a.opt_.streaming_preintegration == b.opt_.streaming_preintegration;
   };
+  int soft_rc = VILO_OK;
   for (int w = 1; w < n; ++w)
     if (!same_kind(*ws[w], *ws[0])) {
       std::vector<SlidingWindow *> rest(ws, ws + n), grp;
@@ -386,10 +389,11 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
         std::vector<SlidingWindow *> other;
         for (SlidingWindow *x : rest) (same_kind(*x, *rest[0]) ? grp : other).push_back(x);
         const int rc = optimizeBatch(ctx, grp.data(), (int)grp.size());
-        if (rc != VILO_OK) return rc;
+        if (rc != VILO_OK && rc != VILO_ERR_NUMERIC) return rc;
+        if (rc == VILO_ERR_NUMERIC) soft_rc = rc;
         rest.swap(other);
       }
-      return VILO_OK;
+      return soft_rc;
     }
   const bool resident = ws[0]->resident_;
   if (streaming) {
@@ -514,7 +518,9 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   }
   int rc = resident ? vilo_optimize_windows_resident(ctx, n, descs.data(), refs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), nullptr, sums.data())
                     : vilo_optimize_windows(ctx, n, descs.data(), states.data(), &ws[0]->opt_.solve, flags.data(), next.data(), sums.data());
-  if (rc != VILO_OK) return rc;
+  // VILO_ERR_NUMERIC: some window's solve failed (its states are untouched) or its marginalisation was not finite (its prior is invalid);
+  // every window's outputs are filled in, so the bookkeeping below runs for the whole fleet and the code is returned at the end
+  if (rc != VILO_OK && rc != VILO_ERR_NUMERIC) return rc;
   const double t3 = now_ms();
   std::vector<int> dump_rc(n, 0);
   parallel_for(n, [&](int w) {
@@ -534,7 +540,7 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
   if (timing)
     fprintf(stderr, "[optimizeBatch] n=%d preintegrate %.2f ms, vector2double+tables %.2f ms, vilo_optimize_windows %.2f ms, double2vector %.2f ms\n", n, t1 - t0,
             t2 - t1, t3 - t2, now_ms() - t3);
-  return VILO_OK;
+  return rc;
 }
 
 void SlidingWindow::outliersRejection(std::vector<int> *remove_ids) const {
@@ -668,12 +674,12 @@ int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int W, const double *
     if (is_due[w]) due.push_back((SlidingWindow *)hs[w]);
   const double t1 = vilo::now_ms_public();
   const int rc = SlidingWindow::optimizeBatch(ctx, due.data(), (int)due.size());
-  if (rc != VILO_OK) return rc;
+  if (rc != VILO_OK && rc != VILO_ERR_NUMERIC) return rc;
   const double t2 = vilo::now_ms_public();
   vilo::parallel_for_public(W, [&](int w) { ((SlidingWindow *)hs[w])->endImage(); });
   if (getenv("VILO_HOST_TIMING"))
     fprintf(stderr, "[vilo_sw_process_images] W=%d beginImage %.2f ms, optimizeBatch %.2f ms, endImage %.2f ms\n", W, t1 - t0, t2 - t1, vilo::now_ms_public() - t2);
-  return VILO_OK;
+  return rc;
 }
 void vilo_sw_get_state(void *h, int *flags, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, double *Rho, double *tic, double *ric,
                        double *td) {
