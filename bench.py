@@ -79,6 +79,34 @@ def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
             "sample": "%d synthetic config-2 windows x %d iterations, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s" % (n_win, ITERS, t_total)}
 
 
+def marginalize_timing(ctx, cfg, windows, n_cpu=8):
+    """The marginalisation half of Estimator::optimization() (estimator.cpp:1247-1455; once per frame, outside the iteration metric):
+    GPU kernel time of vilo_marginalize over a batch (linearisation + MARGIN_OLD marginalisation, HIP events) beside the oracle's
+    marginalize on the same windows. The reference builds the Hessian on 4 pthreads (marginalization_factor.cpp:246-275) and
+    eigen-decomposes on one; the oracle is single-threaded throughout, which the `cores` field says."""
+    import ctypes as C
+    from cerberus_amd import api, synth, _ctypes as T
+    from oracle import oracle_py as O
+    W = len(windows)
+    descs = (T.WindowDesc * W)(); states = (T.WindowState * W)(); priors = (T.Prior * W)()
+    outs = [synth.PriorData() for _ in range(W)]
+    for i, w in enumerate(windows):
+        descs[i], states[i] = w.desc(T)
+        priors[i] = outs[i].struct
+    L = api.lib()
+    L.vilo_last_marginalize_ms.restype = C.c_double
+    for _ in range(2):
+        rc = L.vilo_marginalize(ctx.h, W, descs, states, 0, priors)
+    gpu_ms = L.vilo_last_marginalize_ms(ctx.h)
+    ocfg = O.config_from(cfg)
+    t0 = time.perf_counter()
+    for w in windows[:n_cpu]:
+        O.marginalize(ocfg, w, 0, synth.PriorData())
+    cpu_ms = 1e3 * (time.perf_counter() - t0) / n_cpu
+    return {"mode": "MARGIN_OLD", "gpu_ms_per_window": gpu_ms / W, "gpu_batch": W, "gpu_ms_batch": gpu_ms, "cpu_ms_per_window": cpu_ms, "cpu_cores": 1,
+            "cpu_sample": "%d windows, oracle/liboracle.so, 1 thread" % n_cpu, "rc": int(rc)}
+
+
 def _all_cores_child(k, n_landmarks, t_end, q):
     from cerberus_amd import synth
     from oracle import oracle_py as O
@@ -311,6 +339,10 @@ def main():
             except Exception as e:
                 out["two_streams"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
+            try:
+                out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256])
+            except Exception as e:
+                out["marginalize"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks)
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks)

@@ -80,7 +80,7 @@ class SolveOpts(C.Structure):
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("jacobi_scaling", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("max_solver_time_us", C.c_int32)]
 
 
 class SolveSummary(C.Structure):

@@ -653,7 +653,7 @@ int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b) {
 // =================================================================================================
 struct AcceptParams {
   double min_relative_decrease, function_tolerance, parameter_tolerance;
-  int max_num_iterations, fixed_iterations, init_mode, pad;
+  int max_num_iterations, fixed_iterations, init_mode, max_solver_time_us;
 };
 
 __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
@@ -676,6 +676,7 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
       st.iter++;
       if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
       if (st.iter >= ap.max_num_iterations && !st.done) { st.done = 1; st.termination = 0; }
+      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
     }
     return;
   }
@@ -760,6 +761,8 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
     st.iter++;
     if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
     if (st.iter >= ap.max_num_iterations) { st.done = 1; st.termination = 0; }
+    // max_solver_time_in_seconds: "Maximum solver time reached" before the next iteration starts (TrustRegionMinimizer's iteration check)
+    if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
   }
   __syncthreads();
   if (accept_s) {
@@ -777,6 +780,7 @@ __global__ void k_init_state(BatchDev b, double radius0, int fail_bad) {
   s.radius = radius0;
   s.mu = 1e-8;
   s.need_lin = 1;
+  s.t_start = wall_clock64();
   if (fail_bad && b.win_bad && b.win_bad[w]) { s.done = 1; s.termination = 2; }
 }
 
@@ -795,7 +799,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   AcceptParams ap;
   ap.min_relative_decrease = o->min_relative_decrease; ap.function_tolerance = o->function_tolerance;
   ap.parameter_tolerance = o->parameter_tolerance; ap.max_num_iterations = o->max_num_iterations;
-  ap.fixed_iterations = o->fixed_iterations; ap.init_mode = 1; ap.pad = 0;
+  ap.fixed_iterations = o->fixed_iterations; ap.init_mode = 1; ap.max_solver_time_us = o->max_solver_time_us;
   const int W = b.W;
   int pidx = 0;
   ctx->pev_kind.clear();

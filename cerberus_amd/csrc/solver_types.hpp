@@ -104,7 +104,8 @@ struct SolverState {
   int pad[2];
   double cost_trace[64];
   double radius_trace[64];
-  long long phase_clk[48];   // shader-clock stamps (last linearisation), profiling aid: 0..9 and 16..23 k_solve_wave, 28..32 k_visual_linearize (first packed wave), 33..35 k_imu_linearize (factor 0)
+  long long t_start;         // constant-rate device clock (100 MHz) when the solve began: max_solver_time budget
+  long long phase_clk[47];   // shader-clock stamps (last linearisation), profiling aid: 0..9 and 16..23 k_solve_wave, 28..32 k_visual_linearize (first packed wave), 33..35 k_imu_linearize (factor 0)
 };
 
 struct BatchDev {

@@ -701,7 +701,7 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
     case 8: src = bt->d.lm_y + wm.lm_off; n = wm.L; break;
     case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
     case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
-    case 12: src = (const double *)(bt->d.st + win) + 24 + 128; n = 48; break;   // phase_clk (int64 bit patterns)
+    case 12: src = (const double *)(bt->d.st + win) + 24 + 128 + 1; n = 47; break;   // phase_clk (int64 bit patterns)
     case 11: {
       n = wm.L;
       if ((int)n > max_n) return VILO_ERR_BAD_ARG;

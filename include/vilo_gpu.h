@@ -148,7 +148,9 @@ typedef struct {
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   double min_lm_diagonal, max_lm_diagonal;
   int32_t jacobi_scaling;
-  int32_t reserved;
+  int32_t max_solver_time_us;  /* Solver::Options::max_solver_time_in_seconds (estimator.cpp:1226-1233: SOLVER_TIME = 0.1 s, x 0.8 on MARGIN_OLD) as a
+                                * device-clock budget in microseconds, checked per window where Ceres checks it (before an iteration starts);
+                                * when spent the window ends with termination NO_CONVERGENCE. 0 (default): no budget — a solve takes ~3 ms */
 } vilo_solve_opts;
 void vilo_default_solve_opts(vilo_solve_opts *o);
 

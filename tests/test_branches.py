@@ -122,3 +122,19 @@ def test_invalid_steps_end_in_failure_on_the_fifth(ctx, cfg, ocfg):
     for a, bb, cc in zip(w_g.state_arrays(), w0.state_arrays(), w_o.state_arrays()):
         np.testing.assert_array_equal(a, bb)
         np.testing.assert_array_equal(cc, bb)
+
+
+def test_max_solver_time_budget(ctx, cfg, ocfg):
+    """Solver::Options::max_solver_time_in_seconds (estimator.cpp:1226-1233) as a device-clock budget: with a budget far below one iteration
+    the solve stops after the first iteration it completes, termination NO_CONVERGENCE, the accepted states kept; without a budget
+    (the default) all iterations run."""
+    from cerberus_amd import api
+    w = _window(cfg, ocfg, seed=11)
+    o = api.default_solve_opts(True, 12)
+    assert o.max_solver_time_us == 0
+    o.max_solver_time_us = 1
+    s1 = ctx.solve_windows([w], o)[0]
+    assert 1 <= s1.iterations < 12 and s1.termination == 0 and s1.final_cost < s1.initial_cost
+    w2 = _window(cfg, ocfg, seed=11)
+    s2 = ctx.solve_windows([w2], api.default_solve_opts(True, 12))[0]
+    assert s2.iterations == 12 and s2.final_cost <= s1.final_cost
