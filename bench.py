@@ -10,6 +10,9 @@ time. Inputs are resident in HBM before the timed region (batch created + preint
 
 Workload = BASELINE.json configs[1]: synthetic 10-KF x 200-landmark window, A1 4-leg contact preintegration,
 500 Hz IMU/leg samples; `--windows` independent instances per GPU (config 4 batches 1024 over 8 GPUs).
+`--config 3` = BASELINE.json configs[2]: 1000 landmarks (NUM_OF_F, parameters.h:24), 400 Hz samples (27 per interval), and every
+iteration integrates all 10 intervals of every window again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
+at the biases of the point it linearises, sqrt_info of the new covariances included.
 """
 import argparse
 import ctypes as C
@@ -31,21 +34,25 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
 
 ALG_FLOPS_PER_WINDOW_ITERATION = {200: 13.7e6, 1000: 47.0e6}   # FP64 flops of one window-iteration (FMA = 2)
 ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")   # launched once per iteration
+REPROPAGATION_KERNELS = ("k_repropagate", "k_prepare_preint")   # config 3: once per iteration as well
+# K1 re-propagation adds the raw samples (280 B each) to the compulsory traffic and ~15 Mflop (sparse-aware; 75 Mflop as
+# dense 31 x 31 products) to the flops of one window-iteration
+REPROPAGATION_FLOPS = 15.0e6
 
 
-def profile_evidence(W_run):
+def profile_evidence(W_run, tag=""):
     """Counter evidence of the committed rocprofv3 passes (tools/profile_gpu.sh, tools/profile_sq.sh; measured at 4096 windows per
     dispatch): calibrated HBM bytes per dispatch and the matrix-core busy fraction per kernel. Per-window figures, so they scale."""
     out = {"pmc": None, "mfma": None}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc%s.json" % tag)))
         Wp = pmc.get("windows_per_dispatch", 4096)
         out["pmc"] = {k: v * W_run / Wp for k, v in pmc["hbm_bytes_per_dispatch"].items()}
         out["pmc_kernel_us"] = {k: v["avg_us"] for k, v in pmc["kernel_trace"].items()}
     except Exception:
         pass
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "round2_mfma.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "round2_mfma%s.json" % tag)))
         util = {}
         for k, c in sq["kernels"].items():
             us = (out.get("pmc_kernel_us") or {}).get(k)
@@ -58,25 +65,33 @@ def profile_evidence(W_run):
     return out
 
 
-def cpu_baseline(cfg, n_landmarks, budget_s=15.0):
-    """The oracle (CPU restatement of the reference path, scalar FP64, 1 thread) on windows of the same workload."""
-    import numpy as np  # noqa: F401
+def make_synth_window(cfg, n_landmarks, rate, seed):
     from cerberus_amd import synth
+    prm = synth.default_params(n_landmarks=n_landmarks, seed=seed)
+    prm.imu_rate_hz = float(rate)
+    return synth.make_window(cfg, params=prm)
+
+
+def cpu_baseline(cfg, n_landmarks, budget_s=15.0, rate=500, repropagate=False):
+    """The oracle (CPU restatement of the reference path, scalar FP64, 1 thread) on windows of the same workload."""
+    import contextlib
     from oracle import oracle_py as O
     ocfg = O.config_from(cfg)
     opts = O.default_opts(fixed_iterations=True, max_num_iterations=ITERS)
     opts.recompute_sqrt_info = 1
     t_total, n_it, n_win = 0.0, 0, 0
     while t_total < budget_s and n_win < 256:
-        w = synth.make_window(cfg, n_landmarks=n_landmarks, seed=777000 + n_win)
+        w = make_synth_window(cfg, n_landmarks, rate, 777000 + n_win)
         O.fill_preint(ocfg, w)
-        t0 = time.perf_counter()
-        sm = O.solve_window(ocfg, w, opts)
-        t_total += time.perf_counter() - t0
+        with (O.repropagation(w) if repropagate else contextlib.nullcontext()):
+            t0 = time.perf_counter()
+            sm = O.solve_window(ocfg, w, opts)
+            t_total += time.perf_counter() - t0
         n_it += sm.iterations
         n_win += 1
     return {"value": n_it / t_total, "unit": "GN iters/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic config-2 windows x %d iterations, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s" % (n_win, ITERS, t_total)}
+            "sample": "%d synthetic %d-landmark %d Hz windows x %d iterations%s, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s"
+                      % (n_win, n_landmarks, rate, ITERS, ", every factor evaluation integrating its interval again" if repropagate else "", t_total)}
 
 
 def marginalize_timing(ctx, cfg, windows, n_cpu=8):
@@ -100,6 +115,7 @@ def marginalize_timing(ctx, cfg, windows, n_cpu=8):
     gpu_ms = L.vilo_last_marginalize_ms(ctx.h)
     ocfg = O.config_from(cfg)
     t0 = time.perf_counter()
+    n_cpu = min(n_cpu, W)
     for w in windows[:n_cpu]:
         O.marginalize(ocfg, w, 0, synth.PriorData())
     cpu_ms = 1e3 * (time.perf_counter() - t0) / n_cpu
@@ -165,14 +181,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=4096, help="independent windows per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="2: BASELINE configs[1] (200 landmarks, 500 Hz; the headline metric); "
+                    "3: BASELINE configs[2] (1000 landmarks, 400 Hz, K1 re-propagation inside every iteration)")
+    ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 4096; 1024 with --config 3)")
     ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
-    ap.add_argument("--landmarks", type=int, default=200)
-    ap.add_argument("--rate", type=int, default=500, help="IMU / leg sample rate of the synthetic windows (Hz)")
+    ap.add_argument("--landmarks", type=int, default=0, help="default 200 (1000 with --config 3)")
+    ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
     args = ap.parse_args()
+    rp = args.config == 3
+    args.landmarks = args.landmarks or (1000 if rp else 200)
+    args.rate = args.rate or (400 if rp else 500)
+    args.windows = args.windows or (1024 if rp else 4096)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,15 +224,17 @@ def main():
         W = args.windows
         ids = [rank * W + i for i in range(W)]
         scaling = "weak"
-        workload = "BASELINE configs[1]" if args.landmarks == 200 else "BASELINE configs[2]-sized"
+        workload = "BASELINE configs[2]" if rp else "BASELINE configs[1]" if args.landmarks == 200 else "BASELINE configs[2]-sized"
     t0 = time.perf_counter()
-    def mk(seed):
-        prm = synth.default_params(n_landmarks=args.landmarks, seed=seed)
-        prm.imu_rate_hz = float(args.rate)
-        return synth.make_window(cfg, params=prm)
-    windows = [mk(20260925 + g) for g in ids]
+    windows = [make_synth_window(cfg, args.landmarks, args.rate, 20260925 + g) for g in ids]
     ctx.preintegrate_windows(windows)   # K1 on the GPU: contact preintegration of all 10 * W intervals
-    batch = api.Batch(ctx, windows)
+
+    def make_batch(c, ws):
+        b = api.Batch(c, ws)
+        if rp:
+            b.set_samples()   # samples resident: every iteration integrates the intervals again at the point it linearises
+        return b
+    batch = make_batch(ctx, windows)
     setup_s = time.perf_counter() - t0
     opts = api.default_solve_opts(fixed_iterations=True, max_num_iterations=ITERS)
     lib = api.lib()
@@ -230,8 +254,9 @@ def main():
     gpu_ms = 0.0
     for _ in range(args.steps):
         batch.reset()
-        batch.prepare()               # sqrt_info of the preintegration records: the reference pays it in every IMULegFactor::Evaluate
-        gpu_ms += batch.solve(opts)   # returns after the stream has drained (HIP event)
+        if not rp:
+            batch.prepare()           # sqrt_info of the preintegration records: the reference pays it in every IMULegFactor::Evaluate
+        gpu_ms += batch.solve(opts)   # returns after the stream has drained (HIP event); config 3: re-propagation + sqrt_info inside, per iteration
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -263,31 +288,39 @@ def main():
         unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
         value = unit_work / elapsed
         sum_k = int(windows[0].n_obs)
-        b_alg = algorithmic_bytes(sum_k, args.landmarks)
+        n_samples = int(windows[0].sample_offsets[-1])
+        b_alg = algorithmic_bytes(sum_k, args.landmarks) + (280 * n_samples if rp else 0)
         dom = max((k for k in kern if kern[k]["launches"] > 0), key=lambda k: kern[k]["ms_total"])
         dom_avg_s = kern[dom]["avg_ms"] * 1e-3
         achieved = b_alg * W / dom_avg_s / 1e9             # one launch of the dominant kernel covers W window-iterations
         iter_ms = sum(v["ms_total"] for v in kern.values()) / (args.steps * ITERS)
-        ev = profile_evidence(W) if args.landmarks == 200 else {"pmc": None, "mfma": None}
+        ev = profile_evidence(W, "_config3" if rp else "") if (rp or args.landmarks == 200) else {"pmc": None, "mfma": None}
         traffic = ev["pmc"].get(dom) if ev["pmc"] else None
-        it_traffic = sum(ev["pmc"].get(k, 0.0) for k in ITERATION_KERNELS) if ev["pmc"] else None
+        it_kernels = ITERATION_KERNELS + (REPROPAGATION_KERNELS if rp else ())
+        it_traffic = sum(ev["pmc"].get(k, 0.0) for k in it_kernels) if ev["pmc"] else None
         alg_flops = ALG_FLOPS_PER_WINDOW_ITERATION.get(args.landmarks)
+        if alg_flops and rp:
+            alg_flops += REPROPAGATION_FLOPS
+        tag = "_config3" if rp else ""
         out = {
-            "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput",
+            "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput" if not rp else
+                      "GN iters/sec, 10-KF x 1000-landmark VILO window + 400 Hz IMU preintegration re-propagated every iteration (BASELINE configs[2])",
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (%d Hz), "
-                                   "%d independent windows per GPU; one step = state reset + sqrt_info of the %d preintegration records + "
-                                   "%d fixed dogleg iterations" % (args.landmarks, args.rate, W, 10 * W, ITERS),
+                                   "%d independent windows per GPU; one step = state reset + %s + %d fixed dogleg iterations%s"
+                                   % (args.landmarks, args.rate, W, "nothing else" if rp else "sqrt_info of the %d preintegration records" % (10 * W), ITERS,
+                                      ", each integrating all %d intervals (%d samples per window) again at the point it linearises and "
+                                      "recomputing their sqrt_info" % (10 * W, n_samples) if rp else ""),
                        "windows_per_gpu": W, "total_windows": W * world, "iterations_per_step": ITERS, "observations_per_window": sum_k,
                        "parallelism": "independent windows sharded over ranks, no collective",
                        "shards": shard_info},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
-                         "traffic_source": "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated on a 1 GiB copy; per-window figure scaled to this batch)" if traffic else None,
+                         "traffic_source": "profiles/round2_pmc%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated on a 1 GiB copy; per-window figure scaled to this batch)" % tag if traffic else None,
                          "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
-                         "rocprof_summary": "profiles/round2_rocprof_summary.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)",
+                         "rocprof_summary": "profiles/round2_rocprof_summary%s.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)" % tag,
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration": {"gbps": b_alg * W / (iter_ms * 1e-3) / 1e9, "frac": b_alg * W / (iter_ms * 1e-3) / 1e9 / 8000.0,
                                              "traffic_bytes_per_window_iteration": it_traffic / W if it_traffic else None,
@@ -298,12 +331,12 @@ def main():
                                   "whole_iteration_tflops": alg_flops * W / (iter_ms * 1e-3) / 1e12 if alg_flops else None,
                                   "whole_iteration_frac": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 78.6 if alg_flops else None,
                                   "mfma_util": ev["mfma"],
-                                  "mfma_util_source": "profiles/round2_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" if ev["mfma"] else None}},
+                                  "mfma_util_source": "profiles/round2_mfma%s.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" % tag if ev["mfma"] else None}},
             "kernels": kern,
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
         if (args.single_window_latency or world == 1) and not args.no_single_window:   # absolute rate of ONE window on one GPU
-            b1 = api.Batch(ctx, windows[:1])
+            b1 = make_batch(ctx, windows[:1])
             lib.vilo_set_profiling(ctx.h, 0)
             for _ in range(3):
                 b1.reset(); b1.solve(opts)
@@ -320,9 +353,9 @@ def main():
                 import threading
                 lib.vilo_set_profiling(ctx.h, 0)
                 ctx2 = api.Context(cfg, device=local_rank)
-                windows2 = [synth.make_window(cfg, n_landmarks=args.landmarks, seed=30260925 + i) for i in range(W)]
+                windows2 = [make_synth_window(cfg, args.landmarks, args.rate, 30260925 + i) for i in range(W)]
                 ctx2.preintegrate_windows(windows2)
-                batch2 = api.Batch(ctx2, windows2)
+                batch2 = make_batch(ctx2, windows2)
 
                 def run(b, n):
                     for _ in range(n):
@@ -340,12 +373,12 @@ def main():
                 out["two_streams"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256])
+                out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256], n_cpu=2 if rp else 8)
             except Exception as e:
                 out["marginalize"] = {"error": repr(e)}
-            out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks, rate=args.rate, repropagate=rp)
             try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks) if not rp else None
             except Exception as e:   # the single-thread number above is the contract; this one is extra information
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
         else:

@@ -72,6 +72,37 @@ class Batch:
         """sqrt_info of every preintegration record again (what the reference does per IMULegFactor::Evaluate), asynchronous."""
         self.ctx._check(lib().vilo_batch_prepare(self.ctx.h, self.handle))
 
+    def set_samples(self, on=True):
+        """BASELINE configs[2]: keep the windows' samples in HBM and integrate every interval again (repropagate) at the biases of
+        every point the solver linearises; on=False goes back to records integrated once."""
+        if not on:
+            self.ctx._check(lib().vilo_batch_set_samples(self.ctx.h, self.handle, None, None))
+            return
+        parts, offs, base = [], [0], 0
+        for w in self.windows:
+            n = int(w.sample_offsets[-1])
+            parts.append(w.samples[:n])
+            offs.extend((w.sample_offsets[1:] + base).tolist())
+            offs.extend([base + n] * (10 - (len(w.sample_offsets) - 1)))
+            base += n
+        samples = np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
+        offsets = np.ascontiguousarray(offs, dtype=np.int32)
+        self.ctx._check(lib().vilo_batch_set_samples(self.ctx.h, self.handle, C.cast(samples.ctypes.data, C.POINTER(T.Sample)), T.iptr(offsets)))
+
+    def marginalize(self, modes, priors_out):
+        """vilo_batch_marginalize at the batch's device state (call download() first: the windows' arrays are the host copy of it).
+        priors_out: one synth.PriorData per window."""
+        n = len(self.windows)
+        m = (C.c_int * n)(*modes)
+        outs = (T.Prior * n)()
+        for i, p in enumerate(priors_out):
+            p.rebind()
+            outs[i] = p.struct
+        self.ctx._check(lib().vilo_batch_marginalize(self.ctx.h, self.handle, n, self._descs, self._states, m, outs))
+        for i, p in enumerate(priors_out):
+            C.memmove(C.byref(p.struct), C.byref(outs[i]), C.sizeof(T.Prior))
+            p.rebind()
+
     def solve(self, opts):
         self.ctx._check(lib().vilo_batch_solve(self.ctx.h, self.handle, C.byref(opts)))
         return lib().vilo_last_solve_ms(self.ctx.h)

@@ -1006,6 +1006,17 @@ extern "C" int vilo_marginalize(vilo_ctx *ctx, int W, const vilo_window_desc *in
   return rc;
 }
 
+// The marginalisation half on a batch that is already resident (after vilo_batch_solve + vilo_batch_download): linearised at the batch's
+// device state; `state` is the host copy of it (keep_block_data of the new prior). modes[w]: 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW, < 0 skip.
+extern "C" int vilo_batch_marginalize(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_window_desc *in, const vilo_window_state *state, const int *modes,
+                                      vilo_prior *out) {
+  if (!ctx || !bt || W <= 0 || W != vilo_batch_dev(bt)->W || !in || !state || !modes || !out) return VILO_ERR_BAD_ARG;
+  for (int w = 0; w < W; ++w)
+    if (modes[w] > 1) return VILO_ERR_BAD_ARG;
+  VILO_HIP(hipSetDevice(ctx->device));
+  return marginalize_batch(ctx, bt, W, in, nullptr, state, modes, out);
+}
+
 // Estimator::optimization() (estimator.cpp:1054-1458) as one call on one device-resident batch: ceres::Solve, double2vector's
 // gauge fix, then the marginalisation linearised at that result.
 extern "C" int vilo_optimize_windows_resident(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, vilo_window_state *inout,

@@ -3,7 +3,7 @@
 // (integration_base.h:18-170), batched over intervals: one wave per interval, samples sequential (each step
 // depends on the previous one), the 31x31 jacobian / covariance updates parallel over columns (lane = column),
 // F / V / jacobian / covariance resident in LDS, leg kinematics of the 4 legs x 2 endpoints on 8 lanes.
-#include "vilo_internal.hpp"
+#include "solver_types.hpp"
 
 using namespace vilo;
 
@@ -365,6 +365,29 @@ __global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config 
   preint_imu_leg_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 10 * f, out + f, nullptr);
 }
 
+// IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) for every live interval of a resident batch, at the biases of
+// the candidate state the next linearisation pass evaluates: the record an interval's factor reads is integrated again from its samples
+// with linearized_ba / bg / rho = the candidate's (BASELINE configs[2]: "K1 re-propagation of all 10 intervals inside the iteration").
+__global__ void __launch_bounds__(64) k_repropagate(BatchDev b, const vilo_config *cfgp, int mode) {
+  __shared__ double lin_s[10];
+  __shared__ int same_s;
+  const int f = blockIdx.x, win = f / 10, k = f % 10;
+  if (b.imu_skip[f] || b.rp_offsets[f + 1] <= b.rp_offsets[f]) return;
+  if (mode && b.st[win].done) return;
+  const double *xs = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
+  vilo_preint *rec = (vilo_preint *)b.rp_pre + f;
+  if (threadIdx.x == 0) same_s = 1;
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    const double v = threadIdx.x < 6 ? xs[XO_SB + 9 * k + 3 + threadIdx.x] : xs[XO_LB + 4 * k + (threadIdx.x - 6)];
+    lin_s[threadIdx.x] = v;
+    if (v != rec->lin_ba[threadIdx.x]) same_s = 0;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
+  }
+  __syncthreads();
+  if (!mode && same_s) return;   // (marginalisation) the record already is the one integrated at the accepted state
+  preint_imu_leg_body<false>(*cfgp, b.rp_samples, b.rp_offsets[f], b.rp_offsets[f + 1], lin_s, rec, nullptr);
+}
+
 // push_back() on device-resident objects: workgroup k appends samples[offsets[k] .. offsets[k+1]) to stream ids[k]
 __global__ void __launch_bounds__(64) k_preint_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
                                                            PreintStream *streams) {
@@ -685,4 +708,18 @@ int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, in
   else hipLaunchKernelGGL(k_preint_stream_gather, dim3(n), dim3(256), 0, ctx->stream, n, d_ids, d_dst, (const PreintStream *)pool->d, (vilo_preint *)d_out);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
+}
+
+// mode 1: at the candidate the next linearisation pass evaluates; mode 0: at the accepted state (before marginalisation). The
+// whitening matrices of the factors follow (sqrt_info of the new covariance).
+int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage) {
+  if (!b.rp_on || !b.rp_samples || !b.leg) return VILO_OK;
+  if (stage == 0) {
+    hipLaunchKernelGGL(k_repropagate, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, (const vilo_config *)ctx->d_cfg, mode);
+    VILO_HIP(hipGetLastError());
+    return VILO_OK;
+  }
+  int rc = vilo_launch_prepare_preint(ctx, b.W * 10, (const vilo_preint *)b.rp_pre, b.prep, b.prep_bad, b.imu_skip, 1);
+  if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, b);
+  return rc;
 }

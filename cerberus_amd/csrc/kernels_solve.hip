@@ -822,6 +822,14 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   if (b.n_lm > 0) VILO_HIP(hipMemcpyAsync(b.lamc, b.lam, sizeof(double) * (size_t)b.n_lm, hipMemcpyDeviceToDevice, s));
   for (int it = 0; it < o->max_num_iterations; ++it) {
     // cost + linearisation of the candidate -> accept / reject -> (accepted: normal equations) -> step -> next candidate
+    if (b.rp_on) {
+      P0(10);
+      if (vilo_repropagate_launch(ctx, b, 1, 0) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(11);
+      if (vilo_repropagate_launch(ctx, b, 1, 1) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+    }
     P0(0);
     launch_visual_linearize(b, sq, ha, s, 1);
     P1();
@@ -846,6 +854,14 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   P0(3);
   if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha);
   P1();
+  if (b.rp_on) {
+    P0(10);
+    if (vilo_repropagate_launch(ctx, b, 1, 0) != VILO_OK) return VILO_ERR_HIP;
+    P1();
+    P0(11);
+    if (vilo_repropagate_launch(ctx, b, 1, 1) != VILO_OK) return VILO_ERR_HIP;
+    P1();
+  }
   P0(4);
   hipLaunchKernelGGL(k_imu_cost, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn);
   P1();
@@ -860,6 +876,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
 int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
   hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4, 0);
+  if (b.rp_on && (vilo_repropagate_launch(ctx, b, 0, 0) != VILO_OK || vilo_repropagate_launch(ctx, b, 0, 1) != VILO_OK)) return VILO_ERR_HIP;
   launch_visual_linearize(b, sq, ha, ctx->stream, 0);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn, 0);
   hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 5), dim3(64), 0, ctx->stream, b, 0);

@@ -151,5 +151,12 @@ struct BatchDev {
   double *Bimg;               // [W][BI_N] speed / leg-bias part of the assembled system (BI_* layout)
   SolverState *st;
   int *status;
+  // preintegration inputs behind the records (optional: vilo_batch_set_samples) for re-propagation inside the iteration, and what the
+  // sqrt_info preparation needs
+  const vilo_sample *rp_samples;   // all intervals of all windows, concatenated
+  const int *rp_offsets;           // [W * 10 + 1] interval f integrates samples [rp_offsets[f], rp_offsets[f + 1]) (first = constructor sample)
+  void *rp_pre;                    // [W * 10] vilo_preint / vilo_preint_imu records the preparation reads
+  int *prep_bad;                   // [W * 10] covariance of the record not positive definite
+  int rp_on, leg;
   int *win_bad;               // [W] 1: a preintegration covariance of the window has no sqrt_info: the window fails alone (termination FAILURE)
 };

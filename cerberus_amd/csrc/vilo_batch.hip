@@ -569,6 +569,40 @@ extern "C" int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *bt) {
   return rc;
 }
 
+// BASELINE configs[2]: keep the samples behind the batch's IMU-leg records in HBM and integrate every live interval again
+// (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86) at the biases of each point the solver linearises
+extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_sample *samples, const int32_t *offsets) {
+  if (!ctx || !bt) return VILO_ERR_BAD_ARG;
+  BatchDev &D = bt->d;
+  if (!samples) {   // back to records integrated once
+    D.rp_on = 0;
+    if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
+    return VILO_OK;
+  }
+  if (!offsets) return VILO_ERR_BAD_ARG;
+  if (!bt->leg || !bt->d_pre) { ctx->err = "vilo_batch_set_samples: the batch has no IMU-leg preintegration records"; return VILO_ERR_UNSUPPORTED; }
+  VILO_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)bt->W * 10;
+  std::vector<unsigned char> skip(n);
+  VILO_HIP(hipMemcpy(skip.data(), D.imu_skip, n, hipMemcpyDeviceToHost));
+  if (offsets[0] < 0) return VILO_ERR_BAD_ARG;
+  for (size_t f = 0; f < n; ++f)
+    if (offsets[f + 1] < offsets[f] || (!skip[f] && offsets[f + 1] == offsets[f])) {
+      ctx->err = "vilo_batch_set_samples: a live interval without samples";
+      return VILO_ERR_BAD_ARG;
+    }
+  vilo_sample *d_s = nullptr;
+  int *d_o = nullptr;
+  int rc = dev_alloc(ctx, bt, &d_s, (size_t)offsets[n]);
+  if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &d_o, n + 1);
+  if (rc != VILO_OK) return rc;
+  VILO_HIP(hipMemcpy(d_s, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice));
+  VILO_HIP(hipMemcpy(d_o, offsets, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+  D.rp_samples = d_s; D.rp_offsets = d_o; D.rp_pre = bt->d_pre; D.prep_bad = bt->d_prep_bad; D.leg = 1; D.rp_on = 1;
+  if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }   // the captured launch sequence changes
+  return VILO_OK;
+}
+
 extern "C" int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *bt) {
   if (!ctx || !bt) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));

@@ -20,7 +20,7 @@
 #define VILO_GRAM 351      // packed upper triangle of the 26 x 26 per-(group, t) Gram matrix
 #define VILO_GCOLS 26      // [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td 1 | r 1]
 
-#define VILO_NKERNEL 10
+#define VILO_NKERNEL 12
 struct vilo_ctx {
   vilo_config cfg;
   int device;
@@ -97,6 +97,7 @@ int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *
 struct BatchDev;
 int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b);
 int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b);
+int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage);
 
 // ---- device-resident hand-over objects (include/vilo_gpu.h) ----
 struct vilo_prior_pool {

@@ -246,6 +246,14 @@ int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *batch);  /* restore the uploaded
 /* sqrt_info = LLT(cov^-1)^T of the batch's preintegration records again (asynchronous): vilo_batch_create runs it once; the reference
  * recomputes it in every IMULegFactor::Evaluate (imu_leg_factor.cpp:197-198), a caller that replays a resident batch can charge it per solve */
 int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *batch);
+/* BASELINE configs[2] ("K1 re-propagation of all 10 intervals inside the iteration"): hand the batch the samples behind its IMU-leg
+ * records — samples [offsets[10 w + k], offsets[10 w + k + 1]) are interval k of window w, the first one the constructor sample
+ * (IMULegIntegrationBase(acc_0, gyr_0, ...), imu_leg_integration_base.cpp:7-42), the rest its push_back()s; n_windows * 10 + 1 offsets,
+ * empty ranges for intervals the window does not have. From then on vilo_batch_solve integrates every live interval again
+ * (IMULegIntegrationBase::repropagate(Bai, Bgi, rhoi), imu_leg_integration_base.cpp:62-86) at the biases of every point it
+ * linearises or evaluates, followed by the sqrt_info of the new covariance, and vilo_batch_marginalize does so at the accepted state.
+ * samples == NULL switches it off again. The records the batch was built with are overwritten. */
+int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *batch, const vilo_sample *samples, const int32_t *offsets);
 int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *batch, const vilo_solve_opts *opts);
 int vilo_batch_download(vilo_ctx *ctx, vilo_batch *batch, vilo_window_state *out, vilo_solve_summary *summaries);
 void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *batch);
@@ -262,6 +270,11 @@ int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before
  * incoming prior back unchanged (estimator.cpp:1379-1380); without any prior out->valid = 0. */
 int vilo_marginalize(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
                      int mode, vilo_prior *out);
+/* The same on a batch that is already resident, linearised at its device state (after vilo_batch_solve + vilo_batch_download; `state` is
+ * the host copy of that state, `in` the descriptors the batch was created from). modes[w]: 0, 1 as above, < 0: leave window w alone.
+ * With vilo_batch_set_samples in force the intervals are integrated again at the accepted state first. */
+int vilo_batch_marginalize(vilo_ctx *ctx, vilo_batch *batch, int n_windows, const vilo_window_desc *in, const vilo_window_state *state,
+                           const int *modes, vilo_prior *out);
 
 /* ---- Estimator::optimization() as ONE call (estimator.cpp:1054-1458): solve, double2vector gauge fix, marginalisation
  * linearised at that result, all on one device-resident batch (one packing, no host round trip between the halves).

@@ -87,6 +87,11 @@ struct RBlock {
   std::vector<std::vector<double>> J;  // per param: nres x lsize (row-major), corrected
 };
 
+// set by orc_set_repropagation: samples of the window's intervals (interval i = samples [offsets[i], offsets[i + 1]), the first one the
+// constructor sample) — while set, every IMU-leg factor evaluation integrates its interval again at the evaluation point's biases
+const orc_sample *g_rp_samples = nullptr;
+const int32_t *g_rp_offsets = nullptr;
+
 struct Problem {
   const orc_config *cfg;
   const orc_window *w;
@@ -214,7 +219,18 @@ double eval_block(const Problem &P, RBlock &b, bool want_jac, bool ref_sqrt_info
   (void)ref_sqrt_info;
   switch (b.kind) {
     case 0: orc_eval_prior(P.w->prior, par, r_out.data(), jac); break;
-    case 1: orc_eval_imu_leg(P.cfg, &P.w->preint[b.aux], par, r_out.data(), jac); break;
+    case 1:
+      if (g_rp_samples) {
+        // BASELINE configs[2]: the interval is integrated again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
+        // at the biases of the point the factor is evaluated at, then evaluated as usual
+        const int o0 = g_rp_offsets[b.aux], o1 = g_rp_offsets[b.aux + 1];
+        orc_preint tmp;
+        orc_preintegrate_imu_leg(P.cfg, g_rp_samples + o0, g_rp_samples + o0 + 1, o1 - o0 - 1, par[1] + 3, par[1] + 6, par[2], &tmp);
+        orc_eval_imu_leg(P.cfg, &tmp, par, r_out.data(), jac);
+      } else {
+        orc_eval_imu_leg(P.cfg, &P.w->preint[b.aux], par, r_out.data(), jac);
+      }
+      break;
     case 2: orc_eval_imu(P.cfg, &P.w->preint_imu[b.aux], par, r_out.data(), jac); break;
     case 3: orc_eval_proj2f1c(P.cfg, b.obs12, par, r_out.data(), jac); break;
     case 4: orc_eval_proj2f2c(P.cfg, b.obs12, par, r_out.data(), jac); break;
@@ -901,4 +917,9 @@ extern "C" int orc_marginalize(const orc_config *cfg, const orc_window *w, const
   }
   out->valid = 1;
   return 0;
+}
+
+extern "C" void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets) {
+  g_rp_samples = samples;
+  g_rp_offsets = offsets;
 }

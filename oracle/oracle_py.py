@@ -272,6 +272,23 @@ def solve_window(cfg, w, opts=None, check=True):
     return sm
 
 
+class repropagation:
+    """Context manager: while active, every IMU-leg factor evaluation of window w (solve_window, marginalize, window_cost, ...) first
+    integrates its interval again from w.samples at the biases of the evaluation point (BASELINE configs[2])."""
+
+    def __init__(self, w):
+        self._s = np.ascontiguousarray(w.samples, dtype=np.float64)
+        self._o = np.ascontiguousarray(w.sample_offsets, dtype=np.int32)
+
+    def __enter__(self):
+        lib().orc_set_repropagation(C.cast(self._s.ctypes.data, C.POINTER(Sample)), self._o.ctypes.data_as(C.POINTER(C.c_int32)))
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_repropagation(None, None)
+        return False
+
+
 def branch_counts():
     """Branches the last solve_window took: [gn, cauchy, interpolated, rejected, longest rejected run, invalid, mu escalations, accepted]."""
     out = (C.c_int * 8)()

@@ -192,6 +192,10 @@ typedef struct {
 } orc_summary;
 
 void orc_default_opts(orc_solve_opts *o);
+/* BASELINE configs[2] ("K1 re-propagation inside the iteration"): while samples != NULL every IMULegFactor evaluation of the window
+ * solved / marginalised next first integrates its interval again (repropagate, imu_leg_integration_base.cpp:62-86) at the biases
+ * of the evaluation point. offsets[i]..offsets[i+1] are interval i's samples, the first being the constructor sample. Not thread safe. */
+void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets);
 
 /* Cost 1/2 sum rho(|r|^2) at state, and optionally gradient/Hessian pieces in the reduced (camera)
  * ordering used by tests: local layout [frame k: pose6 sb9 lb4]*n_frames, ex0 6, ex1 6, td 1, then landmarks. */

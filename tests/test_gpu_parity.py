@@ -658,9 +658,9 @@ def test_solve_window_at_the_feature_cap(ctx, cfg, ocfg):
     from cerberus_amd import api
     w_g = _fresh(cfg, ocfg, n_landmarks=1000, seed=91)
     w_o = _fresh(cfg, ocfg, n_landmarks=1000, seed=91)
-    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 3))[0]
-    so = O.solve_window(ocfg, w_o, O.default_opts(True, 3))
-    assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful)
+    sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 12))[0]
+    so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
+    assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful) and sg.iterations == 12
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())

@@ -1,0 +1,164 @@
+"""BASELINE configs[2]: "K1 re-propagation of all 10 intervals inside the iteration". With the samples of a window's intervals at hand,
+every IMULegFactor evaluation integrates its interval again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
+at the biases of the evaluation point — in the oracle through orc_set_repropagation, on the device through vilo_batch_set_samples."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+
+def _window(cfg, ocfg, **kw):
+    from cerberus_amd import synth
+    w = synth.make_window(cfg, params=synth.default_params(config=3, **kw))
+    O.fill_preint(ocfg, w)
+    return w
+
+
+def test_400hz_window_shape(cfg, ocfg):
+    """27 samples per interval (26 x 2.5 ms + one trimmed step) plus the constructor sample."""
+    w = _window(cfg, ocfg, n_landmarks=30, seed=3)
+    n = np.diff(w.sample_offsets)
+    assert n.shape == (10,) and np.all(n == 28)
+    dt = w.samples[w.sample_offsets[0] + 1: w.sample_offsets[1], 0]
+    np.testing.assert_allclose(dt[:-1], 2.5e-3, rtol=1e-12)
+    assert 0 < dt[-1] <= 2.5e-3 + 1e-15
+    np.testing.assert_allclose(dt.sum(), 1 / 15.0, rtol=1e-12)
+
+
+def test_oracle_repropagation_at_the_linearisation_point_changes_nothing(cfg, ocfg):
+    """A record integrated at ba/bg/rho = the state's biases has no first-order correction to apply: the cost is the plain one."""
+    w = _window(cfg, ocfg, n_landmarks=30, seed=3)
+    w.speed_bias[:10, 3:9] = w.lin[:, :6]
+    w.leg_bias[:10] = w.lin[:, 6:]
+    plain = O.window_cost(ocfg, w)
+    with O.repropagation(w):
+        again = O.window_cost(ocfg, w)
+    np.testing.assert_allclose(again, plain, rtol=1e-12)
+
+
+def test_oracle_repropagation_replaces_the_first_order_bias_correction(cfg, ocfg):
+    """Away from the linearisation point the plain factor corrects delta_p/q/v/eps to first order in the bias change; integrating
+    again is exact: the two costs differ, by much less than the bias change moved the cost."""
+    w = _window(cfg, ocfg, n_landmarks=30, seed=3)
+    c0 = O.window_cost(ocfg, w)
+    rng = np.random.default_rng(0)
+    w.speed_bias[:, 3:6] += 2e-2 * rng.normal(size=(11, 3))
+    w.speed_bias[:, 6:9] += 2e-3 * rng.normal(size=(11, 3))
+    w.leg_bias += 2e-3 * rng.normal(size=(11, 4))
+    plain = O.window_cost(ocfg, w)
+    with O.repropagation(w):
+        again = O.window_cost(ocfg, w)
+    assert again != plain
+    assert abs(again - plain) < 0.05 * abs(plain - c0)
+    # and the hook is off again
+    np.testing.assert_array_equal(O.window_cost(ocfg, w), plain)
+
+
+def test_oracle_solve_with_repropagation_lands_next_to_the_plain_solution(cfg, ocfg):
+    w1 = _window(cfg, ocfg, n_landmarks=40, seed=5)
+    w2 = _window(cfg, ocfg, n_landmarks=40, seed=5)
+    s1 = O.solve_window(ocfg, w1, O.default_opts(True, 6))
+    with O.repropagation(w2):
+        s2 = O.solve_window(ocfg, w2, O.default_opts(True, 6))
+    assert s2.final_cost < s2.initial_cost
+    np.testing.assert_allclose(s2.initial_cost, s1.initial_cost, rtol=1e-9)   # biases ~1e-2 from the records' linearisation point
+    assert s2.initial_cost != s1.initial_cost
+    np.testing.assert_allclose(s2.final_cost, s1.final_cost, rtol=1e-3)
+    assert np.abs(w1.pose - w2.pose).max() < 1e-4
+    assert not np.array_equal(w1.speed_bias, w2.speed_bias)
+
+
+@pytest.fixture(scope="module")
+def ctx(cfg):
+    from cerberus_amd import api
+    c = api.Context(cfg)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,L", [(5, 40), (6, 120)])
+def test_gpu_solve_with_repropagation_vs_oracle(ctx, cfg, ocfg, seed, L):
+    from cerberus_amd import api
+    w_g = _window(cfg, ocfg, n_landmarks=L, seed=seed)
+    w_o = _window(cfg, ocfg, n_landmarks=L, seed=seed)
+    w_p = _window(cfg, ocfg, n_landmarks=L, seed=seed)
+    opts = api.default_solve_opts(True, 6)
+    b = api.Batch(ctx, [w_g])
+    try:
+        b.set_samples()
+        b.solve(opts)
+        sg = b.download()[0]
+        # the same batch without: the plain solve again (records are integrated anew from the initial state's biases first)
+        b.set_samples(False)
+    finally:
+        b.close()
+    with O.repropagation(w_o):
+        so = O.solve_window(ocfg, w_o, O.default_opts(True, 6))
+    assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful)
+    np.testing.assert_allclose(sg.initial_cost, so.initial_cost, rtol=1e-9)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
+        if a.size:
+            assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+    # it is a different problem from the one with records integrated once
+    sp = ctx.solve_windows([w_p], opts)[0]
+    assert abs(sp.final_cost - sg.final_cost) > 1e-9 * sg.final_cost
+
+
+@pytest.mark.gpu
+def test_gpu_repropagated_batch_of_windows_equals_the_single_solves(ctx, cfg, ocfg):
+    """Interval offsets of a batch are global: every window integrates its own samples."""
+    from cerberus_amd import api
+    opts = api.default_solve_opts(True, 4)
+    ws = [_window(cfg, ocfg, n_landmarks=40 + 10 * i, seed=20 + i) for i in range(5)]
+    alone = [_window(cfg, ocfg, n_landmarks=40 + 10 * i, seed=20 + i) for i in range(5)]
+    b = api.Batch(ctx, ws)
+    try:
+        b.set_samples()
+        b.solve(opts)
+        b.download()
+    finally:
+        b.close()
+    for w in alone:
+        b1 = api.Batch(ctx, [w])
+        try:
+            b1.set_samples()
+            b1.solve(opts)
+            b1.download()
+        finally:
+            b1.close()
+    for w, w1 in zip(ws, alone):
+        for a, bb in zip(w.state_arrays(), w1.state_arrays()):
+            np.testing.assert_array_equal(a, bb)
+
+
+@pytest.mark.gpu
+def test_gpu_marginalisation_after_a_repropagated_solve_vs_oracle(ctx, cfg, ocfg):
+    """The prior is linearised with the intervals integrated again at the accepted state (which the last, possibly rejected, candidate
+    of the solve need not be)."""
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    w_g = _window(cfg, ocfg, n_landmarks=50, seed=8)
+    w_o = _window(cfg, ocfg, n_landmarks=50, seed=8)
+    opts = api.default_solve_opts(True, 5)
+    pg, po = PriorData(), PriorData()
+    b = api.Batch(ctx, [w_g])
+    try:
+        b.set_samples()
+        b.solve(opts)
+        b.download()
+        b.marginalize([0], [pg])
+    finally:
+        b.close()
+    with O.repropagation(w_o):
+        O.solve_window(ocfg, w_o, O.default_opts(True, 5))
+        w_o.set_state(w_g.clone_state())   # the same linearisation point for the two marginalisations
+        rc, m = O.marginalize(ocfg, w_o, 0, po)[:2]
+    assert rc == 0 and pg.struct.valid == 1 and pg.blocks() == po.blocks()
+    n = pg.n
+    Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+    Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+    assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max()
+    bg, bo = Jg.T @ pg.r0[:n], Jo.T @ po.r0[:n]
+    assert np.abs(bg - bo).max() < 1e-6 * np.abs(bo).max()
