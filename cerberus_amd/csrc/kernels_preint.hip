@@ -3,6 +3,12 @@
 // (integration_base.h:18-170), batched over intervals: one wave per interval, samples sequential (each step
 // depends on the previous one), the 31x31 jacobian / covariance updates parallel over columns (lane = column),
 // F / V / jacobian / covariance resident in LDS, leg kinematics of the 4 legs x 2 endpoints on 8 lanes.
+//
+// The batch form, the streaming form and the re-propagation of a resident batch are three instantiations of one body and must give
+// bitwise the same record (tests: streaming == batch). With the default -ffp-contract=fast the optimiser fuses a multiply with an
+// add wherever inlining happens to bring them together, which differs between the instantiations; contract(on) fuses inside one
+// source expression only — decided by the front end, the same in every instantiation.
+#pragma clang fp contract(on)
 #include "solver_types.hpp"
 
 using namespace vilo;
@@ -129,7 +135,7 @@ struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
 // identity) or streaming form (STREAM = true: the object lives in HBM between calls, this call push_back()s the new samples).
 // Both run the same arithmetic in the same order: pushing an interval in pieces gives bitwise the batch result.
 template <bool STREAM>
-__device__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
+__device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
                                     PreintStream *st) {
   // padded to 32 rows (48 noise columns) with odd leading dimensions: rows / columns 31 and noise 46, 47 stay zero, so the FP64
   // MFMA tiles of jac_cov_update_mfma need no masks
@@ -425,7 +431,7 @@ __global__ void k_preint_stream_gather(int n, const int *ids, const int *dst_idx
 }
 
 template <bool STREAM>
-__device__ void preint_imu_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint_imu *outp,
+__device__ __forceinline__ void preint_imu_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint_imu *outp,
                                 PreintImuStream *st) {
   __shared__ double Fm[15 * 15], Vm[15 * 18], nd[18];
   __shared__ double Jm[15 * 16], Pm[15 * 16], Qm[15 * 16];

@@ -13,6 +13,7 @@
 // rejected one costs a wasted linearisation, which is rare): observations and preintegration records are read once per iteration.
 // k_visual_cost / k_imu_cost are the cost-only forms for the last candidate of a solve.
 #include "solve_common.hpp"
+#include "visual_lin.hpp"
 
 using namespace vilo;
 
@@ -101,11 +102,16 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
 // TPAR = true (small batches, b.lm_part != null): one wave per (packed wave, frame offset) so that a handful of windows still
 // fills the chip; every landmark-side term is written per (frame, camera) and k_visual_reduce adds the terms in the order the
 // walking form adds them — the two forms give bitwise the same linearisation.
+// The factor bodies are visual_lin.hpp's: rotation products hoisted per (start frame, observing frame) pair into an LDS table that 48
+// lanes of the wave build for VT_TB frames at a time, Huber weight folded into the projection Jacobian.
 #define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
+#define VT_TB 2       // frames per table build: lane = (frame of the pair, segment, camera, row) = 2 x 4 x 2 x 3
 template <bool TPAR>
 __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a, int mode) {
   __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
-  __shared__ double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
+  __shared__ __attribute__((aligned(16))) double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
+  __shared__ __attribute__((aligned(16))) double wt[VW_N];
+  __shared__ __attribute__((aligned(16))) double tab[VT_TB * 4 * VT_N];
   const int wave_id = b.wave_order[blockIdx.x];
   const WaveMeta wv = b.wave[wave_id];
   SolverState &st = b.st[wv.win];
@@ -123,7 +129,6 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
   const int li = ls.li;
   for (int e = lane; e < XSTRIDE; e += 64) xs[e] = xg[e];
-  const double *x = xs;
 
   // Gram of a (start frame, t) slot on the FP64 matrix cores: X^T X with X = the 2 n corrected Jacobian rows (26 columns,
   // padded to 32) as three 16 x 16 tiles (0,0), (0,1), (1,1). One k-step = 4 rows = 2 landmarks; lane (lr, lk) supplies
@@ -138,17 +143,42 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 
   const double *obs = b.obs + wv.obs_off;
   const unsigned char *flg = b.flags + wv.flag_off;
-  double o12[12];
+  double oi[6];   // pts_i (3), vel_i (2), td_i: the observation in the start frame
   double lam = 1.0;
-  for (int c = 0; c < 12; ++c) o12[c] = 0.0;
+  for (int c = 0; c < 6; ++c) oi[c] = 0.0;
+  oi[2] = 1.0;
   if (active) {
     lam = (mode ? b.lamc : b.lam)[ls.gi];
-    o12[0] = obs[(size_t)0 * n + lane]; o12[1] = obs[(size_t)1 * n + lane]; o12[2] = obs[(size_t)2 * n + lane];
-    o12[6] = obs[(size_t)6 * n + lane]; o12[7] = obs[(size_t)7 * n + lane]; o12[10] = obs[(size_t)10 * n + lane];
+    oi[0] = obs[(size_t)0 * n + lane]; oi[1] = obs[(size_t)1 * n + lane]; oi[2] = obs[(size_t)2 * n + lane];
+    oi[3] = obs[(size_t)6 * n + lane]; oi[4] = obs[(size_t)7 * n + lane]; oi[5] = obs[(size_t)10 * n + lane];
   }
   lds_barrier();
-  const double *pose_s = x + XO_POSE + 7 * s, *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
-  const double td = x[XO_TD];
+  // window-level table: the two extrinsic rotations as matrices, their translations, ric2^T ric
+  if (lane < 9) {
+    const m3 ric = qR(ldq_pose(xs + XO_EX)), ric2 = qR(ldq_pose(xs + XO_EX + 7));
+    const m3 A2 = tr(ric2) * ric;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      if (q == lane) { e0 = ric.a[q]; e1 = ric2.a[q]; e2 = A2.a[q]; }
+    wt[VW_RIC + lane] = e0; wt[VW_RIC2 + lane] = e1; wt[VW_A2 + lane] = e2;
+    if (lane < 3) { wt[VW_TIC + lane] = xs[XO_EX + lane]; wt[VW_TIC2 + lane] = xs[XO_EX + 7 + lane]; }
+  }
+  lds_barrier();
+  const double td = xs[XO_TD];
+  VisLane VL;
+  {
+    const double dti = td - oi[5];
+    VL.inv_lam = 1.0 / lam;
+    VL.vix = oi[3]; VL.viy = oi[4];
+    VL.pci = mk3((oi[0] - oi[3] * dti) * VL.inv_lam, (oi[1] - oi[4] * dti) * VL.inv_lam, oi[2] * VL.inv_lam);
+    const double *ric = wt + VW_RIC, *tic = wt + VW_TIC;
+    VL.p_i = mk3(ric[0] * VL.pci.x + ric[1] * VL.pci.y + ric[2] * VL.pci.z + tic[0], ric[3] * VL.pci.x + ric[4] * VL.pci.y + ric[5] * VL.pci.z + tic[1],
+                 ric[6] * VL.pci.x + ric[7] * VL.pci.y + ric[8] * VL.pci.z + tic[2]);
+    const double *pose_s = xs + XO_POSE + 7 * s;
+    VL.p_w = qrot(ldq_pose(pose_s), VL.p_i) + ld3(pose_s);
+  }
+  const v3 pts_i = mk3(oi[0], oi[1], oi[2]);
 
   double E = 0.0, gl = 0.0, cost = 0.0;
   double wc_s[6], wc_e0[6], wc_e1[6], wc_td = 0.0;
@@ -171,10 +201,22 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 #pragma unroll
     for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
   }
+  // table-builder role of this lane: (frame of the pair, segment, camera, row)
+  const int tb_tt = lane / 24, tb_g = (lane % 24) / 6, tb_kind = ((lane % 6) >= 3) ? 1 : 0, tb_r = lane % 3;
+  int tb_s = 0, tb_km = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (g == tb_g) { tb_s = cs[g]; tb_km = (g < wv.nseg) ? ckm[g] : 0; }
+  const int tb_base = max(t_begin, 1);   // (frame 0 is the one-frame factor: no pair)
   for (int t = t_begin; t < t_end; ++t) {
+    const int tslot = (t >= tb_base) ? (t - tb_base) % VT_TB : 0;
+    if (t >= tb_base && tslot == 0) {
+      if (lane < 24 * VT_TB && t + tb_tt < tb_km && t + tb_tt < t_end)
+        vis_build_pair_row(xs, wt, tb_s, min(tb_s + t + tb_tt, VILO_MAX_FRAMES - 1), tb_kind, tb_r, tab + (tb_tt * 4 + tb_g) * VT_N);
+      lds_barrier();
+    }
     const int j = min(s + t, VILO_MAX_FRAMES - 1);
     const unsigned char fl = fl_next;
-    const double *pose_j = x + XO_POSE + 7 * j;
     double ob[11];
 #pragma unroll
     for (int c = 0; c < 11; ++c) ob[c] = on[c];
@@ -189,6 +231,13 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     for (int g = 0; g < 4; ++g) { G00[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G01[g] = G00[g]; G11[g] = G00[g]; }
     double wj[6];
     for (int c = 0; c < 6; ++c) wj[c] = 0.0;
+    const double *tb = tab + (tslot * 4 + max(ls.seg, 0)) * VT_N;
+    v3 p_j = VL.p_i;
+    if (t > 0) {
+      const v3 d = mk3(VL.p_w.x - tb[VT_PJ], VL.p_w.y - tb[VT_PJ + 1], VL.p_w.z - tb[VT_PJ + 2]);
+      p_j = mk3(tb[0] * d.x + tb[3] * d.y + tb[6] * d.z, tb[1] * d.x + tb[4] * d.y + tb[7] * d.z, tb[2] * d.x + tb[5] * d.y + tb[8] * d.z);
+    }
+    const double dtj = td - ob[10];
 
     for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
@@ -196,37 +245,29 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
       double *xr0 = &X[lane * XLANE], *xr1 = xr0 + 26;
       c_a = clock64();
       if (produce) {
-        double r[2], Ji[12], Jj[12], Je0[12], Je1[12], Jl[2], Jt[2];
-        for (int c = 0; c < 12; ++c) Ji[c] = Jj[c] = Je0[c] = Je1[c] = 0.0;
-        if (cam == 0) { o12[3] = ob[0]; o12[4] = ob[1]; o12[5] = ob[2]; o12[8] = ob[6]; o12[9] = ob[7]; }
-        else { o12[3] = ob[3]; o12[4] = ob[4]; o12[5] = ob[5]; o12[8] = ob[8]; o12[9] = ob[9]; }
-        o12[11] = ob[10];
-        if (cam == 0) proj_factor<0>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
-        else if (t > 0) proj_factor<1>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
-        else proj_factor<2>(o12, pose_s, pose_j, ex0, ex1, lam, td, sq, r, true, Ji, Jj, Je0, Je1, Jl, Jt);
-        const Corrector cr = make_corrector(huber_a, r[0] * r[0] + r[1] * r[1]);
-        cost += cr.rho0;
-        for (int c = 0; c < 6; ++c) {
-          correct_col(cr, r[0], r[1], Ji[c], Ji[6 + c]);
-          correct_col(cr, r[0], r[1], Jj[c], Jj[6 + c]);
-          correct_col(cr, r[0], r[1], Je0[c], Je0[6 + c]);
-          correct_col(cr, r[0], r[1], Je1[c], Je1[6 + c]);
+        double x0[26], x1[26], Jl[2], obc[5];
+        double rho0;
+        if (cam == 0) {
+          obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
+          rho0 = vis_two_frame<0>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+        } else {
+          obc[0] = ob[3]; obc[1] = ob[4]; obc[2] = ob[5]; obc[3] = ob[8]; obc[4] = ob[9];
+          if (t > 0) rho0 = vis_two_frame<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+          else rho0 = vis_one_frame(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl);
         }
-        correct_col(cr, r[0], r[1], Jl[0], Jl[1]);
-        correct_col(cr, r[0], r[1], Jt[0], Jt[1]);
-        r[0] *= cr.residual_scaling;
-        r[1] *= cr.residual_scaling;
+        cost += rho0;
         // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
         double term[LM_NTERM];
         term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
-        term[1] = Jl[0] * r[0] + Jl[1] * r[1];
+        term[1] = Jl[0] * x0[25] + Jl[1] * x1[25];
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
-          term[2 + c] = Ji[c] * Jl[0] + Ji[6 + c] * Jl[1];
-          term[8 + c] = Je0[c] * Jl[0] + Je0[6 + c] * Jl[1];
-          term[14 + c] = Je1[c] * Jl[0] + Je1[6 + c] * Jl[1];
-          wj[c] += Jj[c] * Jl[0] + Jj[6 + c] * Jl[1];
+          term[2 + c] = x0[c] * Jl[0] + x1[c] * Jl[1];
+          term[8 + c] = x0[12 + c] * Jl[0] + x1[12 + c] * Jl[1];
+          term[14 + c] = x0[18 + c] * Jl[0] + x1[18 + c] * Jl[1];
+          wj[c] += x0[6 + c] * Jl[0] + x1[6 + c] * Jl[1];
         }
-        term[20] = Jt[0] * Jl[0] + Jt[1] * Jl[1];
+        term[20] = x0[24] * Jl[0] + x1[24] * Jl[1];
         if (TPAR) {
           double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
 #pragma unroll
@@ -234,42 +275,58 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         } else {
           E += term[0];
           gl += term[1];
+#pragma unroll
           for (int c = 0; c < 6; ++c) { wc_s[c] += term[2 + c]; wc_e0[c] += term[8 + c]; wc_e1[c] += term[14 + c]; }
           wc_td += term[20];
         }
-        for (int c = 0; c < 6; ++c) {
-          xr0[c] = Ji[c]; xr1[c] = Ji[6 + c];
-          xr0[6 + c] = Jj[c]; xr1[6 + c] = Jj[6 + c];
-          xr0[12 + c] = Je0[c]; xr1[12 + c] = Je0[6 + c];
-          xr0[18 + c] = Je1[c]; xr1[18 + c] = Je1[6 + c];
-        }
-        xr0[24] = Jt[0]; xr1[24] = Jt[1];
-        xr0[25] = r[0]; xr1[25] = r[1];
+#pragma unroll
+        for (int c = 0; c < 26; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
       } else {
+#pragma unroll
         for (int c = 0; c < 26; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
       }
       lds_barrier();
       { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
       // rows of padding / unobserved lanes are zero, and every segment spans a multiple of 8 lanes = 4 k-steps:
-      // 8 LDS reads in flight, then 12 MFMAs per trip
+      // the operands of the next trip are in flight behind the 12 MFMAs of this one
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (g >= wv.nseg || t >= ckm[g]) continue;
         const int k0 = wv.seg_lane0[g] >> 1, k1 = k0 + (((cn[g] + 7) & ~7) >> 1);
-        for (int kk0 = k0; kk0 < k1; kk0 += 4) {
-          double a0[4], a1[4];
+        // Lanes lr >= 10 of the second tile column read past column 25 (the next row / lane: in bounds, arbitrary values): they only
+        // reach rows / columns 26 .. 31 of the tiles, which nobody stores.
+        double a0[4], a1[4], n0[4], n1[4];
+        auto ldtrip = [&](int kk, double *p0, double *p1) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const double *xr = &X[2 * (kk0 + u) * XLANE + xoff];
-            a0[u] = xr[0];
-            a1[u] = xr[16];
+            const double *xr = &X[2 * (kk + u) * XLANE + xoff];
+            p0[u] = xr[0];
+            p1[u] = xr[16];
           }
+        };
+        auto dotrip = [&](const double *p0, const double *p1) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const double b1 = c1on ? a1[u] : 0.0;
-            G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], G00[g], 0, 0, 0);
-            G01[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1, G01[g], 0, 0, 0);
-            G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, G11[g], 0, 0, 0);
+            G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G00[g], 0, 0, 0);
+            G01[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p1[u], G01[g], 0, 0, 0);
+            G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1[u], p1[u], G11[g], 0, 0, 0);
+          }
+        };
+        // two trips per turn, the operands of the next trip in flight behind the 12 MFMAs of this one (a segment has an even number of
+        // trips or is the last of its wave: the trip after its last one reads rows that exist — zero pad lanes at the end — and is dropped)
+        // (sched_barrier: the scheduler otherwise sinks every load to just before its MFMA to save registers, and the wave waits out
+        // an LDS round trip per k-step)
+        ldtrip(k0, a0, a1);
+        for (int kk0 = k0; kk0 < k1; kk0 += 8) {
+          ldtrip(min(kk0 + 4, 30), n0, n1);
+          __builtin_amdgcn_sched_barrier(0);
+          dotrip(a0, a1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk0 + 4 < k1) {
+            ldtrip(min(kk0 + 8, 30), a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            dotrip(n0, n1);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }

@@ -2,6 +2,7 @@
 // vilo_math.hpp) for the HOST so the `-m "not gpu"` suite can compare it with the oracle before any GPU
 // minute is spent. This library is never loaded by the product (libvilo_gpu.so has no CPU path).
 #include "../../cerberus_amd/csrc/factors.hpp"
+#include "../../cerberus_amd/csrc/visual_lin.hpp"
 #include "../../include/vilo_gpu.h"
 
 using namespace vilo;
@@ -49,4 +50,33 @@ void hc_leg_kin(const double *q, double lc, const double *rf, double *f3, double
 }
 void hc_pose_plus(const double *x, const double *d, double *out) { pose_plus(x, d, out); }
 void hc_prior_dx(const double *x, const double *x0, int size, double *dx) { prior_dx(x, x0, size, dx); }
+
+// The fused linearisation's factor forms (visual_lin.hpp: hoisted rotation products, Huber weight folded into `reduce`) for one landmark:
+// kind 0 / 1 / 2 as in hc_proj; x0 / x1: the two corrected rows [J_pose_i 6 | J_pose_j 6 | J_ex0 6 | J_ex1 6 | J_td | r]; returns rho(s).
+// The tables are built the way k_visual_linearize builds them (window table, then the 2 x 3 rows of the pair's table).
+double hc_vis_lin(int kind, const double *obs12, const double *pose_i, const double *pose_j, const double *ex0, const double *ex1,
+                  double inv_dep, double td, double sq, double huber_a, double *x0, double *x1, double *Jl) {
+  double xs[14], wt[VW_N], tb[VT_N];
+  for (int i = 0; i < 7; ++i) { xs[i] = pose_i[i]; xs[7 + i] = pose_j[i]; }
+  const m3 ric = qR(ldq_pose(ex0)), ric2 = qR(ldq_pose(ex1));
+  const m3 A2 = tr(ric2) * ric;
+  for (int q = 0; q < 9; ++q) { wt[VW_RIC + q] = ric.a[q]; wt[VW_RIC2 + q] = ric2.a[q]; wt[VW_A2 + q] = A2.a[q]; }
+  for (int q = 0; q < 3; ++q) { wt[VW_TIC + q] = ex0[q]; wt[VW_TIC2 + q] = ex1[q]; }
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 3; ++r) vis_build_pair_row(xs, wt, 0, 1, k, r, tb);
+  VisLane L;
+  const double dti = td - obs12[10];
+  L.inv_lam = 1.0 / inv_dep;
+  L.vix = obs12[6]; L.viy = obs12[7];
+  L.pci = mk3((obs12[0] - obs12[6] * dti) * L.inv_lam, (obs12[1] - obs12[7] * dti) * L.inv_lam, obs12[2] * L.inv_lam);
+  L.p_i = ric * L.pci + ld3(ex0);
+  L.p_w = qrot(ldq_pose(pose_i), L.p_i) + ld3(pose_i);
+  const v3 d = mk3(L.p_w.x - tb[VT_PJ], L.p_w.y - tb[VT_PJ + 1], L.p_w.z - tb[VT_PJ + 2]);
+  const v3 p_j = mk3(tb[0] * d.x + tb[3] * d.y + tb[6] * d.z, tb[1] * d.x + tb[4] * d.y + tb[7] * d.z, tb[2] * d.x + tb[5] * d.y + tb[8] * d.z);
+  const double obc[5] = {obs12[3], obs12[4], obs12[5], obs12[8], obs12[9]};
+  const double dtj = td - obs12[11];
+  if (kind == 0) return vis_two_frame<0>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+  if (kind == 1) return vis_two_frame<1>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+  return vis_one_frame(wt, L, mk3(obs12[0], obs12[1], obs12[2]), obc, dtj, sq, huber_a, x0, x1, Jl);
+}
 }

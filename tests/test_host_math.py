@@ -20,11 +20,12 @@ def hc():
     d = os.path.join(ROOT, "tests", "host_check")
     so = os.path.join(d, "libhostcheck.so")
     srcs = [os.path.join(d, "host_check.cpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "factors.hpp"),
-            os.path.join(ROOT, "cerberus_amd", "csrc", "vilo_math.hpp")]
+            os.path.join(ROOT, "cerberus_amd", "csrc", "vilo_math.hpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "visual_lin.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
     lib = C.CDLL(so)
     lib.hc_correct.restype = C.c_double
+    lib.hc_vis_lin.restype = C.c_double
     return lib
 
 
@@ -53,6 +54,59 @@ def test_proj_matches_oracle(hc, ocfg, kind):
         for a, b in zip(mine, J_o):
             b = b[:, :6] if b.shape[1] == 7 else b[:, 0]
             np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-11 * max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("outlier", [False, True])
+def test_fused_visual_forms_match_the_literal_factor_bodies(hc, kind, outlier):
+    """k_visual_linearize evaluates the projection factors from hoisted rotation products with the Huber weight folded into the
+    projection Jacobian (csrc/visual_lin.hpp). Against the literal Evaluate bodies (proj_factor, pinned to the oracle and the compiled
+    reference above) followed by the generic ceres Corrector: the corrected rows [J | r], d r / d lambda and rho(s)."""
+    rng = np.random.default_rng(70 + kind)
+    sq, a = 460.0 / 1.5, 1.0
+    for it in range(40):
+        obs, params = _proj_setup(rng, kind)
+        if kind == 0:
+            pose_i, pose_j, ex0, lam, td = params
+            ex1 = ex0.copy(); ex1[1] = -0.025
+        elif kind == 1:
+            pose_i, pose_j, ex0, ex1, lam, td = params
+        else:
+            ex0, ex1, lam, td = params
+            pose_i = rand_pose(rng, 0.3); pose_j = rand_pose(rng, 0.3)
+        # make the residual consistent (inlier) or leave it as drawn (tens of pixels: outlier)
+        r = np.zeros(2); Ji = np.zeros((2, 6)); Jj = np.zeros((2, 6)); Je0 = np.zeros((2, 6)); Je1 = np.zeros((2, 6))
+        Jl = np.zeros(2); Jt = np.zeros(2)
+
+        def literal():
+            hc.hc_proj(kind, P(obs), P(pose_i), P(pose_j), P(ex0), P(ex1), C.c_double(lam[0]), C.c_double(td[0]), C.c_double(sq), P(r), 1,
+                       P(Ji), P(Jj), P(Je0), P(Je1), P(Jl), P(Jt))
+        literal()
+        if not outlier:
+            obs[3:5] += r / sq * (1.0 - 1e-3 * rng.uniform(0.1, 1.0, size=2))   # move the observation onto the projection: sub-pixel residual
+            literal()
+            assert r @ r < a * a
+        else:
+            assert r @ r > a * a
+        # generic corrector on every column and on the residual
+        cols = np.concatenate([Ji, Jj, Je0, Je1, Jt[:, None], Jl[:, None]], axis=1)
+        want = np.zeros((2, 27)); rho0 = 0.0
+        for c in range(26):
+            r2 = r.copy(); j2 = np.ascontiguousarray(cols[:, c])
+            rho0 = hc.hc_correct(C.c_double(a), P(r2), P(j2))
+            want[:, c] = j2
+            want[:, 26] = r2
+        x0 = np.zeros(26); x1 = np.zeros(26); jl = np.zeros(2)
+        got_rho = hc.hc_vis_lin(kind, P(obs), P(pose_i), P(pose_j), P(ex0), P(ex1), C.c_double(lam[0]), C.c_double(td[0]), C.c_double(sq),
+                                C.c_double(a), P(x0), P(x1), P(jl))
+        got = np.stack([x0, x1])
+        scale = max(1.0, np.abs(want).max())
+        np.testing.assert_allclose(got[:, :25], want[:, :25], rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(jl, want[:, 25], rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[:, 25], want[:, 26], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(got_rho, rho0, rtol=1e-10, atol=1e-13)   # (rho = |r|^2 of a sub-pixel residual formed by cancellation)
+        if kind != 1:
+            assert np.all(got[:, 18:24] == 0.0) if kind == 0 else np.all(got[:, 0:12] == 0.0)
 
 
 def test_imu_leg_raw_matches_oracle(hc, ocfg, small_window):

@@ -32,3 +32,10 @@ print("chain, frame 5 (window 0): loads + S_k %d  chol13 %d  substitutions %d  S
       (c[16] - c[16], c[17] - c[16], c[18] - c[17], c[19] - c[18], c[20] - c[19]))
 print("bias back-substitution (window 0): M / T_A copy %d  c = g - B yP %d  forward sweep %d  backward sweep %d" %
       (c[21] - c[6], c[22] - c[21], c[23] - c[22], c[7] - c[23]))
+vis = np.zeros(5)
+for w in sample:
+    c = b.fetch(12, w).view(np.int64)
+    vis += c[28:33].astype(np.float64)
+vis /= len(sample)
+print("k_visual_linearize, first packed wave of a window (%d lanes, %d frames): total %d cycles, factor evaluation + row staging %d, Gram MFMA pass %d" %
+      (vis[3], vis[4], vis[0], vis[1], vis[2]))
