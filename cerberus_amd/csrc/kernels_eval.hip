@@ -10,46 +10,67 @@ using namespace vilo;
 // iteration loop: one wave per interval, computed once per solve. cov = M M^T with M upper triangular
 // (Cholesky of the index-reversed matrix), sqrt_info = M^-1. No explicit inverse of cov is formed.
 // -------------------------------------------------------------------------------------------------
+// Register form: lane i owns row i of the index-reversed covariance (N <= 31 doubles per lane); pivots and factor entries reach the
+// other lanes through v_readlane (SGPR broadcast, no LDS round trip, no barrier): right-looking Cholesky, then column c of M^-1 by back
+// substitution in lane c with the factor broadcast entry by entry. The arithmetic (operands, order of the subtractions, sqrt and division
+// of the pivots) is the one of a left-looking loop over LDS, which this replaces: 98 k -> ~20 k cycles per 31 x 31 record.
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
 template <int N>
-__device__ void sqrt_info_wave(const double *cov, double *U_out, double *R /*LDS N*(N+1)*/, double *Ub /*LDS N*(N+1)*/,
-                               int *status) {
+__device__ __forceinline__ void sqrt_info_wave(const double *cov, double *U_out, double *R /*LDS >= N*N*/, double * /*Ub*/, int *status) {
   const int lane = threadIdx.x;
-  const int LD = N + 1;
-  for (int e = lane; e < N * N; e += 64) {
-    const int i = e / N, j = e % N;
-    R[i * LD + j] = cov[(N - 1 - i) * N + (N - 1 - j)];
-  }
+  const int row = lane < N ? lane : N - 1;
+  for (int e = lane; e < N * N; e += 64) R[e] = cov[e];   // coalesced; lane = row reads stride N (odd): no bank conflicts
   __syncthreads();
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = R[(N - 1 - row) * N + (N - 1 - j)];
+  bool bad = false;
+#pragma unroll
   for (int j = 0; j < N; ++j) {
-    double s = 0.0;
-    if (lane >= j && lane < N) {
-      s = R[lane * LD + j];
-      for (int k = 0; k < j; ++k) s -= R[lane * LD + k] * R[j * LD + k];
+    double piv = bcast_lane(a[j], j);
+    if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
+    const double d = sqrt(piv);
+    const double lj = (row == j) ? d : a[j] / d;   // (rows above the diagonal carry values nobody reads)
+    a[j] = lj;
+#pragma unroll
+    for (int q = j + 1; q < N; ++q) {
+      a[q] -= lj * bcast_lane(lj, q);
+      if (((q - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // eight broadcasts (SGPR pairs) in flight at a time: hoisted together they spill
     }
-    __syncthreads();
-    if (lane == j) {
-      if (!(s > 0.0) || !isfinite(s)) { *status = 1; s = 1.0; }
-      R[j * LD + j] = sqrt(s);
-    }
-    __syncthreads();
-    if (lane > j && lane < N) R[lane * LD + j] = s / R[j * LD + j];
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // M(i,k) = L(N-1-i, N-1-k) (upper). Column c of U = M^-1 by back substitution, one lane per column.
+  if (bad && lane == 0) *status = 1;
+  // M(i,k) = L(N-1-i, N-1-k) (upper). Column c = lane of U = M^-1 by back substitution; U(k,c) = 0 below the diagonal, so every lane can
+  // run the sum to the end (the extra terms are exact zeros)
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(a[j]));   // (opaque: else the broadcasts above are recognised and kept alive in SGPRs)
+  double u[N];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = (i == lane) ? 1.0 : 0.0;
+    // (the source lane is opaque per row: as constants, instruction selection emits the 496 broadcasts of all rows up front — they depend
+    // on nothing that changes here — and the register allocator spills every one of them)
+    int src = N - 1 - i;
+    asm volatile("" : "+s"(src));
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) {
+      s -= bcast_lane(a[N - 1 - k], src) * u[k];
+      if (((k - i) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    double v = s / bcast_lane(a[N - 1 - i], src);
+    asm volatile("" : "+v"(v));   // (pins this row's arithmetic before the next row's broadcasts)
+    u[i] = (i <= lane) ? v : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (lane < N) {
-    const int c = lane;
-    for (int i = N - 1; i >= 0; --i) {
-      double v = 0.0;
-      if (i <= c) {
-        double s = (i == c) ? 1.0 : 0.0;
-        for (int k = i + 1; k <= c; ++k) s -= R[(N - 1 - i) * LD + (N - 1 - k)] * Ub[k * LD + c];
-        v = s / R[(N - 1 - i) * LD + (N - 1 - i)];
-      }
-      Ub[i * LD + c] = v;
-    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) U_out[i * N + lane] = u[i];
   }
-  __syncthreads();
-  for (int e = lane; e < N * N; e += 64) U_out[e] = Ub[(e / N) * LD + (e % N)];
 }
 
 // The reference's route taken literally (imu_leg_factor.cpp:197-198: LLT(covariance.inverse()).matrixL().transpose()): the inverse by

@@ -316,45 +316,48 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
 // =================================================================================================
 // k_solve_wave
 // =================================================================================================
-// LDS map (doubles; 5120 = 40960 B per workgroup, four workgroups per CU)
-#define WS_C 0          // 15 lower tiles, 256 each, element (r, c) of a tile at 16 r + ((c + r) & 15): conflict-free for accumulator-order
-                        // accesses (row lk + 4 reg, column lr) and for operand-order accesses (row lr, column 4 kk + lk)
-#define WS_G 3840
-#define WS_DH2 3920
-#define WS_Y 4000
-#define WS_V 4080
-#define WS_SCR 4160
-#define WS_TOTAL 5120
-// while the pose tiles live in registers (until the Cholesky) their LDS region holds vectors of the speed / leg-bias part
-#define WC_VB 0         // [144] v = g / dhat^2
+// LDS map (doubles; 2176 = 17408 B per workgroup: eight workgroups per CU = two per SIMD, the register file's limit at 256 VGPRs — the
+// latency-bound phases of one window (readlane chains of the 13 x 13 / 16 x 16 factorisations, substitutions, memory round trips) run
+// under the matrix-core phases of the other). The pose system and its Cholesky factor live in REGISTERS from the tile load to the
+// backward solve; LDS only stages what changes layout between accumulator order and operand order.
+#define WS_C 0          // 1024: scratch region with three lives
+#define WS_G 1024
+#define WS_DH2 1104
+#define WS_Y 1184
+#define WS_V 1264
+#define WS_SCR 1344
+#define WS_TOTAL 2176
+// (1) chain + Schur pass: vectors of the speed / leg-bias part
 #define WC_DB 144       // [144] dhat^2
 #define WC_GB 288       // [144] gradient
+// (2) Cholesky: the panel tiles L_Ij (I > j) of the current block column, slot I - j - 1, 256 each, element (r, c) of a tile at
+//     16 r + ((c + r) & 15): conflict-free for accumulator-order stores (row lk + 4 reg, column lr) and operand-order reads (row lr, column 4 kk + lk)
+// (3) back-substitution of the speed / leg-bias part: M_k and T_A of the frame in flight
+#define WB_M 0          // [169]
+#define WB_TA 176       // [169]
 // scratch during the chain
 #define WX_LM 0         // 13 x 13: M_k = L_k^-1
 #define WX_TA0 176
 #define WX_TA1 352
 #define WX_SN 528       // 13 x 13: S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
-// scratch during the Cholesky / solves
+// scratch during the Cholesky
 #define WX_D16 0        // 16 x 17
 #define WX_LI16 272     // 16 x 17 + 16
 #define WX_P16 560      // 16 x 17
-#define WX_COL 832      // [80] reciprocal diagonal of the factor
-// back-substitution of the speed / leg-bias part (the factor in the C region is dead by then)
-#define WB_M 0          // [11][169]
-#define WB_TA 1859      // [11][169]
+// back-substitution of the speed / leg-bias part, step
 #define WX_U 0          // [144]
 #define WX_YB 144       // [144]
 #define WX_DEL 288      // [224] step of the camera dimensions
 
 extern "C" size_t vilo_solve_wave_lds_bytes() { return (size_t)WS_TOTAL * sizeof(double); }
 
-__device__ __forceinline__ int cswz(int t, int r, int c) { return WS_C + 256 * t + 16 * r + ((c + r) & 15); }
+__device__ __forceinline__ int pswz(int slot, int r, int c) { return WS_C + 256 * slot + 16 * r + ((c + r) & 15); }
 
 // 16 x 16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80 x 80 factorisation).
 // A: LDS 16 x 17 row-major in. Lane i (< 16, replicated in the four 16-lane groups) owns row i; pivots broadcast with v_readlane.
-// Writes L^-1 (lower, zeros above) to Linv (16 x 17, for the panel products) and into swizzled tile t of the C region (for the triangular
-// solves: nothing reads L_jj itself again). Returns 0 / 1 (not positive definite).
-__device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, double *Linv, bool need_inv) {
+// Writes L^-1 (lower, zeros above) to Linv (16 x 17): the panel products and the backward solve need L_jj^-1, nothing reads L_jj again.
+// Returns 0 / 1 (not positive definite).
+__device__ __forceinline__ int chol16_tile(const double *A, double *Linv) {
   const int lane = threadIdx.x & 63;
   const int row = lane & 15;
   double a[16];
@@ -373,7 +376,6 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
 #pragma unroll
     for (int q = j + 1; q < 16; ++q) a[q] -= lj * readlane_d(lj, q);
   }
-  (void)need_inv;
   // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers. (The copies are opaque to the
   // compiler: it would otherwise recognise these broadcasts as the ones of the factorisation loop and keep all 120 alive in SGPRs.)
 #pragma unroll
@@ -385,15 +387,14 @@ __device__ __forceinline__ int chol16_tile(double *lds, const double *A, int t, 
 #pragma unroll
     for (int q = 0; q < i; ++q) v -= readlane_d(a[q], i) * cl[q];   // L[i][q] lives in lane i, register q
     cl[i] = v * readlane_d(myrinv, i);
-    __builtin_amdgcn_sched_barrier(0);   // keep the v_readlane results (SGPR pairs) of one row at a time: hoisted, they spill by the hundred
+    // keep the v_readlane results (SGPR pairs) of one row at a time: the broadcasts depend on nothing that changes in this loop, so
+    // instruction selection emits them all up front and they spill by the hundred unless every row's arithmetic is pinned in place
+    asm volatile("" : "+v"(cl[i]));
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const double li = (i >= lane) ? cl[i] : 0.0;
-      Linv[i * 17 + lane] = li;
-      lds[cswz(t, i, lane)] = li;
-    }
+    for (int i = 0; i < 16; ++i) Linv[i * 17 + lane] = (i >= lane) ? cl[i] : 0.0;
   }
   lds_fence();
   return fail;
@@ -573,6 +574,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
             for (int q = 0; q < i; ++q) vv -= readlane_d(l[q], i) * cl[q];
             cl[i] = vv * readlane_d(myrinv, i);
+            asm volatile("" : "+v"(cl[i]));
             __builtin_amdgcn_sched_barrier(0);   // (one row's v_readlane results at a time)
           }
           if (c < 13 && grp < 2) {
@@ -738,19 +740,26 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       if (lane == 0) st.phase_clk[4] = clock64();
 
       // ---- dense Cholesky of the 80 x 80 reduced pose system, blocked by 16: diagonal tile in registers + v_readlane (also its
-      //      inverse), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores. L is left in the C
-      //      region (swizzled lower tiles) for the solves ----
+      //      inverse), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores. The reduced right-hand
+      //      side rides along as a sixth block row (one row of a tile), which makes it y = L^-1 rhs by the end: the forward solve costs
+      //      the same 60 MFMAs and the factor never has to be read in operand order again — it stays in the accumulator registers
+      //      (L_Ij, and L_jj^-1 in the diagonal tiles), which IS the operand order of L^T for the backward solve ----
       {
         double *D16 = scr + WX_D16, *LI16 = scr + WX_LI16, *P16 = scr + WX_P16;
+        double vrow[5];   // lane (lr, lk == 0): entry 16 J + lr of the right-hand-side row
+#pragma unroll
+        for (int J = 0; J < 5; ++J) vrow[J] = (lk == 0) ? v[16 * J + lr] : 0.0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[tile_index(j, j)][r];
           lds_fence();
-          fail |= chol16_tile(lds, D16, tile_index(j, j), LI16, j < 4);
+          fail |= chol16_tile(D16, LI16);
           double li[4];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) li[kk] = LI16[lr * 17 + 4 * kk + lk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[tile_index(j, j)][r] = LI16[(lk + 4 * r) * 17 + lr];   // L_jj^-1 in accumulator order
 #pragma unroll
           for (int I = j + 1; I < 5; ++I) {
             const int t = tile_index(I, j);
@@ -762,15 +771,29 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
             acc[t] = nacc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[cswz(t, lk + 4 * r, lr)] = nacc[r];
+            for (int r = 0; r < 4; ++r) lds[pswz(I - j - 1, lk + 4 * r, lr)] = nacc[r];
             lds_fence();   // (P16 is reused by the next panel)
+          }
+          // right-hand-side row: y_j^T = rhs_j^T L_jj^-T; its operand-order copy (row 0 of a tile) through the LDS vector y
+          double pv[4];
+          {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P16[(lk + 4 * r) * 17 + lr] = (r == 0) ? vrow[j] : 0.0;
+            lds_fence();
+            mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
+            if (lk == 0) y[16 * j + lr] = nacc[0];
+            lds_fence();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) pv[kk] = (lr == 0) ? y[16 * j + 4 * kk + lk] : 0.0;
           }
           // trailing update: operand (row lr, columns 4 kk + lk) of every panel tile once
           double pa[5][4];
 #pragma unroll
           for (int I = j + 1; I < 5; ++I)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) pa[I][kk] = lds[cswz(tile_index(I, j), lr, 4 * kk + lk)];
+            for (int kk = 0; kk < 4; ++kk) pa[I][kk] = lds[pswz(I - j - 1, lr, 4 * kk + lk)];
 #pragma unroll
           for (int I = j + 1; I < 5; ++I)
 #pragma unroll
@@ -778,6 +801,14 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
               for (int kk = 0; kk < 4; ++kk)
                 acc[tile_index(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[I][kk], pa[J][kk], acc[tile_index(I, J)], 0, 0, 0);
+#pragma unroll
+          for (int J = j + 1; J < 5; ++J) {
+            mfma_d4 tv = {vrow[J], 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) tv = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[kk], pa[J][kk], tv, 0, 0, 0);
+            vrow[J] = tv[0];
+          }
+          lds_fence();   // (the panel slots are rewritten by the next block column)
         }
       }
       if (fail) {
@@ -799,50 +830,29 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       }
       if (lane == 0) st.phase_clk[5] = clock64();
 
-      // ---- L L^T yP = rhs ----
-      // M_k / T_A(k) of the chain (written to global memory by this wave) come back for the bias sweeps: the loads fly during the solves
-      double mreg[30], tareg[30];
+      // ---- L^T yP = y (the forward solve rode along with the factorisation) ----
       {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const double *Mg_ = b.Lk + (size_t)win * 11 * 169, *TAg_ = b.TAg + (size_t)win * 11 * 169;
-#pragma unroll
-        for (int u = 0; u < 30; ++u) {
-          const int e = min(lane + 64 * u, F * 169 - 1);
-          mreg[u] = Mg_[e]; tareg[u] = TAg_[e];
-        }
-      }
-      {
-        // Blockwise on the FP64 matrix cores, with the inverses of the diagonal tiles (kept in the factor's diagonal tiles):
-        //   forward   y_j = L_jj^-1 (b_j - sum_{i<j} L_ji y_i),   backward   x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i).
-        // A block vector lives in accumulator order, replicated over the 16 columns (register r of lane (lr, lk) = entry lk + 4 r), which
-        // is the B-operand order of the next product: the 2 x 60 MFMAs touch no memory but the factor's operand reads.
+        // Blockwise on the FP64 matrix cores: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i). A block vector lives in accumulator order,
+        // replicated over the 16 columns (register r of lane (lr, lk) = entry lk + 4 r), which is the B-operand order of the next
+        // product; the A operands are the factor's accumulator registers as they stand.
         mfma_d4 yb[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          mfma_d4 accv;
+        for (int j = 0; j < 5; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) accv[r] = v[16 * j + lk + 4 * r];
-#pragma unroll
-          for (int i = 0; i < j; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds[cswz(tile_index(j, i), lr, 4 * kk + lk)], yb[i][kk], accv, 0, 0, 0);
-          mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[cswz(tile_index(j, j), lr, 4 * kk + lk)], accv[kk], n, 0, 0, 0);
-          yb[j] = n;
-        }
+          for (int r = 0; r < 4; ++r) yb[j][r] = y[16 * j + lk + 4 * r];
 #pragma unroll
         for (int j = 4; j >= 0; --j) {
           mfma_d4 accv = yb[j];
 #pragma unroll
           for (int i = j + 1; i < 5; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds[cswz(tile_index(i, j), 4 * kk + lk, lr)], yb[i][kk], accv, 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[tile_index(i, j)][kk], yb[i][kk], accv, 0, 0, 0);
           mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[cswz(tile_index(j, j), 4 * kk + lk, lr)], accv[kk], n, 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tile_index(j, j)][kk], accv[kk], n, 0, 0, 0);
           yb[j] = n;
         }
+        lds_fence();
         if (lr == 0) {
 #pragma unroll
           for (int j = 0; j < 5; ++j)
@@ -865,11 +875,6 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       const double *lm_g = b.lm_gbuf[st.cur] + lmoff_b, *lm_dh2 = b.lm_dh2 + lmoff_b, *lm_einv = b.lm_einv + lmoff_b;
       double *lm_y = b.lm_y + lmoff_b;
       {
-#pragma unroll
-        for (int u = 0; u < 30; ++u) {
-          const int e = lane + 64 * u;
-          if (e < 11 * 169) { lds[WB_M + e] = mreg[u]; lds[WB_TA + e] = tareg[u]; }
-        }
         double *U = scr + WX_U, *YB = scr + WX_YB;
         if (lane == 0) st.phase_clk[21] = clock64();
         // c: the IMU part of B_k spans poses k-1 .. k+1 (one dimension per lane and trip), the prior part frame kb only
@@ -902,33 +907,63 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         lds_fence();
         const int row = lr < 13 ? lr : 0;
         if (lane == 0) st.phase_clk[22] = clock64();
+        // M_k / T_A(k) of the chain (written to global memory by this wave, L2-resident) come back one frame at a time: the next
+        // frame's 2 x 169 values are in flight while this frame's are used out of LDS
+        double *MB = lds + WB_M, *TB = lds + WB_TA;
+        const double *Mg_ = b.Lk + (size_t)win_b * 11 * 169, *TAg_ = b.TAg + (size_t)win_b * 11 * 169;
+        int pe[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) pe[m] = min(lane + 64 * m, 168);
+        double pm[3], pt[3];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { pm[m] = Mg_[(F - 1) * 169 + pe[m]]; pt[m] = 0.0; }
         // forward sweep
         double unext = 0.0;   // u_{k+1}[row]
         for (int k = F - 1; k >= 0; --k) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (lane + 64 * m < 169) { MB[pe[m]] = pm[m]; TB[pe[m]] = pt[m]; }
+          {
+            // next step: M_{k-1}, T_A(k); after the last one the backward sweep's first frame: M_0 (again) and nothing
+            const int kn = max(k - 1, 0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { pm[m] = Mg_[kn * 169 + pe[m]]; pt[m] = TAg_[k * 169 + pe[m]]; }
+          }
+          lds_fence();
           double s = U[13 * k + row];
           if (k < F - 1) {
 #pragma unroll
-            for (int q = 0; q < 13; ++q) s -= lds[WB_TA + (k + 1) * 169 + q * 13 + row] * readlane_d(unext, q);
+            for (int q = 0; q < 13; ++q) s -= TB[q * 13 + row] * readlane_d(unext, q);
           }
           double u = 0.0;
 #pragma unroll
-          for (int q = 0; q < 13; ++q) u += lds[WB_M + k * 169 + row * 13 + q] * readlane_d(s, q);
+          for (int q = 0; q < 13; ++q) u += MB[row * 13 + q] * readlane_d(s, q);
           if (lane < 13) U[13 * k + lane] = u;
           unext = u;
         }
         lds_fence();
         if (lane == 0) st.phase_clk[23] = clock64();
-        // backward sweep
+        // backward sweep (pm holds M_0; T_A(0) does not exist)
         double yprev = 0.0;
         for (int k = 0; k < F; ++k) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (lane + 64 * m < 169) { MB[pe[m]] = pm[m]; TB[pe[m]] = pt[m]; }
+          {
+            const int kn = min(k + 1, F - 1);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { pm[m] = Mg_[kn * 169 + pe[m]]; pt[m] = TAg_[kn * 169 + pe[m]]; }
+          }
+          lds_fence();
           double s = U[13 * k + row];
           if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < 13; ++q) s -= lds[WB_TA + k * 169 + row * 13 + q] * readlane_d(yprev, q);
+            for (int q = 0; q < 13; ++q) s -= TB[row * 13 + q] * readlane_d(yprev, q);
           }
           double yk = 0.0;
 #pragma unroll
-          for (int q = 0; q < 13; ++q) yk += lds[WB_M + k * 169 + q * 13 + row] * readlane_d(s, q);
+          for (int q = 0; q < 13; ++q) yk += MB[q * 13 + row] * readlane_d(s, q);
           if (!cd_active(CD_B0 + 13 * k + row, F, cmask)) yk = 0.0;
           if (lane < 13) YB[13 * k + lane] = yk;
           yprev = yk;
