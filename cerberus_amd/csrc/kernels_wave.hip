@@ -14,6 +14,7 @@
 //                     part with its coupling rows T(k) and C -= T^T T on the FP64 matrix cores  ->  landmark Schur complement on the
 //                     matrix cores straight from global memory  ->  blocked 80 x 80 Cholesky  ->  triangular solves  ->  bias and landmark
 //                     back-substitution  ->  dogleg step and candidate state.
+#include <type_traits>
 #include "solve_common.hpp"
 
 using namespace vilo;
@@ -682,30 +683,52 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           yacc[X] = 0.0;
         }
         const int nks = (L + 3) >> 2;
+        // A landmark that starts in frame s couples with poses s .. only: rows 0 .. 6 s - 1 of its coupling column are structural zeros
+        // (k_visual_linearize writes them as such), and the landmarks of a window are ordered by start frame. A trip of 16 landmarks
+        // whose first one starts in frame s >= 3 has nothing in tile row 0 (rows 0 .. 15): neither loaded nor multiplied — 10 tiles
+        // instead of 15. Two branch-free forms of the trip, chosen per trip (per-tile conditions inside one form stall the MFMA stream).
+        int *skip_tab = (int *)(scr + WX_LM);   // (the chain's scratch is dead)
+        const int ntrip = (L + 15) >> 4;
+        if (L > 0) {
+          const unsigned char *lms = b.lm_s + wm.lm_off;
+          for (int tr = lane; tr < ntrip + 2; tr += 64) skip_tab[tr] = (6 * (int)lms[min(16 * tr, L - 1)] >= 16) ? 1 : 0;
+          lds_fence();
+        }
         double opb[2][4][5], eb[2][4], gb[2][4], db[2][4];
         auto ldtrip = [&](int kk0, int bsel) {
+          const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(kk0 >> 2, ntrip)]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int l = 4 * (kk0 + u) + lk, lc = min(l, L - 1);
             eb[bsel][u] = lm_einv[lc]; gb[bsel][u] = lm_g[lc]; db[bsel][u] = lm_y[lc];
 #pragma unroll
-            for (int X = 0; X < 5; ++X) opb[bsel][u][X] = wl[(size_t)(16 * X + lr) * L + lc];
+            for (int X = 1; X < 5; ++X) opb[bsel][u][X] = wl[(size_t)(16 * X + lr) * L + lc];
+          }
+          if (!skip0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) opb[bsel][u][0] = wl[(size_t)lr * L + min(4 * (kk0 + u) + lk, L - 1)];
           }
         };
-        auto dotrip = [&](int kk0, int bsel) {
+        auto dotrip = [&](int kk0, int bsel, auto xl) {
+          constexpr int XL = decltype(xl)::value;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int l = 4 * (kk0 + u) + lk;
             const double ei = (l < L) ? eb[bsel][u] : 0.0, ge = gb[bsel][u] * ei, vl = (l < L) ? db[bsel][u] : 0.0;
             double op[5];
 #pragma unroll
-            for (int X = 0; X < 5; ++X) op[X] = opb[bsel][u][X] * actv[X];
+            for (int X = 0; X < 5; ++X) op[X] = (X >= XL) ? opb[bsel][u][X] * actv[X] : 0.0;
 #pragma unroll
             for (int t = 0; t < 15; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[c_tI[t]] * ei), op[c_tJ[t]], acc[t], 0, 0, 0);
+              if (c_tJ[t] >= XL) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(op[c_tI[t]] * ei), op[c_tJ[t]], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int X = 0; X < 5; ++X) { yacc[X] += op[X] * ge; qacc += op[X] * vv[X] * vl; }
+            for (int X = XL; X < 5; ++X) { yacc[X] += op[X] * ge; qacc += op[X] * vv[X] * vl; }
           }
+        };
+        auto trip = [&](int kk0, int bsel) {
+          const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(kk0 >> 2, ntrip)]);
+          if (skip0) dotrip(kk0, bsel, std::integral_constant<int, 1>{});
+          else dotrip(kk0, bsel, std::integral_constant<int, 0>{});
         };
         if (L > 0) {
           // the landmark vectors written above (lm_einv, lm_y) are read back through global memory by other lanes
@@ -713,9 +736,9 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           ldtrip(0, 0);
           for (int kk0 = 0; kk0 < nks; kk0 += 8) {
             ldtrip(kk0 + 4, 1);
-            dotrip(kk0, 0);
+            trip(kk0, 0);
             ldtrip(kk0 + 8, 0);
-            dotrip(kk0 + 4, 1);
+            trip(kk0 + 4, 1);
           }
         }
         if (!have_q) {
@@ -897,9 +920,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
         lds_fence();
         if (kb >= 0) {
-          double sacc = 0.0;
-          if (lr < 13)
-            for (int p = lk; p < VILO_NPU; p += 4) sacc += bimg[BI_BP + lr * 80 + p] * y[p];
+          // (unrolled: as a rolled loop every one of its 20 dependent-free loads waited out a memory round trip on its own)
+          double sacc = 0.0, bpv[20];
+#pragma unroll
+          for (int u = 0; u < 20; ++u) bpv[u] = (lr < 13 && lk + 4 * u < VILO_NPU) ? bimg[BI_BP + lr * 80 + lk + 4 * u] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 20; ++u) sacc += bpv[u] * y[min(lk + 4 * u, 79)];
           sacc += __shfl_xor(sacc, 16, 64);
           sacc += __shfl_xor(sacc, 32, 64);
           if (lane < 13) U[13 * kb + lane] -= sacc;

@@ -120,6 +120,7 @@ struct BatchDev {
   double *x, *xc, *x0;        // [W][XSTRIDE] current / candidate / initial
   double *lam, *lamc, *lam0;  // [n_lm]
   int *lm_perm;               // device order -> original index within its window
+  unsigned char *lm_s;        // [n_lm] start frame of a landmark (ascending inside a window): its coupling rows below pose s are structurally zero
   // landmark-side linearisation
   double *lm_E, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
   double *lm_gbuf[2];         // [n_lm] x 2: landmark gradients of the current linearisation (SolverState::cur) and of the candidate's

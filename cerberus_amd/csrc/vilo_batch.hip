@@ -194,6 +194,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   std::vector<WaveMeta> waves;
   std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
   std::vector<double> x0((size_t)W * XSTRIDE, 0.0), lam0;
+  std::vector<unsigned char> lm_s;   // start frame per landmark (device order)
   std::vector<double> px0((size_t)W * 280, 0.0);
   // J0 / r0 of the priors, packed n x n per window, staged for k_prior_pack (uninitialised storage: only n x n of a slot is read)
   double *pJ = (double *)vilo_host_stage(ctx, 0, sizeof(double) * (size_t)W * 96 * 96), *pr0 = (double *)vilo_host_stage(ctx, 1, sizeof(double) * (size_t)W * 96);
@@ -256,6 +257,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
           const int l = ids[c0 + i];
           bt->perm_host.push_back(l);
           lam0.push_back(s.inv_depth[l]);
+          lm_s.push_back((unsigned char)sf);
         }
         chunk_ids.push_back(std::vector<int>(ids.begin() + c0, ids.begin() + c0 + n));
         local += n;
@@ -417,6 +419,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_upload_raw(ctx, bt, &D.flags, flags, flags_total));
   TRYB(dev_upload(ctx, bt, &D.x0, x0));
   TRYB(dev_upload(ctx, bt, &D.lam0, lam0));
+  TRYB(dev_upload(ctx, bt, &D.lm_s, lm_s));
   TRYB(dev_upload(ctx, bt, &D.lm_perm, bt->perm_host));
   TRYB(dev_alloc(ctx, bt, &D.x, (size_t)W * XSTRIDE));
   TRYB(dev_alloc(ctx, bt, &D.xc, (size_t)W * XSTRIDE));
