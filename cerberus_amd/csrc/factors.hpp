@@ -14,6 +14,21 @@
 #pragma once
 #include "vilo_math.hpp"
 
+// Per-(chunk, t) Gram slot of the visual factors: packed upper triangle of X^T X, X = the corrected [J | r] rows of the chunk's landmarks
+// seen from frame s + t, in 23 columns. d r / d P_j = - d r / d P_i in both two-frame factors (projectionTwoFrameOneCamFactor.cpp:97-107,
+// projectionTwoFrameTwoCamFactor.cpp:100-112), so the translation columns are stored once; the order puts everything the left-camera
+// factor touches except td into the first 16 columns = one FP64-MFMA tile.
+#define GC_T 0             // d r / d P_i (3); the P_j columns are their negatives
+#define GC_RI 3            // d r / d theta_i (3)
+#define GC_RJ 6            // d r / d theta_j (3)
+#define GC_E0 9            // ex0 (6)
+#define GC_R 15            // residual
+#define GC_E1 16           // ex1 (6)
+#define GC_TD 22           // td
+#define VILO_GCOLS 23
+#define VILO_GRAM 276      // 23 * 24 / 2
+#define VILO_GRAM26 351    // consumers walk the 26-column view [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td | r] through gram26_index
+
 namespace vilo {
 
 // ---------------------------------------------------------------------------------------------

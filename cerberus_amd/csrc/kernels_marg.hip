@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <chrono>
 
-#include "solver_types.hpp"
+#include "solve_common.hpp"
 
 using namespace vilo;
 
@@ -177,13 +177,15 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
       if (cm.s != 0) continue;
       for (int t = 0; t < cm.kmax; ++t) {
         const double *gs = bd.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
-        for (int e = tid; e < VILO_GRAM; e += MT) {
+        for (int e = tid; e < VILO_GRAM26; e += MT) {   // the 26-column view of the slot
           int a = 0, rem = e;
           while (rem >= 26 - a) { rem -= 26 - a; ++a; }
           const int bc = a + rem;
           if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;
           auto cdof = [&](int c) { return c < 6 ? c : (c < 12 ? 6 * t + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
-          const double v = gs[e];
+          double sg;
+          const int ge = gram26_index(a, bc, sg);
+          const double v = sg * gs[ge];
           if (bc == 25) { if (a < 25) { const int q = M.cdmap[cdof(a)]; if (q >= 0) bv[q] += v; } }
           else {
             add(cdof(a), cdof(bc), v);
@@ -471,13 +473,15 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
       if (cm.s != 0) continue;
       for (int t = 0; t < cm.kmax; ++t) {
         const double *gs = bd.gram + (size_t)(cm.gram_off + t) * VILO_GRAM;
-        for (int e = tid; e < VILO_GRAM; e += MGT) {
+        for (int e = tid; e < VILO_GRAM26; e += MGT) {   // the 26-column view of the slot
           int a = 0, rem = e;
           while (rem >= 26 - a) { rem -= 26 - a; ++a; }
           const int bc = a + rem;
           if (t == 0 && ((a >= 6 && a < 12) || (bc >= 6 && bc < 12))) continue;
           auto cdof = [&](int c) { return c < 6 ? c : (c < 12 ? 6 * t + (c - 6) : (c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD))); };
-          const double v = gs[e];
+          double sg;
+          const int ge = gram26_index(a, bc, sg);
+          const double v = sg * gs[ge];
           if (bc == 25) { if (a < 25) { const int q = loc(cdof(a)); if (q >= 0) b1[q] += v; } }
           else {
             add(cdof(a), cdof(bc), v);

@@ -75,7 +75,8 @@ __device__ double block_max(double v, double *red) {
 // right after an accepted candidate and has one buffer.
 __device__ __forceinline__ bool lin_skip(const SolverState &st, int mode) { return st.done || (mode == 0 && !st.need_lin); }
 __device__ __forceinline__ double *lin_lm_g(BatchDev &b, const SolverState &st, int mode) { return mode ? b.lm_gbuf[1 - st.cur] : b.lm_gbuf[0]; }
-#define XLANE 54  // LDS stride per lane: 2 rows x 26 cols + 2 pad; even so that every row starts 16-byte aligned (ds_read_b128)
+#define XROW 24   // LDS stride of a row: 23 columns + 1 pad (rows start 16-byte aligned: ds_write_b128)
+#define XLANE 50  // LDS stride per lane: 2 rows + 2 pad (8 consecutive lanes of a 16-byte store hit 8 distinct groups of 4 banks)
 
 // Per-lane view of a packed wave (WaveMeta): which chunk (start frame) a lane belongs to.
 struct LaneSeg {
@@ -130,13 +131,17 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const int li = ls.li;
   for (int e = lane; e < XSTRIDE; e += 64) xs[e] = xg[e];
 
-  // Gram of a (start frame, t) slot on the FP64 matrix cores: X^T X with X = the 2 n corrected Jacobian rows (26 columns,
+  // Gram of a (start frame, t) slot on the FP64 matrix cores: X^T X with X = the 2 n corrected Jacobian rows (23 columns,
   // padded to 32) as three 16 x 16 tiles (0,0), (0,1), (1,1). One k-step = 4 rows = 2 landmarks; lane (lr, lk) supplies
   // X[row 4 kk + lk][lr] (tile column 0) and X[..][16 + lr] (tile column 1), which serve as A and B operands alike.
   // Every segment of the wave (its own start frame) accumulates into its own three tiles.
+  // The first tile column holds everything a left-camera factor touches except td (factors.hpp: GC_*): while td is a constant block of
+  // the solve (estimate_td: 0, estimator.cpp:1104) its rows need tile (0,0) only — one MFMA per k-step instead of three. (The
+  // marginalisation keeps td: mode 0 always runs the full form.)
   const int lr = lane & 15, lk = lane >> 4;
-  const int xoff = (lk >> 1) * XLANE + (lk & 1) * 26 + lr;
-  const bool c1on = lr < 10;   // columns 26 .. 31 of the second tile column do not exist
+  const int xoff = (lk >> 1) * XLANE + (lk & 1) * XROW + lr;
+  const bool c1on = lr < 7;    // columns 23 .. 31 of the second tile column do not exist
+  const bool lean = mode != 0 && (wm.const_mask & CONST_TD);
   // (coupling rows w: every row of a landmark's column is written exactly once — the observed poses and the extrinsic / td rows with their
   // sums, the rest with zeros at the end; TPAR: the host clears w before the launch, the frames of a landmark run in different workgroups)
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
@@ -242,10 +247,11 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
       const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
-      double *xr0 = &X[lane * XLANE], *xr1 = xr0 + 26;
+      double *xr0 = &X[lane * XLANE], *xr1 = xr0 + XROW;
       c_a = clock64();
       if (produce) {
-        double x0[26], x1[26], Jl[2], obc[5];
+        double x0[XROW], x1[XROW], Jl[2], obc[5];
+        x0[23] = 0.0; x1[23] = 0.0;
         double rho0;
         if (cam == 0) {
           obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
@@ -259,15 +265,19 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
         double term[LM_NTERM];
         term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
-        term[1] = Jl[0] * x0[25] + Jl[1] * x1[25];
+        term[1] = Jl[0] * x0[GC_R] + Jl[1] * x1[GC_R];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           term[2 + c] = x0[c] * Jl[0] + x1[c] * Jl[1];
-          term[8 + c] = x0[12 + c] * Jl[0] + x1[12 + c] * Jl[1];
-          term[14 + c] = x0[18 + c] * Jl[0] + x1[18 + c] * Jl[1];
-          wj[c] += x0[6 + c] * Jl[0] + x1[6 + c] * Jl[1];
+          term[8 + c] = x0[GC_E0 + c] * Jl[0] + x1[GC_E0 + c] * Jl[1];
+          term[14 + c] = x0[GC_E1 + c] * Jl[0] + x1[GC_E1 + c] * Jl[1];
         }
-        term[20] = x0[24] * Jl[0] + x1[24] * Jl[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          wj[c] -= term[2 + c];   // d r / d P_j = -d r / d P_i
+          wj[3 + c] += x0[GC_RJ + c] * Jl[0] + x1[GC_RJ + c] * Jl[1];
+        }
+        term[20] = x0[GC_TD] * Jl[0] + x1[GC_TD] * Jl[1];
         if (TPAR) {
           double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
 #pragma unroll
@@ -280,10 +290,10 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
           wc_td += term[20];
         }
 #pragma unroll
-        for (int c = 0; c < 26; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
+        for (int c = 0; c < XROW; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
       } else {
 #pragma unroll
-        for (int c = 0; c < 26; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+        for (int c = 0; c < XROW; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
       }
       lds_barrier();
       { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
@@ -293,8 +303,8 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
       for (int g = 0; g < 4; ++g) {
         if (g >= wv.nseg || t >= ckm[g]) continue;
         const int k0 = wv.seg_lane0[g] >> 1, k1 = k0 + (((cn[g] + 7) & ~7) >> 1);
-        // Lanes lr >= 10 of the second tile column read past column 25 (the next row / lane: in bounds, arbitrary values): they only
-        // reach rows / columns 26 .. 31 of the tiles, which nobody stores.
+        // Lanes lr >= 7 of the second tile column read past column 22 (the next row / lane: in bounds, arbitrary values): they only
+        // reach rows / columns 23 .. 31 of the tiles, which nobody stores.
         double a0[4], a1[4], n0[4], n1[4];
         auto ldtrip = [&](int kk, double *p0, double *p1) {
 #pragma unroll
@@ -304,6 +314,10 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             p1[u] = xr[16];
           }
         };
+        auto ldtrip0 = [&](int kk, double *p0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p0[u] = X[2 * (kk + u) * XLANE + xoff];
+        };
         auto dotrip = [&](const double *p0, const double *p1) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -312,21 +326,41 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1[u], p1[u], G11[g], 0, 0, 0);
           }
         };
-        // two trips per turn, the operands of the next trip in flight behind the 12 MFMAs of this one (a segment has an even number of
+        auto dotrip0 = [&](const double *p0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G00[g], 0, 0, 0);
+        };
+        // two trips per turn, the operands of the next trip in flight behind the MFMAs of this one (a segment has an even number of
         // trips or is the last of its wave: the trip after its last one reads rows that exist — zero pad lanes at the end — and is dropped)
         // (sched_barrier: the scheduler otherwise sinks every load to just before its MFMA to save registers, and the wave waits out
         // an LDS round trip per k-step)
-        ldtrip(k0, a0, a1);
-        for (int kk0 = k0; kk0 < k1; kk0 += 8) {
-          ldtrip(min(kk0 + 4, 30), n0, n1);
-          __builtin_amdgcn_sched_barrier(0);
-          dotrip(a0, a1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kk0 + 4 < k1) {
-            ldtrip(min(kk0 + 8, 30), a0, a1);
+        if (lean && cam == 0) {
+          ldtrip0(k0, a0);
+          for (int kk0 = k0; kk0 < k1; kk0 += 8) {
+            ldtrip0(min(kk0 + 4, 30), n0);
             __builtin_amdgcn_sched_barrier(0);
-            dotrip(n0, n1);
+            dotrip0(a0);
             __builtin_amdgcn_sched_barrier(0);
+            if (kk0 + 4 < k1) {
+              ldtrip0(min(kk0 + 8, 30), a0);
+              __builtin_amdgcn_sched_barrier(0);
+              dotrip0(n0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        } else {
+          ldtrip(k0, a0, a1);
+          for (int kk0 = k0; kk0 < k1; kk0 += 8) {
+            ldtrip(min(kk0 + 4, 30), n0, n1);
+            __builtin_amdgcn_sched_barrier(0);
+            dotrip(a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk0 + 4 < k1) {
+              ldtrip(min(kk0 + 8, 30), a0, a1);
+              __builtin_amdgcn_sched_barrier(0);
+              dotrip(n0, n1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
@@ -340,9 +374,9 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = lk + 4 * r;
-        if (row <= lr) gs[tri26(row, lr)] = G00[g][r];
-        if (c1on) gs[tri26(row, 16 + lr)] = G01[g][r];
-        if (c1on && row < 10 && row <= lr) gs[tri26(16 + row, 16 + lr)] = G11[g][r];
+        if (row <= lr) gs[tri23(row, lr)] = G00[g][r];
+        if (c1on) gs[tri23(row, 16 + lr)] = G01[g][r];
+        if (c1on && row < 7 && row <= lr) gs[tri23(16 + row, 16 + lr)] = G11[g][r];
       }
     }
     if (TPAR) {

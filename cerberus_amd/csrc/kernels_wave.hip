@@ -87,7 +87,10 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
     else if (tid < 141) { cls = 3; a = (tid - 57) / 14; bc = 12 + (tid - 57) % 14; }
     else if (tid < 246) { cls = 4; int rem = tid - 141; while (rem >= 14 - a) { rem -= 14 - a; ++a; } bc = 12 + a + rem; a += 12; }
     const bool isg = (bc == 25), dead = (cls == 0) || (a == 25);
-    const int e1 = tri26(min(a, 25), bc), e2 = (cls == 1) ? tri26(a + 6, bc + 6) : (cls == 3 ? tri26(a + 6, bc) : e1);
+    // (a, bc index the 26-column view [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td | r] of a slot; the packed slot has 23 columns and a sign)
+    double sg1, sg2 = 1.0;
+    const int e1 = gram26_index(min(a, 25), bc, sg1);
+    const int e2 = (cls == 1) ? gram26_index(a + 6, bc + 6, sg2) : (cls == 3 ? gram26_index(a + 6, bc, sg2) : e1);
     auto restcd = [](int c) { return c < 18 ? CD_EX0 + c - 12 : (c < 24 ? CD_EX1 + c - 18 : CD_TD); };
     const int rb = (bc >= 12 && bc < 25) ? restcd(bc) : 0, ra_ = (a >= 12 && a < 25) ? restcd(a) : 0;
     // Walk the window's chunks (fixed s, t = 0 .. kmax-1), two per trip = 44 loads in flight. Per chunk:
@@ -105,8 +108,8 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
           const int tc = min(t, km2[c2] - 1);
-          v1[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
-          v2[c2][t] = gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
+          v1[c2][t] = sg1 * gs[(size_t)(sl0 + tc) * VILO_GRAM + e1];
+          v2[c2][t] = sg2 * gs[(size_t)(sl0 + tc) * VILO_GRAM + e2];
         }
       }
 #pragma unroll

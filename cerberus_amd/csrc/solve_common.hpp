@@ -19,6 +19,24 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 }
 
 __device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+__device__ __forceinline__ int tri23(int a, int b) { return a * 23 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+// Entry (c1, c2) of the 26-column view [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td | r] of a Gram slot: index into the packed 23-column
+// slot and the sign it carries (the pose_j translation columns are minus the pose_s ones).
+__device__ __forceinline__ int gram_col(int c, int &sg) {
+  sg = 1;
+  if (c < 6) return c;
+  if (c < 9) { sg = -1; return GC_T + (c - 6); }
+  if (c < 12) return GC_RJ + (c - 9);
+  if (c < 18) return GC_E0 + (c - 12);
+  if (c < 24) return GC_E1 + (c - 18);
+  return c == 24 ? GC_TD : GC_R;
+}
+__device__ __forceinline__ int gram26_index(int c1, int c2, double &sign) {
+  int s1, s2;
+  const int m1 = gram_col(c1, s1), m2 = gram_col(c2, s2);
+  sign = (double)(s1 * s2);
+  return tri23(min(m1, m2), max(m1, m2));
+}
 __device__ __forceinline__ int tri39(int a, int b) { return a * 39 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -17,9 +17,6 @@
 #define VILO_NP 80         // pose part: 11*6 poses + 6 ex0 + 6 ex1 + 1 td = 79, padded to 80
 #define VILO_NPU 79
 #define VILO_NCAM (VILO_F * 19 + 13)   // 222
-#define VILO_GRAM 351      // packed upper triangle of the 26 x 26 per-(group, t) Gram matrix
-#define VILO_GCOLS 26      // [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td 1 | r 1]
-
 #define VILO_NKERNEL 12
 struct vilo_ctx {
   vilo_config cfg;

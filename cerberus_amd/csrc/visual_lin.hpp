@@ -102,7 +102,8 @@ VD double vis_residual(const v3 &pcj, double ptx, double pty, double sq, double 
 }
 
 // ProjectionTwoFrameOneCamFactor (CAM 0) / ProjectionTwoFrameTwoCamFactor (CAM 1) of one landmark seen from frame j.
-// x0 / x1: the two corrected rows [J_pose_i 6 | J_pose_j 6 | J_ex0 6 | J_ex1 6 | J_td | r]; Jl: d r / d lambda. Returns rho(s).
+// x0 / x1: the two corrected rows in the Gram slot's column order (vilo_internal.hpp: GC_T 3 | GC_RI 3 | GC_RJ 3 | GC_E0 6 | GC_R |
+// GC_E1 6 | GC_TD; d r / d P_j = -d r / d P_i is not stored); Jl: d r / d lambda. Returns rho(s).
 // ob: pts_j (3), vel_j (2) of this camera; dtj = td - td_j.
 template <int CAM>
 VD double vis_two_frame(const double *wt, const double *tb, const VisLane &L, const v3 &p_j, const double *ob, double dtj, double sq,
@@ -117,54 +118,52 @@ VD double vis_two_frame(const double *wt, const double *tb, const VisLane &L, co
   double sqw, r[2];
   const double rho0 = vis_residual(pcj, ob[0] - ob[3] * dtj, ob[1] - ob[4] * dtj, sq, huber_a, r, R, sqw);
   double t0[3], t1[3];
-  // pose_i: [A | -A Ri skew(pts_imu_i)], pose_j translation: -A
-  red_mul(R, A, t0, t1);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { x0[c] = t0[c]; x1[c] = t1[c]; x0[6 + c] = -t0[c]; x1[6 + c] = -t1[c]; }
+  // pose_i: [A | -A Ri skew(pts_imu_i)] (pose_j translation: -A)
+  red_mul(R, A, x0 + GC_T, x1 + GC_T);
   double e0[3], e1[3];
   red_mul(R, AR, e0, e1);
-  cross3(L.p_i, e0, x0 + 3);
-  cross3(L.p_i, e1, x1 + 3);
+  cross3(L.p_i, e0, x0 + GC_RI);
+  cross3(L.p_i, e1, x1 + GC_RI);
   // pose_j rotation: ricK^T skew(pts_imu_j)
   red_mul_t(R, ricK, t0, t1);
-  cross3(t0, p_j, x0 + 9);
-  cross3(t1, p_j, x1 + 9);
+  cross3(t0, p_j, x0 + GC_RJ);
+  cross3(t1, p_j, x1 + GC_RJ);
   double c0[3], c1[3];
   red_mul(R, ARC, c0, c1);
   if (CAM == 0) {
     // ex0: [ric^T (Rj^T Ri - I) | -tmp_r skew(pts_camera_i) + skew(pts_camera_j)], no ex1 block
     double s0[3], s1[3];
     red_skew(R, pcj, s0, s1);
-    cross3(L.pci, c0, x0 + 15);
-    cross3(L.pci, c1, x1 + 15);
+    cross3(L.pci, c0, x0 + GC_E0 + 3);
+    cross3(L.pci, c1, x1 + GC_E0 + 3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      x0[12 + c] = e0[c] - t0[c]; x1[12 + c] = e1[c] - t1[c];
-      x0[15 + c] += s0[c]; x1[15 + c] += s1[c];
-      x0[18 + c] = 0.0; x1[18 + c] = 0.0; x0[21 + c] = 0.0; x1[21 + c] = 0.0;
+      x0[GC_E0 + c] = e0[c] - t0[c]; x1[GC_E0 + c] = e1[c] - t1[c];
+      x0[GC_E0 + 3 + c] += s0[c]; x1[GC_E0 + 3 + c] += s1[c];
+      x0[GC_E1 + c] = 0.0; x1[GC_E1 + c] = 0.0; x0[GC_E1 + 3 + c] = 0.0; x1[GC_E1 + 3 + c] = 0.0;
     }
   } else {
     // ex0: [A Ri | -A Ri ric skew(pts_camera_i)], ex1: [-ric2^T | skew(pts_camera_j)]
-    cross3(L.pci, c0, x0 + 15);
-    cross3(L.pci, c1, x1 + 15);
-    red_skew(R, pcj, x0 + 21, x1 + 21);
+    cross3(L.pci, c0, x0 + GC_E0 + 3);
+    cross3(L.pci, c1, x1 + GC_E0 + 3);
+    red_skew(R, pcj, x0 + GC_E1 + 3, x1 + GC_E1 + 3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      x0[12 + c] = e0[c]; x1[12 + c] = e1[c];
-      x0[18 + c] = -t0[c]; x1[18 + c] = -t1[c];
+      x0[GC_E0 + c] = e0[c]; x1[GC_E0 + c] = e1[c];
+      x0[GC_E1 + c] = -t0[c]; x1[GC_E1 + c] = -t1[c];
     }
   }
   // lambda: reduce * (tmp_r pts_i_td) * (-1 / lambda^2);  td: reduce * (tmp_r vel_i) * (-1 / lambda) + sqrt_info vel_j
   const double nil = -L.inv_lam;
   Jl[0] = nil * (c0[0] * L.pci.x + c0[1] * L.pci.y + c0[2] * L.pci.z);
   Jl[1] = nil * (c1[0] * L.pci.x + c1[1] * L.pci.y + c1[2] * L.pci.z);
-  x0[24] = nil * (c0[0] * L.vix + c0[1] * L.viy) + sqw * ob[3];
-  x1[24] = nil * (c1[0] * L.vix + c1[1] * L.viy) + sqw * ob[4];
-  x0[25] = r[0]; x1[25] = r[1];
+  x0[GC_TD] = nil * (c0[0] * L.vix + c0[1] * L.viy) + sqw * ob[3];
+  x1[GC_TD] = nil * (c1[0] * L.vix + c1[1] * L.viy) + sqw * ob[4];
+  x0[GC_R] = r[0]; x1[GC_R] = r[1];
   return rho0;
 }
 
-// ProjectionOneFrameTwoCamFactor: the right-camera observation in the start frame (ex0, ex1, lambda, td only).
+// ProjectionOneFrameTwoCamFactor: the right-camera observation in the start frame (ex0, ex1, lambda, td only; the pose columns are zero).
 // pts_i: the un-shifted left observation (the factor's lambda Jacobian uses pts_i, not pts_i_td: projectionOneFrameTwoCamFactor.cpp:119).
 VD double vis_one_frame(const double *wt, const VisLane &L, const v3 &pts_i, const double *ob, double dtj, double sq, double huber_a, double *x0,
                         double *x1, double *Jl) {
@@ -179,21 +178,21 @@ VD double vis_one_frame(const double *wt, const VisLane &L, const v3 &pts_i, con
   red_mul_t(R, ric2, t0, t1);   // reduce * ric2^T
   red_mul(R, A, c0, c1);        // reduce * ric2^T ric
 #pragma unroll
-  for (int c = 0; c < 12; ++c) { x0[c] = 0.0; x1[c] = 0.0; }
-  cross3(L.pci, c0, x0 + 15);
-  cross3(L.pci, c1, x1 + 15);
-  red_skew(R, pcj, x0 + 21, x1 + 21);
+  for (int c = 0; c < GC_E0; ++c) { x0[c] = 0.0; x1[c] = 0.0; }
+  cross3(L.pci, c0, x0 + GC_E0 + 3);
+  cross3(L.pci, c1, x1 + GC_E0 + 3);
+  red_skew(R, pcj, x0 + GC_E1 + 3, x1 + GC_E1 + 3);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    x0[12 + c] = t0[c]; x1[12 + c] = t1[c];
-    x0[18 + c] = -t0[c]; x1[18 + c] = -t1[c];
+    x0[GC_E0 + c] = t0[c]; x1[GC_E0 + c] = t1[c];
+    x0[GC_E1 + c] = -t0[c]; x1[GC_E1 + c] = -t1[c];
   }
   const double il2 = -(L.inv_lam * L.inv_lam), nil = -L.inv_lam;
   Jl[0] = il2 * (c0[0] * pts_i.x + c0[1] * pts_i.y + c0[2] * pts_i.z);
   Jl[1] = il2 * (c1[0] * pts_i.x + c1[1] * pts_i.y + c1[2] * pts_i.z);
-  x0[24] = nil * (c0[0] * L.vix + c0[1] * L.viy) + sqw * ob[3];
-  x1[24] = nil * (c1[0] * L.vix + c1[1] * L.viy) + sqw * ob[4];
-  x0[25] = r[0]; x1[25] = r[1];
+  x0[GC_TD] = nil * (c0[0] * L.vix + c0[1] * L.viy) + sqw * ob[3];
+  x1[GC_TD] = nil * (c1[0] * L.vix + c1[1] * L.viy) + sqw * ob[4];
+  x0[GC_R] = r[0]; x1[GC_R] = r[1];
   return rho0;
 }
 

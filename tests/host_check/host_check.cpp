@@ -52,7 +52,8 @@ void hc_pose_plus(const double *x, const double *d, double *out) { pose_plus(x, 
 void hc_prior_dx(const double *x, const double *x0, int size, double *dx) { prior_dx(x, x0, size, dx); }
 
 // The fused linearisation's factor forms (visual_lin.hpp: hoisted rotation products, Huber weight folded into `reduce`) for one landmark:
-// kind 0 / 1 / 2 as in hc_proj; x0 / x1: the two corrected rows [J_pose_i 6 | J_pose_j 6 | J_ex0 6 | J_ex1 6 | J_td | r]; returns rho(s).
+// kind 0 / 1 / 2 as in hc_proj; x0 / x1: the two corrected rows in the Gram slot's 23-column order (factors.hpp: GC_T 3 | GC_RI 3 | GC_RJ 3 |
+// GC_E0 6 | GC_R | GC_E1 6 | GC_TD; d r / d P_j = -d r / d P_i is not stored); returns rho(s).
 // The tables are built the way k_visual_linearize builds them (window table, then the 2 x 3 rows of the pair's table).
 double hc_vis_lin(int kind, const double *obs12, const double *pose_i, const double *pose_j, const double *ex0, const double *ex1,
                   double inv_dep, double td, double sq, double huber_a, double *x0, double *x1, double *Jl) {

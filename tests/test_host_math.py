@@ -96,10 +96,12 @@ def test_fused_visual_forms_match_the_literal_factor_bodies(hc, kind, outlier):
             rho0 = hc.hc_correct(C.c_double(a), P(r2), P(j2))
             want[:, c] = j2
             want[:, 26] = r2
-        x0 = np.zeros(26); x1 = np.zeros(26); jl = np.zeros(2)
+        x0 = np.zeros(23); x1 = np.zeros(23); jl = np.zeros(2)
         got_rho = hc.hc_vis_lin(kind, P(obs), P(pose_i), P(pose_j), P(ex0), P(ex1), C.c_double(lam[0]), C.c_double(td[0]), C.c_double(sq),
                                 C.c_double(a), P(x0), P(x1), P(jl))
-        got = np.stack([x0, x1])
+        g23 = np.stack([x0, x1])
+        # the Gram slot's 23 columns (trans 3 | rot_i 3 | rot_j 3 | ex0 6 | r | ex1 6 | td) back in the order [pose_i 6 | pose_j 6 | ex0 6 | ex1 6 | td | r]
+        got = np.concatenate([g23[:, 0:6], -g23[:, 0:3], g23[:, 6:9], g23[:, 9:15], g23[:, 16:22], g23[:, 22:23], g23[:, 15:16]], axis=1)
         scale = max(1.0, np.abs(want).max())
         np.testing.assert_allclose(got[:, :25], want[:, :25], rtol=1e-11, atol=1e-12 * scale)
         np.testing.assert_allclose(jl, want[:, 25], rtol=1e-11, atol=1e-12 * scale)
