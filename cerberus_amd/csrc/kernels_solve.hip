@@ -586,7 +586,12 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // both factors' values, which halves the scattered 32-byte sectors the gather touches per factor.
 __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
   __shared__ double Jw[32 * IW_JS];
-  const int f0 = 2 * blockIdx.x, win = f0 / 10;
+  // The entry-major raw Jacobians put the same entry of 8 consecutive factors in one 64-byte line, i.e. four pairs share every line they
+  // gather from. Workgroup b runs on XCD b % 8 (its own L2): inside each group of 32 workgroups, the four that land on XCD x take the
+  // pairs 4 x .. 4 x + 3, so a line is fetched from HBM by one L2 instead of four. (A permutation of [0, gridDim.x); ragged tail: identity.)
+  int pair = blockIdx.x;
+  if ((pair | 31) < (int)gridDim.x) pair = (pair & ~31) + 4 * (pair & 7) + ((pair >> 3) & 3);
+  const int f0 = 2 * pair, win = f0 / 10;
   SolverState &st = b.st[win];
   if (lin_skip(st, mode)) return;
   const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
