@@ -39,3 +39,9 @@ for w in sample:
 vis /= len(sample)
 print("k_visual_linearize, first packed wave of a window (%d lanes, %d frames): total %d cycles, factor evaluation + row staging %d, Gram MFMA pass %d" %
       (vis[3], vis[4], vis[0], vis[1], vis[2]))
+imu = np.zeros(3)
+for w in sample:
+    c = b.fetch(12, w).view(np.int64)
+    imu += c[33:36].astype(np.float64)
+imu /= len(sample)
+print("k_imu_linearize, first factor of a window: sqrt_info operand loads %d cycles, whitening %d, Gram + stores %d" % (imu[0], imu[1], imu[2]))
