@@ -1118,7 +1118,8 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 // launch
 // =================================================================================================
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
-  const size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
+  size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
+  if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
     hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
   } else {
