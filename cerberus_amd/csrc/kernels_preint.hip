@@ -140,7 +140,9 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   // padded to 32 rows (48 noise columns) with odd leading dimensions: rows / columns 31 and noise 46, 47 stay zero, so the FP64
   // MFMA tiles of jac_cov_update_mfma need no masks
   __shared__ double Fm[32 * FLD], Vm[32 * VLD], nd[48];
-  __shared__ double Jm[32 * FLD], Pm[32 * FLD], Qm[32 * FLD];
+  // (Q = F P overwrites P once every product that reads P has its operands: 40 000 B of LDS instead of 48 448 = four intervals per CU,
+  // one per SIMD, instead of three)
+  __shared__ double Jm[32 * FLD], Pm[32 * FLD];
   __shared__ LegTerms lt[8];
   const int lane = threadIdx.x;
   if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
@@ -336,7 +338,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       put33(Vm, VLD, 24, 15, I3 * (-dt));
     }
     __syncthreads();
-    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, Qm);
+    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, Pm);
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
