@@ -139,14 +139,23 @@ __device__ void sqrt_info_literal_wave(const double *cov, double *U_out, double 
 
 // skip (optional, [n]): records that carry no factor (interval beyond the window, sum_dt > 10 s) are left alone. per_record: the
 // "covariance not positive definite" flag goes to status[f] instead of status[0], so that a batch can fail the one window it concerns.
-__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record, int literal) {
+// (the literal route is a kernel of its own: it needs two LDS matrices, the default one a single staging copy — 8 KB instead of 16 KB
+// per wave lets the register file, not LDS, set the occupancy)
+__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
+  __shared__ double R[31 * 32];
+  const int f = blockIdx.x;
+  if (f >= n || (skip && skip[f])) return;
+  const vilo_preint &p = pre[f];
+  if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
+  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, nullptr, status + (per_record ? f : 0));
+}
+__global__ void __launch_bounds__(64) k_prepare_preint_literal(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
   __shared__ double R[31 * 32], Ub[31 * 32];
   const int f = blockIdx.x;
   if (f >= n || (skip && skip[f])) return;
   const vilo_preint &p = pre[f];
   if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
-  if (literal) sqrt_info_literal_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
-  else sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
+  sqrt_info_literal_wave<31>(p.covariance, out[f].sqrt_info, R, Ub, status + (per_record ? f : 0));
 }
 
 __global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_preint_imu *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record, int literal) {
@@ -162,7 +171,8 @@ __global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_pre
 
 int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
-  hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record, ctx->sqrt_info_mode);
+  if (ctx->sqrt_info_mode) hipLaunchKernelGGL(k_prepare_preint_literal, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
+  else hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }
