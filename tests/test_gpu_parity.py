@@ -372,21 +372,32 @@ def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
             assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
 
 
-def test_small_and_large_batches_linearise_identically(ctx, cfg, ocfg):
+@pytest.mark.parametrize("td_const", [1, 0])
+def test_small_and_large_batches_linearise_identically(ctx, cfg, ocfg, td_const):
     """Up to 256 packed waves a batch is linearised frame-parallel (k_visual_linearize_tpar + k_visual_reduce: one workgroup per
     (packed wave, frame) so that a few windows still fill the chip), above that by one wave per packed wave. Same window, both forms,
-    bit for bit — a robot gets the same answer alone and inside a fleet of any size."""
+    bit for bit — a robot gets the same answer alone and inside a fleet of any size. td_const = 1 (estimate_td: 0, the reference's
+    configuration): a left-camera factor's rows take one Gram tile; td_const = 0: all three — the second case also against the oracle."""
     from cerberus_amd import api
     opts = api.default_solve_opts(False, 12)
-    alone = [_fresh(cfg, ocfg, n_landmarks=60, seed=300 + i) for i in range(3)]
+
+    def fresh(seed):
+        w = _fresh(cfg, ocfg, n_landmarks=60, seed=seed)
+        w.td_const = td_const
+        return w
+    alone = [fresh(300 + i) for i in range(3)]
     for w in alone:
         ctx.solve_windows([w], opts)                                   # 2 packed waves: frame-parallel form
-    crowd = [_fresh(cfg, ocfg, n_landmarks=60, seed=300 + i) for i in range(3)] + \
-            [_fresh(cfg, ocfg, n_landmarks=60, seed=900 + i) for i in range(160)]   # > 256 packed waves: walking form
+    crowd = [fresh(300 + i) for i in range(3)] + [fresh(900 + i) for i in range(160)]   # > 256 packed waves: walking form
     ctx.solve_windows(crowd, opts)
     for w1, w2 in zip(alone, crowd[:3]):
         for a, b in zip(w1.state_arrays(), w2.state_arrays()):
             np.testing.assert_array_equal(a, b)
+    if not td_const:
+        w_o = fresh(300)
+        O.solve_window(ocfg, w_o, O.default_opts(False, 12))
+        for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], crowd[0].state_arrays(), w_o.state_arrays()):
+            assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
 
 
 def test_size_independent_properties(ctx, cfg):
