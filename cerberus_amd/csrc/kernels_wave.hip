@@ -518,24 +518,21 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
           for (int i = 0; i < 13; ++i) rhsn[i] = (k > 0) ? bimg[BI_AOT + (max(k - 1, 0) * 13 + row) * 13 + i] : 0.0;   // column `row` of A_{k,k-1}
 #pragma unroll
-          for (int m = 0; m < 3; ++m) adnn[m] = (k > 0 && lane + 64 * m < 169) ? bimg[BI_AD + max(k - 1, 0) * 169 + lane + 64 * m] : 0.0;   // A_{k-1,k-1}
+          for (int r = 0; r < 4; ++r) adnn[r] = (k > 0 && lr < 13 && lk + 4 * r < 13) ? bimg[BI_AD + max(k - 1, 0) * 169 + (lk + 4 * r) * 13 + lr] : 0.0;   // A_{k-1,k-1}, accumulator order
         };
         mfma_d4 nV[5];
-        double nrhs[13], nadn[3];
+        double nrhs[13], nadn[4];
         load_blocks(F - 1, nV, nrhs, nadn);
-        int ei[3], ej[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { const int e = min(lane + 64 * m, 168); ei[m] = e / 13; ej[m] = e - 13 * ei[m]; }
         for (int k = F - 1; k >= 0; --k) {
           const int x_lo = (k <= kb) ? 0 : max(0, (6 * (k - 1)) >> 4);   // T(k) is zero left of pose k - 1 (dense from the prior's frame down)
           mfma_d4 V[5];
-          double a[13], l[13], rhs[13], adn[3];
+          double a[13], l[13], rhs[13], adn[4];
 #pragma unroll
           for (int X = 0; X < 5; ++X) V[X] = nV[X];
 #pragma unroll
           for (int i = 0; i < 13; ++i) rhs[i] = nrhs[i];
 #pragma unroll
-          for (int m = 0; m < 3; ++m) adn[m] = nadn[m];
+          for (int m = 0; m < 4; ++m) adn[m] = nadn[m];
           if (lr == 15) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) V[4][r] = (lk + 4 * r < 13) ? GB[13 * k + lk + 4 * r] : 0.0;
@@ -592,18 +589,18 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           }
           lds_fence();
           if (k == 5 && lane == 0) st.phase_clk[18] = clock64();
-          // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
+          // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k): one 16 x 16 tile on the matrix cores (the operand serves as A and B)
           if (k > 0) {
+            mfma_d4 sn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-              const int e = lane + 64 * m;
-              if (e < 169) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 13; ++q) sacc += TAcur[q * 13 + ei[m]] * TAcur[q * 13 + ej[m]];
-                SN[e] = adn[m] - sacc;
-              }
+            for (int kk = 0; kk < 4; ++kk) {
+              const int q = 4 * kk + lk;
+              const double ta = ((lr < 13) && (q < 13)) ? TAcur[min(q, 12) * 13 + min(lr, 12)] : 0.0;
+              sn = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, ta, sn, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (lr < 13 && lk + 4 * r < 13) SN[(lk + 4 * r) * 13 + lr] = adn[r] - sn[r];
           }
           // V -= T_A(k+1)^T T(k+1);  T(k) = M_k V
           double at[4], am[4];
