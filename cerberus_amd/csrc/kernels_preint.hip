@@ -101,21 +101,69 @@ __device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr] = acc[t][r];
 }
-// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468)
-__device__ void jac_cov_update_mfma(const double *Fm, const double *Vm, const double *nd, double *Jm, double *Pm, double *Qm) {
-  const mfma_d4 z = {0.0, 0.0, 0.0, 0.0};
-  mfma_d4 accJ[4] = {z, z, z, z}, accQ[4] = {z, z, z, z};
-  gemm32<8, false>(Fm, FLD, Jm, FLD, nullptr, accJ);   // F J
-  gemm32<8, false>(Fm, FLD, Pm, FLD, nullptr, accQ);   // Q = F P
+// F = I + dF, and dF has non-zero columns only at K = {3 .. 8, 21 .. 30} (d/d theta, d/d v, d/d ba, d/d bg, d/d rho): 16 of 31.
+// With dFm = F - I in LDS the products keep their identity part in the accumulators and contract over the 16 columns of K only:
+//   F X = X + dF[:, K] X[K, :],   Q F^T = Q + Q[:, K] dF[:, K]^T        (4 k-steps instead of 8 each).
+__device__ __forceinline__ int fk_col(int k) { return k < 6 ? 3 + k : 15 + k; }
+// acc (32 x 32, accumulator order) += A[:, K] * B[K, :]   (A, B row-major 32 x FLD in LDS); all 16 operands of a lane in flight first
+__device__ __forceinline__ void gemm32_fk(const double *A, const double *B, mfma_d4 acc[4]) {
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+  double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = fk_col(4 * kk + lk);
+    a0[kk] = A[lr * FLD + k]; a1[kk] = A[(16 + lr) * FLD + k];
+    b0[kk] = B[k * FLD + lr]; b1[kk] = B[k * FLD + 16 + lr];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+  }
+}
+// acc += A[:, K] * Bt[:, K]^T
+__device__ __forceinline__ void gemm32_fk_t(const double *A, const double *Bt, mfma_d4 acc[4]) {
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+  double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = fk_col(4 * kk + lk);
+    a0[kk] = A[lr * FLD + k]; a1[kk] = A[(16 + lr) * FLD + k];
+    b0[kk] = Bt[lr * FLD + k]; b1[kk] = Bt[(16 + lr) * FLD + k];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void load32(const double *C, int ldc, mfma_d4 acc[4]) {
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr];
+}
+// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468); dFm = F - I.
+// Q = F P overwrites P in LDS once every product that reads P has its operands.
+__device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const double *Vm, const double *nd, double *Jm, double *Pm) {
+  mfma_d4 accJ[4], accQ[4];
+  load32(Jm, FLD, accJ);
+  load32(Pm, FLD, accQ);
+  gemm32_fk(dFm, Jm, accJ);   // J + dF J
+  gemm32_fk(dFm, Pm, accQ);   // Q = P + dF P
   __syncthreads();
   store32(Jm, FLD, accJ);
-  store32(Qm, FLD, accQ);
+  store32(Pm, FLD, accQ);
   __syncthreads();
-  mfma_d4 accP[4] = {z, z, z, z};
-  gemm32<8, true>(Qm, FLD, Fm, FLD, nullptr, accP);    // Q F^T
-  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accP);        // + V N V^T
+  gemm32_fk_t(Pm, dFm, accQ);                        // Q + Q dF^T
+  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accQ);      // + V N V^T
   __syncthreads();
-  store32(Pm, FLD, accP);
+  store32(Pm, FLD, accQ);
   __syncthreads();
 }
 
@@ -175,6 +223,10 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   } else {
     for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = ((e / FLD) == (e % FLD) && e / FLD < 31) ? 1.0 : 0.0; Pm[e] = 0.0; }
   }
+  // dF = F - I and V have a fixed sparsity pattern: zeroed once, every sample overwrites the same entries
+  for (int e = lane; e < 32 * FLD; e += 64) Fm[e] = 0.0;
+  for (int e = lane; e < 32 * VLD; e += 64) Vm[e] = 0.0;
+  if (lane >= 46 && lane < 48) nd[lane] = 0.0;
   __syncthreads();
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
@@ -240,9 +292,6 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       st3(lt[lane].f, k.f); st3(lt[lane].v, v); st3(lt[lane].g, g);
       for (int q = 0; q < 9; ++q) { lt[lane].J[q] = k.J.a[q]; lt[lane].h[q] = h.a[q]; }
     }
-    for (int e = lane; e < 32 * FLD; e += 64) Fm[e] = 0.0;
-    for (int e = lane; e < 32 * VLD; e += 64) Vm[e] = 0.0;
-    if (lane >= 46 && lane < 48) nd[lane] = 0.0;
     __syncthreads();
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
@@ -283,21 +332,19 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       for (int k = 0; k < 12; ++k) nd[30 + k] = unc[k];
       for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
     }
-    // F and V blocks (:376-465): lane 0 the IMU rows, lanes 1..4 the epsilon rows of leg (lane - 1), lane 5 the identities
+    // dF = F - I and V blocks (:376-465): lane 0 the IMU rows, lanes 1..4 the epsilon rows of leg (lane - 1), lane 5 the identities
     const v3 a0 = acc_0 - ba, a1 = acc_1 - ba;
     const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
     const m3 kappa_7 = I3 - Rwx * dt;
     if (lane == 0) {
       const m3 kappa_1 = (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * kappa_7) * (-0.5 * dt);
-      put33(Fm, FLD, 0, 0, I3);
       put33(Fm, FLD, 0, 3, kappa_1 * (0.5 * dt));
       put33(Fm, FLD, 0, 6, I3 * dt);
       put33(Fm, FLD, 0, 21, (R0 + R1) * (-0.25 * dt * dt));
       put33(Fm, FLD, 0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
-      put33(Fm, FLD, 3, 3, kappa_7);
+      put33(Fm, FLD, 3, 3, Rwx * (-dt));   // kappa_7 - I
       put33(Fm, FLD, 3, 24, I3 * (-1.0 * dt));
       put33(Fm, FLD, 6, 3, kappa_1);
-      put33(Fm, FLD, 6, 6, I3);
       put33(Fm, FLD, 6, 21, (R0 + R1) * (-0.5 * dt));
       put33(Fm, FLD, 6, 24, (R1 * Ra1) * (0.5 * dt * dt));
       const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt);
@@ -319,7 +366,6 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       const m3 hi = ld_m3_rowmajor(lt[2 * j].h), hi1 = ld_m3_rowmajor(lt[2 * j + 1].h);
       const v3 gi = ld3(lt[2 * j].g), gi1 = ld3(lt[2 * j + 1].g);
       put33(Fm, FLD, e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
-      put33(Fm, FLD, e, e, I3);
       put33(Fm, FLD, e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(pbr + Rbr * fi) + R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
       const v3 gsum = (gi + gi1) * (0.5 * dt);
       Fm[(e + 0) * FLD + 27 + j] = gsum.x; Fm[(e + 1) * FLD + 27 + j] = gsum.y; Fm[(e + 2) * FLD + 27 + j] = gsum.z;
@@ -331,14 +377,12 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       put33(Vm, VLD, e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
       put33(Vm, VLD, e, 30 + 3 * j, I3 * (-dt));
     } else if (lane == 5) {
-      put33(Fm, FLD, 21, 21, I3);
-      put33(Fm, FLD, 24, 24, I3);
-      for (int j = 0; j < 4; ++j) { Fm[(27 + j) * FLD + 27 + j] = 1.0; Vm[(27 + j) * VLD + 42 + j] = -dt; }
+      for (int j = 0; j < 4; ++j) Vm[(27 + j) * VLD + 42 + j] = -dt;
       put33(Vm, VLD, 21, 12, I3 * (-dt));
       put33(Vm, VLD, 24, 15, I3 * (-dt));
     }
     __syncthreads();
-    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, Pm);
+    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm);
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
