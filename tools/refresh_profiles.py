@@ -1,0 +1,37 @@
+"""Copy the summaries of tools/profile_gpu.sh / tools/profile_sq.sh (run on the GPU box, merged back under gpurun_out/) into
+profiles/round2_* — the files bench.py's roofline block and DESIGN.md cite.
+Usage: python tools/refresh_profiles.py <prof_tag> <sq_tag> [bench.json] [bench_config3.json]"""
+import json
+import os
+import shutil
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof, sq = sys.argv[1], sys.argv[2]
+lines = open(os.path.join(R, "gpurun_out", "prof_" + prof, "summary.txt")).read().rstrip("\n").split("\n")
+js = json.loads(lines[-1])
+js["windows_per_dispatch"] = 4096
+js["note"] = ("rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (bench.py --steps 2 --warmup 1 "
+              "--windows 4096), calibrated on k_calib_copy; end of round 2")
+open(os.path.join(R, "profiles", "round2_rocprof_summary.txt"), "w").write("\n".join(lines[:-1]) + "\n")
+json.dump(js, open(os.path.join(R, "profiles", "round2_pmc.json"), "w"))
+lines = open(os.path.join(R, "gpurun_out", "prof_" + sq, "summary.txt")).read().rstrip("\n").split("\n")
+res = json.loads(lines[-1])
+open(os.path.join(R, "profiles", "round2_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
+json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py --steps 1 --warmup 1 --windows 4096): per-dispatch means summed over the "
+                   "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; end of round 2",
+           "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", "round2_mfma.json"), "w"))
+if len(sys.argv) > 3:
+    shutil.copy(sys.argv[3], os.path.join(R, "profiles", "round2_bench_final.json"))
+if len(sys.argv) > 4:
+    shutil.copy(sys.argv[4], os.path.join(R, "profiles", "round2_bench_config3.json"))
+it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")
+tot = 0.0
+for k in it:
+    b, us = js["hbm_bytes_per_dispatch"][k], js["kernel_trace"][k]["avg_us"]
+    tot += b
+    c = res.get(k, {})
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) if "GRBM_GUI_ACTIVE" in c else float("nan")
+    print("%-20s %8.1f us  %7.1f KB/window  %5.2f TB/s  mfma busy %4.1f %%  active %4.1f %%  wait %4.1f %%" %
+          (k, us, b / 4096 / 1e3, b / us / 1e6, 100 * busy, 100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1), 100 * c.get("SQ_WAIT_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1)))
+print("iteration: %.1f KB per window-iteration = %.2f x 299 088 B; kernels %.1f us" % (tot / 4096 / 1e3, tot / 4096 / 299088, sum(js["kernel_trace"][k]["avg_us"] for k in it)))
