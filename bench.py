@@ -205,7 +205,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; VILO_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box
-        dist.init_process_group(os.environ.get("VILO_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("VILO_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            # the rank's own GPU is named explicitly (RCCL otherwise guesses it from the global rank at the first collective)
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except TypeError:   # (a torch without the device_id argument)
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
@@ -242,7 +252,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
