@@ -771,7 +771,5 @@ int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage) {
     VILO_HIP(hipGetLastError());
     return VILO_OK;
   }
-  int rc = vilo_launch_prepare_preint(ctx, b.W * 10, (const vilo_preint *)b.rp_pre, b.prep, b.prep_bad, b.imu_skip, 1);
-  if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, b);
-  return rc;
+  return vilo_launch_prepare_preint(ctx, b.W * 10, (const vilo_preint *)b.rp_pre, b.prep, b.prep_bad, b.imu_skip, 1);
 }

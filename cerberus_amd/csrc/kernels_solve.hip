@@ -676,42 +676,56 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
   }
 }
 
-// residual-only at the candidate: one thread per factor; sqrt_info is read from its entry-major transpose
-// (b.sqrtT[e][factor], coalesced across the lanes of a wave)
+// residual-only at the candidate (the last one of a solve). One wave per 64 factors: lane = factor for the raw residual (a scalar chain),
+// then factor by factor lane = row of sqrt_info for |sqrt_info r|^2, the residual broadcast from LDS — sqrt_info is read where the
+// preparation left it (row-major per record; a lane's row is 248 B: its lines stay in L1 across the 31 column steps), so no entry-major
+// transpose of all 40 960 matrices per solve is needed for this one pass.
 __global__ void __launch_bounds__(64) k_imu_cost(BatchDev b, double g_norm) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double rs[32 * 64];   // [entry][factor of the wave]; row 31: the squared whitened entries summed per factor
+  const int lane = threadIdx.x, f0 = blockIdx.x * 64, f = f0 + lane;
   const int NF = b.W * 10;
-  if (f >= NF) return;
-  const int win = f / 10, k = f % 10;
-  const SolverState &st = b.st[win];
-  if (st.done) return;
-  if (b.imu_skip[f]) { b.imu_cost[f] = 0.0; return; }
-  const PreintPrepared &pp = b.prep[f];
-  const double *x = b.xc + (size_t)win * XSTRIDE;
-  double r[31];
-  if (b.win[win].use_leg) {
-    imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
-                x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
-  } else {
+  bool live = false;
+  {
+    double r[31];
 #pragma unroll
-    for (int i = 15; i < 31; ++i) r[i] = 0.0;
-    imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, false, nullptr, 0);
+    for (int i = 0; i < 31; ++i) r[i] = 0.0;
+    if (f < NF) {
+      const int win = f / 10, k = f % 10;
+      live = !b.st[win].done && !b.imu_skip[f];
+      if (live) {
+        const PreintPrepared &pp = b.prep[f];
+        const double *x = b.xc + (size_t)win * XSTRIDE;
+        if (b.win[win].use_leg) {
+          imu_leg_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_LB + 4 * k, x + XO_POSE + 7 * (k + 1),
+                      x + XO_SB + 9 * (k + 1), x + XO_LB + 4 * (k + 1), r, false, nullptr, 0);
+        } else {
+          imu_raw(pp.head, g_norm, x + XO_POSE + 7 * k, x + XO_SB + 9 * k, x + XO_POSE + 7 * (k + 1), x + XO_SB + 9 * (k + 1), r, false, nullptr, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 31; ++i) rs[i * 64 + lane] = r[i];
+    rs[31 * 64 + lane] = 0.0;
   }
-  const double *ut = b.sqrtT + f;
-  double c = 0.0;
-  int e = 0;
+  lds_barrier();
+  const unsigned long long livem = __ballot(live);
+  const int row = min(lane, 30);
+  for (int fl = 0; fl < 64; ++fl) {
+    if (!((livem >> fl) & 1ULL)) continue;
+    const double *U = b.prep[f0 + fl].sqrt_info + row * 31;
+    double u[31];
 #pragma unroll
-  for (int i = 0; i < 31; ++i) {
+    for (int q = 0; q < 31; ++q) u[q] = (q >= row) ? U[q] : 0.0;
     double sacc = 0.0;
 #pragma unroll
-    for (int q = i; q < 31; ++q) { sacc += ut[(size_t)e * NF] * r[q]; ++e; }
-    c += sacc * sacc;
+    for (int q = 0; q < 31; ++q) sacc += u[q] * rs[q * 64 + fl];
+    const double c = wave_sum(lane < 31 ? sacc * sacc : 0.0);
+    if (lane == 0) rs[31 * 64 + fl] = c;
   }
-  b.imu_cost[f] = c;
+  lds_barrier();
+  if (f < NF && !b.st[f / 10].done) b.imu_cost[f] = live ? rs[31 * 64 + lane] : 0.0;
 }
 
-// use_leg == 0: the 15 x 15 sqrt_info of an IMUFactor (leading 225 doubles, row stride 15) re-laid out as the leading block of a
-// 31 x 31 matrix (row stride 31, zeros elsewhere) so that the IMU-leg kernels can be used unchanged
 __global__ void __launch_bounds__(256) k_embed_sqrt15(BatchDev b) {
   __shared__ double t[225];
   PreintPrepared &pp = b.prep[blockIdx.x];
@@ -728,20 +742,6 @@ int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b) {
   return VILO_OK;
 }
 
-// entry-major transpose of the upper triangles of sqrt_info (once per batch)
-__global__ void k_sqrt_transpose(BatchDev b) {
-  const int f = blockIdx.x, NF = b.W * 10;
-  const PreintPrepared &pp = b.prep[f];
-  for (int e = threadIdx.x; e < 31 * 31; e += blockDim.x) {
-    const int i = e / 31, q = e - 31 * i;
-    if (q >= i) b.sqrtT[(size_t)(i * 31 - (i * (i - 1)) / 2 + (q - i)) * NF + f] = pp.sqrt_info[e];
-  }
-}
-int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b) {
-  hipLaunchKernelGGL(k_sqrt_transpose, dim3(b.W * 10), dim3(64), 0, ctx->stream, b);
-  VILO_HIP(hipGetLastError());
-  return VILO_OK;
-}
 
 // =================================================================================================
 // k_accept: candidate cost, step quality, accept / reject (TrustRegionMinimizer::{IsStepSuccessful,

@@ -132,7 +132,6 @@ struct BatchDev {
   // IMU factors
   PreintPrepared *prep;       // [W][10]
   double *imu_raw;            // [31*39][W*10]   raw [J (31x38) | r], entry-major over the factors; zeros written once, structural non-zeros per linearisation
-  double *sqrtT;              // [496][W*10]     upper triangles of sqrt_info, entry-major (coalesced per-thread reads)
   double *imu_lin;            // [W][10][31*39]  whitened J (31x38) | whitened r (col 38)
   double *imu_gram;           // [W][10][780]    packed upper triangle of [J | r]^T [J | r]
   double *imu_cost;           // [W][10]

@@ -443,7 +443,6 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
   TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
   TRYB(dev_alloc(ctx, bt, &D.imu_raw, (size_t)W * 10 * 31 * 39));
-  TRYB(dev_alloc(ctx, bt, &D.sqrtT, (size_t)W * 10 * 496));
   if (hipMemset(D.imu_raw, 0, sizeof(double) * (size_t)W * 10 * 31 * 39) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
@@ -568,7 +567,6 @@ extern "C" int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *bt) {
   int rc = bt->leg ? vilo_launch_prepare_preint(ctx, bt->W * 10, (const vilo_preint *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1)
                    : vilo_launch_prepare_preint_imu(ctx, bt->W * 10, (const vilo_preint_imu *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1);
   if (rc == VILO_OK && !bt->leg) rc = vilo_launch_embed_sqrt15(ctx, D);
-  if (rc == VILO_OK) rc = vilo_launch_sqrt_transpose(ctx, D);
   return rc;
 }
 

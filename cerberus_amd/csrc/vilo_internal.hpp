@@ -92,7 +92,6 @@ static_assert(sizeof(PreintPrepared) == 8 * 1087, "SURVEY 8(d): 1087 doubles per
 int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record);
 int vilo_launch_prepare_preint_imu(vilo_ctx *ctx, int n, const vilo_preint_imu *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record);
 struct BatchDev;
-int vilo_launch_sqrt_transpose(vilo_ctx *ctx, BatchDev &b);
 int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b);
 int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage);
 
