@@ -22,7 +22,7 @@ json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py -
                    "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; end of round 2",
            "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", "round2_mfma.json"), "w"))
 if len(sys.argv) > 3:
-    shutil.copy(sys.argv[3], os.path.join(R, "profiles", "round2_bench_final.json"))
+    shutil.copy(sys.argv[3], os.path.join(R, "profiles", "round2_bench_v2_final.json"))
 if len(sys.argv) > 4:
     shutil.copy(sys.argv[4], os.path.join(R, "profiles", "round2_bench_config3.json"))
 it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")
