@@ -144,8 +144,8 @@ struct BatchDev {
   // camera-side vectors [W][CD_N]
   double *cam_g, *cam_dh2, *cam_y, *cam_scale;
   // block scratch
-  double *Tm, *Lk;            // [W][11][13*96] T_k = [T_A | T_B | t_g], [W][11][169] L_k^-1
-  double *TAg;                // [W][11][169] T_A(k) = L_k^-1 A_{k,k-1} (single-wave solver: kept for the back-substitution sweeps)
+  double *Lk;                 // [W][11][169] M_k = L_k^-1 of the bias chain
+  double *TAg;                // [W][11][169] T_A(k) = L_k^-1 A_{k,k-1} (both written by the chain and read back by the back-substitution sweeps)
   double *Cimg;               // [W][3840] assembled pose system: 15 lower 16 x 16 tiles in FP64-MFMA accumulator order (k_assemble_pose)
   double *cam_gin;            // [W][CD_N] gradient at the linearisation point (k_assemble)
   double *Bimg;               // [W][BI_N] speed / leg-bias part of the assembled system (BI_* layout)

@@ -466,7 +466,6 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.cam_dh2, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_y, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_scale, (size_t)W * CD_N));
-  TRYB(dev_alloc(ctx, bt, &D.Tm, (size_t)W * 11 * 13 * 96));
   TRYB(dev_alloc(ctx, bt, &D.Lk, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.TAg, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.Cimg, (size_t)W * 3840));
