@@ -1,19 +1,20 @@
 // Single-wave solver for gfx950: what ceres::Solve does per linearisation for Estimator::optimization()
 // (estimator.cpp:1221-1236; DENSE_SCHUR + traditional DOGLEG, Ceres 1.14 semantics), one WAVE per window.
 //
-//   k_assemble        one 256-thread workgroup per window (five per CU): the camera-side normal equations of the window in the layouts
+//   k_assemble        one 256-thread workgroup per window (four per CU): the camera-side normal equations of the window in the layouts
 //                     the solver streams. Pose / extrinsic / td system (80 x 80): owner-computes scatter (no atomics) of the
 //                     per-(start frame, t) Gram slots of k_visual_linearize, the pose blocks of the IMU factor Grams and the prior
 //                     image into an LDS image of 15 lower 16 x 16 tiles, written out in FP64-MFMA accumulator order (one coalesced
 //                     load per register in the solver). Speed / leg-bias part: diagonal blocks A_kk, off-diagonal blocks (transposed),
 //                     IMU coupling blocks with poses k-1 .. k+1, prior coupling rows, the diagonal and the gradient — constant blocks
 //                     and absent frames already masked, so the solver has no index arithmetic in its loops.
-//   k_solve_wave      one 64-lane workgroup per window, 40 KB of LDS: four windows per CU, one per SIMD, no workgroup barriers and no
-//                     idle waves (the four-wave k_build_solve kept one wave of four busy through its serial phases).
+//   k_solve_wave      one 64-lane workgroup per window, 17 KB of LDS, all 512 registers of its SIMD: four windows per CU, one per SIMD,
+//                     no workgroup barriers and no idle waves. The 80 x 80 pose system lives in accumulator registers from its load to
+//                     the backward solve.
 //                     Jacobi scaling / dogleg diagonal / q = |J D^-2 g|^2  ->  block-tridiagonal Cholesky chain of the speed / leg-bias
 //                     part with its coupling rows T(k) and C -= T^T T on the FP64 matrix cores  ->  landmark Schur complement on the
-//                     matrix cores straight from global memory  ->  blocked 80 x 80 Cholesky  ->  triangular solves  ->  bias and landmark
-//                     back-substitution  ->  dogleg step and candidate state.
+//                     matrix cores straight from global memory  ->  blocked 80 x 80 Cholesky with the forward solve riding along  ->
+//                     backward solve from the registers  ->  bias and landmark back-substitution  ->  dogleg step and candidate state.
 #include <type_traits>
 #include "solve_common.hpp"
 

@@ -1,5 +1,5 @@
-// Small device helpers shared by the solver kernels (kernels_solve.hip: linearisation, cost, accept, the four-wave solver;
-// kernels_wave.hip: pose-system assembly and the single-wave solver).
+// Small device helpers shared by the solver kernels (kernels_solve.hip: linearisation, cost, accept; kernels_wave.hip: pose-system
+// assembly and the single-wave solver; kernels_marg.hip reads the Gram slots through gram26_index).
 #pragma once
 #include "solver_types.hpp"
 

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 KNOWN = ("k_visual_linearize", "k_imu_linearize", "k_assemble", "k_solve_wave", "k_imu_raw", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
-         "k_preint_imu_leg", "k_prepare_preint", "k_sqrt_transpose", "k_calib_copy", "k_marginalize")
+         "k_preint_imu_leg", "k_prepare_preint", "k_calib_copy", "k_marginalize")
 
 
 def short(name):

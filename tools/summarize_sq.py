@@ -8,7 +8,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 KNOWN = ("k_visual_linearize", "k_visual_cost", "k_visual", "k_imu_linearize", "k_imu_raw", "k_imu_cost", "k_imu", "k_assemble", "k_solve_wave", "k_accept",
-         "k_init_state", "k_preint_imu_leg", "k_prepare_preint", "k_sqrt_transpose", "k_marginalize")
+         "k_init_state", "k_preint_imu_leg", "k_prepare_preint", "k_marginalize")
 
 
 def short(name):
