@@ -899,14 +899,17 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   const int W = b.W;
   int pidx = 0;
   ctx->pev_kind.clear();
+  // profile: 0 off, 1 every kernel, 2 + k only kernel kind k (a pair of event records costs the stream ~7 us; ~80 pairs per solve)
+  bool pev_open = false;
   auto P0 = [&](int kind) {
-    if (!ctx->profile) return;
+    pev_open = ctx->profile == 1 || ctx->profile == 2 + kind;
+    if (!pev_open) return;
     while ((int)ctx->pev.size() < 2 * (pidx + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ctx->pev.push_back(e); }
     ctx->pev_kind.push_back(kind);
     (void)hipEventRecord(ctx->pev[2 * pidx], s);
   };
   auto P1 = [&]() {
-    if (!ctx->profile) return;
+    if (!pev_open) return;
     (void)hipEventRecord(ctx->pev[2 * pidx + 1], s);
     ++pidx;
   };

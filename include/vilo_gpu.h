@@ -325,6 +325,8 @@ int vilo_debug_marg_general_count(const vilo_ctx *ctx);
  * forming the inverse of a covariance whose condition number is 1e13..1e14. 1: the reference's route literally (inverse by pivoted Gauss-Jordan
  * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
 int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
+/* Per-kernel HIP-event timing of the solve loop on the context's stream: 0 off (resident batches replay a hipGraph), 1 every kernel,
+ * 2 + k only kernel kind k (vilo_kernel_name(k)). Resets the accumulated times. */
 void vilo_set_profiling(vilo_ctx *ctx, int on);
 int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n);
 const char *vilo_kernel_name(int kind);
