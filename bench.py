@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
     ap.add_argument("--landmarks", type=int, default=0, help="default 200 (1000 with --config 3)")
     ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
+    ap.add_argument("--streams", type=int, default=2, help="resident batches solved concurrently in the multi-stream side figure (default 2: `two_streams`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
@@ -381,29 +382,37 @@ def main():
             out["single_window_iters_per_s"] = 20 * ITERS / (time.perf_counter() - t1)
             b1.close()
         if world == 1 and not args.no_single_window:
-            # Two resident batches of the same size solved concurrently, each on its own context = HIP stream, one host thread each:
-            # the small kernels and the tails of the large ones of one batch run in the gaps of the other. Reported beside `value`,
+            # S resident batches of the same size solved concurrently, each on its own context = HIP stream, one host thread each:
+            # the small kernels and the tails of the large ones of one batch run in the gaps of the others. Reported beside `value`,
             # not as `value`: per-launch kernel durations (the roofline block above) are only meaningful without a co-runner.
             try:
                 import threading
                 lib.vilo_set_profiling(ctx.h, 0)
-                ctx2 = api.Context(cfg, device=local_rank)
-                windows2 = [make_synth_window(cfg, args.landmarks, args.rate, 30260925 + i) for i in range(W)]
-                ctx2.preintegrate_windows(windows2)
-                batch2 = make_batch(ctx2, windows2)
+                S = max(2, args.streams)
+                ctxs, batches = [ctx], [batch]
+                for k in range(1, S):
+                    ck = api.Context(cfg, device=local_rank)
+                    wk = [make_synth_window(cfg, args.landmarks, args.rate, 30260925 + 100000 * k + i) for i in range(W)]
+                    ck.preintegrate_windows(wk)
+                    ctxs.append(ck); batches.append(make_batch(ck, wk))
 
                 def run(b, n):
                     for _ in range(n):
-                        b.reset(); b.solve(opts)
-                for b in (batch, batch2):
+                        b.reset()
+                        if not rp:
+                            b.prepare()
+                        b.solve(opts)
+                for b in batches:
                     run(b, 2)
                 t2 = time.perf_counter()
-                th = [threading.Thread(target=run, args=(b, args.steps)) for b in (batch, batch2)]
+                th = [threading.Thread(target=run, args=(b, args.steps)) for b in batches]
                 [t.start() for t in th]; [t.join() for t in th]
                 dt2 = time.perf_counter() - t2
-                out["two_streams"] = {"value": 2 * W * ITERS * args.steps / dt2, "unit": "GN window-iterations/s", "windows_per_gpu": 2 * W,
-                                      "note": "two batches of %d windows on two HIP streams, same kernels; not the headline value" % W}
-                batch2.close(); ctx2.close()
+                out["two_streams" if S == 2 else "multi_stream"] = {
+                    "value": S * W * ITERS * args.steps / dt2, "unit": "GN window-iterations/s", "streams": S, "windows_per_gpu": S * W,
+                    "note": "%d batches of %d windows on %d HIP streams, same kernels; not the headline value" % (S, W, S)}
+                for b, ck in zip(batches[1:], ctxs[1:]):
+                    b.close(); ck.close()
             except Exception as e:
                 out["two_streams"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
