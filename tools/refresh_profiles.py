@@ -1,20 +1,34 @@
 """Copy the summaries of tools/profile_gpu.sh / tools/profile_sq.sh (run on the GPU box, merged back under gpurun_out/) into
 profiles/round2_* — the files bench.py's roofline block and DESIGN.md cite.
-Usage: python tools/refresh_profiles.py <prof_tag> <sq_tag> [bench.json] [bench_config3.json]"""
+Usage: python tools/refresh_profiles.py <prof_tag> <sq_tag> [bench.json] [bench_config3.json]
+       python tools/refresh_profiles.py --config3 <prof_tag>     (PROFILE_ARGS="--config 3 --windows 1024" bash tools/profile_gpu.sh <prof_tag>)"""
 import json
 import os
 import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def trace_and_pmc(tag, suffix, windows, what):
+    lines = open(os.path.join(R, "gpurun_out", "prof_" + tag, "summary.txt")).read().rstrip("\n").split("\n")
+    js = json.loads(lines[-1])
+    js["windows_per_dispatch"] = windows
+    js["note"] = ("rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (bench.py --steps 2 --warmup 1 %s), "
+                  "calibrated on k_calib_copy; end of round 2" % what)
+    open(os.path.join(R, "profiles", "round2_rocprof_summary%s.txt" % suffix), "w").write("\n".join(lines[:-1]) + "\n")
+    json.dump(js, open(os.path.join(R, "profiles", "round2_pmc%s.json" % suffix), "w"))
+    return js
+
+
+if sys.argv[1] == "--config3":
+    js = trace_and_pmc(sys.argv[2], "_config3", 1024, "--config 3 --windows 1024")
+    for k, v in sorted(js["kernel_trace"].items(), key=lambda kv: -kv[1]["total_ms"])[:8]:
+        print("%-24s %9.1f us  %8.1f KB/window" % (k, v["avg_us"], js["hbm_bytes_per_dispatch"].get(k, 0.0) / 1024 / 1e3))
+    sys.exit(0)
+
 prof, sq = sys.argv[1], sys.argv[2]
-lines = open(os.path.join(R, "gpurun_out", "prof_" + prof, "summary.txt")).read().rstrip("\n").split("\n")
-js = json.loads(lines[-1])
-js["windows_per_dispatch"] = 4096
-js["note"] = ("rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (bench.py --steps 2 --warmup 1 "
-              "--windows 4096), calibrated on k_calib_copy; end of round 2")
-open(os.path.join(R, "profiles", "round2_rocprof_summary.txt"), "w").write("\n".join(lines[:-1]) + "\n")
-json.dump(js, open(os.path.join(R, "profiles", "round2_pmc.json"), "w"))
+js = trace_and_pmc(prof, "", 4096, "--windows 4096")
 lines = open(os.path.join(R, "gpurun_out", "prof_" + sq, "summary.txt")).read().rstrip("\n").split("\n")
 res = json.loads(lines[-1])
 open(os.path.join(R, "profiles", "round2_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
