@@ -531,6 +531,64 @@ __global__ void __launch_bounds__(64) k_visual_cost(BatchDev b, double sq, doubl
   if (lane == 0) *cost_out = csum;
 }
 
+// The same for large batches: one wave per packed wave walks its frames (lane = landmark). The start-frame observation, 1 / lambda and the
+// world point are formed once per landmark and every observation is read once (the per-(wave, frame) form reads the start frame's
+// with every frame: 2 x the bytes); the partial-cost slots keep the layout k_accept sums (slot 0 of the wave, the rest zero).
+__global__ void __launch_bounds__(64) k_visual_cost_walk(BatchDev b, double sq, double huber_a) {
+  const int wave_id = b.wave_order[blockIdx.x];
+  const WaveMeta wv = b.wave[wave_id];
+  const SolverState &st = b.st[wv.win];
+  if (st.done) return;
+  const int lane = threadIdx.x;
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
+  const int n = wv.n_lanes, s = ls.s;
+  const double *x = b.xc + (size_t)wv.win * XSTRIDE;
+  const double *obs = b.obs + wv.obs_off;
+  const unsigned char *flg = b.flags + wv.flag_off;
+  double cost = 0.0;
+  if (ls.active) {
+    const double td = x[XO_TD];
+    const double *ex0 = x + XO_EX, *ex1 = x + XO_EX + 7;
+    const quat qic = ldq_pose(ex0), qic2 = ldq_pose(ex1);
+    const v3 tic = ld3(ex0), tic2 = ld3(ex1);
+    const double inv_lam = 1.0 / b.lamc[ls.gi];
+    const double dti = td - obs[(size_t)10 * n + lane];
+    const v3 pci = mk3((obs[(size_t)0 * n + lane] - obs[(size_t)6 * n + lane] * dti) * inv_lam, (obs[(size_t)1 * n + lane] - obs[(size_t)7 * n + lane] * dti) * inv_lam,
+                       obs[(size_t)2 * n + lane] * inv_lam);
+    const v3 p_i = qrot(qic, pci) + tic;
+    const double *pose_s = x + XO_POSE + 7 * s;
+    const v3 p_w = qrot(ldq_pose(pose_s), p_i) + ld3(pose_s);
+    auto rho_of = [&](const v3 &pcj, double px, double py) {
+      const double inv_z = 1.0 / pcj.z;
+      const double r0 = sq * (pcj.x * inv_z - px), r1 = sq * (pcj.y * inv_z - py);
+      double rho[3];
+      huber_rho(huber_a, r0 * r0 + r1 * r1, rho);
+      return rho[0];
+    };
+    for (int t = 0; t < wv.kmax; ++t) {
+      const unsigned char fl = flg[(size_t)t * n + lane];
+      if (!(fl & 1)) continue;
+      const double *ob = obs + (size_t)t * 11 * n + lane;
+      const double dtj = td - ob[(size_t)10 * n];
+      v3 p_j = p_i;
+      if (t > 0) {
+        const double *pose_j = x + XO_POSE + 7 * min(s + t, VILO_MAX_FRAMES - 1);
+        p_j = qrot(qinv(ldq_pose(pose_j)), p_w - ld3(pose_j));
+        const v3 pcj = qrot(qinv(qic), p_j - tic);
+        cost += rho_of(pcj, ob[0] - ob[(size_t)6 * n] * dtj, ob[(size_t)1 * n] - ob[(size_t)7 * n] * dtj);
+      }
+      if (fl & 2) {
+        const v3 pcj = qrot(qinv(qic2), p_j - tic2);
+        cost += rho_of(pcj, ob[(size_t)3 * n] - ob[(size_t)8 * n] * dtj, ob[(size_t)4 * n] - ob[(size_t)9 * n] * dtj);
+      }
+    }
+  }
+  const double csum = wave_sum(ls.active ? cost : 0.0);
+  double *cost_out = b.chunk_cost + (size_t)wave_id * VILO_MAX_FRAMES;
+  if (lane < VILO_MAX_FRAMES) cost_out[lane] = (lane == 0) ? csum : 0.0;
+}
+
 // =================================================================================================
 // IMU-leg factors
 // =================================================================================================
@@ -951,7 +1009,11 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   }
   // the last candidate (or, without iterations, the initial point) only needs its cost
   P0(3);
-  if (b.n_waves > 0) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha);
+  if (b.n_waves > 0) {
+    // few packed waves: one workgroup per (packed wave, frame) fills the chip; many: one wave per packed wave reads every observation once
+    if (b.lm_part) hipLaunchKernelGGL(k_visual_cost, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha);
+    else hipLaunchKernelGGL(k_visual_cost_walk, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha);
+  }
   P1();
   if (b.rp_on) {
     P0(10);
