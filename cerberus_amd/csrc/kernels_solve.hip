@@ -99,43 +99,13 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
   return ls;
 }
 
-#define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
-#define E1_NTERM 21   // upper triangle of the 6 x 6 ex1 x ex1 block of a right-camera factor's Gram
-#define LM_PTERM (LM_NTERM + E1_NTERM)   // terms per (frame, camera) and landmark in the frame-parallel form's buffer
-// While td is a constant block of the solve the (ex1, td) tile of a right-camera factor's Gram is its 6 x 6 ex1 x ex1 block alone, and that
-// block's target in the pose system does not depend on the observing frame: instead of a third MFMA per k-step (36 useful products in a
-// 16 x 16 tile) every lane sums its 21 products over its frames on the VALU, and the lanes of a segment are added once per wave, in a
-// fixed order, into the (start frame, t = 0) slot; the slots of t > 0 carry zeros there (consumers add the slots of a chunk over t).
-// red: LDS [28][64] scratch. Both forms of the linearisation end with this function on the same per-lane sums: bitwise the same slots.
-__device__ __forceinline__ void e1_segment_totals(BatchDev &b, const WaveMeta &wv, const int cn[4], const int cgo[4], const double *e1acc, double *red) {
-  const int lane = threadIdx.x;
-#pragma unroll
-  for (int v = 0; v < E1_NTERM; ++v) red[v * 64 + lane] = e1acc[v];
-  lds_barrier();
-  if (lane < 28) {
-    // entry `lane` of the packed 7 x 7 upper triangle over (ex1 6, td): 21 ex1 x ex1 entries, then the td column (zeros: td is constant)
-    int a = 0, rem = lane;
-    while (rem >= 7 - a) { rem -= 7 - a; ++a; }
-    const int bc = a + rem;
-    int v = -1;
-    if (bc < 6) { v = 0; for (int q = 0; q < a; ++q) v += 6 - q; v += bc - a; }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g >= wv.nseg) continue;
-      double tot = 0.0;
-      if (v >= 0) for (int i = 0; i < cn[g]; ++i) tot += red[v * 64 + wv.seg_lane0[g] + i];
-      b.gram[(size_t)cgo[g] * VILO_GRAM + tri23(GC_E1 + a, GC_E1 + bc)] = tot;
-    }
-  }
-  lds_barrier();
-}
-
 // TPAR = false: one wave per packed wave walks all its frames (the throughput form: landmark-side sums stay in registers).
 // TPAR = true (small batches, b.lm_part != null): one wave per (packed wave, frame offset) so that a handful of windows still
 // fills the chip; every landmark-side term is written per (frame, camera) and k_visual_reduce adds the terms in the order the
 // walking form adds them — the two forms give bitwise the same linearisation.
 // The factor bodies are visual_lin.hpp's: rotation products hoisted per (start frame, observing frame) pair into an LDS table that 48
 // lanes of the wave build for VT_TB frames at a time, Huber weight folded into the projection Jacobian.
+#define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
 #define VT_TB 2       // frames per table build: lane = (frame of the pair, segment, camera, row) = 2 x 4 x 2 x 3
 template <bool TPAR>
 __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a, int mode) {
@@ -172,9 +142,6 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const int xoff = (lk >> 1) * XLANE + (lk & 1) * XROW + lr;
   const bool c1on = lr < 7;    // columns 23 .. 31 of the second tile column do not exist
   const bool lean = mode != 0 && (wm.const_mask & CONST_TD);
-  double e1acc[E1_NTERM];   // lean: this landmark's ex1 x ex1 products summed over its right-camera factors (e1_segment_totals)
-#pragma unroll
-  for (int v = 0; v < E1_NTERM; ++v) e1acc[v] = 0.0;
   // (coupling rows w: every row of a landmark's column is written exactly once — the observed poses and the extrinsic / td rows with their
   // sums, the rest with zeros at the end; TPAR: the host clears w before the launch, the frames of a landmark run in different workgroups)
   for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
@@ -311,19 +278,8 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
           wj[3 + c] += x0[GC_RJ + c] * Jl[0] + x1[GC_RJ + c] * Jl[1];
         }
         term[20] = x0[GC_TD] * Jl[0] + x1[GC_TD] * Jl[1];
-        if (lean && cam == 1) {
-          int v = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = a; c < 6; ++c, ++v) {
-              const double pr = x0[GC_E1 + a] * x0[GC_E1 + c] + x1[GC_E1 + a] * x1[GC_E1 + c];
-              if (TPAR) b.lm_part[((size_t)(t * 2 + cam) * LM_PTERM + LM_NTERM + v) * b.n_lm + ls.gi] = pr;
-              else e1acc[v] += pr;
-            }
-        }
         if (TPAR) {
-          double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_PTERM) * b.n_lm + ls.gi;
+          double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
 #pragma unroll
           for (int v = 0; v < LM_NTERM; ++v) pt[(size_t)v * b.n_lm] = term[v];
         } else {
@@ -370,13 +326,6 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1[u], p1[u], G11[g], 0, 0, 0);
           }
         };
-        auto dotrip01 = [&](const double *p0, const double *p1) {   // (lean, right camera: the ex1 x ex1 block is summed on the VALU)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G00[g], 0, 0, 0);
-            G01[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p1[u], G01[g], 0, 0, 0);
-          }
-        };
         auto dotrip0 = [&](const double *p0) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G00[g], 0, 0, 0);
@@ -396,20 +345,6 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
               ldtrip0(min(kk0 + 8, 30), a0);
               __builtin_amdgcn_sched_barrier(0);
               dotrip0(n0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        } else if (lean) {
-          ldtrip(k0, a0, a1);
-          for (int kk0 = k0; kk0 < k1; kk0 += 8) {
-            ldtrip(min(kk0 + 4, 30), n0, n1);
-            __builtin_amdgcn_sched_barrier(0);
-            dotrip01(a0, a1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk0 + 4 < k1) {
-              ldtrip(min(kk0 + 8, 30), a0, a1);
-              __builtin_amdgcn_sched_barrier(0);
-              dotrip01(n0, n1);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -441,7 +376,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         const int row = lk + 4 * r;
         if (row <= lr) gs[tri23(row, lr)] = G00[g][r];
         if (c1on) gs[tri23(row, 16 + lr)] = G01[g][r];
-        if (c1on && row < 7 && row <= lr && !(lean && t == 0)) gs[tri23(16 + row, 16 + lr)] = lean ? 0.0 : G11[g][r];
+        if (c1on && row < 7 && row <= lr) gs[tri23(16 + row, 16 + lr)] = G11[g][r];
       }
     }
     if (TPAR) {
@@ -466,7 +401,6 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     }
     wbase[(size_t)CD_TD * L + li] = wc_td;
   }
-  if (!TPAR && lean) e1_segment_totals(b, wv, cn, cgo, e1acc, X);   // (every lane of the wave: padding lanes carry zeros)
   // robust cost of the evaluated point: per packed wave (walking form: slot 0 of the wave's frame slots, the rest zero) or per (packed
   // wave, frame); k_accept adds the slots of a window in a fixed order
   {
@@ -491,24 +425,16 @@ __global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) {
   const int lane = threadIdx.x;
   int cs[4], cn[4], ckm[4], cgo[4];
   const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
-  __shared__ double red[28 * 64];
-  const bool lean = mode != 0 && (wm.const_mask & CONST_TD);
-  double acc[LM_PTERM];
-#pragma unroll
-  for (int v = 0; v < LM_PTERM; ++v) acc[v] = 0.0;
-  if (ls.active)
-    for (int t = 0; t < wv.kmax; ++t)
-      for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
-        const double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_PTERM) * b.n_lm + ls.gi;
-#pragma unroll
-        for (int v = 0; v < LM_NTERM; ++v) acc[v] += pt[(size_t)v * b.n_lm];
-        if (lean && cam == 1) {
-#pragma unroll
-          for (int v = LM_NTERM; v < LM_PTERM; ++v) acc[v] += pt[(size_t)v * b.n_lm];
-        }
-      }
-  if (lean) e1_segment_totals(b, wv, cn, cgo, acc + LM_NTERM, red);
   if (!ls.active) return;
+  double acc[LM_NTERM];
+#pragma unroll
+  for (int v = 0; v < LM_NTERM; ++v) acc[v] = 0.0;
+  for (int t = 0; t < wv.kmax; ++t)
+    for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
+      const double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
+#pragma unroll
+      for (int v = 0; v < LM_NTERM; ++v) acc[v] += pt[(size_t)v * b.n_lm];
+    }
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
   const int L = wm.L, li = ls.li, s = ls.s;
   b.lm_E[ls.gi] = acc[0];
@@ -540,7 +466,7 @@ static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream
   if (b.n_waves <= 0) return;
   if (b.lm_part) {
     hipLaunchKernelGGL(k_visual_clear, dim3(b.n_waves), dim3(64), 0, s, b, mode);
-    (void)hipMemsetAsync(b.lm_part, 0, sizeof(double) * (size_t)VILO_MAX_FRAMES * 2 * LM_PTERM * b.n_lm, s);
+    (void)hipMemsetAsync(b.lm_part, 0, sizeof(double) * (size_t)VILO_MAX_FRAMES * 2 * LM_NTERM * b.n_lm, s);
     hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     hipLaunchKernelGGL(k_visual_reduce, dim3(b.n_waves), dim3(64), 0, s, b, mode);
   } else {

@@ -125,7 +125,7 @@ struct BatchDev {
   double *lm_E, *lm_dh2, *lm_y, *lm_scale, *lm_einv;  // [n_lm]
   double *lm_gbuf[2];         // [n_lm] x 2: landmark gradients of the current linearisation (SolverState::cur) and of the candidate's
   double *lm_w;               // per window: [80][L] at 80 * lm_off
-  double *lm_part;            // small batches only (else null): [11 frames][2 cameras][42 terms][n_lm] landmark-side terms (21) and ex1 x ex1 products (21) of the
+  double *lm_part;            // small batches only (else null): [11 frames][2 cameras][21 terms][n_lm] landmark-side terms of the
                               // frame-parallel linearisation (k_visual_linearize_tpar / k_visual_reduce)
   double *gram;               // [n_gram][VILO_GRAM]
   double *chunk_cost;         // [n_waves][VILO_MAX_FRAMES] partial visual cost per (packed wave, frame offset)

@@ -437,7 +437,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   D.lm_part = nullptr;
   const char *tp_env = getenv("VILO_TPAR_MAX_WAVES");   // tuning aid; VILO_NO_TPAR=1 = 0
   const size_t tpar_max = getenv("VILO_NO_TPAR") ? 0 : (tp_env ? (size_t)atol(tp_env) : 256);
-  if (waves.size() <= tpar_max) TRYB(dev_alloc(ctx, bt, &D.lm_part, (size_t)lm_total * VILO_MAX_FRAMES * 2 * 42));   // LM_PTERM terms per (frame, camera) and landmark
+  if (waves.size() <= tpar_max) TRYB(dev_alloc(ctx, bt, &D.lm_part, (size_t)lm_total * VILO_MAX_FRAMES * 2 * 21));
   TRYB(dev_alloc(ctx, bt, &D.gram, (size_t)gram_total * VILO_GRAM));
   TRYB(dev_alloc(ctx, bt, &D.chunk_cost, waves.size() * VILO_MAX_FRAMES));   // per (packed wave, frame offset) partial costs
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
