@@ -519,22 +519,47 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
         tile[e] = (j < nl) ? wl[(size_t)act_a[k] * wm.L + drop_lm[(size_t)win * max_l0 + l0 + j]] : 0.0;
       }
       __syncthreads();
+      // W D^-1 W^T of the tile on the FP64 matrix cores: one 16 x 16 block of the (compact) active-dimension index per wave, K = the
+      // 32 landmarks of the tile (8 k-steps); lane (lr, lk) supplies W[16 K1 + lr][4 kk + lk] / D and W[16 K2 + lr][4 kk + lk]
+      {
+        const int wv_ = tid >> 6, lane_ = tid & 63, lr = lane_ & 15, lk = lane_ >> 4;
+        const int nb = (na + 15) >> 4;
+        for (int blk = wv_; blk < (nb * (nb + 1)) / 2; blk += MGT / 64) {
+          int K1 = 0;
+          while (((K1 + 1) * (K1 + 2)) / 2 <= blk) ++K1;
+          const int K2 = blk - (K1 * (K1 + 1)) / 2;
+          const int ra = 16 * K1 + lr, rb = 16 * K2 + lr;
+          mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < MG_TILE / 4; ++kk) {
+            const int j = 4 * kk + lk;
+            const double wa = (ra < na && j < nl) ? tile[ra * MG_TILE + j] * dinv[j] : 0.0;
+            const double wb = (rb < na && j < nl) ? tile[rb * MG_TILE + j] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, wb, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k1 = 16 * K1 + lk + 4 * r, k2 = 16 * K2 + lr;
+            if (k1 < na && k2 < na && (K1 != K2 || k2 <= k1)) {
+              const int t1 = act_t[k1], t2 = act_t[k2];
+              A1[t1 * T + t2] -= acc[r];
+              if (t1 != t2) A1[t2 * T + t1] -= acc[r];
+            }
+          }
+        }
+      }
+      // the certificate's copy of the dense dropped block takes the same update with 1 / (D - eps)
       for (int e = tid; e < na * (na + 1) / 2; e += MGT) {
         int k1 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((k1 + 1) * (k1 + 2) / 2 <= e) ++k1;
         while (k1 * (k1 + 1) / 2 > e) --k1;
         const int k2 = e - k1 * (k1 + 1) / 2;
-        double sacc = 0.0, se = 0.0;
         const int t1 = act_t[k1], t2 = act_t[k2];
-        const bool cert = t1 < md && t2 < md;
-        for (int j = 0; j < nl; ++j) {
-          const double ww = tile[k1 * MG_TILE + j] * tile[k2 * MG_TILE + j];
-          sacc += ww * dinv[j];
-          if (cert) se += ww * deps[j];
-        }
-        A1[t1 * T + t2] -= sacc;
-        if (t1 != t2) A1[t2 * T + t1] -= sacc;
-        if (cert) { Ce[t1 * md + t2] -= se; if (t1 != t2) Ce[t2 * md + t1] -= se; }
+        if (!(t1 < md && t2 < md)) continue;
+        double se = 0.0;
+        for (int j = 0; j < nl; ++j) se += tile[k1 * MG_TILE + j] * tile[k2 * MG_TILE + j] * deps[j];
+        Ce[t1 * md + t2] -= se;
+        if (t1 != t2) Ce[t2 * md + t1] -= se;
       }
       if (tid < na) {
         double sacc = 0.0;
@@ -562,19 +587,35 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
     }
   }
   __syncthreads();
-  // A' (lower triangle, mirrored: SelfAdjointEigenSolver reads the lower triangle) into registers, then compact to ld = MG_LD
-  constexpr int PER = (MG_NMAX * MG_NMAX + MGT - 1) / MGT;
-  double keep[PER];
+  // A' = Arr - Y^T Y (lower triangle, mirrored: SelfAdjointEigenSolver reads the lower triangle) on the FP64 matrix cores: 16 x 16 blocks
+  // of the kept dimensions, K = the <= 19 dense dropped dims (5 k-steps); the blocks stay in registers until every wave has read its part
+  // of A1, then go to the compact layout (ld = MG_LD) that overlaps it
+  constexpr int NBN = (MG_NMAX + 15) / 16, NBLK = (NBN * (NBN + 1)) / 2, BPW = (NBLK + MGT / 64 - 1) / (MGT / 64);
+  mfma_d4 keep[BPW];
+  {
+    const int wv_ = tid >> 6, lane_ = tid & 63, lr = lane_ & 15, lk = lane_ >> 4;
+    const int nbn = (n + 15) >> 4;
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int e = tid + u * MGT;
-    keep[u] = 0.0;
-    if (e < n * n) {
-      int i = e / n, j = e % n;
-      if (j > i) { const int t_ = i; i = j; j = t_; }
-      double sacc = A1[(md + i) * T + md + j];
-      for (int k = 0; k < md; ++k) sacc -= Y[k * n + i] * Y[k * n + j];
-      keep[u] = sacc;
+    for (int u = 0; u < BPW; ++u) {
+      const int blk = wv_ + u * (MGT / 64);
+      keep[u] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      if (blk >= (nbn * (nbn + 1)) / 2) continue;
+      int I = 0;
+      while (((I + 1) * (I + 2)) / 2 <= blk) ++I;
+      const int J = blk - (I * (I + 1)) / 2;
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const int k = 4 * kk + lk;
+        const double ya = (k < md && 16 * I + lr < n) ? Y[k * n + 16 * I + lr] : 0.0;
+        const double yc = (k < md && 16 * J + lr < n) ? Y[k * n + 16 * J + lr] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, yc, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + lk + 4 * r, j = 16 * J + lr;
+        keep[u][r] = (i < n && j < n && j <= i) ? A1[(md + i) * T + md + j] - acc[r] : 0.0;
+      }
     }
   }
   if (tid < n) {
@@ -584,10 +625,22 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   }
   __syncthreads();
   double *Ar = ml, *V2 = ml + MG_NMAX * MG_LD;
+  {
+    const int wv_ = tid >> 6, lane_ = tid & 63, lr = lane_ & 15, lk = lane_ >> 4;
+    const int nbn = (n + 15) >> 4;
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int e = tid + u * MGT;
-    if (e < n * n) Ar[(e / n) * MG_LD + e % n] = keep[u];
+    for (int u = 0; u < BPW; ++u) {
+      const int blk = wv_ + u * (MGT / 64);
+      if (blk >= (nbn * (nbn + 1)) / 2) continue;
+      int I = 0;
+      while (((I + 1) * (I + 2)) / 2 <= blk) ++I;
+      const int J = blk - (I * (I + 1)) / 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + lk + 4 * r, j = 16 * J + lr;
+        if (i < n && j < n && j <= i) { Ar[i * MG_LD + j] = keep[u][r]; Ar[j * MG_LD + i] = keep[u][r]; }
+      }
+    }
   }
   __syncthreads();
   stamp(4);
