@@ -319,86 +319,216 @@ __device__ void chol_lds(double *M, int ld, int d, int *fail) {
   }
 }
 
-// sum over the workgroup: wave shuffles, then one LDS slot per wave
-__device__ double blk_sum_w(double v, double *wsum /*LDS [MGT/64]*/) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  const int tid = threadIdx.x;
-  __syncthreads();
-  if ((tid & 63) == 0) wsum[tid >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int i = 0; i < MGT / 64; ++i) r += wsum[i];
-  return r;
+// A' -> J0, r0 (marginalization_factor.cpp:297-305: J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b over the eigenpairs with S > eps) without forming V.
+//
+// With A' = X X^T, rotating the columns of X from the right until they are mutually orthogonal (one-sided Jacobi, Hestenes) leaves
+// X = V sqrt(S): the columns ARE the rows of J0, their squared norms the eigenvalues, r0_i = x_i^T b / S_i, and X X^T = A' holds after
+// every rotation, so J0^T J0 = A' to rounding whatever the state of convergence (which only decides the eps threshold and r0).
+//   1. X from a diagonally pivoted Cholesky without row exchanges: step k takes the largest remaining diagonal entry j, column
+//      k of X = A[:, j] / sqrt(A[j][j]) over the rows not yet taken, A -= x_k x_k^T. It stops at the first pivot <= 0: a
+//      semi-definite A' (the 4 gauge directions of a first prior) gives r < n columns. Jacobi then works on X^T X = L^T L, one
+//      step of the LR iteration past A'.
+//   2. Pair i of a step = the two columns lane i holds in registers (its "top" and "bottom"), 12 rows of them per wave (8 of the 16
+//      waves). A step: every wave leaves the three partial dot products of its rows in LDS, wave 0 sums them and computes the rotation
+//      of every pair, every wave rotates its rows and makes the round-robin tournament's move inside the registers (tops one lane up,
+//      bottoms one lane down: v_mov_b32_dpp wave_shr:1 / wave_shl:1). The matrix never touches LDS inside the sweeps.
+//   3. Sweeps end when the largest |cos| a sweep met is <= 1e-7 (quadratic convergence: the sweep itself took it to 1e-14).
+// 1 / sqrt(x) to double rounding: v_rsq_f64 (about 2^-23) and two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// max over the wave of non-negative values (0.0 is the identity the DPP steps shift in), the same in every lane: prefix maxima within
+// each row of 16 lanes (row_shr 1, 2, 4, 8), row_bcast15 / row_bcast31 across rows, lane 63 holds the result
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+  v = dpp_max_step<0x111, 0xF>(v);
+  v = dpp_max_step<0x112, 0xF>(v);
+  v = dpp_max_step<0x114, 0xF>(v);
+  v = dpp_max_step<0x118, 0xF>(v);
+  v = dpp_max_step<0x142, 0xA>(v);
+  v = dpp_max_step<0x143, 0xC>(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// Two-sided cyclic Jacobi on LDS-resident A, V (ne x ne with ne even: an odd problem is padded by a decoupled zero row/column).
-// diag(A) = eigenvalues, columns of V = eigenvectors. Round-robin pairing gives ne/2 disjoint rotations per step; each 2x2 block
-// A[{p_a,q_a}][{p_b,q_b}] is rotated from both sides in one pass (read once, written once), V from the right.
-__device__ void jacobi_eigh_lds(double *A, double *V, int n, int ld, double *cs, int *pq, double *wsum) {
+__device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetric, destroyed */, double *P /* MG_NMAX x MG_LD */, const double *br, int n, double eps,
+                                 double *cs /* LDS [96] */, double *J0, double *r0, int *status_w, long long *clk_w /* [8] or null */) {
+  __shared__ int bad, conv;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int ne = (n + 1) & ~1, half = ne / 2;
-  for (int e = tid; e < ne * ld; e += MGT) {
-    const int i = e / ld, j = e % ld;
-    if (j < ne) {
-      V[e] = (i == j) ? 1.0 : 0.0;
-      if (i >= n || j >= n) A[e] = 0.0;
+  const int ty = tid >> 5, tx = tid & 31;
+  for (int e = tid; e < MG_NMAX * MG_LD; e += MGT) P[e] = 0.0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  {
+    bool nf = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        if (ty + 32 * a < n && tx + 32 * b < n) nf |= !isfinite(Ar[(ty + 32 * a) * MG_LD + tx + 32 * b]);
+    if (tid < n) nf |= !isfinite(br[tid]);
+    if (nf) bad = 1;
+  }
+  // ---- pivoted Cholesky, one barrier per step: every wave finds the pivot for itself (diagonal entry with its index in the low 7 mantissa
+  //      bits, so one max decides value and index; ties go to the smaller index), then the 32 x 32 thread grid forms column k from
+  //      column / row j of A (read-only in this step: the taken rows and columns are never written again) and applies the rank-1 update.
+  //      Which rows are taken lives in registers: every thread tracks its own 3 rows and 3 columns. ----
+  //      No guarded loads or stores in the step (each would be a branch with its own wait): rows / columns beyond n count as taken, a taken
+  //      row contributes x = 0, so its entries are rewritten with the value they hold. ----
+  int r = 0;
+  bool ur[3], uc[3], ud[2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { ur[a] = ty + 32 * a >= n; uc[a] = tx + 32 * a >= n; }
+  ud[0] = lane >= n; ud[1] = lane + 64 >= n;
+  const int dg0 = lane * (MG_LD + 1), dg1 = min(lane + 64, MG_NMAX - 1) * (MG_LD + 1);
+  for (int k = 0; k < n; ++k) {
+    const double d0 = Ar[dg0], d1 = Ar[dg1];
+    double best = 0.0;
+    if (!ud[0] && d0 > 0.0) best = __hiloint2double(__double2hiint(d0), (__double2loint(d0) & ~127) | (127 - lane));
+    if (!ud[1] && d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
+    best = wave_max_nonneg(best);
+    if (!(best > 0.0)) break;
+    const int j = 127 - (__double2loint(best) & 127);
+    ud[0] |= (lane == j); ud[1] |= (lane + 64 == j);
+    const double rs = rsqrt_nr(Ar[j * (MG_LD + 1)]);
+    double xr[3], xc[3], av[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      xr[a] = Ar[(ty + 32 * a) * MG_LD + j];
+      xc[a] = Ar[j * MG_LD + tx + 32 * a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) av[a][b] = Ar[(ty + 32 * a) * MG_LD + tx + 32 * b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      xr[a] = ur[a] ? 0.0 : xr[a] * rs;
+      xc[a] = uc[a] ? 0.0 : xc[a] * rs;
+    }
+    if (tx == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) P[k * MG_LD + ty + 32 * a] = xr[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      ur[a] |= (ty + 32 * a == j); uc[a] |= (tx + 32 * a == j);
+      xr[a] = ur[a] ? 0.0 : xr[a];
+      xc[a] = uc[a] ? 0.0 : xc[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Ar[(ty + 32 * a) * MG_LD + tx + 32 * b] = av[a][b] - xr[a] * xc[b];
+    __syncthreads();
+    ++r;
+  }
+  __syncthreads();
+  if (clk_w && tid == 0) clk_w[7] = (long long)__builtin_readcyclecounter();
+  const int ne = max(4, (r + 1) & ~1), h = ne >> 1;   // zero columns fill up; at least two pairs, so the move below has no special case
+  constexpr int JW = 8, JR = 12;   // waves that hold rows, rows per wave (JW * JR >= MG_NMAX)
+  static_assert(JW * JR >= MG_NMAX && JW <= MGT / 64, "row split of the Jacobi sweeps");
+  double *part = Ar;   // [3][JW][48] partial dot products; A' is spent
+  {
+    const bool act = lane < h && wv < JW;
+    const int lc = min(lane, 47);
+    double t[JR], b[JR];   // this wave's JR rows of the two columns of pair `lane`
+#pragma unroll
+    for (int i = 0; i < JR; ++i) {
+      const double tv = P[lc * MG_LD + wv % JW + JW * i], bv = P[min(h + lc, MG_NMAX - 1) * MG_LD + wv % JW + JW * i];
+      t[i] = act ? tv : 0.0;
+      b[i] = act ? bv : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+      double mx = 0.0;   // largest cos^2 this sweep rotated away (wave 0)
+      for (int step = 0; step < ne - 1; ++step) {
+        if (wv < JW) {
+          double a_ = 0.0, b_ = 0.0, g_ = 0.0;
+#pragma unroll
+          for (int i = 0; i < JR; ++i) { a_ += t[i] * t[i]; b_ += b[i] * b[i]; g_ += t[i] * b[i]; }
+          if (act) { part[wv * 48 + lane] = a_; part[(JW + wv) * 48 + lane] = b_; part[(2 * JW + wv) * 48 + lane] = g_; }
+        }
+        __syncthreads();
+        if (wv == 0 && act) {
+          double sa = 0.0, sb = 0.0, sg = 0.0;
+#pragma unroll
+          for (int w = 0; w < JW; ++w) { sa += part[w * 48 + lane]; sb += part[(JW + w) * 48 + lane]; sg += part[(2 * JW + w) * 48 + lane]; }
+          // tan 2 theta = 2 sg / (sb - sa), |theta| <= pi / 4: cos 2 theta = |zeta| / hyp, c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
+          double c = 1.0, sn = 0.0;
+          const double ab = sa * sb, g2 = sg * sg;
+          const double zeta = sb - sa, gam = 2.0 * sg, hyp2 = zeta * zeta + gam * gam;
+          if (g2 > 1e-28 * ab && hyp2 > 1e-290) {
+            mx = fmax(mx, g2 * __builtin_amdgcn_rcp(ab));
+            const double rh = rsqrt_nr(hyp2);
+            const double c2 = fabs(zeta) * rh, s2 = (zeta >= 0.0 ? gam : -gam) * rh;
+            const double hc = 0.5 + 0.5 * c2, rc = rsqrt_nr(hc);
+            c = hc * rc;
+            sn = 0.5 * s2 * rc;
+          }
+          cs[2 * lane] = c; cs[2 * lane + 1] = sn;
+        }
+        __syncthreads();
+        if (wv < JW) {
+          // rotate, then the round-robin move inside the registers: tops go one lane up (lane 0 keeps its own, lane 1 takes lane 0's
+          // bottom), bottoms one lane down (lane h - 1 takes its own top). All 64 lanes run this: a DPP move reads its neighbour's register.
+          const double c = cs[2 * lc], sn = cs[2 * lc + 1];
+          const bool first = lane == 0, last = lane == h - 1;
+#pragma unroll
+          for (int i = 0; i < JR; ++i) {
+            const double tn = c * t[i] - sn * b[i], bn = sn * t[i] + c * b[i];
+            t[i] = dpp_mov<0x138>(tn, first ? bn : tn);   // wave_shr:1
+            const double bd = dpp_mov<0x130>(bn, bn);     // wave_shl:1
+            b[i] = last ? tn : bd;
+          }
+        }
+      }
+      if (wv == 0) {
+        mx = wave_max_nonneg(mx);
+        if (lane == 0) conv = (mx <= 1e-14) ? 1 : 0;
+      }
+      __syncthreads();
+      if (conv) break;
+    }
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < JR; ++i) { P[lane * MG_LD + wv + JW * i] = t[i]; P[(h + lane) * MG_LD + wv + JW * i] = b[i]; }
     }
   }
   __syncthreads();
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, dg = 0.0;
-    for (int i = wv; i < n; i += MGT / 64)
-      for (int j = lane; j < n; j += 64) {
-        const double v = A[i * ld + j];
-        if (i == j) dg += v * v; else if (j > i) off += v * v;
-      }
-    off = blk_sum_w(off, wsum);
-    dg = blk_sum_w(dg, wsum);
-    if (off <= 1e-60 || off <= 1e-32 * dg) break;
-    for (int step = 0; step < ne - 1; ++step) {
-      if (tid < half) {
-        // circle method: position tid plays position ne-1-tid; the player at position k is (k == ne-1) ? ne-1 : (k + step) % (ne-1)
-        const int ka = tid, kb = ne - 1 - tid;
-        int p = (ka + step) % (ne - 1);
-        int q = (kb == ne - 1) ? ne - 1 : (kb + step) % (ne - 1);
-        if (p > q) { const int t_ = p; p = q; q = t_; }
-        double c = 1.0, sn = 0.0;
-        const double apq = A[p * ld + q];
-        if (apq != 0.0) {
-          const double app = A[p * ld + p], aqq = A[q * ld + q];
-          const double tau = (aqq - app) / (2.0 * apq);
-          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          sn = t * c;
-        }
-        pq[2 * tid] = p; pq[2 * tid + 1] = q;
-        cs[2 * tid] = c; cs[2 * tid + 1] = sn;
-      }
-      __syncthreads();
-      // A <- J^T A J, block (a, b) = rows {p_a, q_a} x columns {p_b, q_b}
-      if (lane < half) {
-        const int pb = pq[2 * lane], qb = pq[2 * lane + 1];
-        const double cb = cs[2 * lane], sb = cs[2 * lane + 1];
-        for (int a = wv; a < half; a += MGT / 64) {
-          const int pa = pq[2 * a], qa = pq[2 * a + 1];
-          const double ca = cs[2 * a], sa = cs[2 * a + 1];
-          const double x00 = A[pa * ld + pb], x01 = A[pa * ld + qb], x10 = A[qa * ld + pb], x11 = A[qa * ld + qb];
-          const double r00 = ca * x00 - sa * x10, r01 = ca * x01 - sa * x11;   // rows: J_a^T
-          const double r10 = sa * x00 + ca * x10, r11 = sa * x01 + ca * x11;
-          A[pa * ld + pb] = cb * r00 - sb * r01; A[pa * ld + qb] = sb * r00 + cb * r01;   // columns: J_b
-          A[qa * ld + pb] = cb * r10 - sb * r11; A[qa * ld + qb] = sb * r10 + cb * r11;
-        }
-        // V <- V J
-        for (int k = wv; k < ne; k += MGT / 64) {
-          const double vkp = V[k * ld + pb], vkq = V[k * ld + qb];
-          V[k * ld + pb] = cb * vkp - sb * vkq;
-          V[k * ld + qb] = sb * vkp + cb * vkq;
-        }
-      }
-      __syncthreads();
+  if (clk_w && tid == 0) clk_w[5] = (long long)__builtin_readcyclecounter();
+  // eigenvalue of position i = |x_i|^2; after whole sweeps every column is back at the position it started from, any order of the rows of J0 is as good
+  if (tid < MG_NMAX) {
+    double S = 0.0, xb = 0.0;
+    if (tid < ne)
+      for (int row = 0; row < n; ++row) { const double v = P[tid * MG_LD + row]; S += v * v; xb += v * br[row]; }
+    cs[tid] = S;
+    if (tid < n) {
+      const double rv = (S > eps) ? xb / S : 0.0;
+      r0[tid] = rv;
+      if (!isfinite(rv) || bad) *status_w = 1;
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int i = ty + 32 * a;
+    if (i >= n) continue;
+    const bool keep = cs[i] > eps;
+    for (int j = tx; j < n; j += 32) J0[i * n + j] = keep ? P[i * MG_LD + j] : 0.0;
+  }
 }
 
 __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const MargWin *mw, const int *drop_lm, int max_l0, double *J0_out,
@@ -407,8 +537,6 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   double *A1 = ml, *tile = ml + MG_TILE_OFF;
   double *b1 = ml + MG_R0, *dinv = b1 + MG_TMAX, *deps = dinv + MG_TILE, *gl = deps + MG_TILE, *Ce = gl + MG_TILE, *cs = Ce + 19 * 19;
   double *yb = cs + 2 * 48, *br = yb + 19;
-  __shared__ double wsum[MGT / 64];
-  __shared__ int pq[2 * 48];
   __shared__ int act_a[80], act_t[80];
   __shared__ int n_act, fail;
   __shared__ double dx[VILO_MAX_PRIOR_DIM];
@@ -644,21 +772,8 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   }
   __syncthreads();
   stamp(4);
-  jacobi_eigh_lds(Ar, V2, n, MG_LD, cs, pq, wsum);
-  stamp(5);
   double *J0 = J0_out + (size_t)win * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, *r0 = r0_out + (size_t)win * VILO_MAX_PRIOR_DIM;
-  for (int e = tid; e < n * n; e += MGT) {
-    const int i = e / n, j = e % n;
-    const double S = Ar[i * MG_LD + i];
-    J0[e] = (S > eps) ? sqrt(S) * V2[j * MG_LD + i] : 0.0;
-  }
-  for (int i = tid; i < n; i += MGT) {
-    const double S = Ar[i * MG_LD + i];
-    double sacc = 0.0;
-    for (int j = 0; j < n; ++j) sacc += V2[j * MG_LD + i] * br[j];
-    r0[i] = (S > eps) ? sqrt(1.0 / S) * sacc : 0.0;
-    if (!isfinite(r0[i])) status[win] = 1;
-  }
+  prior_factor_lds(Ar, V2, br, n, eps, cs, J0, r0, &status[win], clk ? clk + win * 8 : nullptr);
   stamp(6);
 }
 
@@ -937,8 +1052,8 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     if (want_clk) {
       long long c[8];
       if (hipMemcpy(c, d_clk.p, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
-        fprintf(stderr, "[k_marginalize_lds] window 0 cycles: assemble %lld, landmarks %lld, cholesky %lld, schur %lld, jacobi %lld, output %lld\n", c[1] - c[0],
-                c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[6] - c[5]);
+        fprintf(stderr, "[k_marginalize_lds] window 0 cycles: assemble %lld, landmarks %lld, cholesky %lld, schur %lld, pivoted cholesky %lld, jacobi %lld, output %lld\n", c[1] - c[0],
+                c[2] - c[1], c[3] - c[2], c[4] - c[3], c[7] - c[4], c[5] - c[7], c[6] - c[5]);
     }
   }
   ctx->marg_general_count = 0;

@@ -633,6 +633,13 @@ def test_marginalize_and_next_solve_without_leg_factors(ctx, cfg, ocfg):
     Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
     assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max()
     assert np.abs(Jg.T @ pg.r0[:n] - Jo.T @ po.r0[:n]).max() < 1e-6 * np.abs(Jo.T @ po.r0[:n]).max()
+    # no prior: A' is semi-definite (the gauge directions). The eigenvalues the reference keeps (> 1e-8) and the squared column norms
+    # the one-sided Jacobi of k_marginalize_lds keeps agree in number up to the ones that are rounding noise around the threshold,
+    # and the part of r0 that matters (|r0|^2 = b^T A'^+ b) agrees
+    kept_g, kept_o = int((np.abs(Jg).max(axis=1) > 0).sum()), int((np.abs(Jo).max(axis=1) > 0).sum())
+    sv = np.linalg.eigvalsh(Ao)
+    noise = int(((sv > 1e-10) & (sv < 1e-6 * sv[-1] * 1e-6)).sum())
+    assert abs(kept_g - kept_o) <= noise + 0, (kept_g, kept_o, noise, sv[:8])
     w_g, w_o = _vins(cfg, ocfg, n_landmarks=50, seed=62), _vins(cfg, ocfg, n_landmarks=50, seed=62)
     for w in (w_g, w_o):
         w.prior = pg.copy()
