@@ -452,25 +452,41 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
       b[i] = act ? bv : 0.0;
     }
     __syncthreads();
+    const bool first = lane == 0, last = lane == h - 1;
+    double na = 0.0, nb = 0.0;   // wave 0: squared norms of the two columns of pair `lane`
     for (int sweep = 0; sweep < 30; ++sweep) {
       double mx = 0.0;   // largest cos^2 this sweep rotated away (wave 0)
+      // squared column norms from the data once per sweep; inside the sweep they follow the rotations in closed form
+      // (|x_p'|^2 = c^2 a - 2 c s g + s^2 b, |x_q'|^2 = s^2 a + 2 c s g + c^2 b) and travel with their columns
+      if (wv < JW) {
+        double a_ = 0.0, b_ = 0.0;
+#pragma unroll
+        for (int i = 0; i < JR; ++i) { a_ += t[i] * t[i]; b_ += b[i] * b[i]; }
+        if (act) { part[wv * 48 + lane] = a_; part[(JW + wv) * 48 + lane] = b_; }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        na = 0.0; nb = 0.0;
+#pragma unroll
+        for (int w = 0; w < JW; ++w) { na += part[w * 48 + lc]; nb += part[(JW + w) * 48 + lc]; }
+      }
       for (int step = 0; step < ne - 1; ++step) {
         if (wv < JW) {
-          double a_ = 0.0, b_ = 0.0, g_ = 0.0;
+          double g_ = 0.0;
 #pragma unroll
-          for (int i = 0; i < JR; ++i) { a_ += t[i] * t[i]; b_ += b[i] * b[i]; g_ += t[i] * b[i]; }
-          if (act) { part[wv * 48 + lane] = a_; part[(JW + wv) * 48 + lane] = b_; part[(2 * JW + wv) * 48 + lane] = g_; }
+          for (int i = 0; i < JR; ++i) g_ += t[i] * b[i];
+          if (act) part[(2 * JW + wv) * 48 + lane] = g_;
         }
         __syncthreads();
-        if (wv == 0 && act) {
-          double sa = 0.0, sb = 0.0, sg = 0.0;
+        if (wv == 0) {   // all 64 lanes: the norms move by DPP like the columns; lanes >= h carry values nobody reads
+          double sg = 0.0;
 #pragma unroll
-          for (int w = 0; w < JW; ++w) { sa += part[w * 48 + lane]; sb += part[(JW + w) * 48 + lane]; sg += part[(2 * JW + w) * 48 + lane]; }
-          // tan 2 theta = 2 sg / (sb - sa), |theta| <= pi / 4: cos 2 theta = |zeta| / hyp, c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
+          for (int w = 0; w < JW; ++w) sg += part[(2 * JW + w) * 48 + lc];
+          // tan 2 theta = 2 sg / (nb - na), |theta| <= pi / 4: cos 2 theta = |zeta| / hyp, c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
           double c = 1.0, sn = 0.0;
-          const double ab = sa * sb, g2 = sg * sg;
-          const double zeta = sb - sa, gam = 2.0 * sg, hyp2 = zeta * zeta + gam * gam;
-          if (g2 > 1e-28 * ab && hyp2 > 1e-290) {
+          const double ab = na * nb, g2 = sg * sg;
+          const double zeta = nb - na, gam = 2.0 * sg, hyp2 = zeta * zeta + gam * gam;
+          if (act && g2 > 1e-28 * ab && hyp2 > 1e-290) {
             mx = fmax(mx, g2 * __builtin_amdgcn_rcp(ab));
             const double rh = rsqrt_nr(hyp2);
             const double c2 = fabs(zeta) * rh, s2 = (zeta >= 0.0 ? gam : -gam) * rh;
@@ -478,14 +494,18 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
             c = hc * rc;
             sn = 0.5 * s2 * rc;
           }
-          cs[2 * lane] = c; cs[2 * lane + 1] = sn;
+          if (act) { cs[2 * lane] = c; cs[2 * lane + 1] = sn; }
+          const double cc = c * c, ss = sn * sn, x2 = 2.0 * c * sn * sg;
+          const double an = fmax(cc * na - x2 + ss * nb, 0.0), bn = fmax(ss * na + x2 + cc * nb, 0.0);
+          na = dpp_mov<0x138>(an, first ? bn : an);
+          const double bd = dpp_mov<0x130>(bn, bn);
+          nb = last ? an : bd;
         }
         __syncthreads();
         if (wv < JW) {
           // rotate, then the round-robin move inside the registers: tops go one lane up (lane 0 keeps its own, lane 1 takes lane 0's
           // bottom), bottoms one lane down (lane h - 1 takes its own top). All 64 lanes run this: a DPP move reads its neighbour's register.
           const double c = cs[2 * lc], sn = cs[2 * lc + 1];
-          const bool first = lane == 0, last = lane == h - 1;
 #pragma unroll
           for (int i = 0; i < JR; ++i) {
             const double tn = c * t[i] - sn * b[i], bn = sn * t[i] + c * b[i];
