@@ -365,6 +365,97 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// The sweeps of prior_factor_lds for JR row slots per wave (rows wv + JW * i, i < JR; JW * JR >= n): see the comment above it.
+constexpr int JW = 8;   // waves that hold rows
+template <int JR>
+__device__ __forceinline__ void jacobi_sweeps(double *P, double *part /* [3][JW][48] */, double *cs, int *conv_s, int ne) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, h = ne >> 1;
+  const bool act = lane < h && wv < JW;
+  const int lc = min(lane, 47);
+  double t[JR], b[JR];   // this wave's JR rows of the two columns of pair `lane`
+#pragma unroll
+  for (int i = 0; i < JR; ++i) {
+    const double tv = P[lc * MG_LD + wv % JW + JW * i], bv = P[min(h + lc, MG_NMAX - 1) * MG_LD + wv % JW + JW * i];
+    t[i] = act ? tv : 0.0;
+    b[i] = act ? bv : 0.0;
+  }
+  __syncthreads();
+  const bool first = lane == 0, last = lane == h - 1;
+  double na = 0.0, nb = 0.0;   // wave 0: squared norms of the two columns of pair `lane`
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double mx = 0.0;   // largest cos^2 this sweep rotated away (wave 0)
+    // squared column norms from the data once per sweep; inside the sweep they follow the rotations in closed form
+    // (|x_p'|^2 = c^2 a - 2 c s g + s^2 b, |x_q'|^2 = s^2 a + 2 c s g + c^2 b) and travel with their columns
+    if (wv < JW) {
+      double a_ = 0.0, b_ = 0.0;
+#pragma unroll
+      for (int i = 0; i < JR; ++i) { a_ += t[i] * t[i]; b_ += b[i] * b[i]; }
+      if (act) { part[wv * 48 + lane] = a_; part[(JW + wv) * 48 + lane] = b_; }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      na = 0.0; nb = 0.0;
+#pragma unroll
+      for (int w = 0; w < JW; ++w) { na += part[w * 48 + lc]; nb += part[(JW + w) * 48 + lc]; }
+    }
+    for (int step = 0; step < ne - 1; ++step) {
+      if (wv < JW) {
+        double g_ = 0.0;
+#pragma unroll
+        for (int i = 0; i < JR; ++i) g_ += t[i] * b[i];
+        if (act) part[(2 * JW + wv) * 48 + lane] = g_;
+      }
+      __syncthreads();
+      if (wv == 0) {   // all 64 lanes: the norms move by DPP like the columns; lanes >= h carry values nobody reads
+        double sg = 0.0;
+#pragma unroll
+        for (int w = 0; w < JW; ++w) sg += part[(2 * JW + w) * 48 + lc];
+        // tan 2 theta = 2 sg / (nb - na), |theta| <= pi / 4: cos 2 theta = |zeta| / hyp, c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
+        double c = 1.0, sn = 0.0;
+        const double ab = na * nb, g2 = sg * sg;
+        const double zeta = nb - na, gam = 2.0 * sg, hyp2 = zeta * zeta + gam * gam;
+        if (act && g2 > 1e-28 * ab && hyp2 > 1e-290) {
+          mx = fmax(mx, g2 * __builtin_amdgcn_rcp(ab));
+          const double rh = rsqrt_nr(hyp2);
+          const double c2 = fabs(zeta) * rh, s2 = (zeta >= 0.0 ? gam : -gam) * rh;
+          const double hc = 0.5 + 0.5 * c2, rc = rsqrt_nr(hc);
+          c = hc * rc;
+          sn = 0.5 * s2 * rc;
+        }
+        if (act) { cs[2 * lane] = c; cs[2 * lane + 1] = sn; }
+        const double cc = c * c, ss = sn * sn, x2 = 2.0 * c * sn * sg;
+        const double an = fmax(cc * na - x2 + ss * nb, 0.0), bn = fmax(ss * na + x2 + cc * nb, 0.0);
+        na = dpp_mov<0x138>(an, first ? bn : an);
+        const double bd = dpp_mov<0x130>(bn, bn);
+        nb = last ? an : bd;
+      }
+      __syncthreads();
+      if (wv < JW) {
+        // rotate, then the round-robin move inside the registers: tops go one lane up (lane 0 keeps its own, lane 1 takes lane 0's
+        // bottom), bottoms one lane down (lane h - 1 takes its own top). All 64 lanes run this: a DPP move reads its neighbour's register.
+        const double c = cs[2 * lc], sn = cs[2 * lc + 1];
+#pragma unroll
+        for (int i = 0; i < JR; ++i) {
+          const double tn = c * t[i] - sn * b[i], bn = sn * t[i] + c * b[i];
+          t[i] = dpp_mov<0x138>(tn, first ? bn : tn);   // wave_shr:1
+          const double bd = dpp_mov<0x130>(bn, bn);     // wave_shl:1
+          b[i] = last ? tn : bd;
+        }
+      }
+    }
+    if (wv == 0) {
+      mx = wave_max_nonneg(mx);
+      if (lane == 0) *conv_s = (mx <= 1e-14) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*conv_s) break;
+  }
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < JR; ++i) { P[lane * MG_LD + wv + JW * i] = t[i]; P[(h + lane) * MG_LD + wv + JW * i] = b[i]; }
+  }
+}
+
 __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetric, destroyed */, double *P /* MG_NMAX x MG_LD */, const double *br, int n, double eps,
                                  double *cs /* LDS [96] */, double *J0, double *r0, int *status_w, long long *clk_w /* [8] or null */) {
   __shared__ int bad, conv;
@@ -438,95 +529,11 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
   __syncthreads();
   if (clk_w && tid == 0) clk_w[7] = (long long)__builtin_readcyclecounter();
   const int ne = max(4, (r + 1) & ~1), h = ne >> 1;   // zero columns fill up; at least two pairs, so the move below has no special case
-  constexpr int JW = 8, JR = 12;   // waves that hold rows, rows per wave (JW * JR >= MG_NMAX)
-  static_assert(JW * JR >= MG_NMAX && JW <= MGT / 64, "row split of the Jacobi sweeps");
+  static_assert(JW * 12 >= MG_NMAX && JW <= MGT / 64, "row split of the Jacobi sweeps");
   double *part = Ar;   // [3][JW][48] partial dot products; A' is spent
-  {
-    const bool act = lane < h && wv < JW;
-    const int lc = min(lane, 47);
-    double t[JR], b[JR];   // this wave's JR rows of the two columns of pair `lane`
-#pragma unroll
-    for (int i = 0; i < JR; ++i) {
-      const double tv = P[lc * MG_LD + wv % JW + JW * i], bv = P[min(h + lc, MG_NMAX - 1) * MG_LD + wv % JW + JW * i];
-      t[i] = act ? tv : 0.0;
-      b[i] = act ? bv : 0.0;
-    }
-    __syncthreads();
-    const bool first = lane == 0, last = lane == h - 1;
-    double na = 0.0, nb = 0.0;   // wave 0: squared norms of the two columns of pair `lane`
-    for (int sweep = 0; sweep < 30; ++sweep) {
-      double mx = 0.0;   // largest cos^2 this sweep rotated away (wave 0)
-      // squared column norms from the data once per sweep; inside the sweep they follow the rotations in closed form
-      // (|x_p'|^2 = c^2 a - 2 c s g + s^2 b, |x_q'|^2 = s^2 a + 2 c s g + c^2 b) and travel with their columns
-      if (wv < JW) {
-        double a_ = 0.0, b_ = 0.0;
-#pragma unroll
-        for (int i = 0; i < JR; ++i) { a_ += t[i] * t[i]; b_ += b[i] * b[i]; }
-        if (act) { part[wv * 48 + lane] = a_; part[(JW + wv) * 48 + lane] = b_; }
-      }
-      __syncthreads();
-      if (wv == 0) {
-        na = 0.0; nb = 0.0;
-#pragma unroll
-        for (int w = 0; w < JW; ++w) { na += part[w * 48 + lc]; nb += part[(JW + w) * 48 + lc]; }
-      }
-      for (int step = 0; step < ne - 1; ++step) {
-        if (wv < JW) {
-          double g_ = 0.0;
-#pragma unroll
-          for (int i = 0; i < JR; ++i) g_ += t[i] * b[i];
-          if (act) part[(2 * JW + wv) * 48 + lane] = g_;
-        }
-        __syncthreads();
-        if (wv == 0) {   // all 64 lanes: the norms move by DPP like the columns; lanes >= h carry values nobody reads
-          double sg = 0.0;
-#pragma unroll
-          for (int w = 0; w < JW; ++w) sg += part[(2 * JW + w) * 48 + lc];
-          // tan 2 theta = 2 sg / (nb - na), |theta| <= pi / 4: cos 2 theta = |zeta| / hyp, c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
-          double c = 1.0, sn = 0.0;
-          const double ab = na * nb, g2 = sg * sg;
-          const double zeta = nb - na, gam = 2.0 * sg, hyp2 = zeta * zeta + gam * gam;
-          if (act && g2 > 1e-28 * ab && hyp2 > 1e-290) {
-            mx = fmax(mx, g2 * __builtin_amdgcn_rcp(ab));
-            const double rh = rsqrt_nr(hyp2);
-            const double c2 = fabs(zeta) * rh, s2 = (zeta >= 0.0 ? gam : -gam) * rh;
-            const double hc = 0.5 + 0.5 * c2, rc = rsqrt_nr(hc);
-            c = hc * rc;
-            sn = 0.5 * s2 * rc;
-          }
-          if (act) { cs[2 * lane] = c; cs[2 * lane + 1] = sn; }
-          const double cc = c * c, ss = sn * sn, x2 = 2.0 * c * sn * sg;
-          const double an = fmax(cc * na - x2 + ss * nb, 0.0), bn = fmax(ss * na + x2 + cc * nb, 0.0);
-          na = dpp_mov<0x138>(an, first ? bn : an);
-          const double bd = dpp_mov<0x130>(bn, bn);
-          nb = last ? an : bd;
-        }
-        __syncthreads();
-        if (wv < JW) {
-          // rotate, then the round-robin move inside the registers: tops go one lane up (lane 0 keeps its own, lane 1 takes lane 0's
-          // bottom), bottoms one lane down (lane h - 1 takes its own top). All 64 lanes run this: a DPP move reads its neighbour's register.
-          const double c = cs[2 * lc], sn = cs[2 * lc + 1];
-#pragma unroll
-          for (int i = 0; i < JR; ++i) {
-            const double tn = c * t[i] - sn * b[i], bn = sn * t[i] + c * b[i];
-            t[i] = dpp_mov<0x138>(tn, first ? bn : tn);   // wave_shr:1
-            const double bd = dpp_mov<0x130>(bn, bn);     // wave_shl:1
-            b[i] = last ? tn : bd;
-          }
-        }
-      }
-      if (wv == 0) {
-        mx = wave_max_nonneg(mx);
-        if (lane == 0) conv = (mx <= 1e-14) ? 1 : 0;
-      }
-      __syncthreads();
-      if (conv) break;
-    }
-    if (act) {
-#pragma unroll
-      for (int i = 0; i < JR; ++i) { P[lane * MG_LD + wv + JW * i] = t[i]; P[(h + lane) * MG_LD + wv + JW * i] = b[i]; }
-    }
-  }
+  if (n <= JW * 10) jacobi_sweeps<10>(P, part, cs, &conv, ne);
+  else if (n <= JW * 11) jacobi_sweeps<11>(P, part, cs, &conv, ne);
+  else jacobi_sweeps<12>(P, part, cs, &conv, ne);
   __syncthreads();
   if (clk_w && tid == 0) clk_w[5] = (long long)__builtin_readcyclecounter();
   // eigenvalue of position i = |x_i|^2; after whole sweeps every column is back at the position it started from, any order of the rows of J0 is as good
