@@ -298,7 +298,7 @@ constexpr int MG_TILE_OFF = 13312;
 constexpr int MG_SMALL = MG_TMAX + 3 * MG_TILE + 19 * 19 + 2 * 48 + 19 + MG_NMAX + 8;
 constexpr int MG_LDS_DOUBLES = MG_R0 + MG_SMALL;
 static_assert(MG_TILE_OFF >= MG_TMAX * MG_TMAX && MG_TILE_OFF + MG_TMAX * MG_TILE <= MG_R0, "LDS plan");
-static_assert(MG_LDS_DOUBLES * 8 + 2 * 48 * 4 + 2 * 80 * 4 + 96 * 8 + 64 * 8 + 64 <= 160 * 1024, "LDS budget");
+static_assert(MG_LDS_DOUBLES * 8 + 2 * 80 * 4 + 96 * 8 + 2 * 96 * 8 + 64 <= 160 * 1024, "LDS budget");   // dynamic + act_a / act_t, dx, dgb, flags
 
 // in-place Cholesky of the leading d x d block (lower triangle) of M; all threads call. *fail is set when a pivot is not positive.
 __device__ void chol_lds(double *M, int ld, int d, int *fail) {
@@ -474,57 +474,51 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
     if (tid < n) nf |= !isfinite(br[tid]);
     if (nf) bad = 1;
   }
-  // ---- pivoted Cholesky, one barrier per step: every wave finds the pivot for itself (diagonal entry with its index in the low 7 mantissa
-  //      bits, so one max decides value and index; ties go to the smaller index), then the 32 x 32 thread grid forms column k from
-  //      column / row j of A (read-only in this step: the taken rows and columns are never written again) and applies the rank-1 update.
-  //      Which rows are taken lives in registers: every thread tracks its own 3 rows and 3 columns. ----
-  //      No guarded loads or stores in the step (each would be a branch with its own wait): rows / columns beyond n count as taken, a taken
-  //      row contributes x = 0, so its entries are rewritten with the value they hold. ----
+  // ---- pivoted Cholesky, left-looking, one barrier per step. A' stays as it is; the running diagonal lives in LDS (dg), the finished
+  //      columns of X in LDS (P, for the pivot row) and in registers: thread (i, q) = (tid / 8, tid % 8) keeps X[i][q + 8 m], m < 12.
+  //      Step k: every wave finds the pivot j for itself (diagonal entry with its index in the low 7 mantissa bits, so one DPP max decides
+  //      value and index; ties go to the smaller index; taken rows carry 0), then x_i = (A[i][j] - sum_k' X[i][k'] X[j][k']) / sqrt(d_j):
+  //      12 products per thread (columns >= k of P are still zero, so the sum needs no bound) and a sum over the 8 lanes of the row. ----
   int r = 0;
-  bool ur[3], uc[3], ud[2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { ur[a] = ty + 32 * a >= n; uc[a] = tx + 32 * a >= n; }
-  ud[0] = lane >= n; ud[1] = lane + 64 >= n;
-  const int dg0 = lane * (MG_LD + 1), dg1 = min(lane + 64, MG_NMAX - 1) * (MG_LD + 1);
-  for (int k = 0; k < n; ++k) {
-    const double d0 = Ar[dg0], d1 = Ar[dg1];
-    double best = 0.0;
-    if (!ud[0] && d0 > 0.0) best = __hiloint2double(__double2hiint(d0), (__double2loint(d0) & ~127) | (127 - lane));
-    if (!ud[1] && d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
-    best = wave_max_nonneg(best);
-    if (!(best > 0.0)) break;
-    const int j = 127 - (__double2loint(best) & 127);
-    ud[0] |= (lane == j); ud[1] |= (lane + 64 == j);
-    const double rs = rsqrt_nr(Ar[j * (MG_LD + 1)]);
-    double xr[3], xc[3], av[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      xr[a] = Ar[(ty + 32 * a) * MG_LD + j];
-      xc[a] = Ar[j * MG_LD + tx + 32 * a];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) av[a][b] = Ar[(ty + 32 * a) * MG_LD + tx + 32 * b];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      xr[a] = ur[a] ? 0.0 : xr[a] * rs;
-      xc[a] = uc[a] ? 0.0 : xc[a] * rs;
-    }
-    if (tx == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) P[k * MG_LD + ty + 32 * a] = xr[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      ur[a] |= (ty + 32 * a == j); uc[a] |= (tx + 32 * a == j);
-      xr[a] = ur[a] ? 0.0 : xr[a];
-      xc[a] = uc[a] ? 0.0 : xc[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) Ar[(ty + 32 * a) * MG_LD + tx + 32 * b] = av[a][b] - xr[a] * xc[b];
+  {
+    __shared__ double dgb[2][MG_NMAX];   // the diagonal, double-buffered: step k reads [k & 1] while the finished rows write [(k + 1) & 1]
+    if (tid < MG_NMAX) dgb[0][tid] = (tid < n) ? Ar[tid * (MG_LD + 1)] : 0.0;
     __syncthreads();
-    ++r;
+    const int ri = tid >> 3, rq = tid & 7, ric = min(ri, MG_NMAX - 1);
+    bool taken = ri >= n;
+    double xs[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) xs[m] = 0.0;
+    const int l1 = min(lane + 64, MG_NMAX - 1);
+    for (int k = 0; k < n; ++k) {
+      const double *dg = dgb[k & 1];
+      const double d0 = dg[lane], d1 = (lane + 64 < MG_NMAX) ? dg[l1] : 0.0;
+      double best = 0.0;
+      if (d0 > 0.0) best = __hiloint2double(__double2hiint(d0), (__double2loint(d0) & ~127) | (127 - lane));
+      if (d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
+      best = wave_max_nonneg(best);
+      if (!(best > 0.0)) break;
+      const int j = 127 - (__double2loint(best) & 127);
+      const double pv = dg[j], aij = Ar[ric * MG_LD + j];
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 12; ++m) acc += xs[m] * P[(rq + 8 * m) * MG_LD + j];
+      acc += dpp_mov<0xB1>(0.0, acc);    // quad_perm [1, 0, 3, 2]
+      acc += dpp_mov<0x4E>(0.0, acc);    // quad_perm [2, 3, 0, 1]
+      acc += dpp_mov<0x141>(0.0, acc);   // row_half_mirror: the other quad of the 8 lanes
+      const double rs = rsqrt_nr(pv);
+      const double x = taken ? 0.0 : (ri == j ? pv * rs : (aij - acc) * rs);
+      taken |= (ri == j);
+      const bool mine = rq == (k & 7);
+#pragma unroll
+      for (int m = 0; m < 12; ++m) xs[m] = (mine && m == (k >> 3)) ? x : xs[m];
+      if (rq == 0 && ri < MG_NMAX) {
+        P[k * MG_LD + ri] = x;
+        dgb[(k + 1) & 1][ri] = taken ? 0.0 : dg[ri] - x * x;
+      }
+      __syncthreads();
+      ++r;
+    }
   }
   __syncthreads();
   if (clk_w && tid == 0) clk_w[7] = (long long)__builtin_readcyclecounter();
