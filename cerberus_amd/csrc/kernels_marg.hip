@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 
+#include <type_traits>
 #include "solve_common.hpp"
 
 using namespace vilo;
@@ -490,35 +491,44 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
 #pragma unroll
     for (int m = 0; m < 12; ++m) xs[m] = 0.0;
     const int l1 = min(lane + 64, MG_NMAX - 1);
-    for (int k = 0; k < n; ++k) {
-      const double *dg = dgb[k & 1];
-      const double d0 = dg[lane], d1 = (lane + 64 < MG_NMAX) ? dg[l1] : 0.0;
-      double best = 0.0;
-      if (d0 > 0.0) best = __hiloint2double(__double2hiint(d0), (__double2loint(d0) & ~127) | (127 - lane));
-      if (d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
-      best = wave_max_nonneg(best);
-      if (!(best > 0.0)) break;
-      const int j = 127 - (__double2loint(best) & 127);
-      const double pv = dg[j], aij = Ar[ric * MG_LD + j];
-      double acc = 0.0;
+    // columns in blocks of 8 with the block index a compile-time constant: the sum runs over the blocks that exist, and the new entry
+    // goes into a register the code names
+    bool done = false;
+    auto block = [&](auto mbc) {
+      constexpr int mb = decltype(mbc)::value;
+      if (done || 8 * mb >= n) return;
+      for (int k = 8 * mb; k < min(8 * mb + 8, n); ++k) {
+        const double *dg = dgb[k & 1];
+        const double d0 = dg[lane], d1 = (lane + 64 < MG_NMAX) ? dg[l1] : 0.0;
+        double best = 0.0;
+        if (d0 > 0.0) best = __hiloint2double(__double2hiint(d0), (__double2loint(d0) & ~127) | (127 - lane));
+        if (d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
+        best = wave_max_nonneg(best);
+        if (!(best > 0.0)) { done = true; break; }
+        const int j = 127 - (__double2loint(best) & 127);
+        const double pv = dg[j], aij = Ar[ric * MG_LD + j];
+        double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < 12; ++m) acc += xs[m] * P[(rq + 8 * m) * MG_LD + j];
-      acc += dpp_mov<0xB1>(0.0, acc);    // quad_perm [1, 0, 3, 2]
-      acc += dpp_mov<0x4E>(0.0, acc);    // quad_perm [2, 3, 0, 1]
-      acc += dpp_mov<0x141>(0.0, acc);   // row_half_mirror: the other quad of the 8 lanes
-      const double rs = rsqrt_nr(pv);
-      const double x = taken ? 0.0 : (ri == j ? pv * rs : (aij - acc) * rs);
-      taken |= (ri == j);
-      const bool mine = rq == (k & 7);
-#pragma unroll
-      for (int m = 0; m < 12; ++m) xs[m] = (mine && m == (k >> 3)) ? x : xs[m];
-      if (rq == 0 && ri < MG_NMAX) {
-        P[k * MG_LD + ri] = x;
-        dgb[(k + 1) & 1][ri] = taken ? 0.0 : dg[ri] - x * x;
+        for (int m = 0; m <= mb; ++m) acc += xs[m] * P[(rq + 8 * m) * MG_LD + j];   // columns >= k of P, if a faster wave wrote them, meet xs = 0
+        acc += dpp_mov<0xB1>(0.0, acc);    // quad_perm [1, 0, 3, 2]
+        acc += dpp_mov<0x4E>(0.0, acc);    // quad_perm [2, 3, 0, 1]
+        acc += dpp_mov<0x141>(0.0, acc);   // row_half_mirror: the other quad of the 8 lanes
+        const double rs = rsqrt_nr(pv);
+        const double x = taken ? 0.0 : (ri == j ? pv * rs : (aij - acc) * rs);
+        taken |= (ri == j);
+        xs[mb] = (rq == (k & 7)) ? x : xs[mb];
+        if (rq == 0 && ri < MG_NMAX) {
+          P[k * MG_LD + ri] = x;
+          dgb[(k + 1) & 1][ri] = taken ? 0.0 : dg[ri] - x * x;
+        }
+        __syncthreads();
+        ++r;
       }
-      __syncthreads();
-      ++r;
-    }
+    };
+    block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{});
+    block(std::integral_constant<int, 3>{}); block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{});
+    block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{}); block(std::integral_constant<int, 8>{});
+    block(std::integral_constant<int, 9>{}); block(std::integral_constant<int, 10>{}); block(std::integral_constant<int, 11>{});
   }
   __syncthreads();
   if (clk_w && tid == 0) clk_w[7] = (long long)__builtin_readcyclecounter();
