@@ -175,6 +175,32 @@ __device__ inline void put33(double *M, int ld, int r0, int c0, const m3 &A) {
 struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
   double f[3], J[9], v[3], g[3], h[9];
 };
+constexpr int LT_N = 27;   // doubles of a LegTerms record
+static_assert(sizeof(LegTerms) == LT_N * sizeof(double), "LegTerms is 27 consecutive doubles");
+
+// The part of the leg terms of one (sample, leg) that depends on the sample and the linearisation point only (:232-287 without the
+// rotation of the integration state): f, J, v, and g, h before their rotation R_e (g = -(R_e g0), h = R_e h0). A sample is the second
+// endpoint of one step and the first of the next, and the forward kinematics with its derivatives (six sin / cos) is the longest
+// stretch of a step, so an interval evaluates these records for all its samples up front with lane = (sample, leg) and parks them in HBM.
+__device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const vilo_sample &ss, int j, double rho_j, const v3 &bg, const m3 &Rbr, const v3 &pbr,
+                                                 double *out /* LT_N */) {
+  LegKin k;
+  leg_kin_full(ss.phi + 3 * j, rho_j, cfg.rho_fix[j], k);
+  const v3 dphi = ld3(ss.dphi + 3 * j);
+  const m3 Rw = skew(ld3(ss.gyr) - bg);
+  const v3 v = -(Rbr * (k.J * dphi)) - Rw * (pbr + Rbr * k.f);
+  // (dphi^T kron I) dJ/drho = dJ_drho * dphi ; (dphi^T kron I) dJ/dq = [dJ0 dphi, dJ1 dphi, dJ2 dphi]
+  const v3 g0 = Rbr * (k.dJ_drho * dphi) + Rw * (Rbr * k.df_drho);
+  m3 K;
+  const v3 k0 = k.dJ[0] * dphi, k1 = k.dJ[1] * dphi, k2 = k.dJ[2] * dphi;
+  K.a[0] = k0.x; K.a[3] = k0.y; K.a[6] = k0.z;
+  K.a[1] = k1.x; K.a[4] = k1.y; K.a[7] = k1.z;
+  K.a[2] = k2.x; K.a[5] = k2.y; K.a[8] = k2.z;
+  const m3 h0 = Rbr * K + Rw * Rbr * k.J;
+  st3(out, k.f);
+  for (int q = 0; q < 9; ++q) { out[3 + q] = k.J.a[q]; out[18 + q] = h0.a[q]; }
+  st3(out + 12, v); st3(out + 15, g0);
+}
 
 
 }  // namespace
@@ -184,7 +210,7 @@ struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
 // Both run the same arithmetic in the same order: pushing an interval in pieces gives bitwise the batch result.
 template <bool STREAM>
 __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
-                                    PreintStream *st) {
+                                    PreintStream *st, double *terms /* HBM scratch of this interval: 4 * LT_N doubles per sample (+ one sample when STREAM) */) {
   // padded to 32 rows (48 noise columns) with odd leading dimensions: rows / columns 31 and noise 46, 47 stay zero, so the FP64
   // MFMA tiles of jac_cov_update_mfma need no masks
   __shared__ double Fm[32 * FLD], Vm[32 * VLD], nd[48];
@@ -231,6 +257,18 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
+  // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
+  // (batch: the constructor's sample; streaming: the last sample of the previous push)
+  {
+    const int nslots = s_end - s_begin + (STREAM ? 1 : 0);
+    for (int idx = lane; idx < 4 * nslots; idx += 64) {
+      const int slot = idx >> 2, j = idx & 3;
+      const vilo_sample &ss = (STREAM && slot == 0) ? st->last : samples[s_begin + slot - (STREAM ? 1 : 0)];
+      const double rho_j = j == 0 ? rho[0] : (j == 1 ? rho[1] : (j == 2 ? rho[2] : rho[3]));   // (a lane-indexed register array would go to scratch)
+      leg_sample_terms(cfg, ss, j, rho_j, bg, Rbr, pbr, terms + (size_t)idx * LT_N);
+    }
+    __syncthreads();
+  }
 
   for (int si = STREAM ? s_begin : s_begin + 1; si < s_end; ++si) {
     const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
@@ -270,27 +308,26 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
         ff_var[j] = ss / 4;
       }
     }
-    // leg terms on lanes 0..7: lane = 2*leg + endpoint (:232-287)
+    // leg terms (:232-287): the two samples' records come back from HBM (216 doubles, four coalesced loads) into lt[2 * leg + endpoint],
+    // lanes 0..7 rotate g and h by the step's R_0 / R_1
+    {
+      const size_t slot0 = (size_t)(si - 1 - s_begin + (STREAM ? 1 : 0));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = lane + 64 * q;
+        if (idx < 8 * LT_N) {
+          const int e = idx >= 4 * LT_N ? 1 : 0, r = idx - 4 * LT_N * e, j = r / LT_N, c = r - LT_N * j;
+          ((double *)&lt[2 * j + e])[c] = terms[(slot0 + e) * (4 * LT_N) + r];
+        }
+      }
+    }
+    __syncthreads();
     if (lane < 8) {
-      const int j = lane >> 1, e = lane & 1;
-      const vilo_sample &ss = e ? s1 : s0;
-      const m3 &Re = e ? R1 : R0;
-      const v3 we = e ? w1 : w0;
-      LegKin k;
-      leg_kin_full(ss.phi + 3 * j, rho[j], cfg.rho_fix[j], k);
-      const v3 dphi = ld3(ss.dphi + 3 * j);
-      const m3 Rw = skew(we);
-      const v3 v = -(Rbr * (k.J * dphi)) - Rw * (pbr + Rbr * k.f);
-      // (dphi^T kron I) dJ/drho = dJ_drho * dphi ; (dphi^T kron I) dJ/dq = [dJ0 dphi, dJ1 dphi, dJ2 dphi]
-      const v3 g = -(Re * (Rbr * (k.dJ_drho * dphi) + Rw * (Rbr * k.df_drho)));
-      m3 K;
-      const v3 k0 = k.dJ[0] * dphi, k1 = k.dJ[1] * dphi, k2 = k.dJ[2] * dphi;
-      K.a[0] = k0.x; K.a[3] = k0.y; K.a[6] = k0.z;
-      K.a[1] = k1.x; K.a[4] = k1.y; K.a[7] = k1.z;
-      K.a[2] = k2.x; K.a[5] = k2.y; K.a[8] = k2.z;
-      const m3 h = Re * (Rbr * K + Rw * Rbr * k.J);
-      st3(lt[lane].f, k.f); st3(lt[lane].v, v); st3(lt[lane].g, g);
-      for (int q = 0; q < 9; ++q) { lt[lane].J[q] = k.J.a[q]; lt[lane].h[q] = h.a[q]; }
+      const m3 &Re = (lane & 1) ? R1 : R0;
+      const v3 g = -(Re * ld3(lt[lane].g));
+      const m3 h = Re * ld_m3_rowmajor(lt[lane].h);
+      st3(lt[lane].g, g);
+      for (int q = 0; q < 9; ++q) lt[lane].h[q] = h.a[q];
     }
     __syncthreads();
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
@@ -411,10 +448,10 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
 }
 
 __global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
-                                                       const double *lin, vilo_preint *out) {
+                                                       const double *lin, vilo_preint *out, double *terms) {
   const int f = blockIdx.x;
   if (f >= n) return;
-  preint_imu_leg_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 10 * f, out + f, nullptr);
+  preint_imu_leg_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 10 * f, out + f, nullptr, terms + (size_t)offsets[f] * (4 * LT_N));
 }
 
 // IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) for every live interval of a resident batch, at the biases of
@@ -437,16 +474,16 @@ __global__ void __launch_bounds__(64) k_repropagate(BatchDev b, const vilo_confi
   }
   __syncthreads();
   if (!mode && same_s) return;   // (marginalisation) the record already is the one integrated at the accepted state
-  preint_imu_leg_body<false>(*cfgp, b.rp_samples, b.rp_offsets[f], b.rp_offsets[f + 1], lin_s, rec, nullptr);
+  preint_imu_leg_body<false>(*cfgp, b.rp_samples, b.rp_offsets[f], b.rp_offsets[f + 1], lin_s, rec, nullptr, b.rp_terms + (size_t)b.rp_offsets[f] * (4 * LT_N));
 }
 
 // push_back() on device-resident objects: workgroup k appends samples[offsets[k] .. offsets[k+1]) to stream ids[k]
 __global__ void __launch_bounds__(64) k_preint_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
-                                                           PreintStream *streams) {
+                                                           PreintStream *streams, double *terms) {
   const int f = blockIdx.x;
   if (f >= n) return;
   PreintStream *st = streams + ids[f];
-  preint_imu_leg_body<true>(*cfgp, samples, offsets[f], offsets[f + 1], nullptr, &st->rec, st);
+  preint_imu_leg_body<true>(*cfgp, samples, offsets[f], offsets[f + 1], nullptr, &st->rec, st, terms + (size_t)(offsets[f] + f) * (4 * LT_N));
 }
 
 // IMULegIntegrationBase{acc_0, gyr_0, phi_0, dphi_0, c_0, ba, bg, rho} (imu_leg_integration_base.cpp:7-42)
@@ -568,7 +605,7 @@ __device__ __forceinline__ void preint_imu_body(const vilo_config &cfg, const vi
 }
 
 __global__ void __launch_bounds__(64) k_preint_imu(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
-                                                   const double *lin, vilo_preint_imu *out) {
+                                                   const double *lin, vilo_preint_imu *out, double * /* no leg terms */) {
   const int f = blockIdx.x;
   if (f >= n) return;
   preint_imu_body<false>(*cfgp, samples, offsets[f], offsets[f + 1], lin + 6 * f, out + f, nullptr);
@@ -605,14 +642,15 @@ __global__ void k_preint_imu_stream_gather(int n, const int *ids, const int *dst
 
 template <class OUT, class KERNEL>
 static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin, int lin_w,
-                             OUT *out, KERNEL kern) {
+                             OUT *out, KERNEL kern, size_t terms_per_sample) {
   if (!ctx || n < 0 || !samples || !offsets || !lin || !out) return VILO_ERR_BAD_ARG;
   if (n == 0) return VILO_OK;
   VILO_HIP(hipSetDevice(ctx->device));
   const int ns = offsets[n];
   for (int i = 0; i < n; ++i)
     if (offsets[i + 1] <= offsets[i]) return VILO_ERR_BAD_ARG;
-  DevBuf d_s, d_o, d_l, d_out;
+  DevBuf d_s, d_o, d_l, d_out, d_t;
+  VILO_HIP(d_t.alloc(sizeof(double) * terms_per_sample * (size_t)ns));
   VILO_HIP(d_s.alloc(sizeof(vilo_sample) * (size_t)ns));
   VILO_HIP(d_o.alloc(sizeof(int) * (size_t)(n + 1)));
   VILO_HIP(d_l.alloc(sizeof(double) * (size_t)lin_w * n));
@@ -621,7 +659,7 @@ static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, c
   VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * (size_t)lin_w * n, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(),
-                     d_o.as<int>(), d_l.as<double>(), d_out.as<OUT>());
+                     d_o.as<int>(), d_l.as<double>(), d_out.as<OUT>(), d_t.as<double>());
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(OUT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   VILO_HIP(hipStreamSynchronize(ctx->stream));
@@ -630,11 +668,11 @@ static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, c
 
 extern "C" int vilo_preintegrate(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
                                  vilo_preint *out) {
-  return preintegrate_impl(ctx, n, samples, offsets, lin, 10, out, k_preint_imu_leg);
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 10, out, k_preint_imu_leg, 4 * LT_N);
 }
 extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
                                      vilo_preint_imu *out) {
-  return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu);
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu, 0);
 }
 
 // ---- device-resident, incrementally updated preintegration (the reference's push_back as samples arrive, estimator.cpp:619-626) ----
@@ -708,8 +746,9 @@ extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, i
   const int ns = offsets[n] - offsets[0];
   if (ns == 0) return VILO_OK;
   VILO_HIP(hipSetDevice(ctx->device));
-  DevBuf d_i, d_s, d_o;
+  DevBuf d_i, d_s, d_o, d_t;
   VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_s.alloc(sizeof(vilo_sample) * (size_t)offsets[n])); VILO_HIP(d_o.alloc(sizeof(int) * (size_t)(n + 1)));
+  if (!s->kind) VILO_HIP(d_t.alloc(sizeof(double) * 4 * LT_N * ((size_t)offsets[n] + (size_t)n)));   // leg terms: every sample + the stream's last one
   VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -718,7 +757,7 @@ extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, i
                        d_i.as<int>(), s->di);
   else
     hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
-                       d_i.as<int>(), s->d);
+                       d_i.as<int>(), s->d, d_t.as<double>());
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipStreamSynchronize(ctx->stream));
   return VILO_OK;

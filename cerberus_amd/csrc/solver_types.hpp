@@ -154,6 +154,7 @@ struct BatchDev {
   // preintegration inputs behind the records (optional: vilo_batch_set_samples) for re-propagation inside the iteration, and what the
   // sqrt_info preparation needs
   const vilo_sample *rp_samples;   // all intervals of all windows, concatenated
+  double *rp_terms;                // [samples][4 legs][27] leg terms of every sample at the current linearisation point (k_repropagate's scratch)
   const int *rp_offsets;           // [W * 10 + 1] interval f integrates samples [rp_offsets[f], rp_offsets[f + 1]) (first = constructor sample)
   void *rp_pre;                    // [W * 10] vilo_preint / vilo_preint_imu records the preparation reads
   int *prep_bad;                   // [W * 10] covariance of the record not positive definite

@@ -593,12 +593,14 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
     }
   vilo_sample *d_s = nullptr;
   int *d_o = nullptr;
+  double *d_t = nullptr;
   int rc = dev_alloc(ctx, bt, &d_s, (size_t)offsets[n]);
   if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &d_o, n + 1);
+  if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &d_t, (size_t)offsets[n] * 108);   // 4 legs x 27 doubles per sample
   if (rc != VILO_OK) return rc;
   VILO_HIP(hipMemcpy(d_s, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice));
   VILO_HIP(hipMemcpy(d_o, offsets, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
-  D.rp_samples = d_s; D.rp_offsets = d_o; D.rp_pre = bt->d_pre; D.prep_bad = bt->d_prep_bad; D.leg = 1; D.rp_on = 1;
+  D.rp_samples = d_s; D.rp_terms = d_t; D.rp_offsets = d_o; D.rp_pre = bt->d_pre; D.prep_bad = bt->d_prep_bad; D.leg = 1; D.rp_on = 1;
   if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }   // the captured launch sequence changes
   return VILO_OK;
 }
