@@ -287,8 +287,8 @@ __global__ void __launch_bounds__(MT) k_marginalize(BatchDev bd, const MargWin *
 // block of Amm is diagonal: an inverse depth only couples to camera-side blocks), then the <= 19 dense dims of frame 0 by a
 // Cholesky factorisation. The kernel certifies "lambda_min(Amm) > eps" by factorising Amm - eps I the same way (all pivots
 // positive) and hands the window to k_marginalize (global-memory Jacobi on the full Amm) when the certificate fails.
-// The second decomposition (A' -> J0 = sqrt(S) V^T, marginalization_factor.cpp:297-305) needs eigenvectors and a rank decision
-// (A' always carries the 4 unobservable gauge directions): parallel cyclic Jacobi as before, but on LDS-resident A' and V.
+// The second decomposition (A' -> J0 = sqrt(S) V^T, marginalization_factor.cpp:297-305) needs a rank decision (a first prior carries
+// the unobservable gauge directions) and the products sqrt(S) V^T, S^-1/2 V^T b, not V itself: prior_factor_lds below.
 #define MGT 1024
 constexpr int MG_NMAX = VILO_MAX_PRIOR_DIM;       // 96
 constexpr int MG_LD = MG_NMAX + 1;                // odd leading dimension: column walks spread over the LDS banks
