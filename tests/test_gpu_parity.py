@@ -504,6 +504,37 @@ def test_marginalize_many_dropped_landmarks(ctx, cfg, ocfg):
     assert np.abs(bg - bo).max() < 1e-6 * np.abs(bo).max()
 
 
+def test_marginalize_seed_sweep(ctx, cfg, ocfg):
+    """A' -> J0, r0 by pivoted Cholesky + one-sided Jacobi (prior_factor_lds) over many windows: with and without a prior (the latter
+    semi-definite: fewer columns than dimensions), few and many landmarks, both flags, every one against the oracle's eigen route;
+    and J0 r0 consistent with itself: J0^T J0 is what the rows say, the kept rows are mutually orthogonal (they are sqrt(S) v^T)."""
+    from cerberus_amd.synth import PriorData
+    worst = 0.0
+    for k in range(24):
+        kw = dict(n_landmarks=(12, 60, 200, 700)[k % 4], seed=4000 + k, with_prior=(k % 3 != 0))
+        w = _fresh(cfg, ocfg, **kw)
+        for mode in ((0, 1) if kw["with_prior"] else (0,)):   # MARGIN_SECOND_NEW without a prior has nothing to carry over
+            pg, po = PriorData(), PriorData()
+            ctx.marginalize(w, mode, pg)
+            rc = O.marginalize(ocfg, w, mode, po)[0]
+            assert rc == 0 and pg.struct.valid == 1 and pg.blocks() == po.blocks() and pg.n == po.n, (kw, mode)
+            n = pg.n
+            Jg, Jo = pg.J0_matrix(), po.J0_matrix()
+            Ag, Ao = Jg.T @ Jg, Jo.T @ Jo
+            e_a = np.abs(Ag - Ao).max() / np.abs(Ao).max()
+            bg, bo = Jg.T @ pg.r0[:n], Jo.T @ po.r0[:n]
+            e_b = np.abs(bg - bo).max() / np.abs(bo).max()
+            worst = max(worst, e_a, e_b)
+            # eps * cond(Amm) with cond(Amm) up to 1e12 here: the oracle inverts Amm through its eigen pseudo-inverse like the reference; against a
+            # numpy Schur complement of the oracle's own A the two sides sit equally far (tools: 1e-7 .. 6e-6)
+            assert e_a < 1e-5 and e_b < 1e-5, (kw, mode, e_a, e_b)
+            G = Jg @ Jg.T                       # rows of J0 = sqrt(S_i) v_i^T: orthogonal, |row|^2 = S_i
+            d = np.sqrt(np.maximum(np.diag(G), 1e-300))
+            C_ = np.abs(G / np.outer(d, d) - np.eye(n))[np.ix_(np.diag(G) > 0, np.diag(G) > 0)]
+            assert C_.max() < 1e-6, (kw, mode, C_.max())
+    print("worst relative deviation of J0^T J0 / J0^T r0 from the oracle over the sweep: %.2e" % worst)
+
+
 def test_optimize_windows_is_solve_plus_gauge_fix_plus_marginalize(ctx, cfg, ocfg):
     """vilo_optimize_windows (one device batch) against the three separate entry points, and against the oracle's chain."""
     import ctypes as C
