@@ -438,9 +438,10 @@ __device__ __forceinline__ void jacobi_sweeps(double *P, double *part /* [3][JW]
 #pragma unroll
         for (int i = 0; i < JR; ++i) {
           const double tn = c * t[i] - sn * b[i], bn = sn * t[i] + c * b[i];
-          t[i] = dpp_mov<0x138>(tn, first ? bn : tn);   // wave_shr:1
+          const double send = first ? bn : tn;
           const double bd = dpp_mov<0x130>(bn, bn);     // wave_shl:1
           b[i] = last ? tn : bd;
+          t[i] = dpp_mov<0x138>(tn, send);              // wave_shr:1 (tn's last use: the move can land in its register)
         }
       }
     }
