@@ -1,0 +1,160 @@
+// Visual part of a window's pose system from COMPACT Gram slots (visual_lin.hpp: 16 columns B | theta_i | theta_j | theta_ic |
+// theta_ic2 | r per camera): what k_assemble's owner-computes scatter does for the 23-column slots, plus the 3 x 3 transforms that turn
+// the B (= d r / d P_i) blocks into the extrinsic-translation blocks once per (chunk, frame) slot.
+//
+//   slot (start frame s, frame j = s + t):  G = C0 + C1 (upper triangle, tri16), C1B = rows 0..2 of C1 (16 each)
+//   Ri' = R_s, Rj' = R_j for t > 0; identity for t = 0 (the one-frame factor's B is reduce ric2^T itself), N0 = Ri' - Rj'
+//   pose columns of the slot:   P_s = +B, P_j = -B, theta_s = RI, theta_j = RJ            (none for t = 0: OneFrameTwoCam has no pose blocks)
+//   tic  rows:  N0^T C0[B, .] + Ri'^T C1[B, .]  =  N0^T G[B, .] + Rj'^T C1B[.]            (C0[B, .] = G[B, .] - C1B[.])
+//   tic2 rows:  -Rj'^T C1B[.]
+//   tic x tic:  N0^T C0_BB N0 + Ri'^T C1_BB Ri',   tic x tic2: -Ri'^T C1_BB Rj',   tic2 x tic2: Rj'^T C1_BB Rj'
+//
+// One owner thread per TARGET entry class (226 of the workgroup's 256 threads), every target of the 80 x 80 image has exactly one
+// owner, so the read-modify-writes need no atomics and the sums have a fixed order (batch of N == batch of 1, bitwise):
+//   T1  pose_f x pose_f       21   (f = s: sum over t; f = j: per t)         T5  tic  x pose_f   18
+//   T2  pose_s x pose_j       36                                             T6  tic2 x pose_f   18
+//   T3  pose_f x {theta_ic, theta_ic2, r}  42                                T7  {tic, tic2} x {theta_ic, theta_ic2, r}  42
+//   T4  {theta_ic, theta_ic2, r}^2         28                                T8  {tic, tic2}^2   21
+// The function is host-compilable (tests/host_check emulates the 256 threads one after the other against a dense accumulation).
+#pragma once
+#include "visual_lin.hpp"
+#define AC_STAGE (11 * VILO_GRAMC)   // doubles: the slots of one chunk
+
+namespace vilo {
+
+#ifndef CD_EX0
+#define CD_EX0 66
+#define CD_EX1 72
+#endif
+
+VD int ac_jidx(int a) { return a < 3 ? a : a + 3; }                     // pose-local dimension a of frame j -> compact column (B with sign -, RJ)
+VD double ac_jsign(int a) { return a < 3 ? -1.0 : 1.0; }
+VD int ac_kcol(int R) { return R < 3 ? GK_C0 + R : (R < 6 ? GK_C1 + (R - 3) : GK_R); }   // rest index 0..6 -> compact column
+VD int ac_restcd(int R) { return R < 3 ? CD_EX0 + 3 + R : CD_EX1 + 3 + (R - 3); }          // rest index 0..5 -> camera dimension
+VD int ac_tri(int x, int y) { return x <= y ? tri16(x, y) : tri16(y, x); }
+
+// One chunk (start frame s, km frames) of one owner thread. slots: the chunk's km slots back to back (k_assemble stages them in LDS with
+// coalesced loads: every byte of a slot is fetched from HBM once and the owner threads' scattered reads are LDS reads);  Rt: [12][9]
+// rotation matrices of the window's frames (row-major), entry 11 = identity;  rmw(hi, lo, v): image(hi, lo) += v (hi >= lo);
+// gadd(cd, v): gradient. Thread ranges are laid out so that a wave of 64 runs at most two of the class bodies:
+//   wave 0: T1 [0, 21) T2 [21, 57)   wave 1: T3 [64, 106) T8 [106, 127)   wave 2: T5 [128, 146) T6 [146, 164) T4 [164, 192)   wave 3: T7 [192, 234)
+template <class RMW, class GADD>
+VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slots, const double *Rt, RMW rmw, GADD gadd) {
+  if (tid < 21) {
+    // T1: pose_f x pose_f, upper (a <= b) of the 6 x 6 block. f = s: [B | RI] x [B | RI] summed over t >= 1; f = j: [-B | RJ] x [-B | RJ] per t
+    int a = 0, rem = tid;
+    while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+    const int b = a + rem;
+    const int e1 = ac_tri(a, b), e2 = ac_tri(ac_jidx(a), ac_jidx(b));
+    const double sg2 = ac_jsign(a) * ac_jsign(b);
+    double sum = 0.0;
+    for (int t = 1; t < km; ++t) {
+      sum += slots[t * VILO_GRAMC + e1];
+      rmw(6 * (s + t) + b, 6 * (s + t) + a, sg2 * slots[t * VILO_GRAMC + e2]);
+    }
+    rmw(6 * s + b, 6 * s + a, sum);
+  } else if (tid < 57) {
+    // T2: pose_s (a) x pose_j (b), the full 6 x 6 block, per t
+    const int a = (tid - 21) / 6, b = (tid - 21) % 6;
+    const int e = ac_tri(a, ac_jidx(b));
+    const double sg = ac_jsign(b);
+    for (int t = 1; t < km; ++t) rmw(6 * (s + t) + b, 6 * s + a, sg * slots[t * VILO_GRAMC + e]);
+  } else if (tid >= 64 && tid < 106) {
+    // T3: pose_f (a) x rest (b: theta_ic 0..2, theta_ic2 3..5, r 6)
+    const int a = (tid - 64) / 7, b = (tid - 64) % 7;
+    const int e1 = ac_tri(a, ac_kcol(b)), e2 = ac_tri(ac_jidx(a), ac_kcol(b));
+    const double sg2 = ac_jsign(a);
+    double sum = 0.0;
+    for (int t = 1; t < km; ++t) {
+      sum += slots[t * VILO_GRAMC + e1];
+      const double v2 = sg2 * slots[t * VILO_GRAMC + e2];
+      if (b == 6) gadd(6 * (s + t) + a, v2);
+      else rmw(ac_restcd(b), 6 * (s + t) + a, v2);
+    }
+    if (b == 6) gadd(6 * s + a, sum);
+    else rmw(ac_restcd(b), 6 * s + a, sum);
+  } else if (tid >= 106 && tid < 127) {
+    // T8: {tic, tic2} x {tic, tic2}: N0^T C0_BB N0 + Ri'^T C1_BB Ri' | -Ri'^T C1_BB Rj' | Rj'^T C1_BB Rj', summed over every t
+    const int q = tid - 106;
+    int pa = 0, pb = 0, ia = 0, ib = 0;   // which translations (0 tic, 1 tic2) and components
+    if (q < 6) { int rem = q; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
+    else if (q < 15) { pb = 1; ia = (q - 6) / 3; ib = (q - 6) % 3; }
+    else { pa = 1; pb = 1; int rem = q - 15; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
+    double sum = 0.0;
+    for (int t = 0; t < km; ++t) {
+      const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
+      const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);
+      // left / right factors of the two terms: v = sum_cd La[c] C0[c][d] Lb[d] + Ma[c] C1[c][d] Mb[d]
+      double La[3], Lb[3], Ma[3], Mb[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double ria = Ri[3 * c + ia], rib = Ri[3 * c + ib], rja = Rj[3 * c + ia], rjb = Rj[3 * c + ib];
+        La[c] = (pa == 0 && pb == 0) ? ria - rja : 0.0;
+        Lb[c] = (pa == 0 && pb == 0) ? rib - rjb : 0.0;
+        Ma[c] = pa ? rja : ria;
+        Mb[c] = pb ? (pa ? rjb : -rjb) : rib;
+      }
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double c1 = C1B[16 * c + d], c0 = Gb[ac_tri(c, d)] - c1;
+          v += La[c] * c0 * Lb[d] + Ma[c] * c1 * Mb[d];
+        }
+      sum += v;
+    }
+    rmw((pb ? CD_EX1 : CD_EX0) + ib, (pa ? CD_EX1 : CD_EX0) + ia, sum);
+  } else if (tid >= 128 && tid < 164) {
+    // T5 / T6: tic (T5) / tic2 (T6) component a x pose_f dimension b
+    const bool five = tid < 146;
+    const int q = five ? tid - 128 : tid - 146, a = q / 6, b = q % 6, xj = ac_jidx(b);
+    const double sgj = ac_jsign(b);
+    const int cd = (five ? CD_EX0 : CD_EX1) + a;
+    double sum = 0.0;
+    for (int t = 1; t < km; ++t) {
+      const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
+      const double *Ri = Rt + 9 * s, *Rj = Rt + 9 * (s + t);
+      double vs = 0.0, vj = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double rj = Rj[3 * c + a];
+        const double n0 = five ? Ri[3 * c + a] - rj : 0.0, m1 = five ? rj : -rj;
+        vs += n0 * Gb[ac_tri(c, b)] + m1 * C1B[16 * c + b];
+        vj += n0 * Gb[ac_tri(c, xj)] + m1 * C1B[16 * c + xj];
+      }
+      sum += vs;
+      rmw(cd, 6 * (s + t) + b, sgj * vj);
+    }
+    rmw(cd, 6 * s + b, sum);
+  } else if (tid >= 164 && tid < 192) {
+    // T4: rest x rest, upper (a <= b) of the 7 x 7 block {theta_ic, theta_ic2, r}, summed over every t
+    int a = 0, rem = tid - 164;
+    while (rem >= 7 - a) { rem -= 7 - a; ++a; }
+    const int b = a + rem;
+    const int e = ac_tri(ac_kcol(a), ac_kcol(b));
+    double sum = 0.0;
+    for (int t = 0; t < km; ++t) sum += slots[t * VILO_GRAMC + e];
+    if (b == 6) { if (a != 6) gadd(ac_restcd(a), sum); }
+    else rmw(ac_restcd(b), ac_restcd(a), sum);
+  } else if (tid >= 192 && tid < 234) {
+    // T7: {tic 0..2, tic2 3..5} (a) x rest (b), summed over every t (identity transforms at t = 0)
+    const int a = (tid - 192) / 7, b = (tid - 192) % 7, aa = a % 3, x = ac_kcol(b);
+    double sum = 0.0;
+    for (int t = 0; t < km; ++t) {
+      const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
+      const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double rj = Rj[3 * c + aa];
+        const double n0 = (a < 3) ? Ri[3 * c + aa] - rj : 0.0, m1 = (a < 3) ? rj : -rj;
+        sum += n0 * Gb[ac_tri(c, x)] + m1 * C1B[16 * c + x];
+      }
+    }
+    const int cd = (a < 3 ? CD_EX0 : CD_EX1) + aa;
+    if (b == 6) gadd(cd, sum);
+    else { const int rc = ac_restcd(b); rmw(rc > cd ? rc : cd, rc > cd ? cd : rc, sum); }
+  }
+}
+
+}  // namespace vilo

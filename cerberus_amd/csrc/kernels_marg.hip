@@ -1147,6 +1147,25 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       return fail(VILO_ERR_HIP);
   }
   if (hipMemcpy(status.data(), d_status.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  // A window whose preintegration covariance is not positive definite has no sqrt_info (its bad pivots were replaced by 1 so that the
+  // arithmetic stays finite): its solve was failed, and its marginalisation would be a finite but meaningless prior. Treated like a
+  // non-finite result: the window goes on without a prior and the call reports VILO_ERR_NUMERIC. With re-propagation the flags of the
+  // records integrated for this linearisation (prep_bad, rewritten by the mode-0 pass above) count as well.
+  {
+    std::vector<int> bad(W, 0);
+    if (bd.win_bad && hipMemcpy(bad.data(), bd.win_bad, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+    if (bd.rp_on && bd.prep_bad) {
+      std::vector<int> pb((size_t)W * 10);
+      std::vector<unsigned char> sk((size_t)W * 10);
+      if (hipMemcpy(pb.data(), bd.prep_bad, sizeof(int) * pb.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(sk.data(), bd.imu_skip, sk.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+      for (int w = 0; w < W; ++w)
+        for (int k = 0; k < 10; ++k)
+          if (!sk[(size_t)w * 10 + k] && pb[(size_t)w * 10 + k]) bad[w] = 1;
+    }
+    for (int w = 0; w < W; ++w)
+      if (bad[w]) status[w] = 1;
+  }
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
     if (skip[w]) continue;

@@ -810,5 +810,7 @@ int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage) {
     VILO_HIP(hipGetLastError());
     return VILO_OK;
   }
+  // the flags belong to the records integrated for THIS point (k_accept reads them as "candidate not evaluable")
+  VILO_HIP(hipMemsetAsync(b.prep_bad, 0, sizeof(int) * (size_t)b.W * 10, ctx->stream));
   return vilo_launch_prepare_preint(ctx, b.W * 10, (const vilo_preint *)b.rp_pre, b.prep, b.prep_bad, b.imu_skip, 1);
 }

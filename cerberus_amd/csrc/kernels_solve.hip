@@ -107,9 +107,14 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
 // lanes of the wave build for VT_TB frames at a time, Huber weight folded into the projection Jacobian.
 #define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
 #define VT_TB 2       // frames per table build: lane = (frame of the pair, segment, camera, row) = 2 x 4 x 2 x 3
-template <bool TPAR>
+// COMPACT (solve passes of batches whose windows all keep td constant; BatchDev::compact): 16-column rows (visual_lin.hpp: GK_*), one
+// Gram tile per camera, slots of VILO_GRAMC doubles for k_assemble<true>; everything on the landmark side is the same.
+#define XROWC 16   // compact rows: 16 columns, a lane's two rows back to back
+#define XLANEC 34  // + 2 pad: the four rows of a k-step start 0 / 32 / 4 / 36 banks apart (conflict-free operand reads, 16-byte aligned stores)
+template <bool TPAR, bool COMPACT>
 __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a, int mode) {
-  __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XLANE + 16];   // 4 zero pad lanes = 8 pad rows
+  constexpr int XR = COMPACT ? XROWC : XROW, XL = COMPACT ? XLANEC : XLANE;
+  __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XL + 16];   // 4 zero pad lanes = 8 pad rows
   __shared__ __attribute__((aligned(16))) double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
   __shared__ __attribute__((aligned(16))) double wt[VW_N];
   __shared__ __attribute__((aligned(16))) double tab[VT_TB * 4 * VT_N];
@@ -139,12 +144,12 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   // the solve (estimate_td: 0, estimator.cpp:1104) its rows need tile (0,0) only — one MFMA per k-step instead of three. (The
   // marginalisation keeps td: mode 0 always runs the full form.)
   const int lr = lane & 15, lk = lane >> 4;
-  const int xoff = (lk >> 1) * XLANE + (lk & 1) * XROW + lr;
+  const int xoff = (lk >> 1) * XL + (lk & 1) * XR + lr;
   const bool c1on = lr < 7;    // columns 23 .. 31 of the second tile column do not exist
-  const bool lean = mode != 0 && (wm.const_mask & CONST_TD);
+  const bool lean = COMPACT || (mode != 0 && (wm.const_mask & CONST_TD));
   // (coupling rows w: every row of a landmark's column is written exactly once — the observed poses and the extrinsic / td rows with their
   // sums, the rest with zeros at the end; TPAR: the host clears w before the launch, the frames of a landmark run in different workgroups)
-  for (int e = lane; e < 4 * XLANE + 16; e += 64) X[64 * XLANE + e] = 0.0;
+  for (int e = lane; e < 4 * XL + 16; e += 64) X[64 * XL + e] = 0.0;
 
   const double *obs = b.obs + wv.obs_off;
   const unsigned char *flg = b.flags + wv.flag_off;
@@ -231,6 +236,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 #pragma unroll
       for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
     }
+    // (COMPACT: G00 = the left camera's tile C0, G01 = the right camera's C1, G11 unused)
     mfma_d4 G00[4], G01[4], G11[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { G00[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G01[g] = G00[g]; G11[g] = G00[g]; }
@@ -247,37 +253,65 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
       const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
-      double *xr0 = &X[lane * XLANE], *xr1 = xr0 + XROW;
+      double *xr0 = &X[lane * XL], *xr1 = xr0 + XR;
       c_a = clock64();
       if (produce) {
-        double x0[XROW], x1[XROW], Jl[2], obc[5];
-        x0[23] = 0.0; x1[23] = 0.0;
+        double x0[XR], x1[XR], Jl[2], obc[5];
+        double term[LM_NTERM], wjr[3];
         double rho0;
-        if (cam == 0) {
-          obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
-          rho0 = vis_two_frame<0>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+        if (COMPACT) {
+          double tc[4][3];
+          if (cam == 0) {
+            obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
+            rho0 = vis_two_frame_c<0>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+          } else {
+            obc[0] = ob[3]; obc[1] = ob[4]; obc[2] = ob[5]; obc[3] = ob[8]; obc[4] = ob[9];
+            if (t > 0) rho0 = vis_two_frame_c<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+            else rho0 = vis_one_frame_c(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+          }
+          term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
+          term[1] = Jl[0] * x0[GK_R] + Jl[1] * x1[GK_R];
+          const double pw = (t > 0) ? 1.0 : 0.0;   // the one-frame factor has no pose blocks (its B columns carry the tic column)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            term[2 + c] = pw * (x0[GK_B + c] * Jl[0] + x1[GK_B + c] * Jl[1]);
+            term[5 + c] = x0[GK_RI + c] * Jl[0] + x1[GK_RI + c] * Jl[1];
+            term[8 + c] = tc[0][c] * Jl[0] + tc[1][c] * Jl[1];
+            term[11 + c] = x0[GK_C0 + c] * Jl[0] + x1[GK_C0 + c] * Jl[1];
+            term[14 + c] = tc[2][c] * Jl[0] + tc[3][c] * Jl[1];
+            term[17 + c] = x0[GK_C1 + c] * Jl[0] + x1[GK_C1 + c] * Jl[1];
+            wjr[c] = x0[GK_RJ + c] * Jl[0] + x1[GK_RJ + c] * Jl[1];
+          }
+          term[20] = 0.0;   // td is a constant block in this mode
         } else {
-          obc[0] = ob[3]; obc[1] = ob[4]; obc[2] = ob[5]; obc[3] = ob[8]; obc[4] = ob[9];
-          if (t > 0) rho0 = vis_two_frame<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
-          else rho0 = vis_one_frame(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl);
+          x0[XR - 1] = 0.0; x1[XR - 1] = 0.0;
+          if (cam == 0) {
+            obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
+            rho0 = vis_two_frame<0>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+          } else {
+            obc[0] = ob[3]; obc[1] = ob[4]; obc[2] = ob[5]; obc[3] = ob[8]; obc[4] = ob[9];
+            if (t > 0) rho0 = vis_two_frame<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
+            else rho0 = vis_one_frame(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl);
+          }
+          // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
+          term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
+          term[1] = Jl[0] * x0[GC_R] + Jl[1] * x1[GC_R];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            term[2 + c] = x0[c] * Jl[0] + x1[c] * Jl[1];
+            term[8 + c] = x0[GC_E0 + c] * Jl[0] + x1[GC_E0 + c] * Jl[1];
+            term[14 + c] = x0[GC_E1 + c] * Jl[0] + x1[GC_E1 + c] * Jl[1];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) wjr[c] = x0[GC_RJ + c] * Jl[0] + x1[GC_RJ + c] * Jl[1];
+          term[20] = x0[GC_TD] * Jl[0] + x1[GC_TD] * Jl[1];
         }
         cost += rho0;
-        // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
-        double term[LM_NTERM];
-        term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
-        term[1] = Jl[0] * x0[GC_R] + Jl[1] * x1[GC_R];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          term[2 + c] = x0[c] * Jl[0] + x1[c] * Jl[1];
-          term[8 + c] = x0[GC_E0 + c] * Jl[0] + x1[GC_E0 + c] * Jl[1];
-          term[14 + c] = x0[GC_E1 + c] * Jl[0] + x1[GC_E1 + c] * Jl[1];
-        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           wj[c] -= term[2 + c];   // d r / d P_j = -d r / d P_i
-          wj[3 + c] += x0[GC_RJ + c] * Jl[0] + x1[GC_RJ + c] * Jl[1];
+          wj[3 + c] += wjr[c];
         }
-        term[20] = x0[GC_TD] * Jl[0] + x1[GC_TD] * Jl[1];
         if (TPAR) {
           double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
 #pragma unroll
@@ -290,10 +324,10 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
           wc_td += term[20];
         }
 #pragma unroll
-        for (int c = 0; c < XROW; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
+        for (int c = 0; c < XR; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
       } else {
 #pragma unroll
-        for (int c = 0; c < XROW; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+        for (int c = 0; c < XR; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
       }
       lds_barrier();
       { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
@@ -309,14 +343,14 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         auto ldtrip = [&](int kk, double *p0, double *p1) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const double *xr = &X[2 * (kk + u) * XLANE + xoff];
+            const double *xr = &X[2 * (kk + u) * XL + xoff];
             p0[u] = xr[0];
             p1[u] = xr[16];
           }
         };
         auto ldtrip0 = [&](int kk, double *p0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) p0[u] = X[2 * (kk + u) * XLANE + xoff];
+          for (int u = 0; u < 4; ++u) p0[u] = X[2 * (kk + u) * XL + xoff];
         };
         auto dotrip = [&](const double *p0, const double *p1) {
 #pragma unroll
@@ -326,15 +360,16 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             G11[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1[u], p1[u], G11[g], 0, 0, 0);
           }
         };
+        mfma_d4 &G1t = (COMPACT && cam == 1) ? G01[g] : G00[g];   // the one tile of a lean trip
         auto dotrip0 = [&](const double *p0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) G00[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G00[g], 0, 0, 0);
+          for (int u = 0; u < 4; ++u) G1t = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G1t, 0, 0, 0);
         };
         // two trips per turn, the operands of the next trip in flight behind the MFMAs of this one (a segment has an even number of
         // trips or is the last of its wave: the trip after its last one reads rows that exist — zero pad lanes at the end — and is dropped)
         // (sched_barrier: the scheduler otherwise sinks every load to just before its MFMA to save registers, and the wave waits out
         // an LDS round trip per k-step)
-        if (lean && cam == 0) {
+        if (COMPACT || (lean && cam == 0)) {
           ldtrip0(k0, a0);
           for (int kk0 = k0; kk0 < k1; kk0 += 8) {
             ldtrip0(min(kk0 + 4, 30), n0);
@@ -370,6 +405,17 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (g >= wv.nseg || t >= ckm[g]) continue;
+      if (COMPACT) {
+        // upper triangle of C0 + C1, then rows 0 .. 2 (the B rows) of C1: register 0 of the lanes lk = 0 .. 2
+        double *gs = b.gram + (size_t)(cgo[g] + t) * VILO_GRAMC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = lk + 4 * r;
+          if (row <= lr) gs[tri16(row, lr)] = G00[g][r] + G01[g][r];
+        }
+        if (lk < 3) gs[VILO_GRAMC_TRI + 16 * lk + lr] = G01[g][0];
+        continue;
+      }
       double *gs = b.gram + (size_t)(cgo[g] + t) * VILO_GRAM;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -412,8 +458,11 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   if (prof) { st.phase_clk[28] = clock64() - c_t0; st.phase_clk[29] = c_proj; st.phase_clk[30] = c_gram; st.phase_clk[31] = wv.n_lanes; st.phase_clk[32] = wv.kmax; }
 }
 
-__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false>(b, sq, huber_a, mode); }
-__global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true>(b, sq, huber_a, mode); }
+__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, false>(b, sq, huber_a, mode); }
+__global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true, false>(b, sq, huber_a, mode); }
+// the compact forms (solve passes, td constant in every window of the batch)
+__global__ void __launch_bounds__(64) k_visual_linearize_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, true>(b, sq, huber_a, mode); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_tpar_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true, true>(b, sq, huber_a, mode); }
 
 // Second half of the TPAR form: per landmark, the (frame, camera) terms in the order the walking form adds them (frames ascending,
 // left camera before right; an unobserved factor contributed +0.0).
@@ -464,13 +513,16 @@ __global__ void __launch_bounds__(64) k_visual_clear(BatchDev b, int mode) {
 // both forms behind one call (kernel kind 0 of the profiling table)
 static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream_t s, int mode) {
   if (b.n_waves <= 0) return;
+  const bool compact = b.compact && mode != 0;   // (the marginalisation's pass keeps td: full 23-column slots)
   if (b.lm_part) {
     hipLaunchKernelGGL(k_visual_clear, dim3(b.n_waves), dim3(64), 0, s, b, mode);
     (void)hipMemsetAsync(b.lm_part, 0, sizeof(double) * (size_t)VILO_MAX_FRAMES * 2 * LM_NTERM * b.n_lm, s);
-    hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
+    if (compact) hipLaunchKernelGGL(k_visual_linearize_tpar_c, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
+    else hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     hipLaunchKernelGGL(k_visual_reduce, dim3(b.n_waves), dim3(64), 0, s, b, mode);
   } else {
-    hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
+    if (compact) hipLaunchKernelGGL(k_visual_linearize_c, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
+    else hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
   }
 }
 
@@ -861,6 +913,12 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   }
   double cand = 0.5 * (vis + imu + pri);
   if (!isfinite(cand)) cand = 1.7976931348623157e308;
+  if (b.rp_on && b.prep_bad) {
+    // re-propagation: a covariance integrated at this point that is not positive definite has no sqrt_info — the point cannot be
+    // evaluated (its whitened residuals used pivots replaced by 1): treated like a non-finite cost
+    for (int k = 0; k + 1 < wm.n_frames; ++k)
+      if (!b.imu_skip[(size_t)win * 10 + k] && b.prep_bad[(size_t)win * 10 + k]) cand = 1.7976931348623157e308;
+  }
   if (ap.init_mode) {
     if (tid == 0) {
       st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
@@ -868,6 +926,8 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
       // a non-finite evaluation at the initial point: ceres::Solve fails in IterationZero ("Residual and Jacobian evaluation
       // failed", ResidualBlock::Evaluate's IsArrayValid) and leaves the parameters alone; this window is done, the others go on
       if (!(cand < 1.7976931348623157e308)) { st.done = 1; st.termination = 2; }
+      // "Maximum solver time reached" is checked before every iteration, the first included
+      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
       st.cur ^= 1;   // the pass that gave this cost also linearised the point: its landmark gradients become the current ones
     }
     if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;

@@ -17,26 +17,29 @@
 //                     backward solve from the registers  ->  bias and landmark back-substitution  ->  dogleg step and candidate state.
 #include <type_traits>
 #include "solve_common.hpp"
+#include "assemble_compact.hpp"
+#include "wave_common.hpp"
 
 using namespace vilo;
-
-__device__ __forceinline__ int tile_index(int I, int J) { return (I * (I + 1)) / 2 + J; }   // I >= J
-__device__ constexpr int c_tI[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
-__device__ constexpr int c_tJ[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 
 // =================================================================================================
 // k_assemble
 // =================================================================================================
 // position of pose-system entry (row, col) (tile row >= tile column) in the accumulator-order image: tile, register row >> 2, lane
-__device__ __forceinline__ int cimg_pos(int row, int col) {
-  const int rr = row & 15;
-  return 256 * tile_index(row >> 4, col >> 4) + 64 * (rr >> 2) + 16 * (rr & 3) + (col & 15);
-}
+// The LDS copy the scatter works on is the packed lower triangle of the 80 x 80 system (row r starts at r (r + 1) / 2: three integer
+// operations per target instead of the tile arithmetic, 26 KB instead of 30, no mirror writes inside diagonal tiles); it is unpacked into
+// the solver's tile image (15 lower 16 x 16 tiles in accumulator order = each tile row-major, diagonal tiles with both triangles) on the
+// way out.
+#define CL_N 3240
+__device__ __forceinline__ int cl_pos(int hi, int lo) { return ((hi * (hi + 1)) >> 1) + lo; }
 
 #define ASM_THREADS 256
 
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
-  __shared__ double Cl[CIMG_N];
+template <bool COMPACT>
+__device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
+  __shared__ double Cl[CL_N];
+  __shared__ double Rt[COMPACT ? 12 * 9 : 1];   // compact slots: rotation matrices of the window's frames, [11] = identity
+  __shared__ double stage[COMPACT ? AC_STAGE : 1];   // compact slots of the chunk being scattered
   __shared__ double gl[CD_N], hd[CD_N], vS[CD_N], red[12];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
@@ -45,18 +48,27 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[win];
   const int F = wm.n_frames, cmask = wm.const_mask, kb = wm.pad, pn = wm.prior_n;
-  const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
+  const double *gs = b.gram + (size_t)wm.gram_off * (COMPACT ? VILO_GRAMC : VILO_GRAM);
   const double *igram = b.imu_gram + (size_t)win * 10 * 780;
   const double *pd = b.prior_dense + (size_t)win * PD_N;
   double *bimg = b.Bimg + (size_t)win * BI_N;
 
   // ---- the pose system starts from the prior's pre-assembled image (zeros without a prior) ----
   for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
-    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
-    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
-    Cl[idx] = pd[PD_C + max(row, col) * PD_CLD + min(row, col)];
+    const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+    const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc;
+    if (row >= col) Cl[cl_pos(row, col)] = pd[PD_C + row * PD_CLD + col];
   }
   for (int e = tid; e < CD_N; e += ASM_THREADS) inv_pmap[e] = -1;
+  if (COMPACT) {
+    if (tid < 11) {
+      const m3 R = qR(ldq_pose(b.x + (size_t)win * XSTRIDE + XO_POSE + 7 * tid));   // (the accepted state = the point the slots were linearised at)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Rt[9 * tid + q] = R.a[q];
+    } else if (tid < 20) {
+      Rt[99 + (tid - 11)] = ((tid - 11) % 4 == 0) ? 1.0 : 0.0;
+    }
+  }
   if (tid < min(wm.n_chunks, 64)) {
     const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
     chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
@@ -74,11 +86,30 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
   // ---- plain (non-atomic) read-modify-write scatter: every target has exactly one owner thread. Two packed Gram entries can hit the
   //      same target only if they are "twins" (the same local pair taken once in the pose_s block and once in the pose_j block; for IMU
   //      factors once in the frame-i half and once in the frame-j half of the previous factor), so a thread owns an entry and its twin ----
-  auto rmw = [&](int hi, int lo, double v) {   // lower position + mirror inside a diagonal tile
-    Cl[cimg_pos(hi, lo)] += v;
-    if (hi != lo && (hi >> 4) == (lo >> 4)) Cl[cimg_pos(lo, hi)] += v;
-  };
-  {
+  auto rmw = [&](int hi, int lo, double v) { Cl[cl_pos(hi, lo)] += v; };   // hi >= lo
+  if (COMPACT) {
+    // chunk by chunk: the chunk's slots (kmax x 184 doubles, contiguous) come into LDS with coalesced loads — every byte once — and the
+    // owner threads gather from there; the next chunk's slots are in flight (registers) while this one is scattered
+    const int nch = min(wm.n_chunks, 64);
+    double pf[8];
+    auto prefetch = [&](int ch) {
+      const unsigned ct = chunk_tab[ch];
+      const int n = (int)((ct >> 8) & 255) * VILO_GRAMC;
+      const double *src = gs + (size_t)(ct >> 16) * VILO_GRAMC;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; pf[i] = (e < n) ? src[e] : 0.0; }
+    };
+    if (nch > 0) prefetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+      const unsigned ct = chunk_tab[ch];
+      lds_barrier();   // (the previous chunk's readers are done)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; if (e < AC_STAGE) stage[e] = pf[i]; }
+      lds_barrier();
+      if (ch + 1 < nch) prefetch(ch + 1);
+      assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { gl[cd] += v; });
+    }
+  } else {
     // visual Gram slots: 246 owner groups, one per thread
     // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
     // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
@@ -166,10 +197,11 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
   __syncthreads();
   // ---- constant blocks / absent frames / padding as identity rows and columns; diagonal and gradient of all 224 camera dimensions ----
   for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
-    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
-    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
-    double v = Cl[idx];
-    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) { v = (row == col) ? 1.0 : 0.0; Cl[idx] = v; }
+    const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+    const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc, li = cl_pos(max(row, col), min(row, col));
+    if (row < col) continue;   // (the upper half of a diagonal tile: the same entries)
+    double v = Cl[li];
+    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) { v = (row == col) ? 1.0 : 0.0; Cl[li] = v; }
     if (row == col) hd[row] = v;
   }
   for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
@@ -213,9 +245,9 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
   __syncthreads();
   // ---- pose system out in accumulator order; q = v^T H v of the camera-side rows is summed while the blocks pass through registers ----
   for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
-    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
-    const int row = 16 * c_tI[t] + (ln >> 4) + 4 * r, col = 16 * c_tJ[t] + (ln & 15);
-    const double v = Cl[idx];
+    const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+    const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc;
+    const double v = Cl[cl_pos(max(row, col), min(row, col))];
     b.Cimg[(size_t)win * CIMG_N + idx] = v;
     part_q += ((c_tI[t] == c_tJ[t]) ? 1.0 : 2.0) * vS[row] * v * vS[col];   // (a diagonal tile holds both triangles)
   }
@@ -317,6 +349,13 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
     bimg[BI_SCAL + 2] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
   }
 }
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
+  assemble_body<false>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal);
+}
+// compact Gram slots (BatchDev::compact): the extrinsic-translation blocks are 3 x 3 transforms of the slots' B blocks (assemble_compact.hpp)
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble_c(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
+  assemble_body<true>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal);
+}
 
 // =================================================================================================
 // k_solve_wave
@@ -355,55 +394,6 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
 #define WX_DEL 288      // [224] step of the camera dimensions
 
 extern "C" size_t vilo_solve_wave_lds_bytes() { return (size_t)WS_TOTAL * sizeof(double); }
-
-__device__ __forceinline__ int pswz(int slot, int r, int c) { return WS_C + 256 * slot + 16 * r + ((c + r) & 15); }
-
-// 16 x 16 Cholesky + inverse of the factor by one wave (diagonal tile of the blocked 80 x 80 factorisation).
-// A: LDS 16 x 17 row-major in. Lane i (< 16, replicated in the four 16-lane groups) owns row i; pivots broadcast with v_readlane.
-// Writes L^-1 (lower, zeros above) to Linv (16 x 17): the panel products and the backward solve need L_jj^-1, nothing reads L_jj again.
-// Returns 0 / 1 (not positive definite).
-__device__ __forceinline__ int chol16_tile(const double *A, double *Linv) {
-  const int lane = threadIdx.x & 63;
-  const int row = lane & 15;
-  double a[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = A[row * 17 + j];
-  int fail = 0;
-  double myrinv = 1.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double piv = readlane_d(a[j], j);
-    if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
-    const double rinv = rsqrt(piv);
-    const double lj = (row == j) ? piv * rinv : (row > j ? a[j] * rinv : 0.0);
-    a[j] = lj;
-    if (row == j) myrinv = rinv;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) a[q] -= lj * readlane_d(lj, q);
-  }
-  // column c = lane of L^-1 by forward substitution; L is broadcast from the owning lanes' registers. (The copies are opaque to the
-  // compiler: it would otherwise recognise these broadcasts as the ones of the factorisation loop and keep all 120 alive in SGPRs.)
-#pragma unroll
-  for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(a[j]));
-  double cl[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double v = (i == row) ? 1.0 : 0.0;
-#pragma unroll
-    for (int q = 0; q < i; ++q) v -= readlane_d(a[q], i) * cl[q];   // L[i][q] lives in lane i, register q
-    cl[i] = v * readlane_d(myrinv, i);
-    // keep the v_readlane results (SGPR pairs) of one row at a time: the broadcasts depend on nothing that changes in this loop, so
-    // instruction selection emits them all up front and they spill by the hundred unless every row's arithmetic is pinned in place
-    asm volatile("" : "+v"(cl[i]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Linv[i * 17 + lane] = (i >= lane) ? cl[i] : 0.0;
-  }
-  lds_fence();
-  return fail;
-}
 
 __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1119,7 +1109,8 @@ int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, h
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
-    hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
+    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
+    else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

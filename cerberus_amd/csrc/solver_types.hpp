@@ -159,5 +159,6 @@ struct BatchDev {
   void *rp_pre;                    // [W * 10] vilo_preint / vilo_preint_imu records the preparation reads
   int *prep_bad;                   // [W * 10] covariance of the record not positive definite
   int rp_on, leg;
+  int compact;                // 1: every window keeps td constant: the solve passes use the compact 16-column visual rows / Gram slots (visual_lin.hpp GK_*)
   int *win_bad;               // [W] 1: a preintegration covariance of the window has no sqrt_info: the window fails alone (termination FAILURE)
 };

@@ -26,6 +26,9 @@ struct vilo_batch {
   // solved a second time with the same options (vilo_batch_reset + vilo_batch_solve loops: replays, Monte-Carlo seeds, bench)
   hipGraphExec_t gexec = nullptr;
   vilo_solve_opts gopts;
+  int g_sqrt_info_mode = 0, g_rp_on = 0;   // context / batch state the captured launch sequence depends on (part of the cache key)
+  // re-propagation buffers (vilo_batch_set_samples): reused by later calls while they are large enough (the arena cannot free)
+  vilo_sample *rp_s = nullptr; int *rp_o = nullptr; double *rp_t = nullptr; size_t rp_cap = 0;
   int n_solves = 0;
   bool graph_failed = false;
   // what vilo_batch_prepare needs to run the sqrt_info preparation again (the reference does it in every IMULegFactor::Evaluate)
@@ -392,6 +395,11 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   const double t_packed = now();
   BatchDev &D = bt->d;
   D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
+  // compact visual rows / Gram slots in the solve passes: td must be a constant block in every window (estimate_td: 0, all of the
+  // reference's configurations); VILO_NO_COMPACT=1 keeps the 23-column form (A/B runs)
+  D.compact = getenv("VILO_NO_COMPACT") ? 0 : 1;
+  for (int w = 0; w < W; ++w)
+    if (!(wins[w].const_mask & CONST_TD)) D.compact = 0;
   TRYB(dev_upload(ctx, bt, &D.win, wins));
   TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
   TRYB(dev_upload(ctx, bt, &D.wave, waves));
@@ -587,17 +595,24 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
   VILO_HIP(hipMemcpy(skip.data(), D.imu_skip, n, hipMemcpyDeviceToHost));
   if (offsets[0] < 0) return VILO_ERR_BAD_ARG;
   for (size_t f = 0; f < n; ++f)
-    if (offsets[f + 1] < offsets[f] || (!skip[f] && offsets[f + 1] == offsets[f])) {
-      ctx->err = "vilo_batch_set_samples: a live interval without samples";
+    if (offsets[f + 1] < offsets[f] || (!skip[f] && offsets[f + 1] - offsets[f] < 2)) {
+      // (one sample = the constructor's: nothing is integrated and the covariance stays zero, which has no sqrt_info)
+      ctx->err = "vilo_batch_set_samples: a live interval needs at least two samples";
       return VILO_ERR_BAD_ARG;
     }
-  vilo_sample *d_s = nullptr;
-  int *d_o = nullptr;
-  double *d_t = nullptr;
-  int rc = dev_alloc(ctx, bt, &d_s, (size_t)offsets[n]);
-  if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &d_o, n + 1);
-  if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &d_t, (size_t)offsets[n] * 108);   // 4 legs x 27 doubles per sample
-  if (rc != VILO_OK) return rc;
+  if (!bt->rp_s || bt->rp_cap < (size_t)offsets[n]) {
+    bt->rp_cap = (size_t)offsets[n];
+    int rc = dev_alloc(ctx, bt, &bt->rp_s, bt->rp_cap);
+    if (rc == VILO_OK && !bt->rp_o) rc = dev_alloc(ctx, bt, &bt->rp_o, n + 1);
+    if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->rp_t, bt->rp_cap * 108);   // 4 legs x 27 doubles per sample
+    if (rc != VILO_OK) { bt->rp_s = nullptr; bt->rp_cap = 0; return rc; }
+  }
+  vilo_sample *d_s = bt->rp_s;
+  int *d_o = bt->rp_o;
+  double *d_t = bt->rp_t;
+  // the records are integrated again before every linearisation from here on: the flags of the records the batch was created with no
+  // longer describe them (k_accept / the marginalisation read prep_bad of the records in force)
+  if (bt->d.win_bad) VILO_HIP(hipMemset(bt->d.win_bad, 0, sizeof(int) * (size_t)bt->W));
   VILO_HIP(hipMemcpy(d_s, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice));
   VILO_HIP(hipMemcpy(d_o, offsets, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
   D.rp_samples = d_s; D.rp_terms = d_t; D.rp_offsets = d_o; D.rp_pre = bt->d_pre; D.prep_bad = bt->d_prep_bad; D.leg = 1; D.rp_on = 1;
@@ -620,7 +635,8 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   VILO_HIP(hipSetDevice(ctx->device));
   int rc = VILO_OK;
   const bool want_graph = !ctx->profile && !bt->graph_failed && bt->n_solves >= 1 && getenv("VILO_NO_GRAPH") == nullptr;
-  if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0)) {
+  if (opts->max_solver_time_us < 0) { ctx->err = "vilo_solve_opts.max_solver_time_us < 0 (fill the struct with vilo_default_solve_opts)"; return VILO_ERR_BAD_ARG; }
+  if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0 || bt->g_sqrt_info_mode != ctx->sqrt_info_mode || bt->g_rp_on != bt->d.rp_on)) {
     if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -630,7 +646,7 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
       if (g) (void)hipGraphDestroy(g);
     }
     if (!bt->gexec) { bt->graph_failed = true; (void)hipGetLastError(); ctx->err.clear(); }
-    else bt->gopts = *opts;
+    else { bt->gopts = *opts; bt->g_sqrt_info_mode = ctx->sqrt_info_mode; bt->g_rp_on = bt->d.rp_on; }
     rc = VILO_OK;
   }
   VILO_HIP(hipEventRecord(ctx->ev0, ctx->stream));

@@ -196,6 +196,106 @@ VD double vis_one_frame(const double *wt, const VisLane &L, const v3 &pts_i, con
   return rho0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Compact 16-column form of the same rows (solve passes while td is a constant block: estimate_td 0, estimator.cpp:1104).
+// The translation columns of BOTH extrinsics are the pose-translation columns times a rotation that depends on the (start frame,
+// observing frame) pair only — with B = d r / d P_i = reduce ricK^T Rj^T:
+//     TwoFrameOneCam:  d r / d tic  = reduce ric^T (Rj^T Ri - I) = B (Ri - Rj)      (projectionTwoFrameOneCamFactor.cpp:109-118)
+//     TwoFrameTwoCam:  d r / d tic  = reduce ric2^T Rj^T Ri      = B Ri,   d r / d tic2 = -reduce ric2^T = -B Rj   (…TwoCamFactor.cpp:114-132)
+//     OneFrameTwoCam:  d r / d tic  = reduce ric2^T =: B,        d r / d tic2 = -B   (…OneFrameTwoCamFactor.cpp:92-108; no pose columns)
+// so their Gram blocks are 3 x 3 transforms of the B blocks, applied once per (chunk, frame) slot by k_assemble instead of once per
+// factor here: a row has 16 columns = ONE FP64-MFMA tile per camera (the 23-column form needs three for a right-camera factor).
+//   GK_B 3 | GK_RI 3 (theta_i) | GK_RJ 3 (theta_j) | GK_C0 3 (theta_ic) | GK_C1 3 (theta_ic2; zero for the left camera) | GK_R
+// A slot stores the upper triangle of G = C0 + C1 (the Grams of the left / right camera rows; 136) and rows 0..2 (B) of C1 (48):
+// C0's B rows are G's minus C1's.
+#define GK_B 0
+#define GK_RI 3
+#define GK_RJ 6
+#define GK_C0 9
+#define GK_C1 12
+#define GK_R 15
+#define VILO_GKC 16
+#define VILO_GRAMC_TRI 136
+#define VILO_GRAMC 184
+VD int tri16(int a, int b) { return a * 16 - (a * (a - 1)) / 2 + (b - a); }   // a <= b
+
+// tc: the extrinsic translation columns of the two rows (only the landmark's coupling row needs them per factor): tic (row 0, row 1), tic2 (row 0, row 1)
+template <int CAM>
+VD double vis_two_frame_c(const double *wt, const double *tb, const VisLane &L, const v3 &p_j, const double *ob, double dtj, double sq,
+                          double huber_a, double *x0, double *x1, double *Jl, double tc[4][3]) {
+  const double *ricK = wt + (CAM ? VW_RIC2 : VW_RIC), *ticK = wt + (CAM ? VW_TIC2 : VW_TIC);
+  const double *A = tb + (CAM ? VT_A1 : VT_A0), *AR = tb + (CAM ? VT_A1R : VT_A0R), *ARC = tb + (CAM ? VT_A1RC : VT_A0RC);
+  const v3 d = mk3(p_j.x - ticK[0], p_j.y - ticK[1], p_j.z - ticK[2]);
+  const v3 pcj = mk3(ricK[0] * d.x + ricK[3] * d.y + ricK[6] * d.z, ricK[1] * d.x + ricK[4] * d.y + ricK[7] * d.z,
+                     ricK[2] * d.x + ricK[5] * d.y + ricK[8] * d.z);
+  Red3 R;
+  double sqw, r[2];
+  const double rho0 = vis_residual(pcj, ob[0] - ob[3] * dtj, ob[1] - ob[4] * dtj, sq, huber_a, r, R, sqw);
+  double t0[3], t1[3], e0[3], e1[3], c0[3], c1[3];
+  red_mul(R, A, x0 + GK_B, x1 + GK_B);
+  red_mul(R, AR, e0, e1);
+  cross3(L.p_i, e0, x0 + GK_RI);
+  cross3(L.p_i, e1, x1 + GK_RI);
+  red_mul_t(R, ricK, t0, t1);
+  cross3(t0, p_j, x0 + GK_RJ);
+  cross3(t1, p_j, x1 + GK_RJ);
+  red_mul(R, ARC, c0, c1);
+  cross3(L.pci, c0, x0 + GK_C0);
+  cross3(L.pci, c1, x1 + GK_C0);
+  if (CAM == 0) {
+    double s0[3], s1[3];
+    red_skew(R, pcj, s0, s1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      x0[GK_C0 + c] += s0[c]; x1[GK_C0 + c] += s1[c];
+      x0[GK_C1 + c] = 0.0; x1[GK_C1 + c] = 0.0;
+      tc[0][c] = e0[c] - t0[c]; tc[1][c] = e1[c] - t1[c];
+      tc[2][c] = 0.0; tc[3][c] = 0.0;
+    }
+  } else {
+    red_skew(R, pcj, x0 + GK_C1, x1 + GK_C1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tc[0][c] = e0[c]; tc[1][c] = e1[c];
+      tc[2][c] = -t0[c]; tc[3][c] = -t1[c];
+    }
+  }
+  const double nil = -L.inv_lam;
+  Jl[0] = nil * (c0[0] * L.pci.x + c0[1] * L.pci.y + c0[2] * L.pci.z);
+  Jl[1] = nil * (c1[0] * L.pci.x + c1[1] * L.pci.y + c1[2] * L.pci.z);
+  x0[GK_R] = r[0]; x1[GK_R] = r[1];
+  return rho0;
+}
+
+// OneFrameTwoCam in the compact form: B = reduce ric2^T (tic: +B, tic2: -B; k_assemble uses identity transforms for a frame-0 slot)
+VD double vis_one_frame_c(const double *wt, const VisLane &L, const v3 &pts_i, const double *ob, double dtj, double sq, double huber_a, double *x0,
+                          double *x1, double *Jl, double tc[4][3]) {
+  const double *ric2 = wt + VW_RIC2, *tic2 = wt + VW_TIC2, *A = wt + VW_A2;
+  const v3 d = mk3(L.p_i.x - tic2[0], L.p_i.y - tic2[1], L.p_i.z - tic2[2]);
+  const v3 pcj = mk3(ric2[0] * d.x + ric2[3] * d.y + ric2[6] * d.z, ric2[1] * d.x + ric2[4] * d.y + ric2[7] * d.z,
+                     ric2[2] * d.x + ric2[5] * d.y + ric2[8] * d.z);
+  Red3 R;
+  double sqw, r[2];
+  const double rho0 = vis_residual(pcj, ob[0] - ob[3] * dtj, ob[1] - ob[4] * dtj, sq, huber_a, r, R, sqw);
+  double c0[3], c1[3];
+  red_mul_t(R, ric2, x0 + GK_B, x1 + GK_B);   // reduce * ric2^T
+  red_mul(R, A, c0, c1);                      // reduce * ric2^T ric
+  cross3(L.pci, c0, x0 + GK_C0);
+  cross3(L.pci, c1, x1 + GK_C0);
+  red_skew(R, pcj, x0 + GK_C1, x1 + GK_C1);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    x0[GK_RI + c] = 0.0; x1[GK_RI + c] = 0.0; x0[GK_RJ + c] = 0.0; x1[GK_RJ + c] = 0.0;
+    tc[0][c] = x0[GK_B + c]; tc[1][c] = x1[GK_B + c];
+    tc[2][c] = -x0[GK_B + c]; tc[3][c] = -x1[GK_B + c];
+  }
+  const double il2 = -(L.inv_lam * L.inv_lam);
+  Jl[0] = il2 * (c0[0] * pts_i.x + c0[1] * pts_i.y + c0[2] * pts_i.z);
+  Jl[1] = il2 * (c1[0] * pts_i.x + c1[1] * pts_i.y + c1[2] * pts_i.z);
+  x0[GK_R] = r[0]; x1[GK_R] = r[1];
+  return rho0;
+}
+
 // One row (r) of the products of one camera (kind) for the pair (start frame s, observing frame j); kind 0 also stores Rj and Pj.
 // xs: the window's state in vector2double order; wt: the window-level table.
 VD void vis_build_pair_row(const double *xs, const double *wt, int s, int j, int kind, int r, double *tb) {

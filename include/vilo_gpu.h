@@ -150,7 +150,9 @@ typedef struct {
   int32_t jacobi_scaling;
   int32_t max_solver_time_us;  /* Solver::Options::max_solver_time_in_seconds (estimator.cpp:1226-1233: SOLVER_TIME = 0.1 s, x 0.8 on MARGIN_OLD) as a
                                 * device-clock budget in microseconds, checked per window where Ceres checks it (before an iteration starts);
-                                * when spent the window ends with termination NO_CONVERGENCE. 0 (default): no budget — a solve takes ~3 ms */
+                                * when spent the window ends with termination NO_CONVERGENCE. 0 (default): no budget — a solve takes ~3 ms.
+                                * This field took the place of a former `reserved` int: fill the struct with vilo_default_solve_opts() first
+                                * (a negative value is rejected with VILO_ERR_BAD_ARG) */
 } vilo_solve_opts;
 void vilo_default_solve_opts(vilo_solve_opts *o);
 

@@ -3,6 +3,7 @@
 // minute is spent. This library is never loaded by the product (libvilo_gpu.so has no CPU path).
 #include "../../cerberus_amd/csrc/factors.hpp"
 #include "../../cerberus_amd/csrc/visual_lin.hpp"
+#include "../../cerberus_amd/csrc/assemble_compact.hpp"
 #include "../../include/vilo_gpu.h"
 
 using namespace vilo;
@@ -79,5 +80,54 @@ double hc_vis_lin(int kind, const double *obs12, const double *pose_i, const dou
   if (kind == 0) return vis_two_frame<0>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
   if (kind == 1) return vis_two_frame<1>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl);
   return vis_one_frame(wt, L, mk3(obs12[0], obs12[1], obs12[2]), obc, dtj, sq, huber_a, x0, x1, Jl);
+}
+
+// The compact 16-column form of the same rows (visual_lin.hpp: GK_B 3 | GK_RI 3 | GK_RJ 3 | GK_C0 3 | GK_C1 3 | GK_R) and the extrinsic
+// translation columns tc[4][3] (tic row 0 / 1, tic2 row 0 / 1) the landmark's coupling row needs.
+double hc_vis_lin_c(int kind, const double *obs12, const double *pose_i, const double *pose_j, const double *ex0, const double *ex1,
+                    double inv_dep, double td, double sq, double huber_a, double *x0, double *x1, double *Jl, double *tc12) {
+  double xs[14], wt[VW_N], tb[VT_N];
+  for (int i = 0; i < 7; ++i) { xs[i] = pose_i[i]; xs[7 + i] = pose_j[i]; }
+  const m3 ric = qR(ldq_pose(ex0)), ric2 = qR(ldq_pose(ex1));
+  const m3 A2 = tr(ric2) * ric;
+  for (int q = 0; q < 9; ++q) { wt[VW_RIC + q] = ric.a[q]; wt[VW_RIC2 + q] = ric2.a[q]; wt[VW_A2 + q] = A2.a[q]; }
+  for (int q = 0; q < 3; ++q) { wt[VW_TIC + q] = ex0[q]; wt[VW_TIC2 + q] = ex1[q]; }
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 3; ++r) vis_build_pair_row(xs, wt, 0, 1, k, r, tb);
+  VisLane L;
+  const double dti = td - obs12[10];
+  L.inv_lam = 1.0 / inv_dep;
+  L.vix = obs12[6]; L.viy = obs12[7];
+  L.pci = mk3((obs12[0] - obs12[6] * dti) * L.inv_lam, (obs12[1] - obs12[7] * dti) * L.inv_lam, obs12[2] * L.inv_lam);
+  L.p_i = ric * L.pci + ld3(ex0);
+  L.p_w = qrot(ldq_pose(pose_i), L.p_i) + ld3(pose_i);
+  const v3 d = mk3(L.p_w.x - tb[VT_PJ], L.p_w.y - tb[VT_PJ + 1], L.p_w.z - tb[VT_PJ + 2]);
+  const v3 p_j = mk3(tb[0] * d.x + tb[3] * d.y + tb[6] * d.z, tb[1] * d.x + tb[4] * d.y + tb[7] * d.z, tb[2] * d.x + tb[5] * d.y + tb[8] * d.z);
+  const double obc[5] = {obs12[3], obs12[4], obs12[5], obs12[8], obs12[9]};
+  const double dtj = td - obs12[11];
+  double tc[4][3];
+  double rho;
+  if (kind == 0) rho = vis_two_frame_c<0>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+  else if (kind == 1) rho = vis_two_frame_c<1>(wt, tb, L, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+  else rho = vis_one_frame_c(wt, L, mk3(obs12[0], obs12[1], obs12[2]), obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+  for (int i = 0; i < 12; ++i) tc12[i] = tc[i / 3][i % 3];
+  return rho;
+}
+
+// k_assemble's compact visual part, its 256 threads emulated one after the other: H (80 x 80 row-major, lower triangle + mirrored
+// diagonal blocks are NOT formed: entry (hi, lo) only) and the gradient g (80). poses: [11][7] of the window's frames.
+void hc_assemble_compact(int nch, const unsigned *chunk_tab, const double *slots, const double *poses, double *H80, double *g80) {
+  double Rt[12 * 9];
+  for (int f = 0; f < 11; ++f) {
+    const m3 R = qR(ldq_pose(poses + 7 * f));
+    for (int q = 0; q < 9; ++q) Rt[9 * f + q] = R.a[q];
+  }
+  for (int q = 0; q < 9; ++q) Rt[99 + q] = (q % 4 == 0) ? 1.0 : 0.0;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int s = chunk_tab[ch] & 255, km = (chunk_tab[ch] >> 8) & 255, sl0 = chunk_tab[ch] >> 16;
+    for (int tid = 0; tid < 256; ++tid)
+      assemble_visual_compact_chunk(
+          tid, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt, [&](int hi, int lo, double v) { H80[hi * 80 + lo] += v; }, [&](int cd, double v) { g80[cd] += v; });
+  }
 }
 }

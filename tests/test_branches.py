@@ -126,15 +126,23 @@ def test_invalid_steps_end_in_failure_on_the_fifth(ctx, cfg, ocfg):
 
 def test_max_solver_time_budget(ctx, cfg, ocfg):
     """Solver::Options::max_solver_time_in_seconds (estimator.cpp:1226-1233) as a device-clock budget: with a budget far below one iteration
-    the solve stops after the first iteration it completes, termination NO_CONVERGENCE, the accepted states kept; without a budget
+    the solve stops after the iteration in which it runs out, termination NO_CONVERGENCE, the accepted states kept; without a budget
     (the default) all iterations run."""
     from cerberus_amd import api
     w = _window(cfg, ocfg, seed=11)
     o = api.default_solve_opts(True, 12)
     assert o.max_solver_time_us == 0
-    o.max_solver_time_us = 1
+    o.max_solver_time_us = 600   # (an iteration of a single window takes 0.1 .. 0.4 ms)
     s1 = ctx.solve_windows([w], o)[0]
     assert 1 <= s1.iterations < 12 and s1.termination == 0 and s1.final_cost < s1.initial_cost
+    # Ceres checks the budget before EVERY iteration, the first included: a budget that is spent by the time the initial point has been
+    # evaluated ends the solve in IterationZero with the states untouched
+    w0 = _window(cfg, ocfg, seed=11)
+    o.max_solver_time_us = 1
+    s0 = ctx.solve_windows([w0], o)[0]
+    assert s0.iterations == 0 and s0.termination == 0 and s0.final_cost == s0.initial_cost
+    for a, bb in zip(w0.state_arrays(), _window(cfg, ocfg, seed=11).state_arrays()):
+        np.testing.assert_array_equal(a, bb)
     w2 = _window(cfg, ocfg, seed=11)
     s2 = ctx.solve_windows([w2], api.default_solve_opts(True, 12))[0]
     assert s2.iterations == 12 and s2.final_cost <= s1.final_cost

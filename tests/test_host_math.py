@@ -183,3 +183,92 @@ def test_corrector(hc):
         np.testing.assert_allclose([rho0], [rho[0]])
         np.testing.assert_allclose(r2, rr, atol=1e-15)
         np.testing.assert_allclose(j2, jr, atol=1e-15)
+
+
+def _gram26_cols(g23):
+    """23-column rows -> the 26-column view [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td | r]."""
+    return np.concatenate([g23[:, 0:6], -g23[:, 0:3], g23[:, 6:9], g23[:, 9:15], g23[:, 16:22], g23[:, 22:23], g23[:, 15:16]], axis=1)
+
+
+def test_compact_rows_and_their_assembly_match_the_23_column_form(hc):
+    """The compact 16-column rows of the solve passes (visual_lin.hpp: one FP64-MFMA tile per camera) and k_assemble's expansion of
+    their per-slot Grams (assemble_compact.hpp: the extrinsic-translation blocks as 3 x 3 transforms of the B blocks, the 256 owner
+    threads emulated on the host) against a dense accumulation of the 23-column rows: pose system (td left out: a constant block in
+    this mode) and gradient of a window of several chunks (start frames), stereo and mono observations, inliers and outliers."""
+    rng = np.random.default_rng(2026)
+    sq, a = 460.0 / 1.5, 1.0
+    F = 11
+    poses = np.stack([rand_pose(rng, 0.3) for _ in range(F)])
+    q0 = poses[0, 3:].copy()
+    for f in range(1, F):
+        poses[f, 3:] = q0 + 0.08 * rng.normal(size=4); poses[f, 3:] /= np.linalg.norm(poses[f, 3:])
+    ex0 = np.array([0.1, 0.025, 0.11, 0.5, -0.5, 0.5, -0.5]); ex1 = ex0.copy(); ex1[1] = -0.025
+    ex0[3:] += 0.01 * rng.normal(size=4); ex0[3:] /= np.linalg.norm(ex0[3:])
+    ex1[3:] += 0.01 * rng.normal(size=4); ex1[3:] /= np.linalg.norm(ex1[3:])
+    td = 0.003
+    chunks = [(0, 5, 11), (0, 3, 4), (2, 6, 9), (5, 4, 6), (9, 3, 2), (10, 2, 1)]   # (start frame, landmarks, frames seen)
+    H = np.zeros((80, 80)); g = np.zeros(80)
+    slots = []; tab = []
+    cd_of = lambda s, j: np.concatenate([6 * s + np.arange(6), 6 * j + np.arange(6), 66 + np.arange(12), [78]])
+    for (s, n, km) in chunks:
+        tab.append(s | (km << 8) | (len(slots) << 16))
+        lams = 1.0 / rng.uniform(2, 10, size=n)
+        oi = [np.array([rng.uniform(-.5, .5), rng.uniform(-.5, .5), 1.0]) for _ in range(n)]
+        vi = [rng.normal(size=2) * 0.2 for _ in range(n)]
+        for t in range(km):
+            j = s + t
+            Cg = [np.zeros((16, 16)), np.zeros((16, 16))]
+            for l in range(n):
+                if rng.uniform() < 0.15 and t > 0:
+                    continue   # not observed in this frame
+                for cam in ((1,) if t == 0 else (0, 1)):
+                    if cam == 1 and rng.uniform() < 0.3:
+                        continue   # mono observation
+                    kind = 2 if t == 0 else cam
+                    obs = np.concatenate([oi[l], [rng.uniform(-.5, .5), rng.uniform(-.5, .5), 1.0], vi[l], rng.normal(size=2) * 0.2, [0.003, 0.001]])
+                    x0 = np.zeros(23); x1 = np.zeros(23); jl = np.zeros(2)
+                    args = (kind, P(obs), P(poses[s]), P(poses[j]), P(ex0), P(ex1), C.c_double(lams[l]), C.c_double(td), C.c_double(sq), C.c_double(a))
+                    rho = hc.hc_vis_lin(*args, P(x0), P(x1), P(jl))
+                    k0 = np.zeros(16); k1 = np.zeros(16); jlc = np.zeros(2); tc = np.zeros(12)
+                    hc.hc_vis_lin_c.restype = C.c_double
+                    rho_c = hc.hc_vis_lin_c(*args, P(k0), P(k1), P(jlc), P(tc))
+                    assert rho_c == rho
+                    np.testing.assert_array_equal(jlc, jl)
+                    g23 = np.stack([x0, x1]); k16 = np.stack([k0, k1]); tc = tc.reshape(4, 3)
+                    # the columns both forms have are the same numbers; the translation columns of the extrinsics come back as tc
+                    if kind == 2:   # no pose columns: the B columns carry reduce ric2^T = the tic column (k_assemble: identity transforms at t = 0)
+                        np.testing.assert_array_equal(k16[:, 0:3], g23[:, 9:12])
+                        assert np.all(k16[:, 3:9] == 0.0) and np.all(g23[:, 0:9] == 0.0)
+                    else:
+                        np.testing.assert_array_equal(k16[:, 0:9], g23[:, 0:9])
+                    np.testing.assert_array_equal(k16[:, 9:12], g23[:, 12:15])
+                    np.testing.assert_array_equal(k16[:, 12:15], g23[:, 19:22])
+                    np.testing.assert_array_equal(k16[:, 15], g23[:, 15])
+                    np.testing.assert_array_equal(tc[0:2], g23[:, 9:12])
+                    np.testing.assert_array_equal(tc[2:4], g23[:, 16:19])
+                    J26 = _gram26_cols(g23)
+                    if t == 0:
+                        assert np.all(J26[:, 0:12] == 0.0)
+                    cd = cd_of(s, j)
+                    for rrow in range(2):
+                        np.add.at(H, (cd[:, None], cd[None, :]), np.outer(J26[rrow, :25], J26[rrow, :25]))
+                        np.add.at(g, cd, J26[rrow, :25] * J26[rrow, 25])
+                    Cg[cam] += k16.T @ k16
+            G = Cg[0] + Cg[1]
+            slot = np.zeros(184)
+            for x in range(16):
+                for y in range(x, 16):
+                    slot[x * 16 - (x * (x - 1)) // 2 + (y - x)] = G[x, y]
+            slot[136:] = Cg[1][0:3, :].reshape(-1)
+            slots.append(slot)
+    slots = np.ascontiguousarray(np.stack(slots))
+    tab = np.array(tab, dtype=np.uint32)
+    Hc = np.zeros((80, 80)); gc = np.zeros(80)
+    hc.hc_assemble_compact(len(chunks), tab.ctypes.data_as(C.POINTER(C.c_uint32)), P(slots), P(np.ascontiguousarray(poses)), P(Hc), P(gc))
+    keep = [i for i in range(80) if i not in (78, 79)]
+    Hl = np.tril(H)[np.ix_(keep, keep)]
+    scale = np.abs(Hl).max()
+    np.testing.assert_allclose(Hc[np.ix_(keep, keep)], Hl, rtol=0, atol=2e-13 * scale)
+    assert np.all(np.triu(Hc, 1) == 0.0)
+    np.testing.assert_allclose(gc[keep], g[keep], rtol=0, atol=2e-13 * np.abs(g).max())
+    assert np.count_nonzero(Hl) > 1500
