@@ -40,19 +40,36 @@ REPROPAGATION_KERNELS = ("k_repropagate", "k_prepare_preint")   # config 3: once
 REPROPAGATION_FLOPS = 15.0e6
 
 
+def kernels_sha16():
+    """Fingerprint of the kernel sources (cerberus_amd/csrc): profiles/*_pmc.json carries the one of the tree its counters were collected
+    on, so a bench line can say whether the committed counter evidence belongs to the kernels that ran."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cerberus_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PROFILE_ROUND = "round3"
+
+
 def profile_evidence(W_run, tag=""):
     """Counter evidence of the committed rocprofv3 passes (tools/profile_gpu.sh, tools/profile_sq.sh; measured at 4096 windows per
     dispatch): calibrated HBM bytes per dispatch and the matrix-core busy fraction per kernel. Per-window figures, so they scale."""
     out = {"pmc": None, "mfma": None}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc%s.json" % tag)))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc%s.json" % (PROFILE_ROUND, tag))))
         Wp = pmc.get("windows_per_dispatch", 4096)
         out["pmc"] = {k: v * W_run / Wp for k, v in pmc["hbm_bytes_per_dispatch"].items()}
         out["pmc_kernel_us"] = {k: v["avg_us"] for k, v in pmc["kernel_trace"].items()}
+        out["pmc_kernels_sha16"] = pmc.get("kernels_sha16")
+        out["pmc_commit"] = pmc.get("commit")
     except Exception:
         pass
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "round2_mfma%s.json" % tag)))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "%s_mfma%s.json" % (PROFILE_ROUND, tag))))
         util = {}
         for k, c in sq["kernels"].items():
             us = (out.get("pmc_kernel_us") or {}).get(k)
@@ -114,13 +131,19 @@ def marginalize_timing(ctx, cfg, windows, n_cpu=8):
         rc = L.vilo_marginalize(ctx.h, W, descs, states, 0, priors)
     gpu_ms = L.vilo_last_marginalize_ms(ctx.h)
     ocfg = O.config_from(cfg)
-    t0 = time.perf_counter()
     n_cpu = min(n_cpu, W)
-    for w in windows[:n_cpu]:
-        O.marginalize(ocfg, w, 0, synth.PriorData())
-    cpu_ms = 1e3 * (time.perf_counter() - t0) / n_cpu
-    return {"mode": "MARGIN_OLD", "gpu_ms_per_window": gpu_ms / W, "gpu_batch": W, "gpu_ms_batch": gpu_ms, "cpu_ms_per_window": cpu_ms, "cpu_cores": 1,
-            "cpu_sample": "%d windows, oracle/liboracle.so, 1 thread" % n_cpu, "rc": int(rc)}
+    cpu = {}
+    for nt in (1, 4):   # 4: the reference's NUM_THREADS for the Hessian build (marginalization_factor.h:22, .cpp:246-275); the eigen part is single-threaded there too
+        O.lib().orc_set_marginalize_threads(nt)
+        t0 = time.perf_counter()
+        for w in windows[:n_cpu]:
+            O.marginalize(ocfg, w, 0, synth.PriorData())
+        cpu[nt] = 1e3 * (time.perf_counter() - t0) / n_cpu
+    O.lib().orc_set_marginalize_threads(1)
+    return {"mode": "MARGIN_OLD", "gpu_ms_per_window": gpu_ms / W, "gpu_batch": W, "gpu_ms_batch": gpu_ms, "cpu_ms_per_window": cpu[4], "cpu_cores": 4,
+            "cpu_ms_per_window_1_thread": cpu[1],
+            "cpu_sample": "%d windows, oracle/liboracle.so; Hessian build on 4 threads like the reference (cpu_ms_per_window) and on 1 (cpu_ms_per_window_1_thread), "
+                          "Schur complement + eigen-decompositions on one thread in both" % n_cpu, "rc": int(rc)}
 
 
 def _all_cores_child(k, n_landmarks, t_end, q):
@@ -176,6 +199,77 @@ def cpu_baseline_all_cores(n_landmarks, budget_s=6.0):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def parity_sample(cfg, windows, ids, landmarks, rate, summ, n=8, repropagate=False):
+    """Checker leg (outside the timed region): the final states of the first n windows of the timed batch — as the timed kernels left
+    them — against the oracle run on the same seeds for the same fixed number of iterations. The preintegration records are the ones the
+    GPU integrated (K1 has its own goldens); everything after them is recomputed by the oracle."""
+    import contextlib
+    import numpy as np
+    from oracle import oracle_py as O
+    ocfg = O.config_from(cfg)
+    opts = O.default_opts(fixed_iterations=True, max_num_iterations=ITERS)
+    n = min(n, len(windows))
+    max_state, max_cost = 0.0, 0.0
+    for i in range(n):
+        w_ref = make_synth_window(cfg, landmarks, rate, 20260925 + ids[i])
+        w_ref.preint[...] = windows[i].preint
+        with (O.repropagation(w_ref) if repropagate else contextlib.nullcontext()):
+            osum = O.solve_window(ocfg, w_ref, opts)
+        for a, b in zip(windows[i].state_arrays(), w_ref.state_arrays()):
+            max_state = max(max_state, float(np.abs(a - b).max() / max(1.0, np.abs(b).max())))
+        max_cost = max(max_cost, abs(summ[i].final_cost - osum.final_cost) / max(abs(osum.final_cost), 1e-300))
+    return {"windows": n, "max_state_err": max_state, "max_cost_rel": max_cost, "tolerance": 1e-6,
+            "what": "final states (relative to max(1, |state block|)) and final cost of the first %d windows of the timed batch after the last timed step vs "
+                    "oracle/liboracle.so on the same seeds, %d fixed iterations%s" % (n, ITERS, ", intervals integrated again per evaluation" if repropagate else "")}
+
+
+def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
+    """BASELINE configs[2] as a side block of the default line (the driver only runs the default command): 1000 landmarks, 400 Hz,
+    every iteration integrates all 10 intervals again. Same measurement as the headline: `steps` timed steps after one warm-up step that
+    carries the per-kernel event pairs; value = window-iterations / wall time of the timed steps."""
+    import numpy as np
+    from cerberus_amd import api
+    t0 = time.perf_counter()
+    windows = [make_synth_window(cfg, 1000, 400, 40260925 + i) for i in range(W)]
+    ctx.preintegrate_windows(windows)
+    batch = api.Batch(ctx, windows)
+    batch.set_samples()
+    setup_s = time.perf_counter() - t0
+
+    def table():
+        ms = (C.c_double * 16)(); launches = (C.c_longlong * 16)()
+        nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 16)
+        lib.vilo_kernel_name.restype = C.c_char_p
+        return {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]), "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}
+    lib.vilo_set_profiling(ctx.h, 1)   # (also clears the per-kernel table)
+    batch.reset(); batch.solve(opts)
+    kern = {k: v for k, v in table().items() if v["launches"]}
+    lib.vilo_set_profiling(ctx.h, 0)
+    import torch
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        batch.reset(); batch.solve(opts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    summ = batch.download()
+    assert sum(s.iterations for s in summ) == W * ITERS
+    n_samples = int(windows[0].sample_offsets[-1])
+    b_alg = algorithmic_bytes(int(windows[0].n_obs), 1000) + 280 * n_samples
+    dom = max(kern, key=lambda k: kern[k]["ms_total"])
+    achieved = b_alg * W / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    out = {"workload": "BASELINE configs[2]: 10-KF x 1000-landmark window, 400 Hz (%d samples per window), all 10 intervals integrated again in every "
+                       "iteration + their sqrt_info; %d windows, %d timed steps of %d fixed iterations" % (n_samples, W, steps, ITERS),
+           "value": W * ITERS * steps / dt, "unit": "GN window-iterations/s", "ms_per_step": 1e3 * dt / steps, "windows": W, "steps": steps,
+           "kernels": kern, "setup_s": setup_s,
+           "roofline": {"bound": "hbm", "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                        "algorithmic_bytes_per_window_iteration": b_alg},
+           # (parity_sample regenerates window i from seed 20260925 + ids[i]: these windows were drawn from 40260925 + i)
+           "parity_sample": parity_sample(cfg, windows, [20000000 + i for i in range(W)], 1000, 400, summ, n=2, repropagate=True)}
+    batch.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,9 +283,11 @@ def main():
     ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
     ap.add_argument("--streams", type=int, default=2, help="resident batches solved concurrently in the multi-stream side figure (default 2: `two_streams`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] side block of the default line")
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
     args = ap.parse_args()
+    exit_code = 0
     rp = args.config == 3
     args.landmarks = args.landmarks or (1000 if rp else 200)
     args.rate = args.rate or (400 if rp else 500)
@@ -352,9 +448,13 @@ def main():
                        "shards": shard_info},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
-                         "traffic_source": "profiles/round2_pmc%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated on a 1 GiB copy; per-window figure scaled to this batch)" % tag if traffic else None,
+                         "traffic_source": ({"file": "profiles/%s_pmc%s.json" % (PROFILE_ROUND, tag),
+                                             "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 1 GiB copy; per-window figure scaled to this batch",
+                                             "collected_at_commit": ev.get("pmc_commit"), "kernels_sha16_of_profile": ev.get("pmc_kernels_sha16"),
+                                             "kernels_sha16_of_this_run": kernels_sha16(),
+                                             "stale": ev.get("pmc_kernels_sha16") != kernels_sha16()} if traffic else None),
                          "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"],
-                         "rocprof_summary": "profiles/round2_rocprof_summary%s.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)" % tag,
+                         "rocprof_summary": "profiles/%s_rocprof_summary%s.txt (rocprofv3 --kernel-trace --stats of this command, tools/profile_gpu.sh)" % (PROFILE_ROUND, tag),
                          "algorithmic_bytes_per_window_iteration": b_alg,
                          "whole_iteration": {"gbps": b_alg * W / (iter_ms * 1e-3) / 1e9, "frac": b_alg * W / (iter_ms * 1e-3) / 1e9 / 8000.0,
                                              "traffic_bytes_per_window_iteration": it_traffic / W if it_traffic else None,
@@ -365,12 +465,18 @@ def main():
                                   "whole_iteration_tflops": alg_flops * W / (iter_ms * 1e-3) / 1e12 if alg_flops else None,
                                   "whole_iteration_frac": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 78.6 if alg_flops else None,
                                   "mfma_util": ev["mfma"],
-                                  "mfma_util_source": "profiles/round2_mfma%s.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" % tag if ev["mfma"] else None}},
+                                  "mfma_util_source": "profiles/%s_mfma%s.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" % (PROFILE_ROUND, tag) if ev["mfma"] else None},
+                         # calibrated HBM bytes per window of every kernel of the iteration against the algorithmic bytes of the whole iteration
+                         "traffic_per_kernel": ({k: {"bytes_per_window": ev["pmc"][k] / W, "over_algorithmic": ev["pmc"][k] / W / b_alg}
+                                                 for k in it_kernels if k in ev["pmc"]} if ev["pmc"] else None)},
             "kernels": kern,
             "kernels_note": "HIP events on the solver's stream; `steps` = the steps an entry was measured over: the dominant kernel over the timed steps, "
                             "the others over the warm-up steps (the timed steps carry the dominant kernel's event pairs only)",
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
+        if not args.no_cpu_baseline:
+            # checker leg, outside the timed region: did the timed kernels produce the reference's states?
+            out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, n=2 if rp else 8, repropagate=rp)
         if (args.single_window_latency or world == 1) and not args.no_single_window:   # absolute rate of ONE window on one GPU
             b1 = make_batch(ctx, windows[:1])
             lib.vilo_set_profiling(ctx.h, 0)
@@ -415,6 +521,13 @@ def main():
                     b.close(); ck.close()
             except Exception as e:
                 out["two_streams"] = {"error": repr(e)}
+        if not args.no_cpu_baseline and world == 1 and not rp and not args.no_config3:
+            try:
+                out["config3"] = config3_block(ctx, cfg, lib, opts)
+                c3 = cpu_baseline(cfg, 1000, budget_s=4.0, rate=400, repropagate=True)
+                out["config3"]["cpu_baseline"] = c3
+            except Exception as e:
+                out["config3"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256], n_cpu=2 if rp else 8)
@@ -428,10 +541,18 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        bad = [k for k in ("parity_sample",) if isinstance(out.get(k), dict) and max(out[k]["max_state_err"], out[k]["max_cost_rel"]) > out[k]["tolerance"]]
+        c3p = (out.get("config3") or {}).get("parity_sample") if isinstance(out.get("config3"), dict) else None
+        if c3p and max(c3p["max_state_err"], c3p["max_cost_rel"]) > c3p["tolerance"]:
+            bad.append("config3.parity_sample")
+        if bad:
+            print("bench.py: PARITY SAMPLE FAILED (%s): the timed kernels did not reproduce the oracle's states" % ", ".join(bad), file=sys.stderr)
+            exit_code = 3
     batch.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__" and len(sys.argv) >= 2 and sys.argv[1] == "--cpu-all-cores":
@@ -439,4 +560,4 @@ if __name__ == "__main__" and len(sys.argv) >= 2 and sys.argv[1] == "--cpu-all-c
     sys.exit(0)
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

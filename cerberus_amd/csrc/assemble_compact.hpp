@@ -80,28 +80,27 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     if (q < 6) { int rem = q; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
     else if (q < 15) { pb = 1; ia = (q - 6) / 3; ib = (q - 6) % 3; }
     else { pa = 1; pb = 1; int rem = q - 15; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
+    // v = La^T C0 Lb + Ma^T C1 Mb with  (tic, tic): La = N0[:, ia], Lb = N0[:, ib], Ma = Ri'[:, ia], Mb = Ri'[:, ib];
+    // (tic, tic2): Ma = Ri'[:, ia], Mb = -Rj'[:, ib];  (tic2, tic2): Ma = Rj'[:, ia], Mb = Rj'[:, ib]  (La = Lb = 0 in the last two)
+    const double f0 = (pa == 0 && pb == 0) ? 1.0 : 0.0, sb = (pa == 0 && pb == 1) ? -1.0 : 1.0;
     double sum = 0.0;
     for (int t = 0; t < km; ++t) {
       const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
       const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);
-      // left / right factors of the two terms: v = sum_cd La[c] C0[c][d] Lb[d] + Ma[c] C1[c][d] Mb[d]
-      double La[3], Lb[3], Ma[3], Mb[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double ria = Ri[3 * c + ia], rib = Ri[3 * c + ib], rja = Rj[3 * c + ia], rjb = Rj[3 * c + ib];
-        La[c] = (pa == 0 && pb == 0) ? ria - rja : 0.0;
-        Lb[c] = (pa == 0 && pb == 0) ? rib - rjb : 0.0;
-        Ma[c] = pa ? rja : ria;
-        Mb[c] = pb ? (pa ? rjb : -rjb) : rib;
-      }
+      const double *RA = pa ? Rj : Ri, *RB = pb ? Rj : Ri;
       double v = 0.0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < 3; ++c) {
+        // inner sums first: sum_d C[c][d] * right[d]
+        double i0 = 0.0, i1 = 0.0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const double c1 = C1B[16 * c + d], c0 = Gb[ac_tri(c, d)] - c1;
-          v += La[c] * c0 * Lb[d] + Ma[c] * c1 * Mb[d];
+          i0 += c0 * (Ri[3 * d + ib] - Rj[3 * d + ib]);
+          i1 += c1 * RB[3 * d + ib];
         }
+        v += f0 * (Ri[3 * c + ia] - Rj[3 * c + ia]) * i0 + sb * RA[3 * c + ia] * i1;
+      }
       sum += v;
     }
     rmw((pb ? CD_EX1 : CD_EX0) + ib, (pa ? CD_EX1 : CD_EX0) + ia, sum);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const bool active = ls.active;
   const int n = wv.n_lanes, L = wm.L, s = ls.s;
   const bool prof = !TPAR && (wave_id == wm.wave_off) && lane == 0;
-  long long c_proj = 0, c_gram = 0, c_t0 = clock64(), c_a = 0;
+  long long c_proj = 0, c_gram = 0, c_t0 = pclk64(), c_a = 0;
   const double *xg = (mode ? b.xc : b.x) + (size_t)wv.win * XSTRIDE;
   double *lm_g_out = lin_lm_g(b, st, mode);
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
@@ -254,7 +254,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
       // cam 0: left observation (TwoFrameOneCam); cam 1: right observation (TwoFrameTwoCam, or OneFrameTwoCam at t == 0)
       const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
       double *xr0 = &X[lane * XL], *xr1 = xr0 + XR;
-      c_a = clock64();
+      c_a = pclk64();
       if (produce) {
         double x0[XR], x1[XR], Jl[2], obc[5];
         double term[LM_NTERM], wjr[3];
@@ -330,7 +330,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         for (int c = 0; c < XR; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
       }
       lds_barrier();
-      { const long long c_b = clock64(); c_proj += c_b - c_a; c_a = c_b; }
+      { const long long c_b = pclk64(); c_proj += c_b - c_a; c_a = c_b; }
       // rows of padding / unobserved lanes are zero, and every segment spans a multiple of 8 lanes = 4 k-steps:
       // the operands of the next trip are in flight behind the 12 MFMAs of this one
 #pragma unroll
@@ -400,7 +400,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         }
       }
       lds_barrier();
-      c_gram += clock64() - c_a;
+      c_gram += pclk64() - c_a;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -440,12 +440,14 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     wbase[(size_t)79 * L + li] = 0.0;
     b.lm_E[ls.gi] = E;
     lm_g_out[ls.gi] = gl;
+    // (solve passes: the coupling rows of constant blocks are written as zeros, so the solvers need no masks in their Schur loops)
+    const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX), td_on = mode == 0 || !(wm.const_mask & CONST_TD);
     for (int c = 0; c < 6; ++c) {
       wbase[(size_t)(6 * s + c) * L + li] = wc_s[c];
-      wbase[(size_t)(CD_EX0 + c) * L + li] = wc_e0[c];
-      wbase[(size_t)(CD_EX1 + c) * L + li] = wc_e1[c];
+      wbase[(size_t)(CD_EX0 + c) * L + li] = ex_on ? wc_e0[c] : 0.0;
+      wbase[(size_t)(CD_EX1 + c) * L + li] = ex_on ? wc_e1[c] : 0.0;
     }
-    wbase[(size_t)CD_TD * L + li] = wc_td;
+    wbase[(size_t)CD_TD * L + li] = td_on ? wc_td : 0.0;
   }
   // robust cost of the evaluated point: per packed wave (walking form: slot 0 of the wave's frame slots, the rest zero) or per (packed
   // wave, frame); k_accept adds the slots of a window in a fixed order
@@ -455,7 +457,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     if (TPAR) { if (lane == 0) cost_out[blockIdx.y] = csum; }
     else if (lane < VILO_MAX_FRAMES) cost_out[lane] = (lane == 0) ? csum : 0.0;
   }
-  if (prof) { st.phase_clk[28] = clock64() - c_t0; st.phase_clk[29] = c_proj; st.phase_clk[30] = c_gram; st.phase_clk[31] = wv.n_lanes; st.phase_clk[32] = wv.kmax; }
+  PCLK(if (prof) { st.phase_clk[28] = clock64() - c_t0; st.phase_clk[29] = c_proj; st.phase_clk[30] = c_gram; st.phase_clk[31] = wv.n_lanes; st.phase_clk[32] = wv.kmax; });
 }
 
 __global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, false>(b, sq, huber_a, mode); }
@@ -488,12 +490,13 @@ __global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) {
   const int L = wm.L, li = ls.li, s = ls.s;
   b.lm_E[ls.gi] = acc[0];
   lin_lm_g(b, st, mode)[ls.gi] = acc[1];
+  const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX), td_on = mode == 0 || !(wm.const_mask & CONST_TD);
   for (int c = 0; c < 6; ++c) {
     wbase[(size_t)(6 * s + c) * L + li] = acc[2 + c];
-    wbase[(size_t)(CD_EX0 + c) * L + li] = acc[8 + c];
-    wbase[(size_t)(CD_EX1 + c) * L + li] = acc[14 + c];
+    wbase[(size_t)(CD_EX0 + c) * L + li] = ex_on ? acc[8 + c] : 0.0;
+    wbase[(size_t)(CD_EX1 + c) * L + li] = ex_on ? acc[14 + c] : 0.0;
   }
-  wbase[(size_t)CD_TD * L + li] = acc[20];
+  wbase[(size_t)CD_TD * L + li] = td_on ? acc[20] : 0.0;
 }
 
 // First part of the TPAR form: what the walking form does before its frame loop — the coupling rows of the landmarks of every window
@@ -732,7 +735,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
       continue;
     }
     const bool prof = (f % 10 == 0 && lane == 0);
-    const long long c0 = clock64();
+    const long long c0 = pclk64();
     const double *U = b.prep[f].sqrt_info;
     // sqrt_info operands straight from global memory: 12 A values per lane
     double av[2][8];
@@ -743,7 +746,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
         const int row = 16 * I + lr, q = 4 * kk + lk;
         av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
       }
-    const long long c1 = clock64();
+    const long long c1 = pclk64();
     double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
     lds_fence();   // (the previous factor's Gram pass has read Jw)
 #pragma unroll
@@ -762,7 +765,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
       }
     }
     lds_fence();
-    const long long c2 = clock64();
+    const long long c2 = pclk64();
 #pragma unroll
     for (int I = 0; I < 3; ++I) {
 #pragma unroll
@@ -782,7 +785,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
         }
       }
     }
-    if (prof) { const long long c3 = clock64(); st.phase_clk[33] = c1 - c0; st.phase_clk[34] = c2 - c1; st.phase_clk[35] = c3 - c2; }
+    PCLK(if (prof) { const long long c3 = clock64(); st.phase_clk[33] = c1 - c0; st.phase_clk[34] = c2 - c1; st.phase_clk[35] = c3 - c2; });
   }
 }
 

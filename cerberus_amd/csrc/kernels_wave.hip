@@ -43,6 +43,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   __shared__ double gl[CD_N], hd[CD_N], vS[CD_N], red[12];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
+  __shared__ unsigned char act[CD_N];   // cd_active per camera dimension (the predicate has two integer divisions: looked up, not recomputed per entry)
   const int win = blockIdx.x, tid = threadIdx.x;
   const SolverState &st = b.st[win];
   if (st.done || !st.need_lin) return;
@@ -54,12 +55,25 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   double *bimg = b.Bimg + (size_t)win * BI_N;
 
   // ---- the pose system starts from the prior's pre-assembled image (zeros without a prior) ----
-  for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
-    const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
-    const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc;
-    if (row >= col) Cl[cl_pos(row, col)] = pd[PD_C + row * PD_CLD + col];
+  PCLK(if (tid == 0) b.st[win].phase_clk[36] = clock64());
+  {
+    // (all 13 loads of a thread in flight before the first LDS store)
+    double pv[13];
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int e = min(tid + ASM_THREADS * u, CL_N - 1);
+      int row = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (((row + 1) * (row + 2)) / 2 <= e) ++row;
+      while ((row * (row + 1)) / 2 > e) --row;
+      pv[u] = pd[PD_C + row * PD_CLD + (e - (row * (row + 1)) / 2)];
+    }
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < CL_N) Cl[e] = pv[u];
+    }
   }
-  for (int e = tid; e < CD_N; e += ASM_THREADS) inv_pmap[e] = -1;
+  for (int e = tid; e < CD_N; e += ASM_THREADS) { inv_pmap[e] = -1; act[e] = cd_active(e, F, cmask) ? 1 : 0; }
   if (COMPACT) {
     if (tid < 11) {
       const m3 R = qR(ldq_pose(b.x + (size_t)win * XSTRIDE + XO_POSE + 7 * tid));   // (the accepted state = the point the slots were linearised at)
@@ -82,6 +96,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     gl[e] = (pn > 0 && pi >= 0) ? b.prior_b0[(size_t)win * 96 + pi] + b.prior_hd[(size_t)win * 96 + pi] : 0.0;
   }
   __syncthreads();
+  PCLK(if (tid == 0) b.st[win].phase_clk[37] = clock64());
 
   // ---- plain (non-atomic) read-modify-write scatter: every target has exactly one owner thread. Two packed Gram entries can hit the
   //      same target only if they are "twins" (the same local pair taken once in the pose_s block and once in the pose_j block; for IMU
@@ -174,6 +189,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     }
   }
   __syncthreads();   // the IMU owners below are different threads
+  PCLK(if (tid == 0) b.st[win].phase_clk[38] = clock64());
   {
     // IMU factor Grams, pose part: I1 pose_i x pose_i (21, twin +19), I3 pose gradient (6, twin +19), I4 pose_i x pose_j (36)
     int a = 0, bc = 0, cls = 0;
@@ -195,20 +211,15 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     }
   }
   __syncthreads();
+  PCLK(if (tid == 0) b.st[win].phase_clk[39] = clock64());
   // ---- constant blocks / absent frames / padding as identity rows and columns; diagonal and gradient of all 224 camera dimensions ----
-  for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
-    const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
-    const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc, li = cl_pos(max(row, col), min(row, col));
-    if (row < col) continue;   // (the upper half of a diagonal tile: the same entries)
-    double v = Cl[li];
-    if (!cd_active(row, F, cmask) || !cd_active(col, F, cmask)) { v = (row == col) ? 1.0 : 0.0; Cl[li] = v; }
-    if (row == col) hd[row] = v;
-  }
+  // (rows / columns of inactive dimensions become identity rows when the image is written out below)
   for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
     double g = gl[cd];
+    if (cd < CD_B0) hd[cd] = act[cd] ? Cl[cl_pos(cd, cd)] : 1.0;
     if (cd >= CD_B0) {
       double h = 1.0;
-      if (cd < CD_B0 + 143 && cd_active(cd, F, cmask)) {
+      if (cd < CD_B0 + 143 && act[cd]) {
         const int k = (cd - CD_B0) / 13, i = (cd - CD_B0) - 13 * k;
         h = (k == kb) ? pd[PD_AD + k * 169 + i * 14] : 0.0;
         if (k < F - 1) { h += igram[k * 780 + tri39(6 + i, 6 + i)]; g += igram[k * 780 + tri39(6 + i, 38)]; }
@@ -216,18 +227,19 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       }
       hd[cd] = h;
     }
-    if (!cd_active(cd, F, cmask)) g = 0.0;
+    if (!act[cd]) g = 0.0;
     gl[cd] = g;
     b.cam_gin[(size_t)win * CD_N + cd] = g;
   }
   __syncthreads();
+  PCLK(if (tid == 0) b.st[win].phase_clk[40] = clock64());
   // ---- Jacobi scaling 1 / (1 + sqrt(H_ii)) frozen at the first linearisation, dogleg diagonal clamp(diag, 1e-6, 1e32) in the scaled
   //      space, v = D^-2 g (Ceres 1.14 TrustRegionMinimizer / DoglegStrategy) ----
   double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
   for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
     double d = 1.0, ve = 0.0;
     const double ge = gl[cd];
-    if (cd_active(cd, F, cmask)) {
+    if (act[cd]) {
       double sc;
       double *cs = b.cam_scale + (size_t)win * CD_N + cd;
       if (!st.scale_ready) { sc = jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[cd])) : 1.0; *cs = sc; }
@@ -243,16 +255,18 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     part_gmax = fmax(part_gmax, fabs(ge));
   }
   __syncthreads();
+  PCLK(if (tid == 0) b.st[win].phase_clk[41] = clock64());
   // ---- pose system out in accumulator order; q = v^T H v of the camera-side rows is summed while the blocks pass through registers ----
   for (int idx = tid; idx < CIMG_N; idx += ASM_THREADS) {
     const int t = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
     const int row = 16 * c_tI[t] + rr, col = 16 * c_tJ[t] + cc;
-    const double v = Cl[cl_pos(max(row, col), min(row, col))];
+    const double v = (act[row] && act[col]) ? Cl[cl_pos(max(row, col), min(row, col))] : (row == col ? 1.0 : 0.0);
     b.Cimg[(size_t)win * CIMG_N + idx] = v;
     part_q += ((c_tI[t] == c_tJ[t]) ? 1.0 : 2.0) * vS[row] * v * vS[col];   // (a diagonal tile holds both triangles)
   }
   // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams. The loads of all trips of a block
   //      kind are issued before the first store (values in registers): one memory round trip per kind instead of one per trip ----
+  PCLK(if (tid == 0) b.st[win].phase_clk[42] = clock64());
   {
     double val[8];
 #pragma unroll
@@ -260,7 +274,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       const int e = min(tid + ASM_THREADS * u, 11 * 169 - 1);
       const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
       double v;
-      if (!cd_active(CD_B0 + 13 * k + i, F, cmask) || !cd_active(CD_B0 + 13 * k + j, F, cmask)) {
+      if (!act[CD_B0 + 13 * k + i] || !act[CD_B0 + 13 * k + j]) {
         v = (i == j) ? 1.0 : 0.0;
       } else {
         v = (k == kb) ? pd[PD_AD + e] : 0.0;
@@ -279,6 +293,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       }
     }
   }
+  PCLK(if (tid == 0) b.st[win].phase_clk[43] = clock64());
   {
     double val[7];
 #pragma unroll
@@ -286,7 +301,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       const int e = min(tid + ASM_THREADS * u, 10 * 169 - 1);
       const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
       double v = 0.0;
-      if (k < F - 1 && cd_active(CD_B0 + 13 * (k + 1) + i, F, cmask) && cd_active(CD_B0 + 13 * k + j, F, cmask)) v = igram[k * 780 + tri39(6 + j, 25 + i)];
+      if (k < F - 1 && act[CD_B0 + 13 * (k + 1) + i] && act[CD_B0 + 13 * k + j]) v = igram[k * 780 + tri39(6 + j, 25 + i)];
       val[u] = v;
     }
 #pragma unroll
@@ -299,6 +314,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       }
     }
   }
+  PCLK(if (tid == 0) b.st[win].phase_clk[44] = clock64());
   {
     double val[13];
 #pragma unroll
@@ -306,7 +322,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       const int e = min(tid + ASM_THREADS * u, 11 * 288 - 1);
       const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, df = sx / 6, c = sx - 6 * df, f = k - 1 + df;
       double v = 0.0;
-      if (i < 13 && f >= 0 && f < F && cd_active(CD_B0 + 13 * k + i, F, cmask)) {
+      if (i < 13 && f >= 0 && f < F && act[CD_B0 + 13 * k + i]) {
         if (df == 1) {
           if (k < F - 1) v += igram[k * 780 + tri39(c, 6 + i)];
           if (k >= 1) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
@@ -333,7 +349,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     const int e = tid + ASM_THREADS * u;
     const int i = e / 80, p = e - 80 * i;
     double v = 0.0;
-    if (kb >= 0 && i < 13 && p < VILO_NPU && cd_active(CD_B0 + 13 * kb + i, F, cmask) && cd_active(p, F, cmask)) {
+    if (kb >= 0 && i < 13 && p < VILO_NPU && act[CD_B0 + 13 * kb + i] && act[p]) {
       v = pd[PD_BP + e];
       part_q += 2.0 * vS[CD_B0 + 13 * kb + i] * v * vS[p];
     }
@@ -343,6 +359,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   part_q = wave_sum(part_q); part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax);
   if ((tid & 63) == 0) { red[tid >> 6] = part_q; red[4 + (tid >> 6)] = part_gn; red[8 + (tid >> 6)] = part_gmax; }
   __syncthreads();
+  PCLK(if (tid == 0) b.st[win].phase_clk[45] = clock64());
   if (tid == 0) {
     bimg[BI_SCAL + 0] = ((red[0] + red[1]) + red[2]) + red[3];
     bimg[BI_SCAL + 1] = ((red[4] + red[5]) + red[6]) + red[7];
@@ -408,7 +425,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
   double gBr[3], dBr[3], yBr[3];
 
   if (st.need_lin) {
-    if (lane == 0) st.phase_clk[0] = clock64();
+    PCLK(if (lane == 0) st.phase_clk[0] = clock64());
     const double *Cimg = b.Cimg + (size_t)win * CIMG_N;
     const double *gin = b.cam_gin + (size_t)win * CD_N;
     const double *bimg = b.Bimg + (size_t)win * BI_N;
@@ -462,7 +479,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       int fX[5], oX[5];
 #pragma unroll
       for (int X = 0; X < 5; ++X) { const int col = 16 * X + lr; fX[X] = col < 66 ? col / 6 : 99; oX[X] = col < 66 ? col - 6 * fX[X] : 0; }
-      if (lane == 0) st.phase_clk[1] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[1] = clock64());
       for (int l = lane; l < L; l += 64) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
       // ---- pose system: 15 lower tiles in accumulator order, one coalesced load per register ----
       mfma_d4 acc[15];
@@ -470,7 +487,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       for (int t = 0; t < 15; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = Cimg[(t * 4 + r) * 64 + lane];
-      if (lane == 0) st.phase_clk[2] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[2] = clock64());
 
       // ---- block-tridiagonal Cholesky chain of the speed / leg-bias part (13 x 13 blocks, frames F-1 .. 0):
       //        S_k = A_kk + mu D_k - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,  T_A(k) = M_k A_{k,k-1},
@@ -536,7 +553,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
             for (int j = 0; j < 13; ++j) a[j] = SN[row * 13 + j];
           }
-          if (k == 5 && lane == 0) st.phase_clk[16] = clock64();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[16] = clock64());
           {
             const double md = mu * DB[13 * k + row];
 #pragma unroll
@@ -554,7 +571,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 #pragma unroll
             for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
           }
-          if (k == 5 && lane == 0) st.phase_clk[17] = clock64();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[17] = clock64());
           // forward substitutions L x = rhs: T_A(k) columns (group 0), L^-1 columns (group 1); L broadcast from the owning lanes
           // (opaque copies: see chol16_tile)
 #pragma unroll
@@ -579,7 +596,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             }
           }
           lds_fence();
-          if (k == 5 && lane == 0) st.phase_clk[18] = clock64();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[18] = clock64());
           // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k): one 16 x 16 tile on the matrix cores (the operand serves as A and B)
           if (k > 0) {
             mfma_d4 sn = {0.0, 0.0, 0.0, 0.0};
@@ -603,7 +620,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             at[kk] = (in && k < F - 1) ? -ta : 0.0;
             am[kk] = in ? m : 0.0;
           }
-          if (k == 5 && lane == 0) st.phase_clk[19] = clock64();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[19] = clock64());
           if (k < F - 1) {
 #pragma unroll
             for (int X = 0; X < 5; ++X)
@@ -646,7 +663,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           for (int X = 0; X < 5; ++X)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) yr[X] += ((X == 4) ? T4[kk] : T[X][kk]) * tg[kk];
-          if (k == 5 && lane == 0) st.phase_clk[20] = clock64();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[20] = clock64());
           double *sw = TAcur; TAcur = TAprev; TAprev = sw;
           lds_fence();
         }
@@ -658,7 +675,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           if (lk == 0) v[16 * X + lr] = g[16 * X + lr] - yr[X];
         }
       }
-      if (lane == 0) st.phase_clk[3] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[3] = clock64());
 
       // ---- Schur complement of the landmarks on the FP64 matrix cores: C -= sum_l w_l w_l^T / (E_l + mu dhat_l^2). One k-step = 4
       //      landmarks; the operand of tile row X (lane: w[16 X + lr][4 kk + lk]) serves as A of tiles (X, .) and as B of tiles (., X):
@@ -751,7 +768,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
             if (lk + 4 * r == lr) acc[tile_index(I, I)][r] += mu * dh2[16 * I + lr];
       }
       lds_fence();
-      if (lane == 0) st.phase_clk[4] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[4] = clock64());
 
       // ---- dense Cholesky of the 80 x 80 reduced pose system, blocked by 16: diagonal tile in registers + v_readlane (also its
       //      inverse), panel L_Ij = A_Ij L_jj^-T and trailing update A_IJ -= L_Ij L_Jj^T on the FP64 matrix cores. The reduced right-hand
@@ -842,7 +859,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         lds_fence();
         continue;
       }
-      if (lane == 0) st.phase_clk[5] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[5] = clock64());
 
       // ---- L^T yP = y (the forward solve rode along with the factorisation) ----
       {
@@ -875,7 +892,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
       }
       lds_fence();
-      if (lane == 0) st.phase_clk[6] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[6] = clock64());
 
       // ---- back-substitution of the speed / leg-bias part: c = g_B - B yP, then the two block-bidiagonal sweeps
       //        u_k = M_k (c_k - T_A(k+1)^T u_{k+1})   k = F-1 .. 0,      y_k = M_k^T (u_k - T_A(k) y_{k-1})   k = 0 .. F-1 ----
@@ -890,7 +907,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       double *lm_y = b.lm_y + lmoff_b;
       {
         double *U = scr + WX_U, *YB = scr + WX_YB;
-        if (lane == 0) st.phase_clk[21] = clock64();
+        PCLK(if (lane == 0) st.phase_clk[21] = clock64());
         // c: the IMU part of B_k spans poses k-1 .. k+1 (one dimension per lane and trip), the prior part frame kb only
         {
           double bsv[3][18];
@@ -923,7 +940,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
         }
         lds_fence();
         const int row = lr < 13 ? lr : 0;
-        if (lane == 0) st.phase_clk[22] = clock64();
+        PCLK(if (lane == 0) st.phase_clk[22] = clock64());
         // M_k / T_A(k) of the chain (written to global memory by this wave, L2-resident) come back one frame at a time: the next
         // frame's 2 x 169 values are in flight while this frame's are used out of LDS
         double *MB = lds + WB_M, *TB = lds + WB_TA;
@@ -960,7 +977,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           unext = u;
         }
         lds_fence();
-        if (lane == 0) st.phase_clk[23] = clock64();
+        PCLK(if (lane == 0) st.phase_clk[23] = clock64());
         // backward sweep (pm holds M_0; T_A(0) does not exist)
         double yprev = 0.0;
         for (int k = 0; k < F; ++k) {
@@ -994,7 +1011,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
           part_gy += gBr[m] * yBr[m];
         }
       }
-      if (lane == 0) st.phase_clk[7] = clock64();
+      PCLK(if (lane == 0) st.phase_clk[7] = clock64());
       // ---- landmarks: y_l = (g_l - w_l^T yP) / (E_l + mu dhat_l^2), all 80 coupling entries of a landmark in flight at once ----
       for (int l = lane; l < L; l += 64) {
         double wcol[80];
@@ -1047,7 +1064,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
       st.alpha = gnorm2 / qq;
       st.scale_ready = 1;
       st.lin_fail = 0;
-      st.phase_clk[8] = clock64();
+      PCLK(st.phase_clk[8] = clock64());
     }
   } else {
     const double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
@@ -1099,18 +1116,29 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
     if (c < 9) xc[XO_SB + 9 * k + c] = x[XO_SB + 9 * k + c] + del[CD_B0 + e];
     else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
   }
-  if (lane == 0) st.phase_clk[9] = clock64();
+  PCLK(if (lane == 0) st.phase_clk[9] = clock64());
 }
 
 // =================================================================================================
 // launch
 // =================================================================================================
+int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw.hip
+// Which solver: the two-wave form while the batch leaves SIMDs idle (two windows per CU: 512 on the 256 CUs of an MI355X), the single-wave
+// form beyond. VILO_SOLVER=wave / mw overrides (tests run both forms against the oracle).
+static bool vilo_use_mw_solver(const BatchDev &b) {
+  static const int forced = [] { const char *e = getenv("VILO_SOLVER"); return !e ? 0 : (!strcmp(e, "mw") ? 2 : (!strcmp(e, "wave") ? 1 : 0)); }();
+  static const int max_w = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+  if (forced) return forced == 2;
+  return b.W <= max_w;
+}
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
     if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
     else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
+  } else if (vilo_use_mw_solver(b)) {
+    return vilo_launch_mw_solver(ctx, b, sp, s);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -5,6 +5,17 @@
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
+// Shader-clock phase stamps (SolverState::phase_clk, read by tools/phase_clocks_wave.py) exist in a profiling build only
+// (hipcc -DVILO_PHASE_CLOCKS: `VILO_BUILD_PROF=1 python __graft_entry__.py` -> lib/libvilo_gpu_prof.so, loaded through VILO_GPU_LIB);
+// the production kernels carry none.
+#ifdef VILO_PHASE_CLOCKS
+#define PCLK(...) do { __VA_ARGS__; } while (0)
+#define pclk64() clock64()
+#else
+#define PCLK(...) do { } while (0)
+#define pclk64() 0LL
+#endif
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but leaves global loads in flight
 // (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

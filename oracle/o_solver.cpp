@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <limits>
+#include <thread>
 
 #include "o_linalg.h"
 #include "vilo_oracle.h"
@@ -756,6 +757,8 @@ extern "C" void orc_gauge_fix(const orc_state *before, orc_state *after, int F) 
 // dropped blocks first (ascending id), then kept blocks (ascending id); only J0^T J0 and J0^T r0 are
 // ordering-invariant (SURVEY §8a parity note 12).
 // ---------------------------------------------------------------------------------------------
+static int g_marg_threads = 1;
+
 extern "C" int orc_marginalize(const orc_config *cfg, const orc_window *w, const orc_state *s, int mode, orc_prior *out,
                                double *A_out, double *b_out, int *m_out) {
   Problem P;
@@ -825,10 +828,14 @@ extern "C" int orc_marginalize(const orc_config *cfg, const orc_window *w, const
   if (m_out) *m_out = m;
   if (m == 0) { out->valid = 0; return 1; }
 
-  // A = sum J^T J, b = sum J^T r (ThreadsConstructA, :150-181)
+  // A = sum J^T J, b = sum J^T r (ThreadsConstructA, :150-181). The reference splits the factors round-robin over NUM_THREADS = 4 pthreads
+  // (marginalization_factor.h:22, .cpp:246-275), each building its own A / b, and adds the four; orc_set_marginalize_threads(4) does the
+  // same here (default 1: one pass over the factors in order — what the parity tests use; the sums differ from the threaded ones by rounding).
   DMat A(pos, pos);
   std::vector<double> b(pos, 0.0);
-  for (const RBlock &f : factors)
+  auto build = [&](size_t f0, size_t stride, DMat &A, std::vector<double> &b) {
+  for (size_t fi = f0; fi < factors.size(); fi += stride) {
+    const RBlock &f = factors[fi];
     for (size_t k1 = 0; k1 < f.params.size(); ++k1) {
       const int i1 = pidx[f.params[k1]], l1 = P.params[f.params[k1]].lsize;
       for (size_t k2 = 0; k2 < f.params.size(); ++k2) {
@@ -846,6 +853,22 @@ extern "C" int orc_marginalize(const orc_config *cfg, const orc_window *w, const
         b[i1 + c1] += sacc;
       }
     }
+  }
+  };
+  if (g_marg_threads <= 1) {
+    build(0, 1, A, b);
+  } else {
+    const int nt = g_marg_threads;
+    std::vector<DMat> As(nt, DMat(pos, pos));
+    std::vector<std::vector<double>> bs(nt, std::vector<double>(pos, 0.0));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { build((size_t)t, (size_t)nt, As[t], bs[t]); });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nt; ++t) {
+      for (size_t e = 0; e < A.d.size(); ++e) A.d[e] += As[t].d[e];
+      for (int e = 0; e < pos; ++e) b[e] += bs[t][e];
+    }
+  }
   if (A_out) std::memcpy(A_out, A.d.data(), sizeof(double) * pos * pos);
   if (b_out) std::memcpy(b_out, b.data(), sizeof(double) * pos);
 
@@ -918,6 +941,8 @@ extern "C" int orc_marginalize(const orc_config *cfg, const orc_window *w, const
   out->valid = 1;
   return 0;
 }
+
+extern "C" void orc_set_marginalize_threads(int n) { g_marg_threads = n < 1 ? 1 : n; }
 
 extern "C" void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets) {
   g_rp_samples = samples;

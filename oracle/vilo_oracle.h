@@ -196,6 +196,8 @@ void orc_default_opts(orc_solve_opts *o);
  * solved / marginalised next first integrates its interval again (repropagate, imu_leg_integration_base.cpp:62-86) at the biases
  * of the evaluation point. offsets[i]..offsets[i+1] are interval i's samples, the first being the constructor sample. Not thread safe. */
 void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets);
+/* Hessian build of orc_marginalize on n threads (the reference: NUM_THREADS = 4 pthreads, marginalization_factor.h:22, .cpp:246-275); default 1. */
+void orc_set_marginalize_threads(int n);
 
 /* Cost 1/2 sum rho(|r|^2) at state, and optionally gradient/Hessian pieces in the reduced (camera)
  * ordering used by tests: local layout [frame k: pose6 sb9 lb4]*n_frames, ex0 6, ex1 6, td 1, then landmarks. */

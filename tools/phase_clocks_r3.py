@@ -1,0 +1,34 @@
+"""Shader-clock phase breakdown (profiling build: VILO_BUILD_PROF=1 python __graft_entry__.py, then
+VILO_GPU_LIB=cerberus_amd/lib/libvilo_gpu_prof.so python tools/phase_clocks_r3.py [windows ...]) of k_assemble(_c) and of the solver the
+batch size selects (k_solve_mw up to 512 windows, k_solve_wave beyond)."""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from cerberus_amd import api, synth  # noqa: E402
+
+cfg = synth.default_config()
+ctx = api.Context(cfg, 0)
+for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
+    ws = [synth.make_window(cfg, n_landmarks=200, seed=20260925 + i) for i in range(W)]
+    ctx.preintegrate_windows(ws)
+    b = api.Batch(ctx, ws)
+    b.solve(api.default_solve_opts(True, 3))
+    sample = list(range(0, W, max(1, W // 32)))
+    C = np.stack([b.fetch(12, w).view(np.int64).astype(np.float64) for w in sample])
+    m = C.mean(axis=0)
+    print("== %d windows (mean of %d sampled windows, cycles)" % (W, len(sample)))
+    d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
+    print("k_assemble: prior image %d | visual slots %d | IMU pose blocks %d | masks + diagonal %d | scaling %d | tile image out + q %d | A_kk %d | A_k+1,k %d | coupling + prior rows + sums %d | total %d"
+          % (*d, d.sum()))
+    if W <= 512:
+        print("k_solve_mw wave B: scaling %d | 1/(E + mu d) %d | Schur + rank updates (steps) %d | rhs + Cholesky %d | backward solve %d | wait for barrier %d | landmark back-substitution %d | norms + barrier %d | dogleg + candidate %d | total %d"
+              % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[9] - m[0]))
+        print("k_solve_mw wave A: chain %d (from kernel start %d) | idle until y_P %d | c = g_B - B y_P %d | forward sweep %d | backward sweep %d"
+              % (m[17] - m[16], m[16] - m[0], m[18] - m[17], m[19] - m[18], m[20] - m[19], m[21] - m[20]))
+    else:
+        names = ["gathers", "tile load + 1/(E + mu d)", "chain", "landmark Schur", "Cholesky 80", "backward solve", "bias back-substitution", "landmark back-substitution", "dogleg + candidate"]
+        d = np.diff(C[:, 0:10], axis=1).mean(axis=0)
+        print("k_solve_wave: " + " | ".join("%s %d" % (n, v) for n, v in zip(names, d)) + " | total %d" % d.sum())
+    b.close()

@@ -1,5 +1,5 @@
 """Copy the summaries of tools/profile_gpu.sh / tools/profile_sq.sh (run on the GPU box, merged back under gpurun_out/) into
-profiles/round2_* — the files bench.py's roofline block and DESIGN.md cite.
+profiles/round3_* — the files bench.py's roofline block and DESIGN.md cite.
 Usage: python tools/refresh_profiles.py <prof_tag> <sq_tag> [bench.json] [bench_config3.json]
        python tools/refresh_profiles.py --config3 <prof_tag>     (PROFILE_ARGS="--config 3 --windows 1024" bash tools/profile_gpu.sh <prof_tag>)"""
 import json
@@ -8,16 +8,30 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import subprocess  # noqa: E402
+
+from bench import PROFILE_ROUND as RND, kernels_sha16  # noqa: E402
+
+
+def _commit():
+    try:
+        return subprocess.check_output(["git", "-C", R, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        return None
 
 
 def trace_and_pmc(tag, suffix, windows, what):
     lines = open(os.path.join(R, "gpurun_out", "prof_" + tag, "summary.txt")).read().rstrip("\n").split("\n")
     js = json.loads(lines[-1])
     js["windows_per_dispatch"] = windows
+    # which kernels the counters belong to: bench.py compares this fingerprint with the tree it runs from (roofline.traffic_source.stale)
+    js["kernels_sha16"] = kernels_sha16()
+    js["commit"] = _commit()
     js["note"] = ("rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (bench.py --steps 2 --warmup 1 %s), "
-                  "calibrated on k_calib_copy; end of round 2" % what)
-    open(os.path.join(R, "profiles", "round2_rocprof_summary%s.txt" % suffix), "w").write("\n".join(lines[:-1]) + "\n")
-    json.dump(js, open(os.path.join(R, "profiles", "round2_pmc%s.json" % suffix), "w"))
+                  "calibrated on k_calib_copy; round 3" % what)
+    open(os.path.join(R, "profiles", "%s_rocprof_summary%s.txt" % (RND, suffix)), "w").write("\n".join(lines[:-1]) + "\n")
+    json.dump(js, open(os.path.join(R, "profiles", "%s_pmc%s.json" % (RND, suffix)), "w"))
     return js
 
 
@@ -31,14 +45,14 @@ prof, sq = sys.argv[1], sys.argv[2]
 js = trace_and_pmc(prof, "", 4096, "--windows 4096")
 lines = open(os.path.join(R, "gpurun_out", "prof_" + sq, "summary.txt")).read().rstrip("\n").split("\n")
 res = json.loads(lines[-1])
-open(os.path.join(R, "profiles", "round2_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
+open(os.path.join(R, "profiles", RND + "_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
 json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py --steps 1 --warmup 1 --windows 4096): per-dispatch means summed over the "
-                   "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; end of round 2",
-           "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", "round2_mfma.json"), "w"))
+                   "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; round 3", "kernels_sha16": kernels_sha16(), "commit": _commit(),
+           "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", RND + "_mfma.json"), "w"))
 if len(sys.argv) > 3:
-    shutil.copy(sys.argv[3], os.path.join(R, "profiles", "round2_bench_v2_final.json"))
+    shutil.copy(sys.argv[3], os.path.join(R, "profiles", RND + "_bench_final.json"))
 if len(sys.argv) > 4:
-    shutil.copy(sys.argv[4], os.path.join(R, "profiles", "round2_bench_config3.json"))
+    shutil.copy(sys.argv[4], os.path.join(R, "profiles", RND + "_bench_config3.json"))
 it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")
 tot = 0.0
 for k in it:
