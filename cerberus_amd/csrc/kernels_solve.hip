@@ -12,6 +12,7 @@
 // The candidate of iteration i is evaluated AND linearised by one pass (every accepted candidate is the next linearisation point; a
 // rejected one costs a wasted linearisation, which is rare): observations and preintegration records are read once per iteration.
 // k_visual_cost / k_imu_cost are the cost-only forms for the last candidate of a solve.
+#include <type_traits>
 #include "solve_common.hpp"
 #include "visual_lin.hpp"
 
@@ -269,18 +270,18 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             if (t > 0) rho0 = vis_two_frame_c<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
             else rho0 = vis_one_frame_c(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
           }
-          term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
-          term[1] = Jl[0] * x0[GK_R] + Jl[1] * x1[GK_R];
+          term[0] = dot2(Jl[0], Jl[0], Jl[1], Jl[1]);
+          term[1] = dot2(Jl[0], x0[GK_R], Jl[1], x1[GK_R]);
           const double pw = (t > 0) ? 1.0 : 0.0;   // the one-frame factor has no pose blocks (its B columns carry the tic column)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            term[2 + c] = pw * (x0[GK_B + c] * Jl[0] + x1[GK_B + c] * Jl[1]);
-            term[5 + c] = x0[GK_RI + c] * Jl[0] + x1[GK_RI + c] * Jl[1];
-            term[8 + c] = tc[0][c] * Jl[0] + tc[1][c] * Jl[1];
-            term[11 + c] = x0[GK_C0 + c] * Jl[0] + x1[GK_C0 + c] * Jl[1];
-            term[14 + c] = tc[2][c] * Jl[0] + tc[3][c] * Jl[1];
-            term[17 + c] = x0[GK_C1 + c] * Jl[0] + x1[GK_C1 + c] * Jl[1];
-            wjr[c] = x0[GK_RJ + c] * Jl[0] + x1[GK_RJ + c] * Jl[1];
+            term[2 + c] = pw * (dot2(x0[GK_B + c], Jl[0], x1[GK_B + c], Jl[1]));
+            term[5 + c] = dot2(x0[GK_RI + c], Jl[0], x1[GK_RI + c], Jl[1]);
+            term[8 + c] = dot2(tc[0][c], Jl[0], tc[1][c], Jl[1]);
+            term[11 + c] = dot2(x0[GK_C0 + c], Jl[0], x1[GK_C0 + c], Jl[1]);
+            term[14 + c] = dot2(tc[2][c], Jl[0], tc[3][c], Jl[1]);
+            term[17 + c] = dot2(x0[GK_C1 + c], Jl[0], x1[GK_C1 + c], Jl[1]);
+            wjr[c] = dot2(x0[GK_RJ + c], Jl[0], x1[GK_RJ + c], Jl[1]);
           }
           term[20] = 0.0;   // td is a constant block in this mode
         } else {
@@ -294,17 +295,17 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
             else rho0 = vis_one_frame(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl);
           }
           // landmark-side reductions (the e-block of Ceres' Schur eliminator): the same 21 terms in both forms
-          term[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
-          term[1] = Jl[0] * x0[GC_R] + Jl[1] * x1[GC_R];
+          term[0] = dot2(Jl[0], Jl[0], Jl[1], Jl[1]);
+          term[1] = dot2(Jl[0], x0[GC_R], Jl[1], x1[GC_R]);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
-            term[2 + c] = x0[c] * Jl[0] + x1[c] * Jl[1];
-            term[8 + c] = x0[GC_E0 + c] * Jl[0] + x1[GC_E0 + c] * Jl[1];
-            term[14 + c] = x0[GC_E1 + c] * Jl[0] + x1[GC_E1 + c] * Jl[1];
+            term[2 + c] = dot2(x0[c], Jl[0], x1[c], Jl[1]);
+            term[8 + c] = dot2(x0[GC_E0 + c], Jl[0], x1[GC_E0 + c], Jl[1]);
+            term[14 + c] = dot2(x0[GC_E1 + c], Jl[0], x1[GC_E1 + c], Jl[1]);
           }
 #pragma unroll
-          for (int c = 0; c < 3; ++c) wjr[c] = x0[GC_RJ + c] * Jl[0] + x1[GC_RJ + c] * Jl[1];
-          term[20] = x0[GC_TD] * Jl[0] + x1[GC_TD] * Jl[1];
+          for (int c = 0; c < 3; ++c) wjr[c] = dot2(x0[GC_RJ + c], Jl[0], x1[GC_RJ + c], Jl[1]);
+          term[20] = dot2(x0[GC_TD], Jl[0], x1[GC_TD], Jl[1]);
         }
         cost += rho0;
 #pragma unroll
@@ -466,6 +467,274 @@ __global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double
 __global__ void __launch_bounds__(64) k_visual_linearize_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, true>(b, sq, huber_a, mode); }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_tpar_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true, true>(b, sq, huber_a, mode); }
 
+// =================================================================================================
+// k_visual_linearize_pc: the compact walking form as a PRODUCER / CONSUMER pair of waves
+// =================================================================================================
+// One workgroup of two waves per packed wave. The single-wave form alternates two phases that use different parts of the SIMD and wait
+// for each other: evaluating the factors of a (frame, camera) step into LDS rows (FP64 VALU + table reads, latency-bound: ~3.8 k
+// cycles per step for ~1.2 k cycles of issue) and their Gram on the matrix cores (~2.8 k). Here wave P evaluates step n + 1 into one
+// half of a double-buffered row image while wave C runs the MFMA pass of step n out of the other half, one s_barrier per step:
+//     P: eval(0) | eval(1)  | eval(2)  | ...          C:         | mfma(0)  | mfma(1)  | ...
+// P keeps what the landmark side needs (sums, coupling rows, cost) and no accumulators, C keeps the eight Gram tiles and nothing else:
+// both roles fit 256 registers, so the two waves of a workgroup share the chip with the two of another (eight waves per CU as
+// before, but every packed wave advances at the pace of its slower role instead of the sum of both). Same arithmetic per factor and
+// per Gram tile as k_visual_linearize_c: bitwise the same slots, landmark sums and coupling rows.
+#define PC_XN (64 * XLANEC)   // rows of one buffer: 64 lanes x (2 rows x 16 + 2 pad); a trip past the last lane is clamped, not padded
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double X[2 * PC_XN];
+  __shared__ __attribute__((aligned(16))) double xs[XSTRIDE];
+  __shared__ __attribute__((aligned(16))) double wt[VW_N];
+  __shared__ __attribute__((aligned(16))) double tab[4 * VT_N];   // the pair tables of ONE frame (four segments)
+  const int wave_id = b.wave_order[blockIdx.x];
+  const WaveMeta wv = b.wave[wave_id];
+  SolverState &st = b.st[wv.win];
+  if (lin_skip(st, mode)) return;
+  const WinMeta wm = b.win[wv.win];
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: producer, 1: consumer
+  const int lane = threadIdx.x & 63;
+  int cs[4], cn[4], ckm[4], cgo[4];
+  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
+  const int kmax = wv.kmax;
+  auto step_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  if (role == 1) {
+    // ------------------------------------------ consumer: Gram tiles of every (segment, frame) slot ------------------------------------------
+    const int lr = lane & 15, lk = lane >> 4;
+    const int xoff = (lk >> 1) * XLANEC + (lk & 1) * XROWC + lr;
+    mfma_d4 G0[4], G1[4];   // left / right camera tile of the frame in progress, per segment
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { G0[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G1[g] = G0[g]; }
+    // one (frame, camera) step: the MFMA pass over every live segment's rows (CAM is a compile-time constant: the tiles stay in registers)
+    auto pass = [&](int t, auto cam_c) {
+      constexpr int CAM = decltype(cam_c)::value;
+      const int nstep = (t == 0) ? 0 : 2 * t - 1 + CAM;
+      const double *Xb = X + (nstep & 1) * PC_XN;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g >= wv.nseg || t >= ckm[g]) continue;
+        const int k0 = wv.seg_lane0[g] >> 1, k1 = k0 + (((cn[g] + 7) & ~7) >> 1);
+        mfma_d4 G = CAM ? G1[g] : G0[g];
+        double a0[4], n0[4];
+        auto ldtrip0 = [&](int kk, double *p0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p0[u] = Xb[2 * (kk + u) * XLANEC + xoff];
+        };
+        auto dotrip0 = [&](const double *p0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) G = __builtin_amdgcn_mfma_f64_16x16x4f64(p0[u], p0[u], G, 0, 0, 0);
+        };
+        // two trips per turn, the operands of the next trip in flight behind the MFMAs of this one (a trip past the segment's last
+        // one is loaded from rows that exist — clamped to the last trip of the image — and dropped)
+        ldtrip0(k0, a0);
+        for (int kk0 = k0; kk0 < k1; kk0 += 8) {
+          ldtrip0(min(kk0 + 4, 28), n0);
+          __builtin_amdgcn_sched_barrier(0);
+          dotrip0(a0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk0 + 4 < k1) {
+            ldtrip0(min(kk0 + 8, 28), a0);
+            __builtin_amdgcn_sched_barrier(0);
+            dotrip0(n0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (CAM) G1[g] = G; else G0[g] = G;
+      }
+    };
+    step_barrier();   // step 0's rows are there
+    for (int t = 0; t < kmax; ++t) {
+      if (t > 0) {
+        pass(t, std::integral_constant<int, 0>{});
+        step_barrier();
+      }
+      pass(t, std::integral_constant<int, 1>{});
+      // the frame's slots: upper triangle of C0 + C1, then rows 0 .. 2 (the B rows) of C1: register 0 of the lanes lk = 0 .. 2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g >= wv.nseg || t >= ckm[g]) continue;
+        double *gs = b.gram + (size_t)(cgo[g] + t) * VILO_GRAMC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = lk + 4 * r;
+          if (row <= lr) gs[tri16(row, lr)] = G0[g][r] + G1[g][r];
+        }
+        if (lk < 3) gs[VILO_GRAMC_TRI + 16 * lk + lr] = G1[g][0];
+        G0[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G1[g] = G0[g];
+      }
+      step_barrier();
+    }
+    return;
+  }
+
+  // ------------------------------------------ producer: factor evaluation, landmark side ------------------------------------------
+  const bool active = ls.active;
+  const int n = wv.n_lanes, L = wm.L, s = ls.s;
+  const double *xg = (mode ? b.xc : b.x) + (size_t)wv.win * XSTRIDE;
+  double *lm_g_out = lin_lm_g(b, st, mode);
+  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
+  const int li = ls.li;
+  for (int e = lane; e < XSTRIDE; e += 64) xs[e] = xg[e];
+  const double *obs = b.obs + wv.obs_off;
+  const unsigned char *flg = b.flags + wv.flag_off;
+  double oi[6];   // pts_i (3), vel_i (2), td_i: the observation in the start frame
+  double lam = 1.0;
+  for (int c = 0; c < 6; ++c) oi[c] = 0.0;
+  oi[2] = 1.0;
+  if (active) {
+    lam = (mode ? b.lamc : b.lam)[ls.gi];
+    oi[0] = obs[(size_t)0 * n + lane]; oi[1] = obs[(size_t)1 * n + lane]; oi[2] = obs[(size_t)2 * n + lane];
+    oi[3] = obs[(size_t)6 * n + lane]; oi[4] = obs[(size_t)7 * n + lane]; oi[5] = obs[(size_t)10 * n + lane];
+  }
+  lds_fence();   // (xs, wt, tab belong to this wave alone: its own LDS traffic in order is all that is needed)
+  if (lane < 9) {
+    const m3 ric = qR(ldq_pose(xs + XO_EX)), ric2 = qR(ldq_pose(xs + XO_EX + 7));
+    const m3 A2 = tr(ric2) * ric;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      if (q == lane) { e0 = ric.a[q]; e1 = ric2.a[q]; e2 = A2.a[q]; }
+    wt[VW_RIC + lane] = e0; wt[VW_RIC2 + lane] = e1; wt[VW_A2 + lane] = e2;
+    if (lane < 3) { wt[VW_TIC + lane] = xs[XO_EX + lane]; wt[VW_TIC2 + lane] = xs[XO_EX + 7 + lane]; }
+  }
+  lds_fence();
+  const double td = xs[XO_TD];
+  VisLane VL;
+  {
+    const double dti = td - oi[5];
+    VL.inv_lam = 1.0 / lam;
+    VL.vix = oi[3]; VL.viy = oi[4];
+    VL.pci = mk3((oi[0] - oi[3] * dti) * VL.inv_lam, (oi[1] - oi[4] * dti) * VL.inv_lam, oi[2] * VL.inv_lam);
+    const double *ric = wt + VW_RIC, *tic = wt + VW_TIC;
+    VL.p_i = mk3(ric[0] * VL.pci.x + ric[1] * VL.pci.y + ric[2] * VL.pci.z + tic[0], ric[3] * VL.pci.x + ric[4] * VL.pci.y + ric[5] * VL.pci.z + tic[1],
+                 ric[6] * VL.pci.x + ric[7] * VL.pci.y + ric[8] * VL.pci.z + tic[2]);
+    const double *pose_s = xs + XO_POSE + 7 * s;
+    VL.p_w = qrot(ldq_pose(pose_s), VL.p_i) + ld3(pose_s);
+  }
+  const v3 pts_i = mk3(oi[0], oi[1], oi[2]);
+  double E = 0.0, gl = 0.0, cost = 0.0;
+  double wc_s[6], wc_e0[6], wc_e1[6];
+  for (int c = 0; c < 6; ++c) wc_s[c] = wc_e0[c] = wc_e1[c] = 0.0;
+  double on[11];
+  unsigned char fl_next = 0;
+  for (int c = 0; c < 11; ++c) on[c] = 0.0;
+  if (active) {
+    fl_next = flg[lane];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) on[c] = obs[(size_t)c * n + lane];
+  }
+  // table-builder role of this lane: (segment, camera, row) = 4 x 2 x 3
+  const int tb_g = lane / 6, tb_kind = ((lane % 6) >= 3) ? 1 : 0, tb_r = lane % 3;
+  int tb_s = 0, tb_km = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (g == tb_g) { tb_s = cs[g]; tb_km = (g < wv.nseg) ? ckm[g] : 0; }
+  for (int t = 0; t < kmax; ++t) {
+    if (t >= 1) {
+      if (lane < 24 && t < tb_km) vis_build_pair_row(xs, wt, tb_s, min(tb_s + t, VILO_MAX_FRAMES - 1), tb_kind, tb_r, tab + tb_g * VT_N);
+      lds_fence();
+    }
+    const int j = min(s + t, VILO_MAX_FRAMES - 1);
+    const unsigned char fl = fl_next;
+    double ob[11];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) ob[c] = on[c];
+    if (active && t + 1 < kmax) {
+      fl_next = flg[(size_t)(t + 1) * n + lane];
+      const double *obn = obs + (size_t)(t + 1) * 11 * n;
+#pragma unroll
+      for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
+    }
+    double wj[6];
+    for (int c = 0; c < 6; ++c) wj[c] = 0.0;
+    const double *tb = tab + max(ls.seg, 0) * VT_N;
+    v3 p_j = VL.p_i;
+    if (t > 0) {
+      const v3 d = mk3(VL.p_w.x - tb[VT_PJ], VL.p_w.y - tb[VT_PJ + 1], VL.p_w.z - tb[VT_PJ + 2]);
+      p_j = mk3(tb[0] * d.x + tb[3] * d.y + tb[6] * d.z, tb[1] * d.x + tb[4] * d.y + tb[7] * d.z, tb[2] * d.x + tb[5] * d.y + tb[8] * d.z);
+    }
+    const double dtj = td - ob[10];
+    for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
+      const int nstep = (t == 0) ? 0 : 2 * t - 1 + cam;
+      const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
+      double *xr0 = X + (nstep & 1) * PC_XN + lane * XLANEC, *xr1 = xr0 + XROWC;
+      if (produce) {
+        double x0[XROWC], x1[XROWC], Jl[2], obc[5], tc[4][3];
+        double rho0;
+        if (cam == 0) {
+          obc[0] = ob[0]; obc[1] = ob[1]; obc[2] = ob[2]; obc[3] = ob[6]; obc[4] = ob[7];
+          rho0 = vis_two_frame_c<0>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+        } else {
+          obc[0] = ob[3]; obc[1] = ob[4]; obc[2] = ob[5]; obc[3] = ob[8]; obc[4] = ob[9];
+          if (t > 0) rho0 = vis_two_frame_c<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+          else rho0 = vis_one_frame_c(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
+        }
+        // landmark-side reductions: the same 21 terms, formed and added exactly as in the single-wave / frame-parallel forms (bitwise)
+        double term[LM_NTERM], wjr[3];
+        term[0] = dot2(Jl[0], Jl[0], Jl[1], Jl[1]);
+        term[1] = dot2(Jl[0], x0[GK_R], Jl[1], x1[GK_R]);
+        const double pw = (t > 0) ? 1.0 : 0.0;   // the one-frame factor has no pose blocks (its B columns carry the tic column)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          term[2 + c] = pw * (dot2(x0[GK_B + c], Jl[0], x1[GK_B + c], Jl[1]));
+          term[5 + c] = dot2(x0[GK_RI + c], Jl[0], x1[GK_RI + c], Jl[1]);
+          term[8 + c] = dot2(tc[0][c], Jl[0], tc[1][c], Jl[1]);
+          term[11 + c] = dot2(x0[GK_C0 + c], Jl[0], x1[GK_C0 + c], Jl[1]);
+          term[14 + c] = dot2(tc[2][c], Jl[0], tc[3][c], Jl[1]);
+          term[17 + c] = dot2(x0[GK_C1 + c], Jl[0], x1[GK_C1 + c], Jl[1]);
+          wjr[c] = dot2(x0[GK_RJ + c], Jl[0], x1[GK_RJ + c], Jl[1]);
+        }
+        // (every term is a value of its own before it is added — the frame-parallel form stores it, the sums must round alike: opaque to the
+        // optimiser so that no multiply of a term is contracted into the accumulation)
+#pragma unroll
+        for (int v = 0; v < 20; ++v) asm volatile("" : "+v"(term[v]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(wjr[c]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          wj[c] -= term[2 + c];   // d r / d P_j = -d r / d P_i
+          wj[3 + c] += wjr[c];
+        }
+        E += term[0];
+        gl += term[1];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { wc_s[c] += term[2 + c]; wc_e0[c] += term[8 + c]; wc_e1[c] += term[14 + c]; }
+        cost += rho0;
+#pragma unroll
+        for (int c = 0; c < XROWC; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < XROWC; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+      }
+      step_barrier();
+    }
+    if (active && t > 0 && s + t < VILO_MAX_FRAMES) {
+      const bool seen = fl & 1;
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = seen ? wj[c] : 0.0;
+    }
+  }
+  if (active) {
+    for (int f = 0; f < VILO_MAX_FRAMES; ++f)
+      if (f < s || f >= s + kmax)
+        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
+    wbase[(size_t)79 * L + li] = 0.0;
+    b.lm_E[ls.gi] = E;
+    lm_g_out[ls.gi] = gl;
+    const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX);
+    for (int c = 0; c < 6; ++c) {
+      wbase[(size_t)(6 * s + c) * L + li] = wc_s[c];
+      wbase[(size_t)(CD_EX0 + c) * L + li] = ex_on ? wc_e0[c] : 0.0;
+      wbase[(size_t)(CD_EX1 + c) * L + li] = ex_on ? wc_e1[c] : 0.0;
+    }
+    wbase[(size_t)CD_TD * L + li] = 0.0;   // (td is a constant block in the compact mode)
+  }
+  {
+    const double csum = wave_sum(active ? cost : 0.0);
+    double *cost_out = b.chunk_cost + (size_t)wave_id * VILO_MAX_FRAMES;
+    if (lane < VILO_MAX_FRAMES) cost_out[lane] = (lane == 0) ? csum : 0.0;
+  }
+  step_barrier();   // (the consumer's last step)
+}
+
 // Second half of the TPAR form: per landmark, the (frame, camera) terms in the order the walking form adds them (frames ascending,
 // left camera before right; an unobserved factor contributed +0.0).
 __global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) {
@@ -524,7 +793,10 @@ static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream
     else hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     hipLaunchKernelGGL(k_visual_reduce, dim3(b.n_waves), dim3(64), 0, s, b, mode);
   } else {
-    if (compact) hipLaunchKernelGGL(k_visual_linearize_c, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
+    // (VILO_VISUAL_FORM=single keeps the one-wave compact form: A/B runs)
+    static const bool pc = [] { const char *e = getenv("VILO_VISUAL_FORM"); return !(e && !strcmp(e, "single")); }();
+    if (compact && pc) hipLaunchKernelGGL(k_visual_linearize_pc, dim3(b.n_waves), dim3(128), 0, s, b, sq, ha, mode);
+    else if (compact) hipLaunchKernelGGL(k_visual_linearize_c, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
     else hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
   }
 }

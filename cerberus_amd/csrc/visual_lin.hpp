@@ -37,6 +37,11 @@ namespace vilo {
 #define VT_A1RC 64    // ric2^T Rj^T Ri ric
 #define VT_N 74       // 592 B: the four segments of a wave sit 20 banks apart (no conflict between their 16-byte reads)
 
+// a0 b0 + a1 b1 with the rounding spelled out (one product, then one fused multiply-add): the landmark-side terms are formed by three
+// kernels (single wave, frame-parallel, producer / consumer) that must agree bit for bit, and left to the optimiser each of them may
+// contract the expression the other way round
+VD double dot2(double a0, double b0, double a1, double b1) { return fma(a0, b0, a1 * b1); }
+
 struct Red3 { double r00, r02, r12; };   // reduce = [r00 0 r02; 0 r00 r12] (already times sqrt_info and sqrt(rho'))
 
 // T = reduce * M, M 3 x 3 row-major

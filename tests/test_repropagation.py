@@ -162,3 +162,32 @@ def test_gpu_marginalisation_after_a_repropagated_solve_vs_oracle(ctx, cfg, ocfg
     assert np.abs(Ag - Ao).max() < 1e-6 * np.abs(Ao).max()
     bg, bo = Jg.T @ pg.r0[:n], Jo.T @ po.r0[:n]
     assert np.abs(bg - bo).max() < 1e-6 * np.abs(bo).max()
+
+
+@pytest.mark.gpu
+def test_gpu_config3_as_the_bench_times_it_vs_oracle(ctx, cfg, ocfg):
+    """BASELINE configs[2] in the combination bench.py --config 3 times: 1000 landmarks (NUM_OF_F, parameters.h:24) x 400 Hz x every
+    interval integrated again in every iteration (imu_leg_integration_base.cpp:62-86) x 12 fixed iterations, in a batch large enough for
+    the throughput forms of every kernel (walking visual linearisation, single-wave solver: > 512 windows). First and last window of the
+    batch against the oracle on the same seeds."""
+    from cerberus_amd import api
+    W = 520
+    ws = [_window(cfg, ocfg, n_landmarks=1000, seed=700 + i) for i in range(W)]
+    opts = api.default_solve_opts(True, 12)
+    b = api.Batch(ctx, ws)
+    try:
+        b.set_samples()
+        b.solve(opts)
+        summ = b.download()
+    finally:
+        b.close()
+    assert all(s.iterations == 12 for s in summ)
+    for i in (0, W - 1):
+        w_o = _window(cfg, ocfg, n_landmarks=1000, seed=700 + i)
+        with O.repropagation(w_o):
+            so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
+        assert (summ[i].iterations, summ[i].num_successful) == (so.iterations, so.num_successful)
+        np.testing.assert_allclose(summ[i].final_cost, so.final_cost, rtol=1e-6)
+        for a, bb in zip(ws[i].state_arrays(), w_o.state_arrays()):
+            if a.size:
+                assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max()), (i, np.abs(a - bb).max())
