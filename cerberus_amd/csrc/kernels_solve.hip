@@ -1261,13 +1261,13 @@ __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   }
 }
 
-__global__ void k_init_state(BatchDev b, double radius0, int fail_bad) {
+__global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_bad) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= b.W) return;
   SolverState &s = b.st[w];
   memset(&s, 0, sizeof(SolverState));
   s.radius = radius0;
-  s.mu = 1e-8;
+  s.mu = mu0;
   s.need_lin = 1;
   s.t_start = wall_clock64();
   if (fail_bad && b.win_bad && b.win_bad[w]) { s.done = 1; s.termination = 2; }
@@ -1307,7 +1307,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     ++pidx;
   };
   P0(6);
-  hipLaunchKernelGGL(k_init_state, dim3((W + 127) / 128), dim3(128), 0, s, b, o->initial_trust_region_radius, 1);
+  hipLaunchKernelGGL(k_init_state, dim3((W + 127) / 128), dim3(128), 0, s, b, o->initial_trust_region_radius, ctx->initial_mu, 1);
   P1();
   // the first "candidate" is the initial point itself (IterationZero evaluates and linearises it)
   VILO_HIP(hipMemcpyAsync(b.xc, b.x, sizeof(double) * (size_t)W * XSTRIDE, hipMemcpyDeviceToDevice, s));
@@ -1371,7 +1371,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
 // preMarginalize (marginalization_factor.cpp:119-138): evaluate the factors once at the current state.
 int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
-  hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4, 0);
+  hipLaunchKernelGGL(k_init_state, dim3((b.W + 127) / 128), dim3(128), 0, ctx->stream, b, 1e4, 1e-8, 0);
   if (b.rp_on && (vilo_repropagate_launch(ctx, b, 0, 0) != VILO_OK || vilo_repropagate_launch(ctx, b, 0, 1) != VILO_OK)) return VILO_ERR_HIP;
   launch_visual_linearize(b, sq, ha, ctx->stream, 0);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn, 0);

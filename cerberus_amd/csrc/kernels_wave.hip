@@ -39,7 +39,8 @@ template <bool COMPACT>
 __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
   __shared__ double Cl[CL_N];
   __shared__ double Rt[COMPACT ? 12 * 9 : 1];   // compact slots: rotation matrices of the window's frames, [11] = identity
-  __shared__ double stage[COMPACT ? AC_STAGE : 1];   // compact slots of the chunk being scattered
+  __shared__ double stage[COMPACT ? AC_STAGE : 1];   // compact slots of the chunk being scattered; afterwards the ring of two IMU factor Grams
+  __shared__ double gst[COMPACT ? 1 : 2 * 780];       // (23-column form: the ring has its own storage)
   __shared__ double gl[CD_N], hd[CD_N], vS[CD_N], red[12];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
@@ -190,43 +191,127 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   }
   __syncthreads();   // the IMU owners below are different threads
   PCLK(if (tid == 0) b.st[win].phase_clk[38] = clock64());
+  // ---- IMU factors. Factor k (frames k, k + 1) contributes a packed 39 x 39 Gram [pose_i 6 | speed / leg-bias_i 13 | pose_j 6 | speed /
+  //      leg-bias_j 13 | r] (780 entries, contiguous). Frame by frame through a ring of two Grams in LDS: the factor's 780 entries come in
+  //      with coalesced loads (the next factor's are in flight in registers), every consumer gathers from LDS, and what goes to the solver
+  //      (A_kk, A_k+1,k^T, the coupling rows) leaves as coalesced stores. Per frame k: Gi = factor k (frame k is its "i"), Gj = factor k - 1.
+  //        [0, 169)    A_kk             = prior (frame kb) + Gi[6 + .][6 + .] + Gj[25 + .][25 + .]
+  //        [169, 338)  A_{k+1,k}^T      = Gi[6 + j][25 + i]
+  //        [338, 626)  coupling rows    with poses k - 1 (Gj), k (Gi + Gj), k + 1 (Gi); rows 13 .. 15 zero padding
+  //        pose blocks of factor k      -> the pose image (63 owner threads), diagonal and gradient of the frame's 13 dimensions (13 threads)
   {
-    // IMU factor Grams, pose part: I1 pose_i x pose_i (21, twin +19), I3 pose gradient (6, twin +19), I4 pose_i x pose_j (36)
-    int a = 0, bc = 0, cls = 0;
-    if (tid < 21) { cls = 1; int rem = tid; while (rem >= 6 - a) { rem -= 6 - a; ++a; } bc = a + rem; }
-    else if (tid < 27) { cls = 3; a = tid - 21; bc = 38; }
-    else if (tid < 63) { cls = 4; a = (tid - 27) / 6; bc = 19 + (tid - 27) % 6; }
-    if (cls) {
-      const int e1 = tri39(a, bc), e2 = (cls == 4) ? e1 : tri39(a + 19, cls == 3 ? 38 : bc + 19);
-      double vm[10], vt[10];
+    double *ring = COMPACT ? stage : gst;
+    // pose-block owners: I1 pose_i x pose_i (21, twin +19), I3 pose gradient (6, twin +19), I4 pose_i x pose_j (36): threads 128 .. 190 of the last trip
+    int pa = 0, pbc = 0, pcls = 0;
+    {
+      const int q = tid - 128;
+      if (q >= 0 && q < 21) { pcls = 1; int rem = q; while (rem >= 6 - pa) { rem -= 6 - pa; ++pa; } pbc = pa + rem; }
+      else if (q >= 21 && q < 27) { pcls = 3; pa = q - 21; pbc = 38; }
+      else if (q >= 27 && q < 63) { pcls = 4; pa = (q - 27) / 6; pbc = 19 + (q - 27) % 6; }
+    }
+    const int pe1 = tri39(pa, pbc), pe2 = (pcls == 4) ? pe1 : tri39(pa + 19, pcls == 3 ? 38 : pbc + 19);
+    // what this thread's three entries per frame read and write does not depend on the frame: indices worked out once
+    //   kind 0 A_kk, 1 A_{k+1,k}^T, 2 coupling row, 3 nothing;  si / sj: entry of Gi / Gj (-1: none);  d1 / d2: dimensions (within their frame's
+    //   13) whose activity masks the entry (d2 < 0: only d1);  dst: offset inside the frame's block of the target array
+    int e_kind[3], e_si[3], e_sj[3], e_d1[3], e_d2[3], e_dst[3], e_df[3];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) { vm[k] = igram[min(k, F - 2) * 780 + e1]; vt[k] = igram[min(k, F - 2) * 780 + e2]; }
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      e_kind[u] = 3; e_si[u] = -1; e_sj[u] = -1; e_d1[u] = 0; e_d2[u] = -1; e_dst[u] = 0; e_df[u] = 1;
+      if (e < 169) {
+        const int i = e / 13, j = e - 13 * i;
+        e_kind[u] = 0; e_d1[u] = i; e_d2[u] = j; e_dst[u] = e;
+        e_si[u] = tri39(6 + min(i, j), 6 + max(i, j)); e_sj[u] = tri39(25 + min(i, j), 25 + max(i, j));
+      } else if (e < 338) {
+        const int ji = e - 169, j = ji / 13, i = ji - 13 * j;
+        e_kind[u] = 1; e_d1[u] = i; e_d2[u] = j; e_dst[u] = ji;   // d1: dimension of frame k + 1, d2: of frame k
+        e_si[u] = tri39(6 + j, 25 + i);
+      } else if (e < 626) {
+        const int is = e - 338, i = is / 18, sx = is - 18 * i, df = sx / 6, c = sx - 6 * df;
+        e_kind[u] = (i < 13) ? 2 : 4;   // (4: a zero-padding row of the coupling block)
+        e_d1[u] = min(i, 12); e_dst[u] = is; e_df[u] = df;
+        if (df == 1) { e_si[u] = tri39(c, 6 + min(i, 12)); e_sj[u] = tri39(19 + c, 25 + min(i, 12)); }
+        else if (df == 2) e_si[u] = tri39(6 + min(i, 12), 19 + c);
+        else e_sj[u] = tri39(c, 25 + min(i, 12));
+      }
+    }
+    double gp[4];
+    auto prefetch = [&](int k) {
 #pragma unroll
-      for (int k = 0; k < 10; ++k) {
-        if (k >= F - 1) continue;
-        if (cls == 1) { rmw(6 * k + bc, 6 * k + a, vm[k]); rmw(6 * (k + 1) + bc, 6 * (k + 1) + a, vt[k]); }
-        else if (cls == 3) { gl[6 * k + a] += vm[k]; gl[6 * (k + 1) + a] += vt[k]; }
-        else rmw(6 * (k + 1) + (bc - 19), 6 * k + a, vm[k]);
+      for (int u = 0; u < 4; ++u) { const int e = tid + ASM_THREADS * u; gp[u] = (e < 780) ? igram[k * 780 + e] : 0.0; }
+    };
+    if (F > 1) prefetch(0);
+    // the prior's diagonal block of frame kb (169 entries, threads 0 .. 168) comes in before the loop
+    const double prior_ad = (kb >= 0 && tid < 169) ? pd[PD_AD + 169 * kb + tid] : 0.0;
+    const double prior_dg = (kb >= 0 && tid >= 200 && tid < 213) ? pd[PD_AD + 169 * kb + (tid - 200) * 14] : 0.0;
+    for (int k = 0; k < F; ++k) {
+      const bool has_i = k < F - 1, has_j = k >= 1;
+      double *Gi = ring + 780 * (k & 1);
+      const double *Gj = ring + 780 * ((k + 1) & 1);
+      lds_barrier();   // (the readers of this ring slot — frame k - 1's "Gj" of two frames ago — are done)
+      if (has_i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = tid + ASM_THREADS * u; if (e < 780) Gi[e] = gp[u]; }
+      }
+      lds_barrier();
+      if (k + 1 < F - 1) prefetch(k + 1);
+      const unsigned char *actk = act + CD_B0 + 13 * k;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int kind = e_kind[u];
+        if (kind == 0) {
+          double v;
+          if (!actk[e_d1[u]] || !actk[e_d2[u]]) v = (e_d1[u] == e_d2[u]) ? 1.0 : 0.0;
+          else {
+            v = (k == kb) ? prior_ad : 0.0;   // (u == 0 for every A_kk entry: prior_ad is this thread's)
+            if (has_i) v += Gi[e_si[u]];
+            if (has_j) v += Gj[e_sj[u]];
+          }
+          bimg[BI_AD + 169 * k + e_dst[u]] = v;
+        } else if (kind == 1) {
+          if (k < 10) {
+            double v = 0.0;
+            if (has_i && actk[13 + e_d1[u]] && actk[e_d2[u]]) v = Gi[e_si[u]];
+            bimg[BI_AOT + 169 * k + e_dst[u]] = v;
+          }
+        } else if (kind == 2 || kind == 4) {
+          const int f = k - 1 + e_df[u];
+          double v = 0.0;
+          if (kind == 2 && f >= 0 && f < F && actk[e_d1[u]]) {
+            if (has_i && e_si[u] >= 0) v += Gi[e_si[u]];
+            if (has_j && e_sj[u] >= 0) v += Gj[e_sj[u]];
+          }
+          bimg[BI_BS + 288 * k + e_dst[u]] = v;
+        }
+      }
+      if (pcls && has_i) {
+        const double vm = Gi[pe1], vt = Gi[pe2];
+        if (pcls == 1) { rmw(6 * k + pbc, 6 * k + pa, vm); rmw(6 * (k + 1) + pbc, 6 * (k + 1) + pa, vt); }
+        else if (pcls == 3) { gl[6 * k + pa] += vm; gl[6 * (k + 1) + pa] += vt; }
+        else rmw(6 * (k + 1) + (pbc - 19), 6 * k + pa, vm);
+      }
+      if (tid >= 200 && tid < 213) {
+        // diagonal and gradient of the frame's speed / leg-bias dimensions (the prior's share of the gradient is there already)
+        const int i = tid - 200, cd = CD_B0 + 13 * k + i;
+        double h = 1.0, g = gl[cd];
+        if (act[cd]) {
+          h = (k == kb) ? prior_dg : 0.0;
+          if (has_i) { h += Gi[tri39(6 + i, 6 + i)]; g += Gi[tri39(6 + i, 38)]; }
+          if (has_j) { h += Gj[tri39(25 + i, 25 + i)]; g += Gj[tri39(25 + i, 38)]; }
+        }
+        hd[cd] = h;
+        gl[cd] = g;
       }
     }
   }
   __syncthreads();
   PCLK(if (tid == 0) b.st[win].phase_clk[39] = clock64());
-  // ---- constant blocks / absent frames / padding as identity rows and columns; diagonal and gradient of all 224 camera dimensions ----
+  // ---- diagonal of the pose part; gradient of all 224 camera dimensions (inactive ones zero) ----
   // (rows / columns of inactive dimensions become identity rows when the image is written out below)
   for (int cd = tid; cd < CD_N; cd += ASM_THREADS) {
     double g = gl[cd];
     if (cd < CD_B0) hd[cd] = act[cd] ? Cl[cl_pos(cd, cd)] : 1.0;
-    if (cd >= CD_B0) {
-      double h = 1.0;
-      if (cd < CD_B0 + 143 && act[cd]) {
-        const int k = (cd - CD_B0) / 13, i = (cd - CD_B0) - 13 * k;
-        h = (k == kb) ? pd[PD_AD + k * 169 + i * 14] : 0.0;
-        if (k < F - 1) { h += igram[k * 780 + tri39(6 + i, 6 + i)]; g += igram[k * 780 + tri39(6 + i, 38)]; }
-        if (k >= 1) { h += igram[(k - 1) * 780 + tri39(25 + i, 25 + i)]; g += igram[(k - 1) * 780 + tri39(25 + i, 38)]; }
-      }
-      hd[cd] = h;
-    }
+    else if (cd >= CD_B0 + 13 * F) hd[cd] = 1.0;   // (frames beyond the window, padding: the loop above did not visit them)
     if (!act[cd]) g = 0.0;
     gl[cd] = g;
     b.cam_gin[(size_t)win * CD_N + cd] = g;
@@ -264,88 +349,10 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     b.Cimg[(size_t)win * CIMG_N + idx] = v;
     part_q += ((c_tI[t] == c_tJ[t]) ? 1.0 : 2.0) * vS[row] * v * vS[col];   // (a diagonal tile holds both triangles)
   }
-  // ---- speed / leg-bias part: one entry per thread and trip, straight from the packed factor Grams. The loads of all trips of a block
-  //      kind are issued before the first store (values in registers): one memory round trip per kind instead of one per trip ----
   PCLK(if (tid == 0) b.st[win].phase_clk[42] = clock64());
-  {
-    double val[8];
+  // ---- prior rows of the frame whose speed / leg-bias block the prior touches (rows 13 .. 15: zero padding) ----
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {   // A_kk: factor k (frame k is "i": columns 6..18), factor k - 1 ("j": 25..37), prior at frame kb
-      const int e = min(tid + ASM_THREADS * u, 11 * 169 - 1);
-      const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
-      double v;
-      if (!act[CD_B0 + 13 * k + i] || !act[CD_B0 + 13 * k + j]) {
-        v = (i == j) ? 1.0 : 0.0;
-      } else {
-        v = (k == kb) ? pd[PD_AD + e] : 0.0;
-        if (k < F - 1) v += igram[k * 780 + tri39(6 + min(i, j), 6 + max(i, j))];
-        if (k >= 1) v += igram[(k - 1) * 780 + tri39(25 + min(i, j), 25 + max(i, j))];
-      }
-      val[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = tid + ASM_THREADS * u;
-      if (e < 11 * 169) {
-        const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
-        bimg[BI_AD + e] = val[u];
-        part_q += vS[CD_B0 + 13 * k + i] * val[u] * vS[CD_B0 + 13 * k + j];
-      }
-    }
-  }
-  PCLK(if (tid == 0) b.st[win].phase_clk[43] = clock64());
-  {
-    double val[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {   // A_{k+1,k} transposed: [k][j = dimension of frame k][i = dimension of frame k + 1]
-      const int e = min(tid + ASM_THREADS * u, 10 * 169 - 1);
-      const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
-      double v = 0.0;
-      if (k < F - 1 && act[CD_B0 + 13 * (k + 1) + i] && act[CD_B0 + 13 * k + j]) v = igram[k * 780 + tri39(6 + j, 25 + i)];
-      val[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int e = tid + ASM_THREADS * u;
-      if (e < 10 * 169) {
-        const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
-        bimg[BI_AOT + e] = val[u];
-        part_q += 2.0 * vS[CD_B0 + 13 * (k + 1) + i] * val[u] * vS[CD_B0 + 13 * k + j];
-      }
-    }
-  }
-  PCLK(if (tid == 0) b.st[win].phase_clk[44] = clock64());
-  {
-    double val[13];
-#pragma unroll
-    for (int u = 0; u < 13; ++u) {   // coupling of dimension i of frame k with pose k - 1 + df, column c (rows 13..15: zero padding)
-      const int e = min(tid + ASM_THREADS * u, 11 * 288 - 1);
-      const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, df = sx / 6, c = sx - 6 * df, f = k - 1 + df;
-      double v = 0.0;
-      if (i < 13 && f >= 0 && f < F && act[CD_B0 + 13 * k + i]) {
-        if (df == 1) {
-          if (k < F - 1) v += igram[k * 780 + tri39(c, 6 + i)];
-          if (k >= 1) v += igram[(k - 1) * 780 + tri39(19 + c, 25 + i)];
-        } else if (df == 2) {
-          if (k < F - 1) v += igram[k * 780 + tri39(6 + i, 19 + c)];
-        } else {
-          v += igram[(k - 1) * 780 + tri39(c, 25 + i)];   // (f >= 0 means k >= 1)
-        }
-      }
-      val[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < 13; ++u) {
-      const int e = tid + ASM_THREADS * u;
-      if (e < 11 * 288) {
-        const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, f = k - 1 + sx / 6, c = sx % 6;
-        bimg[BI_BS + e] = val[u];
-        if (val[u] != 0.0) part_q += 2.0 * vS[CD_B0 + 13 * k + min(i, 12)] * val[u] * vS[min(max(6 * f + c, 0), 79)];
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 5; ++u) {   // prior rows of the frame whose speed / leg-bias block it touches (rows 13..15: zero padding)
+  for (int u = 0; u < 5; ++u) {
     const int e = tid + ASM_THREADS * u;
     const int i = e / 80, p = e - 80 * i;
     double v = 0.0;
@@ -355,6 +362,56 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     }
     bimg[BI_BP + e] = v;
   }
+  // ---- a partial window (F < 11) leaves the blocks of the absent frames as identity / zero for the solver's fixed-size loops ----
+  if (F < VILO_MAX_FRAMES) {
+    for (int e = tid + 169 * F; e < 11 * 169; e += ASM_THREADS) { const int ij = e % 169; bimg[BI_AD + e] = (ij / 13 == ij % 13) ? 1.0 : 0.0; }
+    for (int e = tid + 169 * max(F - 1, 0); e < 10 * 169; e += ASM_THREADS) bimg[BI_AOT + e] = 0.0;
+    for (int e = tid + 288 * F; e < 11 * 288; e += ASM_THREADS) bimg[BI_BS + e] = 0.0;
+  }
+  PCLK(if (tid == 0) b.st[win].phase_clk[43] = clock64());
+  // ---- q = v^T H v of the speed / leg-bias rows: the blocks just written come back (coalesced, L2-resident; all loads of a kind in flight) ----
+  __threadfence_block();   // (this workgroup's stores above must be visible to its loads below)
+  __syncthreads();
+  {
+    double val[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) val[u] = bimg[BI_AD + min(tid + ASM_THREADS * u, 11 * 169 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 11 * 169) {
+        const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
+        part_q += vS[CD_B0 + 13 * k + i] * val[u] * vS[CD_B0 + 13 * k + j];
+      }
+    }
+  }
+  {
+    double val[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) val[u] = bimg[BI_AOT + min(tid + ASM_THREADS * u, 10 * 169 - 1)];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 10 * 169) {
+        const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
+        part_q += 2.0 * vS[CD_B0 + 13 * (k + 1) + i] * val[u] * vS[CD_B0 + 13 * k + j];
+      }
+    }
+  }
+  {
+    double val[13];
+#pragma unroll
+    for (int u = 0; u < 13; ++u) val[u] = bimg[BI_BS + min(tid + ASM_THREADS * u, 11 * 288 - 1)];
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int e = tid + ASM_THREADS * u;
+      if (e < 11 * 288) {
+        const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, f = k - 1 + sx / 6, c = sx % 6;
+        if (val[u] != 0.0) part_q += 2.0 * vS[CD_B0 + 13 * k + min(i, 12)] * val[u] * vS[min(max(6 * f + c, 0), 79)];
+      }
+    }
+  }
+  PCLK(if (tid == 0) b.st[win].phase_clk[44] = clock64());
   // camera-side sums of |D^-1 g|^2, max |g| and q (the landmarks add theirs in the solver): waves in fixed order
   part_q = wave_sum(part_q); part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax);
   if ((tid & 63) == 0) { red[tid >> 6] = part_q; red[4 + (tid >> 6)] = part_gn; red[8 + (tid >> 6)] = part_gmax; }

@@ -27,6 +27,7 @@ struct vilo_batch {
   hipGraphExec_t gexec = nullptr;
   vilo_solve_opts gopts;
   int g_sqrt_info_mode = 0, g_rp_on = 0;   // context / batch state the captured launch sequence depends on (part of the cache key)
+  double g_initial_mu = 1e-8;
   // re-propagation buffers (vilo_batch_set_samples): reused by later calls while they are large enough (the arena cannot free)
   vilo_sample *rp_s = nullptr; int *rp_o = nullptr; double *rp_t = nullptr; size_t rp_cap = 0;
   int n_solves = 0;
@@ -636,7 +637,8 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   int rc = VILO_OK;
   const bool want_graph = !ctx->profile && !bt->graph_failed && bt->n_solves >= 1 && getenv("VILO_NO_GRAPH") == nullptr;
   if (opts->max_solver_time_us < 0) { ctx->err = "vilo_solve_opts.max_solver_time_us < 0 (fill the struct with vilo_default_solve_opts)"; return VILO_ERR_BAD_ARG; }
-  if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0 || bt->g_sqrt_info_mode != ctx->sqrt_info_mode || bt->g_rp_on != bt->d.rp_on)) {
+  if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0 || bt->g_sqrt_info_mode != ctx->sqrt_info_mode || bt->g_rp_on != bt->d.rp_on ||
+                     bt->g_initial_mu != ctx->initial_mu)) {
     if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -646,7 +648,7 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
       if (g) (void)hipGraphDestroy(g);
     }
     if (!bt->gexec) { bt->graph_failed = true; (void)hipGetLastError(); ctx->err.clear(); }
-    else { bt->gopts = *opts; bt->g_sqrt_info_mode = ctx->sqrt_info_mode; bt->g_rp_on = bt->d.rp_on; }
+    else { bt->gopts = *opts; bt->g_sqrt_info_mode = ctx->sqrt_info_mode; bt->g_rp_on = bt->d.rp_on; bt->g_initial_mu = ctx->initial_mu; }
     rc = VILO_OK;
   }
   VILO_HIP(hipEventRecord(ctx->ev0, ctx->stream));

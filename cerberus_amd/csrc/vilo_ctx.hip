@@ -88,6 +88,13 @@ extern "C" int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode) {
   ctx->sqrt_info_mode = mode;
   return VILO_OK;
 }
+// Test hook (not part of the reference's interface): DoglegStrategy's mu at the start of the next solves, so that a solve can be resumed
+// from a state (x, radius, mu) another implementation reached — tests/test_branches.py compares single steps with the oracle.
+extern "C" int vilo_debug_set_initial_mu(vilo_ctx *ctx, double mu) {
+  if (!ctx || !(mu > 0.0)) return VILO_ERR_BAD_ARG;
+  ctx->initial_mu = mu;
+  return VILO_OK;
+}
 extern "C" void vilo_set_profiling(vilo_ctx *ctx, int on) {
   if (!ctx) return;
   ctx->profile = on;

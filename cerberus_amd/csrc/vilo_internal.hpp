@@ -39,6 +39,7 @@ struct vilo_ctx {
   std::vector<int> pev_kind;        // kernel kind of interval i = [pev[2i], pev[2i+1]]
   double kernel_ms[VILO_NKERNEL];
   long long kernel_launches[VILO_NKERNEL];
+  double initial_mu = 1e-8;         // DoglegStrategy's mu at the start of a solve (Ceres: min_mu; vilo_debug_set_initial_mu: per-step comparisons with the oracle)
   int sqrt_info_mode = 0;           // 0: Cholesky of the index-reversed covariance + triangular inverse; 1: the reference's inverse() + LLT, literally
   bool wave_attr_set = false, marg_attr_set = false, prior_attr_set = false;   // dynamic-LDS opt-ins done on this context's device       // k_solve_wave's dynamic-LDS opt-in done on this context's device
 };

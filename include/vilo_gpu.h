@@ -331,6 +331,9 @@ int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
  * 2 + k only kernel kind k (vilo_kernel_name(k)). Resets the accumulated times. */
 void vilo_set_profiling(vilo_ctx *ctx, int on);
 int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long *launches, int n);
+/* Test hook: DoglegStrategy's mu at the start of the following solves (default 1e-8 = Ceres' min_mu), to resume a solve from a state
+ * (x, radius, mu) reached elsewhere: single steps are compared with the oracle this way (tests/test_branches.py). */
+int vilo_debug_set_initial_mu(vilo_ctx *ctx, double mu);
 const char *vilo_kernel_name(int kind);
 /* Copy an internal device array of one window to the host (tests localise parity failures with it). */
 int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *batch, int what, int win, double *out, int max_n);

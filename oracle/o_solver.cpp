@@ -487,6 +487,13 @@ extern "C" void orc_window_normal_eq(const orc_config *cfg, const orc_window *w,
 // 0 Gauss-Newton step inside the radius, 1 Cauchy-limited step, 2 dogleg-interpolated step, 3 rejected steps, 4 longest run of rejected
 // steps, 5 invalid steps, 6 mu escalations (reduced system not positive definite), 7 accepted steps.
 static int g_branch[8];
+// test hooks: mu at the start of the next solves (resume a solve from a state reached elsewhere), and the scalars of the last iteration
+// of the last solve: [0] alpha (Cauchy), [1] |D^-1 g|^2, [2] |gn step|^2, [3] model_cost_change, [4] candidate cost, [5] relative decrease,
+// [6] dogleg step norm, [7] radius after, [8] mu after, [9] accepted (1) / rejected (0) / invalid (-1), [10] dogleg branch (0 GN, 1 Cauchy, 2 interpolated)
+static double g_initial_mu = 1e-8;
+static double g_last[12];
+extern "C" void orc_set_initial_mu(double mu) { g_initial_mu = mu > 0 ? mu : 1e-8; }
+extern "C" void orc_last_step_scalars(double *out) { for (int i = 0; i < 12; ++i) out[i] = g_last[i]; }
 extern "C" void orc_last_branch_counts(int *out) { for (int i = 0; i < 8; ++i) out[i] = g_branch[i]; }
 
 extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_state *s, const orc_solve_opts *o,
@@ -529,7 +536,8 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
   for (int i = 0; i < 8; ++i) g_branch[i] = 0;
   int consecutive_rejected = 0;
   // DoglegStrategy state
-  double radius = o->initial_trust_region_radius, mu = 1e-8;
+  double radius = o->initial_trust_region_radius, mu = g_initial_mu;
+  for (int i = 0; i < 12; ++i) g_last[i] = 0.0;
   const double min_mu = 1e-8, max_mu = 1.0, mu_increase = 10.0;
   bool reuse = false;
   double alpha = 0, dogleg_step_norm = 0;
@@ -584,6 +592,8 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
     if (linear_ok) {
       // ComputeTraditionalDoglegStep
       const double gradient_norm = vnorm(dl_gradient), gauss_newton_norm = vnorm(gn_step);
+      g_last[0] = alpha; g_last[1] = gradient_norm * gradient_norm; g_last[2] = gauss_newton_norm * gauss_newton_norm;
+      g_last[10] = (gauss_newton_norm <= radius) ? 0 : ((gradient_norm * alpha >= radius) ? 1 : 2);
       if (gauss_newton_norm <= radius) {
         ++g_branch[0];
         step = gn_step;
@@ -619,6 +629,7 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
       reuse = false;
       sum->cost_trace[iter] = x_cost;
       sum->radius_trace[iter] = radius;
+      g_last[3] = model_cost_change; g_last[6] = dogleg_step_norm; g_last[7] = radius; g_last[8] = mu; g_last[9] = -1;
       continue;
     }
     num_consecutive_invalid = 0;
@@ -671,6 +682,8 @@ extern "C" int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_
     }
     sum->cost_trace[iter] = x_cost;
     sum->radius_trace[iter] = radius;
+    g_last[3] = model_cost_change; g_last[4] = candidate_cost; g_last[5] = relative_decrease; g_last[6] = dogleg_step_norm;
+    g_last[7] = radius; g_last[8] = mu; g_last[9] = (relative_decrease > o->min_relative_decrease) ? 1 : 0;
   }
   scatter_x(P, R, x);
   sum->iterations = iter;

@@ -198,6 +198,9 @@ void orc_default_opts(orc_solve_opts *o);
 void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets);
 /* Hessian build of orc_marginalize on n threads (the reference: NUM_THREADS = 4 pthreads, marginalization_factor.h:22, .cpp:246-275); default 1. */
 void orc_set_marginalize_threads(int n);
+/* Test hooks: mu at the start of the following solves (default 1e-8); scalars of the last iteration of the last solve (12 doubles, o_solver.cpp). */
+void orc_set_initial_mu(double mu);
+void orc_last_step_scalars(double *out12);
 
 /* Cost 1/2 sum rho(|r|^2) at state, and optionally gradient/Hessian pieces in the reduced (camera)
  * ordering used by tests: local layout [frame k: pose6 sb9 lb4]*n_frames, ex0 6, ex1 6, td 1, then landmarks. */

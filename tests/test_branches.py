@@ -146,3 +146,146 @@ def test_max_solver_time_budget(ctx, cfg, ocfg):
     w2 = _window(cfg, ocfg, seed=11)
     s2 = ctx.solve_windows([w2], api.default_solve_opts(True, 12))[0]
     assert s2.iterations == 12 and s2.final_cost <= s1.final_cost
+
+
+def _state_of(w):
+    return [a.copy() for a in w.state_arrays()]
+
+
+def _set_state(w, arrays):
+    for dst, src in zip(w.state_arrays(), arrays):
+        dst[...] = src
+
+
+def _single_steps(ctx, cfg, ocfg, n_iters, radius0, lm_diag=None, mu0=1e-8, **wkw):
+    """Teacher-forced comparison: the oracle's trajectory gives the states (x_i, radius_i, mu_i) it visits; from EACH of them both
+    implementations take exactly one trust-region iteration (fresh solve from x_i with initial radius radius_i and initial mu mu_i:
+    vilo_debug_set_initial_mu / orc_set_initial_mu), so that differences cannot accumulate over accepted steps: what is compared is
+    one step's scalars, decision and result. Yields (i, gpu, oracle) dictionaries."""
+    import ctypes as C
+    from cerberus_amd import api
+    L = api.lib()
+    L.vilo_debug_set_initial_mu.argtypes = [C.c_void_p, C.c_double]
+    O.lib().orc_set_initial_mu.argtypes = [C.c_double]
+
+    def opts_pair(iters, radius):
+        go, oo = api.default_solve_opts(True, iters), O.default_opts(True, iters)
+        for o in (go, oo):
+            o.initial_trust_region_radius = radius
+            if lm_diag is not None:
+                o.min_lm_diagonal, o.max_lm_diagonal = lm_diag
+        return go, oo
+
+    def oracle_scalars():
+        out = (C.c_double * 12)()
+        O.lib().orc_last_step_scalars(out)
+        return list(out)
+
+    # the oracle's trajectory: state, radius and mu after i iterations
+    traj = []
+    for i in range(n_iters):
+        w = _window(cfg, ocfg, **wkw)
+        O.lib().orc_set_initial_mu(mu0)
+        _, oo = opts_pair(i, radius0)
+        sm = O.solve_window(ocfg, w, oo, check=False)
+        sc = oracle_scalars()
+        traj.append((_state_of(w), sm.radius_trace[i] if i else radius0, sc[8] if i else mu0, sm.termination))
+        if sm.termination == 2:
+            break
+    out = []
+    try:
+        for i, (x_i, radius_i, mu_i, term) in enumerate(traj):
+            if term == 2:
+                break
+            go, oo = opts_pair(1, radius_i)
+            w_g, w_o = _window(cfg, ocfg, **wkw), _window(cfg, ocfg, **wkw)
+            _set_state(w_g, x_i); _set_state(w_o, x_i)
+            assert L.vilo_debug_set_initial_mu(ctx.h, C.c_double(mu_i)) == 0
+            b = api.Batch(ctx, [w_g])
+            try:
+                b.solve(go)
+                summ = b.download()[0]
+                st = b.fetch(10)
+            finally:
+                b.close()
+            O.lib().orc_set_initial_mu(mu_i)
+            osum = O.solve_window(ocfg, w_o, oo, check=False)
+            sc = oracle_scalars()
+            g = dict(cost0=summ.cost_trace[0], accepted=summ.num_successful, term=summ.termination, alpha=st[9], gnorm2=st[5], gnnorm2=st[6], model=st[4],
+                     cand=st[3], step_norm=st[12], radius=st[0], mu=st[1], state=_state_of(w_g), valid=int(st[4] > 0))
+            o = dict(cost0=osum.cost_trace[0], accepted=osum.num_successful, term=osum.termination, alpha=sc[0], gnorm2=sc[1], gnnorm2=sc[2], model=sc[3],
+                     cand=sc[4], step_norm=sc[6], radius=sc[7], mu=sc[8], state=_state_of(w_o), valid=int(sc[9] >= 0), kind=int(sc[10]), rel=sc[5])
+            out.append((i, radius_i, mu_i, g, o))
+    finally:
+        L.vilo_debug_set_initial_mu(ctx.h, C.c_double(1e-8))
+        O.lib().orc_set_initial_mu(1e-8)
+    return out
+
+
+def _check_steps(steps, tol):
+    worst = 0.0
+    for i, radius_i, mu_i, g, o in steps:
+        assert (g["accepted"], g["term"], g["valid"]) == (o["accepted"], o["term"], o["valid"]), (i, g["accepted"], o["accepted"], g["term"], o["term"])
+        np.testing.assert_allclose(g["cost0"], o["cost0"], rtol=1e-10, err_msg="cost at x_%d" % i)
+        keys = ["alpha", "gnorm2", "gnnorm2", "model", "step_norm", "radius", "mu"] + (["cand"] if o["valid"] else [])
+        for k in keys:
+            err = abs(g[k] - o[k]) / max(abs(o[k]), 1e-300)
+            worst = max(worst, err)
+            assert err < tol, (i, k, g[k], o[k], err, "radius %g mu %g" % (radius_i, mu_i))
+        for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], g["state"], o["state"]):
+            if a.size:
+                err = np.abs(a - bb).max() / max(1.0, np.abs(bb).max())
+                worst = max(worst, err)
+                assert err < tol, (i, name, err)
+    return worst
+
+
+@pytest.mark.parametrize("seed", [42, 48, 51])
+def test_single_steps_along_a_trajectory_with_rejected_runs(ctx, cfg, ocfg, seed):
+    """The far-off starts of test_runs_of_rejected_steps (accept / reject / radius logic pinned there at 1e-3 over a free-running solve,
+    because the two restatements drift over the accepted steps of a badly conditioned problem), step by step: from every state the
+    oracle visits — rejected ones included, where the same point is tried again with half the radius — both implementations take ONE
+    iteration and must agree on the dogleg scalars (alpha, |D^-1 g|^2, |GN step|^2, step norm), model_cost_change, the candidate's
+    cost, accept / reject, the new radius and mu and the new state. That separates the logic (exact) from the conditioning of a long
+    trajectory."""
+    kw = dict(seed=seed, sig_p=1.0, sig_theta=0.4, sig_lambda_rel=0.9, sig_v=1.0, sig_ba=0.3, sig_bg=0.05)
+    steps = _single_steps(ctx, cfg, ocfg, 10, 1e8, **kw)
+    assert sum(1 for s in steps if s[4]["accepted"] == 0 and s[4]["valid"]) >= 2 and sum(1 for s in steps if s[4]["accepted"] == 1) >= 1
+    # Measured: 9e-9 (seed 42), 2e-7 (seeds 48, 51: the full Gauss-Newton step of a start metres off, taken with radius 1e8 on a reduced
+    # system of condition ~1e10 — one linear solve's conditioning, where the free-running comparison above needs 1e-3)
+    worst = _check_steps(steps, 1e-6)
+    print("worst single-step relative difference (seed %d): %.2e" % (seed, worst))
+
+
+@pytest.mark.parametrize("radius", [1e-3, 1e-1, 1e4])
+def test_single_steps_of_the_three_dogleg_kinds(ctx, cfg, ocfg, radius):
+    kw = dict(seed=11) if radius < 1.0 else dict(seed=20, sig_p=0.2, sig_theta=0.08, sig_lambda_rel=0.6, sig_v=0.5)
+    steps = _single_steps(ctx, cfg, ocfg, 8, radius, **kw)
+    kinds = {s[4]["kind"] for s in steps}
+    assert (1 in kinds) if radius < 1.0 else len(kinds) >= 2, kinds
+    worst = _check_steps(steps, 1e-8)
+    print("worst single-step relative difference (radius %g): %.2e" % (radius, worst))
+
+
+def test_single_step_at_equal_mu_after_escalation(ctx, cfg, ocfg):
+    """The mu-escalation window of test_mu_escalation (singular camera-side Hessian, Levenberg-Marquardt diagonal clamped to 1e-12): the
+    free-running solves may stop escalating at different mu (rounding decides whether a factorisation of a numerically singular matrix
+    fails). Started at the mu the oracle ended its first iteration with (times ten, what the escalation would try next), both factorise
+    at the SAME mu, and the step is compared like any other."""
+    import ctypes as C
+    kw = dict(seed=60, prior=False)
+    w = _window(cfg, ocfg, **kw)
+    oo = O.default_opts(True, 1)
+    oo.min_lm_diagonal = oo.max_lm_diagonal = 1e-12
+    O.lib().orc_set_initial_mu.argtypes = [C.c_double]
+    O.lib().orc_set_initial_mu(1e-8)
+    O.solve_window(ocfg, w, oo)
+    assert O.branch_counts()[MU_UP] >= 1
+    out = (C.c_double * 12)()
+    O.lib().orc_last_step_scalars(out)
+    mu_used = out[8] * 5.0 if out[9] == 1 else out[8]   # (an accepted step left mu = max(1e-8, 2 mu / 10))
+    steps = _single_steps(ctx, cfg, ocfg, 1, 1e4, lm_diag=(1e-12, 1e-12), mu0=mu_used * 10.0, **kw)
+    # (the Levenberg-Marquardt diagonal is clamped to 1e-12 here: mu D^2 regularises a singular matrix by 1e-14, so the Gauss-Newton step is
+    # determined to ~1e-4 only — measured 1.0e-4 on |GN step|^2; the decisions, model_cost_change's sign and the radius / mu updates are exact)
+    worst = _check_steps(steps, 1e-3)
+    print("worst single-step relative difference at mu = %g: %.2e" % (mu_used * 10.0, worst))

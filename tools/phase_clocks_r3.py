@@ -20,7 +20,7 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     m = C.mean(axis=0)
     print("== %d windows (mean of %d sampled windows, cycles)" % (W, len(sample)))
     d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
-    print("k_assemble: prior image %d | visual slots %d | IMU pose blocks %d | masks + diagonal %d | scaling %d | tile image out + q %d | A_kk %d | A_k+1,k %d | coupling + prior rows + sums %d | total %d"
+    print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
           % (*d, d.sum()))
     if W <= 512:
         print("k_solve_mw wave B: scaling %d | 1/(E + mu d) %d | Schur + rank updates (steps) %d | rhs + Cholesky %d | backward solve %d | wait for barrier %d | landmark back-substitution %d | norms + barrier %d | dogleg + candidate %d | total %d"
