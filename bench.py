@@ -53,6 +53,7 @@ def kernels_sha16():
 
 
 PROFILE_ROUND = "round3"
+STRONG_TOTAL = 1024   # BASELINE configs[3]
 
 
 def profile_evidence(W_run, tag=""):
@@ -283,6 +284,7 @@ def main():
     ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
     ap.add_argument("--streams", type=int, default=2, help="resident batches solved concurrently in the multi-stream side figure (default 2: `two_streams`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the BASELINE configs[3] (1024 windows in total) side block")
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] side block of the default line")
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
@@ -414,6 +416,35 @@ def main():
     assert iters_done == W * ITERS, "every window must run the fixed iteration count"
     final_cost = float(np.mean([s.final_cost for s in summ]))
 
+    # BASELINE configs[3] as stated, beside the weak-scaling headline: 1024 windows IN TOTAL, window w on GPU w mod N (128 per GPU on 8). Every
+    # rank solves its share with the same barrier / max-over-ranks timing as the headline; reported as a side block, so a 1 / 2 / 4 / 8-GPU
+    # sweep of the default command shows the strong-scaling curve too.
+    strong = None
+    if args.total_windows == 0 and not rp and args.landmarks == 200 and not args.no_strong and STRONG_TOTAL % world == 0:
+        Ws = STRONG_TOTAL // world
+        wins_s = [make_synth_window(cfg, args.landmarks, args.rate, 50260925 + rank + world * i) for i in range(Ws)]
+        ctx.preintegrate_windows(wins_s)
+        bs = make_batch(ctx, wins_s)
+        lib.vilo_set_profiling(ctx.h, 0)
+        for _ in range(2):
+            bs.reset(); bs.prepare(); bs.solve(opts)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            bs.reset(); bs.prepare(); bs.solve(opts)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        barrier()
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        summ_s = bs.download()
+        assert sum(s_.iterations for s_ in summ_s) == Ws * ITERS
+        bs.close()
+        strong = {"workload": "BASELINE configs[3]: %d independent config-2 windows in total, window w on GPU w mod %d" % (STRONG_TOTAL, world),
+                  "scaling": "strong", "total_windows": STRONG_TOTAL, "windows_per_gpu": Ws, "n_gpus": world, "steps": args.steps,
+                  "value": STRONG_TOTAL * ITERS * args.steps / el, "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps}
     if rank == 0:
         unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
         value = unit_work / elapsed
@@ -474,6 +505,8 @@ def main():
                             "the others over the warm-up steps (the timed steps carry the dominant kernel's event pairs only)",
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
+        if strong:
+            out["strong_scaling"] = strong
         if not args.no_cpu_baseline:
             # checker leg, outside the timed region: did the timed kernels produce the reference's states?
             out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, n=2 if rp else 8, repropagate=rp)

@@ -33,11 +33,57 @@ VD int ac_kcol(int R) { return R < 3 ? GK_C0 + R : (R < 6 ? GK_C1 + (R - 3) : GK
 VD int ac_restcd(int R) { return R < 3 ? CD_EX0 + 3 + R : CD_EX1 + 3 + (R - 3); }          // rest index 0..5 -> camera dimension
 VD int ac_tri(int x, int y) { return x <= y ? tri16(x, y) : tri16(y, x); }
 
+// T8: {tic, tic2} x {tic, tic2}, 21 entries (q: 0..5 tic x tic upper, 6..14 tic x tic2, 15..20 tic2 x tic2 upper):
+//   N0^T C0_BB N0 + Ri'^T C1_BB Ri' | -Ri'^T C1_BB Rj' | Rj'^T C1_BB Rj', summed over every frame t of the chunk. The heaviest class (nine
+//   3 x 3 terms per slot): three lanes per entry, lane grp of ngrp takes the frames t = grp, grp + ngrp, ...; the caller adds the partial sums
+//   in the order grp 0, 1, 2 and applies the total.
+VD void ac_t8_decode(int q, int &pa, int &pb, int &ia, int &ib) {
+  pa = 0; pb = 0; ia = 0; ib = 0;
+  if (q < 6) { int rem = q; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
+  else if (q < 15) { pb = 1; ia = (q - 6) / 3; ib = (q - 6) % 3; }
+  else { pa = 1; pb = 1; int rem = q - 15; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
+}
+VD double ac_t8_partial(int q, int grp, int ngrp, int s, int km, const double *slots, const double *Rt) {
+  int pa, pb, ia, ib;
+  ac_t8_decode(q, pa, pb, ia, ib);
+  // v = La^T C0 Lb + Ma^T C1 Mb with  (tic, tic): La = N0[:, ia], Lb = N0[:, ib], Ma = Ri'[:, ia], Mb = Ri'[:, ib];
+  // (tic, tic2): Ma = Ri'[:, ia], Mb = -Rj'[:, ib];  (tic2, tic2): Ma = Rj'[:, ia], Mb = Rj'[:, ib]  (La = Lb = 0 in the last two)
+  const double f0 = (pa == 0 && pb == 0) ? 1.0 : 0.0, sb = (pa == 0 && pb == 1) ? -1.0 : 1.0;
+  double sum = 0.0;
+  for (int t = grp; t < km; t += ngrp) {
+    const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
+    const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);
+    const double *RA = pa ? Rj : Ri, *RB = pb ? Rj : Ri;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // inner sums first: sum_d C[c][d] * right[d]
+      double i0 = 0.0, i1 = 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double c1 = C1B[16 * c + d], c0 = Gb[ac_tri(c, d)] - c1;
+        i0 += c0 * (Ri[3 * d + ib] - Rj[3 * d + ib]);
+        i1 += c1 * RB[3 * d + ib];
+      }
+      v += f0 * (Ri[3 * c + ia] - Rj[3 * c + ia]) * i0 + sb * RA[3 * c + ia] * i1;
+    }
+    sum += v;
+  }
+  return sum;
+}
+template <class RMW>
+VD void ac_t8_apply(int q, double total, RMW rmw) {
+  int pa, pb, ia, ib;
+  ac_t8_decode(q, pa, pb, ia, ib);
+  rmw((pb ? CD_EX1 : CD_EX0) + ib, (pa ? CD_EX1 : CD_EX0) + ia, total);
+}
+
 // One chunk (start frame s, km frames) of one owner thread. slots: the chunk's km slots back to back (k_assemble stages them in LDS with
 // coalesced loads: every byte of a slot is fetched from HBM once and the owner threads' scattered reads are LDS reads);  Rt: [12][9]
 // rotation matrices of the window's frames (row-major), entry 11 = identity;  rmw(hi, lo, v): image(hi, lo) += v (hi >= lo);
 // gadd(cd, v): gradient. Thread ranges are laid out so that a wave of 64 runs at most two of the class bodies:
-//   wave 0: T1 [0, 21) T2 [21, 57)   wave 1: T3 [64, 106) T8 [106, 127)   wave 2: T5 [128, 146) T6 [146, 164) T4 [164, 192)   wave 3: T7 [192, 234)
+//   wave 0: T1 [0, 21) T2 [21, 57), then T3 as a second body of lanes [0, 42)   wave 1: T8, three lanes per entry (ac_t8_partial / ac_t8_apply)
+//   wave 2: T5 [128, 146) T6 [146, 164) T4 [164, 192)   wave 3: T7 [192, 234)
 template <class RMW, class GADD>
 VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slots, const double *Rt, RMW rmw, GADD gadd) {
   if (tid < 21) {
@@ -59,9 +105,10 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     const int e = ac_tri(a, ac_jidx(b));
     const double sg = ac_jsign(b);
     for (int t = 1; t < km; ++t) rmw(6 * (s + t) + b, 6 * s + a, sg * slots[t * VILO_GRAMC + e]);
-  } else if (tid >= 64 && tid < 106) {
-    // T3: pose_f (a) x rest (b: theta_ic 0..2, theta_ic2 3..5, r 6)
-    const int a = (tid - 64) / 7, b = (tid - 64) % 7;
+  }
+  if (tid < 42) {
+    // T3: pose_f (a) x rest (b: theta_ic 0..2, theta_ic2 3..5, r 6) — a second body of the lanes that own T1 / T2 entries
+    const int a = tid / 7, b = tid % 7;
     const int e1 = ac_tri(a, ac_kcol(b)), e2 = ac_tri(ac_jidx(a), ac_kcol(b));
     const double sg2 = ac_jsign(a);
     double sum = 0.0;
@@ -73,38 +120,8 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     }
     if (b == 6) gadd(6 * s + a, sum);
     else rmw(ac_restcd(b), 6 * s + a, sum);
-  } else if (tid >= 106 && tid < 127) {
-    // T8: {tic, tic2} x {tic, tic2}: N0^T C0_BB N0 + Ri'^T C1_BB Ri' | -Ri'^T C1_BB Rj' | Rj'^T C1_BB Rj', summed over every t
-    const int q = tid - 106;
-    int pa = 0, pb = 0, ia = 0, ib = 0;   // which translations (0 tic, 1 tic2) and components
-    if (q < 6) { int rem = q; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
-    else if (q < 15) { pb = 1; ia = (q - 6) / 3; ib = (q - 6) % 3; }
-    else { pa = 1; pb = 1; int rem = q - 15; while (rem >= 3 - ia) { rem -= 3 - ia; ++ia; } ib = ia + rem; }
-    // v = La^T C0 Lb + Ma^T C1 Mb with  (tic, tic): La = N0[:, ia], Lb = N0[:, ib], Ma = Ri'[:, ia], Mb = Ri'[:, ib];
-    // (tic, tic2): Ma = Ri'[:, ia], Mb = -Rj'[:, ib];  (tic2, tic2): Ma = Rj'[:, ia], Mb = Rj'[:, ib]  (La = Lb = 0 in the last two)
-    const double f0 = (pa == 0 && pb == 0) ? 1.0 : 0.0, sb = (pa == 0 && pb == 1) ? -1.0 : 1.0;
-    double sum = 0.0;
-    for (int t = 0; t < km; ++t) {
-      const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
-      const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);
-      const double *RA = pa ? Rj : Ri, *RB = pb ? Rj : Ri;
-      double v = 0.0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // inner sums first: sum_d C[c][d] * right[d]
-        double i0 = 0.0, i1 = 0.0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const double c1 = C1B[16 * c + d], c0 = Gb[ac_tri(c, d)] - c1;
-          i0 += c0 * (Ri[3 * d + ib] - Rj[3 * d + ib]);
-          i1 += c1 * RB[3 * d + ib];
-        }
-        v += f0 * (Ri[3 * c + ia] - Rj[3 * c + ia]) * i0 + sb * RA[3 * c + ia] * i1;
-      }
-      sum += v;
-    }
-    rmw((pb ? CD_EX1 : CD_EX0) + ib, (pa ? CD_EX1 : CD_EX0) + ia, sum);
-  } else if (tid >= 128 && tid < 164) {
+  }
+  if (tid >= 128 && tid < 164) {
     // T5 / T6: tic (T5) / tic2 (T6) component a x pose_f dimension b
     const bool five = tid < 146;
     const int q = five ? tid - 128 : tid - 146, a = q / 6, b = q % 6, xj = ac_jidx(b);

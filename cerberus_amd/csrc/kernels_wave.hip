@@ -124,6 +124,13 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       lds_barrier();
       if (ch + 1 < nch) prefetch(ch + 1);
       assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { gl[cd] += v; });
+      if (tid >= 64 && tid < 128) {
+        // wave 1: the {tic, tic2}^2 entries, three lanes per entry (each a third of the chunk's frames), partial sums added in lane order
+        const int wl = tid - 64, q = wl % 21, grp = min(wl / 21, 2);
+        const double part = (wl < 63) ? ac_t8_partial(q, grp, 3, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt) : 0.0;
+        const double p1 = __shfl(part, q + 21, 64), p2 = __shfl(part, q + 42, 64);
+        if (wl < 21) ac_t8_apply(q, (part + p1) + p2, rmw);
+      }
     }
   } else {
     // visual Gram slots: 246 owner groups, one per thread
@@ -1179,14 +1186,20 @@ __global__ void __launch_bounds__(64) k_solve_wave(BatchDev b, SolveParams sp) {
 // =================================================================================================
 // launch
 // =================================================================================================
-int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw.hip
-// Which solver: the two-wave form while the batch leaves SIMDs idle (two windows per CU: 512 on the 256 CUs of an MI355X), the single-wave
-// form beyond. VILO_SOLVER=wave / mw overrides (tests run both forms against the oracle).
-static bool vilo_use_mw_solver(const BatchDev &b) {
-  static const int forced = [] { const char *e = getenv("VILO_SOLVER"); return !e ? 0 : (!strcmp(e, "mw") ? 2 : (!strcmp(e, "wave") ? 1 : 0)); }();
-  static const int max_w = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
-  if (forced) return forced == 2;
-  return b.W <= max_w;
+int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);    // kernels_mw.hip
+int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw4.hip
+// Which solver (0 single wave, 2 two waves, 4 four waves per window): as many waves per window as the batch leaves SIMDs for — four up to one
+// window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond. VILO_SOLVER=wave / mw / mw4 pins a form
+// (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
+static int vilo_solver_form(const BatchDev &b) {
+  static const int forced = [] {
+    const char *e = getenv("VILO_SOLVER");
+    return !e ? -1 : (!strcmp(e, "mw4") ? 4 : (!strcmp(e, "mw") ? 2 : (!strcmp(e, "wave") ? 0 : -1)));
+  }();
+  static const int max_w4 = [] { const char *e = getenv("VILO_MW4_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
+  static const int max_w2 = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+  if (forced >= 0) return forced;
+  return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : 0);
 }
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
@@ -1194,7 +1207,9 @@ int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, h
   if (stage == 0) {
     if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
     else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
-  } else if (vilo_use_mw_solver(b)) {
+  } else if (vilo_solver_form(b) == 4) {
+    return vilo_launch_mw4_solver(ctx, b, sp, s);
+  } else if (vilo_solver_form(b) == 2) {
     return vilo_launch_mw_solver(ctx, b, sp, s);
   } else {
     if (!ctx->wave_attr_set) {

@@ -125,9 +125,14 @@ void hc_assemble_compact(int nch, const unsigned *chunk_tab, const double *slots
   for (int q = 0; q < 9; ++q) Rt[99 + q] = (q % 4 == 0) ? 1.0 : 0.0;
   for (int ch = 0; ch < nch; ++ch) {
     const int s = chunk_tab[ch] & 255, km = (chunk_tab[ch] >> 8) & 255, sl0 = chunk_tab[ch] >> 16;
+    auto rmw = [&](int hi, int lo, double v) { H80[hi * 80 + lo] += v; };
     for (int tid = 0; tid < 256; ++tid)
-      assemble_visual_compact_chunk(
-          tid, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt, [&](int hi, int lo, double v) { H80[hi * 80 + lo] += v; }, [&](int cd, double v) { g80[cd] += v; });
+      assemble_visual_compact_chunk(tid, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt, rmw, [&](int cd, double v) { g80[cd] += v; });
+    for (int q = 0; q < 21; ++q) {   // wave 1 of the kernel: three lanes per entry, partial sums added in lane order
+      double p[3];
+      for (int grp = 0; grp < 3; ++grp) p[grp] = ac_t8_partial(q, grp, 3, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt);
+      ac_t8_apply(q, (p[0] + p[1]) + p[2], rmw);
+    }
   }
 }
 }

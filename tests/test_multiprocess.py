@@ -67,6 +67,10 @@ def test_bench_py_itself_on_two_ranks_of_one_gpu():
     assert abs(d["value"] - 2 * W * it / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     sh = d["config"]["shards"]
     assert len(sh) == 2 and sh[0][1] < sh[1][0] and sh[0][2] != sh[1][2]   # disjoint seed ranges, different data
+    # the strong-scaling side block of the default (weak) mode: BASELINE configs[3]'s 1024 windows in total, 512 per rank here
+    ss = d["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["total_windows"] == 1024 and ss["windows_per_gpu"] == 512 and ss["n_gpus"] == 2
+    assert abs(ss["value"] - 1024 * it / (ss["ms_per_step"] * 1e-3)) < 1e-6 * ss["value"]
     # BASELINE configs[3] mode: a fixed total, window w on rank w mod 2
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-windows", "64",

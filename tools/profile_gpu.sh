@@ -12,7 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 # PROFILE_ARGS replaces the default workload, e.g. PROFILE_ARGS="--config 3 --windows 1024" for BASELINE configs[2]
-ARGS="--steps 2 --warmup 1 ${PROFILE_ARGS:---windows 4096} --no-cpu-baseline --no-single-window"
+ARGS="--steps 2 --warmup 1 ${PROFILE_ARGS:---windows 4096} --no-cpu-baseline --no-single-window --no-strong"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- python $R/tools/calib_and_bench.py $ARGS > $OUT/bench_pmc_$C.log 2>&1

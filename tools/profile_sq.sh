@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1 --warmup 1 --windows $WIN --no-cpu-baseline --no-single-window"
+ARGS="--steps 1 --warmup 1 --windows $WIN --no-cpu-baseline --no-single-window --no-strong"
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 i=0
 while read -r LINE; do
