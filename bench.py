@@ -33,7 +33,7 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
 
 
 ALG_FLOPS_PER_WINDOW_ITERATION = {200: 13.7e6, 1000: 47.0e6}   # FP64 flops of one window-iteration (FMA = 2)
-ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")   # launched once per iteration
+ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")   # launched once per iteration
 REPROPAGATION_KERNELS = ("k_repropagate", "k_prepare_preint")   # config 3: once per iteration as well
 # K1 re-propagation adds the raw samples (280 B each) to the compulsory traffic and ~15 Mflop (sparse-aware; 75 Mflop as
 # dense 31 x 31 products) to the flops of one window-iteration

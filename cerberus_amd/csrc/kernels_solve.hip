@@ -1277,6 +1277,8 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 // host-side launch sequence
 // =================================================================================================
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage);   // kernels_wave.hip
+int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
+int vilo_solver_form(const BatchDev &b);                                                                    // kernels_wave.hip
 
 int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
@@ -1338,9 +1340,26 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     P0(8);
     if (vilo_launch_wave_solver(ctx, b, sp, s, 0) != VILO_OK) return VILO_ERR_HIP;
     P1();
-    P0(9);
-    if (vilo_launch_wave_solver(ctx, b, sp, s, 1) != VILO_OK) return VILO_ERR_HIP;
-    P1();
+    if (vilo_solver_form(b) == 3) {
+      // three-stage form (kernels_split.hip): chain -> pose system -> back-substitutions + step, then the complete single-wave solver for
+      // the windows a stage flagged (a factorisation failed: the retry loop lives there) — it returns at once for the rest
+      P0(12);
+      if (vilo_launch_split_stage(ctx, b, sp, s, 0) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(13);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 2) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(14);
+      if (vilo_launch_split_stage(ctx, b, sp, s, 1) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(9);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 4) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+    } else {
+      P0(9);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 1) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+    }
   }
   // the last candidate (or, without iterations, the initial point) only needs its cost
   P0(3);

@@ -31,6 +31,8 @@
 
 // assembled camera-side system of a window as the single-wave solver streams it (k_assemble -> k_solve_wave)
 #define CIMG_N 3840     // pose system: 15 lower 16 x 16 tiles x 4 accumulator registers x 64 lanes
+#define TK_N 14208      // k_chain's hand-over: T(k) of 11 frames, 5 tiles x 4 registers x 64 lanes each (14080) + the reduced right-hand side so far (80, padded)
+#define TK_V 14080
 #define BI_AD 0         // [11][13][13]  diagonal blocks A_kk of the speed / leg-bias part
 #define BI_AOT 1859     // [10][13][13]  A_{k+1,k} transposed: [k][dimension of frame k][dimension of frame k + 1]
 #define BI_BS 3552      // [11][16][18]  IMU coupling of frame k's dimensions with poses k-1, k, k+1 (rows 13..15 zero)
@@ -147,6 +149,7 @@ struct BatchDev {
   double *Lk;                 // [W][11][169] M_k = L_k^-1 of the bias chain
   double *TAg;                // [W][11][169] T_A(k) = L_k^-1 A_{k,k-1} (both written by the chain and read back by the back-substitution sweeps)
   double *Cimg;               // [W][3840] assembled pose system: 15 lower 16 x 16 tiles in FP64-MFMA accumulator order (k_assemble_pose)
+  double *Tk;                 // [W][TK_N] three-stage solver: k_chain -> k_solve_wave hand-over (coupling rows T(k) in MFMA operand order)
   double *cam_gin;            // [W][CD_N] gradient at the linearisation point (k_assemble)
   double *Bimg;               // [W][BI_N] speed / leg-bias part of the assembled system (BI_* layout)
   SolverState *st;

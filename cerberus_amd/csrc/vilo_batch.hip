@@ -478,6 +478,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.Lk, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.TAg, (size_t)W * 11 * 169));
   TRYB(dev_alloc(ctx, bt, &D.Cimg, (size_t)W * 3840));
+  TRYB(dev_alloc(ctx, bt, &D.Tk, (size_t)W * TK_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_gin, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.Bimg, (size_t)W * BI_N));
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));

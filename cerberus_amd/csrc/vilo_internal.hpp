@@ -17,7 +17,7 @@
 #define VILO_NP 80         // pose part: 11*6 poses + 6 ex0 + 6 ex1 + 1 td = 79, padded to 80
 #define VILO_NPU 79
 #define VILO_NCAM (VILO_F * 19 + 13)   // 222
-#define VILO_NKERNEL 12
+#define VILO_NKERNEL 15
 struct vilo_ctx {
   vilo_config cfg;
   int device;

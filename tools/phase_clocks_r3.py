@@ -27,6 +27,12 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
               % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[9] - m[0]))
         print("k_solve_mw wave A: chain %d (from kernel start %d) | idle until y_P %d | c = g_B - B y_P %d | forward sweep %d | backward sweep %d"
               % (m[17] - m[16], m[16] - m[0], m[18] - m[17], m[19] - m[18], m[20] - m[19], m[21] - m[20]))
+    elif C[:, 11].max() > 0:   # three-stage form
+        print("k_chain: %d" % (m[11] - m[10]))
+        print("k_solve_mid: gathers %d | 1/(E + mu d) %d | tile load + rank updates from T(k) %d | landmark Schur %d | Cholesky 80 %d | backward solve %d | total %d"
+              % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[6] - m[0]))
+        print("k_backsub: bias back-substitution %d | landmark back-substitution %d | dogleg + candidate %d | total %d"
+              % (m[25] - m[24], m[26] - m[25], m[27] - m[26], m[27] - m[24]))
     else:
         names = ["gathers", "tile load + 1/(E + mu d)", "chain", "landmark Schur", "Cholesky 80", "backward solve", "bias back-substitution", "landmark back-substitution", "dogleg + candidate"]
         d = np.diff(C[:, 0:10], axis=1).mean(axis=0)

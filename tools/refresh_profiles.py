@@ -53,7 +53,7 @@ if len(sys.argv) > 3:
     shutil.copy(sys.argv[3], os.path.join(R, "profiles", RND + "_bench_final.json"))
 if len(sys.argv) > 4:
     shutil.copy(sys.argv[4], os.path.join(R, "profiles", RND + "_bench_config3.json"))
-it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_solve_wave")
+it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")
 tot = 0.0
 for k in it:
     b, us = js["hbm_bytes_per_dispatch"][k], js["kernel_trace"][k]["avg_us"]
