@@ -10,6 +10,7 @@
 // source expression only — decided by the front end, the same in every instantiation.
 #pragma clang fp contract(on)
 #include "solver_types.hpp"
+#include "preint_blocks.hpp"
 
 using namespace vilo;
 
@@ -29,6 +30,8 @@ struct PreintImuStream {
   vilo_sample last;
   int n_pushed, pad;
 };
+
+__constant__ const pb::Tables c_pb_tab = pb::make_tables();
 
 namespace {
 
@@ -74,8 +77,9 @@ __device__ void jac_cov_update(const double *Fm, const double *Vm, const double 
 // zero-padded LDS matrices, 2 x 2 output tiles of v_mfma_f64_16x16x4 (lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16] of a
 // 4-deep k-step and owns C[(l / 16) + 4 r][l % 16], r = 0..3). One wave, 144 MFMAs per sample instead of ~4300 LDS-fed FMAs per lane.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-constexpr int FLD = 33;   // leading dimension of the 32 x 32 matrices (odd: rows land in different LDS banks)
-constexpr int VLD = 49;   // of the 32 x 48 noise Jacobian
+constexpr int FLD = 33;        // leading dimension of the 32 x 32 matrices (odd: rows land in different LDS banks)
+constexpr int VLD = pb::VLD;   // of the 32 x 48 noise Jacobian
+constexpr int FCLD = pb::FCLD; // of dF = F - I, stored with its 16 non-zero columns only (preint_blocks.hpp)
 
 // C(32 x 32) = A(32 x 4 KS) * op(B): row-major A (lda), B given as Bt = B^T row-major (ldb) when BT, else B row-major
 template <int KS, bool BT>
@@ -102,17 +106,18 @@ __device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]
     for (int r = 0; r < 4; ++r) C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr] = acc[t][r];
 }
 // F = I + dF, and dF has non-zero columns only at K = {3 .. 8, 21 .. 30} (d/d theta, d/d v, d/d ba, d/d bg, d/d rho): 16 of 31.
-// With dFm = F - I in LDS the products keep their identity part in the accumulators and contract over the 16 columns of K only:
+// With dFc = (F - I)[:, K] in LDS (32 x 16, leading dimension FCLD) the products keep their identity part in the accumulators and
+// contract over the 16 columns of K only:
 //   F X = X + dF[:, K] X[K, :],   Q F^T = Q + Q[:, K] dF[:, K]^T        (4 k-steps instead of 8 each).
-__device__ __forceinline__ int fk_col(int k) { return k < 6 ? 3 + k : 15 + k; }
-// acc (32 x 32, accumulator order) += A[:, K] * B[K, :]   (A, B row-major 32 x FLD in LDS); all 16 operands of a lane in flight first
+__device__ __forceinline__ int fk_col(int k) { return pb::fk_col(k); }
+// acc (32 x 32, accumulator order) += dFc * B[K, :]   (B row-major 32 x FLD in LDS); all 16 operands of a lane in flight first
 __device__ __forceinline__ void gemm32_fk(const double *A, const double *B, mfma_d4 acc[4]) {
   const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
   double a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const int k = fk_col(4 * kk + lk);
-    a0[kk] = A[lr * FLD + k]; a1[kk] = A[(16 + lr) * FLD + k];
+    const int kc = 4 * kk + lk, k = fk_col(kc);
+    a0[kk] = A[lr * FCLD + kc]; a1[kk] = A[(16 + lr) * FCLD + kc];
     b0[kk] = B[k * FLD + lr]; b1[kk] = B[k * FLD + 16 + lr];
   }
 #pragma unroll
@@ -123,15 +128,15 @@ __device__ __forceinline__ void gemm32_fk(const double *A, const double *B, mfma
     acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
   }
 }
-// acc += A[:, K] * Bt[:, K]^T
+// acc += A[:, K] * dFc^T
 __device__ __forceinline__ void gemm32_fk_t(const double *A, const double *Bt, mfma_d4 acc[4]) {
   const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
   double a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const int k = fk_col(4 * kk + lk);
+    const int kc = 4 * kk + lk, k = fk_col(kc);
     a0[kk] = A[lr * FLD + k]; a1[kk] = A[(16 + lr) * FLD + k];
-    b0[kk] = Bt[lr * FLD + k]; b1[kk] = Bt[(16 + lr) * FLD + k];
+    b0[kk] = Bt[lr * FCLD + kc]; b1[kk] = Bt[(16 + lr) * FCLD + kc];
   }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -148,7 +153,7 @@ __device__ __forceinline__ void load32(const double *C, int ldc, mfma_d4 acc[4])
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr];
 }
-// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468); dFm = F - I.
+// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468); dFm = (F - I)[:, K].
 // Q = F P overwrites P in LDS once every product that reads P has its operands.
 __device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const double *Vm, const double *nd, double *Jm, double *Pm) {
   mfma_d4 accJ[4], accQ[4];
@@ -172,16 +177,14 @@ __device__ inline void put33(double *M, int ld, int r0, int c0, const m3 &A) {
     for (int b = 0; b < 3; ++b) M[(r0 + a) * ld + c0 + b] = A.a[3 * a + b];
 }
 
-struct LegTerms {   // per (leg, endpoint), written by lanes 0..7
-  double f[3], J[9], v[3], g[3], h[9];
-};
-constexpr int LT_N = 27;   // doubles of a LegTerms record
-static_assert(sizeof(LegTerms) == LT_N * sizeof(double), "LegTerms is 27 consecutive doubles");
+constexpr int LT_N = pb::REC_N;   // doubles of the record of one (sample, leg)
+static_assert(LT_N == VILO_LEG_REC, "record size");
 
 // The part of the leg terms of one (sample, leg) that depends on the sample and the linearisation point only (:232-287 without the
 // rotation of the integration state): f, J, v, and g, h before their rotation R_e (g = -(R_e g0), h = R_e h0). A sample is the second
 // endpoint of one step and the first of the next, and the forward kinematics with its derivatives (six sin / cos) is the longest
-// stretch of a step, so an interval evaluates these records for all its samples up front with lane = (sample, leg) and parks them in HBM.
+// stretch of a step, so an interval evaluates these records for all its samples up front with lane = (sample, leg) and parks them in HBM,
+// laid out as the step's matrix pool wants them (preint_blocks.hpp): [v]x, [p_br + R_br f]x, h_0, J (3 x 3 each), g_0, v.
 __device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const vilo_sample &ss, int j, double rho_j, const v3 &bg, const m3 &Rbr, const v3 &pbr,
                                                  double *out /* LT_N */) {
   LegKin k;
@@ -197,9 +200,9 @@ __device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const v
   K.a[1] = k1.x; K.a[4] = k1.y; K.a[7] = k1.z;
   K.a[2] = k2.x; K.a[5] = k2.y; K.a[8] = k2.z;
   const m3 h0 = Rbr * K + Rw * Rbr * k.J;
-  st3(out, k.f);
-  for (int q = 0; q < 9; ++q) { out[3 + q] = k.J.a[q]; out[18 + q] = h0.a[q]; }
-  st3(out + 12, v); st3(out + 15, g0);
+  const m3 skv = skew(v), skp = skew(pbr + Rbr * k.f);
+  for (int q = 0; q < 9; ++q) { out[q] = skv.a[q]; out[9 + q] = skp.a[q]; out[18 + q] = h0.a[q]; out[27 + q] = k.J.a[q]; }
+  st3(out + 36, g0); st3(out + 39, v);
 }
 
 
@@ -211,14 +214,22 @@ __device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const v
 template <bool STREAM>
 __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
                                     PreintStream *st, double *terms /* HBM scratch of this interval: 4 * LT_N doubles per sample (+ one sample when STREAM) */) {
-  // padded to 32 rows (48 noise columns) with odd leading dimensions: rows / columns 31 and noise 46, 47 stay zero, so the FP64
-  // MFMA tiles of jac_cov_update_mfma need no masks
-  __shared__ double Fm[32 * FLD], Vm[32 * VLD], nd[48];
-  // (Q = F P overwrites P once every product that reads P has its operands: 40 000 B of LDS instead of 48 448 = four intervals per CU,
-  // one per SIMD, instead of three)
+  // dF (its 16 non-zero columns), V, the step's 3 x 3 matrix pool, coefficients and noise diagonal: one array, the offsets of
+  // preint_blocks.hpp. Padded to 32 rows (48 noise columns) with odd leading dimensions: row 31 and noise 46, 47 stay zero, so the FP64
+  // MFMA tiles of jac_cov_update_mfma need no masks.
+  __shared__ double Ls[pb::PB_TOTAL];
+  // (Q = F P overwrites P once every product that reads P has its operands: four intervals per CU, one per SIMD — 39 776 B each)
   __shared__ double Jm[32 * FLD], Pm[32 * FLD];
-  __shared__ LegTerms lt[8];
+  double *const Fm = Ls + pb::O_FC, *const Vm = Ls + pb::O_VM, *const nd = Ls + pb::O_ND;
   const int lane = threadIdx.x;
+  // this lane's descriptors of the lane-parallel block construction: product / block (7 round + lane / 9), entry lane % 9; lane 63 idles
+  const int pb_grp = lane / 9, pb_ent = lane - 9 * pb_grp;
+  unsigned pdesc[pb::N_PROD_ROUNDS];
+  unsigned long long bdesc[pb::N_BLK_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[r] = pb_grp < 7 ? c_pb_tab.prod[7 * r + pb_grp] : 0u;
+#pragma unroll
+  for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) bdesc[r] = pb_grp < 7 ? c_pb_tab.blk[7 * r + pb_grp] : 0ull;
   if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
   const v3 ba = ld3(ln), bg = ld3(ln + 3);
   double rho[4] = {ln[6], ln[7], ln[8], ln[9]};
@@ -250,13 +261,12 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = ((e / FLD) == (e % FLD) && e / FLD < 31) ? 1.0 : 0.0; Pm[e] = 0.0; }
   }
   // dF = F - I and V have a fixed sparsity pattern: zeroed once, every sample overwrites the same entries
-  for (int e = lane; e < 32 * FLD; e += 64) Fm[e] = 0.0;
-  for (int e = lane; e < 32 * VLD; e += 64) Vm[e] = 0.0;
-  if (lane >= 46 && lane < 48) nd[lane] = 0.0;
+  for (int e = lane; e < pb::PB_TOTAL; e += 64) Ls[e] = 0.0;
   __syncthreads();
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
+  if (lane < 9) { Ls[pb::O_POOL + 9 * pb::S_RBR + lane] = cfg.R_br[lane]; Ls[pb::O_POOL + 9 * pb::S_I + lane] = (lane % 4 == 0) ? 1.0 : 0.0; }
   // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
   // (batch: the constructor's sample; streaming: the last sample of the previous push)
   {
@@ -308,32 +318,41 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
         ff_var[j] = ss / 4;
       }
     }
-    // leg terms (:232-287): the two samples' records come back from HBM (216 doubles, four coalesced loads) into lt[2 * leg + endpoint],
-    // lanes 0..7 rotate g and h by the step's R_0 / R_1
+    // dF = F - I and V (:232-287, :376-465), every 3 x 3 product entry and every output entry on its own lane (preint_blocks.hpp).
+    // The pool's inputs: the two samples' records come back from HBM (336 doubles, six coalesced loads) into the slots of (leg, endpoint);
+    // lane 0 adds the step's own matrices and the powers of dt.
+    const v3 a0 = acc_0 - ba, a1 = acc_1 - ba;
     {
       const size_t slot0 = (size_t)(si - 1 - s_begin + (STREAM ? 1 : 0));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 6; ++q) {
         const int idx = lane + 64 * q;
         if (idx < 8 * LT_N) {
-          const int e = idx >= 4 * LT_N ? 1 : 0, r = idx - 4 * LT_N * e, j = r / LT_N, c = r - LT_N * j;
-          ((double *)&lt[2 * j + e])[c] = terms[(slot0 + e) * (4 * LT_N) + r];
+          const int e = idx >= 4 * LT_N ? 1 : 0, r4 = idx - 4 * LT_N * e, j = r4 / LT_N, r = r4 - LT_N * j;
+          Ls[pb::record_dest(j, e, r)] = terms[(slot0 + e) * (4 * LT_N) + r4];
         }
+      }
+      if (lane == 0) {
+        const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
+        const m3 kappa_7 = I3 - Rwx * dt;
+        double *pool = Ls + pb::O_POOL;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          pool[9 * pb::S_R0 + q] = R0.a[q]; pool[9 * pb::S_R1 + q] = R1.a[q]; pool[9 * pb::S_K7 + q] = kappa_7.a[q];
+          pool[9 * pb::S_RA0 + q] = Ra0.a[q]; pool[9 * pb::S_RA1 + q] = Ra1.a[q]; pool[9 * pb::S_RWX + q] = Rwx.a[q];
+        }
+        pb::coefficients(dt, Ls + pb::O_COEF);
       }
     }
     __syncthreads();
-    if (lane < 8) {
-      const m3 &Re = (lane & 1) ? R1 : R0;
-      const v3 g = -(Re * ld3(lt[lane].g));
-      const m3 h = Re * ld_m3_rowmajor(lt[lane].h);
-      st3(lt[lane].g, g);
-      for (int q = 0; q < 9; ++q) lt[lane].h[q] = h.a[q];
-    }
-    __syncthreads();
+    // first-level products R_e X and -(R_e g_0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
+    pb::gvec_entry(lane, Ls);
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
     for (int j = 0; j < 4; ++j) {
-      lo_v[j] = (qrot(dq, ld3(lt[2 * j].v)) + qrot(rq, ld3(lt[2 * j + 1].v))) * 0.5;
+      lo_v[j] = (qrot(dq, ld3(Ls + pb::O_VV + 6 * j)) + qrot(rq, ld3(Ls + pb::O_VV + 6 * j + 3))) * 0.5;
       r_eps[j] = eps[j] + lo_v[j] * dt;
     }
     if (lane == 0) {
@@ -369,55 +388,16 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       for (int k = 0; k < 12; ++k) nd[30 + k] = unc[k];
       for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
     }
-    // dF = F - I and V blocks (:376-465): lane 0 the IMU rows, lanes 1..4 the epsilon rows of leg (lane - 1), lane 5 the identities
-    const v3 a0 = acc_0 - ba, a1 = acc_1 - ba;
-    const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
-    const m3 kappa_7 = I3 - Rwx * dt;
-    if (lane == 0) {
-      const m3 kappa_1 = (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * kappa_7) * (-0.5 * dt);
-      put33(Fm, FLD, 0, 3, kappa_1 * (0.5 * dt));
-      put33(Fm, FLD, 0, 6, I3 * dt);
-      put33(Fm, FLD, 0, 21, (R0 + R1) * (-0.25 * dt * dt));
-      put33(Fm, FLD, 0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
-      put33(Fm, FLD, 3, 3, Rwx * (-dt));   // kappa_7 - I
-      put33(Fm, FLD, 3, 24, I3 * (-1.0 * dt));
-      put33(Fm, FLD, 6, 3, kappa_1);
-      put33(Fm, FLD, 6, 21, (R0 + R1) * (-0.5 * dt));
-      put33(Fm, FLD, 6, 24, (R1 * Ra1) * (0.5 * dt * dt));
-      const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt);
-      put33(Vm, VLD, 0, 0, R0 * (0.25 * dt * dt));
-      put33(Vm, VLD, 0, 3, VpG);
-      put33(Vm, VLD, 0, 6, R1 * (0.25 * dt * dt));
-      put33(Vm, VLD, 0, 9, VpG);
-      put33(Vm, VLD, 3, 3, I3 * (0.5 * dt));
-      put33(Vm, VLD, 3, 9, I3 * (0.5 * dt));
-      const m3 VvG = (R1 * Ra1) * (-0.5 * dt * 0.5 * dt);
-      put33(Vm, VLD, 6, 0, R0 * (0.5 * dt));
-      put33(Vm, VLD, 6, 3, VvG);
-      put33(Vm, VLD, 6, 6, R1 * (0.5 * dt));
-      put33(Vm, VLD, 6, 9, VvG);
-    } else if (lane >= 1 && lane <= 4) {
-      const int j = lane - 1, e = 9 + 3 * j;
-      const v3 vi = ld3(lt[2 * j].v), vi1 = ld3(lt[2 * j + 1].v), fi = ld3(lt[2 * j].f), fi1 = ld3(lt[2 * j + 1].f);
-      const m3 Ji = ld_m3_rowmajor(lt[2 * j].J), Ji1 = ld_m3_rowmajor(lt[2 * j + 1].J);
-      const m3 hi = ld_m3_rowmajor(lt[2 * j].h), hi1 = ld_m3_rowmajor(lt[2 * j + 1].h);
-      const v3 gi = ld3(lt[2 * j].g), gi1 = ld3(lt[2 * j + 1].g);
-      put33(Fm, FLD, e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
-      put33(Fm, FLD, e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(pbr + Rbr * fi) + R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
-      const v3 gsum = (gi + gi1) * (0.5 * dt);
-      Fm[(e + 0) * FLD + 27 + j] = gsum.x; Fm[(e + 1) * FLD + 27 + j] = gsum.y; Fm[(e + 2) * FLD + 27 + j] = gsum.z;
-      put33(Vm, VLD, e, 3, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R0 * skew(pbr + Rbr * fi)) * (0.5 * dt));
-      put33(Vm, VLD, e, 9, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R1 * skew(pbr + Rbr * fi1)) * (0.5 * dt));
-      put33(Vm, VLD, e, 18, hi * (-0.5 * dt));
-      put33(Vm, VLD, e, 21, hi1 * (-0.5 * dt));
-      put33(Vm, VLD, e, 24, (R0 * Rbr * Ji) * (-0.5 * dt));
-      put33(Vm, VLD, e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
-      put33(Vm, VLD, e, 30 + 3 * j, I3 * (-dt));
-    } else if (lane == 5) {
-      for (int j = 0; j < 4; ++j) Vm[(27 + j) * VLD + 42 + j] = -dt;
-      put33(Vm, VLD, 21, 12, I3 * (-dt));
-      put33(Vm, VLD, 24, 15, I3 * (-dt));
-    }
+    __syncthreads();
+    // second level: (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e
+#pragma unroll
+    for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
+    __syncthreads();
+    pb::block_entry(bdesc[0], pb_ent, Ls);   // kappa_1 and R_0 + R_1, which other blocks read
+    __syncthreads();
+#pragma unroll
+    for (int r = 1; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[r], pb_ent, Ls);
+    pb::tail_entry(lane, dt, Ls);
     __syncthreads();
     jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm);
     // propagate() (:88-136)

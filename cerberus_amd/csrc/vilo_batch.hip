@@ -606,7 +606,7 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
     bt->rp_cap = (size_t)offsets[n];
     int rc = dev_alloc(ctx, bt, &bt->rp_s, bt->rp_cap);
     if (rc == VILO_OK && !bt->rp_o) rc = dev_alloc(ctx, bt, &bt->rp_o, n + 1);
-    if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->rp_t, bt->rp_cap * 108);   // 4 legs x 27 doubles per sample
+    if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->rp_t, bt->rp_cap * (size_t)(4 * VILO_LEG_REC));   // 4 legs x one record per sample
     if (rc != VILO_OK) { bt->rp_s = nullptr; bt->rp_cap = 0; return rc; }
   }
   vilo_sample *d_s = bt->rp_s;

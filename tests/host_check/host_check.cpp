@@ -4,6 +4,7 @@
 #include "../../cerberus_amd/csrc/factors.hpp"
 #include "../../cerberus_amd/csrc/visual_lin.hpp"
 #include "../../cerberus_amd/csrc/assemble_compact.hpp"
+#include "../../cerberus_amd/csrc/preint_blocks.hpp"
 #include "../../include/vilo_gpu.h"
 
 using namespace vilo;
@@ -133,6 +134,95 @@ void hc_assemble_compact(int nch, const unsigned *chunk_tab, const double *slots
       for (int grp = 0; grp < 3; ++grp) p[grp] = ac_t8_partial(q, grp, 3, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt);
       ac_t8_apply(q, (p[0] + p[1]) + p[2], rmw);
     }
+  }
+}
+
+// dF = F - I (32 x 31, row-major) and V (32 x 48) of one midpoint step of IMULegIntegrationBase.
+// in: R0[9] R1[9] un_gyr[3] a0[3] a1[3] Rbr[9] dt, then per (leg j, endpoint e), q = 2 j + e: v[3] p[3] h0[9] J[9] g0[3]  (27 doubles each).
+// mode 0: the blocks written out one after the other as the reference writes them (imu_leg_integration_base.cpp:376-465), 3 x 3
+// temporaries; mode 1: the product's lane-parallel construction (preint_blocks.hpp), its 64 lanes emulated round by round.
+void hc_preint_blocks(int mode, const double *in, double *dF, double *V) {
+  const m3 R0 = ld_m3_rowmajor(in), R1 = ld_m3_rowmajor(in + 9), Rbr = ld_m3_rowmajor(in + 27);
+  const v3 un_gyr = ld3(in + 18), a0 = ld3(in + 21), a1 = ld3(in + 24);
+  const double dt = in[36];
+  const double *legs = in + 37;
+  const m3 I3 = m3_eye();
+  const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
+  const m3 kappa_7 = I3 - Rwx * dt;
+  for (int i = 0; i < 32 * 31; ++i) dF[i] = 0.0;
+  for (int i = 0; i < 32 * 48; ++i) V[i] = 0.0;
+  if (mode == 0) {
+    auto putF = [&](int r0, int c0, const m3 &A) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) dF[(r0 + a) * 31 + c0 + b] = A.a[3 * a + b]; };
+    auto putV = [&](int r0, int c0, const m3 &A) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) V[(r0 + a) * 48 + c0 + b] = A.a[3 * a + b]; };
+    const m3 kappa_1 = (R0 * Ra0) * (-0.5 * dt) + (R1 * Ra1 * kappa_7) * (-0.5 * dt);
+    putF(0, 3, kappa_1 * (0.5 * dt));
+    putF(0, 6, I3 * dt);
+    putF(0, 21, (R0 + R1) * (-0.25 * dt * dt));
+    putF(0, 24, (R1 * Ra1) * (0.25 * dt * dt * dt));
+    putF(3, 3, Rwx * (-dt));
+    putF(3, 24, I3 * (-1.0 * dt));
+    putF(6, 3, kappa_1);
+    putF(6, 21, (R0 + R1) * (-0.5 * dt));
+    putF(6, 24, (R1 * Ra1) * (0.5 * dt * dt));
+    const m3 VpG = (R1 * Ra1) * (-0.25 * dt * dt * 0.5 * dt);
+    putV(0, 0, R0 * (0.25 * dt * dt)); putV(0, 3, VpG); putV(0, 6, R1 * (0.25 * dt * dt)); putV(0, 9, VpG);
+    putV(3, 3, I3 * (0.5 * dt)); putV(3, 9, I3 * (0.5 * dt));
+    const m3 VvG = (R1 * Ra1) * (-0.5 * dt * 0.5 * dt);
+    putV(6, 0, R0 * (0.5 * dt)); putV(6, 3, VvG); putV(6, 6, R1 * (0.5 * dt)); putV(6, 9, VvG);
+    for (int j = 0; j < 4; ++j) {
+      const int e = 9 + 3 * j;
+      const double *l0 = legs + 27 * (2 * j), *l1 = legs + 27 * (2 * j + 1);
+      const v3 vi = ld3(l0), vi1 = ld3(l1), p0 = ld3(l0 + 3), p1 = ld3(l1 + 3);
+      const m3 hi = R0 * ld_m3_rowmajor(l0 + 6), hi1 = R1 * ld_m3_rowmajor(l1 + 6), Ji = ld_m3_rowmajor(l0 + 15), Ji1 = ld_m3_rowmajor(l1 + 15);
+      const v3 gi = -(R0 * ld3(l0 + 24)), gi1 = -(R1 * ld3(l1 + 24));
+      putF(e, 3, (R0 * skew(vi)) * (-0.5 * dt) - (R1 * skew(vi1) * kappa_7) * (0.5 * dt));
+      putF(e, 24, (R1 * skew(vi1)) * (0.5 * dt * dt) - (R0 * skew(p0) + R1 * skew(p1)) * (0.5 * dt));
+      const v3 gsum = (gi + gi1) * (0.5 * dt);
+      dF[(e + 0) * 31 + 27 + j] = gsum.x; dF[(e + 1) * 31 + 27 + j] = gsum.y; dF[(e + 2) * 31 + 27 + j] = gsum.z;
+      putV(e, 3, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R0 * skew(p0)) * (0.5 * dt));
+      putV(e, 9, (R1 * skew(vi1)) * (-0.25 * dt * dt) + (R1 * skew(p1)) * (0.5 * dt));
+      putV(e, 18, hi * (-0.5 * dt));
+      putV(e, 21, hi1 * (-0.5 * dt));
+      putV(e, 24, (R0 * Rbr * Ji) * (-0.5 * dt));
+      putV(e, 27, (R1 * Rbr * Ji1) * (-0.5 * dt));
+      putV(e, 30 + 3 * j, I3 * (-dt));
+    }
+    for (int j = 0; j < 4; ++j) V[(27 + j) * 48 + 42 + j] = -dt;
+    putV(21, 12, I3 * (-dt));
+    putV(24, 15, I3 * (-dt));
+    return;
+  }
+  static const pb::Tables tab = pb::make_tables();
+  double L[pb::PB_TOTAL];
+  for (int i = 0; i < pb::PB_TOTAL; ++i) L[i] = 0.0;
+  auto putS = [&](int slot, const m3 &A) { for (int q = 0; q < 9; ++q) L[pb::O_POOL + 9 * slot + q] = A.a[q]; };
+  putS(pb::S_R0, R0); putS(pb::S_R1, R1); putS(pb::S_K7, kappa_7); putS(pb::S_RA0, Ra0); putS(pb::S_RA1, Ra1); putS(pb::S_RWX, Rwx);
+  putS(pb::S_RBR, Rbr); putS(pb::S_I, I3);
+  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 2; ++e) {
+      const double *l = legs + 27 * (2 * j + e);
+      double rec[pb::REC_N];
+      const m3 skv = skew(ld3(l)), skp = skew(ld3(l + 3));
+      for (int q = 0; q < 9; ++q) { rec[q] = skv.a[q]; rec[9 + q] = skp.a[q]; rec[18 + q] = l[6 + q]; rec[27 + q] = l[15 + q]; }
+      for (int q = 0; q < 3; ++q) { rec[36 + q] = l[24 + q]; rec[39 + q] = l[q]; }
+      for (int r = 0; r < pb::REC_N; ++r) L[pb::record_dest(j, e, r)] = rec[r];
+    }
+  pb::coefficients(dt, L + pb::O_COEF);
+  auto grp_of = [](int lane) { return lane < 63 ? lane / 9 : 7; };
+  for (int round = 0; round < 4; ++round)
+    for (int lane = 0; lane < 64; ++lane)
+      if (grp_of(lane) < 7) pb::product_entry(tab.prod[7 * round + grp_of(lane)], lane % 9, L);
+  for (int lane = 0; lane < 64; ++lane) pb::gvec_entry(lane, L);
+  for (int round = 4; round < 6; ++round)
+    for (int lane = 0; lane < 64; ++lane)
+      if (grp_of(lane) < 7) pb::product_entry(tab.prod[7 * round + grp_of(lane)], lane % 9, L);
+  for (int round = 0; round < pb::N_BLK_ROUNDS; ++round)
+    for (int lane = 0; lane < 64; ++lane)
+      if (grp_of(lane) < 7) pb::block_entry(tab.blk[7 * round + grp_of(lane)], lane % 9, L);
+  for (int lane = 0; lane < 64; ++lane) pb::tail_entry(lane, dt, L);
+  for (int r = 0; r < 32; ++r) {
+    for (int k = 0; k < 16; ++k) dF[r * 31 + pb::fk_col(k)] = L[pb::O_FC + r * pb::FCLD + k];
+    for (int c = 0; c < 48; ++c) V[r * 48 + c] = L[pb::O_VM + r * pb::VLD + c];
   }
 }
 }

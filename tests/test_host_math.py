@@ -20,7 +20,8 @@ def hc():
     d = os.path.join(ROOT, "tests", "host_check")
     so = os.path.join(d, "libhostcheck.so")
     srcs = [os.path.join(d, "host_check.cpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "factors.hpp"),
-            os.path.join(ROOT, "cerberus_amd", "csrc", "vilo_math.hpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "visual_lin.hpp")]
+            os.path.join(ROOT, "cerberus_amd", "csrc", "vilo_math.hpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "visual_lin.hpp"),
+            os.path.join(ROOT, "cerberus_amd", "csrc", "assemble_compact.hpp"), os.path.join(ROOT, "cerberus_amd", "csrc", "preint_blocks.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
     lib = C.CDLL(so)
@@ -272,3 +273,29 @@ def test_compact_rows_and_their_assembly_match_the_23_column_form(hc):
     assert np.all(np.triu(Hc, 1) == 0.0)
     np.testing.assert_allclose(gc[keep], g[keep], rtol=0, atol=2e-13 * np.abs(g).max())
     assert np.count_nonzero(Hl) > 1500
+
+
+def test_lane_parallel_preintegration_blocks_match_the_blocks_written_out(hc):
+    """cerberus_amd/csrc/preint_blocks.hpp (table-driven, one lane per 3 x 3 entry: what k_preint_imu_leg / k_repropagate run per sample)
+    against dF = F - I and V of IMULegIntegrationBase::midPointIntegration written block by block with 3 x 3 temporaries
+    (imu_leg_integration_base.cpp:376-465). Same products, sums of scaled terms instead of scaled sums: equal to a few ulp."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        inp = np.zeros(37 + 8 * 27)
+        for o in (0, 9):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            inp[o:o + 9] = O.quat_to_rot(q).ravel() if hasattr(O, "quat_to_rot") else np.linalg.qr(rng.normal(size=(3, 3)))[0].ravel()
+        inp[18:27] = rng.normal(size=9) * [1, 1, 1, 9, 9, 9, 9, 9, 9]
+        inp[27:36] = np.linalg.qr(rng.normal(size=(3, 3)))[0].ravel()
+        inp[36] = 0.0025 * (1 + 0.1 * rng.random())
+        inp[37:] = rng.normal(size=8 * 27)
+        out = []
+        for mode in (0, 1):
+            dF, V = np.zeros(32 * 31), np.zeros(32 * 48)
+            hc.hc_preint_blocks(mode, P(inp), P(dF), P(V))
+            out.append((dF.reshape(32, 31), V.reshape(32, 48)))
+        for a, b, name in ((out[1][0], out[0][0], "dF"), (out[1][1], out[0][1], "V")):
+            assert (a != 0).sum() == (b != 0).sum() and ((a != 0) == (b != 0)).all(), name   # the same sparsity pattern
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() <= 4e-16 * max(1.0, scale) + 1e-15 * np.abs(b).max(), (name, np.abs(a - b).max())
+        assert np.count_nonzero(out[0][0]) >= 140 and np.count_nonzero(out[0][1]) >= 300, (np.count_nonzero(out[0][0]), np.count_nonzero(out[0][1]))
