@@ -239,21 +239,15 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   v3 eps[4];
   for (int j = 0; j < 4; ++j) eps[j] = mk3(0, 0, 0);
   double sum_dt = 0.0;
-  // type-2 contact filter state (imu_leg_integration_base.h:100-108)
-  double ff_min[4] = {0, 0, 0, 0}, ff_max[4] = {0, 0, 0, 0}, ff_win[4][5], ff_var[4] = {0, 0, 0, 0};
-  int ff_idx[4] = {0, 0, 0, 0};
-  for (int j = 0; j < 4; ++j)
-    for (int k = 0; k < 5; ++k) ff_win[j][k] = 0.0;
+  // type-2 contact filter state (imu_leg_integration_base.h:100-108) lives in LDS (zeroed with the rest below): min [0..4), max [4..8),
+  // variance [8..12), window [12 + 5 leg + k], index [32..36). Every lane reads it (broadcast), lane 0 writes it back.
+  double *const ffs = Ls + pb::O_FF;
   if (STREAM) {
     const vilo_preint &r = st->rec;
     dp = ld3(r.delta_p); dv = ld3(r.delta_v);
     dq = mkq(r.delta_q[3], r.delta_q[0], r.delta_q[1], r.delta_q[2]);
     for (int j = 0; j < 4; ++j) eps[j] = ld3(r.delta_eps + 3 * j);
     sum_dt = r.sum_dt;
-    for (int j = 0; j < 4; ++j) {
-      ff_min[j] = st->ff_min[j]; ff_max[j] = st->ff_max[j]; ff_var[j] = st->ff_var[j]; ff_idx[j] = st->ff_idx[j];
-      for (int k = 0; k < 5; ++k) ff_win[j][k] = st->ff_win[5 * j + k];
-    }
     for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = 0.0; Pm[e] = 0.0; }
     __syncthreads();
     for (int e = lane; e < 31 * 31; e += 64) { Jm[(e / 31) * FLD + (e % 31)] = r.jacobian[e]; Pm[(e / 31) * FLD + (e % 31)] = r.covariance[e]; }
@@ -267,6 +261,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
   if (lane < 9) { Ls[pb::O_POOL + 9 * pb::S_RBR + lane] = cfg.R_br[lane]; Ls[pb::O_POOL + 9 * pb::S_I + lane] = (lane % 4 == 0) ? 1.0 : 0.0; }
+  if (STREAM && lane < 36) ffs[lane] = lane < 4 ? st->ff_min[lane] : lane < 8 ? st->ff_max[lane - 4] : lane < 12 ? st->ff_var[lane - 8] : lane < 32 ? st->ff_win[lane - 12] : (double)st->ff_idx[lane - 32];
   // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
   // (batch: the constructor's sample; streaming: the last sample of the previous push)
   {
@@ -280,6 +275,26 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     __syncthreads();
   }
 
+  // the records of a step's two samples, one step ahead of their use: element lane + 64 q of [endpoint][leg][LT_N]
+  double rec[6];
+  int rec_dst[6], rec_src[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int idx = min(lane + 64 * q, 8 * LT_N - 1);
+    const int e = idx >= 4 * LT_N ? 1 : 0, r4 = idx - 4 * LT_N * e, j = r4 / LT_N, r = r4 - LT_N * j;
+    rec_dst[q] = pb::record_dest(j, e, r);
+    rec_src[q] = e * (4 * LT_N) + r4;
+    rec[q] = 0.0;
+  }
+  auto load_records = [&](int si) {
+    const double *src = terms + (size_t)(si - 1 - s_begin + (STREAM ? 1 : 0)) * (4 * LT_N);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rec[q] = src[rec_src[q]];
+  };
+  {
+    const int si0 = STREAM ? s_begin : s_begin + 1;
+    if (si0 < s_end) load_records(si0);
+  }
   for (int si = STREAM ? s_begin : s_begin + 1; si < s_end; ++si) {
     const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
     const double dt = s1.dt;
@@ -296,42 +311,41 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     const m3 R0 = qR(dq), R1 = qR(rq);
     // contact flags (:183-229); integer-valued as in the reference (Vector4i foot_contact_flag)
     int flag[4];
+    double ff_var[4] = {0.0, 0.0, 0.0, 0.0};
     if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
       for (int j = 0; j < 4; ++j) flag[j] = s1.c[j] >= 0.5 ? 1 : 0;
     } else {
       for (int j = 0; j < 4; ++j) {
         const double force_mag = 0.5 * (s0.c[j] + s1.c[j]);
-        if (force_mag < ff_min[j]) ff_min[j] = 0.9 * ff_min[j] + 0.1 * force_mag;
-        if (force_mag > ff_max[j]) ff_max[j] = 0.9 * ff_max[j] + 0.1 * force_mag;
-        ff_min[j] *= 0.9991;
-        ff_max[j] *= 0.997;
-        const double thr = ff_min[j] + cfg.v_n_force_thres_ratio * (ff_max[j] - ff_min[j]);
+        double fmn = ffs[j], fmx = ffs[4 + j];
+        if (force_mag < fmn) fmn = 0.9 * fmn + 0.1 * force_mag;
+        if (force_mag > fmx) fmx = 0.9 * fmx + 0.1 * force_mag;
+        fmn *= 0.9991;
+        fmx *= 0.997;
+        const double thr = fmn + cfg.v_n_force_thres_ratio * (fmx - fmn);
         flag[j] = (int)(1.0 / (1 + exp(-cfg.v_n_term1_steep * (force_mag - thr))));
-        ff_idx[j] = (ff_idx[j] + 1) % 5;
-        // dynamic index into a register array would go to scratch: rewrite the 5-window by select
-        for (int k = 0; k < 5; ++k) ff_win[j][k] = (k == ff_idx[j]) ? force_mag : ff_win[j][k];
+        const int fidx = ((int)ffs[32 + j] + 1) % 5;
+        double win[5];
+        for (int k = 0; k < 5; ++k) win[k] = (k == fidx) ? force_mag : ffs[12 + 5 * j + k];
         double mean = 0;
-        for (int k = 0; k < 5; ++k) mean += ff_win[j][k];
+        for (int k = 0; k < 5; ++k) mean += win[k];
         mean /= 5;
         double ss = 0;
-        for (int k = 0; k < 5; ++k) ss += (ff_win[j][k] - mean) * (ff_win[j][k] - mean);
+        for (int k = 0; k < 5; ++k) ss += (win[k] - mean) * (win[k] - mean);
         ff_var[j] = ss / 4;
+        // (LDS operations of one wave complete in order: the reads above precede these writes)
+        if (lane == 0) { ffs[j] = fmn; ffs[4 + j] = fmx; ffs[8 + j] = ff_var[j]; ffs[12 + 5 * j + fidx] = force_mag; ffs[32 + j] = (double)fidx; }
       }
     }
     // dF = F - I and V (:232-287, :376-465), every 3 x 3 product entry and every output entry on its own lane (preint_blocks.hpp).
-    // The pool's inputs: the two samples' records come back from HBM (336 doubles, six coalesced loads) into the slots of (leg, endpoint);
-    // lane 0 adds the step's own matrices and the powers of dt.
+    // The pool's inputs: the two samples' records (336 doubles, six coalesced loads, issued one step ahead) go to the slots of
+    // (leg, endpoint); lane 0 adds the step's own matrices and the powers of dt.
     const v3 a0 = acc_0 - ba, a1 = acc_1 - ba;
     {
-      const size_t slot0 = (size_t)(si - 1 - s_begin + (STREAM ? 1 : 0));
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int idx = lane + 64 * q;
-        if (idx < 8 * LT_N) {
-          const int e = idx >= 4 * LT_N ? 1 : 0, r4 = idx - 4 * LT_N * e, j = r4 / LT_N, r = r4 - LT_N * j;
-          Ls[pb::record_dest(j, e, r)] = terms[(slot0 + e) * (4 * LT_N) + r4];
-        }
-      }
+      for (int q = 0; q < 6; ++q)
+        if (lane + 64 * q < 8 * LT_N) Ls[rec_dst[q]] = rec[q];
+      if (si + 1 < s_end) load_records(si + 1);
       if (lane == 0) {
         const m3 Rwx = skew(un_gyr), Ra0 = skew(a0), Ra1 = skew(a1);
         const m3 kappa_7 = I3 - Rwx * dt;
@@ -349,10 +363,21 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
     pb::gvec_entry(lane, Ls);
+    // the halves q_e v of the leg-odometry velocities (:245): lane 2 leg + endpoint, lanes 0 .. 7
+    {
+      const int q = lane & 7;
+      const quat Q = (q & 1) ? rq : dq;
+      const v3 r = qrot(Q, ld3(Ls + pb::O_VV + 3 * q));
+      if (lane < 8) st3(Ls + pb::O_LOV + 3 * q, r);
+    }
+    __syncthreads();
+    // second level: (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e
+#pragma unroll
+    for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
     for (int j = 0; j < 4; ++j) {
-      lo_v[j] = (qrot(dq, ld3(Ls + pb::O_VV + 6 * j)) + qrot(rq, ld3(Ls + pb::O_VV + 6 * j + 3))) * 0.5;
+      lo_v[j] = (ld3(Ls + pb::O_LOV + 6 * j) + ld3(Ls + pb::O_LOV + 6 * j + 3)) * 0.5;
       r_eps[j] = eps[j] + lo_v[j] * dt;
     }
     if (lane == 0) {
@@ -389,14 +414,8 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
     }
     __syncthreads();
-    // second level: (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e
 #pragma unroll
-    for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
-    __syncthreads();
-    pb::block_entry(bdesc[0], pb_ent, Ls);   // kappa_1 and R_0 + R_1, which other blocks read
-    __syncthreads();
-#pragma unroll
-    for (int r = 1; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[r], pb_ent, Ls);
+    for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[r], pb_ent, Ls);
     pb::tail_entry(lane, dt, Ls);
     __syncthreads();
     jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm);
@@ -416,8 +435,8 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       st->last = samples[s_end - 1];
       st->n_pushed += s_end - s_begin;
       for (int j = 0; j < 4; ++j) {
-        st->ff_min[j] = ff_min[j]; st->ff_max[j] = ff_max[j]; st->ff_var[j] = ff_var[j]; st->ff_idx[j] = ff_idx[j];
-        for (int k = 0; k < 5; ++k) st->ff_win[5 * j + k] = ff_win[j][k];
+        st->ff_min[j] = ffs[j]; st->ff_max[j] = ffs[4 + j]; st->ff_var[j] = ffs[8 + j]; st->ff_idx[j] = (int)ffs[32 + j];
+        for (int k = 0; k < 5; ++k) st->ff_win[5 * j + k] = ffs[12 + 5 * j + k];
       }
     }
   }

@@ -7,9 +7,8 @@
 //            per (leg, endpoint) [v]x, [p_br + R_br f]x, h_0, J (from the interval's precomputed sample records)
 //   level 1  28 products  R_e * X                       (4 rounds of 7 products x 9 entries = 63 lanes)
 //   level 2  13 products  (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e    (2 rounds)
-//   blocks   59 blocks of F / V / the pool, each  sum_k coef[c_k] * pool[s_k]  entry by entry (10 rounds; round 0 = the two pool blocks
-//            the others read: kappa_1 and R_0 + R_1)
-// The tables are compile-time constants; a lane keeps its 6 + 10 descriptors in registers for the whole interval.
+//   blocks   57 blocks of F and V, each  sum_k coef[c_k] * pool[s_k]  entry by entry (9 rounds)
+// The tables are compile-time constants; a lane keeps its 6 + 9 descriptors in registers for the whole interval.
 // Host-compilable: tests/host_check emulates the lanes and compares with the blocks written out as in the reference.
 #pragma once
 #if defined(__HIPCC__)
@@ -32,7 +31,9 @@ constexpr int N_SLOTS = 68;
 constexpr int O_GIN = O_POOL + 9 * N_SLOTS;  // [8 x 3] g_0 of (leg, endpoint)
 constexpr int O_GV = O_GIN + 24;             // [8 x 3] -(R_e g_0)
 constexpr int O_VV = O_GV + 24;              // [8 x 3] v of (leg, endpoint)
-constexpr int O_COEF = O_VV + 24;            // [16]
+constexpr int O_LOV = O_VV + 24;             // [8 x 3] q_e v of (leg, endpoint): the halves of the leg-odometry velocity
+constexpr int O_FF = O_LOV + 24;             // [36] contact-type-2 force filter: min, max, variance (4 each), window (4 x 5), index (4)
+constexpr int O_COEF = O_FF + 36;            // [16]
 constexpr int O_ND = O_COEF + 16;            // [48] noise diagonal
 constexpr int PB_TOTAL = O_ND + 48;
 
@@ -47,8 +48,6 @@ constexpr int S_S = 44, S_P = 52, S_H = 60;                      // + 2 * leg + 
 // second level and pool blocks, in the slots of first-level inputs that are dead by then
 constexpr int S_M3 = 8;       // (R_1 [a_1]x) kappa_7
 constexpr int S_S1K = 9;      // + leg: (R_1 [v_1]x) kappa_7
-constexpr int S_KAP1 = 13;    // kappa_1
-constexpr int S_RSUM = 14;    // R_0 + R_1
 constexpr int S_G = 16;       // + 2 * leg + endpoint: (R_e R_br) J_e
 
 // ---- sample record (per sample and leg, written once per interval): what the pool needs, in pool order ----
@@ -67,7 +66,7 @@ PB_HD void coefficients(double dt, double *c) {
 // ---- descriptors ----
 // product: A | B << 8 | D << 16 | 1 << 31;   pool[D] = pool[A] * pool[B]
 // block:   offset of its (0, 0) entry in the step's LDS array | ld << 16 | (coef | slot << 4) << 22 / 33 / 44 | 1 << 63
-constexpr int N_PROD1 = 28, N_PROD2 = 13, N_PROD_ROUNDS = 6, N_BLK_ROUNDS = 10;
+constexpr int N_PROD1 = 28, N_PROD2 = 13, N_PROD_ROUNDS = 6, N_BLK_ROUNDS = 9;
 struct Tables {
   unsigned prod[7 * N_PROD_ROUNDS];
   unsigned long long blk[7 * N_BLK_ROUNDS];
@@ -79,7 +78,6 @@ constexpr unsigned long long mk_blk(int off, int ld, int c0, int s0, int c1 = C_
 }
 constexpr int fc_off(int r, int c) { return O_FC + r * FCLD + kidx(c); }
 constexpr int vm_off(int r, int c) { return O_VM + r * VLD + c; }
-constexpr int pool_off(int s) { return O_POOL + 9 * s; }
 
 constexpr Tables make_tables() {
   Tables t{};
@@ -101,20 +99,17 @@ constexpr Tables make_tables() {
   for (int j = 0; j < 4; ++j) t.prod[n++] = mk_prod(S_S + 2 * j + 1, S_K7, S_S1K + j);
   for (int j = 0; j < 4; ++j)
     for (int e = 0; e < 2; ++e) t.prod[n++] = mk_prod(e ? S_RB1 : S_RB0, S_J + 2 * j + e, S_G + 2 * j + e);
-  // blocks. Round 0: kappa_1 = (R_0 [a_0]x) (-dt / 2) + (R_1 [a_1]x kappa_7) (-dt / 2)  (:380),  R_0 + R_1
+  // blocks. F - I, IMU rows (:382-399); kappa_1 = (R_0 [a_0]x) (-dt / 2) + (R_1 [a_1]x kappa_7) (-dt / 2) (:380) and R_0 + R_1 are
+  // sums of two pool matrices, so the blocks that scale them take both terms with the product of the scalings
   int m = 0;
-  t.blk[m++] = mk_blk(pool_off(S_KAP1), 3, C_MHDT, S_M1, C_MHDT, S_M3);
-  t.blk[m++] = mk_blk(pool_off(S_RSUM), 3, C_ONE, S_R0, C_ONE, S_R1);
-  m = 7;
-  // F - I, IMU rows (:382-399)
-  t.blk[m++] = mk_blk(fc_off(0, 3), FCLD, C_HDT, S_KAP1);
+  t.blk[m++] = mk_blk(fc_off(0, 3), FCLD, C_MQDT2, S_M1, C_MQDT2, S_M3);       // kappa_1 dt / 2
   t.blk[m++] = mk_blk(fc_off(0, 6), FCLD, C_DT, S_I);
-  t.blk[m++] = mk_blk(fc_off(0, 21), FCLD, C_MQDT2, S_RSUM);
+  t.blk[m++] = mk_blk(fc_off(0, 21), FCLD, C_MQDT2, S_R0, C_MQDT2, S_R1);
   t.blk[m++] = mk_blk(fc_off(0, 24), FCLD, C_QDT3, S_M2);
   t.blk[m++] = mk_blk(fc_off(3, 3), FCLD, C_MDT, S_RWX);
   t.blk[m++] = mk_blk(fc_off(3, 24), FCLD, C_MDT, S_I);
-  t.blk[m++] = mk_blk(fc_off(6, 3), FCLD, C_ONE, S_KAP1);
-  t.blk[m++] = mk_blk(fc_off(6, 21), FCLD, C_MHDT, S_RSUM);
+  t.blk[m++] = mk_blk(fc_off(6, 3), FCLD, C_MHDT, S_M1, C_MHDT, S_M3);         // kappa_1
+  t.blk[m++] = mk_blk(fc_off(6, 21), FCLD, C_MHDT, S_R0, C_MHDT, S_R1);
   t.blk[m++] = mk_blk(fc_off(6, 24), FCLD, C_HDT2, S_M2);
   // V, IMU rows (:420-438)
   t.blk[m++] = mk_blk(vm_off(0, 0), VLD, C_QDT2, S_R0);
@@ -145,7 +140,7 @@ constexpr Tables make_tables() {
   return t;
 }
 static_assert(N_PROD1 + N_PROD2 <= 7 * N_PROD_ROUNDS - 1, "product table");
-static_assert(7 + 21 + 36 <= 7 * N_BLK_ROUNDS, "block table");
+static_assert(21 + 36 <= 7 * N_BLK_ROUNDS, "block table");
 
 // ---- one lane's share of a round ----
 // entry ent (0 .. 8) of pool[D] = pool[A] * pool[B]: a_i0 b_0j + a_i1 b_1j + a_i2 b_2j, summed in that order
@@ -186,6 +181,7 @@ PB_HD void tail_entry(int lane, double dt, double *L) {
     L[vm_off(27 + j, 42 + j)] = -dt;
   }
 }
+// (the callers keep the quaternion rotation of the leg velocities, q_e v, in vilo_math's qrot: lanes 0 .. 7 store it at O_LOV + 3 lane)
 // where element r (0 .. REC_N - 1) of the sample record of (leg j, endpoint e) goes in the step's LDS array
 PB_HD int record_dest(int j, int e, int r) {
   const int q = 2 * j + e;

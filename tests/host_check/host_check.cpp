@@ -216,7 +216,7 @@ void hc_preint_blocks(int mode, const double *in, double *dF, double *V) {
   for (int round = 4; round < 6; ++round)
     for (int lane = 0; lane < 64; ++lane)
       if (grp_of(lane) < 7) pb::product_entry(tab.prod[7 * round + grp_of(lane)], lane % 9, L);
-  for (int round = 0; round < pb::N_BLK_ROUNDS; ++round)
+  for (int round = 0; round < pb::N_BLK_ROUNDS; ++round)   // (no round reads what another writes: any order)
     for (int lane = 0; lane < 64; ++lane)
       if (grp_of(lane) < 7) pb::block_entry(tab.blk[7 * round + grp_of(lane)], lane % 9, L);
   for (int lane = 0; lane < 64; ++lane) pb::tail_entry(lane, dt, L);
