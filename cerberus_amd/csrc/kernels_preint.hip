@@ -154,21 +154,20 @@ __device__ __forceinline__ void load32(const double *C, int ldc, mfma_d4 acc[4])
     for (int r = 0; r < 4; ++r) acc[t][r] = C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr];
 }
 // jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468); dFm = (F - I)[:, K].
-// Q = F P overwrites P in LDS once every product that reads P has its operands.
-__device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const double *Vm, const double *nd, double *Jm, double *Pm) {
-  mfma_d4 accJ[4], accQ[4];
-  load32(Jm, FLD, accJ);
-  load32(Pm, FLD, accQ);
+// Q = F P overwrites P in LDS once every product that reads P has its operands. accJ / accP: the jacobian and the covariance in
+// accumulator order, the same values as Jm / Pm (they stay in registers from one step to the next: LDS holds the operand-order copy).
+__device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const double *Vm, const double *nd, double *Jm, double *Pm, mfma_d4 accJ[4],
+                                                    mfma_d4 accP[4]) {
   gemm32_fk(dFm, Jm, accJ);   // J + dF J
-  gemm32_fk(dFm, Pm, accQ);   // Q = P + dF P
+  gemm32_fk(dFm, Pm, accP);   // Q = P + dF P
   __syncthreads();
   store32(Jm, FLD, accJ);
-  store32(Pm, FLD, accQ);
+  store32(Pm, FLD, accP);
   __syncthreads();
-  gemm32_fk_t(Pm, dFm, accQ);                        // Q + Q dF^T
-  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accQ);      // + V N V^T
+  gemm32_fk_t(Pm, dFm, accP);                        // Q + Q dF^T
+  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accP);      // + V N V^T
   __syncthreads();
-  store32(Pm, FLD, accQ);
+  store32(Pm, FLD, accP);
   __syncthreads();
 }
 
@@ -222,14 +221,14 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   __shared__ double Jm[32 * FLD], Pm[32 * FLD];
   double *const Fm = Ls + pb::O_FC, *const Vm = Ls + pb::O_VM, *const nd = Ls + pb::O_ND;
   const int lane = threadIdx.x;
-  // this lane's descriptors of the lane-parallel block construction: product / block (7 round + lane / 9), entry lane % 9; lane 63 idles
+  // this lane's descriptors of the lane-parallel block construction: product / block (8 round + lane / 9), entry lane % 9 (lane 63: the no-op)
   const int pb_grp = lane / 9, pb_ent = lane - 9 * pb_grp;
   unsigned pdesc[pb::N_PROD_ROUNDS];
   unsigned long long bdesc[pb::N_BLK_ROUNDS];
 #pragma unroll
-  for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[r] = pb_grp < 7 ? c_pb_tab.prod[7 * r + pb_grp] : 0u;
+  for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[r] = c_pb_tab.prod[8 * r + pb_grp];
 #pragma unroll
-  for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) bdesc[r] = pb_grp < 7 ? c_pb_tab.blk[7 * r + pb_grp] : 0ull;
+  for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) bdesc[r] = c_pb_tab.blk[8 * r + pb_grp];
   if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
   const v3 ba = ld3(ln), bg = ld3(ln + 3);
   double rho[4] = {ln[6], ln[7], ln[8], ln[9]};
@@ -261,6 +260,14 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
   if (lane < 9) { Ls[pb::O_POOL + 9 * pb::S_RBR + lane] = cfg.R_br[lane]; Ls[pb::O_POOL + 9 * pb::S_I + lane] = (lane % 4 == 0) ? 1.0 : 0.0; }
+  if (lane == 0) {
+    const double an2 = cfg.acc_n * cfg.acc_n, anz2 = cfg.acc_n_z * cfg.acc_n_z, gn2 = cfg.gyr_n * cfg.gyr_n;
+    const double aw2 = cfg.acc_w * cfg.acc_w, gw2 = cfg.gyr_w * cfg.gyr_w, pn2 = cfg.phi_n * cfg.phi_n, dpn2 = cfg.dphi_n * cfg.dphi_n;
+    nd[0] = an2; nd[1] = an2; nd[2] = anz2; nd[3] = gn2; nd[4] = gn2; nd[5] = gn2;
+    nd[6] = an2; nd[7] = an2; nd[8] = anz2; nd[9] = gn2; nd[10] = gn2; nd[11] = gn2;
+    for (int k = 0; k < 3; ++k) { nd[12 + k] = aw2; nd[15 + k] = gw2; }
+    for (int k = 0; k < 6; ++k) { nd[18 + k] = pn2; nd[24 + k] = dpn2; }
+  }
   if (STREAM && lane < 36) ffs[lane] = lane < 4 ? st->ff_min[lane] : lane < 8 ? st->ff_max[lane - 4] : lane < 12 ? st->ff_var[lane - 8] : lane < 32 ? st->ff_win[lane - 12] : (double)st->ff_idx[lane - 32];
   // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
   // (batch: the constructor's sample; streaming: the last sample of the previous push)
@@ -275,6 +282,9 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     __syncthreads();
   }
 
+  mfma_d4 accJ[4], accP[4];
+  load32(Jm, FLD, accJ);
+  load32(Pm, FLD, accP);
   // the records of a step's two samples, one step ahead of their use: element lane + 64 q of [endpoint][leg][LT_N]
   double rec[6];
   int rec_dst[6], rec_src[6];
@@ -404,12 +414,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
         for (int j = 0; j < 4; ++j) rho_unc[j] = cfg.rho_nc_n;
         for (int k = 0; k < 12; ++k) unc[k] = 10e10;
       }
-      const double an2 = cfg.acc_n * cfg.acc_n, anz2 = cfg.acc_n_z * cfg.acc_n_z, gn2 = cfg.gyr_n * cfg.gyr_n;
-      const double aw2 = cfg.acc_w * cfg.acc_w, gw2 = cfg.gyr_w * cfg.gyr_w, pn2 = cfg.phi_n * cfg.phi_n, dpn2 = cfg.dphi_n * cfg.dphi_n;
-      nd[0] = an2; nd[1] = an2; nd[2] = anz2; nd[3] = gn2; nd[4] = gn2; nd[5] = gn2;
-      nd[6] = an2; nd[7] = an2; nd[8] = anz2; nd[9] = gn2; nd[10] = gn2; nd[11] = gn2;
-      for (int k = 0; k < 3; ++k) { nd[12 + k] = aw2; nd[15 + k] = gw2; }
-      for (int k = 0; k < 6; ++k) { nd[18 + k] = pn2; nd[24 + k] = dpn2; }
+      // (nd[0 .. 30): the IMU, bias and encoder variances do not change from step to step: written before the loop)
       for (int k = 0; k < 12; ++k) nd[30 + k] = unc[k];
       for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
     }
@@ -418,7 +423,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[r], pb_ent, Ls);
     pb::tail_entry(lane, dt, Ls);
     __syncthreads();
-    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm);
+    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, accJ, accP);
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];

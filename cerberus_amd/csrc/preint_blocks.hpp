@@ -27,7 +27,7 @@ constexpr int VLD = 49;     // V: 32 x 48 (46 noise dimensions), odd leading dim
 constexpr int O_FC = 0;                      // [32 x 17]
 constexpr int O_VM = O_FC + 32 * FCLD;       // [32 x 49]
 constexpr int O_POOL = O_VM + 32 * VLD;      // [N_SLOTS x 9]
-constexpr int N_SLOTS = 68;
+constexpr int N_SLOTS = 69;                    // (the last one: where idle lanes write)
 constexpr int O_GIN = O_POOL + 9 * N_SLOTS;  // [8 x 3] g_0 of (leg, endpoint)
 constexpr int O_GV = O_GIN + 24;             // [8 x 3] -(R_e g_0)
 constexpr int O_VV = O_GV + 24;              // [8 x 3] v of (leg, endpoint)
@@ -35,7 +35,8 @@ constexpr int O_LOV = O_VV + 24;             // [8 x 3] q_e v of (leg, endpoint)
 constexpr int O_FF = O_LOV + 24;             // [36] contact-type-2 force filter: min, max, variance (4 each), window (4 x 5), index (4)
 constexpr int O_COEF = O_FF + 36;            // [16]
 constexpr int O_ND = O_COEF + 16;            // [48] noise diagonal
-constexpr int PB_TOTAL = O_ND + 48;
+constexpr int O_DUMMY = O_ND + 48;            // [9] where idle lanes write
+constexpr int PB_TOTAL = O_DUMMY + 9;
 
 PB_HD constexpr int kidx(int c) { return c < 9 ? c - 3 : c - 15; }      // column of F -> compact column (c in K)
 PB_HD constexpr int fk_col(int k) { return k < 6 ? 3 + k : 15 + k; }    // and back
@@ -49,6 +50,7 @@ constexpr int S_S = 44, S_P = 52, S_H = 60;                      // + 2 * leg + 
 constexpr int S_M3 = 8;       // (R_1 [a_1]x) kappa_7
 constexpr int S_S1K = 9;      // + leg: (R_1 [v_1]x) kappa_7
 constexpr int S_G = 16;       // + 2 * leg + endpoint: (R_e R_br) J_e
+constexpr int S_DUMMY = 68;
 
 // ---- sample record (per sample and leg, written once per interval): what the pool needs, in pool order ----
 constexpr int REC_MATS = 4;                  // [v]x, [p_br + R_br f]x, h_0, J
@@ -64,23 +66,27 @@ PB_HD void coefficients(double dt, double *c) {
 }
 
 // ---- descriptors ----
-// product: A | B << 8 | D << 16 | 1 << 31;   pool[D] = pool[A] * pool[B]
-// block:   offset of its (0, 0) entry in the step's LDS array | ld << 16 | (coef | slot << 4) << 22 / 33 / 44 | 1 << 63
+// product: A | B << 8 | D << 16;   pool[D] = pool[A] * pool[B]
+// block:   offset of its (0, 0) entry in the step's LDS array | ld << 16 | (coef | slot << 4) << 22 / 33 / 44
+// A round has 8 descriptors: 7 for the lanes' groups of 9, the eighth (and every unused one) a no-op into the dummy slot — no branches.
 constexpr int N_PROD1 = 28, N_PROD2 = 13, N_PROD_ROUNDS = 6, N_BLK_ROUNDS = 9;
 struct Tables {
-  unsigned prod[7 * N_PROD_ROUNDS];
-  unsigned long long blk[7 * N_BLK_ROUNDS];
+  unsigned prod[8 * N_PROD_ROUNDS];
+  unsigned long long blk[8 * N_BLK_ROUNDS];
 };
-constexpr unsigned mk_prod(int A, int B, int D) { return (unsigned)A | ((unsigned)B << 8) | ((unsigned)D << 16) | (1u << 31); }
+constexpr unsigned mk_prod(int A, int B, int D) { return (unsigned)A | ((unsigned)B << 8) | ((unsigned)D << 16); }
 constexpr unsigned long long mk_term(int c, int s) { return (unsigned long long)c | ((unsigned long long)s << 4); }
 constexpr unsigned long long mk_blk(int off, int ld, int c0, int s0, int c1 = C_ZERO, int s1 = S_I, int c2 = C_ZERO, int s2 = S_I) {
-  return (unsigned long long)off | ((unsigned long long)ld << 16) | (mk_term(c0, s0) << 22) | (mk_term(c1, s1) << 33) | (mk_term(c2, s2) << 44) | (1ull << 63);
+  return (unsigned long long)off | ((unsigned long long)ld << 16) | (mk_term(c0, s0) << 22) | (mk_term(c1, s1) << 33) | (mk_term(c2, s2) << 44);
 }
 constexpr int fc_off(int r, int c) { return O_FC + r * FCLD + kidx(c); }
 constexpr int vm_off(int r, int c) { return O_VM + r * VLD + c; }
 
 constexpr Tables make_tables() {
   Tables t{};
+  for (int i = 0; i < 8 * N_PROD_ROUNDS; ++i) t.prod[i] = mk_prod(S_I, S_I, S_DUMMY);
+  for (int i = 0; i < 8 * N_BLK_ROUNDS; ++i) t.blk[i] = mk_blk(O_DUMMY, 3, C_ZERO, S_I);
+  // (filled in order below, then spread to 8 per round at the end)
   int n = 0;
   // level 1 (rounds 0 .. 3)
   t.prod[n++] = mk_prod(S_R0, S_RA0, S_M1);
@@ -137,6 +143,19 @@ constexpr Tables make_tables() {
     t.blk[m++] = mk_blk(vm_off(e, 27), VLD, C_MHDT, S_G + 2 * j + 1);
     t.blk[m++] = mk_blk(vm_off(e, 30 + 3 * j), VLD, C_MDT, S_I);
   }
+  // spread: entry 7 r + g -> 8 r + g (from the back; slot 8 r + 7 stays the no-op)
+  for (int r = N_PROD_ROUNDS - 1; r >= 0; --r)
+    for (int g = 6; g >= 0; --g) {
+      const unsigned v = (7 * r + g < N_PROD1 + N_PROD2 + 1) ? t.prod[7 * r + g] : mk_prod(S_I, S_I, S_DUMMY);
+      t.prod[8 * r + g] = v;
+    }
+  for (int r = 0; r < N_PROD_ROUNDS; ++r) t.prod[8 * r + 7] = mk_prod(S_I, S_I, S_DUMMY);
+  for (int r = N_BLK_ROUNDS - 1; r >= 0; --r)
+    for (int g = 6; g >= 0; --g) {
+      const unsigned long long v = (7 * r + g < m) ? t.blk[7 * r + g] : mk_blk(O_DUMMY, 3, C_ZERO, S_I);
+      t.blk[8 * r + g] = v;
+    }
+  for (int r = 0; r < N_BLK_ROUNDS; ++r) t.blk[8 * r + 7] = mk_blk(O_DUMMY, 3, C_ZERO, S_I);
   return t;
 }
 static_assert(N_PROD1 + N_PROD2 <= 7 * N_PROD_ROUNDS - 1, "product table");
@@ -145,7 +164,6 @@ static_assert(21 + 36 <= 7 * N_BLK_ROUNDS, "block table");
 // ---- one lane's share of a round ----
 // entry ent (0 .. 8) of pool[D] = pool[A] * pool[B]: a_i0 b_0j + a_i1 b_1j + a_i2 b_2j, summed in that order
 PB_HD void product_entry(unsigned d, int ent, double *L) {
-  if (!(d >> 31)) return;
   const int A = d & 0xff, B = (d >> 8) & 0xff, D = (d >> 16) & 0xff;
   const int i = ent / 3, j = ent - 3 * i;
   const double *a = L + O_POOL + 9 * A + 3 * i, *b = L + O_POOL + 9 * B + j;
@@ -153,7 +171,6 @@ PB_HD void product_entry(unsigned d, int ent, double *L) {
 }
 // entry ent of a block: sum_k coef[c_k] * pool[s_k][ent]
 PB_HD void block_entry(unsigned long long d, int ent, double *L) {
-  if (!(d >> 63)) return;
   const int off = (int)(d & 0xffff), ld = (int)((d >> 16) & 0x3f);
   const int c0 = (int)((d >> 22) & 15), s0 = (int)((d >> 26) & 127), c1 = (int)((d >> 33) & 15), s1 = (int)((d >> 37) & 127),
             c2 = (int)((d >> 44) & 15), s2 = (int)((d >> 48) & 127);

@@ -211,14 +211,14 @@ void hc_preint_blocks(int mode, const double *in, double *dF, double *V) {
   auto grp_of = [](int lane) { return lane < 63 ? lane / 9 : 7; };
   for (int round = 0; round < 4; ++round)
     for (int lane = 0; lane < 64; ++lane)
-      if (grp_of(lane) < 7) pb::product_entry(tab.prod[7 * round + grp_of(lane)], lane % 9, L);
+      pb::product_entry(tab.prod[8 * round + grp_of(lane)], lane % 9, L);
   for (int lane = 0; lane < 64; ++lane) pb::gvec_entry(lane, L);
   for (int round = 4; round < 6; ++round)
     for (int lane = 0; lane < 64; ++lane)
-      if (grp_of(lane) < 7) pb::product_entry(tab.prod[7 * round + grp_of(lane)], lane % 9, L);
+      pb::product_entry(tab.prod[8 * round + grp_of(lane)], lane % 9, L);
   for (int round = 0; round < pb::N_BLK_ROUNDS; ++round)   // (no round reads what another writes: any order)
     for (int lane = 0; lane < 64; ++lane)
-      if (grp_of(lane) < 7) pb::block_entry(tab.blk[7 * round + grp_of(lane)], lane % 9, L);
+      pb::block_entry(tab.blk[8 * round + grp_of(lane)], lane % 9, L);
   for (int lane = 0; lane < 64; ++lane) pb::tail_entry(lane, dt, L);
   for (int r = 0; r < 32; ++r) {
     for (int k = 0; k < 16; ++k) dF[r * 31 + pb::fk_col(k)] = L[pb::O_FC + r * pb::FCLD + k];
