@@ -460,8 +460,11 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble_c(BatchDev b, int jaco
 // (3) back-substitution of the speed / leg-bias part: M_k and T_A of the frame in flight
 #define WB_M 0          // [169]
 #define WB_TA 176       // [169]
-// scratch during the chain: CH_* of chain_common.hpp (704)
-#define WX_LM 0         // (the Schur pass's per-trip flags reuse it)
+// scratch during the chain
+#define WX_LM 0         // 13 x 13: M_k = L_k^-1
+#define WX_TA0 176
+#define WX_TA1 352
+#define WX_SN 528       // 13 x 13: S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
 // scratch during the Cholesky
 #define WX_D16 0        // 16 x 17
 #define WX_LI16 272     // 16 x 17 + 16
@@ -561,22 +564,16 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
       for (int l = lane; l < L; l += 64) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
       PCLK(if (lane == 0) st.phase_clk[2] = clock64());
 
-      // ---- block-tridiagonal Cholesky chain of the speed / leg-bias part (chain_common.hpp): M_k, T_A(k) and the coupling rows T(k) go
-      //      out to global memory, the reduced right-hand side so far too. The middle stage of the three-stage form finds all of that
-      //      done by k_chain. ----
-      int fail = 0;
-      double *Tg = b.Tk + (size_t)win * TK_N;
-      if constexpr (!MID) {
-        fail = chain_to_global(bimg, gin, scr, lds + WC_DB, lds + WC_GB, Mg, TAg, Tg, Tg + TK_V, F, kb, mu, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (read back below, the right-hand side by other lanes)
-      }
       // ---- pose system: 15 lower tiles in accumulator order, one coalesced load per register ----
       mfma_d4 acc[15];
 #pragma unroll
       for (int t = 0; t < 15; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = Cimg[(t * 4 + r) * 64 + lane];
-      {
+      int fail = 0;
+      if constexpr (MID) {
+        // the chain's part comes from k_chain (chain_common.hpp) through global memory: T_B(k) in operand order, the reduced right-hand side
+        const double *Tg = b.Tk + (size_t)win * TK_N;
         // C -= T_B(k)^T T_B(k) for frames F-1 .. 0, operands as the chain left them (L2-resident; the next frame's in flight)
         for (int cd = lane; cd < 80; cd += 64) v[cd] = Tg[TK_V + cd];
         double tb[2][5][4];
@@ -613,6 +610,192 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
             upd(k - 1, s1);
           }
         }
+      } else {
+      // ---- block-tridiagonal Cholesky chain of the speed / leg-bias part (13 x 13 blocks, frames F-1 .. 0):
+      //        S_k = A_kk + mu D_k - T_A(k+1)^T T_A(k+1),  L_k = chol(S_k),  M_k = L_k^-1,  T_A(k) = M_k A_{k,k-1},
+      //        V = [B_k | g_k] - T_A(k+1)^T T(k+1),  T(k) = M_k V   (13 x 80: columns 0..78 coupling rows, column 79 = rhs),
+      //        C -= T_B(k)^T T_B(k),  rhs_P -= T_B(k)^T t_g(k).
+      //      The scalar part runs lane = row in the four 16-lane groups; T, V and the rank update are FP64-MFMA tiles whose accumulator
+      //      layout (register r of lane (lr, lk) = row lk + 4 r, column lr) is the operand layout of the next product. ----
+      {
+        const int grp = lk, c = lr;
+        const int row = c < 13 ? c : 0;
+        double *LM = scr + WX_LM, *SN = scr + WX_SN;
+        double *TAcur = scr + WX_TA0, *TAprev = scr + WX_TA1;
+        const double *DB = lds + WC_DB, *GB = lds + WC_GB;
+        mfma_d4 T[5];
+        double yr[5];
+#pragma unroll
+        for (int X = 0; X < 5; ++X) { T[X] = mfma_d4{0.0, 0.0, 0.0, 0.0}; yr[X] = 0.0; }
+        // this frame's blocks come from the assembled image one frame ahead of their use (registers nV / nrhs / nadn)
+        auto load_blocks = [&](int k, mfma_d4 *Vn, double *rhsn, double *adnn) {
+          // [B_k | g_k] in accumulator order: row lk + 4 r, column 16 X + lr (zero rows 13..15 in the image); column 79 carries the gradient
+#pragma unroll
+          for (int X = 0; X < 5; ++X) {
+            const int df = fX[X] - k + 1;
+            const bool on = df >= 0 && df <= 2;
+            const double *src = bimg + BI_BS + (k * 16 + lk) * 18 + 6 * min(max(df, 0), 2) + oX[X];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vn[X][r] = on ? src[72 * r] : 0.0;
+          }
+          if (k == kb) {
+#pragma unroll
+            for (int X = 0; X < 5; ++X)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Vn[X][r] += bimg[BI_BP + (lk + 4 * r) * 80 + 16 * X + lr];
+          }
+#pragma unroll
+          for (int i = 0; i < 13; ++i) rhsn[i] = (k > 0) ? bimg[BI_AOT + (max(k - 1, 0) * 13 + row) * 13 + i] : 0.0;   // column `row` of A_{k,k-1}
+#pragma unroll
+          for (int r = 0; r < 4; ++r) adnn[r] = (k > 0 && lr < 13 && lk + 4 * r < 13) ? bimg[BI_AD + max(k - 1, 0) * 169 + (lk + 4 * r) * 13 + lr] : 0.0;   // A_{k-1,k-1}, accumulator order
+        };
+        mfma_d4 nV[5];
+        double nrhs[13], nadn[4];
+        load_blocks(F - 1, nV, nrhs, nadn);
+        for (int k = F - 1; k >= 0; --k) {
+          const int x_lo = (k <= kb) ? 0 : max(0, (6 * (k - 1)) >> 4);   // T(k) is zero left of pose k - 1 (dense from the prior's frame down)
+          mfma_d4 V[5];
+          double a[13], l[13], rhs[13], adn[4];
+#pragma unroll
+          for (int X = 0; X < 5; ++X) V[X] = nV[X];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) rhs[i] = nrhs[i];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) adn[m] = nadn[m];
+          if (lr == 15) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) V[4][r] = (lk + 4 * r < 13) ? GB[13 * k + lk + 4 * r] : 0.0;
+          }
+          // S_k (lane = row): the top frame straight from A_kk, later frames from the update left by the previous step
+          if (k == F - 1) {
+#pragma unroll
+            for (int j = 0; j < 13; ++j) a[j] = bimg[BI_AD + (k * 13 + row) * 13 + j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 13; ++j) a[j] = SN[row * 13 + j];
+          }
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[16] = clock64());
+          {
+            const double md = mu * DB[13 * k + row];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) a[j] += (j == row) ? md : 0.0;
+          }
+          double myrinv = 1.0;
+#pragma unroll
+          for (int j = 0; j < 13; ++j) {
+            double piv = readlane_d(a[j], j);
+            if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+            const double rinv = rsqrt(piv);
+            const double lj = (c == j) ? piv * rinv : (c > j ? a[j] * rinv : 0.0);
+            l[j] = lj;
+            if (c == j) myrinv = rinv;
+#pragma unroll
+            for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
+          }
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[17] = clock64());
+          // forward substitutions L x = rhs: T_A(k) columns (group 0), L^-1 columns (group 1); L broadcast from the owning lanes
+          // (opaque copies: see chol16_tile)
+#pragma unroll
+          for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(l[j]));
+          double cl[13];
+#pragma unroll
+          for (int i = 0; i < 13; ++i) {
+            double vv = (grp == 0) ? rhs[i] : ((i == c) ? 1.0 : 0.0);
+#pragma unroll
+            for (int q = 0; q < i; ++q) vv -= readlane_d(l[q], i) * cl[q];
+            cl[i] = vv * readlane_d(myrinv, i);
+            asm volatile("" : "+v"(cl[i]));
+            __builtin_amdgcn_sched_barrier(0);   // (one row's v_readlane results at a time)
+          }
+          if (c < 13 && grp < 2) {
+            if (grp == 0) {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) { TAcur[i * 13 + c] = cl[i]; TAg[k * 169 + i * 13 + c] = cl[i]; }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) { LM[i * 13 + c] = cl[i]; Mg[k * 169 + i * 13 + c] = cl[i]; }
+            }
+          }
+          lds_fence();
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[18] = clock64());
+          // S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k): one 16 x 16 tile on the matrix cores (the operand serves as A and B)
+          if (k > 0) {
+            mfma_d4 sn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int q = 4 * kk + lk;
+              const double ta = ((lr < 13) && (q < 13)) ? TAcur[min(q, 12) * 13 + min(lr, 12)] : 0.0;
+              sn = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, ta, sn, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (lr < 13 && lk + 4 * r < 13) SN[(lk + 4 * r) * 13 + lr] = adn[r] - sn[r];
+          }
+          // V -= T_A(k+1)^T T(k+1);  T(k) = M_k V
+          double at[4], am[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int q = 4 * kk + lk;
+            const bool in = (lr < 13) && (q < 13);
+            const double ta = TAprev[min(q, 12) * 13 + min(lr, 12)], m = LM[min(lr, 12) * 13 + min(q, 12)];
+            at[kk] = (in && k < F - 1) ? -ta : 0.0;
+            am[kk] = in ? m : 0.0;
+          }
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[19] = clock64());
+          if (k < F - 1) {
+#pragma unroll
+            for (int X = 0; X < 5; ++X)
+              if (X >= x_lo) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) V[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], T[X][kk], V[X], 0, 0, 0);
+              }
+          }
+#pragma unroll
+          for (int X = 0; X < 5; ++X)
+            if (X >= x_lo) {
+              mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], V[X][kk], n, 0, 0, 0);
+              T[X] = n;
+            }
+          // the next frame's blocks: in flight behind the rank update below (V, rhs and adn of this frame are dead)
+          if (k > 0) load_blocks(k - 1, nV, nrhs, nadn);
+          // t_g(k) (column 79) to every lane of its 16-lane row group; the pose system must not see it
+          mfma_d4 T4 = T[4];
+          double tg[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            tg[kk] = __shfl(T[4][kk], (lane & 48) | 15, 64);
+            if (lr == 15) T4[kk] = 0.0;
+          }
+          // C -= T_B^T T_B, rhs_P -= T_B^T t_g
+#pragma unroll
+          for (int t = 0; t < 15; ++t) {
+            const int I = c_tI[t], J = c_tJ[t];
+            if (J >= x_lo) {
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const double opa = (I == 4) ? T4[kk] : T[I][kk], opb = (J == 4) ? T4[kk] : T[J][kk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opa, opb, acc[t], 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int X = 0; X < 5; ++X)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) yr[X] += ((X == 4) ? T4[kk] : T[X][kk]) * tg[kk];
+          PCLK(if (k == 5 && lane == 0) st.phase_clk[20] = clock64());
+          double *sw = TAcur; TAcur = TAprev; TAprev = sw;
+          lds_fence();
+        }
+        // reduced right-hand side so far: g_P - sum_k T_B^T t_g
+#pragma unroll
+        for (int X = 0; X < 5; ++X) {
+          yr[X] += __shfl_xor(yr[X], 16, 64);
+          yr[X] += __shfl_xor(yr[X], 32, 64);
+          if (lk == 0) v[16 * X + lr] = g[16 * X + lr] - yr[X];
+        }
+      }
       }
       PCLK(if (lane == 0) st.phase_clk[3] = clock64());
 
@@ -697,7 +880,7 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
                 trip(kk0 + 8, 2);
               }
             }
-          } else {
+          } else if constexpr (MID) {
             ldtrip(0, 0);
             for (int kk0 = 0; kk0 < nks; kk0 += 8) {
               if (kk0 + 4 < nks) ldtrip(kk0 + 4, 1);
@@ -706,6 +889,15 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
                 if (kk0 + 8 < nks) ldtrip(kk0 + 8, 0);
                 trip(kk0 + 4, 1);
               }
+            }
+          } else {
+            // (unguarded: loads past the last landmark are clamped, their products masked; the guards cost this instantiation registers)
+            ldtrip(0, 0);
+            for (int kk0 = 0; kk0 < nks; kk0 += 8) {
+              ldtrip(kk0 + 4, 1);
+              trip(kk0, 0);
+              ldtrip(kk0 + 8, 0);
+              trip(kk0 + 4, 1);
             }
           }
         }
@@ -1105,8 +1297,9 @@ __global__ void __launch_bounds__(64) k_solve_mid(BatchDev b, SolveParams sp) {
 // =================================================================================================
 int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);    // kernels_mw.hip
 int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw4.hip
-// Which solver (0 single wave, 2 two waves, 4 four waves per window): as many waves per window as the batch leaves SIMDs for — four up to one
-// window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond. VILO_SOLVER=wave / mw / mw4 pins a form
+// Which solver (0 single wave, 2 two waves, 4 four waves per window, 3 the single wave in three stages): as many waves per window as the
+// batch leaves SIMDs for — four up to one window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond; in
+// three stages once the batch fills the two-waves-per-SIMD stages too. VILO_SOLVER=wave / mw / mw4 pins a form
 // (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
 int vilo_solver_form(const BatchDev &b) {
   static const int forced = [] {
@@ -1115,8 +1308,9 @@ int vilo_solver_form(const BatchDev &b) {
   }();
   static const int max_w4 = [] { const char *e = getenv("VILO_MW4_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
   static const int max_w2 = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+  static const int min_w3 = [] { const char *e = getenv("VILO_SPLIT_MIN_WINDOWS"); return e ? atoi(e) : 1025; }();
   if (forced >= 0) return forced;
-  return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : 3);
+  return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
 }
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
