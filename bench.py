@@ -238,8 +238,8 @@ def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
     setup_s = time.perf_counter() - t0
 
     def table():
-        ms = (C.c_double * 16)(); launches = (C.c_longlong * 16)()
-        nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 16)
+        ms = (C.c_double * 32)(); launches = (C.c_longlong * 32)()
+        nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 32)
         lib.vilo_kernel_name.restype = C.c_char_p
         return {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]), "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}
     lib.vilo_set_profiling(ctx.h, 1)   # (also clears the per-kernel table)
@@ -358,9 +358,9 @@ def main():
     # keep the pair around the dominant kernel only (what `roofline.achieved` is defined on): the ~80 other pairs cost the stream
     # 0.6 ms per step. Without warm-up steps the timed ones carry the full set.
     def kernel_table():
-        ms = (C.c_double * 16)()
-        launches = (C.c_longlong * 16)()
-        nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 16)
+        ms = (C.c_double * 32)()
+        launches = (C.c_longlong * 32)()
+        nk = lib.vilo_get_kernel_times(ctx.h, ms, launches, 32)
         lib.vilo_kernel_name.restype = C.c_char_p
         return {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]), "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}
 
