@@ -495,6 +495,10 @@ def main():
                          "fp64": {"bound": "mfma", "peak": 78.6, "unit": "TFLOP/s", "algorithmic_flops_per_window_iteration": alg_flops,
                                   "whole_iteration_tflops": alg_flops * W / (iter_ms * 1e-3) / 1e12 if alg_flops else None,
                                   "whole_iteration_frac": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 78.6 if alg_flops else None,
+                                  # what the matrix cores sustain by wall clock with every SIMD issuing FP64 MFMAs back to back (the shader clock
+                                  # drops under that load): tools/micro/mfma_f64_rate.hip, profiles/round3_mfma_f64_rate.txt
+                                  "sustained_mfma_tflops": 44.2, "sustained_mfma_tflops_one_wave_per_simd": 33.2,
+                                  "whole_iteration_frac_of_sustained": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 44.2 if alg_flops else None,
                                   "mfma_util": ev["mfma"],
                                   "mfma_util_source": "profiles/%s_mfma%s.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" % (PROFILE_ROUND, tag) if ev["mfma"] else None},
                          # calibrated HBM bytes per window of every kernel of the iteration against the algorithmic bytes of the whole iteration
