@@ -179,7 +179,8 @@ __device__ __forceinline__ int chain_to_global(const double *bimg, const double 
         for (int X = 0; X < 5; ++X)
           if (X >= x_lo) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) Tb[(X * 4 + kk) * 64 + lane] = (X == 4) ? T4[kk] : T[X][kk];
+            for (int kk = 0; kk < 4; ++kk)
+              if (kk < 3 || lk == 0) Tb[(X * 4 + kk) * 64 + lane] = (X == 4) ? T4[kk] : T[X][kk];   // (rows 13 .. 15 of the 16: padding, never read)
           }
       }
 #pragma unroll

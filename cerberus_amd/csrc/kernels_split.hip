@@ -200,15 +200,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BS_WPE,
       }
       PCLK(if (lane == 0) st.phase_clk[25] = clock64());
       // ---- landmarks: y_l = (g_l - w_l^T yP) / (E_l + mu dhat_l^2), all 80 coupling entries of a landmark in flight at once ----
+      const unsigned char *lms = b.lm_s + lmoff_b;
       for (int l = lane; l < L; l += 64) {
         const double gl = lm_g[l], ei = lm_einv[l], d2 = lm_dh2[l];
+        const int zl = 6 * (int)lms[l];   // rows before the landmark's start frame are structural zeros: not fetched
         double tl = 0.0;
         // (20 coupling entries in flight per lane: the other waves of the SIMD cover the rest of the latency)
 #pragma unroll
         for (int a0 = 0; a0 < 80; a0 += 20) {
           double wcol[20];
 #pragma unroll
-          for (int a = 0; a < 20; ++a) wcol[a] = wl[(size_t)(a0 + a) * L + l];
+          for (int a = 0; a < 20; ++a) wcol[a] = (a0 + a >= 60 || a0 + a >= zl) ? wl[(size_t)(a0 + a) * L + l] : 0.0;
 #pragma unroll
           for (int a = 0; a < 20; ++a)
             if (a0 + a < VILO_NPU) tl += wcol[a] * y[a0 + a];   // y is zero on inactive dimensions

@@ -584,7 +584,7 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
           for (int X = 0; X < 5; ++X)
             if (X >= x_lo) {
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk) tb[sel][X][kk] = Tg[1280 * k + (X * 4 + kk) * 64 + lane];
+              for (int kk = 0; kk < 4; ++kk) tb[sel][X][kk] = (kk < 3 || lk == 0) ? Tg[1280 * k + (X * 4 + kk) * 64 + lane] : 0.0;   // (rows 13 .. 15: padding)
             }
         };
         auto upd = [&](int k, auto selc) {
