@@ -435,9 +435,9 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
     }
   }
   if (!TPAR && active) {
-    for (int f = 0; f < VILO_MAX_FRAMES; ++f)
-      if (f < s || f >= s + wv.kmax)
-        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
+    // (rows of poses before the landmark's start frame are zero since vilo_batch_create and nobody writes them: not stored again)
+    for (int f = s + wv.kmax; f < VILO_MAX_FRAMES; ++f)
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
     wbase[(size_t)79 * L + li] = 0.0;
     b.lm_E[ls.gi] = E;
     lm_g_out[ls.gi] = gl;
@@ -713,9 +713,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
   if (active) {
-    for (int f = 0; f < VILO_MAX_FRAMES; ++f)
-      if (f < s || f >= s + kmax)
-        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
+    // (rows of poses before the landmark's start frame are zero since vilo_batch_create and nobody writes them: not stored again)
+    for (int f = s + kmax; f < VILO_MAX_FRAMES; ++f)
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
     wbase[(size_t)79 * L + li] = 0.0;
     b.lm_E[ls.gi] = E;
     lm_g_out[ls.gi] = gl;

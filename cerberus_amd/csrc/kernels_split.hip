@@ -136,10 +136,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BS_WPE,
         int pe[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) pe[m] = min(lane + 64 * m, 168);
+        bool mlow[3];   // M_k = L_k^-1 is lower triangular (exact zeros above the diagonal): not fetched
+#pragma unroll
+        for (int m = 0; m < 3; ++m) mlow[m] = pe[m] / 13 >= pe[m] % 13;
         double pm[3], pt[3];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int m = 0; m < 3; ++m) { pm[m] = Mg_[(F - 1) * 169 + pe[m]]; pt[m] = 0.0; }
+        for (int m = 0; m < 3; ++m) { pm[m] = mlow[m] ? Mg_[(F - 1) * 169 + pe[m]] : 0.0; pt[m] = 0.0; }
         // forward sweep
         double unext = 0.0;   // u_{k+1}[row]
         for (int k = F - 1; k >= 0; --k) {
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BS_WPE,
             // next step: M_{k-1}, T_A(k); after the last one the backward sweep's first frame: M_0 (again) and nothing
             const int kn = max(k - 1, 0);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { pm[m] = Mg_[kn * 169 + pe[m]]; pt[m] = TAg_[k * 169 + pe[m]]; }
+            for (int m = 0; m < 3; ++m) { pm[m] = mlow[m] ? Mg_[kn * 169 + pe[m]] : 0.0; pt[m] = TAg_[k * 169 + pe[m]]; }
           }
           lds_fence();
           double s = U[13 * k + row];
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BS_WPE,
           {
             const int kn = min(k + 1, F - 1);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { pm[m] = Mg_[kn * 169 + pe[m]]; pt[m] = TAg_[kn * 169 + pe[m]]; }
+            for (int m = 0; m < 3; ++m) { pm[m] = mlow[m] ? Mg_[kn * 169 + pe[m]] : 0.0; pt[m] = TAg_[kn * 169 + pe[m]]; }
           }
           lds_fence();
           double s = U[13 * k + row];

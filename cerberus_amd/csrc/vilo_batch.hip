@@ -442,6 +442,8 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.lm_scale, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_einv, (size_t)lm_total));
   TRYB(dev_alloc(ctx, bt, &D.lm_w, (size_t)lm_total * 80));
+  // a landmark's coupling rows with the poses before its start frame are structural zeros: written here once, never again
+  if (hipMemsetAsync(D.lm_w, 0, sizeof(double) * (size_t)std::max(lm_total, 1) * 80, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   // few windows: one workgroup per (packed wave, frame) instead of per packed wave, so that the chip is not left to 3 waves per window
   D.lm_part = nullptr;
   const char *tp_env = getenv("VILO_TPAR_MAX_WAVES");   // tuning aid; VILO_NO_TPAR=1 = 0
