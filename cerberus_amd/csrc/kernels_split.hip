@@ -1,19 +1,19 @@
-// Three-stage form of the single-wave solver for full batches (more windows than SIMDs): the block-tridiagonal chain of the speed /
-// leg-bias part and the back-substitutions of k_solve_wave (kernels_wave.hip) are chains of dependent scalar work (v_readlane pivots,
-// LDS round trips) that keep a SIMD's issue slots mostly empty, yet inside k_solve_wave they run at ONE wave per SIMD because the 80 x 80
-// pose system's 60 accumulators + the Schur pass's operands need all 512 registers. Split by register footprint instead:
+// Three-stage form of the single-wave solver for full batches: the block-tridiagonal chain of the speed /
+// leg-bias part and the back-substitutions of k_solve_wave (kernels_wave.hip) never touch the pose system's 120 accumulator registers,
+// yet inside k_solve_wave they run at ONE wave per SIMD because those accumulators + the Schur pass's operands need the whole register
+// file. Cut by register footprint instead:
 //
-//   k_chain      (<= 256 registers, two waves per SIMD)  S_k, L_k, M_k = L_k^-1, T_A(k), T(k) for frames F-1 .. 0, rhs_P -= T_B^T t_g:
-//                T_B(k) in MFMA operand order + reduced right-hand side out (Tk), M_k / T_A(k) out (Lk, TAg)
-//   k_solve_wave (mode 1; 512 registers)  C -= T_B(k)^T T_B(k) from Tk, landmark Schur complement, blocked Cholesky-80, backward solve:
-//                y_P out
+//   k_chain      (256 registers, two waves per SIMD)  S_k, L_k, M_k = L_k^-1, T_A(k), T(k) for frames F-1 .. 0, rhs_P -= T_B^T t_g
+//                (chain_common.hpp): T_B(k) in MFMA operand order + reduced right-hand side out (Tk), M_k / T_A(k) out (Lk, TAg)
+//   k_solve_mid  (kernels_wave.hip: solve_wave_body<true>; 512 registers)  C -= T_B(k)^T T_B(k) from Tk, landmark Schur complement,
+//                blocked Cholesky-80, backward solve: y_P out
 //   k_backsub    (<= 128 registers, four waves per SIMD)  c = g_B - B y_P, the two block-bidiagonal sweeps, landmark back-substitution,
 //                Gauss-Newton norms, dogleg step, candidate state
 //
-// Two (four) windows' dependent chains now share a SIMD and fill each other's stalls. The arithmetic is k_solve_wave's, statement by
-// statement. What can go wrong stays in k_solve_wave: a factorisation that fails in k_chain or in the Cholesky-80 makes the middle stage
-// run the complete single-kernel path at mu * 10 (DoglegStrategy::ComputeGaussNewtonStep's retry loop), and a non-finite Gauss-Newton
-// step found in k_backsub flags the window for the complete path in a fourth launch (mode 2) that returns at once for everyone else.
+// The arithmetic is k_solve_wave's, statement by statement: the forms agree bitwise (tests/test_solver_forms.py). What can go wrong
+// stays in k_solve_wave: a factorisation that fails in k_chain or in the Cholesky-80, or a non-finite Gauss-Newton step found in
+// k_backsub, flags the window for the complete single-kernel path in a fourth launch (k_solve_wave with redo_only) that finds the same
+// failure, takes DoglegStrategy::ComputeGaussNewtonStep's retry loop from there, and returns at once for every other window.
 // SolverState::pad[1] carries the hand-over: 0 chain failed, 1 chain ready, 2 y_P ready, 3 nothing left to do, 4 redo.
 #include <type_traits>
 #include "chain_common.hpp"
