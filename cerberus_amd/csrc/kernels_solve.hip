@@ -541,13 +541,73 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (CAM) G1[g] = G; else G0[g] = G;
       }
     };
+    // The landmark side of the step (lane = landmark, as in the producer): the producer is the pair's critical path (it waits 2 % of its
+    // time at the step barriers, this wave 50 %), so the reductions that need nothing but a lane's two rows and its 2 x 1 landmark
+    // Jacobian (handed over in the two pad doubles of the lane's row block) are formed here — the same 15 + 2 terms, formed and added
+    // exactly as in the single-wave / frame-parallel forms (bitwise); the six terms of the extrinsic translations stay with the producer.
+    const bool active = ls.active;
+    const int s_lm = ls.s, li = ls.li, L = wm.L;
+    double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
+    double E = 0.0, gl = 0.0, wc_s[6], wc_e0h[3], wc_e1h[3], wj[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wc_s[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { wc_e0h[c] = 0.0; wc_e1h[c] = 0.0; }
+    auto reduce = [&](int t, int cam) {
+      const int nstep = (t == 0) ? 0 : 2 * t - 1 + cam;
+      const double *xr0 = X + (nstep & 1) * PC_XN + lane * XLANEC, *xr1 = xr0 + XROWC;
+      double x0[XROWC], x1[XROWC], Jl[2];
+#pragma unroll
+      for (int c = 0; c < XROWC; ++c) { x0[c] = xr0[c]; x1[c] = xr1[c]; }
+      Jl[0] = xr0[2 * XROWC]; Jl[1] = xr0[2 * XROWC + 1];
+      double term[LM_NTERM], wjr[3];
+      term[0] = dot2(Jl[0], Jl[0], Jl[1], Jl[1]);
+      term[1] = dot2(Jl[0], x0[GK_R], Jl[1], x1[GK_R]);
+      const double pw = (t > 0) ? 1.0 : 0.0;   // the one-frame factor has no pose blocks (its B columns carry the tic column)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        term[2 + c] = pw * (dot2(x0[GK_B + c], Jl[0], x1[GK_B + c], Jl[1]));
+        term[5 + c] = dot2(x0[GK_RI + c], Jl[0], x1[GK_RI + c], Jl[1]);
+        term[11 + c] = dot2(x0[GK_C0 + c], Jl[0], x1[GK_C0 + c], Jl[1]);
+        term[17 + c] = dot2(x0[GK_C1 + c], Jl[0], x1[GK_C1 + c], Jl[1]);
+        wjr[c] = dot2(x0[GK_RJ + c], Jl[0], x1[GK_RJ + c], Jl[1]);
+        term[8 + c] = 0.0; term[14 + c] = 0.0;   // (the producer's)
+      }
+      term[20] = 0.0;
+      // (every term is a value of its own before it is added — the frame-parallel form stores it, the sums must round alike: opaque to the
+      // optimiser so that no multiply of a term is contracted into the accumulation)
+#pragma unroll
+      for (int v = 0; v < 20; ++v) asm volatile("" : "+v"(term[v]));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(wjr[c]));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        wj[c] -= term[2 + c];   // d r / d P_j = -d r / d P_i
+        wj[3 + c] += wjr[c];
+      }
+      E += term[0];
+      gl += term[1];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) wc_s[c] += term[2 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { wc_e0h[c] += term[11 + c]; wc_e1h[c] += term[17 + c]; }
+    };
     step_barrier();   // step 0's rows are there
     for (int t = 0; t < kmax; ++t) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) wj[c] = 0.0;
       if (t > 0) {
         pass(t, std::integral_constant<int, 0>{});
+        reduce(t, 0);
         step_barrier();
       }
       pass(t, std::integral_constant<int, 1>{});
+      reduce(t, 1);
+      if (active && t > 0 && s_lm + t < VILO_MAX_FRAMES) {   // (a frame that does not see the landmark produced zero rows: wj is zero)
+        const int j = s_lm + t;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
+      }
       // the frame's slots: upper triangle of C0 + C1, then rows 0 .. 2 (the B rows) of C1: register 0 of the lanes lk = 0 .. 2
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -563,6 +623,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
       step_barrier();
     }
+    if (active) {
+      b.lm_E[ls.gi] = E;
+      lin_lm_g(b, st, mode)[ls.gi] = gl;
+      const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * s_lm + c) * L + li] = wc_s[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        wbase[(size_t)(CD_EX0 + 3 + c) * L + li] = ex_on ? wc_e0h[c] : 0.0;
+        wbase[(size_t)(CD_EX1 + 3 + c) * L + li] = ex_on ? wc_e1h[c] : 0.0;
+      }
+    }
     return;
   }
 
@@ -570,7 +642,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   const bool active = ls.active;
   const int n = wv.n_lanes, L = wm.L, s = ls.s;
   const double *xg = (mode ? b.xc : b.x) + (size_t)wv.win * XSTRIDE;
-  double *lm_g_out = lin_lm_g(b, st, mode);
   double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
   const int li = ls.li;
   for (int e = lane; e < XSTRIDE; e += 64) xs[e] = xg[e];
@@ -611,9 +682,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     VL.p_w = qrot(ldq_pose(pose_s), VL.p_i) + ld3(pose_s);
   }
   const v3 pts_i = mk3(oi[0], oi[1], oi[2]);
-  double E = 0.0, gl = 0.0, cost = 0.0;
-  double wc_s[6], wc_e0[6], wc_e1[6];
-  for (int c = 0; c < 6; ++c) wc_s[c] = wc_e0[c] = wc_e1[c] = 0.0;
+  double cost = 0.0;
+  double wc_e0[3], wc_e1[3];   // the extrinsic translations' share of the landmark's coupling rows (the rest: the consumer)
+  for (int c = 0; c < 3; ++c) wc_e0[c] = wc_e1[c] = 0.0;
   double on[11];
   unsigned char fl_next = 0;
   for (int c = 0; c < 11; ++c) on[c] = 0.0;
@@ -644,8 +715,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int c = 0; c < 11; ++c) on[c] = obn[(size_t)c * n + lane];
     }
-    double wj[6];
-    for (int c = 0; c < 6; ++c) wj[c] = 0.0;
     const double *tb = tab + max(ls.seg, 0) * VT_N;
     v3 p_j = VL.p_i;
     if (t > 0) {
@@ -668,48 +737,27 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
           if (t > 0) rho0 = vis_two_frame_c<1>(wt, tb, VL, p_j, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
           else rho0 = vis_one_frame_c(wt, VL, pts_i, obc, dtj, sq, huber_a, x0, x1, Jl, tc);
         }
-        // landmark-side reductions: the same 21 terms, formed and added exactly as in the single-wave / frame-parallel forms (bitwise)
-        double term[LM_NTERM], wjr[3];
-        term[0] = dot2(Jl[0], Jl[0], Jl[1], Jl[1]);
-        term[1] = dot2(Jl[0], x0[GK_R], Jl[1], x1[GK_R]);
-        const double pw = (t > 0) ? 1.0 : 0.0;   // the one-frame factor has no pose blocks (its B columns carry the tic column)
+        // landmark side: the six terms that need the explicit extrinsic-translation columns; the others are the consumer's
+        double te0[3], te1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          term[2 + c] = pw * (dot2(x0[GK_B + c], Jl[0], x1[GK_B + c], Jl[1]));
-          term[5 + c] = dot2(x0[GK_RI + c], Jl[0], x1[GK_RI + c], Jl[1]);
-          term[8 + c] = dot2(tc[0][c], Jl[0], tc[1][c], Jl[1]);
-          term[11 + c] = dot2(x0[GK_C0 + c], Jl[0], x1[GK_C0 + c], Jl[1]);
-          term[14 + c] = dot2(tc[2][c], Jl[0], tc[3][c], Jl[1]);
-          term[17 + c] = dot2(x0[GK_C1 + c], Jl[0], x1[GK_C1 + c], Jl[1]);
-          wjr[c] = dot2(x0[GK_RJ + c], Jl[0], x1[GK_RJ + c], Jl[1]);
+          te0[c] = dot2(tc[0][c], Jl[0], tc[1][c], Jl[1]);
+          te1[c] = dot2(tc[2][c], Jl[0], tc[3][c], Jl[1]);
         }
-        // (every term is a value of its own before it is added — the frame-parallel form stores it, the sums must round alike: opaque to the
-        // optimiser so that no multiply of a term is contracted into the accumulation)
 #pragma unroll
-        for (int v = 0; v < 20; ++v) asm volatile("" : "+v"(term[v]));
+        for (int c = 0; c < 3; ++c) { asm volatile("" : "+v"(te0[c])); asm volatile("" : "+v"(te1[c])); }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(wjr[c]));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          wj[c] -= term[2 + c];   // d r / d P_j = -d r / d P_i
-          wj[3 + c] += wjr[c];
-        }
-        E += term[0];
-        gl += term[1];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) { wc_s[c] += term[2 + c]; wc_e0[c] += term[8 + c]; wc_e1[c] += term[14 + c]; }
+        for (int c = 0; c < 3; ++c) { wc_e0[c] += te0[c]; wc_e1[c] += te1[c]; }
         cost += rho0;
 #pragma unroll
         for (int c = 0; c < XROWC; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
+        xr0[2 * XROWC] = Jl[0]; xr0[2 * XROWC + 1] = Jl[1];
       } else {
 #pragma unroll
         for (int c = 0; c < XROWC; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+        xr0[2 * XROWC] = 0.0; xr0[2 * XROWC + 1] = 0.0;
       }
       step_barrier();
-    }
-    if (active && t > 0 && s + t < VILO_MAX_FRAMES) {
-      const bool seen = fl & 1;
-      for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = seen ? wj[c] : 0.0;
     }
   }
   if (active) {
@@ -717,11 +765,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int f = s + kmax; f < VILO_MAX_FRAMES; ++f)
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * f + c) * L + li] = 0.0;
     wbase[(size_t)79 * L + li] = 0.0;
-    b.lm_E[ls.gi] = E;
-    lm_g_out[ls.gi] = gl;
     const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX);
-    for (int c = 0; c < 6; ++c) {
-      wbase[(size_t)(6 * s + c) * L + li] = wc_s[c];
+    for (int c = 0; c < 3; ++c) {
       wbase[(size_t)(CD_EX0 + c) * L + li] = ex_on ? wc_e0[c] : 0.0;
       wbase[(size_t)(CD_EX1 + c) * L + li] = ex_on ? wc_e1[c] : 0.0;
     }
