@@ -592,6 +592,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int c = 0; c < 3; ++c) { wc_e0h[c] += term[11 + c]; wc_e1h[c] += term[17 + c]; }
     };
+    long long c_wait = 0, cw0 = 0;   // (profiling build only: cycles this wave spends at the step barriers)
+    const long long c_start = pclk64();
     step_barrier();   // step 0's rows are there
     for (int t = 0; t < kmax; ++t) {
 #pragma unroll
@@ -599,7 +601,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (t > 0) {
         pass(t, std::integral_constant<int, 0>{});
         reduce(t, 0);
+        PCLK(cw0 = clock64());
         step_barrier();
+        PCLK(c_wait += clock64() - cw0);
       }
       pass(t, std::integral_constant<int, 1>{});
       reduce(t, 1);
@@ -621,8 +625,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (lk < 3) gs[VILO_GRAMC_TRI + 16 * lk + lr] = G1[g][0];
         G0[g] = mfma_d4{0.0, 0.0, 0.0, 0.0}; G1[g] = G0[g];
       }
+      PCLK(cw0 = clock64());
       step_barrier();
+      PCLK(c_wait += clock64() - cw0);
     }
+    PCLK(if (wave_id == 0 && lane == 0) { st.phase_clk[28] = clock64() - c_start; st.phase_clk[29] = c_wait; st.phase_clk[32] = kmax; });
     if (active) {
       b.lm_E[ls.gi] = E;
       lin_lm_g(b, st, mode)[ls.gi] = gl;
@@ -699,6 +706,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     if (g == tb_g) { tb_s = cs[g]; tb_km = (g < wv.nseg) ? ckm[g] : 0; }
+  long long p_wait = 0, pw0 = 0;   // (profiling build only)
+  const long long p_start = pclk64();
   for (int t = 0; t < kmax; ++t) {
     if (t >= 1) {
       if (lane < 24 && t < tb_km) vis_build_pair_row(xs, wt, tb_s, min(tb_s + t, VILO_MAX_FRAMES - 1), tb_kind, tb_r, tab + tb_g * VT_N);
@@ -757,9 +766,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int c = 0; c < XROWC; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
         xr0[2 * XROWC] = 0.0; xr0[2 * XROWC + 1] = 0.0;
       }
+      PCLK(pw0 = clock64());
       step_barrier();
+      PCLK(p_wait += clock64() - pw0);
     }
   }
+  PCLK(if (wave_id == 0 && lane == 0) { st.phase_clk[30] = clock64() - p_start; st.phase_clk[31] = p_wait; });
   if (active) {
     // (rows of poses before the landmark's start frame are zero since vilo_batch_create and nobody writes them: not stored again)
     for (int f = s + kmax; f < VILO_MAX_FRAMES; ++f)

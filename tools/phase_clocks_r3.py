@@ -19,6 +19,9 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     C = np.stack([b.fetch(12, w).view(np.int64).astype(np.float64) for w in sample])
     m = C.mean(axis=0)
     print("== %d windows (mean of %d sampled windows, cycles)" % (W, len(sample)))
+    if C[0, 30] > 0:   # producer / consumer visual kernel: packed wave 0 (window 0)
+        print("k_visual_linearize_pc (packed wave 0, %d frames): consumer %d cycles, %d of them at the step barriers; producer %d, %d at the barriers"
+              % (C[0, 32], C[0, 28], C[0, 29], C[0, 30], C[0, 31]))
     d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
     print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
           % (*d, d.sum()))
