@@ -116,12 +116,14 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; pf[i] = (e < n) ? src[e] : 0.0; }
     };
     if (nch > 0) prefetch(0);
+    long long w_work = 0, w_t0 = 0;   // (profiling build only: cycles each wave works on a chunk between the barriers)
     for (int ch = 0; ch < nch; ++ch) {
       const unsigned ct = chunk_tab[ch];
       lds_barrier();   // (the previous chunk's readers are done)
 #pragma unroll
       for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; if (e < AC_STAGE) stage[e] = pf[i]; }
       lds_barrier();
+      PCLK(w_t0 = clock64());
       if (ch + 1 < nch) prefetch(ch + 1);
       assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { gl[cd] += v; });
       if (tid >= 64 && tid < 128) {
@@ -131,7 +133,9 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
         const double p1 = __shfl(part, q + 21, 64), p2 = __shfl(part, q + 42, 64);
         if (wl < 21) ac_t8_apply(q, (part + p1) + p2, rmw);
       }
+      PCLK(w_work += clock64() - w_t0);
     }
+    PCLK(if ((tid & 63) == 0) b.st[win].phase_clk[12 + (tid >> 6)] = w_work);
   } else {
     // visual Gram slots: 246 owner groups, one per thread
     // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),

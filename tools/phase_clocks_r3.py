@@ -23,6 +23,7 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
         print("k_visual_linearize_pc (packed wave 0, %d frames): consumer %d cycles, %d of them at the step barriers; producer %d, %d at the barriers"
               % (C[0, 32], C[0, 28], C[0, 29], C[0, 30], C[0, 31]))
     d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
+    print("k_assemble, visual slots: work between the chunk barriers per wave (0: T1 T2 T3, 1: T8, 2: T5 T6 T4, 3: T7): %d %d %d %d" % tuple(m[12:16]))
     print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
           % (*d, d.sum()))
     if W <= 512:
