@@ -72,6 +72,9 @@ __device__ __forceinline__ void q_barrier_global() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// (profiling build: cycles a wave spends at the workgroup barriers, phase_clk[20 + wave]; its total, phase_clk[16 + wave])
+#define Q_BARRIER() do { PCLK(qw0 = clock64()); q_barrier(); PCLK(qwait += clock64() - qw0); } while (0)
+#define Q_BARRIER_GLOBAL() do { PCLK(qw0 = clock64()); q_barrier_global(); PCLK(qwait += clock64() - qw0); } while (0)
 // tiles of the pose system owned by matrix wave 0 / 1 (bit t of the mask = tile t of c_tI / c_tJ)
 //   B1: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) (3,1)   = tiles 0 .. 7;   B2: (3,2) (3,3) (4,0) .. (4,4) = tiles 8 .. 14
 #define B1_MASK 0x00ff
@@ -85,6 +88,8 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: A1 (chain down + middle), 1: A2 (chain up), 2: B1, 3: B2
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int tid = threadIdx.x;
+  long long qwait = 0, qw0 = 0;   // (profiling build only)
+  const long long q_start = pclk64();
   const WinMeta wm = b.win[win];
   const int F = wm.n_frames, L = wm.L, kb = wm.pad, cmask = wm.const_mask;
   const int mid = (F - 1) >> 1, nL = mid, nU = F - 1 - mid, nS = nU;   // frames below / above the middle; nU >= nL, nU >= 1
@@ -121,7 +126,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
     }
     part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax); part_q = wave_sum(part_q);
     if (lane == 0) { red[QR_GN + wave] = part_gn; red[QR_GMAX + wave] = part_gmax; red[QR_Q + wave] = part_q; }
-    q_barrier_global();
+    Q_BARRIER_GLOBAL();
     const double gnorm2 = bimg[BI_SCAL + 1] + (((red[QR_GN] + red[QR_GN + 1]) + red[QR_GN + 2]) + red[QR_GN + 3]);
     const double gmax = fmax(bimg[BI_SCAL + 2], fmax(fmax(red[QR_GMAX], red[QR_GMAX + 1]), fmax(red[QR_GMAX + 2], red[QR_GMAX + 3])));
     const double q_lm = ((red[QR_Q] + red[QR_Q + 1]) + red[QR_Q + 2]) + red[QR_Q + 3];
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       asm volatile("" : "+v"(lane));
       const int lr = lane & 15, lk = lane >> 4;
       for (int l = tid; l < L; l += 256) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
-      q_barrier_global();
+      Q_BARRIER_GLOBAL();
       const int nks = (L + 3) >> 2, NT = (nks + 3) >> 2, NH = (nks + 1) >> 1;   // k-steps of 4 landmarks, trips of 4, half trips of 2
       int fail = 0;
 
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
             for (int kk = 0; kk < 4; ++kk) Tb[(X * 4 + kk) * 64 + lane] = (X >= x_lo) ? T[X][kk] : 0.0;
           double *sw = TAcur; TAcur = TAprev; TAprev = sw;
         };
-        q_barrier();   // (the matrix waves' skip table: every wave meets the same barriers)
+        Q_BARRIER();   // (the matrix waves' skip table: every wave meets the same barriers)
         for (int i = 0; i <= nS + 1; ++i) {
           if (!up) {
             if (i < nU) { const int k = F - 1 - i; frame(k, k - 1, i == 0 ? -1 : k + 1, false, i); }
@@ -315,10 +320,10 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
             frame(i, i + 1, i == 0 ? -1 : i - 1, false, i);
           }
           if (i == nS + 1 && lane == 0) red[QR_FAIL + wave] = (double)fail;
-          q_barrier();
+          Q_BARRIER();
         }
-        q_barrier();   // B2's tiles and the reduced right-hand side
-        q_barrier();   // y_P
+        Q_BARRIER();   // B2's tiles and the reduced right-hand side
+        Q_BARRIER();   // y_P
       } else {
         // =============================== waves B1 / B2: the pose system ===============================
         const int bw = wave - 2;
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
             const unsigned char *lms = b.lm_s + wm.lm_off;
             for (int tr = lane; tr < NT + 2; tr += 64) skip_tab[tr] = (6 * (int)lms[min(16 * tr, L - 1)] >= 16) ? 1 : 0;
           }
-          q_barrier();   // (the skip table is B1's; both matrix waves read it — the chain waves meet this barrier too)
+          Q_BARRIER();   // (the skip table is B1's; both matrix waves read it — the chain waves meet this barrier too)
           constexpr int XMAX = MAIN_RHS ? 5 : 4;   // operand blocks the wave's tiles touch
           double opb[2][2][5], eb[2][2], gb[2][2];
           auto ldhalf = [&](int h, auto bs) {
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
               if (i - 1 < nU || i - 1 == nS) rank_update(lds + Q_T1 + 1280 * ((i - 1) & 1));
               if (i - 1 < nL) rank_update(lds + Q_T2 + 1280 * ((i - 1) & 1));
             }
-            q_barrier();
+            Q_BARRIER();
           }
           if (MAIN_RHS) {
             // reduced right-hand side: g_P - sum_k T_B^T t_g - sum_l w_l g_l / (E_l + mu dhat_l^2)
@@ -442,7 +447,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
         };
         if (bw == 0) run(std::integral_constant<int, B1_MASK>{});
         else run(std::integral_constant<int, B2_MASK>{});
-        q_barrier();   // B2's tiles and the reduced right-hand side are there
+        Q_BARRIER();   // B2's tiles and the reduced right-hand side are there
         if (bw == 0) {
           fail = (red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0) ? 1 : 0;
           if (!fail) {
@@ -553,7 +558,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           }
           if (lane == 0) red[QR_FAIL + 2] = (double)fail;
         }
-        q_barrier();   // y_P (or the failure flags)
+        Q_BARRIER();   // y_P (or the failure flags)
       }
       fail = 0;
       // (wave-uniform flags from LDS: chain up / down, pose system)
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = 0.0; st.gmax = gmax; st.scale_ready = 1; }
           return;
         }
-        q_barrier();   // (every lane has read the flags before the next trip rewrites them)
+        Q_BARRIER();   // (every lane has read the flags before the next trip rewrites them)
         continue;
       }
 
@@ -642,7 +647,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           }
           if (lane < 13) lds[Q_XU + lane] = uprev;   // u of frame m - 1 for the middle
         }
-        q_barrier();
+        Q_BARRIER();
         // the middle frame (A1): u_m = M_m (c_m - T_A(m+1)^T u_{m+1} - T'_A(m-1)^T u_{m-1}),  y_m = M_m^T u_m
         double ymid = 0.0;
         if (!up) {
@@ -669,7 +674,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           if (lane < 13) { YB[13 * mid + lane] = yk; lds[Q_XY + lane] = yk; }
           ymid = yk;
         }
-        q_barrier();
+        Q_BARRIER();
         // backward sweeps, both halves at once:  down  y_k = M_k^T (u_k - T_A(k) y_{k-1})    k = m+1 .. F-1
         //                                        up    y_k = M_k^T (u_k - T'_A(k) y_{k+1})   k = m-1 .. 0
         double yprev = up ? lds[Q_XY + row] : ymid;
@@ -738,12 +743,12 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
             part_gy += g[cd] * y[cd];
           }
         }
-        q_barrier();   // (the chain waves' hand-over points)
-        q_barrier();
+        Q_BARRIER();   // (the chain waves' hand-over points)
+        Q_BARRIER();
       }
       part_gnn = wave_sum(part_gnn); part_gy = wave_sum(part_gy); part_qx = wave_sum(part_qx);
       if (lane == 0) { red[QR_GNN + wave] = part_gnn; red[QR_GY + wave] = part_gy; red[QR_QX + wave] = part_qx; }
-      q_barrier_global();   // (lm_y is read by every wave for the candidate)
+      Q_BARRIER_GLOBAL();   // (lm_y is read by every wave for the candidate)
       gnnorm2 = ((red[QR_GNN] + red[QR_GNN + 1]) + red[QR_GNN + 2]) + red[QR_GNN + 3];
       gy = ((red[QR_GY] + red[QR_GY + 1]) + red[QR_GY + 2]) + red[QR_GY + 3];
       qq = bimg[BI_SCAL + 0] + (q_lm + 2.0 * (red[QR_QX + 2] + red[QR_QX + 3]));
@@ -754,7 +759,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.scale_ready = 1; }
           return;
         }
-        q_barrier();
+        Q_BARRIER();
         continue;
       }
       solved = true;
@@ -789,7 +794,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
     else { dogleg_scalars(st); ca = st.coef_a; cb = st.coef_b; go = st.step_valid; }
     red[QR_CA] = ca; red[QR_CB] = cb; red[QR_GO] = (double)go;
   }
-  q_barrier();
+  Q_BARRIER();
   const double ca = red[QR_CA], cb = red[QR_CB];
   const int go = (red[QR_GO] != 0.0) ? 1 : 0;
   const double *x = b.x + (size_t)win * XSTRIDE;
@@ -809,7 +814,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
   } else if (wave == 0) {
     for (int e = lane; e < 143; e += 64) del[CD_B0 + e] = -ca * GB[e] / DB[e] - cb * YB[e];
   }
-  q_barrier();
+  Q_BARRIER();
   if (wave == 2) {
     if (lane < 11) pose_plus(x + XO_POSE + 7 * lane, del + 6 * lane, xc + XO_POSE + 7 * lane);
     else if (lane < 13) pose_plus(x + XO_EX + 7 * (lane - 11), del + CD_EX0 + 6 * (lane - 11), xc + XO_EX + 7 * (lane - 11));
@@ -821,6 +826,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
     }
   }
+  PCLK(if (lane == 0) { st.phase_clk[16 + wave] = clock64() - q_start; st.phase_clk[20 + wave] = qwait; });
 }
 
 int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s) {

@@ -26,7 +26,9 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     print("k_assemble, visual slots: work between the chunk barriers per wave (0: T1 T2 T3, 1: T8, 2: T5 T6 T4, 3: T7): %d %d %d %d" % tuple(m[12:16]))
     print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
           % (*d, d.sum()))
-    if W <= 512:
+    if W <= 256 and m[16] > 0:   # four-wave solver: total and barrier-wait cycles of its waves
+        print("k_solve_mw4: wave A1 %d cycles (%d at barriers) | A2 %d (%d) | B1 %d (%d) | B2 %d (%d)" % (m[16], m[20], m[17], m[21], m[18], m[22], m[19], m[23]))
+    elif W <= 512:
         print("k_solve_mw wave B: scaling %d | 1/(E + mu d) %d | Schur + rank updates (steps) %d | rhs + Cholesky %d | backward solve %d | wait for barrier %d | landmark back-substitution %d | norms + barrier %d | dogleg + candidate %d | total %d"
               % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[9] - m[0]))
         print("k_solve_mw wave A: chain %d (from kernel start %d) | idle until y_P %d | c = g_B - B y_P %d | forward sweep %d | backward sweep %d"
