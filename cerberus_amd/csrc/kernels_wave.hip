@@ -484,9 +484,6 @@ extern "C" size_t vilo_solve_wave_lds_bytes() { return (size_t)WS_TOTAL * sizeof
 // MID = true: middle stage of the three-stage form (k_solve_mid, kernels_split.hip): the chain's results come from k_chain, the kernel
 // stops after the backward solve (y_P to cam_y; k_backsub goes on). A window whose chain or Cholesky-80 failed is flagged for the complete
 // path (SolverState::pad[1] = 4), which finds the same failure and takes DoglegStrategy::ComputeGaussNewtonStep's retry loop from there.
-#ifndef SCHUR_BUFS
-#define SCHUR_BUFS 2
-#endif
 template <bool MID>
 __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &sp, int redo_only, double *lds) {
   const int win = blockIdx.x;
@@ -581,26 +578,38 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
         // C -= T_B(k)^T T_B(k) for frames F-1 .. 0, operands as the chain left them (L2-resident; the next frame's in flight)
         for (int cd = lane; cd < 80; cd += 64) v[cd] = Tg[TK_V + cd];
         double tb[2][5][4];
-        auto ldT = [&](int k, auto selc) {
-          constexpr int sel = decltype(selc)::value;
-          const int x_lo = chain_x_lo(k, kb);
+        // (one branch-free form per x_lo: conditions between the MFMAs of a frame stall the stream)
+        auto ldT_x = [&](int k, auto selc, auto xc) {
+          constexpr int sel = decltype(selc)::value, XLO = decltype(xc)::value;
 #pragma unroll
-          for (int X = 0; X < 5; ++X)
-            if (X >= x_lo) {
+          for (int X = XLO; X < 5; ++X)
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk) tb[sel][X][kk] = (kk < 3 || lk == 0) ? Tg[1280 * k + (X * 4 + kk) * 64 + lane] : 0.0;   // (rows 13 .. 15: padding)
-            }
+            for (int kk = 0; kk < 4; ++kk) tb[sel][X][kk] = (kk < 3 || lk == 0) ? Tg[1280 * k + (X * 4 + kk) * 64 + lane] : 0.0;   // (rows 13 .. 15: padding)
         };
-        auto upd = [&](int k, auto selc) {
-          constexpr int sel = decltype(selc)::value;
-          const int x_lo = chain_x_lo(k, kb);
+        auto upd_x = [&](auto selc, auto xc) {
+          constexpr int sel = decltype(selc)::value, XLO = decltype(xc)::value;
 #pragma unroll
           for (int t = 0; t < 15; ++t) {
-            const int I = c_tI[t], J = c_tJ[t];
-            if (J >= x_lo) {
+            if (c_tJ[t] >= XLO) {
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tb[sel][I][kk], tb[sel][J][kk], acc[t], 0, 0, 0);
+              for (int kk = 0; kk < 4; ++kk) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tb[sel][c_tI[t]][kk], tb[sel][c_tJ[t]][kk], acc[t], 0, 0, 0);
             }
+          }
+        };
+        auto ldT = [&](int k, auto selc) {
+          switch (chain_x_lo(k, kb)) {
+            case 0: ldT_x(k, selc, std::integral_constant<int, 0>{}); break;
+            case 1: ldT_x(k, selc, std::integral_constant<int, 1>{}); break;
+            case 2: ldT_x(k, selc, std::integral_constant<int, 2>{}); break;
+            default: ldT_x(k, selc, std::integral_constant<int, 3>{}); break;
+          }
+        };
+        auto upd = [&](int k, auto selc) {
+          switch (chain_x_lo(k, kb)) {
+            case 0: upd_x(selc, std::integral_constant<int, 0>{}); break;
+            case 1: upd_x(selc, std::integral_constant<int, 1>{}); break;
+            case 2: upd_x(selc, std::integral_constant<int, 2>{}); break;
+            default: upd_x(selc, std::integral_constant<int, 3>{}); break;
           }
         };
         std::integral_constant<int, 0> s0;
@@ -828,8 +837,7 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
           for (int tr = lane; tr < ntrip + 2; tr += 64) skip_tab[tr] = (6 * (int)lms[min(16 * tr, L - 1)] >= 16) ? 1 : 0;
           lds_fence();
         }
-        constexpr int NB = (MID && SCHUR_BUFS == 3) ? 3 : 2;
-        double opb[NB][4][5], eb[NB][4], gb[NB][4], db[NB][4];
+        double opb[2][4][5], eb[2][4], gb[2][4], db[2][4];
         auto ldtrip = [&](int kk0, int bsel) {
           const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(kk0 >> 2, ntrip)]);
 #pragma unroll
@@ -868,23 +876,7 @@ __device__ __forceinline__ void solve_wave_body(BatchDev &b, const SolveParams &
         if (L > 0) {
           // the landmark vectors written above (lm_einv, lm_y) are read back through global memory by other lanes
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if constexpr (MID && SCHUR_BUFS == 3) {
-            // (two trips ahead: the middle stage has the registers, and a trip's MFMAs do not cover a loaded memory system's round trip)
-            ldtrip(0, 0);
-            if (4 < nks) ldtrip(4, 1);
-            for (int kk0 = 0; kk0 < nks; kk0 += 12) {
-              if (kk0 + 8 < nks) ldtrip(kk0 + 8, 2);
-              trip(kk0, 0);
-              if (kk0 + 4 < nks) {
-                if (kk0 + 12 < nks) ldtrip(kk0 + 12, 0);
-                trip(kk0 + 4, 1);
-              }
-              if (kk0 + 8 < nks) {
-                if (kk0 + 16 < nks) ldtrip(kk0 + 16, 1);
-                trip(kk0 + 8, 2);
-              }
-            }
-          } else if constexpr (MID) {
+          if constexpr (MID) {
             ldtrip(0, 0);
             for (int kk0 = 0; kk0 < nks; kk0 += 8) {
               if (kk0 + 4 < nks) ldtrip(kk0 + 4, 1);
