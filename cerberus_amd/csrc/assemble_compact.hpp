@@ -78,12 +78,46 @@ VD void ac_t8_apply(int q, double total, RMW rmw) {
   rmw((pb ? CD_EX1 : CD_EX0) + ib, (pa ? CD_EX1 : CD_EX0) + ia, total);
 }
 
+// T5 + T6: tic (T5) and tic2 (T6) component a x pose_f dimension b of entry q = 6 a + b (18 entries), the second-longest class: two lanes
+// per entry, lane par takes the frames t = 1 + par, 3 + par, ... and forms both classes' values from the same reads (T6's are a part of
+// T5's). The per-frame targets (pose j = s + t) are applied here; the sums over t (targets in pose s) come back for the caller to add in
+// the order par 0, 1 and apply once.
+template <class RMW>
+VD void ac_t56_partial(int q, int par, int s, int km, const double *slots, const double *Rt, RMW rmw, double &sum5, double &sum6) {
+  const int a = q / 6, b = q % 6, xj = ac_jidx(b);
+  const double sgj = ac_jsign(b);
+  const double *Ri = Rt + 9 * s;
+  sum5 = 0.0; sum6 = 0.0;
+  for (int t = 1 + par; t < km; t += 2) {
+    const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI, *Rj = Rt + 9 * (s + t);
+    double vs5 = 0.0, vj5 = 0.0, vs6 = 0.0, vj6 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double rj = Rj[3 * c + a], n0 = Ri[3 * c + a] - rj;
+      const double gb = Gb[ac_tri(c, b)], cb = C1B[16 * c + b], gx = Gb[ac_tri(c, xj)], cx = C1B[16 * c + xj];
+      vs5 += n0 * gb + rj * cb;
+      vj5 += n0 * gx + rj * cx;
+      vs6 -= rj * cb;
+      vj6 -= rj * cx;
+    }
+    sum5 += vs5; sum6 += vs6;
+    rmw(CD_EX0 + a, 6 * (s + t) + b, sgj * vj5);
+    rmw(CD_EX1 + a, 6 * (s + t) + b, sgj * vj6);
+  }
+}
+template <class RMW>
+VD void ac_t56_apply(int q, int s, double total5, double total6, RMW rmw) {
+  const int a = q / 6, b = q % 6;
+  rmw(CD_EX0 + a, 6 * s + b, total5);
+  rmw(CD_EX1 + a, 6 * s + b, total6);
+}
+
 // One chunk (start frame s, km frames) of one owner thread. slots: the chunk's km slots back to back (k_assemble stages them in LDS with
 // coalesced loads: every byte of a slot is fetched from HBM once and the owner threads' scattered reads are LDS reads);  Rt: [12][9]
 // rotation matrices of the window's frames (row-major), entry 11 = identity;  rmw(hi, lo, v): image(hi, lo) += v (hi >= lo);
 // gadd(cd, v): gradient. Thread ranges are laid out so that a wave of 64 runs at most two of the class bodies:
 //   wave 0: T1 [0, 21) T2 [21, 57), then T3 as a second body of lanes [0, 42)   wave 1: T8, three lanes per entry (ac_t8_partial / ac_t8_apply)
-//   wave 2: T5 [128, 146) T6 [146, 164) T4 [164, 192)   wave 3: T7 [192, 234)
+//   wave 2: T5 + T6, two lanes per entry [128, 164) (ac_t56_partial / ac_t56_apply), T4 [164, 192)   wave 3: T7 [192, 234)
 template <class RMW, class GADD>
 VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slots, const double *Rt, RMW rmw, GADD gadd) {
   if (tid < 21) {
@@ -94,6 +128,7 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     const int e1 = ac_tri(a, b), e2 = ac_tri(ac_jidx(a), ac_jidx(b));
     const double sg2 = ac_jsign(a) * ac_jsign(b);
     double sum = 0.0;
+#pragma unroll 2
     for (int t = 1; t < km; ++t) {
       sum += slots[t * VILO_GRAMC + e1];
       rmw(6 * (s + t) + b, 6 * (s + t) + a, sg2 * slots[t * VILO_GRAMC + e2]);
@@ -104,6 +139,7 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     const int a = (tid - 21) / 6, b = (tid - 21) % 6;
     const int e = ac_tri(a, ac_jidx(b));
     const double sg = ac_jsign(b);
+#pragma unroll 2
     for (int t = 1; t < km; ++t) rmw(6 * (s + t) + b, 6 * s + a, sg * slots[t * VILO_GRAMC + e]);
   }
   if (tid < 42) {
@@ -112,6 +148,7 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     const int e1 = ac_tri(a, ac_kcol(b)), e2 = ac_tri(ac_jidx(a), ac_kcol(b));
     const double sg2 = ac_jsign(a);
     double sum = 0.0;
+#pragma unroll 2
     for (int t = 1; t < km; ++t) {
       sum += slots[t * VILO_GRAMC + e1];
       const double v2 = sg2 * slots[t * VILO_GRAMC + e2];
@@ -121,35 +158,14 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     if (b == 6) gadd(6 * s + a, sum);
     else rmw(ac_restcd(b), 6 * s + a, sum);
   }
-  if (tid >= 128 && tid < 164) {
-    // T5 / T6: tic (T5) / tic2 (T6) component a x pose_f dimension b
-    const bool five = tid < 146;
-    const int q = five ? tid - 128 : tid - 146, a = q / 6, b = q % 6, xj = ac_jidx(b);
-    const double sgj = ac_jsign(b);
-    const int cd = (five ? CD_EX0 : CD_EX1) + a;
-    double sum = 0.0;
-    for (int t = 1; t < km; ++t) {
-      const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
-      const double *Ri = Rt + 9 * s, *Rj = Rt + 9 * (s + t);
-      double vs = 0.0, vj = 0.0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double rj = Rj[3 * c + a];
-        const double n0 = five ? Ri[3 * c + a] - rj : 0.0, m1 = five ? rj : -rj;
-        vs += n0 * Gb[ac_tri(c, b)] + m1 * C1B[16 * c + b];
-        vj += n0 * Gb[ac_tri(c, xj)] + m1 * C1B[16 * c + xj];
-      }
-      sum += vs;
-      rmw(cd, 6 * (s + t) + b, sgj * vj);
-    }
-    rmw(cd, 6 * s + b, sum);
-  } else if (tid >= 164 && tid < 192) {
+  if (tid >= 164 && tid < 192) {
     // T4: rest x rest, upper (a <= b) of the 7 x 7 block {theta_ic, theta_ic2, r}, summed over every t
     int a = 0, rem = tid - 164;
     while (rem >= 7 - a) { rem -= 7 - a; ++a; }
     const int b = a + rem;
     const int e = ac_tri(ac_kcol(a), ac_kcol(b));
     double sum = 0.0;
+#pragma unroll 2
     for (int t = 0; t < km; ++t) sum += slots[t * VILO_GRAMC + e];
     if (b == 6) { if (a != 6) gadd(ac_restcd(a), sum); }
     else rmw(ac_restcd(b), ac_restcd(a), sum);
@@ -157,6 +173,7 @@ VD void assemble_visual_compact_chunk(int tid, int s, int km, const double *slot
     // T7: {tic 0..2, tic2 3..5} (a) x rest (b), summed over every t (identity transforms at t = 0)
     const int a = (tid - 192) / 7, b = (tid - 192) % 7, aa = a % 3, x = ac_kcol(b);
     double sum = 0.0;
+#pragma unroll 2
     for (int t = 0; t < km; ++t) {
       const double *Gb = slots + t * VILO_GRAMC, *C1B = Gb + VILO_GRAMC_TRI;
       const double *Ri = Rt + 9 * (t ? s : 11), *Rj = Rt + 9 * (t ? s + t : 11);

@@ -132,6 +132,13 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
         const double part = (wl < 63) ? ac_t8_partial(q, grp, 3, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt) : 0.0;
         const double p1 = __shfl(part, q + 21, 64), p2 = __shfl(part, q + 42, 64);
         if (wl < 21) ac_t8_apply(q, (part + p1) + p2, rmw);
+      } else if (tid >= 128 && tid < 192) {
+        // wave 2: the tic / tic2 x pose entries, two lanes per entry (odd / even frames), the sums over the frames added in lane order
+        const int wl = tid - 128, q = wl % 18, par = min(wl / 18, 1);
+        double s5 = 0.0, s6 = 0.0;
+        if (wl < 36) ac_t56_partial(q, par, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, s5, s6);
+        const double o5 = __shfl(s5, q + 18, 64), o6 = __shfl(s6, q + 18, 64);
+        if (wl < 18) ac_t56_apply(q, (int)(ct & 255), s5 + o5, s6 + o6, rmw);
       }
       PCLK(w_work += clock64() - w_t0);
     }

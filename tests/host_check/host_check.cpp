@@ -134,6 +134,11 @@ void hc_assemble_compact(int nch, const unsigned *chunk_tab, const double *slots
       for (int grp = 0; grp < 3; ++grp) p[grp] = ac_t8_partial(q, grp, 3, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt);
       ac_t8_apply(q, (p[0] + p[1]) + p[2], rmw);
     }
+    for (int q = 0; q < 18; ++q) {   // wave 2 of the kernel: two lanes per entry (odd / even frames)
+      double s5[2], s6[2];
+      for (int par = 0; par < 2; ++par) ac_t56_partial(q, par, s, km, slots + (size_t)sl0 * VILO_GRAMC, Rt, rmw, s5[par], s6[par]);
+      ac_t56_apply(q, s, s5[0] + s5[1], s6[0] + s6[1], rmw);
+    }
   }
 }
 
