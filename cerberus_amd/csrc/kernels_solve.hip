@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "solve_common.hpp"
 #include "visual_lin.hpp"
+#include "accept_body.hpp"
 
 using namespace vilo;
 
@@ -1189,133 +1190,11 @@ int vilo_launch_embed_sqrt15(vilo_ctx *ctx, BatchDev &b) {
 // k_accept: candidate cost, step quality, accept / reject (TrustRegionMinimizer::{IsStepSuccessful,
 // HandleSuccessfulStep, HandleUnsuccessfulStep, HandleInvalidStep} + DoglegStrategy::Step{Accepted,Rejected,IsInvalid})
 // =================================================================================================
-struct AcceptParams {
-  double min_relative_decrease, function_tolerance, parameter_tolerance;
-  int max_num_iterations, fixed_iterations, init_mode, max_solver_time_us;
-};
-
 __global__ void __launch_bounds__(128) k_accept(BatchDev b, AcceptParams ap) {
   __shared__ double red[128];
   __shared__ double dxs[VILO_MAX_PRIOR_DIM];
   __shared__ int accept_s;
-  const int win = blockIdx.x, tid = threadIdx.x;
-  SolverState &st = b.st[win];
-  if (st.done) return;
-  const WinMeta wm = b.win[win];
-  double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
-  if (!ap.init_mode && !st.step_valid) {
-    if (tid == 0) {
-      // HandleInvalidStep: FAILURE at max_num_consecutive_invalid_steps (5, Ceres default), else DoglegStrategy::StepIsInvalid (mu *= 10,
-      // no reuse). The candidate pass linearised the unchanged point again (the solver left xc = x): the next step starts from it.
-      st.num_invalid++;
-      if (st.num_invalid >= 5) { st.done = 1; st.termination = 2; }
-      else st.mu *= 10.0;
-      st.need_lin = 1;
-      st.iter++;
-      if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
-      if (st.iter >= ap.max_num_iterations && !st.done) { st.done = 1; st.termination = 0; }
-      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-    }
-    return;
-  }
-  // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2)
-  double part = 0.0;
-  for (int c = tid; c < wm.n_waves * VILO_MAX_FRAMES; c += 128) part += b.chunk_cost[(size_t)wm.wave_off * VILO_MAX_FRAMES + c];
-  const double vis = block_sum(part, red);
-  part = 0.0;
-  for (int k = tid; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
-  const double imu = block_sum(part, red);
-  double pri = 0.0, my_hd = 0.0;   // my_hd: row tid of H dx at the candidate (becomes the gradient term when accepted)
-  if (wm.prior_n > 0) {
-    const int n = wm.prior_n;
-    if (tid < wm.prior_nb)
-      prior_dx(xc + b.prior_bstate[win * 40 + tid], b.prior_x0 + (size_t)win * 280 + b.prior_bxoff[win * 40 + tid],
-               b.prior_bsize[win * 40 + tid], dxs + b.prior_bidx[win * 40 + tid]);
-    __syncthreads();
-    const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
-    part = 0.0;
-    if (tid < n) {   // n <= 96 < 128: one row per thread
-      double sacc = 0.0;
-#pragma unroll 16
-      for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + tid] * dxs[q];
-      part = dxs[tid] * (sacc + 2.0 * b0[tid]);
-      my_hd = sacc;
-    }
-    pri = block_sum(part, red) + b.prior_c0[win];
-  }
-  double cand = 0.5 * (vis + imu + pri);
-  if (!isfinite(cand)) cand = 1.7976931348623157e308;
-  if (b.rp_on && b.prep_bad) {
-    // re-propagation: a covariance integrated at this point that is not positive definite has no sqrt_info — the point cannot be
-    // evaluated (its whitened residuals used pivots replaced by 1): treated like a non-finite cost
-    for (int k = 0; k + 1 < wm.n_frames; ++k)
-      if (!b.imu_skip[(size_t)win * 10 + k] && b.prep_bad[(size_t)win * 10 + k]) cand = 1.7976931348623157e308;
-  }
-  if (ap.init_mode) {
-    if (tid == 0) {
-      st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
-      st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
-      // a non-finite evaluation at the initial point: ceres::Solve fails in IterationZero ("Residual and Jacobian evaluation
-      // failed", ResidualBlock::Evaluate's IsArrayValid) and leaves the parameters alone; this window is done, the others go on
-      if (!(cand < 1.7976931348623157e308)) { st.done = 1; st.termination = 2; }
-      // "Maximum solver time reached" is checked before every iteration, the first included
-      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-      st.cur ^= 1;   // the pass that gave this cost also linearised the point: its landmark gradients become the current ones
-    }
-    if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
-    return;
-  }
-  // ambient-space norms for ParameterToleranceReached
-  bool converged = false;
-  if (!ap.fixed_iterations) {
-    double pn = 0.0, ps = 0.0;
-    for (int e = tid; e < XSTRIDE; e += 128) {
-      bool on = e < XO_TD + 1 && !(e >= XO_EX && e < XO_TD && (wm.const_mask & CONST_EX)) && !(e == XO_TD && (wm.const_mask & CONST_TD)) &&
-                !(e >= XO_LB && e < XO_EX && (wm.const_mask & CONST_LB));
-      if (on) { pn += x[e] * x[e]; ps += (x[e] - xc[e]) * (x[e] - xc[e]); }
-    }
-    for (int l = tid; l < wm.L; l += 128) {
-      const double a = b.lam[wm.lm_off + l], c = b.lamc[wm.lm_off + l];
-      pn += a * a; ps += (a - c) * (a - c);
-    }
-    const double xn = sqrt(block_sum(pn, red)), sn = sqrt(block_sum(ps, red));
-    if (sn <= ap.parameter_tolerance * (xn + ap.parameter_tolerance)) converged = true;
-    if (!converged && fabs(st.x_cost - cand) <= ap.function_tolerance * st.x_cost) converged = true;
-  }
-  if (converged) {
-    if (tid == 0) { st.done = 1; st.termination = 1; st.cand_cost = cand; }
-    return;
-  }
-  if (tid == 0) {
-    const double rel = (st.x_cost - cand) / st.model_cost_change;
-    st.cand_cost = cand;
-    st.num_invalid = 0;
-    if (rel > ap.min_relative_decrease) {
-      accept_s = 1;
-      st.x_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
-      if (rel < 0.25) st.radius *= 0.5;
-      if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
-      st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
-      st.need_lin = 1;
-      st.cur ^= 1;   // the candidate's linearisation (made by the pass that evaluated its cost) becomes the current one
-      st.num_successful++;
-    } else {
-      accept_s = 0;
-      st.radius *= 0.5;
-      st.need_lin = 0;
-    }
-    st.iter++;
-    if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
-    if (st.iter >= ap.max_num_iterations) { st.done = 1; st.termination = 0; }
-    // max_solver_time_in_seconds: "Maximum solver time reached" before the next iteration starts (TrustRegionMinimizer's iteration check)
-    if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-  }
-  __syncthreads();
-  if (accept_s) {
-    if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
-    for (int e = tid; e < XSTRIDE; e += 128) x[e] = xc[e];
-    for (int l = tid; l < wm.L; l += 128) b.lam[wm.lm_off + l] = b.lamc[wm.lm_off + l];
-  }
+  accept_body(b, ap, red, dxs, &accept_s);
 }
 
 __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_bad) {
@@ -1333,7 +1212,7 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 // =================================================================================================
 // host-side launch sequence
 // =================================================================================================
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage);   // kernels_wave.hip
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr);   // kernels_wave.hip
 int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
 int vilo_solver_form(const BatchDev &b);                                                                    // kernels_wave.hip
 
@@ -1390,13 +1269,21 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     P0(1);
     hipLaunchKernelGGL(k_imu_linearize, dim3(W * 5), dim3(64), 0, s, b, 1);
     P1();
-    P0(5);
-    hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+    // small batches: the trust-region bookkeeping (k_accept's body) runs as the first phase of k_assemble — an iteration there is a chain
+    // of kernel latencies and loses one (128 windows + 1.1 %, 256 + 1.5 %). A full batch keeps the kernel of its own: its memory-bound
+    // work runs at eight workgroups per CU there, at k_assemble's three it costs more than the launch (4096 windows - 2 %: measured).
+    // VILO_FUSE_ACCEPT_MAX_WINDOWS moves the threshold (0: never).
+    static const int fuse_max = [] { const char *e = getenv("VILO_FUSE_ACCEPT_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+    const bool fuse_accept = W <= fuse_max;
+    if (!fuse_accept) {
+      P0(5);
+      hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+      P1();
+    }
+    P0(8);
+    if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr) != VILO_OK) return VILO_ERR_HIP;
     P1();
     ap.init_mode = 0;
-    P0(8);
-    if (vilo_launch_wave_solver(ctx, b, sp, s, 0) != VILO_OK) return VILO_ERR_HIP;
-    P1();
     if (vilo_solver_form(b) == 3) {
       // three-stage form (kernels_split.hip): chain -> pose system -> back-substitutions + step, then the complete single-wave solver for
       // the windows a stage flagged (a factorisation failed: the retry loop lives there) — it returns at once for the rest

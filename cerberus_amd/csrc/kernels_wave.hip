@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "solve_common.hpp"
 #include "assemble_compact.hpp"
+#include "accept_body.hpp"
 #include "chain_common.hpp"
 
 using namespace vilo;
@@ -36,7 +37,7 @@ __device__ __forceinline__ int cl_pos(int hi, int lo) { return ((hi * (hi + 1)) 
 #define ASM_THREADS 256
 
 template <bool COMPACT>
-__device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
+__device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, const AcceptParams &ap, int fuse_accept) {
   __shared__ double Cl[CL_N];
   __shared__ double Rt[COMPACT ? 12 * 9 : 1];   // compact slots: rotation matrices of the window's frames, [11] = identity
   __shared__ double stage[COMPACT ? AC_STAGE : 1];   // compact slots of the chunk being scattered; afterwards the ring of two IMU factor Grams
@@ -46,6 +47,14 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   __shared__ short inv_pmap[CD_N];
   __shared__ unsigned char act[CD_N];   // cd_active per camera dimension (the predicate has two integer divisions: looked up, not recomputed per entry)
   const int win = blockIdx.x, tid = threadIdx.x;
+  if (fuse_accept) {
+    // k_accept's work first (accept_body.hpp: the candidate's cost, accept / reject, radius and mu, the accepted state): its launch and
+    // this one were consecutive one-workgroup-per-window kernels; threads 0 .. 127 do it, in LDS that the assembly does not need yet
+    double *scr = COMPACT ? stage : gst;
+    accept_body(b, ap, scr, scr + 128, (int *)(scr + 128 + VILO_MAX_PRIOR_DIM));
+    __threadfence_block();
+    __syncthreads();
+  }
   const SolverState &st = b.st[win];
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[win];
@@ -441,12 +450,12 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     bimg[BI_SCAL + 2] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
   }
 }
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
-  assemble_body<false>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal);
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
+  assemble_body<false>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
 }
 // compact Gram slots (BatchDev::compact): the extrinsic-translation blocks are 3 x 3 transforms of the slots' B blocks (assemble_compact.hpp)
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble_c(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
-  assemble_body<true>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal);
+__global__ void __launch_bounds__(ASM_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_assemble_c(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
+  assemble_body<true>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
 }
 
 // =================================================================================================
@@ -1315,12 +1324,14 @@ int vilo_solver_form(const BatchDev &b) {
   if (forced >= 0) return forced;
   return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
 }
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
-    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
-    else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
+    // (ap: the trust-region bookkeeping — k_accept's body — runs as the kernel's first phase)
+    const AcceptParams ap0 = ap ? *ap : AcceptParams{};
+    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
+    else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
   } else if (vilo_solver_form(b) == 4) {
     return vilo_launch_mw4_solver(ctx, b, sp, s);
   } else if (vilo_solver_form(b) == 2) {
