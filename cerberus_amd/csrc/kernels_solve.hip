@@ -1027,13 +1027,16 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 // One wave per PAIR of consecutive factors (2 p, 2 p + 1; the same window): a lane's 16-byte load of an entry-major raw entry brings
 // both factors' values, which halves the scattered 32-byte sectors the gather touches per factor.
-__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
+// single: one wave per FACTOR (workgroup 2 p + h takes factor h of pair p; the pair's loads as before) — small batches, where the second
+// factor of a pair only lengthens the wave's latency chain and half of the SIMDs have nothing to do
+__global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode, int single) {
   __shared__ double Jw[32 * IW_JS];
   // The entry-major raw Jacobians put the same entry of 8 consecutive factors in one 64-byte line, i.e. four pairs share every line they
   // gather from. Workgroup b runs on XCD b % 8 (its own L2): inside each group of 32 workgroups, the four that land on XCD x take the
   // pairs 4 x .. 4 x + 3, so a line is fetched from HBM by one L2 instead of four. (A permutation of [0, gridDim.x); ragged tail: identity.)
-  int pair = blockIdx.x;
-  if ((pair | 31) < (int)gridDim.x) pair = (pair & ~31) + 4 * (pair & 7) + ((pair >> 3) & 3);
+  int pair = blockIdx.x, hsel = -1;
+  if (single) { hsel = pair & 1; pair >>= 1; }
+  else if ((pair | 31) < (int)gridDim.x) pair = (pair & ~31) + 4 * (pair & 7) + ((pair >> 3) & 3);
   const int f0 = 2 * pair, win = f0 / 10;
   SolverState &st = b.st[win];
   if (lin_skip(st, mode)) return;
@@ -1056,6 +1059,7 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode) {
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
+    if (hsel >= 0 && h != hsel) continue;
     const int f = f0 + h;
     double *gout = b.imu_gram + (size_t)f * 780;
     if (b.imu_skip[f]) {   // no factor for this interval: it contributes nothing to the normal equations
@@ -1267,7 +1271,11 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
     P1();
     P0(1);
-    hipLaunchKernelGGL(k_imu_linearize, dim3(W * 5), dim3(64), 0, s, b, 1);
+    {
+      static const int single_max = [] { const char *e = getenv("VILO_IMU_SINGLE_MAX_WINDOWS"); return e ? atoi(e) : 128; }();   // (measured: 128 windows + 1 %, 256 equal, 512 - 3 %)
+      const int single = W <= single_max ? 1 : 0;   // (one wave per factor while the batch leaves SIMDs idle)
+      hipLaunchKernelGGL(k_imu_linearize, dim3(W * (single ? 10 : 5)), dim3(64), 0, s, b, 1, single);
+    }
     P1();
     // small batches: the trust-region bookkeeping (k_accept's body) runs as the first phase of k_assemble — an iteration there is a chain
     // of kernel latencies and loses one (128 windows + 1.1 %, 256 + 1.5 %). A full batch keeps the kernel of its own: its memory-bound
@@ -1338,7 +1346,7 @@ int vilo_marg_linearize(vilo_ctx *ctx, BatchDev &b) {
   if (b.rp_on && (vilo_repropagate_launch(ctx, b, 0, 0) != VILO_OK || vilo_repropagate_launch(ctx, b, 0, 1) != VILO_OK)) return VILO_ERR_HIP;
   launch_visual_linearize(b, sq, ha, ctx->stream, 0);
   hipLaunchKernelGGL(k_imu_raw, dim3((b.W * 10 + 63) / 64), dim3(64), 0, ctx->stream, b, gn, 0);
-  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 5), dim3(64), 0, ctx->stream, b, 0);
+  hipLaunchKernelGGL(k_imu_linearize, dim3(b.W * 5), dim3(64), 0, ctx->stream, b, 0, 0);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }
