@@ -271,11 +271,26 @@ def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
     return out
 
 
+def self_launch(n):
+    """Re-run this command under torch.distributed.run with one rank per GPU of this node (what the driver does for N > 1)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: --gpus %d without a launcher: " % n + " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="2: BASELINE configs[1] (200 landmarks, 500 Hz; the headline metric); "
                     "3: BASELINE configs[2] (1000 landmarks, 400 Hz, K1 re-propagation inside every iteration)")
     ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 4096; 1024 with --config 3)")
@@ -289,6 +304,12 @@ def main():
     ap.add_argument("--single-window-latency", action="store_true", help="also time a batch of one window (default at N = 1)")
     ap.add_argument("--no-single-window", action="store_true", help="skip the one-window timing (rocprofv3 runs: keeps per-kernel averages pure)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1), so
+        # that a bare invocation can never measure one GPU and label it N
+        return self_launch(args.gpus)
     exit_code = 0
     rp = args.config == 3
     args.landmarks = args.landmarks or (1000 if rp else 200)
@@ -298,6 +319,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to label one as the other" % (args.gpus, world), file=sys.stderr)
+        return 2
     import torch
     dist = None
     if world > 1:
@@ -444,7 +468,8 @@ def main():
         bs.close()
         strong = {"workload": "BASELINE configs[3]: %d independent config-2 windows in total, window w on GPU w mod %d" % (STRONG_TOTAL, world),
                   "scaling": "strong", "total_windows": STRONG_TOTAL, "windows_per_gpu": Ws, "n_gpus": world, "steps": args.steps,
-                  "value": STRONG_TOTAL * ITERS * args.steps / el, "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps}
+                  "value": STRONG_TOTAL * ITERS * args.steps / el, "value_per_gpu": STRONG_TOTAL * ITERS * args.steps / el / world,
+                  "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps}
     if rank == 0:
         unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
         value = unit_work / elapsed
@@ -467,6 +492,7 @@ def main():
             "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput" if not rp else
                       "GN iters/sec, 10-KF x 1000-landmark VILO window + 400 Hz IMU preintegration re-propagated every iteration (BASELINE configs[2])",
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value_per_gpu": value / world, "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (%d Hz), "

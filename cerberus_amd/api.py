@@ -226,6 +226,16 @@ class Context:
         if rc != 0:
             raise ViloError("vilo error %d: %s" % (rc, lib().vilo_last_error(self.h).decode()))
 
+    SOLVER_FORMS = {"auto": -1, "wave": 0, "mw": 2, "split": 3, "mw4": 4}
+
+    def set_solver_form(self, form):
+        """vilo_set_solver_form: 'auto' (by batch size), 'wave', 'split' (bitwise equal to 'wave'), 'mw', 'mw4'."""
+        self._check(lib().vilo_set_solver_form(self.h, self.SOLVER_FORMS[form]))
+
+    def set_compact_rows(self, on):
+        """vilo_set_compact_rows: batches created afterwards may / may not use the compact 16-column visual rows."""
+        self._check(lib().vilo_set_compact_rows(self.h, 1 if on else 0))
+
     # ---- ceres::CostFunction-shaped batched evaluation ----
     def eval_proj(self, kind, obs, params, want_jac=True):
         """kind 0/1/2 = TwoFrameOneCam / TwoFrameTwoCam / OneFrameTwoCam; params: list of (n, size) arrays."""

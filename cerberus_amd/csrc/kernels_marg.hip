@@ -1113,6 +1113,24 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       hipEventElapsedTime(&marg_ms, ctx->ev0, ctx->ev1) != hipSuccess)
     return fail(VILO_ERR_HIP);
   ctx->last_marg_ms = marg_ms;
+  // Status first: a window whose result is unusable must not overwrite a pool slot either.
+  std::vector<int> status(W, 0);
+  int any_bad = 0;
+  if (hipMemcpy(status.data(), d_status.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  // A preintegration covariance that is not positive definite has no sqrt_info (its bad pivots were replaced by 1 so that the arithmetic
+  // stays finite): an IMU factor built on it would give a finite but meaningless prior. Only the factors that ENTER this marginalisation
+  // count — MARGIN_OLD uses the factor of interval 0 alone (estimator.cpp:1271-1297), MARGIN_SECOND_NEW no IMU factor at all
+  // (:1389-1410) —, like the reference, which would yield a valid prior whatever the other intervals look like. The flags are those of
+  // the records in force: written by the preparation (batch creation / vilo_batch_prepare) or, with re-propagation, by the mode-0 pass
+  // above. Treated like a non-finite result: the window goes on without a prior and the call reports VILO_ERR_NUMERIC.
+  if (bd.prep_bad) {
+    std::vector<int> pb((size_t)W * 10);
+    std::vector<unsigned char> sk((size_t)W * 10);
+    if (hipMemcpy(pb.data(), bd.prep_bad, sizeof(int) * pb.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(sk.data(), bd.imu_skip, sk.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+    for (int w = 0; w < W; ++w)
+      if (!skip[w] && modes[w] == 0 && !sk[(size_t)w * 10] && pb[(size_t)w * 10]) status[w] = 1;
+  }
   // windows with a prior pool leave J0 / r0 on the device (slot next_prior_slot); only their kept-block bookkeeping is host side
   std::vector<int> dst_slot(W, -1), src_slot(W, -1);
   bool any_host = false;
@@ -1122,6 +1140,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       vilo_prior_pool *pl = refs[w].prior_pool;
       if (refs[w].next_prior_slot < 0 || refs[w].next_prior_slot >= pl->n) return VILO_ERR_BAD_ARG;
       if (keep_prior[w]) { if (refs[w].prior_slot != refs[w].next_prior_slot) src_slot[w] = refs[w].prior_slot; else continue; }
+      else if (status[w] || mws[w].m == 0 || mws[w].n == 0) continue;   // (no prior comes out of this window: its slot is left alone, meta.valid cleared below)
       dst_slot[w] = refs[w].next_prior_slot;
     } else {
       any_host = true;
@@ -1138,33 +1157,11 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return VILO_ERR_HIP;
   }
   std::vector<double> J0, r0((size_t)W * VILO_MAX_PRIOR_DIM);
-  std::vector<int> status(W, 0);
-  int any_bad = 0;
   if (any_host) {
     J0.resize((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM);
     if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(VILO_ERR_HIP);
-  }
-  if (hipMemcpy(status.data(), d_status.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
-  // A window whose preintegration covariance is not positive definite has no sqrt_info (its bad pivots were replaced by 1 so that the
-  // arithmetic stays finite): its solve was failed, and its marginalisation would be a finite but meaningless prior. Treated like a
-  // non-finite result: the window goes on without a prior and the call reports VILO_ERR_NUMERIC. With re-propagation the flags of the
-  // records integrated for this linearisation (prep_bad, rewritten by the mode-0 pass above) count as well.
-  {
-    std::vector<int> bad(W, 0);
-    if (bd.win_bad && hipMemcpy(bad.data(), bd.win_bad, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
-    if (bd.rp_on && bd.prep_bad) {
-      std::vector<int> pb((size_t)W * 10);
-      std::vector<unsigned char> sk((size_t)W * 10);
-      if (hipMemcpy(pb.data(), bd.prep_bad, sizeof(int) * pb.size(), hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(sk.data(), bd.imu_skip, sk.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
-      for (int w = 0; w < W; ++w)
-        for (int k = 0; k < 10; ++k)
-          if (!sk[(size_t)w * 10 + k] && pb[(size_t)w * 10 + k]) bad[w] = 1;
-    }
-    for (int w = 0; w < W; ++w)
-      if (bad[w]) status[w] = 1;
   }
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];

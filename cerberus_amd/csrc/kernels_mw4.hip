@@ -831,10 +831,9 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
 
 int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s) {
   const size_t lds_bytes = (size_t)Q_TOTAL * sizeof(double);
-  static bool attr_set = false;   // (per process: the attribute belongs to the function, not to a context)
-  if (!attr_set) {
+  if (!ctx->mw4_attr_set) {   // (per context = per device, like the other dynamic-LDS opt-ins)
     VILO_HIP(hipFuncSetAttribute((const void *)k_solve_mw4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    ctx->mw4_attr_set = true;
   }
   hipLaunchKernelGGL(k_solve_mw4, dim3(b.W), dim3(256), lds_bytes, s, b, sp);
   return VILO_OK;

@@ -212,7 +212,8 @@ __device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const v
 // Both run the same arithmetic in the same order: pushing an interval in pieces gives bitwise the batch result.
 template <bool STREAM>
 __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
-                                    PreintStream *st, double *terms /* HBM scratch of this interval: 4 * LT_N doubles per sample (+ one sample when STREAM) */) {
+                                    PreintStream *st, double *terms /* HBM scratch of this interval: 4 * LT_N doubles per sample (+ one sample when STREAM) */,
+                                    double *ff_io = nullptr /* repropagate(): the object's force filter (36 doubles, O_FF layout), in and out */) {
   // dF (its 16 non-zero columns), V, the step's 3 x 3 matrix pool, coefficients and noise diagonal: one array, the offsets of
   // preint_blocks.hpp. Padded to 32 rows (48 noise columns) with odd leading dimensions: row 31 and noise 46, 47 stay zero, so the FP64
   // MFMA tiles of jac_cov_update_mfma need no masks.
@@ -268,6 +269,10 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     for (int k = 0; k < 3; ++k) { nd[12 + k] = aw2; nd[15 + k] = gw2; }
     for (int k = 0; k < 6; ++k) { nd[18 + k] = pn2; nd[24 + k] = dpn2; }
   }
+  // IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) resets what the constructor sets EXCEPT the contact-force filter
+  // (foot_force_min / max / window / window_idx / var, :29-41): a re-integration starts from the filter state the previous pass over the
+  // samples left in the object (contact_sensor_type 2 only: the other types have no filter)
+  if (!STREAM && ff_io && cfg.contact_sensor_type == 2 && lane < 36) ffs[lane] = ff_io[lane];
   if (STREAM && lane < 36) ffs[lane] = lane < 4 ? st->ff_min[lane] : lane < 8 ? st->ff_max[lane - 4] : lane < 12 ? st->ff_var[lane - 8] : lane < 32 ? st->ff_win[lane - 12] : (double)st->ff_idx[lane - 32];
   // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
   // (batch: the constructor's sample; streaming: the last sample of the previous push)
@@ -430,6 +435,10 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     sum_dt += dt;
   }
   vilo_preint &o = *outp;
+  if (!STREAM && ff_io && cfg.contact_sensor_type == 2) {
+    __syncthreads();   // (lane 0's last filter update)
+    if (lane < 36) ff_io[lane] = ffs[lane];
+  }
   if (lane == 0) {
     o.sum_dt = sum_dt;
     st3(o.delta_p, dp); st3(o.delta_v, dv);
@@ -466,19 +475,22 @@ __global__ void __launch_bounds__(64) k_repropagate(BatchDev b, const vilo_confi
   __shared__ int same_s;
   const int f = blockIdx.x, win = f / 10, k = f % 10;
   if (b.imu_skip[f] || b.rp_offsets[f + 1] <= b.rp_offsets[f]) return;
-  if (mode && b.st[win].done) return;
+  if (mode == 1 && b.st[win].done) return;
   const double *xs = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
   vilo_preint *rec = (vilo_preint *)b.rp_pre + f;
   if (threadIdx.x == 0) same_s = 1;
   __syncthreads();
   if (threadIdx.x < 10) {
-    const double v = threadIdx.x < 6 ? xs[XO_SB + 9 * k + 3 + threadIdx.x] : xs[XO_LB + 4 * k + (threadIdx.x - 6)];
+    // (mode 2: the object's original integration, at the record's own linearisation point — vilo_batch_set_samples runs it once for
+    // contact_sensor_type 2 so that the force filter holds what constructor + push_back left when the first repropagate() comes)
+    const double v = mode == 2 ? rec->lin_ba[threadIdx.x] : threadIdx.x < 6 ? xs[XO_SB + 9 * k + 3 + threadIdx.x] : xs[XO_LB + 4 * k + (threadIdx.x - 6)];
     lin_s[threadIdx.x] = v;
     if (v != rec->lin_ba[threadIdx.x]) same_s = 0;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
   }
   __syncthreads();
   if (!mode && same_s) return;   // (marginalisation) the record already is the one integrated at the accepted state
-  preint_imu_leg_body<false>(*cfgp, b.rp_samples, b.rp_offsets[f], b.rp_offsets[f + 1], lin_s, rec, nullptr, b.rp_terms + (size_t)b.rp_offsets[f] * (4 * LT_N));
+  preint_imu_leg_body<false>(*cfgp, b.rp_samples, b.rp_offsets[f], b.rp_offsets[f + 1], lin_s, rec, nullptr, b.rp_terms + (size_t)b.rp_offsets[f] * (4 * LT_N),
+                             b.rp_ff ? b.rp_ff + (size_t)f * VILO_FF_N : nullptr);
 }
 
 // push_back() on device-resident objects: workgroup k appends samples[offsets[k] .. offsets[k+1]) to stream ids[k]
@@ -808,7 +820,7 @@ int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, in
 // mode 1: at the candidate the next linearisation pass evaluates; mode 0: at the accepted state (before marginalisation). The
 // whitening matrices of the factors follow (sqrt_info of the new covariance).
 int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage) {
-  if (!b.rp_on || !b.rp_samples || !b.leg) return VILO_OK;
+  if ((!b.rp_on && mode != 2) || !b.rp_samples || !b.leg) return VILO_OK;
   if (stage == 0) {
     hipLaunchKernelGGL(k_repropagate, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, (const vilo_config *)ctx->d_cfg, mode);
     VILO_HIP(hipGetLastError());

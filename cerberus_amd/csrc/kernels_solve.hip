@@ -1218,7 +1218,7 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 // =================================================================================================
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr);   // kernels_wave.hip
 int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
-int vilo_solver_form(const BatchDev &b);                                                                    // kernels_wave.hip
+int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);                                                                    // kernels_wave.hip
 
 int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
@@ -1292,7 +1292,7 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr) != VILO_OK) return VILO_ERR_HIP;
     P1();
     ap.init_mode = 0;
-    if (vilo_solver_form(b) == 3) {
+    if (vilo_solver_form(ctx, b) == 3) {
       // three-stage form (kernels_split.hip): chain -> pose system -> back-substitutions + step, then the complete single-wave solver for
       // the windows a stage flagged (a factorisation failed: the retry loop lives there) — it returns at once for the rest
       P0(12);

@@ -1311,13 +1311,10 @@ int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hip
 int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw4.hip
 // Which solver (0 single wave, 2 two waves, 4 four waves per window, 3 the single wave in three stages): as many waves per window as the
 // batch leaves SIMDs for — four up to one window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond; in
-// three stages once the batch fills the two-waves-per-SIMD stages too. VILO_SOLVER=wave / mw / mw4 pins a form
+// three stages once the batch fills the two-waves-per-SIMD stages too. vilo_set_solver_form pins a form
 // (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
-int vilo_solver_form(const BatchDev &b) {
-  static const int forced = [] {
-    const char *e = getenv("VILO_SOLVER");
-    return !e ? -1 : (!strcmp(e, "mw4") ? 4 : (!strcmp(e, "mw") ? 2 : (!strcmp(e, "wave") ? 0 : (!strcmp(e, "split") ? 3 : -1))));
-  }();
+int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b) {
+  const int forced = ctx->solver_form;   // (vilo_set_solver_form; VILO_SOLVER gives the default at vilo_create)
   static const int max_w4 = [] { const char *e = getenv("VILO_MW4_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
   static const int max_w2 = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
   static const int min_w3 = [] { const char *e = getenv("VILO_SPLIT_MIN_WINDOWS"); return e ? atoi(e) : 1025; }();
@@ -1332,14 +1329,18 @@ int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, h
     const AcceptParams ap0 = ap ? *ap : AcceptParams{};
     if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
     else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
-  } else if (vilo_solver_form(b) == 4) {
+  } else if (vilo_solver_form(ctx, b) == 4) {
     return vilo_launch_mw4_solver(ctx, b, sp, s);
-  } else if (vilo_solver_form(b) == 2) {
+  } else if (vilo_solver_form(ctx, b) == 2) {
     return vilo_launch_mw_solver(ctx, b, sp, s);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       ctx->wave_attr_set = true;
+    }
+    if (stage == 2 && !ctx->mid_attr_set) {   // (k_solve_mid takes the same dynamic LDS, VILO_WAVE_LDS included)
+      VILO_HIP(hipFuncSetAttribute((const void *)k_solve_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      ctx->mid_attr_set = true;
     }
     // stage 1: the complete single-wave solver; stages 2 .. 4: the rest of the three-stage form (k_chain is stage 5 in kernels_split.hip)
     if (stage == 1) hipLaunchKernelGGL(k_solve_wave, dim3(b.W), dim3(64), lds_bytes, s, b, sp, 0);

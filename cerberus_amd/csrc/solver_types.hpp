@@ -30,6 +30,7 @@
 #define PD_N (PD_BP + 13 * 80)
 
 // assembled camera-side system of a window as the single-wave solver streams it (k_assemble -> k_solve_wave)
+#define VILO_FF_N 36      // doubles of an interval's contact-force filter state (preint_blocks.hpp: O_FF layout)
 #define VILO_LEG_REC 42   // doubles of the per-(sample, leg) record of the contact preintegration (preint_blocks.hpp: REC_N)
 #define CIMG_N 3840     // pose system: 15 lower 16 x 16 tiles x 4 accumulator registers x 64 lanes
 #define TK_N 14208      // k_chain's hand-over: T(k) of 11 frames, 5 tiles x 4 registers x 64 lanes each (14080) + the reduced right-hand side so far (80, padded)
@@ -158,6 +159,7 @@ struct BatchDev {
   // preintegration inputs behind the records (optional: vilo_batch_set_samples) for re-propagation inside the iteration, and what the
   // sqrt_info preparation needs
   const vilo_sample *rp_samples;   // all intervals of all windows, concatenated
+  double *rp_ff;                   // [W * 10][VILO_FF_N] contact-force filter of every interval's IMULegIntegrationBase object (contact_sensor_type 2): repropagate() does not reset it
   double *rp_terms;                // [samples][4 legs][VILO_LEG_REC] leg terms of every sample at the current linearisation point (k_repropagate's scratch)
   const int *rp_offsets;           // [W * 10 + 1] interval f integrates samples [rp_offsets[f], rp_offsets[f + 1]) (first = constructor sample)
   void *rp_pre;                    // [W * 10] vilo_preint / vilo_preint_imu records the preparation reads

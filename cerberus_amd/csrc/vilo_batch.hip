@@ -26,10 +26,12 @@ struct vilo_batch {
   // solved a second time with the same options (vilo_batch_reset + vilo_batch_solve loops: replays, Monte-Carlo seeds, bench)
   hipGraphExec_t gexec = nullptr;
   vilo_solve_opts gopts;
-  int g_sqrt_info_mode = 0, g_rp_on = 0;   // context / batch state the captured launch sequence depends on (part of the cache key)
+  int g_sqrt_info_mode = 0, g_rp_on = 0, g_solver_form = -1;   // context / batch state the captured launch sequence depends on (part of the cache key)
   double g_initial_mu = 1e-8;
   // re-propagation buffers (vilo_batch_set_samples): reused by later calls while they are large enough (the arena cannot free)
   vilo_sample *rp_s = nullptr; int *rp_o = nullptr; double *rp_t = nullptr; size_t rp_cap = 0;
+  double *rp_ff = nullptr;          // [W * 10][VILO_FF_N]
+  vilo_preint *rp_orig = nullptr;   // [W * 10] the records as created, kept from the first vilo_batch_set_samples on
   int n_solves = 0;
   bool graph_failed = false;
   // what vilo_batch_prepare needs to run the sqrt_info preparation again (the reference does it in every IMULegFactor::Evaluate)
@@ -397,8 +399,8 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   BatchDev &D = bt->d;
   D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
   // compact visual rows / Gram slots in the solve passes: td must be a constant block in every window (estimate_td: 0, all of the
-  // reference's configurations); VILO_NO_COMPACT=1 keeps the 23-column form (A/B runs)
-  D.compact = getenv("VILO_NO_COMPACT") ? 0 : 1;
+  // reference's configurations); vilo_set_compact_rows(ctx, 0) keeps the 23-column form
+  D.compact = ctx->compact_rows;
   for (int w = 0; w < W; ++w)
     if (!(wins[w].const_mask & CONST_TD)) D.compact = 0;
   TRYB(dev_upload(ctx, bt, &D.win, wins));
@@ -547,6 +549,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
     }
     bt->d_pre = d_pre; bt->leg = leg;
     if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->d_prep_bad, (size_t)W * 10);
+    D.prep_bad = bt->d_prep_bad;   // (per-interval flags of the records in force: the marginalisation looks at the intervals it uses)
     if (rc == VILO_OK) rc = vilo_batch_prepare(ctx, bt);
     // a covariance that is not positive definite has no sqrt_info: that window alone fails (termination FAILURE, like a non-finite
     // IterationZero); the flag is looked at for live intervals only
@@ -587,8 +590,25 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
   if (!ctx || !bt) return VILO_ERR_BAD_ARG;
   BatchDev &D = bt->d;
   if (!samples) {   // back to records integrated once
+    if (!D.rp_on) return VILO_OK;
     D.rp_on = 0;
     if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
+    // d_pre holds what the last re-integration left (the records at the last candidate point): the records the batch was created with come
+    // back from their copy, their sqrt_info is prepared again and win_bad is rebuilt from the flags of that preparation — a covariance
+    // without sqrt_info fails its window again, as it did before the samples were set
+    VILO_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)bt->W * 10;
+    if (bt->rp_orig) VILO_HIP(hipMemcpyAsync(bt->d_pre, bt->rp_orig, sizeof(vilo_preint) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = vilo_batch_prepare(ctx, bt);
+    if (rc != VILO_OK) return rc;
+    std::vector<int> bad(n, 0), winbad(bt->W, 0);
+    std::vector<unsigned char> skip(n);
+    VILO_HIP(hipStreamSynchronize(ctx->stream));
+    VILO_HIP(hipMemcpy(bad.data(), bt->d_prep_bad, sizeof(int) * n, hipMemcpyDeviceToHost));
+    VILO_HIP(hipMemcpy(skip.data(), D.imu_skip, n, hipMemcpyDeviceToHost));
+    for (size_t f = 0; f < n; ++f)
+      if (!skip[f] && bad[f]) winbad[f / 10] = 1;
+    if (D.win_bad) VILO_HIP(hipMemcpy(D.win_bad, winbad.data(), sizeof(int) * (size_t)bt->W, hipMemcpyHostToDevice));
     return VILO_OK;
   }
   if (!offsets) return VILO_ERR_BAD_ARG;
@@ -609,7 +629,18 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
     int rc = dev_alloc(ctx, bt, &bt->rp_s, bt->rp_cap);
     if (rc == VILO_OK && !bt->rp_o) rc = dev_alloc(ctx, bt, &bt->rp_o, n + 1);
     if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &bt->rp_t, bt->rp_cap * (size_t)(4 * VILO_LEG_REC));   // 4 legs x one record per sample
-    if (rc != VILO_OK) { bt->rp_s = nullptr; bt->rp_cap = 0; return rc; }
+    if (rc != VILO_OK) {   // (nothing of a previous set of samples may stay referenced by the launch sequence)
+      bt->rp_s = nullptr; bt->rp_cap = 0;
+      D.rp_on = 0; D.rp_samples = nullptr; D.rp_terms = nullptr; D.rp_offsets = nullptr;
+      if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
+      return rc;
+    }
+  }
+  if (!bt->rp_orig) {   // the records the batch was created with (vilo_batch_set_samples(NULL) brings them back)
+    int rc = dev_alloc(ctx, bt, &bt->rp_orig, n);
+    if (rc != VILO_OK) return rc;
+    VILO_HIP(hipMemcpyAsync(bt->rp_orig, bt->d_pre, sizeof(vilo_preint) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    VILO_HIP(hipStreamSynchronize(ctx->stream));
   }
   vilo_sample *d_s = bt->rp_s;
   int *d_o = bt->rp_o;
@@ -620,6 +651,17 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
   VILO_HIP(hipMemcpy(d_s, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice));
   VILO_HIP(hipMemcpy(d_o, offsets, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
   D.rp_samples = d_s; D.rp_terms = d_t; D.rp_offsets = d_o; D.rp_pre = bt->d_pre; D.prep_bad = bt->d_prep_bad; D.leg = 1; D.rp_on = 1;
+  // Every interval is one IMULegIntegrationBase object that integrated its samples once (the record the batch was created with); the
+  // solver's re-integrations are repropagate() calls on it, and repropagate() leaves the contact-force filter of contact_sensor_type 2 as
+  // the previous pass left it (imu_leg_integration_base.cpp:62-86). The filter state after the original integration depends on the
+  // samples only: that pass is run here once (mode 2: at the records' own linearisation point, which reproduces the records).
+  if (!bt->rp_ff) { int rc = dev_alloc(ctx, bt, &bt->rp_ff, n * VILO_FF_N); if (rc != VILO_OK) { D.rp_on = 0; return rc; } }
+  D.rp_ff = bt->rp_ff;
+  VILO_HIP(hipMemsetAsync(bt->rp_ff, 0, sizeof(double) * n * VILO_FF_N, ctx->stream));
+  if (ctx->cfg.contact_sensor_type == 2) {
+    int rc = vilo_repropagate_launch(ctx, D, 2, 0);
+    if (rc != VILO_OK) { D.rp_on = 0; return rc; }
+  }
   if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }   // the captured launch sequence changes
   return VILO_OK;
 }
@@ -641,7 +683,7 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   const bool want_graph = !ctx->profile && !bt->graph_failed && bt->n_solves >= 1 && getenv("VILO_NO_GRAPH") == nullptr;
   if (opts->max_solver_time_us < 0) { ctx->err = "vilo_solve_opts.max_solver_time_us < 0 (fill the struct with vilo_default_solve_opts)"; return VILO_ERR_BAD_ARG; }
   if (want_graph && (!bt->gexec || memcmp(&bt->gopts, opts, sizeof(*opts)) != 0 || bt->g_sqrt_info_mode != ctx->sqrt_info_mode || bt->g_rp_on != bt->d.rp_on ||
-                     bt->g_initial_mu != ctx->initial_mu)) {
+                     bt->g_initial_mu != ctx->initial_mu || bt->g_solver_form != ctx->solver_form)) {
     if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -651,7 +693,7 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
       if (g) (void)hipGraphDestroy(g);
     }
     if (!bt->gexec) { bt->graph_failed = true; (void)hipGetLastError(); ctx->err.clear(); }
-    else { bt->gopts = *opts; bt->g_sqrt_info_mode = ctx->sqrt_info_mode; bt->g_rp_on = bt->d.rp_on; bt->g_initial_mu = ctx->initial_mu; }
+    else { bt->gopts = *opts; bt->g_sqrt_info_mode = ctx->sqrt_info_mode; bt->g_rp_on = bt->d.rp_on; bt->g_initial_mu = ctx->initial_mu; bt->g_solver_form = ctx->solver_form; }
     rc = VILO_OK;
   }
   VILO_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -733,7 +775,8 @@ extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_windo
 
 // Test / profiling hook: copy an internal device array of window `win` to the host. Not part of the
 // reference's interface. what: 0 gram slots, 1 lm_E, 2 lm_g, 3 lm_w (80 x L), 4 cam_g, 5 cam_dh2, 6 cam_y,
-// 7 imu_lin, 8 lm_y, 9 lm_dh2, 10 SolverState scalars + cost trace (24 + 64 doubles), 11 landmark permutation (as doubles)
+// 7 imu_lin, 8 lm_y, 9 lm_dh2, 10 SolverState scalars + cost trace (24 + 64 doubles), 11 landmark permutation (as doubles),
+// 13 the preintegration records (10 x vilo_preint)
 extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win, double *out, int max_n) {
   if (!ctx || !bt || win < 0 || win >= bt->W || !out) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
@@ -759,6 +802,9 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
     case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
     case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
     case 12: src = (const double *)(bt->d.st + win) + 24 + 128 + 1; n = 47; break;   // phase_clk (int64 bit patterns)
+    case 13:   // the window's preintegration records as they stand (vilo_preint x 10; with vilo_batch_set_samples: the last re-integration)
+      if (!bt->leg || !bt->d_pre) return VILO_ERR_UNSUPPORTED;
+      src = (const double *)((const vilo_preint *)bt->d_pre + (size_t)win * 10); n = 10 * sizeof(vilo_preint) / sizeof(double); break;
     case 11: {
       n = wm.L;
       if ((int)n > max_n) return VILO_ERR_BAD_ARG;

@@ -53,6 +53,9 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   ctx->last_solve_ms = 0.0;
   ctx->d_cfg = nullptr;
   ctx->profile = 0;
+  if (const char *e = getenv("VILO_SOLVER"))
+    ctx->solver_form = !strcmp(e, "mw4") ? VILO_SOLVER_MW4 : (!strcmp(e, "mw") ? VILO_SOLVER_MW : (!strcmp(e, "wave") ? VILO_SOLVER_WAVE : (!strcmp(e, "split") ? VILO_SOLVER_SPLIT : VILO_SOLVER_AUTO)));
+  ctx->compact_rows = getenv("VILO_NO_COMPACT") ? 0 : 1;
   for (int i = 0; i < VILO_NKERNEL; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
       hipEventCreate(&ctx->ev1) != hipSuccess || hipMalloc((void **)&ctx->d_cfg, sizeof(vilo_config)) != hipSuccess ||
@@ -86,6 +89,21 @@ extern "C" double vilo_last_solve_ms(const vilo_ctx *ctx) { return ctx ? ctx->la
 extern "C" int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode) {
   if (!ctx || (mode != 0 && mode != 1)) return VILO_ERR_BAD_ARG;
   ctx->sqrt_info_mode = mode;
+  return VILO_OK;
+}
+// Which of the solver's forms the batches of this context take. The forms restate one algorithm; the multi-wave ones differ from the
+// single wave in elimination order and agree with it to rounding, not bitwise, so a caller that needs the same answer for a window
+// whatever the size of the batch it shares pins one (the choice is part of the key of a batch's captured launch sequence).
+extern "C" int vilo_set_solver_form(vilo_ctx *ctx, int form) {
+  if (!ctx || !(form == VILO_SOLVER_AUTO || form == VILO_SOLVER_WAVE || form == VILO_SOLVER_MW || form == VILO_SOLVER_SPLIT || form == VILO_SOLVER_MW4)) return VILO_ERR_BAD_ARG;
+  ctx->solver_form = form;
+  return VILO_OK;
+}
+extern "C" int vilo_get_solver_form(const vilo_ctx *ctx) { return ctx ? ctx->solver_form : VILO_ERR_BAD_ARG; }
+// Batches created from here on may (1, default) or may not (0) use the compact 16-column visual rows when every window keeps td constant.
+extern "C" int vilo_set_compact_rows(vilo_ctx *ctx, int on) {
+  if (!ctx || (on != 0 && on != 1)) return VILO_ERR_BAD_ARG;
+  ctx->compact_rows = on;
   return VILO_OK;
 }
 // Test hook (not part of the reference's interface): DoglegStrategy's mu at the start of the next solves, so that a solve can be resumed

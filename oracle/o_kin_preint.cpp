@@ -382,11 +382,8 @@ void il_propagate(const orc_config &cfg, ILState &st, const orc_sample &s) {
 
 }  // namespace
 
-extern "C" void orc_preintegrate_imu_leg(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
-                                         const double ba[3], const double bg[3], const double rho[4], orc_preint *out) {
-  ILState st;
-  il_init(st, s0, ba, bg, rho);
-  for (int i = 0; i < n; ++i) il_propagate(*cfg, st, samples[i]);
+namespace {
+void il_export(const ILState &st, orc_preint *out) {
   out->sum_dt = st.sum_dt;
   for (int k = 0; k < 3; ++k) {
     out->delta_p[k] = st.delta_p[k];
@@ -401,6 +398,37 @@ extern "C" void orc_preintegrate_imu_leg(const orc_config *cfg, const orc_sample
   }
   std::memcpy(out->jacobian, st.jacobian.d, sizeof(out->jacobian));
   std::memcpy(out->covariance, st.covariance.d, sizeof(out->covariance));
+}
+}  // namespace
+
+extern "C" void orc_preintegrate_imu_leg(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
+                                         const double ba[3], const double bg[3], const double rho[4], orc_preint *out) {
+  ILState st;
+  il_init(st, s0, ba, bg, rho);
+  for (int i = 0; i < n; ++i) il_propagate(*cfg, st, samples[i]);
+  il_export(st, out);
+}
+
+// IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) on an object that already integrated its samples: everything
+// the constructor initialises is reset EXCEPT the contact-force filter of contact_sensor_type 2 — foot_force_min / max / window / window_idx
+// / var are members repropagate() does not touch (:62-86 against :29-41), so the pass starts from the filter state the previous pass
+// left and leaves its own behind. ff (in / out): min[4], max[4], var[4], window[4][5], idx[4] as 36 doubles; all zero = a fresh object.
+extern "C" void orc_preintegrate_imu_leg_ff(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
+                                            const double ba[3], const double bg[3], const double rho[4], double ff[36], orc_preint *out) {
+  ILState st;
+  il_init(st, s0, ba, bg, rho);
+  for (int j = 0; j < 4; ++j) {
+    st.foot_force_min[j] = ff[j]; st.foot_force_max[j] = ff[4 + j]; st.foot_force_var[j] = ff[8 + j];
+    for (int k = 0; k < 5; ++k) st.foot_force_window[j][k] = ff[12 + 5 * j + k];
+    st.foot_force_window_idx[j] = (int)ff[32 + j];
+  }
+  for (int i = 0; i < n; ++i) il_propagate(*cfg, st, samples[i]);
+  for (int j = 0; j < 4; ++j) {
+    ff[j] = st.foot_force_min[j]; ff[4 + j] = st.foot_force_max[j]; ff[8 + j] = st.foot_force_var[j];
+    for (int k = 0; k < 5; ++k) ff[12 + 5 * j + k] = st.foot_force_window[j][k];
+    ff[32 + j] = (double)st.foot_force_window_idx[j];
+  }
+  il_export(st, out);
 }
 
 extern "C" void orc_imu_leg_step_FV(const orc_config *cfg, const orc_sample *s0, const orc_sample *s1, const double delta_q[4],

@@ -8,6 +8,7 @@
 // (corrector.cc), Jacobi scaling. PARITY UNPINNED for the trust-region trajectory (no Ceres here).
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <limits>
 #include <thread>
 
@@ -92,6 +93,17 @@ struct RBlock {
 // constructor sample) — while set, every IMU-leg factor evaluation integrates its interval again at the evaluation point's biases
 const orc_sample *g_rp_samples = nullptr;
 const int32_t *g_rp_offsets = nullptr;
+// One IMULegIntegrationBase object per interval, as far as repropagate() is concerned: the record of the last point it was integrated at
+// (a factor evaluated again at the same biases — Ceres evaluates an accepted candidate's cost and then its Jacobian — does not integrate
+// again) and the contact-force filter of contact_sensor_type 2, which repropagate() does not reset (imu_leg_integration_base.cpp:62-86):
+// pass n starts from the filter state pass n - 1 left, pass 1 being the object's original integration (constructor + push_back).
+struct RpObject {
+  bool valid, ff_ready;
+  double lin[10];
+  double ff[36];
+  orc_preint rec;
+};
+RpObject g_rp_obj[16];   // (10 intervals per window)
 
 struct Problem {
   const orc_config *cfg;
@@ -225,9 +237,25 @@ double eval_block(const Problem &P, RBlock &b, bool want_jac, bool ref_sqrt_info
         // BASELINE configs[2]: the interval is integrated again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
         // at the biases of the point the factor is evaluated at, then evaluated as usual
         const int o0 = g_rp_offsets[b.aux], o1 = g_rp_offsets[b.aux + 1];
-        orc_preint tmp;
-        orc_preintegrate_imu_leg(P.cfg, g_rp_samples + o0, g_rp_samples + o0 + 1, o1 - o0 - 1, par[1] + 3, par[1] + 6, par[2], &tmp);
-        orc_eval_imu_leg(P.cfg, &tmp, par, r_out.data(), jac);
+        RpObject &ob = g_rp_obj[b.aux];
+        double lin[10];
+        for (int c = 0; c < 6; ++c) lin[c] = par[1][3 + c];
+        for (int c = 0; c < 4; ++c) lin[6 + c] = par[2][c];
+        if (!ob.ff_ready) {
+          // the object's first integration: what it leaves in the force filter does not depend on the biases (only type 2 has a filter)
+          for (int c = 0; c < 36; ++c) ob.ff[c] = 0.0;
+          if (P.cfg->contact_sensor_type == 2) {
+            orc_preint first;
+            orc_preintegrate_imu_leg_ff(P.cfg, g_rp_samples + o0, g_rp_samples + o0 + 1, o1 - o0 - 1, lin, lin + 3, lin + 6, ob.ff, &first);
+          }
+          ob.ff_ready = true;
+        }
+        if (!ob.valid || std::memcmp(lin, ob.lin, sizeof(lin)) != 0) {
+          orc_preintegrate_imu_leg_ff(P.cfg, g_rp_samples + o0, g_rp_samples + o0 + 1, o1 - o0 - 1, lin, lin + 3, lin + 6, ob.ff, &ob.rec);
+          std::memcpy(ob.lin, lin, sizeof(lin));
+          ob.valid = true;
+        }
+        orc_eval_imu_leg(P.cfg, &ob.rec, par, r_out.data(), jac);
       } else {
         orc_eval_imu_leg(P.cfg, &P.w->preint[b.aux], par, r_out.data(), jac);
       }
@@ -960,4 +988,5 @@ extern "C" void orc_set_marginalize_threads(int n) { g_marg_threads = n < 1 ? 1 
 extern "C" void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets) {
   g_rp_samples = samples;
   g_rp_offsets = offsets;
+  for (RpObject &ob : g_rp_obj) ob.valid = ob.ff_ready = false;   // (new objects)
 }

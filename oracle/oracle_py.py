@@ -153,6 +153,23 @@ def preintegrate_imu_leg(cfg, samples, lin):
     return out
 
 
+def repropagate_imu_leg(cfg, samples, lin0, lins):
+    """One IMULegIntegrationBase object: constructor + push_back of `samples` at lin0, then one repropagate(ba, bg, rho) per row of lins
+    (imu_leg_integration_base.cpp:62-86: the contact-force filter of contact_sensor_type 2 is NOT reset between the passes).
+    Returns (1 + len(lins), PREINT_DOUBLES): the object's public state after the original integration and after every repropagate."""
+    s, _ = _d(samples)
+    lins = np.atleast_2d(np.ascontiguousarray(lins, dtype=np.float64))
+    out = np.zeros((1 + lins.shape[0], PREINT_DOUBLES))
+    ff = np.zeros(36)
+    sp = C.cast(s.ctypes.data, C.POINTER(Sample))
+    for i, lin in enumerate([np.ascontiguousarray(lin0, dtype=np.float64)] + list(lins)):
+        lin = np.ascontiguousarray(lin)
+        lib().orc_preintegrate_imu_leg_ff(C.byref(cfg), sp, C.cast(s[1:].ctypes.data, C.POINTER(Sample)), C.c_int(s.shape[0] - 1),
+                                          lin[0:3].ctypes.data_as(dp), lin[3:6].ctypes.data_as(dp), lin[6:10].ctypes.data_as(dp),
+                                          ff.ctypes.data_as(dp), C.cast(out[i].ctypes.data, C.POINTER(Preint)))
+    return out
+
+
 def preintegrate_imu(cfg, samples, lin):
     s, _ = _d(samples)
     lin, _ = _d(lin)

@@ -118,6 +118,13 @@ void ref_dJ_drho(const double q[3], double lc, const double rho_fix[4], double d
 }
 
 // ---- preintegration: constructor + push_back per sample
+static void export_il(const IMULegIntegrationBase *il, orc_preint *out) {
+  out->sum_dt = il->sum_dt;
+  for (int i = 0; i < 3; ++i) { out->delta_p[i] = il->delta_p(i); out->delta_v[i] = il->delta_v(i); out->lin_ba[i] = il->linearized_ba(i); out->lin_bg[i] = il->linearized_bg(i); }
+  out->delta_q[0] = il->delta_q.x(); out->delta_q[1] = il->delta_q.y(); out->delta_q[2] = il->delta_q.z(); out->delta_q[3] = il->delta_q.w();
+  for (int j = 0; j < 4; ++j) { out->lin_rho[j] = il->linearized_rho(j); for (int i = 0; i < 3; ++i) out->delta_eps[3 * j + i] = il->delta_epsilon[j](i); }
+  for (int i = 0; i < 31; ++i) for (int j = 0; j < 31; ++j) { out->jacobian[31 * i + j] = il->jacobian(i, j); out->covariance[31 * i + j] = il->covariance(i, j); }
+}
 void ref_preintegrate_imu_leg(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n, const double ba[3],
                               const double bg[3], const double rho[4], orc_preint *out) {
   apply_config(cfg);
@@ -126,11 +133,25 @@ void ref_preintegrate_imu_leg(const orc_config *cfg, const orc_sample *s0, const
     const orc_sample &s = samples[k];
     il->push_back(s.dt, v3(s.acc), v3(s.gyr), vn<12>(s.phi), vn<12>(s.dphi), vn<4>(s.c));
   }
-  out->sum_dt = il->sum_dt;
-  for (int i = 0; i < 3; ++i) { out->delta_p[i] = il->delta_p(i); out->delta_v[i] = il->delta_v(i); out->lin_ba[i] = il->linearized_ba(i); out->lin_bg[i] = il->linearized_bg(i); }
-  out->delta_q[0] = il->delta_q.x(); out->delta_q[1] = il->delta_q.y(); out->delta_q[2] = il->delta_q.z(); out->delta_q[3] = il->delta_q.w();
-  for (int j = 0; j < 4; ++j) { out->lin_rho[j] = il->linearized_rho(j); for (int i = 0; i < 3; ++i) out->delta_eps[3 * j + i] = il->delta_epsilon[j](i); }
-  for (int i = 0; i < 31; ++i) for (int j = 0; j < 31; ++j) { out->jacobian[31 * i + j] = il->jacobian(i, j); out->covariance[31 * i + j] = il->covariance(i, j); }
+  export_il(il, out);
+  delete il;
+}
+// the same object integrated once (constructor + push_back at lin0 = ba bg rho), then IMULegIntegrationBase::repropagate() n_rep times at
+// lins[r] = ba(3) bg(3) rho(4); out[0] = the state after the original integration, out[1 + r] = after repropagate number r
+void ref_repropagate_imu_leg(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n, const double lin0[10], int n_rep,
+                             const double *lins, orc_preint *out) {
+  apply_config(cfg);
+  IMULegIntegrationBase *il = new_il(s0, lin0, lin0 + 3, lin0 + 6);
+  for (int k = 0; k < n; ++k) {
+    const orc_sample &s = samples[k];
+    il->push_back(s.dt, v3(s.acc), v3(s.gyr), vn<12>(s.phi), vn<12>(s.dphi), vn<4>(s.c));
+  }
+  export_il(il, out);
+  for (int r = 0; r < n_rep; ++r) {
+    const double *l = lins + 10 * r;
+    il->repropagate(v3(l), v3(l + 3), vn<4>(l + 6));
+    export_il(il, out + 1 + r);
+  }
   delete il;
 }
 void ref_preintegrate_imu(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n, const double ba[3], const double bg[3],

@@ -76,3 +76,16 @@ def prior_information(prior):
     bb = {a: b[ia:ia + la] for a, (ia, la, _) in blocks.items()}
     x0 = {a: x for a, (_, _, x) in blocks.items()}
     return Hb, bb, x0
+
+
+def repropagate_imu_leg(cfg, samples, lin0, lins):
+    """The reference's own IMULegIntegrationBase: constructor + push_back at lin0, then repropagate() once per row of lins on the SAME
+    object; its public state after each (oracle_py.repropagate_imu_leg is the restatement)."""
+    s = np.ascontiguousarray(samples, dtype=np.float64)
+    lin0 = np.ascontiguousarray(lin0, dtype=np.float64)
+    lins = np.atleast_2d(np.ascontiguousarray(lins, dtype=np.float64))
+    out = np.zeros((1 + lins.shape[0], O.PREINT_DOUBLES))
+    ref_lib().ref_repropagate_imu_leg(C.byref(cfg), C.cast(s.ctypes.data, C.POINTER(O.Sample)), C.cast(s[1:].ctypes.data, C.POINTER(O.Sample)),
+                                      C.c_int(s.shape[0] - 1), lin0.ctypes.data_as(O.dp), C.c_int(lins.shape[0]), lins.ctypes.data_as(O.dp),
+                                      C.cast(out.ctypes.data, C.POINTER(O.Preint)))
+    return out

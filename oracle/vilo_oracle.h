@@ -88,6 +88,11 @@ void orc_dJ_drho(const double q[3], double lc, const double rho_fix[4], double d
  * samples[0..n) (imu_leg_integration_base.cpp:7-136). s0->dt is ignored. */
 void orc_preintegrate_imu_leg(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
                               const double ba[3], const double bg[3], const double rho[4], orc_preint *out);
+/* repropagate() on an object that integrated its samples before (imu_leg_integration_base.cpp:62-86): as orc_preintegrate_imu_leg, but the
+ * contact-force filter of contact_sensor_type 2 (which repropagate does not reset) starts from ff and its final state comes back in ff:
+ * min[4], max[4], var[4], window[4][5], window_idx[4] as 36 doubles; all zero = the constructor's state. */
+void orc_preintegrate_imu_leg_ff(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
+                                 const double ba[3], const double bg[3], const double rho[4], double ff[36], orc_preint *out);
 void orc_preintegrate_imu(const orc_config *cfg, const orc_sample *s0, const orc_sample *samples, int n,
                           const double ba[3], const double bg[3], orc_preint_imu *out);
 /* One midPointIntegration step's F (31x31) and V (31x46), row-major, for FD checks
@@ -194,7 +199,11 @@ typedef struct {
 void orc_default_opts(orc_solve_opts *o);
 /* BASELINE configs[2] ("K1 re-propagation inside the iteration"): while samples != NULL every IMULegFactor evaluation of the window
  * solved / marginalised next first integrates its interval again (repropagate, imu_leg_integration_base.cpp:62-86) at the biases
- * of the evaluation point. offsets[i]..offsets[i+1] are interval i's samples, the first being the constructor sample. Not thread safe. */
+ * of the evaluation point — once per point: an interval evaluated again at the biases it was last integrated at (an accepted candidate's
+ * cost, then its Jacobian) keeps its record. Each interval behaves like ONE IMULegIntegrationBase object across those calls: the
+ * contact-force filter of contact_sensor_type 2, which repropagate() leaves alone, carries over from pass to pass, the first pass being
+ * the object's original integration. The call (also with the same pointers) makes new objects.
+ * offsets[i]..offsets[i+1] are interval i's samples, the first being the constructor sample. Not thread safe. */
 void orc_set_repropagation(const orc_sample *samples, const int32_t *offsets);
 /* Hessian build of orc_marginalize on n threads (the reference: NUM_THREADS = 4 pthreads, marginalization_factor.h:22, .cpp:246-275); default 1. */
 void orc_set_marginalize_threads(int n);

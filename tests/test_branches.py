@@ -157,6 +157,16 @@ def _set_state(w, arrays):
         dst[...] = src
 
 
+@pytest.fixture(params=["auto", "wave", "split"])
+def form_ctx(request, ctx):
+    """The single-step comparisons with each solver form in turn: 'auto' takes the small-batch form a batch of one window gets (four waves
+    per window), 'wave' the single-wave solver of 513 .. 1024 windows, 'split' its three-stage form — the one the headline batch of 4096
+    windows runs (vilo_set_solver_form: a per-context choice, so one process covers them)."""
+    ctx.set_solver_form(request.param)
+    yield ctx
+    ctx.set_solver_form("auto")
+
+
 def _single_steps(ctx, cfg, ocfg, n_iters, radius0, lm_diag=None, mu0=1e-8, **wkw):
     """Teacher-forced comparison: the oracle's trajectory gives the states (x_i, radius_i, mu_i) it visits; from EACH of them both
     implementations take exactly one trust-region iteration (fresh solve from x_i with initial radius radius_i and initial mu mu_i:
@@ -241,13 +251,14 @@ def _check_steps(steps, tol, keys=None, check_state=True):
 
 
 @pytest.mark.parametrize("seed", [42, 48, 51])
-def test_single_steps_along_a_trajectory_with_rejected_runs(ctx, cfg, ocfg, seed):
+def test_single_steps_along_a_trajectory_with_rejected_runs(form_ctx, cfg, ocfg, seed):
     """The far-off starts of test_runs_of_rejected_steps (accept / reject / radius logic pinned there at 1e-3 over a free-running solve,
     because the two restatements drift over the accepted steps of a badly conditioned problem), step by step: from every state the
     oracle visits — rejected ones included, where the same point is tried again with half the radius — both implementations take ONE
     iteration and must agree on the dogleg scalars (alpha, |D^-1 g|^2, |GN step|^2, step norm), model_cost_change, the candidate's
     cost, accept / reject, the new radius and mu and the new state. That separates the logic (exact) from the conditioning of a long
     trajectory."""
+    ctx = form_ctx
     kw = dict(seed=seed, sig_p=1.0, sig_theta=0.4, sig_lambda_rel=0.9, sig_v=1.0, sig_ba=0.3, sig_bg=0.05)
     steps = _single_steps(ctx, cfg, ocfg, 12, 1e8, **kw)
     assert sum(1 for s in steps if s[4]["accepted"] == 0 and s[4]["valid"]) >= 1 and sum(1 for s in steps if s[4]["accepted"] == 1) >= 1
@@ -258,7 +269,8 @@ def test_single_steps_along_a_trajectory_with_rejected_runs(ctx, cfg, ocfg, seed
 
 
 @pytest.mark.parametrize("radius", [1e-3, 1e-1, 1e4])
-def test_single_steps_of_the_three_dogleg_kinds(ctx, cfg, ocfg, radius):
+def test_single_steps_of_the_three_dogleg_kinds(form_ctx, cfg, ocfg, radius):
+    ctx = form_ctx
     kw = dict(seed=11) if radius < 1.0 else dict(seed=20, sig_p=0.2, sig_theta=0.08, sig_lambda_rel=0.6, sig_v=0.5)
     steps = _single_steps(ctx, cfg, ocfg, 8, radius, **kw)
     kinds = {s[4]["kind"] for s in steps}
@@ -267,12 +279,13 @@ def test_single_steps_of_the_three_dogleg_kinds(ctx, cfg, ocfg, radius):
     print("worst single-step relative difference (radius %g): %.2e" % (radius, worst))
 
 
-def test_single_step_at_equal_mu_after_escalation(ctx, cfg, ocfg):
+def test_single_step_at_equal_mu_after_escalation(form_ctx, cfg, ocfg):
     """The mu-escalation window of test_mu_escalation (singular camera-side Hessian, Levenberg-Marquardt diagonal clamped to 1e-12): the
     free-running solves may stop escalating at different mu (rounding decides whether a factorisation of a numerically singular matrix
     fails). Started at the mu the oracle ended its first iteration with (times ten, what the escalation would try next), both factorise
     at the SAME mu, and the step is compared like any other."""
     import ctypes as C
+    ctx = form_ctx
     kw = dict(seed=60, prior=False)
     w = _window(cfg, ocfg, **kw)
     oo = O.default_opts(True, 1)

@@ -105,3 +105,45 @@ def test_a_non_finite_window_fails_alone(ctx, cfg, ocfg):
     assert summ[0].termination != 2 and summ[0].final_cost == s_ref.final_cost
     for a, b in zip(good.state_arrays(), ref.state_arrays()):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_a_bad_covariance_only_spoils_the_marginalisations_that_use_its_factor(ctx, cfg, ocfg):
+    """A preintegration covariance that is not positive definite has no sqrt_info. MARGIN_OLD uses the IMU factor of interval 0 alone
+    (estimator.cpp:1271-1297) and MARGIN_SECOND_NEW none (:1389-1410): a bad covariance in interval 7 must leave both priors exactly as
+    they are without it (the reference would produce them), a bad one in interval 0 fails MARGIN_OLD (NUMERIC, no prior) and nothing else."""
+    from cerberus_amd import api, _ctypes as T
+    from cerberus_amd.synth import PriorData
+    L = api.lib()
+
+    def marg(w, mode):
+        p = PriorData()
+        d, s = w.desc(T)
+        rc = L.vilo_marginalize(ctx.h, 1, C.byref(d), C.byref(s), mode, C.byref(p.struct))
+        p.rebind()
+        return rc, p
+
+    cov0 = 33 + 961   # vilo_preint: 33 scalars, jacobian, covariance
+    for mode in (0, 1):
+        good = _win(cfg, ocfg, n_landmarks=30, seed=8)
+        rc, pg = marg(good, mode)
+        assert rc == OK and pg.struct.valid == 1
+        w7 = _win(cfg, ocfg, n_landmarks=30, seed=8)
+        w7.preint[7, cov0 + 5 * 31 + 5] = -1.0                       # interval 7: a negative diagonal entry
+        rc, p7 = marg(w7, mode)
+        assert rc == OK and p7.struct.valid == 1 and p7.n == pg.n
+        np.testing.assert_array_equal(p7.J0_matrix(), pg.J0_matrix())
+        np.testing.assert_array_equal(p7.r0[:p7.n], pg.r0[:pg.n])
+        w0 = _win(cfg, ocfg, n_landmarks=30, seed=8)
+        w0.preint[0, cov0 + 5 * 31 + 5] = -1.0                       # interval 0: the factor MARGIN_OLD marginalises
+        rc, p0 = marg(w0, mode)
+        if mode == 0:
+            assert rc == NUMERIC and p0.struct.valid == 0
+        else:
+            assert rc == OK and p0.struct.valid == 1
+            np.testing.assert_array_equal(p0.J0_matrix(), pg.J0_matrix())
+    # the solve of such a window still fails alone, whichever interval it is
+    w7 = _win(cfg, ocfg, n_landmarks=30, seed=8)
+    w7.preint[7, cov0 + 5 * 31 + 5] = -1.0
+    rc, summ = _solve_rc(ctx, [w7])
+    assert summ[0].termination == 2

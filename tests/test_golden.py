@@ -243,3 +243,75 @@ def test_gpu_force_model_preintegration_vs_reference(gwin):
     w, smp = gwin, _force_inputs(gwin)
     _check_force_records(c.preintegrate(smp, w.sample_offsets, w.lin), 1e-11, 1e-9, 1e-8)
     c.close()
+
+
+# ------------------------------------------------------------------------------ repropagate() with the force-based contact model
+GR = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preint_force_model_reprop.npz"))
+
+
+def _check_records(pre, ref, rt_state, rt_jac, rt_cov):
+    np.testing.assert_allclose(pre[:, :33], ref[:, :33], rtol=rt_state, atol=1e-13)
+    np.testing.assert_allclose(pre[:, 33:994], ref[:, 33:994], rtol=rt_jac, atol=1e-11)
+    for k in range(ref.shape[0]):
+        cov = ref[k, 994:]
+        np.testing.assert_allclose(pre[k, 994:], cov, rtol=rt_cov, atol=1e-11 * np.abs(cov).max())
+
+
+def test_oracle_repropagation_keeps_the_force_filter(gwin):
+    """tests/golden/preint_force_model_reprop.npz: the reference's own repropagate() (imu_leg_integration_base.cpp:62-86) called twice on
+    an object that integrated its samples with contact_sensor_type 2. It does not reset foot_force_min / max / window (:29-41 are
+    constructor-only), so each pass starts from the filter the previous one left — the frozen passes differ from one another even at
+    equal biases, and from a fresh integration by tens of percent in the covariance."""
+    import copy
+    cfg2 = copy.copy(O.default_config())
+    cfg2.contact_sensor_type = 2
+    w, smp = gwin, _force_inputs(gwin)
+    for name, second in (("same", GR["l1"]), ("vary", GR["l2"])):
+        for k in range(w.F - 1):
+            s = smp[w.sample_offsets[k]:w.sample_offsets[k + 1]]
+            got = O.repropagate_imu_leg(cfg2, s, w.lin[k], [GR["l1"][k], second[k]])
+            _check_records(got, GR[name][k], 1e-12, 1e-10, 1e-9)
+    # the effect is not small: pass 3 at the biases of pass 2 is another record, and a fresh integration at l1 is neither
+    k = 0
+    cov2, cov3 = GR["same"][k, 1, 994:], GR["same"][k, 2, 994:]
+    fresh = O.preintegrate_imu_leg(cfg2, smp[w.sample_offsets[k]:w.sample_offsets[k + 1]], GR["l1"][k])[994:]
+    assert np.abs(cov3 - cov2).max() > 1e-6 * np.abs(cov2).max()
+    assert np.abs(fresh - cov2).max() > 1e-2 * np.abs(cov2).max()
+    np.testing.assert_array_equal(GR["same"][:, 0], GF["preint"])   # (pass 1 is the record of preint_force_model.npz)
+
+
+@pytest.mark.gpu
+def test_gpu_force_model_repropagation_vs_reference(gwin):
+    """k_repropagate on a resident batch (vilo_batch_set_samples) against the reference's repropagate(): the batch's intervals are objects
+    that integrated their samples once; a solve of zero iterations evaluates the initial point = one repropagate() at its biases (pass 2),
+    the next one another (pass 3) — same biases, and still a different record, because the force filter carries on."""
+    import copy
+    from cerberus_amd import api
+    c2 = copy.copy(synth.default_config())
+    c2.contact_sensor_type = 2
+    c = api.Context(c2, 0)
+    w = synth.make_window(synth.default_config(), n_landmarks=24, seed=5)   # (gwin's twin: this one is modified)
+    np.testing.assert_array_equal(w.lin, gwin.lin)
+    smp = _force_inputs(gwin)
+    w.samples[...] = smp
+    w.preint[...] = c.preintegrate(smp, w.sample_offsets, w.lin)
+    _check_records(w.preint, GR["same"][:, 0], 1e-11, 1e-9, 1e-8)
+    w.speed_bias[:10, 3:9] = GR["l1"][:, :6]
+    w.leg_bias[:10, :] = GR["l1"][:, 6:]
+    b = api.Batch(c, [w])
+    try:
+        b.set_samples()
+        opts = api.default_solve_opts(True, 0)
+        for p in (1, 2):
+            b.solve(opts)
+            rec = b.fetch(13).reshape(10, -1)
+            np.testing.assert_array_equal(rec[:, 23:33], GR["l1"])   # lin_ba, lin_bg, lin_rho of the re-integration
+            _check_records(rec, GR["same"][:, p], 1e-11, 1e-9, 1e-8)
+        # switching the samples off and on again makes new objects: the first re-integration is pass 2 again
+        b.set_samples(False)
+        b.set_samples()
+        b.solve(opts)
+        _check_records(b.fetch(13).reshape(10, -1), GR["same"][:, 1], 1e-11, 1e-9, 1e-8)
+    finally:
+        b.close()
+        c.close()

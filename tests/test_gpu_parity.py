@@ -285,10 +285,15 @@ def test_solve_parity(ctx, cfg, ocfg, iters):
     rt_g = np.array([summ.radius_trace[i] for i in range(iters + 1)]); rt_o = np.array([osum.radius_trace[i] for i in range(iters + 1)])
     print("cost gpu", ct_g, "\ncost orc", ct_o, "\nradius gpu", rt_g, "\nradius orc", rt_o)
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
-    np.testing.assert_allclose(ct_g, ct_o, rtol=1e-7)
-    np.testing.assert_allclose(rt_g, rt_o, rtol=1e-6)
+    # states after an equal number of iterations <= 1e-8
+    np.testing.assert_allclose(ct_g, ct_o, rtol=1e-8)
+    np.testing.assert_allclose(rt_g, rt_o, rtol=1e-7)
+    worst = 0.0
     for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
+        err = np.abs(a - bb).max() / max(1.0, np.abs(bb).max())
+        worst = max(worst, err)
+        assert err < 1e-8, (name, err)
+    print("MEASURED test_solve_parity[%d]: states %.2e, cost %.2e" % (iters, worst, np.abs(ct_g / ct_o - 1).max()))
 
 
 def test_solve_skips_long_intervals(ctx, cfg, ocfg):
@@ -346,9 +351,47 @@ def test_solve_config2_window_and_tolerances(ctx, cfg, ocfg):
     summ = ctx.solve_windows([w_g], api.default_solve_opts(False, 12))[0]
     osum = O.solve_window(ocfg, w_o, O.default_opts(False, 12))
     assert (summ.iterations, summ.termination) == (osum.iterations, osum.termination)
-    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
-    for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-8)
+    worst = max(np.abs(a - bb).max() / max(1.0, np.abs(bb).max()) for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()))
+    print("MEASURED test_solve_config2_window_and_tolerances: states %.2e, cost %.2e" % (worst, abs(summ.final_cost / osum.final_cost - 1)))
+    assert worst < 1e-8, worst
+
+
+def test_headline_kernel_set_vs_oracle(ctx, cfg, ocfg):
+    """The exact kernel set bench.py times at its default size, against the oracle: a batch of more than 1024 config-2 windows (seeds
+    20260925 + i, 200 landmarks, 500 Hz: the bench's windows) takes the producer / consumer visual kernel, the compact assembly and the
+    three-stage solver (k_chain / k_solve_mid / k_backsub) — below that size other forms of the same kernels run, so the smaller tests do
+    not see this combination. 12 fixed iterations; first, middle and last window against the oracle at SURVEY 8(c)'s 1e-8."""
+    from cerberus_amd import api, synth
+    W = 1100
+    ws = [synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i)) for i in range(W)]
+    ctx.preintegrate_windows(ws)
+    assert api.lib().vilo_get_solver_form(ctx.h) == -1   # (the batch size chooses)
+    opts = api.default_solve_opts(True, 12)
+    api.lib().vilo_set_profiling(ctx.h, 1)
+    try:
+        summ = ctx.solve_windows(ws, opts)
+        import ctypes as C
+        ms = (C.c_double * 32)(); launches = (C.c_longlong * 32)()
+        nk = api.lib().vilo_get_kernel_times(ctx.h, ms, launches, 32)
+        api.lib().vilo_kernel_name.restype = C.c_char_p
+        ran = {api.lib().vilo_kernel_name(i).decode() for i in range(nk) if launches[i] > 0}
+    finally:
+        api.lib().vilo_set_profiling(ctx.h, 0)
+    assert {"k_chain", "k_solve_mid", "k_backsub", "k_assemble", "k_visual_linearize"} <= ran, ran
+    assert all(s.iterations == 12 for s in summ)
+    worst = 0.0
+    for i in (0, W // 2, W - 1):
+        w_o = synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i))
+        w_o.preint[...] = ws[i].preint   # (the records the GPU integrated: K1 has its own goldens)
+        so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
+        assert (summ[i].iterations, summ[i].num_successful) == (so.iterations, so.num_successful)
+        np.testing.assert_allclose(summ[i].final_cost, so.final_cost, rtol=1e-8)
+        for a, bb in zip(ws[i].state_arrays(), w_o.state_arrays()):
+            if a.size:
+                worst = max(worst, np.abs(a - bb).max() / max(1.0, np.abs(bb).max()))
+    print("MEASURED test_headline_kernel_set_vs_oracle: states %.2e" % worst)
+    assert worst < 1e-8, worst
 
 
 def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
@@ -378,7 +421,9 @@ def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
 def test_small_and_large_batches_linearise_identically(ctx, cfg, ocfg, td_const):
     """Up to 256 packed waves a batch is linearised frame-parallel (k_visual_linearize_tpar + k_visual_reduce: one workgroup per
     (packed wave, frame) so that a few windows still fill the chip), above that by one wave per packed wave. Same window, both forms,
-    bit for bit — a robot gets the same answer alone and inside a fleet of any size. td_const = 1 (estimate_td: 0, the reference's
+    bit for bit: the LINEARISATION of a window does not depend on how many windows share the call. (The per-linearisation solver has several
+    forms chosen by batch size that agree to rounding, not bitwise — tests/test_solver_forms.py; vilo_set_solver_form pins one where a
+    robot must get the same answer alone and inside a fleet of any size.) td_const = 1 (estimate_td: 0, the reference's
     configuration): a left-camera factor's rows take one Gram tile; td_const = 0: all three — the second case also against the oracle."""
     from cerberus_amd import api
     opts = api.default_solve_opts(False, 12)

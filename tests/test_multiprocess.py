@@ -82,3 +82,25 @@ def test_bench_py_itself_on_two_ranks_of_one_gpu():
     assert abs(d["value"] - 64 * it / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     sh = d["config"]["shards"]
     assert sh[0][0] + 1 == sh[1][0]   # interleaved: w mod 2
+    assert d["ranks_in_process_group"] == 2 and abs(d["value_per_gpu"] * 2 - d["value"]) < 1e-9 * d["value"]
+    # the same WITHOUT a launcher: `python bench.py --gpus 2` starts its two ranks itself (a bare invocation must not measure one GPU
+    # and call it two)
+    bare = {k: v for k, v in env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-windows", "64",
+                          "--no-cpu-baseline", "--no-single-window"], capture_output=True, text=True, timeout=900, env=bare, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_in_process_group"] == 2 and d["config"]["windows_per_gpu"] == 32
+
+
+def test_bench_py_refuses_a_world_size_that_is_not_its_gpus_flag():
+    """`--gpus N` is checked against the ranks the launcher started (before anything touches a device): one rank can never be reported as
+    N GPUs, nor N ranks as one."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=ROOT)
+    assert out.returncode == 2 and "WORLD_SIZE=1" in out.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=ROOT)
+    assert out.returncode == 2

@@ -87,6 +87,34 @@ def test_preintegration_contact_sensor_type_2(window):
         assert np.abs(po["cov"] - p0["cov"]).max() > 1e-3 * np.abs(p0["cov"]).max()
 
 
+def test_repropagate_on_the_same_object(window):
+    """IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) three times on one object, oracle restatement beside the
+    compiled reference: with the flag-based contact models every pass equals a fresh integration at its biases; with the force-based
+    model (type 2) the filter members repropagate() does not reset make every pass depend on the ones before."""
+    import copy
+    w = window
+    rng = np.random.default_rng(3)
+    scale = np.array([0.05] * 3 + [0.01] * 3 + [0.005] * 4)
+    for ctype in (0, 2):
+        cfg2 = copy.copy(O.default_config())
+        cfg2.contact_sensor_type = ctype
+        for k in (0, 3, 9):
+            a, b = w.sample_offsets[k], w.sample_offsets[k + 1]
+            smp = force_samples(w.samples[a:b], seed=k) if ctype == 2 else w.samples[a:b]
+            lins = w.lin[k] + rng.normal(size=(3, 10)) * scale
+            po, pr = O.repropagate_imu_leg(cfg2, smp, w.lin[k], lins), R.repropagate_imu_leg(cfg2, smp, w.lin[k], lins)
+            for i in range(4):
+                o_, r_ = _split(po[i]), _split(pr[i])
+                for f in ("sum_dt", "dp", "dq", "dv", "de", "lin"):
+                    np.testing.assert_allclose(o_[f], r_[f], rtol=1e-12, atol=1e-14, err_msg=f)
+                np.testing.assert_allclose(o_["jac"], r_["jac"], rtol=1e-10, atol=1e-12)
+                np.testing.assert_allclose(o_["cov"], r_["cov"], rtol=1e-9, atol=1e-18 + 1e-12 * np.abs(r_["cov"]).max())
+                if i:
+                    fresh = _split(O.preintegrate_imu_leg(cfg2, smp, lins[i - 1]))
+                    d = np.abs(fresh["cov"] - r_["cov"]).max() / np.abs(r_["cov"]).max()
+                    assert (d < 1e-12) if ctype == 0 else (d > 1e-3), (ctype, k, i, d)
+
+
 def test_preintegration_imu(cfg, window):
     w = window
     for k in (0, 4, 9):

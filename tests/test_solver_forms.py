@@ -61,3 +61,40 @@ def test_every_form_escalates_mu(results):
             assert w["retries"] >= 1 and w["iterations"] == 8
             assert w["cost_trace"][-1] <= w["cost_trace"][0]
         assert any(w["cost_trace"][-1] < 0.5 * w["cost_trace"][0] and w["successful"] >= 1 for w in results[form]["escalation"]), form
+
+
+def test_the_form_is_a_property_of_the_context_not_of_the_process(results):
+    """vilo_set_solver_form: two contexts of one process solve the same windows with different forms (each bitwise what a process pinned
+    to that form by VILO_SOLVER gets), and a resident batch that was solved — and its launch sequence captured — with one form follows
+    the context when the form changes (the form is part of the captured sequence's key)."""
+    from cerberus_amd import api, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cfg = synth.default_config()
+
+    def window(seed, L=40):
+        return synth.make_window(cfg, params=synth.default_params(n_landmarks=L, seed=seed, with_prior=True))
+    seeds = [(42, 40), (48, 90), (51, 12), (7, 200)]
+    opts = api.default_solve_opts(True, 8)
+    ca, cb = api.Context(cfg, 0), api.Context(cfg, 0)
+    ca.set_solver_form("wave"); cb.set_solver_form("mw4")
+    got = {}
+    for name, c in (("wave", ca), ("mw4", cb)):
+        ws = [window(s, L) for s, L in seeds]
+        c.preintegrate_windows(ws)
+        c.solve_windows(ws, opts)
+        got[name] = [[a.tolist() for a in w.state_arrays()] for w in ws]
+    for name in ("wave", "mw4"):
+        assert got[name] == [w["state"] for w in results[name]["plain"]], name
+    # one resident batch, solved three times per form (the third replays a captured graph), then the other form on the same batch
+    ws = [window(s, L) for s, L in seeds]
+    ca.preintegrate_windows(ws)
+    b = api.Batch(ca, ws)
+    for form in ("wave", "mw4", "wave"):
+        ca.set_solver_form(form)
+        for _ in range(3):
+            b.reset(); b.solve(opts)
+        b.download()
+        assert [[a.tolist() for a in w.state_arrays()] for w in ws] == got[form], form
+    b.close()
+    assert api.lib().vilo_set_solver_form(ca.h, 1) != 0   # no such form
+    ca.close(); cb.close()
