@@ -16,6 +16,7 @@
 #include "solve_common.hpp"
 #include "visual_lin.hpp"
 #include "accept_body.hpp"
+#include "lin_common.hpp"
 
 using namespace vilo;
 
@@ -70,36 +71,8 @@ __device__ double block_max(double v, double *red) {
 // =================================================================================================
 // k_visual_linearize
 // =================================================================================================
-// Linearisation modes. 0: at the current point (x, lambda), for windows that ask for it (need_lin) — the marginalisation's preMarginalize
-// pass; the landmark gradients go to buffer 0. 1: at the candidate (xc, lambda_c) of every window still iterating — the solve loop; the
-// landmark gradients go to the buffer the current linearisation does NOT use (k_accept flips st.cur when the candidate is accepted; the
-// steps that follow a rejected candidate still need the current one's gradients). Everything else a linearisation writes is read only
-// right after an accepted candidate and has one buffer.
-__device__ __forceinline__ bool lin_skip(const SolverState &st, int mode) { return st.done || (mode == 0 && !st.need_lin); }
-__device__ __forceinline__ double *lin_lm_g(BatchDev &b, const SolverState &st, int mode) { return mode ? b.lm_gbuf[1 - st.cur] : b.lm_gbuf[0]; }
 #define XROW 24   // LDS stride of a row: 23 columns + 1 pad (rows start 16-byte aligned: ds_write_b128)
 #define XLANE 50  // LDS stride per lane: 2 rows + 2 pad (8 consecutive lanes of a 16-byte store hit 8 distinct groups of 4 banks)
-
-// Per-lane view of a packed wave (WaveMeta): which chunk (start frame) a lane belongs to.
-struct LaneSeg {
-  int seg, s, gi, li;   // segment (-1: padding lane), start frame, global / window-local landmark index
-  bool active;
-};
-__device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkMeta *chunks, int lane, int cs[4], int cn[4], int ckm[4], int cgo[4]) {
-  LaneSeg ls;
-  ls.seg = -1; ls.s = 0; ls.gi = 0; ls.li = 0; ls.active = false;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    cs[g] = 0; cn[g] = 0; ckm[g] = 0; cgo[g] = 0;
-    if (g < wv.nseg) {
-      const ChunkMeta cm = chunks[wv.seg_chunk[g]];
-      cs[g] = cm.s; cn[g] = cm.n; ckm[g] = cm.kmax; cgo[g] = cm.gram_off;
-      const int i = lane - wv.seg_lane0[g];
-      if (i >= 0 && i < cm.n) { ls.seg = g; ls.s = cm.s; ls.gi = cm.lm_off + i; ls.li = cm.lm_local + i; ls.active = true; }
-    }
-  }
-  return ls;
-}
 
 // TPAR = false: one wave per packed wave walks all its frames (the throughput form: landmark-side sums stay in registers).
 // TPAR = true (small batches, b.lm_part != null): one wave per (packed wave, frame offset) so that a handful of windows still
@@ -107,20 +80,29 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
 // walking form adds them — the two forms give bitwise the same linearisation.
 // The factor bodies are visual_lin.hpp's: rotation products hoisted per (start frame, observing frame) pair into an LDS table that 48
 // lanes of the wave build for VT_TB frames at a time, Huber weight folded into the projection Jacobian.
-#define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
 #define VT_TB 2       // frames per table build: lane = (frame of the pair, segment, camera, row) = 2 x 4 x 2 x 3
 // COMPACT (solve passes of batches whose windows all keep td constant; BatchDev::compact): 16-column rows (visual_lin.hpp: GK_*), one
 // Gram tile per camera, slots of VILO_GRAMC doubles for k_assemble<true>; everything on the landmark side is the same.
 #define XROWC 16   // compact rows: 16 columns, a lane's two rows back to back
 #define XLANEC 34  // + 2 pad: the four rows of a k-step start 0 / 32 / 4 / 36 banks apart (conflict-free operand reads, 16-byte aligned stores)
+// LDS of one workgroup of the single-wave visual forms (doubles; every array starts 16-byte aligned). The kernels own the pool and hand it
+// to the body, so that a kernel whose workgroups take different roles (k_lin_small_c: visual and IMU workgroups in one launch) pays for the
+// larger role's LDS, not for the sum.
+template <bool COMPACT> struct VisPool {
+  static constexpr int XL = COMPACT ? XLANEC : XLANE;
+  static constexpr int O_X = 0, N_X = (64 + 4) * XL + 16;          // 4 zero pad lanes = 8 pad rows
+  static constexpr int O_XS = O_X + N_X;                            // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
+  static constexpr int O_WT = O_XS + XSTRIDE;
+  static constexpr int O_TAB = O_WT + ((VW_N + 1) & ~1);
+  static constexpr int N = O_TAB + VT_TB * 4 * VT_N;
+};
 template <bool TPAR, bool COMPACT>
-__device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a, int mode) {
+__device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, double huber_a, int mode, double *pool, int bx, int by) {
   constexpr int XR = COMPACT ? XROWC : XROW, XL = COMPACT ? XLANEC : XLANE;
-  __shared__ __attribute__((aligned(16))) double X[(64 + 4) * XL + 16];   // 4 zero pad lanes = 8 pad rows
-  __shared__ __attribute__((aligned(16))) double xs[XSTRIDE];   // the window's state: poses are indexed per lane (lanes of a wave have different start frames)
-  __shared__ __attribute__((aligned(16))) double wt[VW_N];
-  __shared__ __attribute__((aligned(16))) double tab[VT_TB * 4 * VT_N];
-  const int wave_id = b.wave_order[blockIdx.x];
+  typedef VisPool<COMPACT> VP;
+  static_assert((VP::N_X & 1) == 0 && (VP::O_XS & 1) == 0 && (VP::O_WT & 1) == 0 && (VP::O_TAB & 1) == 0, "16-byte aligned arrays");
+  double *const X = pool + VP::O_X, *const xs = pool + VP::O_XS, *const wt = pool + VP::O_WT, *const tab = pool + VP::O_TAB;
+  const int wave_id = TPAR ? bx : b.wave_order[bx];
   const WaveMeta wv = b.wave[wave_id];
   SolverState &st = b.st[wv.win];
   if (lin_skip(st, mode)) return;
@@ -150,7 +132,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   const bool c1on = lr < 7;    // columns 23 .. 31 of the second tile column do not exist
   const bool lean = COMPACT || (mode != 0 && (wm.const_mask & CONST_TD));
   // (coupling rows w: every row of a landmark's column is written exactly once — the observed poses and the extrinsic / td rows with their
-  // sums, the rest with zeros at the end; TPAR: the host clears w before the launch, the frames of a landmark run in different workgroups)
+  // sums, the rest with zeros at the end; TPAR: the workgroup of frame offset t owns the rows of pose s + t, k_visual_reduce the rest)
   for (int e = lane; e < 4 * XL + 16; e += 64) X[64 * XL + e] = 0.0;
 
   const double *obs = b.obs + wv.obs_off;
@@ -206,7 +188,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
 #pragma unroll
     for (int c = 0; c < 11; ++c) on[c] = obs[(size_t)c * n + lane];
   }
-  const int t_begin = TPAR ? (int)blockIdx.y : 0, t_end = TPAR ? min((int)blockIdx.y + 1, wv.kmax) : wv.kmax;
+  const int t_begin = TPAR ? by : 0, t_end = TPAR ? min(by + 1, wv.kmax) : wv.kmax;
   if (TPAR && t_begin > 0 && active && t_begin < wv.kmax) {   // this workgroup's frame instead of frame 0
     fl_next = flg[(size_t)t_begin * n + lane];
     const double *obn = obs + (size_t)t_begin * 11 * n;
@@ -330,6 +312,12 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
       } else {
 #pragma unroll
         for (int c = 0; c < XR; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
+        if (TPAR && active) {
+          // (a factor that does not exist contributes + 0.0 to the landmark's sums: written, so that nobody has to clear the terms first)
+          double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
+#pragma unroll
+          for (int v = 0; v < LM_NTERM; ++v) pt[(size_t)v * b.n_lm] = 0.0;
+        }
       }
       lds_barrier();
       { const long long c_b = pclk64(); c_proj += c_b - c_a; c_a = c_b; }
@@ -427,10 +415,7 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
         if (c1on && row < 7 && row <= lr) gs[tri23(16 + row, 16 + lr)] = G11[g][r];
       }
     }
-    if (TPAR) {
-      if (active && t > 0 && (fl & 1))
-        for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = wj[c];
-    } else if (active && t > 0 && s + t < VILO_MAX_FRAMES) {
+    if (active && t > 0 && s + t < VILO_MAX_FRAMES) {
       const bool seen = fl & 1;
       for (int c = 0; c < 6; ++c) wbase[(size_t)(6 * j + c) * L + li] = seen ? wj[c] : 0.0;
     }
@@ -456,17 +441,29 @@ __device__ __forceinline__ void visual_linearize_body(BatchDev &b, double sq, do
   {
     const double csum = wave_sum(active ? cost : 0.0);
     double *cost_out = b.chunk_cost + (size_t)wave_id * VILO_MAX_FRAMES;
-    if (TPAR) { if (lane == 0) cost_out[blockIdx.y] = csum; }
+    if (TPAR) { if (lane == 0) cost_out[by] = csum; }
     else if (lane < VILO_MAX_FRAMES) cost_out[lane] = (lane == 0) ? csum : 0.0;
   }
   PCLK(if (prof) { st.phase_clk[28] = clock64() - c_t0; st.phase_clk[29] = c_proj; st.phase_clk[30] = c_gram; st.phase_clk[31] = wv.n_lanes; st.phase_clk[32] = wv.kmax; });
 }
 
-__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, false>(b, sq, huber_a, mode); }
-__global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true, false>(b, sq, huber_a, mode); }
+__global__ void __launch_bounds__(64) k_visual_linearize(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double pool[VisPool<false>::N];
+  visual_linearize_body<false, false>(b, sq, huber_a, mode, pool, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(64) k_visual_linearize_tpar(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double pool[VisPool<false>::N];
+  visual_linearize_body<true, false>(b, sq, huber_a, mode, pool, blockIdx.x, blockIdx.y);
+}
 // the compact forms (solve passes, td constant in every window of the batch)
-__global__ void __launch_bounds__(64) k_visual_linearize_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<false, true>(b, sq, huber_a, mode); }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_tpar_c(BatchDev b, double sq, double huber_a, int mode) { visual_linearize_body<true, true>(b, sq, huber_a, mode); }
+__global__ void __launch_bounds__(64) k_visual_linearize_c(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double pool[VisPool<true>::N];
+  visual_linearize_body<false, true>(b, sq, huber_a, mode, pool, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_tpar_c(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double pool[VisPool<true>::N];
+  visual_linearize_body<true, true>(b, sq, huber_a, mode, pool, blockIdx.x, blockIdx.y);
+}
 
 // =================================================================================================
 // k_visual_linearize_pc: the compact walking form as a PRODUCER / CONSUMER pair of waves
@@ -481,11 +478,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // before, but every packed wave advances at the pace of its slower role instead of the sum of both). Same arithmetic per factor and
 // per Gram tile as k_visual_linearize_c: bitwise the same slots, landmark sums and coupling rows.
 #define PC_XN (64 * XLANEC)   // rows of one buffer: 64 lanes x (2 rows x 16 + 2 pad); a trip past the last lane is clamped, not padded
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc(BatchDev b, double sq, double huber_a, int mode) {
-  __shared__ __attribute__((aligned(16))) double X[2 * PC_XN];
-  __shared__ __attribute__((aligned(16))) double xs[XSTRIDE];
-  __shared__ __attribute__((aligned(16))) double wt[VW_N];
-  __shared__ __attribute__((aligned(16))) double tab[4 * VT_N];   // the pair tables of ONE frame (four segments)
+#define PC_POOL_N (2 * PC_XN + XSTRIDE + 40 + 4 * VT_N)
+__device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm, int mode, double *lds);
+#define IMU_FUSED_LDS 1736   // doubles of one wave of imu_fused_body (below)
+static_assert(2 * IMU_FUSED_LDS <= PC_POOL_N, "two IMU waves fit the visual pair's pool");
+// WITH_IMU (k_visual_linearize_pc_imu; small batches, vilo_solve_launch): workgroups behind the packed waves' linearise the IMU(-leg)
+// factors, one per wave (imu_fused_body): the IMU pass of the iteration runs under the visual one instead of after it. The full-batch
+// kernel is the instantiation without them (its register allocation is not to be disturbed by the other role's).
+template <bool WITH_IMU>
+__device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq, double huber_a, int mode, double gn, double *pool) {
+  if (WITH_IMU && (int)blockIdx.x >= b.n_waves) {
+    const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = 2 * ((int)blockIdx.x - b.n_waves) + wv_;
+    if (f < b.W * 10) imu_fused_body(b, f, gn, mode, pool + wv_ * IMU_FUSED_LDS);
+    return;
+  }
+  double *const X = pool, *const xs = pool + 2 * PC_XN, *const wt = xs + XSTRIDE, *const tab = wt + 40;   // tab: the pair tables of ONE frame (four segments)
   const int wave_id = b.wave_order[blockIdx.x];
   const WaveMeta wv = b.wave[wave_id];
   SolverState &st = b.st[wv.win];
@@ -792,71 +799,48 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   step_barrier();   // (the consumer's last step)
 }
-
-// Second half of the TPAR form: per landmark, the (frame, camera) terms in the order the walking form adds them (frames ascending,
-// left camera before right; an unobserved factor contributed +0.0).
-__global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) {
-  const WaveMeta wv = b.wave[blockIdx.x];
-  const SolverState &st = b.st[wv.win];
-  if (lin_skip(st, mode)) return;
-  const WinMeta wm = b.win[wv.win];
-  const int lane = threadIdx.x;
-  int cs[4], cn[4], ckm[4], cgo[4];
-  const LaneSeg ls = lane_segment(wv, b.chunk, lane, cs, cn, ckm, cgo);
-  if (!ls.active) return;
-  double acc[LM_NTERM];
-#pragma unroll
-  for (int v = 0; v < LM_NTERM; ++v) acc[v] = 0.0;
-  for (int t = 0; t < wv.kmax; ++t)
-    for (int cam = (t == 0 ? 1 : 0); cam < 2; ++cam) {
-      const double *pt = b.lm_part + ((size_t)(t * 2 + cam) * LM_NTERM) * b.n_lm + ls.gi;
-#pragma unroll
-      for (int v = 0; v < LM_NTERM; ++v) acc[v] += pt[(size_t)v * b.n_lm];
-    }
-  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
-  const int L = wm.L, li = ls.li, s = ls.s;
-  b.lm_E[ls.gi] = acc[0];
-  lin_lm_g(b, st, mode)[ls.gi] = acc[1];
-  const bool ex_on = mode == 0 || !(wm.const_mask & CONST_EX), td_on = mode == 0 || !(wm.const_mask & CONST_TD);
-  for (int c = 0; c < 6; ++c) {
-    wbase[(size_t)(6 * s + c) * L + li] = acc[2 + c];
-    wbase[(size_t)(CD_EX0 + c) * L + li] = ex_on ? acc[8 + c] : 0.0;
-    wbase[(size_t)(CD_EX1 + c) * L + li] = ex_on ? acc[14 + c] : 0.0;
-  }
-  wbase[(size_t)CD_TD * L + li] = td_on ? acc[20] : 0.0;
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc(BatchDev b, double sq, double huber_a, int mode) {
+  __shared__ __attribute__((aligned(16))) double pool[PC_POOL_N];
+  visual_linearize_pc_body<false>(b, sq, huber_a, mode, 0.0, pool);
+}
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc_imu(BatchDev b, double sq, double huber_a, int mode, double gn) {
+  __shared__ __attribute__((aligned(16))) double pool[PC_POOL_N];
+  visual_linearize_pc_body<true>(b, sq, huber_a, mode, gn, pool);
 }
 
-// First part of the TPAR form: what the walking form does before its frame loop — the coupling rows of the landmarks of every window
-// that is about to be re-linearised start from zero (windows that keep their linearisation after a rejected step are not touched).
-__global__ void __launch_bounds__(64) k_visual_clear(BatchDev b, int mode) {
-  const WaveMeta wv = b.wave[blockIdx.x];
-  const SolverState &st = b.st[wv.win];
-  if (lin_skip(st, mode)) return;
-  const WinMeta wm = b.win[wv.win];
-  int cs[4], cn[4], ckm[4], cgo[4];
-  const LaneSeg ls = lane_segment(wv, b.chunk, threadIdx.x, cs, cn, ckm, cgo);
-  if (!ls.active) return;
-  double *wbase = b.lm_w + 80 * (size_t)wm.lm_off;
-  for (int a = 0; a < 80; ++a) wbase[(size_t)a * wm.L + ls.li] = 0.0;
-}
+__global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) { visual_reduce_body(b, blockIdx.x, mode, false); }
 
-// both forms behind one call (kernel kind 0 of the profiling table)
-static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream_t s, int mode) {
+// both forms behind one call (kernel kind 0 of the profiling table).
+// fuse_imu (solve passes of small batches with compact rows; gn = g_norm): the IMU factors are linearised by extra workgroups of the same
+// launch (imu_fused_body) and the second half of the frame-parallel form is left to k_assemble_c's extra workgroups (reduce_later).
+__global__ void k_lin_small_c(BatchDev b, double sq, double huber_a, double gn, int mode, int n_imu);   // (below, behind the IMU kernels)
+static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream_t s, int mode, bool fuse_imu = false, double gn = 0.0) {
   if (b.n_waves <= 0) return;
   const bool compact = b.compact && mode != 0;   // (the marginalisation's pass keeps td: full 23-column slots)
   if (b.lm_part) {
-    hipLaunchKernelGGL(k_visual_clear, dim3(b.n_waves), dim3(64), 0, s, b, mode);
-    (void)hipMemsetAsync(b.lm_part, 0, sizeof(double) * (size_t)VILO_MAX_FRAMES * 2 * LM_NTERM * b.n_lm, s);
+    // (every (packed wave, frame) workgroup writes all the terms and coupling rows it owns, zeros included: nothing to clear first)
+    if (compact && fuse_imu) {
+      hipLaunchKernelGGL(k_lin_small_c, dim3(b.W * 10 + b.n_waves * VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, gn, mode, b.W * 10);
+      return;   // (k_assemble_c's extra workgroups finish the frame-parallel form)
+    }
     if (compact) hipLaunchKernelGGL(k_visual_linearize_tpar_c, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     else hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     hipLaunchKernelGGL(k_visual_reduce, dim3(b.n_waves), dim3(64), 0, s, b, mode);
   } else {
     // (VILO_VISUAL_FORM=single keeps the one-wave compact form: A/B runs)
     static const bool pc = [] { const char *e = getenv("VILO_VISUAL_FORM"); return !(e && !strcmp(e, "single")); }();
-    if (compact && pc) hipLaunchKernelGGL(k_visual_linearize_pc, dim3(b.n_waves), dim3(128), 0, s, b, sq, ha, mode);
+    if (compact && pc) {
+      if (fuse_imu) hipLaunchKernelGGL(k_visual_linearize_pc_imu, dim3(b.n_waves + (b.W * 10 + 1) / 2), dim3(128), 0, s, b, sq, ha, mode, gn);
+      else hipLaunchKernelGGL(k_visual_linearize_pc, dim3(b.n_waves), dim3(128), 0, s, b, sq, ha, mode);
+    }
     else if (compact) hipLaunchKernelGGL(k_visual_linearize_c, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
     else hipLaunchKernelGGL(k_visual_linearize, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
   }
+}
+// does launch_visual_linearize(fuse_imu = true) take the IMU factors along for this batch?
+static bool visual_launch_takes_imu(const BatchDev &b) {
+  static const bool pc = [] { const char *e = getenv("VILO_VISUAL_FORM"); return !(e && !strcmp(e, "single")); }();
+  return b.n_waves > 0 && b.compact && (b.lm_part || pc);
 }
 
 // Residual-only evaluation at the candidate point (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
@@ -1123,6 +1107,123 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode, int 
   }
 }
 
+// k_imu_raw + k_imu_linearize of ONE factor in one wave, for small batches: the [J | r] block never leaves LDS. Lane 0 evaluates the
+// factor (the same inline body as k_imu_raw, the same arithmetic) into the zeroed 32 x 48 operand image, the wave whitens it and forms the
+// Gram exactly as k_imu_linearize does (same operand order, same MFMA sequence: bitwise the same Gram and cost). What it buys is the
+// launch structure: the body takes its LDS from the caller, so the workgroups of a visual kernel's launch that are not packed waves can
+// run it — an iteration of a small batch is a chain of kernel latencies, and this takes the two IMU launches out of the chain.
+// lds: IMU_FUSED_LDS doubles = Jw 32 x 48 | PreintHead (126, padded to 128) | the two frames' states (40) | the raw residual (31, padded to 32)
+__device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm, int mode, double *lds) {
+  static_assert(32 * IW_JS + 128 + 40 + 32 == IMU_FUSED_LDS, "LDS of the fused IMU body");
+  double *const Jw = lds, *const hd = lds + 32 * IW_JS, *const xl = hd + 128, *const rl = xl + 40;
+  const int win = f / 10, k = f - 10 * win;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  SolverState &st = b.st[win];
+  // (the buffer the visual half of this pass writes its landmark gradients to: kept for the workgroups of the NEXT launch that finish the
+  // frame-parallel form while the bookkeeping of their window flips st.cur — visual_reduce_body)
+  if (k == 0 && lane == 0 && b.lin_cur) b.lin_cur[win] = st.cur;
+  if (lin_skip(st, mode)) return;
+  double *gout = b.imu_gram + (size_t)f * 780;
+  if (b.imu_skip[f]) {   // no factor for this interval: it contributes nothing to the normal equations
+    if (mode == 0) for (int e = lane; e < IMU_LIN_STRIDE; e += 64) b.imu_lin[(size_t)f * IMU_LIN_STRIDE + e] = 0.0;
+    for (int e = lane; e < 780; e += 64) gout[e] = 0.0;
+    if (lane == 0) b.imu_cost[f] = 0.0;
+    return;
+  }
+  const PreintPrepared &pp = b.prep[f];
+  const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
+  {
+    // stage the record's head and the two frames' states (coalesced), clear the operand image
+    const double *hsrc = (const double *)&pp.head;
+    const double h0 = hsrc[lane], h1 = (lane + 64 < 126) ? hsrc[lane + 64] : 0.0;
+    double xv = 0.0;
+    if (lane < 40) {
+      // [pose_i 7 | sb_i 9 | lb_i 4 | pose_j 7 | sb_j 9 | lb_j 4]
+      const int h = lane >= 20 ? 1 : 0, e = lane - 20 * h;
+      xv = e < 7 ? x[XO_POSE + 7 * (k + h) + e] : (e < 16 ? x[XO_SB + 9 * (k + h) + (e - 7)] : x[XO_LB + 4 * (k + h) + (e - 16)]);
+    }
+    for (int e = lane; e < 32 * IW_JS; e += 64) Jw[e] = 0.0;
+    hd[lane] = h0; hd[lane + 64] = h1;
+    if (lane < 40) xl[lane] = xv;
+  }
+  // sqrt_info operands straight from global memory (in flight under the raw evaluation): 12 A values per lane
+  const double *U = pp.sqrt_info;
+  double av[2][8];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int row = 16 * I + lr, q = 4 * kk + lk;
+      av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
+    }
+  lds_fence();
+  const bool leg = b.win[win].use_leg != 0;
+  if (lane == 0) {
+    // (the residual goes to LDS as it is formed, not through 31 registers that live across the Jacobian blocks)
+    const vilo::PreintHead &P = *(const vilo::PreintHead *)hd;
+    if (leg) imu_leg_raw(P, g_norm, xl, xl + 7, xl + 16, xl + 20, xl + 27, xl + 36, rl, true, Jw, IW_JS, 1);
+    else imu_raw(P, g_norm, xl, xl + 7, xl + 20, xl + 27, rl, true, Jw, IW_JS, 19, 1);
+  }
+  lds_fence();
+  if (lane < (leg ? 31 : 15)) Jw[lane * IW_JS + 38] = rl[lane];
+  lds_fence();
+  // [J | r] operands of the whitening: every entry of the 32 x 48 image (zeros outside the structural non-zeros, as k_imu_linearize's masks)
+  double bv[8][3];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) bv[kk][J] = Jw[(4 * kk + lk) * IW_JS + 16 * J + lr];
+  lds_fence();   // (every operand is in registers before the whitened block overwrites the image)
+  double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
+#pragma unroll
+  for (int I = 0; I < 2; ++I) {
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = (I == 0 ? 0 : 4); kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I][kk], bv[kk][J], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + lk + 4 * r, col = 16 * J + lr;
+        Jw[row * IW_JS + col] = acc[r];   // padding rows / columns come out as exact zeros
+        if (mode == 0 && row < 31 && col < 39) out[row * 39 + col] = acc[r];
+      }
+    }
+  }
+  lds_fence();
+#pragma unroll
+  for (int I = 0; I < 3; ++I) {
+#pragma unroll
+    for (int J = I; J < 3; ++J) {
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const double a_ = Jw[(4 * kk + lk) * IW_JS + 16 * I + lr];
+        const double b_ = Jw[(4 * kk + lk) * IW_JS + 16 * J + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * I + lk + 4 * r, bc = 16 * J + lr;
+        if (a <= bc && bc < 39) gout[tri39(a, bc)] = acc[r];
+        if (a == 38 && bc == 38) b.imu_cost[f] = acc[r];   // |sqrt_info r|^2
+      }
+    }
+  }
+}
+
+// Small batches with compact visual rows: the frame-parallel visual workgroups (one per (packed wave, frame)) and the IMU factors' (one
+// per factor) in ONE launch. The IMU workgroups come first in the grid (they are the longer ones: started first, they end under the
+// visual ones).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lin_small_c(BatchDev b, double sq, double huber_a, double gn, int mode, int n_imu) {
+  constexpr int POOL = VisPool<true>::N > IMU_FUSED_LDS ? VisPool<true>::N : IMU_FUSED_LDS;
+  __shared__ __attribute__((aligned(16))) double pool[POOL];
+  const int bid = blockIdx.x;
+  if (bid < n_imu) { imu_fused_body(b, bid, gn, mode, pool); return; }
+  const int v = bid - n_imu;
+  visual_linearize_body<true, true>(b, sq, huber_a, mode, pool, v % b.n_waves, v / b.n_waves);
+}
+
 // residual-only at the candidate (the last one of a solve). One wave per 64 factors: lane = factor for the raw residual (a scalar chain),
 // then factor by factor lane = row of sqrt_info for |sqrt_info r|^2, the residual broadcast from LDS — sqrt_info is read where the
 // preparation left it (row-major per record; a lane's row is 248 B: its lines stay in L1 across the 31 column steps), so no entry-major
@@ -1216,7 +1317,7 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 // =================================================================================================
 // host-side launch sequence
 // =================================================================================================
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr);   // kernels_wave.hip
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr, int reduce_waves = 0);   // kernels_wave.hip
 int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);                                                                    // kernels_wave.hip
 
@@ -1264,32 +1365,41 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
       if (vilo_repropagate_launch(ctx, b, 1, 1) != VILO_OK) return VILO_ERR_HIP;
       P1();
     }
+    // Small batches: an iteration is a chain of kernel latencies, so the chain is kept short — the IMU factors are linearised by extra
+    // workgroups of the visual launch (imu_fused_body: k_imu_raw + k_imu_linearize of one factor in one wave, bitwise the same Gram), and
+    // the second half of the frame-parallel visual form runs in extra workgroups of k_assemble_c: three launches per iteration
+    // (linearise, bookkeeping + assemble, solve) instead of eight. VILO_SMALL_FUSE_MAX_WINDOWS moves the threshold (0: never).
+    static const int small_max = [] { const char *e = getenv("VILO_SMALL_FUSE_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+    const bool fuse_imu = W <= small_max && visual_launch_takes_imu(b);
     P0(0);
-    launch_visual_linearize(b, sq, ha, s, 1);
+    launch_visual_linearize(b, sq, ha, s, 1, fuse_imu, gn);
     P1();
-    P0(7);
-    hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
-    P1();
-    P0(1);
-    {
-      static const int single_max = [] { const char *e = getenv("VILO_IMU_SINGLE_MAX_WINDOWS"); return e ? atoi(e) : 128; }();   // (measured: 128 windows + 1 %, 256 equal, 512 - 3 %)
-      const int single = W <= single_max ? 1 : 0;   // (one wave per factor while the batch leaves SIMDs idle)
-      hipLaunchKernelGGL(k_imu_linearize, dim3(W * (single ? 10 : 5)), dim3(64), 0, s, b, 1, single);
+    if (!fuse_imu) {
+      P0(7);
+      hipLaunchKernelGGL(k_imu_raw, dim3((W * 10 + 63) / 64), dim3(64), 0, s, b, gn, 1);
+      P1();
+      P0(1);
+      {
+        static const int single_max = [] { const char *e = getenv("VILO_IMU_SINGLE_MAX_WINDOWS"); return e ? atoi(e) : 128; }();   // (measured: 128 windows + 1 %, 256 equal, 512 - 3 %)
+        const int single = W <= single_max ? 1 : 0;   // (one wave per factor while the batch leaves SIMDs idle)
+        hipLaunchKernelGGL(k_imu_linearize, dim3(W * (single ? 10 : 5)), dim3(64), 0, s, b, 1, single);
+      }
+      P1();
     }
-    P1();
+    const bool reduce_later = fuse_imu && b.lm_part;   // (k_assemble_c's extra workgroups run visual_reduce_body)
     // small batches: the trust-region bookkeeping (k_accept's body) runs as the first phase of k_assemble — an iteration there is a chain
     // of kernel latencies and loses one (128 windows + 1.1 %, 256 + 1.5 %). A full batch keeps the kernel of its own: its memory-bound
     // work runs at eight workgroups per CU there, at k_assemble's three it costs more than the launch (4096 windows - 2 %: measured).
     // VILO_FUSE_ACCEPT_MAX_WINDOWS moves the threshold (0: never).
     static const int fuse_max = [] { const char *e = getenv("VILO_FUSE_ACCEPT_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
-    const bool fuse_accept = W <= fuse_max;
+    const bool fuse_accept = W <= fuse_max || reduce_later;   // (the reduce workgroups ride in k_assemble_c's launch, beside the bookkeeping)
     if (!fuse_accept) {
       P0(5);
       hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
       P1();
     }
     P0(8);
-    if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr) != VILO_OK) return VILO_ERR_HIP;
+    if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr, reduce_later ? b.n_waves : 0) != VILO_OK) return VILO_ERR_HIP;
     P1();
     ap.init_mode = 0;
     if (vilo_solver_form(ctx, b) == 3) {

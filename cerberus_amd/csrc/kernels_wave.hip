@@ -20,6 +20,7 @@
 #include "assemble_compact.hpp"
 #include "accept_body.hpp"
 #include "chain_common.hpp"
+#include "lin_common.hpp"
 
 using namespace vilo;
 
@@ -454,7 +455,15 @@ __global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi
   assemble_body<false>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
 }
 // compact Gram slots (BatchDev::compact): the extrinsic-translation blocks are 3 x 3 transforms of the slots' B blocks (assemble_compact.hpp)
+// Workgroups beyond the windows' (small batches, vilo_solve_launch's reduce_later): the second half of the frame-parallel visual form, one
+// packed wave each on their first wave. It writes what only the solver's launch reads (landmark sums, coupling rows), so it runs beside the
+// bookkeeping + assembly of the windows instead of in a launch of its own; the gradient buffer it fills is the one the linearisation
+// pass noted (b.lin_cur), since the bookkeeping of the same launch may flip st.cur under it.
 __global__ void __launch_bounds__(ASM_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_assemble_c(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
+  if ((int)blockIdx.x >= b.W) {
+    if (threadIdx.x < 64) visual_reduce_body(b, (int)blockIdx.x - b.W, 1, true);
+    return;
+  }
   assemble_body<true>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
 }
 
@@ -1321,13 +1330,13 @@ int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b) {
   if (forced >= 0) return forced;
   return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
 }
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap) {
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap, int reduce_waves) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
     // (ap: the trust-region bookkeeping — k_accept's body — runs as the kernel's first phase)
     const AcceptParams ap0 = ap ? *ap : AcceptParams{};
-    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
+    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W + reduce_waves), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
     else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
   } else if (vilo_solver_form(ctx, b) == 4) {
     return vilo_launch_mw4_solver(ctx, b, sp, s);

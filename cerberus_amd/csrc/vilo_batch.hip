@@ -447,6 +447,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   // a landmark's coupling rows with the poses before its start frame are structural zeros: written here once, never again
   if (hipMemsetAsync(D.lm_w, 0, sizeof(double) * (size_t)std::max(lm_total, 1) * 80, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   // few windows: one workgroup per (packed wave, frame) instead of per packed wave, so that the chip is not left to 3 waves per window
+  // (the landmark-side terms every such workgroup writes: all of them, zeros included — nothing reads an entry nobody wrote)
   D.lm_part = nullptr;
   const char *tp_env = getenv("VILO_TPAR_MAX_WAVES");   // tuning aid; VILO_NO_TPAR=1 = 0
   const size_t tpar_max = getenv("VILO_NO_TPAR") ? 0 : (tp_env ? (size_t)atol(tp_env) : 256);
@@ -487,6 +488,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.Bimg, (size_t)W * BI_N));
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));
   TRYB(dev_alloc(ctx, bt, &D.status, 1));
+  TRYB(dev_alloc(ctx, bt, &D.lin_cur, (size_t)W));
   if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
     vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP;
   }
