@@ -13,21 +13,25 @@ struct AcceptParams {
   int max_num_iterations, fixed_iterations, init_mode, max_solver_time_us;
 };
 
-// sum over threads 0 .. 127 through LDS (every thread of the workgroup must call); the tree k_accept has always used
-__device__ __forceinline__ double block_sum128(double v, double *red) {
+// sums over threads 0 .. 127 (every thread of the workgroup must call): within each of the two waves by shuffles, across them through
+// LDS — two workgroup barriers per call whatever the number of sums (the 7-step LDS tree this replaces cost nine per sum, and the
+// bookkeeping is a chain of barriers and global round trips: see accept_body). red: 8 doubles.
+__device__ __forceinline__ void block_sum128x3(double &a, double &b_, double &c, double *red) {
   const int t = threadIdx.x;
-  if (t < 128) red[t] = v;
+  const bool in = t < 128;
+  const double wa = wave_sum(in ? a : 0.0), wb = wave_sum(in ? b_ : 0.0), wc = wave_sum(in ? c : 0.0);
+  if (in && (t & 63) == 0) { red[(t >> 6)] = wa; red[2 + (t >> 6)] = wb; red[4 + (t >> 6)] = wc; }
   __syncthreads();
-  for (int s = 64; s > 0; s >>= 1) {
-    if (t < s) red[t] += red[t + s];
-    __syncthreads();
-  }
-  const double r = red[0];
+  a = red[0] + red[1]; b_ = red[2] + red[3]; c = red[4] + red[5];
   __syncthreads();
-  return r;
+}
+__device__ __forceinline__ double block_sum128(double v, double *red) {
+  double z0 = 0.0, z1 = 0.0;
+  block_sum128x3(v, z0, z1, red);
+  return v;
 }
 
-// red: 128 doubles, dxs: VILO_MAX_PRIOR_DIM doubles, accept_sp: one int (LDS)
+// red: 128 doubles (8 used), dxs: VILO_MAX_PRIOR_DIM doubles, accept_sp: one int (LDS)
 __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap, double *red, double *dxs, int *accept_sp) {
 #define accept_s (*accept_sp)
 
@@ -52,14 +56,11 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
     }
     return;
   }
-  // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2)
-  double part = 0.0;
-  for (int c = t128; c < wm.n_waves * VILO_MAX_FRAMES; c += 128) part += b.chunk_cost[(size_t)wm.wave_off * VILO_MAX_FRAMES + c];
-  const double vis = block_sum128(part, red);
-  part = 0.0;
-  for (int k = t128; k + 1 < wm.n_frames; k += 128) part += b.imu_cost[(size_t)win * 10 + k];
-  const double imu = block_sum128(part, red);
-  double pri = 0.0, my_hd = 0.0;   // my_hd: row tid of H dx at the candidate (becomes the gradient term when accepted)
+  // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2). Every load of the three parts is issued before the
+  // first barrier (the partial sums wait in registers), the three sums share one exchange.
+  double vis = 0.0, imu = 0.0, pri = 0.0, my_hd = 0.0;   // my_hd: row tid of H dx at the candidate (becomes the gradient term when accepted)
+  for (int c = t128; c < wm.n_waves * VILO_MAX_FRAMES; c += 128) vis += b.chunk_cost[(size_t)wm.wave_off * VILO_MAX_FRAMES + c];
+  for (int k = t128; k + 1 < wm.n_frames; k += 128) imu += b.imu_cost[(size_t)win * 10 + k];
   if (wm.prior_n > 0) {
     const int n = wm.prior_n;
     if (tid < wm.prior_nb)
@@ -67,16 +68,16 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
                b.prior_bsize[win * 40 + tid], dxs + b.prior_bidx[win * 40 + tid]);
     __syncthreads();
     const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
-    part = 0.0;
     if (tid < n) {   // n <= 96 < 128: one row per thread
       double sacc = 0.0;
 #pragma unroll 16
       for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + tid] * dxs[q];
-      part = dxs[tid] * (sacc + 2.0 * b0[tid]);
+      pri = dxs[tid] * (sacc + 2.0 * b0[tid]);
       my_hd = sacc;
     }
-    pri = block_sum128(part, red) + b.prior_c0[win];
   }
+  block_sum128x3(vis, imu, pri, red);
+  if (wm.prior_n > 0) pri += b.prior_c0[win];
   double cand = 0.5 * (vis + imu + pri);
   if (!isfinite(cand)) cand = 1.7976931348623157e308;
   if (b.rp_on && b.prep_bad) {
@@ -112,7 +113,9 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
       const double a = b.lam[wm.lm_off + l], c = b.lamc[wm.lm_off + l];
       pn += a * a; ps += (a - c) * (a - c);
     }
-    const double xn = sqrt(block_sum128(pn, red)), sn = sqrt(block_sum128(ps, red));
+    double z_ = 0.0;
+    block_sum128x3(pn, ps, z_, red);
+    const double xn = sqrt(pn), sn = sqrt(ps);
     if (sn <= ap.parameter_tolerance * (xn + ap.parameter_tolerance)) converged = true;
     if (!converged && fabs(st.x_cost - cand) <= ap.function_tolerance * st.x_cost) converged = true;
   }

@@ -12,6 +12,7 @@
 //                       (integration_base.h:172-198, imu_factor.h:28-188)
 //   prior_dx            MarginalizationFactor::Evaluate's dx (marginalization_factor.cpp:357-377)
 #pragma once
+#include <cstddef>
 #include "vilo_math.hpp"
 
 // Per-(chunk, t) Gram slot of the visual factors: packed upper triangle of X^T X, X = the corrected [J | r] rows of the chunk's landmarks
@@ -356,6 +357,113 @@ VD void imu_raw(const PreintHead &P, double g_norm, const double *pose_i, const 
   put(9, cj + 9, I3);
   put(12, cj + 12, I3);
 }
+
+// ---- The same two factors as a handful of 3 x 3 blocks + a gather table (small batches: imu_fused_body of kernels_solve.hip) ----
+// imu_leg_raw / imu_raw write ~300 Jacobian entries one after the other — a single lane's chain of stores. Every entry of [J | r] is
+// one of: an entry of seven 3 x 3 matrices that depend on the states (R_i^T, [a_p]x, [a_v]x, [dP]x, the two quaternion-product blocks and
+// Qleft(..) dq_dbg), an entry of the preintegration record's head, a residual, or +-1 — times a coefficient out of {1, -1, T, -T}.
+// imu_blocks evaluates the seven matrices and the residual with the expressions of the functions above (same values) into a pool;
+// imu_gather_table says, for every entry of the 32 x 48 operand image of the whitening, where it comes from, so that each lane of a
+// wave fetches the entries it needs for its matrix-core operands itself instead of waiting for one lane to write them all.
+#define IB_RIT 0      // R_i^T
+#define IB_SKAP 9     // [a_p]x
+#define IB_SKAV 18    // [a_v]x
+#define IB_SKDP 27    // [dP]x             (leg factor only)
+#define IB_QLQR 36    // (Qleft(q_j^-1 q_i) Qright(corrected delta_q)).bottomRightCorner<3,3>()
+#define IB_QLDQ 45    // Qleft(q_j^-1 q_i delta_q).bottomRightCorner<3,3>() dq_dbg
+#define IB_QL2 54     // Qleft(corrected delta_q^-1 q_i^-1 q_j).bottomRightCorner<3,3>()
+#define IB_RES 63     // residual (31, padded to 32)
+#define IB_ONE 95     // 1.0
+#define IB_N 96
+// pool: IB_N doubles. leg: IMULegFactor (31 residuals), else IMUFactor (15). Returns T = sum_dt.
+VD double imu_blocks(const PreintHead &P, double g_norm, bool leg, const double *pose_i, const double *sb_i, const double *lb_i,
+                     const double *pose_j, const double *sb_j, const double *lb_j, double *pool) {
+  const v3 G = mk3(0, 0, g_norm);
+  const v3 Pi = ld3(pose_i), Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
+  const v3 Pj = ld3(pose_j), Vj = ld3(sb_j), Baj = ld3(sb_j + 3), Bgj = ld3(sb_j + 6);
+  const quat Qi = ldq_pose(pose_i), Qj = ldq_pose(pose_j);
+  const double T = P.sum_dt;
+  const quat delta_q = mkq(P.delta_q[3], P.delta_q[0], P.delta_q[1], P.delta_q[2]);
+  const m3 dp_dba = ldm(P.dp_dba), dp_dbg = ldm(P.dp_dbg), dq_dbg = ldm(P.dq_dbg), dv_dba = ldm(P.dv_dba), dv_dbg = ldm(P.dv_dbg);
+  const v3 dba = Bai - ld3(P.lin_ba), dbg = Bgi - ld3(P.lin_bg);
+  const quat cq = qmul(delta_q, deltaQ(dq_dbg * dbg));
+  const v3 cv = ld3(P.delta_v) + dv_dba * dba + dv_dbg * dbg;
+  const v3 cp = ld3(P.delta_p) + dp_dba * dba + dp_dbg * dbg;
+  const quat Qi_inv = qinv(Qi);
+  const v3 a_p = qrot(Qi_inv, G * (0.5 * T * T) + Pj - Pi - Vi * T);
+  const v3 a_v = qrot(Qi_inv, G * T + Vj - Vi);
+  double *r = pool + IB_RES;
+  st3(r + 0, a_p - cp);
+  st3(r + 3, qvec(qmul(qinv(cq), qmul(Qi_inv, Qj))) * 2.0);
+  st3(r + 6, a_v - cv);
+  if (leg) {
+    const v3 dP = qrot(Qi_inv, Pj - Pi);
+    for (int j = 0; j < 4; ++j) {
+      const double drho = lb_i[j] - P.lin_rho[j];
+      const v3 ceps = ld3(P.delta_eps + 3 * j) + ldm(P.dep_dbg[j]) * dbg + ld3(P.dep_drho[j]) * drho;
+      st3(r + 9 + 3 * j, dP - ceps);
+      r[27 + j] = lb_j[j] - lb_i[j];
+    }
+    st3(r + 21, Baj - Bai);
+    st3(r + 24, Bgj - Bgi);
+    const m3 skdP = skew(dP);
+    for (int e = 0; e < 9; ++e) pool[IB_SKDP + e] = skdP.a[e];
+  } else {
+    st3(r + 9, Baj - Bai);
+    st3(r + 12, Bgj - Bgi);
+  }
+  const m3 RiT = qR(Qi_inv), skap = skew(a_p), skav = skew(a_v);
+  const m3 qlqr = QleftQright33(qmul(qinv(Qj), Qi), cq);
+  const m3 qldq = Qleft33(qmul(qmul(qinv(Qj), Qi), delta_q)) * dq_dbg;
+  const m3 ql2 = Qleft33(qmul(qmul(qinv(cq), Qi_inv), Qj));
+  for (int e = 0; e < 9; ++e) {
+    pool[IB_RIT + e] = RiT.a[e]; pool[IB_SKAP + e] = skap.a[e]; pool[IB_SKAV + e] = skav.a[e];
+    pool[IB_QLQR + e] = qlqr.a[e]; pool[IB_QLDQ + e] = qldq.a[e]; pool[IB_QL2 + e] = ql2.a[e];
+  }
+  pool[IB_ONE] = 1.0;
+  return T;
+}
+
+// Where entry (row, col) of the 32 x 48 operand image [J | r] comes from: source = (region << 8 | offset), region 0 = pool (IB_*),
+// 1 = the record's head (doubles of PreintHead); coefficient code 0: the entry is a structural zero, 1: +1, 2: -1, 3: +T, 4: -T.
+// Packed as (code << 12 | region << 8 | offset). Built at compile time from the same block list as imu_leg_raw / imu_raw write.
+struct ImuGatherTable { unsigned short e[32 * 48]; };
+constexpr ImuGatherTable imu_gather_table(bool leg) {
+  ImuGatherTable t{};
+  for (int i = 0; i < 32 * 48; ++i) t.e[i] = 0;
+  auto set = [&](int r, int c, unsigned region, unsigned off, unsigned code) { t.e[r * 48 + c] = (unsigned short)((code << 12) | (region << 8) | off); };
+  auto put = [&](int r0, int c0, unsigned region, unsigned off, unsigned code) {
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) set(r0 + a, c0 + b, region, off + 3 * a + b, code);
+  };
+  auto diag = [&](int r0, int c0, unsigned code) { for (int a = 0; a < 3; ++a) set(r0 + a, c0 + a, 0, IB_ONE, code); };
+  constexpr unsigned POS = 1, NEG = 2, NEGT = 4;
+  // the blocks both factors share: rows P 0, R 3, V 6; columns pose_i 0, speed-bias_i 6
+  put(0, 0, 0, IB_RIT, NEG); put(0, 3, 0, IB_SKAP, POS); put(3, 3, 0, IB_QLQR, NEG); put(6, 3, 0, IB_SKAV, POS);
+  put(0, 6, 0, IB_RIT, NEGT); put(0, 9, 1, 33, NEG); put(0, 12, 1, 42, NEG); put(3, 12, 0, IB_QLDQ, NEG);
+  put(6, 6, 0, IB_RIT, NEG); put(6, 9, 1, 60, NEG); put(6, 12, 1, 69, NEG);
+  // frame-j blocks start at column 19 in both layouts (the plain IMU factor is embedded in the 38-column layout)
+  put(0, 19, 0, IB_RIT, POS); put(3, 22, 0, IB_QL2, POS); put(6, 25, 0, IB_RIT, POS);
+  if (leg) {
+    for (int j = 0; j < 4; ++j) {
+      put(9 + 3 * j, 0, 0, IB_RIT, NEG); put(9 + 3 * j, 3, 0, IB_SKDP, POS);
+      put(9 + 3 * j, 12, 1, 78 + 9 * j, NEG);
+      for (int a = 0; a < 3; ++a) set(9 + 3 * j + a, 15 + j, 1, 114 + 3 * j + a, NEG);
+      set(27 + j, 15 + j, 0, IB_ONE, NEG);
+      put(9 + 3 * j, 19, 0, IB_RIT, POS);
+      set(27 + j, 34 + j, 0, IB_ONE, POS);
+    }
+    diag(21, 9, NEG); diag(24, 12, NEG); diag(21, 28, POS); diag(24, 31, POS);
+    for (int q = 0; q < 31; ++q) set(q, 38, 0, IB_RES + q, POS);
+  } else {
+    diag(9, 9, NEG); diag(12, 12, NEG); diag(9, 28, POS); diag(12, 31, POS);
+    for (int q = 0; q < 15; ++q) set(q, 38, 0, IB_RES + q, POS);
+  }
+  return t;
+}
+static_assert(offsetof(PreintHead, dp_dba) == 33 * 8 && offsetof(PreintHead, dp_dbg) == 42 * 8 && offsetof(PreintHead, dv_dba) == 60 * 8 &&
+              offsetof(PreintHead, dv_dbg) == 69 * 8 && offsetof(PreintHead, dep_dbg) == 78 * 8 && offsetof(PreintHead, dep_drho) == 114 * 8,
+              "head offsets used by imu_gather_table");
 
 // dx of one kept block of the prior (marginalization_factor.cpp:357-377); size = global size (7 -> 6 local).
 VD void prior_dx(const double *x, const double *x0, int size, double *dx) {

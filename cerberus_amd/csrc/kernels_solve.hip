@@ -480,20 +480,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define PC_XN (64 * XLANEC)   // rows of one buffer: 64 lanes x (2 rows x 16 + 2 pad); a trip past the last lane is clamped, not padded
 #define PC_POOL_N (2 * PC_XN + XSTRIDE + 40 + 4 * VT_N)
 __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm, int mode, double *lds);
-#define IMU_FUSED_LDS 1736   // doubles of one wave of imu_fused_body (below)
+#define IMU_FUSED_LDS 1800   // doubles of one wave of imu_fused_body (below)
 static_assert(2 * IMU_FUSED_LDS <= PC_POOL_N, "two IMU waves fit the visual pair's pool");
 // WITH_IMU (k_visual_linearize_pc_imu; small batches, vilo_solve_launch): workgroups behind the packed waves' linearise the IMU(-leg)
 // factors, one per wave (imu_fused_body): the IMU pass of the iteration runs under the visual one instead of after it. The full-batch
 // kernel is the instantiation without them (its register allocation is not to be disturbed by the other role's).
 template <bool WITH_IMU>
-__device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq, double huber_a, int mode, double gn, double *pool) {
-  if (WITH_IMU && (int)blockIdx.x >= b.n_waves) {
-    const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = 2 * ((int)blockIdx.x - b.n_waves) + wv_;
+__device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq, double huber_a, int mode, double gn, double *pool, int imu_first) {
+  // WITH_IMU: the first (W * 10 + 1) / 2 workgroups are the IMU factors', one factor per wave. First, because they are the short ones (a
+  // third of the longest packed wave's time): the packed waves are launched longest first, so what has to wait for a slot behind the IMU
+  // workgroups are the short packed waves, which still end before the long ones. (Behind the packed waves the IMU workgroups of 128
+  // windows start when the first packed waves retire and end last: 57 instead of 49 us; two factors per wave to make them all resident
+  // from the start: slower still, 128 windows 545 -> 536 k, 256 windows 963 -> 863 k window-iterations/s.)
+  const int n_imu_wg = WITH_IMU ? (b.W * 10 + 1) / 2 : 0;
+  const int imu_lo = imu_first ? 0 : b.n_waves;
+  if (WITH_IMU && (int)blockIdx.x >= imu_lo && (int)blockIdx.x < imu_lo + n_imu_wg) {
+    const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = 2 * ((int)blockIdx.x - imu_lo) + wv_;
     if (f < b.W * 10) imu_fused_body(b, f, gn, mode, pool + wv_ * IMU_FUSED_LDS);
     return;
   }
   double *const X = pool, *const xs = pool + 2 * PC_XN, *const wt = xs + XSTRIDE, *const tab = wt + 40;   // tab: the pair tables of ONE frame (four segments)
-  const int wave_id = b.wave_order[blockIdx.x];
+  const int wave_id = b.wave_order[(int)blockIdx.x - (imu_first ? n_imu_wg : 0)];
   const WaveMeta wv = b.wave[wave_id];
   SolverState &st = b.st[wv.win];
   if (lin_skip(st, mode)) return;
@@ -801,11 +808,11 @@ __device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq,
 }
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc(BatchDev b, double sq, double huber_a, int mode) {
   __shared__ __attribute__((aligned(16))) double pool[PC_POOL_N];
-  visual_linearize_pc_body<false>(b, sq, huber_a, mode, 0.0, pool);
+  visual_linearize_pc_body<false>(b, sq, huber_a, mode, 0.0, pool, 0);
 }
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc_imu(BatchDev b, double sq, double huber_a, int mode, double gn) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_visual_linearize_pc_imu(BatchDev b, double sq, double huber_a, int mode, double gn, int imu_first) {
   __shared__ __attribute__((aligned(16))) double pool[PC_POOL_N];
-  visual_linearize_pc_body<true>(b, sq, huber_a, mode, gn, pool);
+  visual_linearize_pc_body<true>(b, sq, huber_a, mode, gn, pool, imu_first);
 }
 
 __global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) { visual_reduce_body(b, blockIdx.x, mode, false); }
@@ -830,7 +837,11 @@ static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream
     // (VILO_VISUAL_FORM=single keeps the one-wave compact form: A/B runs)
     static const bool pc = [] { const char *e = getenv("VILO_VISUAL_FORM"); return !(e && !strcmp(e, "single")); }();
     if (compact && pc) {
-      if (fuse_imu) hipLaunchKernelGGL(k_visual_linearize_pc_imu, dim3(b.n_waves + (b.W * 10 + 1) / 2), dim3(128), 0, s, b, sq, ha, mode, gn);
+      // (order of the two kinds of workgroup, measured in the captured launch sequence: IMU first 564 k / last 430 k window-iterations/s at
+      // 128 windows, 986 / 838 k at 256; 1018 / 1054 k at 384, 1227 / 1239 k at 512. VILO_IMU_FIRST = 0 / 1 pins it.)
+      static const int imu_first_env = [] { const char *e = getenv("VILO_IMU_FIRST"); return e ? atoi(e) : -1; }();
+      const int imu_first = imu_first_env >= 0 ? imu_first_env : (b.W <= 256 ? 1 : 0);
+      if (fuse_imu) hipLaunchKernelGGL(k_visual_linearize_pc_imu, dim3(b.n_waves + (b.W * 10 + 1) / 2), dim3(128), 0, s, b, sq, ha, mode, gn, imu_first);
       else hipLaunchKernelGGL(k_visual_linearize_pc, dim3(b.n_waves), dim3(128), 0, s, b, sq, ha, mode);
     }
     else if (compact) hipLaunchKernelGGL(k_visual_linearize_c, dim3(b.n_waves), dim3(64), 0, s, b, sq, ha, mode);
@@ -1107,15 +1118,19 @@ __global__ void __launch_bounds__(64) k_imu_linearize(BatchDev b, int mode, int 
   }
 }
 
-// k_imu_raw + k_imu_linearize of ONE factor in one wave, for small batches: the [J | r] block never leaves LDS. Lane 0 evaluates the
-// factor (the same inline body as k_imu_raw, the same arithmetic) into the zeroed 32 x 48 operand image, the wave whitens it and forms the
-// Gram exactly as k_imu_linearize does (same operand order, same MFMA sequence: bitwise the same Gram and cost). What it buys is the
-// launch structure: the body takes its LDS from the caller, so the workgroups of a visual kernel's launch that are not packed waves can
-// run it — an iteration of a small batch is a chain of kernel latencies, and this takes the two IMU launches out of the chain.
-// lds: IMU_FUSED_LDS doubles = Jw 32 x 48 | PreintHead (126, padded to 128) | the two frames' states (40) | the raw residual (31, padded to 32)
+// k_imu_raw + k_imu_linearize of ONE factor in one wave, for small batches: the [J | r] block never leaves the wave. Lane 0 evaluates
+// what depends on the states — the residual and seven 3 x 3 matrices (imu_blocks, the expressions of imu_leg_raw / imu_raw) — into a
+// pool of 96 doubles; every lane then fetches the 24 entries of [J | r] its matrix-core operands hold from where the compile-time table
+// says they come from (pool, the record's head, +-1, times 1 / -1 / T / -T: imu_gather_table), and the wave whitens and forms the Gram
+// exactly as k_imu_linearize does (same operand order, same MFMA sequence). A single lane writing the ~300 entries one after the other
+// took 17 k cycles alone on the chip and 35 k beside the visual waves; the block evaluation takes a fraction of that.
+// The body takes its LDS from the caller, so the workgroups of a visual kernel's launch that are not packed waves can run it — an
+// iteration of a small batch is a chain of kernel latencies, and this takes the two IMU launches out of the chain.
+// lds: IMU_FUSED_LDS doubles = Jw 32 x 48 | PreintHead (126, padded to 128) | the two frames' states (40) | block pool (IB_N = 96)
+__device__ const vilo::ImuGatherTable c_imu_gather[2] = {vilo::imu_gather_table(false), vilo::imu_gather_table(true)};
 __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm, int mode, double *lds) {
-  static_assert(32 * IW_JS + 128 + 40 + 32 == IMU_FUSED_LDS, "LDS of the fused IMU body");
-  double *const Jw = lds, *const hd = lds + 32 * IW_JS, *const xl = hd + 128, *const rl = xl + 40;
+  static_assert(32 * IW_JS + 128 + 40 + IB_N == IMU_FUSED_LDS, "LDS of the fused IMU body");
+  double *const Jw = lds, *const hd = lds + 32 * IW_JS, *const xl = hd + 128, *const pool = xl + 40;
   const int win = f / 10, k = f - 10 * win;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   SolverState &st = b.st[win];
@@ -1132,8 +1147,19 @@ __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm
   }
   const PreintPrepared &pp = b.prep[f];
   const double *x = (mode ? b.xc : b.x) + (size_t)win * XSTRIDE;
+  const bool leg = b.win[win].use_leg != 0;
+  const long long fc0 = pclk64();
+  // this lane's 24 entries of the gather table (operand layout of the whitening: row 4 kk + lk, column 16 J + lr)
+  unsigned short gt[8][3];
   {
-    // stage the record's head and the two frames' states (coalesced), clear the operand image
+    const unsigned short *tab = c_imu_gather[leg ? 1 : 0].e;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+      for (int J = 0; J < 3; ++J) gt[kk][J] = tab[(4 * kk + lk) * 48 + 16 * J + lr];
+  }
+  {
+    // stage the record's head and the two frames' states (coalesced)
     const double *hsrc = (const double *)&pp.head;
     const double h0 = hsrc[lane], h1 = (lane + 64 < 126) ? hsrc[lane + 64] : 0.0;
     double xv = 0.0;
@@ -1142,11 +1168,10 @@ __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm
       const int h = lane >= 20 ? 1 : 0, e = lane - 20 * h;
       xv = e < 7 ? x[XO_POSE + 7 * (k + h) + e] : (e < 16 ? x[XO_SB + 9 * (k + h) + (e - 7)] : x[XO_LB + 4 * (k + h) + (e - 16)]);
     }
-    for (int e = lane; e < 32 * IW_JS; e += 64) Jw[e] = 0.0;
     hd[lane] = h0; hd[lane + 64] = h1;
     if (lane < 40) xl[lane] = xv;
   }
-  // sqrt_info operands straight from global memory (in flight under the raw evaluation): 12 A values per lane
+  // sqrt_info operands straight from global memory (in flight under the block evaluation): 12 A values per lane
   const double *U = pp.sqrt_info;
   double av[2][8];
 #pragma unroll
@@ -1157,22 +1182,22 @@ __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm
       av[I][kk] = (kk >= 4 * I && row < 31 && q < 31) ? U[row * 31 + q] : 0.0;   // U(16 .. 31, 0 .. 15) = 0: never loaded
     }
   lds_fence();
-  const bool leg = b.win[win].use_leg != 0;
-  if (lane == 0) {
-    // (the residual goes to LDS as it is formed, not through 31 registers that live across the Jacobian blocks)
-    const vilo::PreintHead &P = *(const vilo::PreintHead *)hd;
-    if (leg) imu_leg_raw(P, g_norm, xl, xl + 7, xl + 16, xl + 20, xl + 27, xl + 36, rl, true, Jw, IW_JS, 1);
-    else imu_raw(P, g_norm, xl, xl + 7, xl + 20, xl + 27, rl, true, Jw, IW_JS, 19, 1);
-  }
+  const long long fc1 = pclk64();
+  if (lane == 0) imu_blocks(*(const vilo::PreintHead *)hd, g_norm, leg, xl, xl + 7, xl + 16, xl + 20, xl + 27, xl + 36, pool);
   lds_fence();
-  if (lane < (leg ? 31 : 15)) Jw[lane * IW_JS + 38] = rl[lane];
-  lds_fence();
-  // [J | r] operands of the whitening: every entry of the 32 x 48 image (zeros outside the structural non-zeros, as k_imu_linearize's masks)
+  const long long fc2 = pclk64();
+  // [J | r] operands of the whitening, each from its source
+  const double T = hd[0];
   double bv[8][3];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-    for (int J = 0; J < 3; ++J) bv[kk][J] = Jw[(4 * kk + lk) * IW_JS + 16 * J + lr];
+    for (int J = 0; J < 3; ++J) {
+      const unsigned g_ = gt[kk][J], code = g_ >> 12;
+      const double val = ((g_ & 0x100) ? hd : pool)[g_ & 0xff];
+      const double cf = code == 1 ? 1.0 : (code == 2 ? -1.0 : (code == 3 ? T : -T));
+      bv[kk][J] = code ? cf * val : 0.0;
+    }
   lds_fence();   // (every operand is in registers before the whitened block overwrites the image)
   double *out = b.imu_lin + (size_t)f * IMU_LIN_STRIDE;
 #pragma unroll
@@ -1210,6 +1235,7 @@ __device__ __forceinline__ void imu_fused_body(BatchDev &b, int f, double g_norm
       }
     }
   }
+  PCLK(if (k == 0 && lane == 0) { const long long fc3 = clock64(); st.phase_clk[33] = fc1 - fc0; st.phase_clk[34] = fc2 - fc1; st.phase_clk[35] = fc3 - fc2; });
 }
 
 // Small batches with compact visual rows: the frame-parallel visual workgroups (one per (packed wave, frame)) and the IMU factors' (one
@@ -1368,8 +1394,10 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     // Small batches: an iteration is a chain of kernel latencies, so the chain is kept short — the IMU factors are linearised by extra
     // workgroups of the visual launch (imu_fused_body: k_imu_raw + k_imu_linearize of one factor in one wave, bitwise the same Gram), and
     // the second half of the frame-parallel visual form runs in extra workgroups of k_assemble_c: three launches per iteration
-    // (linearise, bookkeeping + assemble, solve) instead of eight. VILO_SMALL_FUSE_MAX_WINDOWS moves the threshold (0: never).
-    static const int small_max = [] { const char *e = getenv("VILO_SMALL_FUSE_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+    // (linearise, bookkeeping + assemble, solve) instead of eight. The IMU workgroups inside the visual launch pay up to 2048 windows
+    // (768: + 5 %, 1024: + 2.6 %, 2048: + 0.9 %; at 4096 the two forms take the same time and the full batch keeps its separate kernels).
+    // VILO_SMALL_FUSE_MAX_WINDOWS moves the threshold (0: never).
+    static const int small_max = [] { const char *e = getenv("VILO_SMALL_FUSE_MAX_WINDOWS"); return e ? atoi(e) : 2048; }();
     const bool fuse_imu = W <= small_max && visual_launch_takes_imu(b);
     P0(0);
     launch_visual_linearize(b, sq, ha, s, 1, fuse_imu, gn);

@@ -32,8 +32,7 @@ using namespace vilo;
 // operations per target instead of the tile arithmetic, 26 KB instead of 30, no mirror writes inside diagonal tiles); it is unpacked into
 // the solver's tile image (15 lower 16 x 16 tiles in accumulator order = each tile row-major, diagonal tiles with both triangles) on the
 // way out.
-#define CL_N 3240
-__device__ __forceinline__ int cl_pos(int hi, int lo) { return ((hi * (hi + 1)) >> 1) + lo; }
+// (CL_N, cl_pos: lin_common.hpp — the small-batch assembly of kernels_asm_small.hip uses the same packed image)
 
 #define ASM_THREADS 256
 
@@ -1317,6 +1316,7 @@ __global__ void __launch_bounds__(64) k_solve_mid(BatchDev b, SolveParams sp) {
 // launch
 // =================================================================================================
 int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);    // kernels_mw.hip
+int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves);   // kernels_asm_small.hip
 int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw4.hip
 // Which solver (0 single wave, 2 two waves, 4 four waves per window, 3 the single wave in three stages): as many waves per window as the
 // batch leaves SIMDs for — four up to one window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond; in
@@ -1334,6 +1334,9 @@ int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, h
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
+    // small batches with compact slots: the 512-thread form of the assembly (kernels_asm_small.hip)
+    const int took = vilo_launch_assemble_small(ctx, b, sp, s, ap, reduce_waves);
+    if (took != 0) return took < 0 ? took : VILO_OK;
     // (ap: the trust-region bookkeeping — k_accept's body — runs as the kernel's first phase)
     const AcceptParams ap0 = ap ? *ap : AcceptParams{};
     if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W + reduce_waves), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);

@@ -6,6 +6,10 @@
 
 #define LM_NTERM 21   // E, g, w_pose_s (6), w_ex0 (6), w_ex1 (6), w_td
 
+// the LDS copy of the pose system the assembly kernels scatter into: packed lower triangle of the 80 x 80 system, row r at r (r + 1) / 2
+#define CL_N 3240
+__device__ __forceinline__ int cl_pos(int hi, int lo) { return ((hi * (hi + 1)) >> 1) + lo; }
+
 // Linearisation modes. 0: at the current point (x, lambda), for windows that ask for it (need_lin) — the marginalisation's preMarginalize
 // pass; the landmark gradients go to buffer 0. 1: at the candidate (xc, lambda_c) of every window still iterating — the solve loop; the
 // landmark gradients go to the buffer the current linearisation does NOT use (k_accept flips st.cur when the candidate is accepted; the

@@ -41,6 +41,25 @@ void hc_imu_raw(const vilo_preint_imu *pre, double g_norm, const double *pose_i,
   for (int i = 0; i < 15 * 30; ++i) J15x30[i] = 0.0;
   imu_raw(h, g_norm, pose_i, sb_i, pose_j, sb_j, r15, true, J15x30, 30);
 }
+// imu_fused_body's way to the same [J | r] (kernels_solve.hip): the seven 3 x 3 matrices and the residual from imu_blocks, every entry of the
+// 32 x 48 operand image fetched through imu_gather_table — emulated entry by entry. leg: 1 IMULegFactor, 0 IMUFactor embedded in the
+// 38-column layout (frame-j blocks from column 19). out: 32 x 48 row-major.
+void hc_imu_blocks_gather(const vilo_preint *pre, const vilo_preint_imu *pre_imu, int leg, double g_norm, const double *pose_i, const double *sb_i,
+                          const double *lb_i, const double *pose_j, const double *sb_j, const double *lb_j, double *out32x48) {
+  PreintHead h;
+  if (leg) fill_preint_head(*pre, h); else fill_preint_head_imu(*pre_imu, h);
+  double pool[IB_N];
+  for (int i = 0; i < IB_N; ++i) pool[i] = 0.0;
+  const double T = imu_blocks(h, g_norm, leg != 0, pose_i, sb_i, lb_i, pose_j, sb_j, lb_j, pool);
+  static const ImuGatherTable tabs[2] = {imu_gather_table(false), imu_gather_table(true)};
+  const double *hd = (const double *)&h;
+  for (int e = 0; e < 32 * 48; ++e) {
+    const unsigned g = tabs[leg ? 1 : 0].e[e], code = g >> 12;
+    const double val = ((g & 0x100) ? hd : pool)[g & 0xff];
+    const double cf = code == 1 ? 1.0 : (code == 2 ? -1.0 : (code == 3 ? T : -T));
+    out32x48[e] = code ? cf * val : 0.0;
+  }
+}
 void hc_leg_kin(const double *q, double lc, const double *rf, double *f3, double *J9, double *dfdrho3, double *dJ27, double *dJdrho9) {
   LegKin k;
   leg_kin_full(q, lc, rf, k);

@@ -141,6 +141,34 @@ def test_imu_raw_matches_oracle(hc, ocfg, small_window):
         np.testing.assert_allclose(U @ J, loc, rtol=1e-9, atol=1e-10 * np.abs(loc).max())
 
 
+def test_imu_block_pool_and_gather_table_reproduce_the_raw_factors(hc, small_window):
+    """Small batches linearise an IMU factor inside one wave (imu_fused_body): lane 0 evaluates seven 3 x 3 matrices and the residual
+    (imu_blocks), every lane fetches its entries of the [J | r] operand image through a compile-time table (imu_gather_table). Emulated
+    on the host entry by entry against what imu_leg_raw / imu_raw write: the same image, bit for bit — the expressions are shared, the
+    table only says where an entry lives and which of 1 / -1 / T / -T multiplies it."""
+    w = small_window
+    for k in range(10):
+        params = [np.ascontiguousarray(p) for p in (w.pose[k], w.speed_bias[k], w.leg_bias[k], w.pose[k + 1], w.speed_bias[k + 1], w.leg_bias[k + 1])]
+        pre, pre_imu = np.ascontiguousarray(w.preint[k]), np.ascontiguousarray(w.preint_imu[k])
+        # IMULegFactor
+        r = np.zeros(31); J = np.zeros((31, 38))
+        hc.hc_imu_leg_raw(P(pre), C.c_double(9.805), *[P(p) for p in params], P(r), P(J))
+        img = np.zeros((32, 48))
+        hc.hc_imu_blocks_gather(P(pre), P(pre_imu), 1, C.c_double(9.805), *[P(p) for p in params], P(img))
+        np.testing.assert_array_equal(img[:31, :38], J)
+        np.testing.assert_array_equal(img[:31, 38], r)
+        assert not img[31].any() and not img[:, 39:].any()
+        # IMUFactor, embedded: rows 0 .. 14, frame-j blocks from column 19
+        r = np.zeros(15); J = np.zeros((15, 30))
+        hc.hc_imu_raw(P(pre_imu), C.c_double(9.805), P(params[0]), P(params[1]), P(params[3]), P(params[4]), P(r), P(J))
+        img = np.zeros((32, 48))
+        hc.hc_imu_blocks_gather(P(pre), P(pre_imu), 0, C.c_double(9.805), *[P(p) for p in params], P(img))
+        np.testing.assert_array_equal(img[:15, :15], J[:, :15])
+        np.testing.assert_array_equal(img[:15, 19:34], J[:, 15:])
+        np.testing.assert_array_equal(img[:15, 38], r)
+        assert not img[15:].any() and not img[:15, 15:19].any() and not img[:15, 34:38].any()
+
+
 def test_leg_kin_matches_oracle(hc):
     rng = np.random.default_rng(5)
     rf = np.array([0.1805, -0.047, -0.0838, 0.21])

@@ -26,6 +26,10 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     print("k_assemble, visual slots: work between the chunk barriers per wave (0: T1 T2 T3, 1: T8, 2: T5 T6 T4, 3: T7): %d %d %d %d" % tuple(m[12:16]))
     print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
           % (*d, d.sum()))
+    if m[34] > 0:
+        print("IMU factor 0 (imu_fused_body / k_imu_linearize): stage %d | raw evaluation on lane 0 %d | whitening + Gram %d cycles" % (m[33], m[34], m[35]))
+    if m[46] > 0:
+        print("k_assemble_s: trust-region bookkeeping (accept_body) before the assembly: %d cycles" % m[46])
     if W <= 256 and m[16] > 0:   # four-wave solver: total and barrier-wait cycles of its waves
         print("k_solve_mw4: wave A1 %d cycles (%d at barriers) | A2 %d (%d) | B1 %d (%d) | B2 %d (%d)" % (m[16], m[20], m[17], m[21], m[18], m[22], m[19], m[23]))
     elif W <= 512:
