@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
   const int tid = threadIdx.x;
   long long qwait = 0, qw0 = 0;   // (profiling build only)
   const long long q_start = pclk64();
+#define QSTAMP(w_, i_) PCLK(if (wave == (w_) && lane == 0) st.phase_clk[i_] = clock64() - q_start)
   const WinMeta wm = b.win[win];
   const int F = wm.n_frames, L = wm.L, kb = wm.pad, cmask = wm.const_mask;
   const int mid = (F - 1) >> 1, nL = mid, nU = F - 1 - mid, nS = nU;   // frames below / above the middle; nU >= nL, nU >= 1
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       return;
     }
 
+    QSTAMP(2, 0);   // prologue: scaling of the landmarks
     bool solved = false;
     double qq = 0.0, gnnorm2 = 0.0, gy = 0.0;
     const int lane_outer = lane;
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
           if (i == nS + 1 && lane == 0) red[QR_FAIL + wave] = (double)fail;
           Q_BARRIER();
         }
+        QSTAMP(0, 8);   // A1: chain done (own work + step barriers)
         Q_BARRIER();   // B2's tiles and the reduced right-hand side
         Q_BARRIER();   // y_P
       } else {
@@ -447,7 +450,9 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
         };
         if (bw == 0) run(std::integral_constant<int, B1_MASK>{});
         else run(std::integral_constant<int, B2_MASK>{});
+        QSTAMP(2, 1);   // Schur complement + rank updates (own work done)
         Q_BARRIER();   // B2's tiles and the reduced right-hand side are there
+        QSTAMP(2, 2);
         if (bw == 0) {
           fail = (red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0) ? 1 : 0;
           if (!fail) {
@@ -529,6 +534,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
               lds_fence();   // (the panel slots are rewritten by the next block column)
             }
           }
+          QSTAMP(2, 3);   // blocked Cholesky + forward solve
           if (!fail) {
             // L^T yP = y, blockwise on the matrix cores: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i)
             mfma_d4 yb[5];
@@ -557,6 +563,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
             }
           }
           if (lane == 0) red[QR_FAIL + 2] = (double)fail;
+          QSTAMP(2, 4);   // backward solve
         }
         Q_BARRIER();   // y_P (or the failure flags)
       }
@@ -746,6 +753,8 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
         Q_BARRIER();   // (the chain waves' hand-over points)
         Q_BARRIER();
       }
+      QSTAMP(2, 5);   // landmark back-substitution (+ waiting for the sweeps' hand-over barriers)
+      QSTAMP(0, 9);   // A1: sweeps done
       part_gnn = wave_sum(part_gnn); part_gy = wave_sum(part_gy); part_qx = wave_sum(part_qx);
       if (lane == 0) { red[QR_GNN + wave] = part_gnn; red[QR_GY + wave] = part_gy; red[QR_QX + wave] = part_qx; }
       Q_BARRIER_GLOBAL();   // (lm_y is read by every wave for the candidate)
@@ -786,6 +795,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
     }
   }
 
+  QSTAMP(2, 6);   // norms, vectors kept
   // ---- dogleg step for the current radius, candidate camera state ----
   if (tid == 0) {
     double ca = 0.0, cb = 0.0;
@@ -826,6 +836,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
     }
   }
+  QSTAMP(2, 7);   // dogleg + candidate
   PCLK(if (lane == 0) { st.phase_clk[16 + wave] = clock64() - q_start; st.phase_clk[20 + wave] = qwait; });
 }
 

@@ -30,6 +30,9 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
         print("IMU factor 0 (imu_fused_body / k_imu_linearize): stage %d | raw evaluation on lane 0 %d | whitening + Gram %d cycles" % (m[33], m[34], m[35]))
     if m[46] > 0:
         print("k_assemble_s: trust-region bookkeeping (accept_body) before the assembly: %d cycles" % m[46])
+    if W <= 256 and m[16] > 0:
+        print("k_solve_mw4 wave B1 (cycles from kernel start): scaling %d | Schur + rank updates %d (barrier %d) | Cholesky %d | backward solve %d | landmark back-substitution + hand-over barriers %d | norms %d | dogleg + candidate %d;  A1: chain %d, sweeps %d"
+              % (m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9]))
     if W <= 256 and m[16] > 0:   # four-wave solver: total and barrier-wait cycles of its waves
         print("k_solve_mw4: wave A1 %d cycles (%d at barriers) | A2 %d (%d) | B1 %d (%d) | B2 %d (%d)" % (m[16], m[20], m[17], m[21], m[18], m[22], m[19], m[23]))
     elif W <= 512:
