@@ -52,7 +52,7 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "round3"
+PROFILE_ROUND = "round4"
 STRONG_TOTAL = 1024   # BASELINE configs[3]
 
 
@@ -470,6 +470,28 @@ def main():
                   "scaling": "strong", "total_windows": STRONG_TOTAL, "windows_per_gpu": Ws, "n_gpus": world, "steps": args.steps,
                   "value": STRONG_TOTAL * ITERS * args.steps / el, "value_per_gpu": STRONG_TOTAL * ITERS * args.steps / el / world,
                   "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps}
+    # Small batches per GPU (BASELINE configs[3] on 8 GPUs is 128 windows per GPU; the reference itself solves one window per image): the
+    # same timed loop on batches of 128 and 256 windows, reported as a side block of the default single-GPU line.
+    small = None
+    if world == 1 and args.total_windows == 0 and not rp and args.landmarks == 200 and not args.no_strong:
+        small = {}
+        lib.vilo_set_profiling(ctx.h, 0)
+        for Wsm in (128, 256):
+            wsm = [make_synth_window(cfg, args.landmarks, args.rate, 60260925 + i) for i in range(Wsm)]
+            ctx.preintegrate_windows(wsm)
+            bsm = make_batch(ctx, wsm)
+            for _ in range(3):
+                bsm.reset(); bsm.prepare(); bsm.solve(opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                bsm.reset(); bsm.prepare(); bsm.solve(opts)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            assert sum(s_.iterations for s_ in bsm.download()) == Wsm * ITERS
+            bsm.close()
+            small[str(Wsm)] = {"windows": Wsm, "value": Wsm * ITERS * args.steps / el, "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps,
+                               "us_per_iteration": 1e6 * el / args.steps / ITERS}
     if rank == 0:
         unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
         value = unit_work / elapsed
@@ -537,6 +559,8 @@ def main():
         }
         if strong:
             out["strong_scaling"] = strong
+        if small:
+            out["small_batches"] = small
         if not args.no_cpu_baseline:
             # checker leg, outside the timed region: did the timed kernels produce the reference's states?
             out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, n=2 if rp else 8, repropagate=rp)

@@ -40,8 +40,12 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
   SolverState &st = b.st[win];
   if (st.done) return;
   const WinMeta wm = b.win[win];
+  // (asking for the state's scalars and the window table ahead of the early exits — the body is a chain of global round trips on a
+  // nearly idle chip — bought nothing at one window and cost the full batch's k_accept 10 us: measured, not kept)
+  const int step_valid0 = st.step_valid;
+  const double x_cost0 = st.x_cost, mcc0 = st.model_cost_change;
   double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
-  if (!ap.init_mode && !st.step_valid) {
+  if (!ap.init_mode && !step_valid0) {
     if (tid == 0) {
       // HandleInvalidStep: FAILURE at max_num_consecutive_invalid_steps (5, Ceres default), else DoglegStrategy::StepIsInvalid (mu *= 10,
       // no reuse). The candidate pass linearised the unchanged point again (the solver left xc = x): the next step starts from it.
@@ -59,6 +63,7 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
   // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2). Every load of the three parts is issued before the
   // first barrier (the partial sums wait in registers), the three sums share one exchange.
   double vis = 0.0, imu = 0.0, pri = 0.0, my_hd = 0.0;   // my_hd: row tid of H dx at the candidate (becomes the gradient term when accepted)
+  const double c0 = (wm.prior_n > 0) ? b.prior_c0[win] : 0.0;
   for (int c = t128; c < wm.n_waves * VILO_MAX_FRAMES; c += 128) vis += b.chunk_cost[(size_t)wm.wave_off * VILO_MAX_FRAMES + c];
   for (int k = t128; k + 1 < wm.n_frames; k += 128) imu += b.imu_cost[(size_t)win * 10 + k];
   if (wm.prior_n > 0) {
@@ -77,7 +82,7 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
     }
   }
   block_sum128x3(vis, imu, pri, red);
-  if (wm.prior_n > 0) pri += b.prior_c0[win];
+  if (wm.prior_n > 0) pri += c0;
   double cand = 0.5 * (vis + imu + pri);
   if (!isfinite(cand)) cand = 1.7976931348623157e308;
   if (b.rp_on && b.prep_bad) {
@@ -117,14 +122,14 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
     block_sum128x3(pn, ps, z_, red);
     const double xn = sqrt(pn), sn = sqrt(ps);
     if (sn <= ap.parameter_tolerance * (xn + ap.parameter_tolerance)) converged = true;
-    if (!converged && fabs(st.x_cost - cand) <= ap.function_tolerance * st.x_cost) converged = true;
+    if (!converged && fabs(x_cost0 - cand) <= ap.function_tolerance * x_cost0) converged = true;
   }
   if (converged) {
     if (tid == 0) { st.done = 1; st.termination = 1; st.cand_cost = cand; }
     return;
   }
   if (tid == 0) {
-    const double rel = (st.x_cost - cand) / st.model_cost_change;
+    const double rel = (x_cost0 - cand) / mcc0;
     st.cand_cost = cand;
     st.num_invalid = 0;
     if (rel > ap.min_relative_decrease) {

@@ -1,12 +1,12 @@
 // k_assemble_s: the camera-side normal equations of a window (what k_assemble_c of kernels_wave.hip builds: Ceres' Evaluate -> block-sparse
 // J^T J behind estimator.cpp:1221-1236) for SMALL batches — up to one window per CU, where an iteration is a chain of kernel latencies and
 // the assembly's is one chain of ~110 k cycles per window. Same owner-computes scatter (no atomics), cut by parallelism one window can use
-// when it has a CU to itself (512 threads, 97 KB of LDS):
-//   * the visual Gram slots of TWO chunks at a time: thread group g = tid / 256 takes the chunks of parity g into its own copy of the packed
-//     image (and of the gradient); the copies are added once (even chunks + odd chunks: sums agree with k_assemble_c's chunk-by-chunk order
-//     to rounding, not bitwise — like the solver forms, the small-batch assembly is a form of its own);
+// when it has a CU to itself (768 threads, 137 KB of LDS):
+//   * the visual Gram slots of THREE chunks at a time: thread group g = tid / 256 takes the chunks g, g + 3, ... into its own copy of the
+//     packed image (and of the gradient); the copies are added once in group order (the sums agree with k_assemble_c's chunk-by-chunk
+//     order to rounding, not bitwise — like the solver forms, the small-batch assembly is a form of its own);
 //   * all IMU factor Grams of the window in LDS at once (62 KB over the second image copy and the staging areas, free by then): every
-//     entry of A_kk / A_{k+1,k}^T / the coupling rows of every frame is independent work for 512 threads instead of a frame loop with
+//     entry of A_kk / A_{k+1,k}^T / the coupling rows of every frame is independent work for 768 threads instead of a frame loop with
 //     two barriers per frame;
 //   * the output passes (tile image, prior rows, q) on twice the threads.
 // The trust-region bookkeeping (accept_body.hpp) runs as its first phase and the second half of the frame-parallel visual form in extra
@@ -20,29 +20,29 @@
 
 using namespace vilo;
 
-#define AS_THREADS 512
+#define AS_NG 3           // thread groups of 256: chunks scattered at a time
+#define AS_THREADS (256 * AS_NG)
 // LDS map (doubles)
 #define AS_CL0 0                         // [CL_N] packed image (group 0's copy, then the sum)
 #define AS_R1 (AS_CL0 + CL_N)            // region with two lives:
-#define AS_CL1 AS_R1                     //   [CL_N] group 1's copy of the image
-#define AS_ST0 (AS_CL1 + CL_N)           //   [AC_STAGE] the chunk group 0 scatters; first: accept_body's scratch
-#define AS_ST1 (AS_ST0 + AC_STAGE)       //   [AC_STAGE] the chunk group 1 scatters
+#define AS_CL1 AS_R1                     //   [AS_NG - 1][CL_N] the other groups' copies of the image
+#define AS_ST0 (AS_CL1 + (AS_NG - 1) * CL_N)   //   [AS_NG][AC_STAGE] the chunks the groups scatter; first: accept_body's scratch
 #define AS_GR AS_R1                      //   [10 x 780] afterwards: the window's IMU factor Grams
-#define AS_R1_N 7800
+#define AS_R1_N ((AS_NG - 1) * CL_N + AS_NG * AC_STAGE)
 #define AS_GL (AS_R1 + AS_R1_N)          // [CD_N] gradient (group 0's, then the sum)
-#define AS_GL1 (AS_GL + CD_N)            // [CD_N] group 1's share of the gradient
-#define AS_HD (AS_GL1 + CD_N)            // [CD_N] diagonal
+#define AS_GL1 (AS_GL + CD_N)            // [AS_NG - 1][CD_N] the other groups' shares of the gradient
+#define AS_HD (AS_GL1 + (AS_NG - 1) * CD_N)   // [CD_N] diagonal
 #define AS_VS (AS_HD + CD_N)             // [CD_N] v = g / dhat^2
 #define AS_RT (AS_VS + CD_N)             // [12 x 9] rotation matrices of the frames, [11] = identity
-#define AS_RED (AS_RT + 108)             // [24] per-wave partial sums
-#define AS_TAB (AS_RED + 24)             // [64 unsigned = 32 doubles] chunk table
+#define AS_RED (AS_RT + 108)             // [48] per-wave partial sums
+#define AS_TAB (AS_RED + 48)             // [64 unsigned = 32 doubles] chunk table
 #define AS_PMAP (AS_TAB + 32)            // [CD_N shorts = 56 doubles] prior dimension of a camera dimension
 #define AS_ACT (AS_PMAP + 56)            // [CD_N bytes = 28 doubles] activity of a camera dimension
 #define AS_TOTAL (AS_ACT + 28)
-static_assert(CL_N + 2 * AC_STAGE <= AS_R1_N, "image copy + two staging areas inside the Gram region");
-static_assert((AS_R1 & 1) == 0 && (AS_ST0 & 1) == 0 && (AS_ST1 & 1) == 0, "16-byte aligned areas");
+static_assert(7800 <= AS_R1_N, "the Gram region lies inside the image copies + staging areas");
+static_assert((AS_R1 & 1) == 0 && (AS_ST0 & 1) == 0 && (AC_STAGE & 1) == 0 && (CL_N & 1) == 0, "16-byte aligned areas");
 
-__global__ void __launch_bounds__(AS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(AS_THREADS) __attribute__((amdgpu_waves_per_eu(AS_NG, AS_NG)))
 k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
@@ -51,7 +51,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     if (tid < 64) visual_reduce_body(b, (int)blockIdx.x - b.W, 1, true);
     return;
   }
-  double *const Cl = lds + AS_CL0, *const Cl1 = lds + AS_CL1, *const gl = lds + AS_GL, *const gl1 = lds + AS_GL1, *const hd = lds + AS_HD, *const vS = lds + AS_VS;
+  double *const Cl = lds + AS_CL0, *const Cl1 = lds + AS_CL1, *const gl = lds + AS_GL, *const gl1 = lds + AS_GL1, *const hd = lds + AS_HD, *const vS = lds + AS_VS;   // (Cl1 / gl1: AS_NG - 1 copies back to back)
   double *const Rt = lds + AS_RT, *const red = lds + AS_RED, *const grams = lds + AS_GR;
   unsigned *const chunk_tab = (unsigned *)(lds + AS_TAB);
   short *const inv_pmap = (short *)(lds + AS_PMAP);
@@ -77,9 +77,10 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
 
   // ---- group 0's image starts from the prior's pre-assembled image (zeros without a prior), group 1's from zero ----
   {
-    double pv[7];
+    constexpr int NPV = (CL_N + AS_THREADS - 1) / AS_THREADS;
+    double pv[NPV];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
+    for (int u = 0; u < NPV; ++u) {
       const int e = min(tid + AS_THREADS * u, CL_N - 1);
       int row = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
       while (((row + 1) * (row + 2)) / 2 <= e) ++row;
@@ -87,12 +88,20 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
       pv[u] = pd[PD_C + row * PD_CLD + (e - (row * (row + 1)) / 2)];
     }
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
+    for (int u = 0; u < NPV; ++u) {
       const int e = tid + AS_THREADS * u;
-      if (e < CL_N) { Cl[e] = pv[u]; Cl1[e] = 0.0; }
+      if (e < CL_N) {
+        Cl[e] = pv[u];
+#pragma unroll
+        for (int g2 = 0; g2 < AS_NG - 1; ++g2) Cl1[g2 * CL_N + e] = 0.0;
+      }
     }
   }
-  for (int e = tid; e < CD_N; e += AS_THREADS) { inv_pmap[e] = -1; act[e] = cd_active(e, F, cmask) ? 1 : 0; gl1[e] = 0.0; }
+  for (int e = tid; e < CD_N; e += AS_THREADS) {
+    inv_pmap[e] = -1; act[e] = cd_active(e, F, cmask) ? 1 : 0;
+#pragma unroll
+    for (int g2 = 0; g2 < AS_NG - 1; ++g2) gl1[g2 * CD_N + e] = 0.0;
+  }
   if (tid < 11) {
     const m3 R = qR(ldq_pose(b.x + (size_t)win * XSTRIDE + XO_POSE + 7 * tid));   // (the accepted state = the point the slots were linearised at)
 #pragma unroll
@@ -115,11 +124,11 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   __syncthreads();
 
   PCLK(if (tid == 0) b.st[win].phase_clk[37] = clock64());
-  // ---- visual Gram slots: two chunks per trip, one per thread group, each into its own image / gradient copy ----
+  // ---- visual Gram slots: AS_NG chunks per trip, one per thread group, each into its own image / gradient copy ----
   {
-    double *const Cg = grp ? Cl1 : Cl, *const gg = grp ? gl1 : gl, *const stage = lds + (grp ? AS_ST1 : AS_ST0);
+    double *const Cg = grp ? Cl1 + (grp - 1) * CL_N : Cl, *const gg = grp ? gl1 + (grp - 1) * CD_N : gl, *const stage = lds + AS_ST0 + grp * AC_STAGE;
     auto rmw = [&](int hi, int lo, double v) { Cg[cl_pos(hi, lo)] += v; };   // hi >= lo
-    const int nch = min(wm.n_chunks, 64), ntrip = (nch + 1) >> 1;
+    const int nch = min(wm.n_chunks, 64), ntrip = (nch + AS_NG - 1) / AS_NG;
     double pf[8];
     auto prefetch = [&](int ch) {
       if (ch < nch) {
@@ -132,14 +141,14 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     };
     prefetch(grp);
     for (int trip = 0; trip < ntrip; ++trip) {
-      const int ch = 2 * trip + grp;
+      const int ch = AS_NG * trip + grp;
       lds_barrier();   // (the previous trip's readers are done)
       if (ch < nch) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const int e = lt + 256 * i; if (e < AC_STAGE) stage[e] = pf[i]; }
       }
       lds_barrier();
-      prefetch(ch + 2);
+      prefetch(ch + AS_NG);
       if (ch < nch) {
         const unsigned ct = chunk_tab[ch];
         const int cs_ = (int)(ct & 255), km = (int)((ct >> 8) & 255);
@@ -162,9 +171,19 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     }
   }
   __syncthreads();
-  // the two copies become one (even chunks' sums + odd chunks' sums)
-  for (int e = tid; e < CL_N; e += AS_THREADS) Cl[e] += Cl1[e];
-  for (int e = tid; e < CD_N; e += AS_THREADS) gl[e] += gl1[e];
+  // the copies become one (the groups' sums added in group order)
+  for (int e = tid; e < CL_N; e += AS_THREADS) {
+    double sacc = Cl[e];
+#pragma unroll
+    for (int g2 = 0; g2 < AS_NG - 1; ++g2) sacc += Cl1[g2 * CL_N + e];
+    Cl[e] = sacc;
+  }
+  for (int e = tid; e < CD_N; e += AS_THREADS) {
+    double sacc = gl[e];
+#pragma unroll
+    for (int g2 = 0; g2 < AS_NG - 1; ++g2) sacc += gl1[g2 * CD_N + e];
+    gl[e] = sacc;
+  }
   __syncthreads();
 
   PCLK(if (tid == 0) b.st[win].phase_clk[38] = clock64());
@@ -176,11 +195,12 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   //        [338, 626)  coupling rows    with poses k - 1 (Gj), k (Gi + Gj), k + 1 (Gi); rows 13 .. 15 zero padding ----
   {
     const int ng = max(F - 1, 0) * 780;
-    double gp[16];
+    constexpr int NGP = (7800 + AS_THREADS - 1) / AS_THREADS;
+    double gp[NGP];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const int e = tid + AS_THREADS * u; gp[u] = (e < ng) ? igram[e] : 0.0; }
+    for (int u = 0; u < NGP; ++u) { const int e = tid + AS_THREADS * u; gp[u] = (e < ng) ? igram[e] : 0.0; }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const int e = tid + AS_THREADS * u; if (e < 7800) grams[e] = gp[u]; }
+    for (int u = 0; u < NGP; ++u) { const int e = tid + AS_THREADS * u; if (e < 7800) grams[e] = gp[u]; }
   }
   __syncthreads();
   {
@@ -190,7 +210,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     auto on = [&](int k, int i) { return k < F && !(i >= 9 && lb_off); };
     // A_kk
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < (11 * 169 + AS_THREADS - 1) / AS_THREADS; ++it) {
       const int e = tid + AS_THREADS * it;
       if (e < F * 169) {
         const int k = e / 169, u = e - 169 * k, i = u / 13, j = u - 13 * i;
@@ -209,7 +229,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     }
     // A_{k+1,k}^T of the factors' frames (a partial window's remaining blocks are zeroed below)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < (10 * 169 + AS_THREADS - 1) / AS_THREADS; ++it) {
       const int e = tid + AS_THREADS * it;
       if (e < (F - 1) * 169) {
         const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;   // i: dimension of frame k + 1, j: of frame k
@@ -219,7 +239,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     }
     // coupling rows with poses k - 1 (Gj), k (Gi + Gj), k + 1 (Gi); rows 13 .. 15 zero padding
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
+    for (int it = 0; it < (11 * 288 + AS_THREADS - 1) / AS_THREADS; ++it) {
       const int e = tid + AS_THREADS * it;
       if (e < F * 288) {
         const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, df = sx / 6, c = sx - 6 * df;
@@ -240,9 +260,9 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   }
   // pose blocks of the factors -> the pose image: I1 pose_i x pose_i (21, twin + 19), I3 pose gradient (6, twin + 19), I4 pose_i x pose_j (36).
   // Consecutive factors meet in the diagonal block of the frame they share: one owner thread per entry walks the factors in order.
-  if (tid >= 448 && tid < 511) {
+  if (tid >= AS_THREADS - 64 && tid < AS_THREADS - 1) {
     int pa = 0, pbc = 0, pcls = 0;
-    const int q = tid - 448;
+    const int q = tid - (AS_THREADS - 64);
     if (q < 21) { pcls = 1; int rem = q; while (rem >= 6 - pa) { rem -= 6 - pa; ++pa; } pbc = pa + rem; }
     else if (q < 27) { pcls = 3; pa = q - 21; pbc = 38; }
     else { pcls = 4; pa = (q - 27) / 6; pbc = 19 + (q - 27) % 6; }
@@ -334,11 +354,12 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   __threadfence_block();   // (this workgroup's stores above must be visible to its loads below)
   __syncthreads();
   {
-    double val[4];
+    constexpr int NV = (11 * 169 + AS_THREADS - 1) / AS_THREADS;
+    double val[NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) val[u] = bimg[BI_AD + min(tid + AS_THREADS * u, 11 * 169 - 1)];
+    for (int u = 0; u < NV; ++u) val[u] = bimg[BI_AD + min(tid + AS_THREADS * u, 11 * 169 - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV; ++u) {
       const int e = tid + AS_THREADS * u;
       if (e < 11 * 169) {
         const int k = e / 169, ij = e - 169 * k, i = ij / 13, j = ij - 13 * i;
@@ -347,11 +368,12 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     }
   }
   {
-    double val[4];
+    constexpr int NV = (10 * 169 + AS_THREADS - 1) / AS_THREADS;
+    double val[NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) val[u] = bimg[BI_AOT + min(tid + AS_THREADS * u, 10 * 169 - 1)];
+    for (int u = 0; u < NV; ++u) val[u] = bimg[BI_AOT + min(tid + AS_THREADS * u, 10 * 169 - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV; ++u) {
       const int e = tid + AS_THREADS * u;
       if (e < 10 * 169) {
         const int k = e / 169, ji = e - 169 * k, j = ji / 13, i = ji - 13 * j;
@@ -360,11 +382,12 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     }
   }
   {
-    double val[7];
+    constexpr int NV = (11 * 288 + AS_THREADS - 1) / AS_THREADS;
+    double val[NV];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) val[u] = bimg[BI_BS + min(tid + AS_THREADS * u, 11 * 288 - 1)];
+    for (int u = 0; u < NV; ++u) val[u] = bimg[BI_BS + min(tid + AS_THREADS * u, 11 * 288 - 1)];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
+    for (int u = 0; u < NV; ++u) {
       const int e = tid + AS_THREADS * u;
       if (e < 11 * 288) {
         const int k = e / 288, is = e - 288 * k, i = is / 18, sx = is - 18 * i, f = k - 1 + sx / 6, c = sx % 6;
@@ -375,12 +398,13 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   PCLK(if (tid == 0) b.st[win].phase_clk[44] = clock64());
   // camera-side sums of |D^-1 g|^2, max |g| and q (the landmarks add theirs in the solver): waves in fixed order
   part_q = wave_sum(part_q); part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax);
-  if ((tid & 63) == 0) { red[tid >> 6] = part_q; red[8 + (tid >> 6)] = part_gn; red[16 + (tid >> 6)] = part_gmax; }
+  constexpr int NWV = AS_THREADS / 64;
+  if ((tid & 63) == 0) { red[tid >> 6] = part_q; red[NWV + (tid >> 6)] = part_gn; red[2 * NWV + (tid >> 6)] = part_gmax; }
   __syncthreads();
   PCLK(if (tid == 0) b.st[win].phase_clk[45] = clock64());
   if (tid == 0) {
     double sq_ = 0.0, sg_ = 0.0, mx = 0.0;
-    for (int w = 0; w < 8; ++w) { sq_ += red[w]; sg_ += red[8 + w]; mx = fmax(mx, red[16 + w]); }
+    for (int w = 0; w < NWV; ++w) { sq_ += red[w]; sg_ += red[NWV + w]; mx = fmax(mx, red[2 * NWV + w]); }
     bimg[BI_SCAL + 0] = sq_;
     bimg[BI_SCAL + 1] = sg_;
     bimg[BI_SCAL + 2] = mx;

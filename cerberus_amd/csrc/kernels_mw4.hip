@@ -96,6 +96,10 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
   const int mid = (F - 1) >> 1, nL = mid, nU = F - 1 - mid, nS = nU;   // frames below / above the middle; nU >= nL, nU >= 1
   double *g = lds + Q_G, *dh2 = lds + Q_DH2, *y = lds + Q_Y, *v = lds + Q_V, *red = lds + Q_RED;
   double *DB = lds + Q_DB, *GB = lds + Q_GB, *U = lds + Q_U, *YB = lds + Q_YB;
+  // the dogleg's inputs of a fresh linearisation stay in lane 0's registers (tid 0); the radius is the bookkeeping's, read up front
+  struct DoglegIn { double radius, mu, gnorm2, gnnorm2, gdotgn, q, alpha, coef_a, coef_b, dogleg_step_norm, model_cost_change; int step_valid; } fresh;
+  bool have_fresh = false;
+  const double radius0 = st.radius;
 
   if (st.need_lin) {
     const double *bimg = b.Bimg + (size_t)win * BI_N;
@@ -120,6 +124,7 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       else sc = lm_scale[l];
       const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
       lm_dh2[l] = d2;
+      lm_einv[l] = 1.0 / (E + mu * d2);   // (of the first factorisation: a retry at a larger mu forms its own below)
       const double vl = gl / d2;
       part_q += E * vl * vl;   // (the cross term 2 vl w_l^T v_P comes from the back-substitution)
       part_gn += gl * vl;
@@ -137,15 +142,18 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
     }
 
     QSTAMP(2, 0);   // prologue: scaling of the landmarks
-    bool solved = false;
+    bool solved = false, retry = false;
     double qq = 0.0, gnnorm2 = 0.0, gy = 0.0;
     const int lane_outer = lane;
     while (!solved) {
       int lane = lane_outer;
       asm volatile("" : "+v"(lane));
       const int lr = lane & 15, lk = lane >> 4;
-      for (int l = tid; l < L; l += 256) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
-      Q_BARRIER_GLOBAL();
+      if (retry) {
+        for (int l = tid; l < L; l += 256) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
+        Q_BARRIER_GLOBAL();
+      }
+      retry = true;
       const int nks = (L + 3) >> 2, NT = (nks + 3) >> 2, NH = (nks + 1) >> 1;   // k-steps of 4 landmarks, trips of 4, half trips of 2
       int fail = 0;
 
@@ -785,6 +793,9 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
       st.alpha = gnorm2 / qq;
       st.scale_ready = 1;
       st.lin_fail = 0;
+      // (the dogleg below works on a register copy of these: no round trip through what was just stored)
+      fresh.gnorm2 = gnorm2; fresh.gnnorm2 = gnnorm2; fresh.gdotgn = -gy; fresh.q = qq; fresh.alpha = gnorm2 / qq; fresh.mu = mu;
+      have_fresh = true;
     }
   } else {
     const double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
@@ -800,7 +811,15 @@ __global__ void __launch_bounds__(256) k_solve_mw4(BatchDev b, SolveParams sp) {
   if (tid == 0) {
     double ca = 0.0, cb = 0.0;
     int go = 0;
-    if (st.radius <= sp.min_radius) { st.done = 1; st.termination = 1; st.step_valid = 0; }
+    const double radius = radius0;   // (read when the kernel started)
+    if (radius <= sp.min_radius) { st.done = 1; st.termination = 1; st.step_valid = 0; }
+    else if (have_fresh) {
+      fresh.radius = radius;
+      dogleg_scalars(fresh);
+      st.coef_a = fresh.coef_a; st.coef_b = fresh.coef_b; st.dogleg_step_norm = fresh.dogleg_step_norm; st.model_cost_change = fresh.model_cost_change;
+      st.step_valid = fresh.step_valid;
+      ca = fresh.coef_a; cb = fresh.coef_b; go = fresh.step_valid;
+    }
     else { dogleg_scalars(st); ca = st.coef_a; cb = st.coef_b; go = st.step_valid; }
     red[QR_CA] = ca; red[QR_CB] = cb; red[QR_GO] = (double)go;
   }

@@ -76,7 +76,9 @@ __device__ __forceinline__ bool cd_active(int cd, int F, int cmask) {
 }
 
 // DoglegStrategy::ComputeTraditionalDoglegStep in scalar form + TrustRegionMinimizer's model_cost_change.
-__device__ __forceinline__ void dogleg_scalars(SolverState &s) {
+// (S: SolverState, or a register copy of the fields it reads and writes)
+template <class S>
+__device__ __forceinline__ void dogleg_scalars(S &s) {
   const double gradient_norm = sqrt(s.gnorm2), gn_norm = sqrt(s.gnnorm2), radius = s.radius;
   double a, bb, step_norm;
   if (gn_norm <= radius) {
