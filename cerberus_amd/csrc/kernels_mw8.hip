@@ -1,0 +1,1053 @@
+// Eight-wave solver for gfx950, the form of batches that leave most of the chip idle (one workgroup = one window per CU, up to 256
+// windows): what ceres::Solve does per linearisation for Estimator::optimization(), estimator.cpp:1221-1236 — DENSE_SCHUR + traditional
+// DOGLEG, Ceres 1.14 semantics. At this size a solve is ONE latency chain per window, so the window's work is cut into roles that run side
+// by side, two waves per SIMD at 256 registers each (the four-wave form this replaces ran its serial parts on one wave each):
+//
+//   waves C1 / C2   the block-tridiagonal Cholesky of the speed / leg-bias part as a TWISTED factorisation: C1 eliminates frames F-1 .. m+1
+//                   downwards, C2 frames 0 .. m-1 upwards, at the same time; the middle frame m = (F-1)/2 takes the Schur updates of both
+//                   neighbours and is factorised last (by C1). Only the 13 x 13 part — S_k, L_k, M_k = L_k^-1 and the off-diagonal factor:
+//                   the v_readlane chains that nothing shortens. The back-substitution sweeps run the same way: both halves forward, the
+//                   middle, both halves backward. M_k and the off-diagonal factors stay in LDS (no round trip through L2).
+//                     downwards:  T_A(k)  = L_k^-1 A_{k,k-1}      S_{k-1} = A_{k-1,k-1} - T_A(k)^T T_A(k)
+//                     upwards:    T'_A(k) = L_k^-1 A_{k+1,k}^T    S_{k+1} = A_{k+1,k+1} - T'_A(k)^T T'_A(k)
+//                     middle:     S_m = A_mm - T_A(m+1)^T T_A(m+1) - T'_A(m-1)^T T'_A(m-1)
+//   waves TD / TU   the coupling rows of the chain on the matrix cores, one step behind their chain wave (M_k / T_A(k) come through LDS):
+//                     downwards:  T(k) = M_k (V_k - T_A(k+1)^T T(k+1))      upwards:  T(k) = M_k (V_k - T'_A(k-1)^T T(k-1))
+//                     middle (TD): V_m loses both neighbours' terms
+//                   T(k) goes to the matrix waves through a double-buffered LDS image in operand order.
+//   waves B1 .. B4  the 80 x 80 pose system split by tiles (4 + 4 + 4 + 3 of the 15 lower 16 x 16 tiles): each runs the landmark Schur
+//                   complement and the rank updates C -= T(k)^T T(k) on its own tiles, two steps behind the chain; the tiles then move to
+//                   B1, which runs the blocked Cholesky and the backward solve; all four share the landmark back-substitution.
+// The chain step (13 x 13 factorisation + substitutions) sets the pace of the main loop; in the four-wave form a chain wave also formed
+// T(k) (twice the cycles per frame) and two matrix waves shared the 15 tiles.
+// A different elimination order of the speed / leg-bias part and different partial sums than the single-wave forms: results agree with
+// them to rounding (tests run every form against the oracle at the same tolerances); batch-of-N == batch-of-1 bitwise within the form.
+#include <type_traits>
+#include "wave_common.hpp"
+
+// LDS map (doubles)
+#define E_G 0          // [80]  gradient of the pose part
+#define E_DH2 80       // [80]  dogleg diagonal
+#define E_Y 160        // [80]  Gauss-Newton step of the pose part
+#define E_V 240        // [80]  reduced right-hand side
+#define E_VP 320       // [80]  v_P = D^-2 g
+#define E_DB 400       // [144] dogleg diagonal of the speed / leg-bias part
+#define E_GB 544       // [144] its gradient
+#define E_RED 688      // [96]  cross-wave sums and flags
+#define E_CH1 784      // [704] C1's chain scratch
+#define E_CH2 1488     // [704] C2's
+#define E_XSN 2192     // [176] T'_A(m-1)^T T'_A(m-1): C2's update of the middle frame's diagonal block
+#define E_XU 2368      // [16]  u of frame m - 1 (forward sweep hand-over)
+#define E_XY 2384      // [16]  y of frame m (backward sweep hand-over)
+#define E_M 2400       // [11][176] M_k = L_k^-1
+#define E_TA 4336      // [11][176] T_A(k) (frames above the middle), T'_A(k) (frames below)
+#define E_T1 6272      // [2][1280] TD's T(k) hand-over
+#define E_T2 8832      // [2][1280] TU's
+#define E_TILES E_T1   // after the main loop, over the hand-over buffers: [15][256] the tiles on their way to the Cholesky (accumulator order)
+#define E_DEL 11392    // [224] the step
+#define E_U 11616      // [144]
+#define E_YB 11760     // [144]
+#define E_SKIP 11904   // [40]
+#define E_CHOL 11944   // Cholesky scratch (832, padded to 1024) + panel slots (1024)
+#define E_WS 13992     // [2][ES_N] slices of the landmarks' coupling rows, 1 / (E + mu dhat^2) and gradients (mw8_role_T loads them)
+#define ES_NL 32       // landmarks per slice (four half trips)
+#define ES_LD 33       // row stride of a slice (16 rows x 4 landmarks of an operand read: distinct banks up to two-way)
+#define ES_EI (80 * ES_LD)         // [32] 1 / (E_l + mu dhat_l^2), zero beyond the window's landmarks
+#define ES_G (ES_EI + ES_NL)       // [32] landmark gradients
+#define ES_N (ES_G + ES_NL + 8)    // 2712
+#define E_TOTAL (E_WS + 2 * ES_N)
+static_assert(15 * 256 <= 2 * 2560, "the tiles fit the hand-over buffers");
+extern __shared__ __attribute__((aligned(16))) double e_lds[];   // the workgroup's dynamic LDS (k_solve_mw8 and its roles)
+
+// Every role below is a function of its own (__noinline__): the kernel's eight waves share one register allocation of 256 per lane, and
+// with the roles inlined into one body the allocator spilled all over it (each role's live ranges crowd the others'; measured: 100 - 500
+// spilled registers, the loads of the hot loops waiting in scratch). A call costs the callee-saved registers' round trip, once per role
+// and linearisation. The roles find the workgroup's LDS through the dynamic-LDS symbol; their inputs come as (wave-uniform) arguments.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(double x) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x))); }
+template <class T> __device__ __forceinline__ T *uni(T *p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+// main-loop geometry shared by the roles: chain step c at iteration c, its T(k) at iteration c + 1, the rank update at iteration c + 2;
+// enough iterations for the landmark Schur complement to pass one LDS slice (four half trips) per iteration
+struct E_Geom { int mid, nL, nU, nS, NH, NT, NSTEP; };
+__device__ __forceinline__ E_Geom e_geom(int F, int L) {
+  E_Geom G;
+  G.mid = (F - 1) >> 1; G.nL = G.mid; G.nU = F - 1 - G.mid; G.nS = G.nU;
+  const int nks = (L + 3) >> 2;
+  G.NT = (nks + 3) >> 2; G.NH = (nks + 1) >> 1;
+  G.NSTEP = max(G.nS + 3, (G.NH + 3) >> 2);
+  return G;
+}
+__device__ __forceinline__ int e_slice_h0(const E_Geom &G, int i) { return (i * G.NH) / G.NSTEP; }   // slice i = half trips [h0(i), h0(i + 1)): at most four
+// The matrix waves' operands reach them through LDS, a slice of 32 landmarks (all 80 coupling rows, 1 / (E + mu dhat^2), the gradients)
+// per iteration of the main loop: the chain and T waves — the four that have a few registers to spare — fetch the next iteration's
+// slice at the start of an iteration (coalesced, 11 loads per lane, in flight behind the iteration's own work) and store it before the
+// iteration's barrier. With the operands straight from global memory, as the forms with one or two matrix waves have them, a half trip's
+// ~1 k cycles of matrix instructions wait for a ~3 k cycle round trip on a nearly idle chip.
+#define ES_NLD 11   // loads per lane of a loader wave (4 x 64 x 11 >= 80 x 32 + 64)
+struct E_Slice {
+  double r[ES_NLD];
+  __device__ __forceinline__ void load(const E_Geom &G, int i, int t256, const double *wl, const double *lm_einv, const double *lm_g, int L) {
+    const int l0 = 8 * e_slice_h0(G, i);
+#pragma unroll
+    for (int u = 0; u < ES_NLD; ++u) {
+      const int e = t256 + 256 * u;
+      double val = 0.0;
+      if (e < 80 * ES_NL) { const int a = e >> 5, l = l0 + (e & 31); if (l < L) val = wl[(size_t)a * L + l]; }
+      else if (e < 80 * ES_NL + ES_NL) { const int l = l0 + (e - 80 * ES_NL); if (l < L) val = lm_einv[l]; }
+      else if (e < 80 * ES_NL + 2 * ES_NL) { const int l = l0 + (e - 80 * ES_NL - ES_NL); if (l < L) val = lm_g[l]; }
+      r[u] = val;
+    }
+  }
+  __device__ __forceinline__ void store(int i, int t256) const {
+    double *Ws = e_lds + E_WS + ES_N * (i & 1);
+#pragma unroll
+    for (int u = 0; u < ES_NLD; ++u) {
+      const int e = t256 + 256 * u;
+      if (e < 80 * ES_NL) Ws[(e >> 5) * ES_LD + (e & 31)] = r[u];
+      else if (e < 80 * ES_NL + ES_NL) Ws[ES_EI + (e - 80 * ES_NL)] = r[u];
+      else if (e < 80 * ES_NL + 2 * ES_NL) Ws[ES_G + (e - 80 * ES_NL - ES_NL)] = r[u];
+    }
+  }
+};
+
+// chain scratch (per chain wave)
+#define MC_LM 0
+#define MC_TA0 176
+#define MC_SN 528
+// Cholesky (E_CHOL region)
+#define MX_D16 0
+#define MX_LI16 272
+#define MX_P16 560
+#define MX_PANEL 1024
+// reduction slots (per wave: 8 each)
+#define QR_GN 0
+#define QR_GMAX 8
+#define QR_Q 16
+#define QR_GNN 24
+#define QR_GY 32
+#define QR_QX 40
+#define QR_FAIL 48     // [4] chain down, chain up, pose system
+#define QR_CA 52
+#define QR_CB 53
+#define QR_GO 54
+
+extern "C" size_t vilo_solve_mw8_lds_bytes() { return (size_t)E_TOTAL * sizeof(double); }
+
+__device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void e_barrier_global() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+#define E_BARRIER() e_barrier()
+#define E_BARRIER_GLOBAL() e_barrier_global()
+// (profiling build: cycles a role waits at the main loop's step barriers, left in red[QR_WAIT + slot] for the kernel body)
+#define E_STEP_BARRIER() do { const long long w0_ = pclk64(); e_barrier(); PCLK(ewait += clock64() - w0_); } while (0)
+#define QR_WAIT 56
+// tiles of the pose system owned by the matrix waves (bit t of the mask = tile t of c_tI / c_tJ) and the blocks X of the reduced
+// right-hand side each of them accumulates (a wave has the operands of the blocks its tiles touch):
+//   B1: (0,0) (1,0) (1,1) (2,0)   rhs 0, 1        B2: (2,1) (2,2) (3,0) (3,1)   rhs 2
+//   B3: (3,2) (3,3) (4,0) (4,1)   rhs 3           B4: (4,2) (4,3) (4,4)         rhs 4
+#define EB1_MASK 0x000f
+#define EB2_MASK 0x00f0
+#define EB3_MASK 0x0f00
+#define EB4_MASK 0x7000
+constexpr int e_blocks_of(int mask, int rhs) {   // operand blocks a matrix wave needs: those of its tiles' rows and columns + its rhs blocks
+  constexpr int tI[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4}, tJ[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+  int m = rhs;
+  for (int t = 0; t < 15; ++t)
+    if ((mask >> t) & 1) m |= (1 << tI[t]) | (1 << tJ[t]);
+  return m;
+}
+
+// The 80 x 80 pose system's Cholesky, forward and backward solve on ONE wave (B1), with all 15 accumulator tiles in registers. In: the tiles in E_TILES (accumulator order), dh2, the reduced right-hand side v. Out: y (E_Y), masked
+// to the active dimensions. Blocked by 16: diagonal tile in registers + v_readlane, panel and trailing update on the matrix cores, the
+// right-hand side riding along as a sixth block row; backward solve with the factor's accumulator registers as operands: as in
+// k_solve_wave / k_solve_mw. Returns 1 if a pivot failed.
+__device__ __noinline__ int mw8_chol80(double mu, int F, int cmask) {
+  double *const lds = e_lds;
+  mu = uni(mu); F = uni(F); cmask = uni(cmask);
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double *dh2 = lds + E_DH2, *y = lds + E_Y, *v = lds + E_V;
+  mfma_d4 acc[15];
+  int fail = 0;
+  const double *Gt = lds + E_TILES;
+#pragma unroll
+  for (int t = 0; t < 15; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = Gt[(t * 4 + r) * 64 + lane];
+#pragma unroll
+  for (int I = 0; I < 5; ++I)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (lk + 4 * r == lr) acc[tile_index(I, I)][r] += mu * dh2[16 * I + lr];
+  double *scr = lds + E_CHOL;
+  double *D16 = scr + MX_D16, *LI16 = scr + MX_LI16, *P16 = scr + MX_P16;
+  double vrow[5];
+#pragma unroll
+  for (int J = 0; J < 5; ++J) vrow[J] = (lk == 0) ? v[16 * J + lr] : 0.0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[tile_index(j, j)][r];
+    lds_fence();
+    fail |= chol16_tile(D16, LI16);
+    double li[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) li[kk] = LI16[lr * 17 + 4 * kk + lk];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[tile_index(j, j)][r] = LI16[(lk + 4 * r) * 17 + lr];   // L_jj^-1 in accumulator order
+#pragma unroll
+    for (int I = j + 1; I < 5; ++I) {
+      const int t = tile_index(I, j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P16[(lk + 4 * r) * 17 + lr] = acc[t][r];
+      lds_fence();
+      mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
+      acc[t] = nacc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[pswz_at(E_CHOL + MX_PANEL, I - j - 1, lk + 4 * r, lr)] = nacc[r];
+      lds_fence();   // (P16 is reused by the next panel)
+    }
+    double pv[4];
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P16[(lk + 4 * r) * 17 + lr] = (r == 0) ? vrow[j] : 0.0;
+      lds_fence();
+      mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
+      if (lk == 0) y[16 * j + lr] = nacc[0];
+      lds_fence();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) pv[kk] = (lr == 0) ? y[16 * j + 4 * kk + lk] : 0.0;
+    }
+    double pa[5][4];
+#pragma unroll
+    for (int I = j + 1; I < 5; ++I)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) pa[I][kk] = lds[pswz_at(E_CHOL + MX_PANEL, I - j - 1, lr, 4 * kk + lk)];
+#pragma unroll
+    for (int I = j + 1; I < 5; ++I)
+#pragma unroll
+      for (int J = j + 1; J <= I; ++J)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[tile_index(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[I][kk], pa[J][kk], acc[tile_index(I, J)], 0, 0, 0);
+#pragma unroll
+    for (int J = j + 1; J < 5; ++J) {
+      mfma_d4 tv = {vrow[J], 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) tv = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[kk], pa[J][kk], tv, 0, 0, 0);
+      vrow[J] = tv[0];
+    }
+    lds_fence();   // (the panel slots are rewritten by the next block column)
+  }
+  if (fail) return 1;
+  // L^T yP = y, blockwise on the matrix cores: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i)
+  mfma_d4 yb[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yb[j][r] = y[16 * j + lk + 4 * r];
+#pragma unroll
+  for (int j = 4; j >= 0; --j) {
+    mfma_d4 accv = yb[j];
+#pragma unroll
+    for (int i2 = j + 1; i2 < 5; ++i2)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[tile_index(i2, j)][kk], yb[i2][kk], accv, 0, 0, 0);
+    mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tile_index(j, j)][kk], accv[kk], n, 0, 0, 0);
+    yb[j] = n;
+  }
+  lds_fence();
+  if (lr == 0) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[16 * j + lk + 4 * r] = cd_active(16 * j + lk + 4 * r, F, cmask) ? yb[j][r] : 0.0;
+  }
+  return 0;
+}
+
+// waves C1 / C2: the twisted chain, 13 x 13 part (see the head of the file). The failure flag goes to red[QR_FAIL + (up ? 1 : 0)].
+__device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const double *wl, const double *lm_einv, const double *lm_g, double mu, int F, int L) {
+  double *const lds = e_lds;
+  const bool up = uni(up_) != 0;   // C2 walks the frames upwards from 0
+  bimg = uni(bimg); wl = uni(wl); lm_einv = uni(lm_einv); lm_g = uni(lm_g); mu = uni(mu); F = uni(F); L = uni(L);
+  const E_Geom G = e_geom(F, L);
+  const int mid = G.mid, nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double *red = lds + E_RED, *DB = lds + E_DB;
+  int fail = 0;
+  long long ewait = 0;
+  const int t256 = (up ? 64 : 0) + lane;   // loader index (C1, C2, TD, TU)
+  E_Slice sl;
+  sl.load(G, 0, t256, wl, lm_einv, lm_g, L);
+  sl.store(0, t256);
+  const int grp = lk, c = lr;
+  const int row = c < 13 ? c : 0;
+  double *scr = lds + (up ? E_CH2 : E_CH1);
+  double *LM = scr + MC_LM, *SN = scr + MC_SN, *TAcur = scr + MC_TA0;
+  // one frame of a chain. nb: the neighbour this frame hands its Schur update to (-1: none: the middle frame); prevk: the frame
+  // eliminated before this one in the same direction (-1: first)
+  auto frame = [&](int k, int nb, int prevk, bool middle) {
+    double a[13], l[13], rhs[13], adn[4];
+    // right-hand sides of the off-diagonal factor: column `row` of A_{k,k-1} (downwards), of A_{k+1,k}^T (upwards)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      double rv = 0.0;
+      if (nb >= 0) rv = up ? bimg[BI_AOT + (k * 13 + i) * 13 + row] : bimg[BI_AOT + ((k - 1) * 13 + row) * 13 + i];
+      rhs[i] = rv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) adn[r] = (nb >= 0 && lr < 13 && lk + 4 * r < 13) ? bimg[BI_AD + nb * 169 + (lk + 4 * r) * 13 + lr] : 0.0;   // A_{nb,nb}, accumulator order
+    // S_k (lane = row): the first frame of a direction straight from A_kk, later ones from the update left by the previous step
+    if (prevk < 0) {
+#pragma unroll
+      for (int j = 0; j < 13; ++j) a[j] = bimg[BI_AD + (k * 13 + row) * 13 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 13; ++j) a[j] = SN[row * 13 + j];
+    }
+    if (middle && nL > 0) {
+      const double *XS = lds + E_XSN;
+#pragma unroll
+      for (int j = 0; j < 13; ++j) a[j] -= XS[row * 13 + j];
+    }
+    {
+      const double md = mu * DB[13 * k + row];
+#pragma unroll
+      for (int j = 0; j < 13; ++j) a[j] += (j == row) ? md : 0.0;
+    }
+    double myrinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      double piv = readlane_d(a[j], j);
+      if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+      const double rinv = rsqrt(piv);
+      const double lj = (c == j) ? piv * rinv : (c > j ? a[j] * rinv : 0.0);
+      l[j] = lj;
+      if (c == j) myrinv = rinv;
+#pragma unroll
+      for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(l[j]));
+    double cl[13];
+#pragma unroll
+    for (int q2 = 0; q2 < 13; ++q2) {
+      double vv = (grp == 0) ? rhs[q2] : ((q2 == c) ? 1.0 : 0.0);
+#pragma unroll
+      for (int q = 0; q < q2; ++q) vv -= readlane_d(l[q], q2) * cl[q];
+      cl[q2] = vv * readlane_d(myrinv, q2);
+      asm volatile("" : "+v"(cl[q2]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double *Mk = lds + E_M + 176 * k, *TAk = lds + E_TA + 176 * k;
+    if (c < 13 && grp < 2) {
+      if (grp == 0) {
+#pragma unroll
+        for (int q = 0; q < 13; ++q) { TAcur[q * 13 + c] = cl[q]; TAk[q * 13 + c] = cl[q]; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 13; ++q) { LM[q * 13 + c] = cl[q]; Mk[q * 13 + c] = cl[q]; }
+      }
+    }
+    lds_fence();
+    // the neighbour's diagonal block loses T_A^T T_A: one 16 x 16 tile on the matrix cores. The frame next to the middle leaves C2's
+    // share where C1 finds it (C1's own share goes into its SN with A_mm)
+    if (nb >= 0) {
+      mfma_d4 sn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int q = 4 * kk + lk;
+        const double ta = ((lr < 13) && (q < 13)) ? TAcur[min(q, 12) * 13 + min(lr, 12)] : 0.0;
+        sn = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, ta, sn, 0, 0, 0);
+      }
+      const bool to_mid = up && nb == mid;
+      double *dst = to_mid ? lds + E_XSN : SN;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lr < 13 && lk + 4 * r < 13) dst[(lk + 4 * r) * 13 + lr] = to_mid ? sn[r] : adn[r] - sn[r];
+    }
+  };
+  E_BARRIER();   // (the matrix waves' skip table and slice 0: every wave meets the same barriers)
+  for (int i = 0; i < NSTEP; ++i) {
+    if (i + 1 < NSTEP) sl.load(G, i + 1, t256, wl, lm_einv, lm_g, L);
+    if (!up) {
+      if (i < nU) { const int k = F - 1 - i; frame(k, k - 1, i == 0 ? -1 : k + 1, false); }
+      else if (i == nS) frame(mid, -1, mid + 1, true);
+    } else if (i < nL) {
+      frame(i, i + 1, i == 0 ? -1 : i - 1, false);
+    }
+    if (i == nS && lane == 0) red[QR_FAIL + (up ? 1 : 0)] = (double)fail;
+    if (i + 1 < NSTEP) sl.store(i + 1, t256);
+    E_STEP_BARRIER();
+  }
+  PCLK(if (lane == 0) red[QR_WAIT + (up ? 1 : 0)] = (double)ewait);
+  E_BARRIER();   // the tiles and the reduced right-hand side
+  E_BARRIER();   // y_P
+}
+
+// waves TD / TU: the chain's coupling rows T(k), one step behind their chain wave (and a quarter of the operand slices: E_Slice).
+__device__ __noinline__ void mw8_role_T(int up_, const double *bimg, const double *wl, const double *lm_einv, const double *lm_g, int F, int L, int kb) {
+  double *const lds = e_lds;
+  const bool up = uni(up_) != 0;
+  bimg = uni(bimg); wl = uni(wl); lm_einv = uni(lm_einv); lm_g = uni(lm_g); F = uni(F); L = uni(L); kb = uni(kb);
+  const E_Geom G = e_geom(F, L);
+  const int mid = G.mid, nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double *GB = lds + E_GB;
+  const int t256 = 128 + (up ? 64 : 0) + lane;   // loader index (C1, C2, TD, TU)
+  long long ewait = 0;
+  E_Slice sl;
+  sl.load(G, 0, t256, wl, lm_einv, lm_g, L);
+  sl.store(0, t256);
+  int fX[5], oX[5];
+#pragma unroll
+  for (int X = 0; X < 5; ++X) { const int col = 16 * X + lr; fX[X] = col < 66 ? col / 6 : 99; oX[X] = col < 66 ? col - 6 * fX[X] : 0; }
+  double *Tbase = lds + (up ? E_T2 : E_T1);
+  mfma_d4 T[5];
+#pragma unroll
+  for (int X = 0; X < 5; ++X) T[X] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  // T(k) of the frame the chain wave of this direction eliminated in step `step` (prevk: the frame before it in that direction, -1: first)
+  auto tframe = [&](int k, int prevk, bool middle, int step) {
+    const int x_lo = (up || middle || k <= kb) ? 0 : max(0, (6 * (k - 1)) >> 4);   // (upwards and in the middle T(k) is dense)
+    mfma_d4 V[5];
+    // [B_k | g_k] in accumulator order: row lk + 4 r, column 16 X + lr; column 79 carries the gradient
+#pragma unroll
+    for (int X = 0; X < 5; ++X) {
+      const int df = fX[X] - k + 1;
+      const bool on = df >= 0 && df <= 2;
+      const double *src = bimg + BI_BS + (k * 16 + lk) * 18 + 6 * min(max(df, 0), 2) + oX[X];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) V[X][r] = on ? src[72 * r] : 0.0;
+    }
+    if (k == kb) {
+#pragma unroll
+      for (int X = 0; X < 5; ++X)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[X][r] += bimg[BI_BP + (lk + 4 * r) * 80 + 16 * X + lr];
+    }
+    if (lr == 15) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) V[4][r] = (lk + 4 * r < 13) ? GB[13 * k + lk + 4 * r] : 0.0;
+    }
+    // V -= T_A(prev)^T T(prev);  T(k) = M_k V
+    const double *TAprev = lds + E_TA + 176 * max(prevk, 0), *LM = lds + E_M + 176 * k;
+    double at[4], am[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int q = 4 * kk + lk;
+      const bool in = (lr < 13) && (q < 13);
+      const double ta = TAprev[min(q, 12) * 13 + min(lr, 12)], m = LM[min(lr, 12) * 13 + min(q, 12)];
+      at[kk] = (in && prevk >= 0) ? -ta : 0.0;
+      am[kk] = in ? m : 0.0;
+    }
+    if (prevk >= 0) {
+#pragma unroll
+      for (int X = 0; X < 5; ++X)
+        if (X >= x_lo) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) V[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], T[X][kk], V[X], 0, 0, 0);
+        }
+    }
+    if (middle && nL > 0) {
+      // the lower neighbour's term: T'_A(m-1) from the factor store, T(m-1) from TU's hand-over buffer (its last frame)
+      const double *TAl = lds + E_TA + 176 * (mid - 1);
+      const double *Tl = lds + E_T2 + 1280 * ((nL - 1) & 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int q = 4 * kk + lk;
+        const double ta = ((lr < 13) && (q < 13)) ? -TAl[min(q, 12) * 13 + min(lr, 12)] : 0.0;
+#pragma unroll
+        for (int X = 0; X < 5; ++X) V[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, Tl[(X * 4 + kk) * 64 + lane], V[X], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int X = 0; X < 5; ++X)
+      if (X >= x_lo) {
+        mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], V[X][kk], n, 0, 0, 0);
+        T[X] = n;
+      }
+    // hand T(k) over (tiles left of x_lo are zero: written as such, the consumers need no per-frame sparsity table)
+    double *Tb = Tbase + 1280 * (step & 1);
+#pragma unroll
+    for (int X = 0; X < 5; ++X)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) Tb[(X * 4 + kk) * 64 + lane] = (X >= x_lo) ? T[X][kk] : 0.0;
+  };
+  E_BARRIER();   // (skip table, slice 0)
+  for (int i = 0; i < NSTEP; ++i) {
+    if (i + 1 < NSTEP) sl.load(G, i + 1, t256, wl, lm_einv, lm_g, L);
+    const int cstep = i - 1;   // the chain step whose M_k / T_A(k) are in LDS now
+    if (cstep >= 0) {
+      if (!up) {
+        if (cstep < nU) { const int k = F - 1 - cstep; tframe(k, cstep == 0 ? -1 : k + 1, false, cstep); }
+        else if (cstep == nS) tframe(mid, mid + 1, true, cstep);
+      } else if (cstep < nL) {
+        tframe(cstep, cstep == 0 ? -1 : cstep - 1, false, cstep);
+      }
+    }
+    if (i + 1 < NSTEP) sl.store(i + 1, t256);
+    E_STEP_BARRIER();
+  }
+  PCLK(if (lane == 0) lds[E_RED + QR_WAIT + 2 + (up ? 1 : 0)] = (double)ewait);
+  E_BARRIER();   // the tiles and the reduced right-hand side
+  E_BARRIER();   // y_P
+}
+
+// waves B1 .. B4: the pose system's tiles MASK — landmark Schur complement from the LDS slices, rank updates from the T waves' hand-over
+// buffers, the blocks RHS of the reduced right-hand side; at the end the tiles go to E_TILES for the Cholesky.
+template <int MASK, int RHS>
+__device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg, const unsigned char *lms, int F, int L) {
+  double *const lds = e_lds;
+  const int bw = uni(bw_);
+  Cimg = uni(Cimg); lms = uni(lms); F = uni(F); L = uni(L);
+  const E_Geom G = e_geom(F, L);
+  const int nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP, NT = G.NT;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double *g = lds + E_G, *v = lds + E_V;
+  constexpr int NEED = e_blocks_of(MASK, RHS);            // operand blocks the wave reads
+  long long ewait = 0;
+  mfma_d4 acc[15];   // (only the tiles of MASK exist)
+#pragma unroll
+  for (int t = 0; t < 15; ++t)
+    if ((MASK >> t) & 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = Cimg[(t * 4 + r) * 64 + lane];
+    }
+  double yacc[5], yr[5];
+#pragma unroll
+  for (int X = 0; X < 5; ++X) { yacc[X] = 0.0; yr[X] = 0.0; }
+  int *skip_tab = (int *)(lds + E_SKIP);
+  if (bw == 0 && L > 0) {
+    for (int tr = lane; tr < NT + 2; tr += 64) skip_tab[tr] = (6 * (int)lms[min(16 * tr, L - 1)] >= 16) ? 1 : 0;
+  }
+  E_BARRIER();   // (the skip table is B1's, slice 0 the T waves'; every wave meets this barrier)
+  // operands of a half trip (two k-steps of 4 landmarks) from the iteration's slice, the next half's behind this one's matrix instructions;
+  // hl: the half's position inside the slice
+  double opb[2][2][5], eb[2][2], gb[2][2];
+  auto ldhalf = [&](int h, int hl, const double *Ws, auto bs) {
+    constexpr int bsel = decltype(bs)::value;
+    const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(h >> 1, NT)]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int lc = 8 * hl + 4 * u + lk;
+      eb[bsel][u] = Ws[ES_EI + lc]; gb[bsel][u] = Ws[ES_G + lc];
+#pragma unroll
+      for (int X = 1; X < 5; ++X)
+        if ((NEED >> X) & 1) opb[bsel][u][X] = Ws[(16 * X + lr) * ES_LD + lc];
+    }
+    if ((NEED & 1) && !skip0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) opb[bsel][u][0] = Ws[lr * ES_LD + 8 * hl + 4 * u + lk];
+    }
+  };
+  auto dohalf = [&](auto bs, auto xl) {
+    constexpr int bsel = decltype(bs)::value;
+    constexpr int XL = decltype(xl)::value;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double ei = eb[bsel][u], ge = gb[bsel][u] * ei;
+#pragma unroll
+      for (int t = 0; t < 15; ++t)
+        if (((MASK >> t) & 1) && c_tJ[t] >= XL)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(opb[bsel][u][c_tI[t]] * ei), opb[bsel][u][c_tJ[t]], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int X = XL; X < 5; ++X)
+        if ((RHS >> X) & 1) yacc[X] += opb[bsel][u][X] * ge;
+    }
+  };
+  auto half = [&](int h, auto bs) {
+    const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(h >> 1, NT)]);
+    if (skip0) dohalf(bs, std::integral_constant<int, 1>{});
+    else dohalf(bs, std::integral_constant<int, 0>{});
+  };
+    // C -= T^T T for one delivered frame (all five tile columns: the T waves write zeros where T(k) has none)
+    auto rank_update = [&](const double *Tb) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double Tk[5];
+#pragma unroll
+        for (int X = 0; X < 5; ++X) Tk[X] = ((NEED >> X) & 1 || X == 4) ? Tb[(X * 4 + kk) * 64 + lane] : 0.0;
+        const double tg = __shfl(Tk[4], (lane & 48) | 15, 64);   // t_g(k) (column 79): the pose system must not see it
+        if (lr == 15) Tk[4] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 15; ++t)
+          if ((MASK >> t) & 1) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Tk[c_tI[t]], Tk[c_tJ[t]], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int X = 0; X < 5; ++X)
+          if ((RHS >> X) & 1) yr[X] += Tk[X] * tg;
+      }
+    };
+  for (int i = 0; i < NSTEP; ++i) {
+    const int h0 = e_slice_h0(G, i), h1 = e_slice_h0(G, i + 1);
+    const double *Ws = lds + E_WS + ES_N * (i & 1);
+    if (h0 < h1) ldhalf(h0, 0, Ws, std::integral_constant<int, 0>{});
+    for (int h = h0; h < h1; ++h) {
+      if ((h - h0) & 1) {
+        if (h + 1 < h1) ldhalf(h + 1, h + 1 - h0, Ws, std::integral_constant<int, 0>{});
+        half(h, std::integral_constant<int, 1>{});
+      } else {
+        if (h + 1 < h1) ldhalf(h + 1, h + 1 - h0, Ws, std::integral_constant<int, 1>{});
+        half(h, std::integral_constant<int, 0>{});
+      }
+    }
+    if (i >= 2) {
+      // what the T waves finished in iteration i - 1 = the chain's step i - 2: TD a frame above the middle or (step nS) the middle, TU a frame below
+      const int cstep = i - 2;
+      if (cstep < nU || cstep == nS) rank_update(lds + E_T1 + 1280 * (cstep & 1));
+      if (cstep < nL) rank_update(lds + E_T2 + 1280 * (cstep & 1));
+    }
+    E_STEP_BARRIER();
+  }
+  PCLK(if (lane == 0) lds[E_RED + QR_WAIT + 4 + bw] = (double)ewait);
+    // reduced right-hand side: g_P - sum_k T_B^T t_g - sum_l w_l g_l / (E_l + mu dhat_l^2), the blocks this wave owns
+#pragma unroll
+    for (int X = 0; X < 5; ++X)
+      if ((RHS >> X) & 1) {
+        double s = yr[X] + yacc[X];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lk == 0) v[16 * X + lr] = g[16 * X + lr] - s;
+      }
+    {
+      // the tiles move to the Cholesky (accumulator order, one coalesced LDS store per register)
+      double *Gt = lds + E_TILES;
+#pragma unroll
+      for (int t = 0; t < 15; ++t)
+        if ((MASK >> t) & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Gt[(t * 4 + r) * 64 + lane] = acc[t][r];
+        }
+    }
+  E_BARRIER();   // every wave's tiles and the reduced right-hand side are there
+}
+
+// C1 / C2 after y_P: back-substitution of the speed / leg-bias part (twisted sweeps). Partial sums of |D y|^2 and g^T y of the wave's frames
+// go to red[QR_GNN / QR_GY + wave].
+__device__ __noinline__ void mw8_role_sweeps(int up_, int wave_, const double *bimg, int F, int L, int kb, int cmask) {
+  double *const lds = e_lds;
+  const bool up = uni(up_) != 0;
+  const int wave = uni(wave_);
+  bimg = uni(bimg); F = uni(F); L = uni(L); kb = uni(kb); cmask = uni(cmask);
+  const E_Geom G = e_geom(F, L);
+  const int mid = G.mid, nL = G.nL, nU = G.nU;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double *y = lds + E_Y, *red = lds + E_RED, *DB = lds + E_DB, *GB = lds + E_GB, *U = lds + E_U, *YB = lds + E_YB;
+  double part_gnn = 0.0, part_gy = 0.0;
+  const int k_lo = up ? 0 : mid, k_hi = up ? mid - 1 : F - 1;   // this wave's frames (C1 owns the middle)
+  // c = g_B - B yP for this wave's frames: the IMU part of B_k spans poses k-1 .. k+1, the prior part frame kb only
+  {
+    double bsv[3][18];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int e = min(lane + 64 * m, 142), k = e / 13;
+#pragma unroll
+      for (int s2 = 0; s2 < 18; ++s2) bsv[m][s2] = bimg[BI_BS + (16 * k + (e - 13 * k)) * 18 + s2];
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int e = lane + 64 * m, k = min(e, 142) / 13;
+      double sacc = GB[min(e, 143)];
+#pragma unroll
+      for (int s2 = 0; s2 < 18; ++s2) sacc -= bsv[m][s2] * y[min(max(6 * (k - 1) + s2, 0), 79)];
+      if (e < 143 && k >= k_lo && k <= k_hi) U[e] = sacc;
+    }
+  }
+  lds_fence();
+  if (kb >= k_lo && kb <= k_hi) {
+    double sacc = 0.0, bpv[20];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) bpv[u] = (lr < 13 && lk + 4 * u < VILO_NPU) ? bimg[BI_BP + lr * 80 + lk + 4 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 20; ++u) sacc += bpv[u] * y[min(lk + 4 * u, 79)];
+    sacc += __shfl_xor(sacc, 16, 64);
+    sacc += __shfl_xor(sacc, 32, 64);
+    if (lane < 13) U[13 * kb + lane] -= sacc;
+  }
+  lds_fence();
+  const int row = lr < 13 ? lr : 0;
+  const double *Mall = lds + E_M, *TAall = lds + E_TA;
+  // forward sweeps, both halves at once:   down  u_k = M_k (c_k - T_A(k+1)^T u_{k+1})   k = F-1 .. m+1
+  //                                        up    u_k = M_k (c_k - T'_A(k-1)^T u_{k-1})  k = 0 .. m-1
+  double uprev = 0.0;
+  if (!up) {
+    for (int k = F - 1; k > mid; --k) {
+      double s2 = U[13 * k + row];
+      if (k < F - 1) {
+        const double *TB = TAall + 176 * (k + 1);
+#pragma unroll
+        for (int q = 0; q < 13; ++q) s2 -= TB[q * 13 + row] * readlane_d(uprev, q);
+      }
+      const double *MB = Mall + 176 * k;
+      double u = 0.0;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) u += MB[row * 13 + q] * readlane_d(s2, q);
+      if (lane < 13) U[13 * k + lane] = u;
+      uprev = u;
+    }
+  } else {
+    for (int k = 0; k < mid; ++k) {
+      double s2 = U[13 * k + row];
+      if (k > 0) {
+        const double *TB = TAall + 176 * (k - 1);
+#pragma unroll
+        for (int q = 0; q < 13; ++q) s2 -= TB[q * 13 + row] * readlane_d(uprev, q);
+      }
+      const double *MB = Mall + 176 * k;
+      double u = 0.0;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) u += MB[row * 13 + q] * readlane_d(s2, q);
+      if (lane < 13) U[13 * k + lane] = u;
+      uprev = u;
+    }
+    if (lane < 13) lds[E_XU + lane] = uprev;   // u of frame m - 1 for the middle
+  }
+  E_BARRIER();
+  // the middle frame (C1): u_m = M_m (c_m - T_A(m+1)^T u_{m+1} - T'_A(m-1)^T u_{m-1}),  y_m = M_m^T u_m
+  double ymid = 0.0;
+  if (!up) {
+    double s2 = U[13 * mid + row];
+    if (nU > 0) {
+      const double *TB = TAall + 176 * (mid + 1);
+#pragma unroll
+      for (int q = 0; q < 13; ++q) s2 -= TB[q * 13 + row] * readlane_d(uprev, q);
+    }
+    if (nL > 0) {
+      const double *TB = TAall + 176 * (mid - 1);
+      const double ul = lds[E_XU + row];
+#pragma unroll
+      for (int q = 0; q < 13; ++q) s2 -= TB[q * 13 + row] * readlane_d(ul, q);
+    }
+    const double *MB = Mall + 176 * mid;
+    double u = 0.0;
+#pragma unroll
+    for (int q = 0; q < 13; ++q) u += MB[row * 13 + q] * readlane_d(s2, q);
+    double yk = 0.0;
+#pragma unroll
+    for (int q = 0; q < 13; ++q) yk += MB[q * 13 + row] * readlane_d(u, q);
+    if (!cd_active(CD_B0 + 13 * mid + row, F, cmask)) yk = 0.0;
+    if (lane < 13) { YB[13 * mid + lane] = yk; lds[E_XY + lane] = yk; }
+    ymid = yk;
+  }
+  E_BARRIER();
+  // backward sweeps, both halves at once:  down  y_k = M_k^T (u_k - T_A(k) y_{k-1})    k = m+1 .. F-1
+  //                                        up    y_k = M_k^T (u_k - T'_A(k) y_{k+1})   k = m-1 .. 0
+  double yprev = up ? lds[E_XY + row] : ymid;
+  if (!up) {
+    for (int k = mid + 1; k < F; ++k) {
+      const double *TB = TAall + 176 * k, *MB = Mall + 176 * k;
+      double s2 = U[13 * k + row];
+#pragma unroll
+      for (int q = 0; q < 13; ++q) s2 -= TB[row * 13 + q] * readlane_d(yprev, q);
+      double yk = 0.0;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) yk += MB[q * 13 + row] * readlane_d(s2, q);
+      if (!cd_active(CD_B0 + 13 * k + row, F, cmask)) yk = 0.0;
+      if (lane < 13) YB[13 * k + lane] = yk;
+      yprev = yk;
+    }
+  } else {
+    for (int k = mid - 1; k >= 0; --k) {
+      const double *TB = TAall + 176 * k, *MB = Mall + 176 * k;
+      double s2 = U[13 * k + row];
+#pragma unroll
+      for (int q = 0; q < 13; ++q) s2 -= TB[row * 13 + q] * readlane_d(yprev, q);
+      double yk = 0.0;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) yk += MB[q * 13 + row] * readlane_d(s2, q);
+      if (!cd_active(CD_B0 + 13 * k + row, F, cmask)) yk = 0.0;
+      if (lane < 13) YB[13 * k + lane] = yk;
+      yprev = yk;
+    }
+  }
+  lds_fence();
+  // norms of this wave's frames
+  for (int e = lane; e < 143; e += 64) {
+    const int k = e / 13;
+    if (k >= k_lo && k <= k_hi && k < F) {
+      const double yb = YB[e];
+      part_gnn += DB[e] * yb * yb;   // (y is zero on inactive dimensions)
+      part_gy += GB[e] * yb;
+    }
+  }
+  part_gnn = wave_sum(part_gnn); part_gy = wave_sum(part_gy);
+  if (lane == 0) { red[QR_GNN + wave] = part_gnn; red[QR_GY + wave] = part_gy; red[QR_QX + wave] = 0.0; }
+}
+
+// B1 .. B4 after y_P: landmarks y_l = (g_l - w_l^T yP) / (E_l + mu dhat_l^2), a quarter each; partial sums to red[.. + wave].
+__device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl, const double *lm_g, const double *lm_einv, const double *lm_dh2, double *lm_y, int L) {
+  double *const lds = e_lds;
+  const int bw = uni(bw_), wave = uni(wave_);
+  wl = uni(wl); lm_g = uni(lm_g); lm_einv = uni(lm_einv); lm_dh2 = uni(lm_dh2); lm_y = uni(lm_y); L = uni(L);
+  const int lane = threadIdx.x & 63;
+  double *g = lds + E_G, *dh2 = lds + E_DH2, *y = lds + E_Y, *red = lds + E_RED;
+  double part_gnn = 0.0, part_gy = 0.0, part_qx = 0.0;
+  const double *vP = lds + E_VP;
+  for (int l = lane + 64 * bw; l < L; l += 256) {
+    const double gl = lm_g[l], ei = lm_einv[l], d2 = lm_dh2[l], vl = gl / d2;
+    double tl = 0.0, tq = 0.0;
+    // (20 coupling entries in flight per lane: the wave shares its SIMD's registers with a second one)
+#pragma unroll 1
+    for (int a0 = 0; a0 < 80; a0 += 20) {
+      double wcol[20];
+#pragma unroll
+      for (int a = 0; a < 20; ++a) wcol[a] = wl[(size_t)(a0 + a) * L + l];
+#pragma unroll
+      for (int a = 0; a < 20; ++a)
+        if (a0 + a < VILO_NPU) { tl += wcol[a] * y[a0 + a]; tq += wcol[a] * vP[a0 + a]; }   // y and v_P are zero on inactive dimensions
+    }
+    const double yl = (gl - tl) * ei;
+    lm_y[l] = yl;
+    part_gnn += d2 * yl * yl;
+    part_gy += gl * yl;
+    part_qx += vl * tq;   // cross term of q = v^T H v: 2 v_l w_l^T v_P
+  }
+  if (bw == 0) {
+    for (int cd = lane; cd < 80; cd += 64) {
+      part_gnn += dh2[cd] * y[cd] * y[cd];
+      part_gy += g[cd] * y[cd];
+    }
+  }
+  part_gnn = wave_sum(part_gnn); part_gy = wave_sum(part_gy); part_qx = wave_sum(part_qx);
+  if (lane == 0) { red[QR_GNN + wave] = part_gnn; red[QR_GY + wave] = part_gy; red[QR_QX + wave] = part_qx; }
+  E_BARRIER();   // (the chain waves' hand-over points)
+  E_BARRIER();
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_solve_mw8(BatchDev b, SolveParams sp) {
+  double *const lds = e_lds;
+  const int win = blockIdx.x;
+  SolverState &st = b.st[win];
+  if (st.done) return;
+  // roles: 0: C1 (chain down + middle), 1: C2 (chain up), 2: TD, 3: TU, 4 .. 7: B1 .. B4. Hardware wave w of a workgroup runs on SIMD w % 4
+  // (measured: waves w and w + 4 share a matrix pipe — one FP64 MFMA per 64 cycles per SIMD — and the older wave goes first): the chain waves
+  // are paired with the T waves, the matrix waves with each other. (Pairing each matrix wave with a chain or T wave instead, which balances
+  // the four pipes' instruction counts, changed nothing — 90.2 / 90.4 / 90.3 us for one window: the iterations are bound by the waves'
+  // own dependency chains, not by the pipes.)
+  const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = (hw_wave & 2) ? (4 + (hw_wave & 1) + ((hw_wave & 4) >> 1)) : ((hw_wave & 1) + ((hw_wave & 4) >> 1));   // 0 1 4 5 | 2 3 6 7
+  const int lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
+  const WinMeta wm = b.win[win];
+  const int F = wm.n_frames, L = wm.L, kb = wm.pad, cmask = wm.const_mask;
+  double *g = lds + E_G, *dh2 = lds + E_DH2, *y = lds + E_Y, *red = lds + E_RED;
+  double *DB = lds + E_DB, *GB = lds + E_GB, *YB = lds + E_YB;
+  struct DoglegIn { double radius, mu, gnorm2, gnnorm2, gdotgn, q, alpha, coef_a, coef_b, dogleg_step_norm, model_cost_change; int step_valid; } fresh;
+  bool have_fresh = false;
+  const double radius0 = st.radius;
+  const long long q_start = pclk64();
+#define ESTAMP(w_, i_) PCLK(if (wave == (w_) && lane == 0) st.phase_clk[i_] = clock64() - q_start)
+
+  if (st.need_lin) {
+    const double *bimg = b.Bimg + (size_t)win * BI_N;
+    const double *gin = b.cam_gin + (size_t)win * CD_N;
+    const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
+    double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_gbuf[st.cur] + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
+           *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
+    const bool first_scale = !st.scale_ready;
+    double mu = st.mu;
+
+    // ---- camera-side vectors come scaled from k_assemble; the landmarks are scaled here (landmark tid + 512 n) ----
+    double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
+    if (wave == 4) {
+      for (int cd = lane; cd < 80; cd += 64) { g[cd] = gin[cd]; dh2[cd] = bimg[BI_DH2 + cd]; lds[E_VP + cd] = cd_active(cd, F, cmask) ? bimg[BI_V + cd] : 0.0; }
+    } else if (wave == 0) {
+      for (int e = lane; e < 144; e += 64) { DB[e] = bimg[BI_DH2 + CD_B0 + min(e, 143)]; GB[e] = gin[CD_B0 + min(e, 143)]; }
+    }
+    for (int l = tid; l < L; l += 512) {
+      const double E = lm_E[l], gl = lm_g[l];
+      double sc;
+      if (first_scale) { sc = sp.jacobi_scaling ? 1.0 / (1.0 + sqrt(E)) : 1.0; lm_scale[l] = sc; }
+      else sc = lm_scale[l];
+      const double d2 = fmin(fmax(sc * sc * E, sp.min_lm_diagonal), sp.max_lm_diagonal) / (sc * sc);
+      lm_dh2[l] = d2;
+      lm_einv[l] = 1.0 / (E + mu * d2);   // (of the first factorisation: a retry at a larger mu forms its own below)
+      const double vl = gl / d2;
+      part_q += E * vl * vl;   // (the cross term 2 vl w_l^T v_P comes from the back-substitution)
+      part_gn += gl * vl;
+      part_gmax = fmax(part_gmax, fabs(gl));
+    }
+    part_gn = wave_sum(part_gn); part_gmax = wave_max(part_gmax); part_q = wave_sum(part_q);
+    if (lane == 0) { red[QR_GN + wave] = part_gn; red[QR_GMAX + wave] = part_gmax; red[QR_Q + wave] = part_q; }
+    E_BARRIER_GLOBAL();
+    double s_gn = 0.0, s_q = 0.0, s_gmax = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { s_gn += red[QR_GN + w8]; s_q += red[QR_Q + w8]; s_gmax = fmax(s_gmax, red[QR_GMAX + w8]); }
+    const double gnorm2 = bimg[BI_SCAL + 1] + s_gn;
+    const double gmax = fmax(bimg[BI_SCAL + 2], s_gmax);
+    const double q_lm = s_q;
+    if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
+      if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
+      return;
+    }
+
+    ESTAMP(4, 0);   // prologue: scaling of the landmarks
+    bool solved = false, retry = false;
+    double qq = 0.0, gnnorm2 = 0.0, gy = 0.0;
+    while (!solved) {
+      if (retry) {
+        for (int l = tid; l < L; l += 512) lm_einv[l] = 1.0 / (lm_E[l] + mu * lm_dh2[l]);
+        E_BARRIER_GLOBAL();
+      }
+      retry = true;
+      // ---- the roles of the factorisation (see the head of the file): every one meets 1 + NSTEP + 2 barriers ----
+      if (wave < 2) { mw8_role_chain(wave, bimg, wl, lm_einv, lm_g, mu, F, L); ESTAMP(0, 8); }
+      else if (wave < 4) mw8_role_T(wave - 2, bimg, wl, lm_einv, lm_g, F, L, kb);
+      else {
+        const double *Cimg = b.Cimg + (size_t)win * CIMG_N;
+        const unsigned char *lms = b.lm_s + wm.lm_off;
+        if (wave == 4) mw8_role_B<EB1_MASK, 0x03>(0, Cimg, lms, F, L);
+        else if (wave == 5) mw8_role_B<EB2_MASK, 0x04>(1, Cimg, lms, F, L);
+        else if (wave == 6) mw8_role_B<EB3_MASK, 0x08>(2, Cimg, lms, F, L);
+        else mw8_role_B<EB4_MASK, 0x10>(3, Cimg, lms, F, L);
+        ESTAMP(4, 2);   // main loop (Schur complement + rank updates) and the tiles' hand-over
+        if (wave == 4) {
+          int f2 = (red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0) ? 1 : 0;
+          if (!f2) f2 = mw8_chol80(mu, F, cmask);
+          if (lane == 0) red[QR_FAIL + 2] = (double)f2;
+          ESTAMP(4, 4);   // Cholesky, forward and backward solve
+        }
+        E_BARRIER();   // y_P (or the failure flags)
+      }
+      // (wave-uniform flags from LDS: chain down / up, pose system)
+      if (red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0 || red[QR_FAIL + 2] != 0.0) {
+        // DoglegStrategy::ComputeGaussNewtonStep: mu *= 10 and retry while mu < max_mu (1.0)
+        mu *= 10.0;
+        if (tid == 0) { st.mu = mu; st.pad[0]++; }   // (pad[0]: factorisation retries of this solve, read by the tests)
+        if (!(mu < 1.0)) {
+          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.gnorm2 = gnorm2; st.q = 0.0; st.gmax = gmax; st.scale_ready = 1; }
+          return;
+        }
+        E_BARRIER();   // (every lane has read the flags before the next trip rewrites them)
+        continue;
+      }
+
+      // ---- back-substitution: C1 / C2 the speed / leg-bias part (twisted sweeps), B1 .. B4 the landmarks; TD / TU keep the barriers company ----
+      if (wave < 2) mw8_role_sweeps(wave, wave, bimg, F, L, kb, cmask);
+      else if (wave < 4) {
+        if (lane == 0) { red[QR_GNN + wave] = 0.0; red[QR_GY + wave] = 0.0; red[QR_QX + wave] = 0.0; }
+        E_BARRIER();   // (the chain waves' hand-over points)
+        E_BARRIER();
+      } else mw8_role_lm(wave - 4, wave, wl, lm_g, lm_einv, lm_dh2, lm_y, L);
+      ESTAMP(4, 5); ESTAMP(0, 9);   // back-substitutions
+      E_BARRIER_GLOBAL();   // (lm_y is read by every wave for the candidate)
+      double s_gnn = 0.0, s_gy = 0.0, s_qx = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { s_gnn += red[QR_GNN + w8]; s_gy += red[QR_GY + w8]; s_qx += red[QR_QX + w8]; }
+      gnnorm2 = s_gnn;
+      gy = s_gy;
+      qq = bimg[BI_SCAL + 0] + (q_lm + 2.0 * s_qx);
+      if (!(isfinite(gnnorm2) && isfinite(gy))) {   // IsArrayValid(gauss_newton_step_) failed
+        mu *= 10.0;
+        if (tid == 0) { st.mu = mu; st.pad[0]++; }
+        if (!(mu < 1.0)) {
+          if (tid == 0) { st.lin_fail = 1; st.step_valid = 0; st.scale_ready = 1; }
+          return;
+        }
+        E_BARRIER();
+        continue;
+      }
+      solved = true;
+    }
+    // keep the linearisation's vectors for the steps that reuse it after a rejected candidate
+    double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
+    if (wave == 4) {
+      for (int cd = lane; cd < 80; cd += 64) { cam_g[cd] = g[cd]; cam_dh2[cd] = dh2[cd]; cam_y[cd] = y[cd]; }
+    } else if (wave == 0) {
+      for (int e = lane; e < 144; e += 64) { cam_g[CD_B0 + e] = GB[e]; cam_dh2[CD_B0 + e] = DB[e]; cam_y[CD_B0 + e] = (e < 13 * F) ? YB[e] : 0.0; }
+    }
+    if (tid == 0) {
+      st.gnorm2 = gnorm2; st.gnnorm2 = gnnorm2; st.gdotgn = -gy; st.q = qq; st.gmax = gmax;
+      st.alpha = gnorm2 / qq;
+      st.scale_ready = 1;
+      st.lin_fail = 0;
+      // (the dogleg below works on a register copy of these: no round trip through what was just stored)
+      fresh.gnorm2 = gnorm2; fresh.gnnorm2 = gnnorm2; fresh.gdotgn = -gy; fresh.q = qq; fresh.alpha = gnorm2 / qq; fresh.mu = mu;
+      have_fresh = true;
+    }
+  } else {
+    const double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
+    if (wave == 4) {
+      for (int cd = lane; cd < 80; cd += 64) { g[cd] = cam_g[cd]; dh2[cd] = cam_dh2[cd]; y[cd] = cam_y[cd]; }
+    } else if (wave == 0) {
+      for (int e = lane; e < 144; e += 64) { GB[e] = cam_g[CD_B0 + min(e, 143)]; DB[e] = cam_dh2[CD_B0 + min(e, 143)]; YB[e] = cam_y[CD_B0 + min(e, 143)]; }
+    }
+  }
+
+  ESTAMP(4, 6);   // norms, vectors kept
+  // ---- dogleg step for the current radius, candidate camera state ----
+  if (tid == 0) {
+    double ca = 0.0, cb = 0.0;
+    int go = 0;
+    const double radius = radius0;   // (read when the kernel started)
+    if (radius <= sp.min_radius) { st.done = 1; st.termination = 1; st.step_valid = 0; }
+    else if (have_fresh) {
+      fresh.radius = radius;
+      dogleg_scalars(fresh);
+      st.coef_a = fresh.coef_a; st.coef_b = fresh.coef_b; st.dogleg_step_norm = fresh.dogleg_step_norm; st.model_cost_change = fresh.model_cost_change;
+      st.step_valid = fresh.step_valid;
+      ca = fresh.coef_a; cb = fresh.coef_b; go = fresh.step_valid;
+    }
+    else { dogleg_scalars(st); ca = st.coef_a; cb = st.coef_b; go = st.step_valid; }
+    red[QR_CA] = ca; red[QR_CB] = cb; red[QR_GO] = (double)go;
+  }
+  E_BARRIER();
+  const double ca = red[QR_CA], cb = red[QR_CB];
+  const int go = (red[QR_GO] != 0.0) ? 1 : 0;
+  const double *x = b.x + (size_t)win * XSTRIDE;
+  double *xc = b.xc + (size_t)win * XSTRIDE;
+  {
+    const double *lam = b.lam + wm.lm_off, *lmg = b.lm_gbuf[st.cur] + wm.lm_off, *lmd = b.lm_dh2 + wm.lm_off, *lmy = b.lm_y + wm.lm_off;
+    double *lamc = b.lamc + wm.lm_off;
+    for (int l = tid; l < L; l += 512) lamc[l] = go ? lam[l] - ca * lmg[l] / lmd[l] - cb * lmy[l] : lam[l];
+  }
+  if (!go) {
+    for (int e = tid; e < XSTRIDE; e += 512) xc[e] = x[e];
+    return;
+  }
+  double *del = lds + E_DEL;
+  if (wave == 4) {
+    for (int cd = lane; cd < 80; cd += 64) del[cd] = -ca * g[cd] / dh2[cd] - cb * y[cd];
+  } else if (wave == 0) {
+    for (int e = lane; e < 143; e += 64) del[CD_B0 + e] = -ca * GB[e] / DB[e] - cb * YB[e];
+  }
+  E_BARRIER();
+  if (wave == 4) {
+    if (lane < 11) pose_plus(x + XO_POSE + 7 * lane, del + 6 * lane, xc + XO_POSE + 7 * lane);
+    else if (lane < 13) pose_plus(x + XO_EX + 7 * (lane - 11), del + CD_EX0 + 6 * (lane - 11), xc + XO_EX + 7 * (lane - 11));
+    else if (lane == 13) xc[XO_TD] = x[XO_TD] + del[CD_TD];
+  } else if (wave == 0) {
+    for (int e = lane; e < 143; e += 64) {
+      const int k = e / 13, c = e - 13 * k;
+      if (c < 9) xc[XO_SB + 9 * k + c] = x[XO_SB + 9 * k + c] + del[CD_B0 + e];
+      else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
+    }
+  }
+  ESTAMP(4, 7);   // dogleg + candidate
+  PCLK(if (tid == 0) { for (int r_ = 0; r_ < 8; ++r_) st.phase_clk[16 + r_] = (long long)red[QR_WAIT + r_]; });
+}
+
+int vilo_launch_mw8_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s) {
+  const size_t lds_bytes = (size_t)E_TOTAL * sizeof(double);
+  if (!ctx->mw8_attr_set) {   // (per context = per device, like the other dynamic-LDS opt-ins)
+    VILO_HIP(hipFuncSetAttribute((const void *)k_solve_mw8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ctx->mw8_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_solve_mw8, dim3(b.W), dim3(512), lds_bytes, s, b, sp);
+  return VILO_OK;
+}

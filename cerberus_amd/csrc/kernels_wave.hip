@@ -1317,18 +1317,18 @@ __global__ void __launch_bounds__(64) k_solve_mid(BatchDev b, SolveParams sp) {
 // =================================================================================================
 int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);    // kernels_mw.hip
 int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves);   // kernels_asm_small.hip
-int vilo_launch_mw4_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw4.hip
+int vilo_launch_mw8_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw8.hip
 // Which solver (0 single wave, 2 two waves, 4 four waves per window, 3 the single wave in three stages): as many waves per window as the
 // batch leaves SIMDs for — four up to one window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond; in
 // three stages once the batch fills the two-waves-per-SIMD stages too. vilo_set_solver_form pins a form
 // (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b) {
   const int forced = ctx->solver_form;   // (vilo_set_solver_form; VILO_SOLVER gives the default at vilo_create)
-  static const int max_w4 = [] { const char *e = getenv("VILO_MW4_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
+  static const int max_w8 = [] { const char *e = getenv("VILO_MW8_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
   static const int max_w2 = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
   static const int min_w3 = [] { const char *e = getenv("VILO_SPLIT_MIN_WINDOWS"); return e ? atoi(e) : 1025; }();
   if (forced >= 0) return forced;
-  return b.W <= max_w4 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
+  return b.W <= max_w8 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
 }
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap, int reduce_waves) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
@@ -1342,7 +1342,7 @@ int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, h
     if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W + reduce_waves), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
     else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
   } else if (vilo_solver_form(ctx, b) == 4) {
-    return vilo_launch_mw4_solver(ctx, b, sp, s);
+    return vilo_launch_mw8_solver(ctx, b, sp, s);
   } else if (vilo_solver_form(ctx, b) == 2) {
     return vilo_launch_mw_solver(ctx, b, sp, s);
   } else {

@@ -41,7 +41,7 @@ struct vilo_ctx {
   long long kernel_launches[VILO_NKERNEL];
   double initial_mu = 1e-8;         // DoglegStrategy's mu at the start of a solve (Ceres: min_mu; vilo_debug_set_initial_mu: per-step comparisons with the oracle)
   int sqrt_info_mode = 0;           // 0: Cholesky of the index-reversed covariance + triangular inverse; 1: the reference's inverse() + LLT, literally
-  bool wave_attr_set = false, mid_attr_set = false, mw4_attr_set = false, asm_s_attr_set = false, marg_attr_set = false, prior_attr_set = false;   // dynamic-LDS opt-ins done on this context's device
+  bool wave_attr_set = false, mid_attr_set = false, mw8_attr_set = false, asm_s_attr_set = false, marg_attr_set = false, prior_attr_set = false;   // dynamic-LDS opt-ins done on this context's device
   // solver form of the batches this context solves (vilo_set_solver_form; -1: chosen from the batch size) and whether batches created on it
   // may use the compact 16-column visual rows (vilo_set_compact_rows). VILO_SOLVER / VILO_NO_COMPACT give the defaults at vilo_create.
   int solver_form = -1;

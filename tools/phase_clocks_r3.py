@@ -31,10 +31,10 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     if m[46] > 0:
         print("k_assemble_s: trust-region bookkeeping (accept_body) before the assembly: %d cycles" % m[46])
     if W <= 256 and m[16] > 0:
-        print("k_solve_mw4 wave B1 (cycles from kernel start): scaling %d | Schur + rank updates %d (barrier %d) | Cholesky %d | backward solve %d | landmark back-substitution + hand-over barriers %d | norms %d | dogleg + candidate %d;  A1: chain %d, sweeps %d"
+        print("k_solve_mw8 wave B1 (cycles from kernel start): scaling %d | main loop, own work %d, with the tiles' hand-over %d | (unused) %d | Cholesky + solves %d | back-substitutions %d | norms %d | dogleg + candidate %d;  C1: chain role %d, sweeps %d"
               % (m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9]))
     if W <= 256 and m[16] > 0:   # four-wave solver: total and barrier-wait cycles of its waves
-        print("k_solve_mw4: wave A1 %d cycles (%d at barriers) | A2 %d (%d) | B1 %d (%d) | B2 %d (%d)" % (m[16], m[20], m[17], m[21], m[18], m[22], m[19], m[23]))
+        print("k_solve_mw8, cycles at the main loop's step barriers: C1 %d C2 %d | TD %d TU %d | B1 %d B2 %d B3 %d B4 %d" % tuple(m[16:24]))
     elif W <= 512:
         print("k_solve_mw wave B: scaling %d | 1/(E + mu d) %d | Schur + rank updates (steps) %d | rhs + Cholesky %d | backward solve %d | wait for barrier %d | landmark back-substitution %d | norms + barrier %d | dogleg + candidate %d | total %d"
               % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[9] - m[0]))

@@ -1,5 +1,5 @@
 """Copy the summaries of tools/profile_gpu.sh / tools/profile_sq.sh (run on the GPU box, merged back under gpurun_out/) into
-profiles/round3_* — the files bench.py's roofline block and DESIGN.md cite.
+profiles/<round>_* (bench.PROFILE_ROUND) — the files bench.py's roofline block and DESIGN.md cite.
 Usage: python tools/refresh_profiles.py <prof_tag> <sq_tag> [bench.json] [bench_config3.json]
        python tools/refresh_profiles.py --config3 <prof_tag>     (PROFILE_ARGS="--config 3 --windows 1024" bash tools/profile_gpu.sh <prof_tag>)"""
 import json
@@ -29,7 +29,7 @@ def trace_and_pmc(tag, suffix, windows, what):
     js["kernels_sha16"] = kernels_sha16()
     js["commit"] = _commit()
     js["note"] = ("rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (bench.py --steps 2 --warmup 1 %s), "
-                  "calibrated on k_calib_copy; round 3" % what)
+                  "calibrated on k_calib_copy; %s" % (what, RND))
     open(os.path.join(R, "profiles", "%s_rocprof_summary%s.txt" % (RND, suffix)), "w").write("\n".join(lines[:-1]) + "\n")
     json.dump(js, open(os.path.join(R, "profiles", "%s_pmc%s.json" % (RND, suffix)), "w"))
     return js
@@ -47,7 +47,7 @@ lines = open(os.path.join(R, "gpurun_out", "prof_" + sq, "summary.txt")).read().
 res = json.loads(lines[-1])
 open(os.path.join(R, "profiles", RND + "_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
 json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py --steps 1 --warmup 1 --windows 4096): per-dispatch means summed over the "
-                   "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; round 3", "kernels_sha16": kernels_sha16(), "commit": _commit(),
+                   "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; " + RND, "kernels_sha16": kernels_sha16(), "commit": _commit(),
            "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", RND + "_mfma.json"), "w"))
 if len(sys.argv) > 3:
     shutil.copy(sys.argv[3], os.path.join(R, "profiles", RND + "_bench_final.json"))
