@@ -16,8 +16,14 @@
 //                     middle (TD): V_m loses both neighbours' terms
 //                   T(k) goes to the matrix waves through a double-buffered LDS image in operand order.
 //   waves B1 .. B4  the 80 x 80 pose system split by tiles (4 + 4 + 4 + 3 of the 15 lower 16 x 16 tiles): each runs the landmark Schur
-//                   complement and the rank updates C -= T(k)^T T(k) on its own tiles, two steps behind the chain; the tiles then move to
-//                   B1, which runs the blocked Cholesky and the backward solve; all four share the landmark back-substitution.
+//                   complement and the rank updates C -= T(k)^T T(k) on its own tiles, two steps behind the chain (operands from LDS slices
+//                   that the chain and T waves fetch one iteration ahead); all four share the landmark back-substitution.
+//   all eight       the Cholesky of the 80 x 80 pose system (mw8_chol80): one wave carries the critical path — diagonal tile, its next
+//                   block row, the next diagonal tile's update — the others the rest of the panel and the trailing tiles beside it.
+// Every role is a __noinline__ function: the register allocator then sees one role at a time (as one kernel the roles spilled 46 .. 533
+// registers inside their loops). Three things a role that is not a kernel needs, each measured: its pointer arguments typed as global
+// memory (uni_g), the dynamic LDS base pinned in a register (e_lds_base), tables read at uniform addresses through a vector base
+// (lds_in_vgpr) — see there.
 // The chain step (13 x 13 factorisation + substitutions) sets the pace of the main loop; in the four-wave form a chain wave also formed
 // T(k) (twice the cycles per frame) and two matrix waves shared the 15 tiles.
 // A different elimination order of the speed / leg-bias part and different partial sums than the single-wave forms: results agree with
@@ -56,8 +62,27 @@
 #define ES_G (ES_EI + ES_NL)       // [32] landmark gradients
 #define ES_N (ES_G + ES_NL + 8)    // 2712
 #define E_TOTAL (E_WS + 2 * ES_N)
-static_assert(15 * 256 <= 2 * 2560, "the tiles fit the hand-over buffers");
+static_assert(3920 <= 2 * 2560, "the pose system (pm_at) fits the hand-over buffers");
 extern __shared__ __attribute__((aligned(16))) double e_lds[];   // the workgroup's dynamic LDS (k_solve_mw8 and its roles)
+// Its address, once per role. In a function that is not a kernel the address of dynamic LDS is a scalar load from a per-kernel table, and
+// the compiler repeats that load wherever it needs the address rather than keep a register: every such load is an `s_waitcnt lgkmcnt(0)`
+// in the middle of the LDS operand stream (scalar loads return out of order, so the counter cannot be waited on partially) — the matrix
+// waves waited for the next half trip's operands before every half trip. The empty asm makes the value opaque, so it stays in its SGPR.
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ double *e_lds_base() {
+  unsigned off = (unsigned)(unsigned long long)(lds_double *)e_lds;
+  off = __builtin_amdgcn_readfirstlane(off);
+  asm volatile("" : "+s"(off));
+  return (double *)(lds_double *)(unsigned long long)off;
+}
+// The same LDS pointer held in a vector register (opaque to the compiler): for tables read at many compile-time offsets with the same
+// address in every lane. From a scalar base the compiler forms every address on the scalar unit (one SGPR each, hoisted out of the loops,
+// then spilled to VGPR lanes: v_readlane + v_mov in front of every read); from a vector base they are immediate offsets of one register.
+__device__ __forceinline__ double *lds_in_vgpr(double *p) {
+  unsigned off = (unsigned)(unsigned long long)(lds_double *)p;
+  asm volatile("" : "+v"(off));
+  return (double *)(lds_double *)(unsigned long long)off;
+}
 
 // Every role below is a function of its own (__noinline__): the kernel's eight waves share one register allocation of 256 per lane, and
 // with the roles inlined into one body the allocator spilled all over it (each role's live ranges crowd the others'; measured: 100 - 500
@@ -65,6 +90,12 @@ extern __shared__ __attribute__((aligned(16))) double e_lds[];   // the workgrou
 // and linearisation. The roles find the workgroup's LDS through the dynamic-LDS symbol; their inputs come as (wave-uniform) arguments.
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ double uni(double x) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x))); }
+// a role's pointer arguments, wave-uniform and typed as what they are — global memory. (Through a generic pointer a role that is not a
+// kernel loads with flat instructions; those count on both memory counters and return out of order, so while one may be in flight the
+// compiler waits for lgkmcnt(0) before anything that depends on LDS: no LDS prefetch survives.)
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ T *uni(T *p);
+template <class T> __device__ __forceinline__ GLOBAL_AS T *uni_g(T *p) { return (GLOBAL_AS T *)uni(p); }
 template <class T> __device__ __forceinline__ T *uni(T *p) {
   const unsigned long long a = (unsigned long long)p;
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
@@ -90,7 +121,8 @@ __device__ __forceinline__ int e_slice_h0(const E_Geom &G, int i) { return (i * 
 #define ES_NLD 11   // loads per lane of a loader wave (4 x 64 x 11 >= 80 x 32 + 64)
 struct E_Slice {
   double r[ES_NLD];
-  __device__ __forceinline__ void load(const E_Geom &G, int i, int t256, const double *wl, const double *lm_einv, const double *lm_g, int L) {
+  template <class P>
+  __device__ __forceinline__ void load(const E_Geom &G, int i, int t256, P wl, P lm_einv, P lm_g, int L) {
     const int l0 = 8 * e_slice_h0(G, i);
 #pragma unroll
     for (int u = 0; u < ES_NLD; ++u) {
@@ -102,8 +134,8 @@ struct E_Slice {
       r[u] = val;
     }
   }
-  __device__ __forceinline__ void store(int i, int t256) const {
-    double *Ws = e_lds + E_WS + ES_N * (i & 1);
+  __device__ __forceinline__ void store(double *lds, int i, int t256) const {
+    double *Ws = lds + E_WS + ES_N * (i & 1);
 #pragma unroll
     for (int u = 0; u < ES_NLD; ++u) {
       const int e = t256 + 256 * u;
@@ -165,142 +197,240 @@ constexpr int e_blocks_of(int mask, int rhs) {   // operand blocks a matrix wave
   return m;
 }
 
-// The 80 x 80 pose system's Cholesky, forward and backward solve on ONE wave (B1), with all 15 accumulator tiles in registers. In: the tiles in E_TILES (accumulator order), dh2, the reduced right-hand side v. Out: y (E_Y), masked
-// to the active dimensions. Blocked by 16: diagonal tile in registers + v_readlane, panel and trailing update on the matrix cores, the
-// right-hand side riding along as a sixth block row; backward solve with the factor's accumulator registers as operands: as in
-// k_solve_wave / k_solve_mw. Returns 1 if a pivot failed.
-__device__ __noinline__ int mw8_chol80(double mu, int F, int cmask) {
-  double *const lds = e_lds;
+// The pose system in LDS while it is factored (over the T hand-over buffers): the lower block triangle, row-major — row i of block row
+// I = i / 16 holds the columns 0 .. 16 I + 15 with the odd stride 16 (I + 1) + 1, so a lane that owns a row, a lane that owns a column and a
+// matrix-instruction operand read (16 rows x 4 columns) all reach distinct banks. 3920 doubles.
+__device__ __forceinline__ int pm_at(int i, int c) {
+  const int I = i >> 4;
+  return E_TILES + 128 * I * (I + 1) + 16 * I + (i & 15) * (16 * (I + 1) + 1) + c;
+}
+#define E_RINV E_CHOL            // [80] 1 / L_cc
+#define E_LD16 (E_CHOL + 80)     // [16][17] the diagonal tile's factor L_jj of the block column at hand (fixed place: compile-time addresses)
+#define E_RV16 (E_CHOL + 352)    // [16] its 1 / L_cc
+
+// The 80 x 80 pose system's Cholesky, forward and backward solve by all eight waves. In: the matrix (pm_at) without its mu D^2, dh2, the
+// reduced right-hand side v. Out: y (E_Y), masked to the active dimensions. Returns 1 (on the factor wave, cw 0) if a pivot failed.
+//
+// Right-looking by block columns of 16. The critical path is one wave's (cw 0): factor the diagonal tile (a lane per row, v_readlane
+// broadcasts: ~5 k cycles), solve the next block row against it (a lane per row again: x L_jj^T = a with L's entries as broadcast LDS
+// reads, no inverse is ever formed), take that block's update of the next diagonal tile on the matrix cores, factor again. The right-hand
+// side rides in lane 16 of the same solve. Everything else happens beside it: cw 1 solves the other block rows of the panel (up to 48 rows
+// at once), cw 2 .. 7 apply the panel to the trailing tiles (4 matrix instructions each) while cw 0 is already factoring the next
+// diagonal tile. Two workgroup barriers per block column: L_jj is there / the panel is there. The backward solve L^T x = y is 80 steps
+// of a column sweep on cw 0 (a lane per unknown, the row of L a coalesced LDS read issued ahead).
+// The one-wave version this replaces (factor + inverse of each diagonal tile, panels, trailing updates and both solves on B1 with the
+// other seven waves waiting) took 69 k of the solve's 198 k cycles.
+__device__ __noinline__ int mw8_chol80(int cw_, double mu, int F, int cmask) {
+  double *const lds = e_lds_base();
+  const int cw = uni(cw_);
   mu = uni(mu); F = uni(F); cmask = uni(cmask);
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  double *dh2 = lds + E_DH2, *y = lds + E_Y, *v = lds + E_V;
-  mfma_d4 acc[15];
+  double *dh2 = lds + E_DH2, *y = lds + E_Y, *v = lds + E_V, *rinvs = lds + E_RINV;
+  double *const LD16 = lds_in_vgpr(lds + E_LD16), *const RV16 = LD16 + (E_RV16 - E_LD16);
   int fail = 0;
-  const double *Gt = lds + E_TILES;
+  const long long cclk0 = pclk64();
+#define CSTAMP(n_) PCLK(if (cw == 0 && lane == 0) lds[E_RED + 76 + (n_)] = (double)(clock64() - cclk0))
+  // x L_jj^T = a for the rows the lanes hold (x: a on entry), column by column: x_q = x_q / L_qq, then x_c -= x_q L_cq for c > q. L's
+  // entries are broadcast LDS reads (the same address in every lane); the reads of a column are issued two columns ahead of its use and
+  // pinned there — left to itself the compiler keeps two reads in flight and the solve waits ~70 times for an LDS round trip (9.5 k
+  // cycles for what is 136 multiply-adds per lane).
+  auto row_solve = [&](double (&x)[16]) {
+    double Lq[16][16], rv[16];
+    auto ldcol = [&](int q) {
+      rv[q] = RV16[q];
 #pragma unroll
-  for (int t = 0; t < 15; ++t)
+      for (int c = q + 1; c < 16; ++c) Lq[q][c] = LD16[c * 17 + q];
+    };
+    ldcol(0); ldcol(1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = Gt[(t * 4 + r) * 64 + lane];
+    for (int q = 0; q < 16; ++q) {
+      if (q + 2 < 16) ldcol(q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      x[q] *= rv[q];
 #pragma unroll
-  for (int I = 0; I < 5; ++I)
+      for (int c = q + 1; c < 16; ++c) x[c] -= x[q] * Lq[q][c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // tile (I, J) -= P_I P_J^T, P the panel of block column j
+  auto trailing = [&](int I, int J, int j) {
+    mfma_d4 acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (lk + 4 * r == lr) acc[tile_index(I, I)][r] += mu * dh2[16 * I + lr];
-  double *scr = lds + E_CHOL;
-  double *D16 = scr + MX_D16, *LI16 = scr + MX_LI16, *P16 = scr + MX_P16;
-  double vrow[5];
+    for (int r = 0; r < 4; ++r) acc[r] = lds[pm_at(16 * I + lk + 4 * r, 16 * J + lr)];
 #pragma unroll
-  for (int J = 0; J < 5; ++J) vrow[J] = (lk == 0) ? v[16 * J + lr] : 0.0;
+    for (int kk = 0; kk < 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds[pm_at(16 * I + lr, 16 * j + 4 * kk + lk)], lds[pm_at(16 * J + lr, 16 * j + 4 * kk + lk)], acc, 0, 0, 0);
 #pragma unroll
+    for (int r = 0; r < 4; ++r) lds[pm_at(16 * I + lk + 4 * r, 16 * J + lr)] = acc[r];
+  };
+#pragma unroll 1
   for (int j = 0; j < 5; ++j) {
+    if (cw == 0) {
+      // the diagonal tile, a lane per row (the four lane groups do the same work), + mu D^2
+      double a[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) D16[(lk + 4 * r) * 17 + lr] = acc[tile_index(j, j)][r];
+      for (int c = 0; c < 16; ++c) a[c] = lds[pm_at(16 * j + lr, 16 * j + c)];
+      {
+        const double md = mu * dh2[16 * j + lr];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] += (c == lr) ? md : 0.0;
+      }
+      double myrinv = 1.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        double piv = readlane_d(a[q], q);
+        if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+        const double rinv = rsqrt(piv);
+        const double lq = (lr == q) ? piv * rinv : (lr > q ? a[q] * rinv : 0.0);
+        a[q] = lq;
+        if (lr == q) myrinv = rinv;
+#pragma unroll
+        for (int q2 = q + 1; q2 < 16; ++q2) a[q2] -= lq * readlane_d(lq, q2);
+      }
+      if (lk == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { lds[pm_at(16 * j + lr, 16 * j + c)] = a[c]; LD16[lr * 17 + c] = a[c]; }   // (zeros above the diagonal)
+        rinvs[16 * j + lr] = myrinv; RV16[lr] = myrinv;
+      }
+    }
+    CSTAMP(2 * j);
+    E_BARRIER();   // L_jj
+    double x[16];
+    const int i1 = 16 * (j + 2) + lane;   // cw 1's row
+    const bool isr1 = cw == 1 && lane < 16 * (3 - j);
+    if (cw == 0) {
+      if (j < 4) {
+        // block row j + 1 (every lane group solves the same 16 rows: the matrix instructions below take their operands from registers)
+        const int ib = 16 * (j + 1) + lr;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = lds[pm_at(ib, 16 * j + c)];
+        mfma_d4 acc;   // the next diagonal tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = lds[pm_at(16 * (j + 1) + lk + 4 * r, 16 * (j + 1) + lr)];
+        row_solve(x);
+        if (lk == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) lds[pm_at(ib, 16 * j + c)] = x[c];
+        }
+        // D_{j+1} -= P P^T ahead of everything else: lane (lr, lk) supplies P[lr][4 kk + lk] as both operands
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double p = lk == 0 ? x[4 * kk] : (lk == 1 ? x[4 * kk + 1] : (lk == 2 ? x[4 * kk + 2] : x[4 * kk + 3]));
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-p, p, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[pm_at(16 * (j + 1) + lk + 4 * r, 16 * (j + 1) + lr)] = acc[r];
+      }
+    } else if (cw == 1) {
+      // the other block rows of the panel (up to 48 rows), the right-hand side in lane 63
+      const bool isv = lane == 63;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {   // (both reads unconditional: every address exists)
+        const double tr = lds[pm_at(min(i1, 79), 16 * j + c)], tv = v[16 * j + c];
+        x[c] = isr1 ? tr : (isv ? tv : 0.0);
+      }
+      row_solve(x);
+      if (isr1) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lds[pm_at(i1, 16 * j + c)] = x[c];
+      }
+      if (lane == 63) {   // y_j (the backward solve reads it after the last of these barriers)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) y[16 * j + c] = x[c];
+      }
+    }
+    CSTAMP(2 * j + 1);
+    E_BARRIER();   // the panel, y_j
+    if (cw == 1) {
+      // the right-hand side of the rows below loses P y_j (after the barrier: the factor wave is not kept waiting for it)
+      double yj[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) yj[c] = readlane_d(x[c], 63);
+      if (j < 4) {
+        double s = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s += x[c] * yj[c]; s1 += lds[pm_at(16 * (j + 1) + lr, 16 * j + c)] * yj[c]; }   // (block row j + 1's panel rows are cw 0's)
+        if (isr1) v[i1] -= s;
+        if (lane < 16) v[16 * (j + 1) + lr] -= s1;
+      }
+    }
+    if (cw >= 2) {
+      int n = 0;
+#pragma unroll 1
+      for (int I = j + 1; I < 5; ++I)
+#pragma unroll 1
+        for (int J = j + 1; J <= I; ++J) {
+          if (I == j + 1 && J == j + 1) continue;   // (cw 0's)
+          if (cw - 2 == n % 6) trailing(I, J, j);
+          ++n;
+        }
+    }
+  }
+  // L^T x = y on cw 0: from the last unknown up, a lane per unknown (lane c & 63; z0: 0 .. 63, z1: 64 .. 79). Step c: x_c = y_c / L_cc, then
+  // y_q -= L_cq x_c for q < c. The lanes carry z_q = y_q / L_qq instead of y_q (the row of L is scaled by 1 / L_qq when it arrives, off the
+  // dependent chain), so a step is v_readlane -> multiply-add; x_c goes to its lane of xs by v_writelane, and the lanes at and beyond c,
+  // which are never read again, may take whatever the row's read brings (no masks). Rows are read four steps ahead.
+  if (cw == 0) {
     lds_fence();
-    fail |= chol16_tile(D16, LI16);
-    double li[4];
+    const double r0 = rinvs[lane], r1 = (lane < 16) ? rinvs[64 + lane] : 0.0;
+    double z0 = y[lane] * r0, z1 = (lane < 16) ? y[64 + lane] * r1 : 0.0;
+    int xs0h = 0, xs0l = 0, xs1h = 0, xs1l = 0;
+    const double *rowp = lds + lane;
+    double l0v[80], l1v[80];
+    auto ldrow = [&](int c) {
+      if (c > 0) l0v[c] = rowp[pm_at(c, 0)];
+      if (c > 64) l1v[c] = rowp[pm_at(c, 64)];   // (lanes 0 .. c - 65; the others read on into LDS that exists)
+    };
+    ldrow(79); ldrow(78); ldrow(77); ldrow(76);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) li[kk] = LI16[lr * 17 + 4 * kk + lk];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[tile_index(j, j)][r] = LI16[(lk + 4 * r) * 17 + lr];   // L_jj^-1 in accumulator order
-#pragma unroll
-    for (int I = j + 1; I < 5; ++I) {
-      const int t = tile_index(I, j);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P16[(lk + 4 * r) * 17 + lr] = acc[t][r];
-      lds_fence();
-      mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
-      acc[t] = nacc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[pswz_at(E_CHOL + MX_PANEL, I - j - 1, lk + 4 * r, lr)] = nacc[r];
-      lds_fence();   // (P16 is reused by the next panel)
+    for (int c = 79; c >= 0; --c) {
+      if (c >= 4) ldrow(c - 4);
+      __builtin_amdgcn_sched_barrier(0);
+      const double zsrc = (c >= 64) ? z1 : z0;
+      const int xl = __builtin_amdgcn_readlane(__double2loint(zsrc), c & 63), xh = __builtin_amdgcn_readlane(__double2hiint(zsrc), c & 63);
+      const double xc = __hiloint2double(xh, xl);
+      if (c >= 64) { asm("v_writelane_b32 %0, %1, %2" : "+v"(xs1l) : "s"(xl), "i"(c & 63)); asm("v_writelane_b32 %0, %1, %2" : "+v"(xs1h) : "s"(xh), "i"(c & 63)); }
+      else { asm("v_writelane_b32 %0, %1, %2" : "+v"(xs0l) : "s"(xl), "i"(c & 63)); asm("v_writelane_b32 %0, %1, %2" : "+v"(xs0h) : "s"(xh), "i"(c & 63)); }
+      if (c > 64) z1 -= (l1v[c] * r1) * xc;
+      if (c > 0) z0 -= (l0v[c] * r0) * xc;
+      __builtin_amdgcn_sched_barrier(0);
     }
-    double pv[4];
-    {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P16[(lk + 4 * r) * 17 + lr] = (r == 0) ? vrow[j] : 0.0;
-      lds_fence();
-      mfma_d4 nacc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) nacc = __builtin_amdgcn_mfma_f64_16x16x4f64(P16[lr * 17 + 4 * kk + lk], li[kk], nacc, 0, 0, 0);
-      if (lk == 0) y[16 * j + lr] = nacc[0];
-      lds_fence();
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) pv[kk] = (lr == 0) ? y[16 * j + 4 * kk + lk] : 0.0;
-    }
-    double pa[5][4];
-#pragma unroll
-    for (int I = j + 1; I < 5; ++I)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) pa[I][kk] = lds[pswz_at(E_CHOL + MX_PANEL, I - j - 1, lr, 4 * kk + lk)];
-#pragma unroll
-    for (int I = j + 1; I < 5; ++I)
-#pragma unroll
-      for (int J = j + 1; J <= I; ++J)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          acc[tile_index(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[I][kk], pa[J][kk], acc[tile_index(I, J)], 0, 0, 0);
-#pragma unroll
-    for (int J = j + 1; J < 5; ++J) {
-      mfma_d4 tv = {vrow[J], 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) tv = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[kk], pa[J][kk], tv, 0, 0, 0);
-      vrow[J] = tv[0];
-    }
-    lds_fence();   // (the panel slots are rewritten by the next block column)
+    const double y0 = __hiloint2double(xs0h, xs0l), y1 = __hiloint2double(xs1h, xs1l);
+    y[lane] = cd_active(lane, F, cmask) ? y0 : 0.0;
+    if (lane < 16) y[64 + lane] = cd_active(64 + lane, F, cmask) ? y1 : 0.0;
   }
-  if (fail) return 1;
-  // L^T yP = y, blockwise on the matrix cores: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i)
-  mfma_d4 yb[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) yb[j][r] = y[16 * j + lk + 4 * r];
-#pragma unroll
-  for (int j = 4; j >= 0; --j) {
-    mfma_d4 accv = yb[j];
-#pragma unroll
-    for (int i2 = j + 1; i2 < 5; ++i2)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[tile_index(i2, j)][kk], yb[i2][kk], accv, 0, 0, 0);
-    mfma_d4 n = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tile_index(j, j)][kk], accv[kk], n, 0, 0, 0);
-    yb[j] = n;
-  }
-  lds_fence();
-  if (lr == 0) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y[16 * j + lk + 4 * r] = cd_active(16 * j + lk + 4 * r, F, cmask) ? yb[j][r] : 0.0;
-  }
-  return 0;
+  CSTAMP(10);
+  return fail;
 }
 
 // waves C1 / C2: the twisted chain, 13 x 13 part (see the head of the file). The failure flag goes to red[QR_FAIL + (up ? 1 : 0)].
-__device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const double *wl, const double *lm_einv, const double *lm_g, double mu, int F, int L) {
-  double *const lds = e_lds;
+__device__ __noinline__ void mw8_role_chain(int up_, const double *bimg_, const double *wl_, const double *lm_einv_, const double *lm_g_, double mu, int F, int L) {
+  double *const lds = e_lds_base();
   const bool up = uni(up_) != 0;   // C2 walks the frames upwards from 0
-  bimg = uni(bimg); wl = uni(wl); lm_einv = uni(lm_einv); lm_g = uni(lm_g); mu = uni(mu); F = uni(F); L = uni(L);
+  const auto bimg = uni_g(bimg_), wl = uni_g(wl_), lm_einv = uni_g(lm_einv_), lm_g = uni_g(lm_g_);
+  mu = uni(mu); F = uni(F); L = uni(L);
   const E_Geom G = e_geom(F, L);
   const int mid = G.mid, nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   double *red = lds + E_RED, *DB = lds + E_DB;
   int fail = 0;
-  long long ewait = 0;
+  long long ewait = 0, fclk0 = 0;
   const int t256 = (up ? 64 : 0) + lane;   // loader index (C1, C2, TD, TU)
   E_Slice sl;
   sl.load(G, 0, t256, wl, lm_einv, lm_g, L);
-  sl.store(0, t256);
+  sl.store(lds, 0, t256);
   const int grp = lk, c = lr;
   const int row = c < 13 ? c : 0;
   double *scr = lds + (up ? E_CH2 : E_CH1);
   double *LM = scr + MC_LM, *SN = scr + MC_SN, *TAcur = scr + MC_TA0;
   // one frame of a chain. nb: the neighbour this frame hands its Schur update to (-1: none: the middle frame); prevk: the frame
   // eliminated before this one in the same direction (-1: first)
+  PCLK(fclk0 = 0);
   auto frame = [&](int k, int nb, int prevk, bool middle) {
+#define FSTAMP(n_) PCLK(if (!up && prevk >= 0 && !middle && k == F - 2 && lane == 0) red[64 + (n_)] = (double)(clock64() - fclk0))
+    PCLK(fclk0 = clock64());
     double a[13], l[13], rhs[13], adn[4];
     // right-hand sides of the off-diagonal factor: column `row` of A_{k,k-1} (downwards), of A_{k+1,k}^T (upwards)
 #pragma unroll
@@ -329,6 +459,7 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
 #pragma unroll
       for (int j = 0; j < 13; ++j) a[j] += (j == row) ? md : 0.0;
     }
+    FSTAMP(0);
     double myrinv = 1.0;
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
@@ -343,6 +474,7 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
     }
 #pragma unroll
     for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(l[j]));
+    FSTAMP(1);
     double cl[13];
 #pragma unroll
     for (int q2 = 0; q2 < 13; ++q2) {
@@ -353,6 +485,7 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
       asm volatile("" : "+v"(cl[q2]));
       __builtin_amdgcn_sched_barrier(0);
     }
+    FSTAMP(2);
     double *Mk = lds + E_M + 176 * k, *TAk = lds + E_TA + 176 * k;
     if (c < 13 && grp < 2) {
       if (grp == 0) {
@@ -364,6 +497,7 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
       }
     }
     lds_fence();
+    FSTAMP(3);
     // the neighbour's diagonal block loses T_A^T T_A: one 16 x 16 tile on the matrix cores. The frame next to the middle leaves C2's
     // share where C1 finds it (C1's own share goes into its SN with A_mm)
     if (nb >= 0) {
@@ -380,6 +514,8 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
       for (int r = 0; r < 4; ++r)
         if (lr < 13 && lk + 4 * r < 13) dst[(lk + 4 * r) * 13 + lr] = to_mid ? sn[r] : adn[r] - sn[r];
     }
+    FSTAMP(4);
+#undef FSTAMP
   };
   E_BARRIER();   // (the matrix waves' skip table and slice 0: every wave meets the same barriers)
   for (int i = 0; i < NSTEP; ++i) {
@@ -391,19 +527,19 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg, const d
       frame(i, i + 1, i == 0 ? -1 : i - 1, false);
     }
     if (i == nS && lane == 0) red[QR_FAIL + (up ? 1 : 0)] = (double)fail;
-    if (i + 1 < NSTEP) sl.store(i + 1, t256);
+    if (i + 1 < NSTEP) sl.store(lds, i + 1, t256);
     E_STEP_BARRIER();
   }
   PCLK(if (lane == 0) red[QR_WAIT + (up ? 1 : 0)] = (double)ewait);
   E_BARRIER();   // the tiles and the reduced right-hand side
-  E_BARRIER();   // y_P
 }
 
 // waves TD / TU: the chain's coupling rows T(k), one step behind their chain wave (and a quarter of the operand slices: E_Slice).
-__device__ __noinline__ void mw8_role_T(int up_, const double *bimg, const double *wl, const double *lm_einv, const double *lm_g, int F, int L, int kb) {
-  double *const lds = e_lds;
+__device__ __noinline__ void mw8_role_T(int up_, const double *bimg_, const double *wl_, const double *lm_einv_, const double *lm_g_, int F, int L, int kb) {
+  double *const lds = e_lds_base();
   const bool up = uni(up_) != 0;
-  bimg = uni(bimg); wl = uni(wl); lm_einv = uni(lm_einv); lm_g = uni(lm_g); F = uni(F); L = uni(L); kb = uni(kb);
+  const auto bimg = uni_g(bimg_), wl = uni_g(wl_), lm_einv = uni_g(lm_einv_), lm_g = uni_g(lm_g_);
+  F = uni(F); L = uni(L); kb = uni(kb);
   const E_Geom G = e_geom(F, L);
   const int mid = G.mid, nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -412,7 +548,7 @@ __device__ __noinline__ void mw8_role_T(int up_, const double *bimg, const doubl
   long long ewait = 0;
   E_Slice sl;
   sl.load(G, 0, t256, wl, lm_einv, lm_g, L);
-  sl.store(0, t256);
+  sl.store(lds, 0, t256);
   int fX[5], oX[5];
 #pragma unroll
   for (int X = 0; X < 5; ++X) { const int col = 16 * X + lr; fX[X] = col < 66 ? col / 6 : 99; oX[X] = col < 66 ? col - 6 * fX[X] : 0; }
@@ -429,7 +565,7 @@ __device__ __noinline__ void mw8_role_T(int up_, const double *bimg, const doubl
     for (int X = 0; X < 5; ++X) {
       const int df = fX[X] - k + 1;
       const bool on = df >= 0 && df <= 2;
-      const double *src = bimg + BI_BS + (k * 16 + lk) * 18 + 6 * min(max(df, 0), 2) + oX[X];
+      const auto *src = bimg + BI_BS + (k * 16 + lk) * 18 + 6 * min(max(df, 0), 2) + oX[X];
 #pragma unroll
       for (int r = 0; r < 4; ++r) V[X][r] = on ? src[72 * r] : 0.0;
     }
@@ -501,21 +637,22 @@ __device__ __noinline__ void mw8_role_T(int up_, const double *bimg, const doubl
         tframe(cstep, cstep == 0 ? -1 : cstep - 1, false, cstep);
       }
     }
-    if (i + 1 < NSTEP) sl.store(i + 1, t256);
+    if (i + 1 < NSTEP) sl.store(lds, i + 1, t256);
     E_STEP_BARRIER();
   }
   PCLK(if (lane == 0) lds[E_RED + QR_WAIT + 2 + (up ? 1 : 0)] = (double)ewait);
   E_BARRIER();   // the tiles and the reduced right-hand side
-  E_BARRIER();   // y_P
 }
 
 // waves B1 .. B4: the pose system's tiles MASK — landmark Schur complement from the LDS slices, rank updates from the T waves' hand-over
 // buffers, the blocks RHS of the reduced right-hand side; at the end the tiles go to E_TILES for the Cholesky.
 template <int MASK, int RHS>
-__device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg, const unsigned char *lms, int F, int L) {
-  double *const lds = e_lds;
+__device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg_, const unsigned char *lms_, int F, int L) {
+  double *const lds = e_lds_base();
   const int bw = uni(bw_);
-  Cimg = uni(Cimg); lms = uni(lms); F = uni(F); L = uni(L);
+  const auto Cimg = uni_g(Cimg_);
+  const auto lms = uni_g(lms_);
+  F = uni(F); L = uni(L);
   const E_Geom G = e_geom(F, L);
   const int nL = G.nL, nU = G.nU, nS = G.nS, NSTEP = G.NSTEP, NT = G.NT;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -532,49 +669,52 @@ __device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg, const unsig
   double yacc[5], yr[5];
 #pragma unroll
   for (int X = 0; X < 5; ++X) { yacc[X] = 0.0; yr[X] = 0.0; }
-  int *skip_tab = (int *)(lds + E_SKIP);
-  if (bw == 0 && L > 0) {
-    for (int tr = lane; tr < NT + 2; tr += 64) skip_tab[tr] = (6 * (int)lms[min(16 * tr, L - 1)] >= 16) ? 1 : 0;
-  }
-  E_BARRIER();   // (the skip table is B1's, slice 0 the T waves'; every wave meets this barrier)
-  // operands of a half trip (two k-steps of 4 landmarks) from the iteration's slice, the next half's behind this one's matrix instructions;
-  // hl: the half's position inside the slice
+  // trips (16 landmarks) whose landmarks all start at frame 3 or later have no coupling to the first 16 pose columns: bit tr of a wave-uniform
+  // mask (the landmarks are sorted by start frame; trips beyond the mask's 64 are simply not skipped)
+  unsigned long long skipmask = 0;
+  if (L > 0) skipmask = __ballot(lane < NT + 2 && 6 * (int)lms[min(16 * lane, L - 1)] >= 16);
+  auto skip_of = [&](int h) -> bool { const int tr = h >> 1; return tr < 64 && ((skipmask >> tr) & 1); };
+  E_BARRIER();   // (slice 0 is the chain and T waves'; every wave meets this barrier)
+  // operands of a half trip (two k-steps of 4 landmarks) from the iteration's slice, the next half's behind this one's matrix instructions
+  // (hl: the half's position inside the slice; the two buffers and the slice's at most four halves are unrolled: every operand and every
+  // accumulator keeps its registers — with the buffer picked at run time the compiler moved the accumulators after every half trip and
+  // waited for the matrix pipe to drain first: 1650 cycles per half trip of 8 matrix instructions)
   double opb[2][2][5], eb[2][2], gb[2][2];
-  auto ldhalf = [&](int h, int hl, const double *Ws, auto bs) {
+  auto ldhalf = [&](int hl, const double *Ws, auto bs) {
     constexpr int bsel = decltype(bs)::value;
-    const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(h >> 1, NT)]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int lc = 8 * hl + 4 * u + lk;
       eb[bsel][u] = Ws[ES_EI + lc]; gb[bsel][u] = Ws[ES_G + lc];
 #pragma unroll
-      for (int X = 1; X < 5; ++X)
+      for (int X = 0; X < 5; ++X)   // (block 0 of a skipped trip too)
         if ((NEED >> X) & 1) opb[bsel][u][X] = Ws[(16 * X + lr) * ES_LD + lc];
     }
-    if ((NEED & 1) && !skip0) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) opb[bsel][u][0] = Ws[lr * ES_LD + 8 * hl + 4 * u + lk];
-    }
   };
-  auto dohalf = [&](auto bs, auto xl) {
+  auto dohalf = [&](bool sk, auto bs) {
     constexpr int bsel = decltype(bs)::value;
-    constexpr int XL = decltype(xl)::value;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const double ei = eb[bsel][u], ge = gb[bsel][u] * ei;
 #pragma unroll
       for (int t = 0; t < 15; ++t)
-        if (((MASK >> t) & 1) && c_tJ[t] >= XL)
+        if (((MASK >> t) & 1) && c_tJ[t] > 0)
           acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(opb[bsel][u][c_tI[t]] * ei), opb[bsel][u][c_tJ[t]], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int X = XL; X < 5; ++X)
+      for (int X = 1; X < 5; ++X)
         if ((RHS >> X) & 1) yacc[X] += opb[bsel][u][X] * ge;
     }
-  };
-  auto half = [&](int h, auto bs) {
-    const int skip0 = __builtin_amdgcn_readfirstlane(skip_tab[min(h >> 1, NT)]);
-    if (skip0) dohalf(bs, std::integral_constant<int, 1>{});
-    else dohalf(bs, std::integral_constant<int, 0>{});
+    if (!sk) {   // the tiles of the first 16 columns
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const double ei = eb[bsel][u];
+#pragma unroll
+        for (int t = 0; t < 15; ++t)
+          if (((MASK >> t) & 1) && c_tJ[t] == 0)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(opb[bsel][u][c_tI[t]] * ei), opb[bsel][u][0], acc[t], 0, 0, 0);
+        if (RHS & 1) yacc[0] += opb[bsel][u][0] * (gb[bsel][u] * ei);
+      }
+    }
   };
     // C -= T^T T for one delivered frame (all five tile columns: the T waves write zeros where T(k) has none)
     auto rank_update = [&](const double *Tb) {
@@ -596,22 +736,28 @@ __device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg, const unsig
   for (int i = 0; i < NSTEP; ++i) {
     const int h0 = e_slice_h0(G, i), h1 = e_slice_h0(G, i + 1);
     const double *Ws = lds + E_WS + ES_N * (i & 1);
-    if (h0 < h1) ldhalf(h0, 0, Ws, std::integral_constant<int, 0>{});
-    for (int h = h0; h < h1; ++h) {
-      if ((h - h0) & 1) {
-        if (h + 1 < h1) ldhalf(h + 1, h + 1 - h0, Ws, std::integral_constant<int, 0>{});
-        half(h, std::integral_constant<int, 1>{});
-      } else {
-        if (h + 1 < h1) ldhalf(h + 1, h + 1 - h0, Ws, std::integral_constant<int, 1>{});
-        half(h, std::integral_constant<int, 0>{});
-      }
-    }
+    const long long bclk0 = pclk64();
+#define BSTAMP(n_) PCLK(if (bw == 2 && i == 3 && lane == 0) lds[E_RED + 72 + (n_)] = (double)(clock64() - bclk0))
+    const int nh = h1 - h0;   // <= 4 (e_geom)
+    // (the loads are unconditional — a slice always holds four halves, zero beyond the window's landmarks: a load under a branch costs
+    //  the compiler its count of the loads in flight, and every half trip then waits for the next one's operands)
+    ldhalf(0, Ws, std::integral_constant<int, 0>{});
+    auto hstep = [&](auto hlc) {
+      constexpr int hl = decltype(hlc)::value;
+      if constexpr (hl < 3) ldhalf(hl + 1, Ws, std::integral_constant<int, (hl + 1) & 1>{});
+      if (hl < nh) dohalf(skip_of(h0 + hl), std::integral_constant<int, hl & 1>{});
+    };
+    hstep(std::integral_constant<int, 0>{}); hstep(std::integral_constant<int, 1>{});
+    hstep(std::integral_constant<int, 2>{}); hstep(std::integral_constant<int, 3>{});
+    BSTAMP(0);
     if (i >= 2) {
       // what the T waves finished in iteration i - 1 = the chain's step i - 2: TD a frame above the middle or (step nS) the middle, TU a frame below
       const int cstep = i - 2;
       if (cstep < nU || cstep == nS) rank_update(lds + E_T1 + 1280 * (cstep & 1));
       if (cstep < nL) rank_update(lds + E_T2 + 1280 * (cstep & 1));
     }
+    BSTAMP(1);
+#undef BSTAMP
     E_STEP_BARRIER();
   }
   PCLK(if (lane == 0) lds[E_RED + QR_WAIT + 4 + bw] = (double)ewait);
@@ -624,26 +770,24 @@ __device__ __noinline__ void mw8_role_B(int bw_, const double *Cimg, const unsig
         s += __shfl_xor(s, 32, 64);
         if (lk == 0) v[16 * X + lr] = g[16 * X + lr] - s;
       }
-    {
-      // the tiles move to the Cholesky (accumulator order, one coalesced LDS store per register)
-      double *Gt = lds + E_TILES;
+    // the tiles move to the Cholesky's layout (pm_at; accumulator register r of lane (lr, lk) is row lk + 4 r, column lr of the tile)
 #pragma unroll
-      for (int t = 0; t < 15; ++t)
-        if ((MASK >> t) & 1) {
+    for (int t = 0; t < 15; ++t)
+      if ((MASK >> t) & 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Gt[(t * 4 + r) * 64 + lane] = acc[t][r];
-        }
-    }
+        for (int r = 0; r < 4; ++r) lds[pm_at(16 * c_tI[t] + lk + 4 * r, 16 * c_tJ[t] + lr)] = acc[t][r];
+      }
   E_BARRIER();   // every wave's tiles and the reduced right-hand side are there
 }
 
 // C1 / C2 after y_P: back-substitution of the speed / leg-bias part (twisted sweeps). Partial sums of |D y|^2 and g^T y of the wave's frames
 // go to red[QR_GNN / QR_GY + wave].
-__device__ __noinline__ void mw8_role_sweeps(int up_, int wave_, const double *bimg, int F, int L, int kb, int cmask) {
-  double *const lds = e_lds;
+__device__ __noinline__ void mw8_role_sweeps(int up_, int wave_, const double *bimg_, int F, int L, int kb, int cmask) {
+  double *const lds = e_lds_base();
   const bool up = uni(up_) != 0;
   const int wave = uni(wave_);
-  bimg = uni(bimg); F = uni(F); L = uni(L); kb = uni(kb); cmask = uni(cmask);
+  const auto bimg = uni_g(bimg_);
+  F = uni(F); L = uni(L); kb = uni(kb); cmask = uni(cmask);
   const E_Geom G = e_geom(F, L);
   const int mid = G.mid, nL = G.nL, nU = G.nU;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -790,10 +934,12 @@ __device__ __noinline__ void mw8_role_sweeps(int up_, int wave_, const double *b
 }
 
 // B1 .. B4 after y_P: landmarks y_l = (g_l - w_l^T yP) / (E_l + mu dhat_l^2), a quarter each; partial sums to red[.. + wave].
-__device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl, const double *lm_g, const double *lm_einv, const double *lm_dh2, double *lm_y, int L) {
-  double *const lds = e_lds;
+__device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl_, const double *lm_g_, const double *lm_einv_, const double *lm_dh2_, double *lm_y_, int L) {
+  double *const lds = e_lds_base();
   const int bw = uni(bw_), wave = uni(wave_);
-  wl = uni(wl); lm_g = uni(lm_g); lm_einv = uni(lm_einv); lm_dh2 = uni(lm_dh2); lm_y = uni(lm_y); L = uni(L);
+  const auto wl = uni_g(wl_), lm_g = uni_g(lm_g_), lm_einv = uni_g(lm_einv_), lm_dh2 = uni_g(lm_dh2_);
+  const auto lm_y = uni_g(lm_y_);
+  L = uni(L);
   const int lane = threadIdx.x & 63;
   double *g = lds + E_G, *dh2 = lds + E_DH2, *y = lds + E_Y, *red = lds + E_RED;
   double part_gnn = 0.0, part_gy = 0.0, part_qx = 0.0;
@@ -830,7 +976,7 @@ __device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl, c
 }
 
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_solve_mw8(BatchDev b, SolveParams sp) {
-  double *const lds = e_lds;
+  double *const lds = e_lds_base();
   const int win = blockIdx.x;
   SolverState &st = b.st[win];
   if (st.done) return;
@@ -840,7 +986,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // the four pipes' instruction counts, changed nothing — 90.2 / 90.4 / 90.3 us for one window: the iterations are bound by the waves'
   // own dependency chains, not by the pipes.)
   const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifndef MW8_MAP
+#define MW8_MAP 0
+#endif
+#if MW8_MAP == 0
   const int wave = (hw_wave & 2) ? (4 + (hw_wave & 1) + ((hw_wave & 4) >> 1)) : ((hw_wave & 1) + ((hw_wave & 4) >> 1));   // 0 1 4 5 | 2 3 6 7
+#elif MW8_MAP == 1
+  const int wave = hw_wave;
+#else
+  const int wave = hw_wave < 4 ? hw_wave : (hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave);
+#endif
   const int lane = threadIdx.x & 63;
   const int tid = threadIdx.x;
   const WinMeta wm = b.win[win];
@@ -915,13 +1070,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         else if (wave == 5) mw8_role_B<EB2_MASK, 0x04>(1, Cimg, lms, F, L);
         else if (wave == 6) mw8_role_B<EB3_MASK, 0x08>(2, Cimg, lms, F, L);
         else mw8_role_B<EB4_MASK, 0x10>(3, Cimg, lms, F, L);
-        ESTAMP(4, 2);   // main loop (Schur complement + rank updates) and the tiles' hand-over
-        if (wave == 4) {
-          int f2 = (red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0) ? 1 : 0;
-          if (!f2) f2 = mw8_chol80(mu, F, cmask);
-          if (lane == 0) red[QR_FAIL + 2] = (double)f2;
-          ESTAMP(4, 4);   // Cholesky, forward and backward solve
-        }
+      }
+      ESTAMP(4, 2);   // main loop (Schur complement + rank updates) and the tiles' hand-over
+      {
+        // the pose system: all eight waves (role c of mw8_chol80 = this wave's role in the main loop)
+        const bool chain_failed = red[QR_FAIL] != 0.0 || red[QR_FAIL + 1] != 0.0;
+        int f2 = chain_failed ? 1 : 0;
+        if (!chain_failed) f2 = mw8_chol80(wave, mu, F, cmask);
+        if (wave == 0 && lane == 0) red[QR_FAIL + 2] = (double)f2;
+        ESTAMP(4, 4);   // Cholesky, forward and backward solve
         E_BARRIER();   // y_P (or the failure flags)
       }
       // (wave-uniform flags from LDS: chain down / up, pose system)
@@ -1039,7 +1196,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
   ESTAMP(4, 7);   // dogleg + candidate
-  PCLK(if (tid == 0) { for (int r_ = 0; r_ < 8; ++r_) st.phase_clk[16 + r_] = (long long)red[QR_WAIT + r_]; });
+  PCLK(if (tid == 0) { for (int r_ = 0; r_ < 8; ++r_) { st.phase_clk[16 + r_] = (long long)red[QR_WAIT + r_]; st.phase_clk[24 + r_] = (long long)red[64 + r_]; } st.phase_clk[10] = (long long)red[72]; st.phase_clk[11] = (long long)red[73]; for (int r_ = 0; r_ < 11; ++r_) st.phase_clk[47 + r_] = (long long)red[76 + r_]; });
 }
 
 int vilo_launch_mw8_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s) {

@@ -109,7 +109,7 @@ struct SolverState {
   double cost_trace[64];
   double radius_trace[64];
   long long t_start;         // constant-rate device clock (100 MHz) when the solve began: max_solver_time budget
-  long long phase_clk[47];   // shader-clock stamps (last linearisation), profiling build only: 0..9 and 16..23 k_solve_wave / k_solve_mid, 10..11 k_chain, 12..15 k_assemble (per wave), 24..27 k_backsub, 28..32 k_visual_linearize (packed wave 0), 33..35 k_imu_linearize (factor 0), 36..45 k_assemble
+  long long phase_clk[63];   // shader-clock stamps (last linearisation), profiling build only: 0..9 and 16..23 k_solve_wave / k_solve_mid / k_solve_mw8, 10..11 k_chain, 12..15 k_assemble (per wave), 24..27 k_backsub (k_solve_mw8: 24..28 a chain frame), 28..32 k_visual_linearize (packed wave 0), 33..35 k_imu_linearize (factor 0), 36..46 k_assemble, 47..57 k_solve_mw8's Cholesky-80
 };
 
 struct BatchDev {

@@ -803,7 +803,7 @@ extern "C" int vilo_debug_fetch(vilo_ctx *ctx, vilo_batch *bt, int what, int win
     case 8: src = bt->d.lm_y + wm.lm_off; n = wm.L; break;
     case 9: src = bt->d.lm_dh2 + wm.lm_off; n = wm.L; break;
     case 10: src = (const double *)(bt->d.st + win); n = 24 + 64; break;
-    case 12: src = (const double *)(bt->d.st + win) + 24 + 128 + 1; n = 47; break;   // phase_clk (int64 bit patterns)
+    case 12: src = (const double *)(bt->d.st + win) + 24 + 128 + 1; n = 63; break;   // phase_clk (int64 bit patterns)
     case 13:   // the window's preintegration records as they stand (vilo_preint x 10; with vilo_batch_set_samples: the last re-integration)
       if (!bt->leg || !bt->d_pre) return VILO_ERR_UNSUPPORTED;
       src = (const double *)((const vilo_preint *)bt->d_pre + (size_t)win * 10); n = 10 * sizeof(vilo_preint) / sizeof(double); break;

@@ -35,6 +35,11 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
               % (m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9]))
     if W <= 256 and m[16] > 0:   # four-wave solver: total and barrier-wait cycles of its waves
         print("k_solve_mw8, cycles at the main loop's step barriers: C1 %d C2 %d | TD %d TU %d | B1 %d B2 %d B3 %d B4 %d" % tuple(m[16:24]))
+        print("k_solve_mw8, C1's second frame (cycles from its start): S_k in registers %d | Cholesky-13 %d | [T_A | M] by substitution %d | handed to LDS %d | neighbour's update %d" % tuple(m[24:29]))
+        d = np.diff(np.concatenate([[0.0], m[47:58]]))
+        print("k_solve_mw8, Cholesky-80 on the factor wave (cycles per phase; block columns 0 .. 4: diagonal tile factored | its panel rows solved + next diagonal tile updated): "
+              + " ".join("%d|%d" % (d[2 * j], d[2 * j + 1]) for j in range(5)) + "; backward solve %d; total %d" % (d[10], m[57]))
+        print("k_solve_mw8, B3's fourth iteration (cycles from its start): the slice's half trips %d | two frames' rank updates %d" % (m[10], m[11]))
     elif W <= 512:
         print("k_solve_mw wave B: scaling %d | 1/(E + mu d) %d | Schur + rank updates (steps) %d | rhs + Cholesky %d | backward solve %d | wait for barrier %d | landmark back-substitution %d | norms + barrier %d | dogleg + candidate %d | total %d"
               % (m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[9] - m[0]))
