@@ -31,8 +31,12 @@ __device__ __forceinline__ double block_sum128(double v, double *red) {
   return v;
 }
 
-// red: 128 doubles (8 used), dxs: VILO_MAX_PRIOR_DIM doubles, accept_sp: one int (LDS)
-__device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap, double *red, double *dxs, int *accept_sp) {
+// red: 128 doubles (8 used), dxs: VILO_MAX_PRIOR_DIM doubles, accept_sp: one int (LDS); part: null, or (blockDim.x / 96) * 96 doubles of LDS —
+// then the prior's H dx is taken by every thread of the workgroup, a slice of the columns each (k_assemble_s: 8 slices of 12 columns; with
+// one row per thread the 73 KB of H are 96 dependent loads per thread, 6 round trips of a batch's 16: 15 k of the bookkeeping's 19 k cycles
+// at one window). The rows' sums then associate differently: a workgroup size is a property of the kernel, so a window's costs still do not
+// depend on the batch it shares.
+__device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap, double *red, double *dxs, int *accept_sp, double *part = nullptr) {
 #define accept_s (*accept_sp)
 
   const int win = blockIdx.x, tid = threadIdx.x;
@@ -73,7 +77,25 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
                b.prior_bsize[win * 40 + tid], dxs + b.prior_bidx[win * 40 + tid]);
     __syncthreads();
     const double *Hp = b.prior_H + (size_t)win * 96 * 96, *b0 = b.prior_b0 + (size_t)win * 96;
-    if (tid < n) {   // n <= 96 < 128: one row per thread
+    if (part) {
+      const int ns = (int)blockDim.x / 96, sl = tid / 96, row = tid - 96 * sl, per = (n + ns - 1) / ns;
+      if (sl < ns) {
+        double sacc = 0.0;
+        if (row < n) {
+          const int q1 = min(n, (sl + 1) * per);
+#pragma unroll 4
+          for (int q = sl * per; q < q1; ++q) sacc += Hp[(size_t)q * n + row] * dxs[q];
+        }
+        part[sl * 96 + row] = sacc;
+      }
+      __syncthreads();
+      if (tid < n) {
+        double sacc = 0.0;
+        for (int s2 = 0; s2 < ns; ++s2) sacc += part[s2 * 96 + tid];
+        pri = dxs[tid] * (sacc + 2.0 * b0[tid]);
+        my_hd = sacc;
+      }
+    } else if (tid < n) {   // n <= 96 < 128: one row per thread
       double sacc = 0.0;
 #pragma unroll 16
       for (int q = 0; q < n; ++q) sacc += Hp[(size_t)q * n + tid] * dxs[q];

@@ -40,6 +40,7 @@ using namespace vilo;
 #define AS_ACT (AS_PMAP + 56)            // [CD_N bytes = 28 doubles] activity of a camera dimension
 #define AS_TOTAL (AS_ACT + 28)
 static_assert(7800 <= AS_R1_N, "the Gram region lies inside the image copies + staging areas");
+static_assert(256 + (AS_THREADS / 96) * 96 <= AS_NG * AC_STAGE, "accept_body's scratch fits the staging areas");
 static_assert((AS_R1 & 1) == 0 && (AS_ST0 & 1) == 0 && (AC_STAGE & 1) == 0 && (CL_N & 1) == 0, "16-byte aligned areas");
 
 __global__ void __launch_bounds__(AS_THREADS) __attribute__((amdgpu_waves_per_eu(AS_NG, AS_NG)))
@@ -60,7 +61,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   const long long c_k0 = pclk64();
   if (fuse_accept) {
     double *scr = lds + AS_ST0;
-    accept_body(b, ap, scr, scr + 128, (int *)(scr + 128 + VILO_MAX_PRIOR_DIM));
+    accept_body(b, ap, scr, scr + 128, (int *)(scr + 128 + VILO_MAX_PRIOR_DIM), scr + 256);   // (scr + 256: AS_THREADS / 96 slices of the prior's H dx)
     __threadfence_block();
     __syncthreads();
   }

@@ -61,7 +61,9 @@
 #define ES_EI (80 * ES_LD)         // [32] 1 / (E_l + mu dhat_l^2), zero beyond the window's landmarks
 #define ES_G (ES_EI + ES_NL)       // [32] landmark gradients
 #define ES_N (ES_G + ES_NL + 8)    // 2712
-#define E_TOTAL (E_WS + 2 * ES_N)
+#define E_X (E_WS + 2 * ES_N)    // [XSTRIDE] the window's state, fetched when the kernel starts (the candidate is formed from it at the end)
+#define E_TOTAL (E_X + ((XSTRIDE + 7) & ~7))
+static_assert(E_TOTAL * 8 <= 160 * 1024, "one workgroup's LDS");
 static_assert(3920 <= 2 * 2560, "the pose system (pm_at) fits the hand-over buffers");
 extern __shared__ __attribute__((aligned(16))) double e_lds[];   // the workgroup's dynamic LDS (k_solve_mw8 and its roles)
 // Its address, once per role. In a function that is not a kernel the address of dynamic LDS is a scalar load from a per-kernel table, and
@@ -947,7 +949,11 @@ __device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl_, 
   for (int l = lane + 64 * bw; l < L; l += 256) {
     const double gl = lm_g[l], ei = lm_einv[l], d2 = lm_dh2[l], vl = gl / d2;
     double tl = 0.0, tq = 0.0;
-    // (20 coupling entries in flight per lane: the wave shares its SIMD's registers with a second one)
+    // (y and v_P through a pointer the compiler cannot see through: it would keep all 160 loop-invariant values in registers across the
+    //  landmark loop, which runs once or twice, and leave 20 for the coupling entries in flight)
+    const double *const yv = lds_in_vgpr(lds + E_Y), *const vPv = yv + (E_VP - E_Y);
+    // (20 coupling entries in flight per lane; 40 — two round trips per landmark instead of four — measured slower: 83.5 against 82.6 us
+    //  for one window, 97.8 against 94.9 us at 256 windows)
 #pragma unroll 1
     for (int a0 = 0; a0 < 80; a0 += 20) {
       double wcol[20];
@@ -955,10 +961,11 @@ __device__ __noinline__ void mw8_role_lm(int bw_, int wave_, const double *wl_, 
       for (int a = 0; a < 20; ++a) wcol[a] = wl[(size_t)(a0 + a) * L + l];
 #pragma unroll
       for (int a = 0; a < 20; ++a)
-        if (a0 + a < VILO_NPU) { tl += wcol[a] * y[a0 + a]; tq += wcol[a] * vP[a0 + a]; }   // y and v_P are zero on inactive dimensions
+        if (a0 + a < VILO_NPU) { tl += wcol[a] * yv[a0 + a]; tq += wcol[a] * vPv[a0 + a]; }   // y and v_P are zero on inactive dimensions
     }
     const double yl = (gl - tl) * ei;
     lm_y[l] = yl;
+    if (l < 2 * ES_N) lds[E_WS + l] = yl;   // (the slices are done with: the candidate reads y_l here)
     part_gnn += d2 * yl * yl;
     part_gy += gl * yl;
     part_qx += vl * tq;   // cross term of q = v^T H v: 2 v_l w_l^T v_P
@@ -979,7 +986,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   double *const lds = e_lds_base();
   const int win = blockIdx.x;
   SolverState &st = b.st[win];
-  if (st.done) return;
+  // (everything the kernel reads of the state and the window table before its first branch: one round trip, not one per question)
+  const WinMeta wm = b.win[win];
+  const int done0 = st.done, need_lin0 = st.need_lin, cur0 = st.cur, scale_ready0 = st.scale_ready;
+  const double radius0 = st.radius, mu0 = st.mu;
+  if (done0) return;
   // roles: 0: C1 (chain down + middle), 1: C2 (chain up), 2: TD, 3: TU, 4 .. 7: B1 .. B4. Hardware wave w of a workgroup runs on SIMD w % 4
   // (measured: waves w and w + 4 share a matrix pipe — one FP64 MFMA per 64 cycles per SIMD — and the older wave goes first): the chain waves
   // are paired with the T waves, the matrix waves with each other. (Pairing each matrix wave with a chain or T wave instead, which balances
@@ -998,24 +1009,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
   const int lane = threadIdx.x & 63;
   const int tid = threadIdx.x;
-  const WinMeta wm = b.win[win];
   const int F = wm.n_frames, L = wm.L, kb = wm.pad, cmask = wm.const_mask;
   double *g = lds + E_G, *dh2 = lds + E_DH2, *y = lds + E_Y, *red = lds + E_RED;
   double *DB = lds + E_DB, *GB = lds + E_GB, *YB = lds + E_YB;
   struct DoglegIn { double radius, mu, gnorm2, gnnorm2, gdotgn, q, alpha, coef_a, coef_b, dogleg_step_norm, model_cost_change; int step_valid; } fresh;
   bool have_fresh = false;
-  const double radius0 = st.radius;
   const long long q_start = pclk64();
+  const double *x = b.x + (size_t)win * XSTRIDE;
+  for (int e = tid; e < XSTRIDE; e += 512) lds[E_X + e] = x[e];   // (in flight behind everything below; read after many barriers)
+  // the landmarks this thread scales and, at the end, moves: tid and tid + 512 keep lambda and g / dhat^2 in registers
+  const double *lam = b.lam + wm.lm_off;
+  double lam_r[2] = {0.0, 0.0}, vl_r[2] = {0.0, 0.0};
+#pragma unroll
+  for (int n = 0; n < 2; ++n) if (tid + 512 * n < wm.L) lam_r[n] = lam[tid + 512 * n];
+  bool lmy_in_lds = false;
 #define ESTAMP(w_, i_) PCLK(if (wave == (w_) && lane == 0) st.phase_clk[i_] = clock64() - q_start)
 
-  if (st.need_lin) {
+  if (need_lin0) {
     const double *bimg = b.Bimg + (size_t)win * BI_N;
+    const double bscal0 = bimg[BI_SCAL + 0], bscal1 = bimg[BI_SCAL + 1], bscal2 = bimg[BI_SCAL + 2];
     const double *gin = b.cam_gin + (size_t)win * CD_N;
     const double *wl = b.lm_w + 80 * (size_t)wm.lm_off;
-    double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_gbuf[st.cur] + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
+    double *lm_E = b.lm_E + wm.lm_off, *lm_g = b.lm_gbuf[cur0] + wm.lm_off, *lm_dh2 = b.lm_dh2 + wm.lm_off, *lm_scale = b.lm_scale + wm.lm_off,
            *lm_einv = b.lm_einv + wm.lm_off, *lm_y = b.lm_y + wm.lm_off;
-    const bool first_scale = !st.scale_ready;
-    double mu = st.mu;
+    const bool first_scale = !scale_ready0;
+    double mu = mu0;
 
     // ---- camera-side vectors come scaled from k_assemble; the landmarks are scaled here (landmark tid + 512 n) ----
     double part_gn = 0.0, part_gmax = 0.0, part_q = 0.0;
@@ -1033,6 +1051,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       lm_dh2[l] = d2;
       lm_einv[l] = 1.0 / (E + mu * d2);   // (of the first factorisation: a retry at a larger mu forms its own below)
       const double vl = gl / d2;
+      if (l == tid) vl_r[0] = vl; else if (l == tid + 512) vl_r[1] = vl;
       part_q += E * vl * vl;   // (the cross term 2 vl w_l^T v_P comes from the back-substitution)
       part_gn += gl * vl;
       part_gmax = fmax(part_gmax, fabs(gl));
@@ -1043,8 +1062,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     double s_gn = 0.0, s_q = 0.0, s_gmax = 0.0;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) { s_gn += red[QR_GN + w8]; s_q += red[QR_Q + w8]; s_gmax = fmax(s_gmax, red[QR_GMAX + w8]); }
-    const double gnorm2 = bimg[BI_SCAL + 1] + s_gn;
-    const double gmax = fmax(bimg[BI_SCAL + 2], s_gmax);
+    const double gnorm2 = bscal1 + s_gn;
+    const double gmax = fmax(bscal2, s_gmax);
     const double q_lm = s_q;
     if (!sp.fixed_iterations && gmax <= sp.gradient_tolerance) {
       if (tid == 0) { st.gmax = gmax; st.done = 1; st.termination = 1; st.step_valid = 0; }
@@ -1102,13 +1121,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         E_BARRIER();
       } else mw8_role_lm(wave - 4, wave, wl, lm_g, lm_einv, lm_dh2, lm_y, L);
       ESTAMP(4, 5); ESTAMP(0, 9);   // back-substitutions
-      E_BARRIER_GLOBAL();   // (lm_y is read by every wave for the candidate)
+      // (the candidate takes lm_y from the LDS copy the landmark role leaves over the slices: no wait for the global stores — unless the
+      //  window has more landmarks than the slices hold)
+      if (L <= 2 * ES_N) E_BARRIER(); else E_BARRIER_GLOBAL();
       double s_gnn = 0.0, s_gy = 0.0, s_qx = 0.0;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) { s_gnn += red[QR_GNN + w8]; s_gy += red[QR_GY + w8]; s_qx += red[QR_QX + w8]; }
       gnnorm2 = s_gnn;
       gy = s_gy;
-      qq = bimg[BI_SCAL + 0] + (q_lm + 2.0 * s_qx);
+      qq = bscal0 + (q_lm + 2.0 * s_qx);
       if (!(isfinite(gnnorm2) && isfinite(gy))) {   // IsArrayValid(gauss_newton_step_) failed
         mu *= 10.0;
         if (tid == 0) { st.mu = mu; st.pad[0]++; }
@@ -1121,6 +1142,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
       solved = true;
     }
+    lmy_in_lds = L <= 2 * ES_N;
     // keep the linearisation's vectors for the steps that reuse it after a rejected candidate
     double *cam_g = b.cam_g + (size_t)win * CD_N, *cam_dh2 = b.cam_dh2 + (size_t)win * CD_N, *cam_y = b.cam_y + (size_t)win * CD_N;
     if (wave == 4) {
@@ -1166,15 +1188,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   E_BARRIER();
   const double ca = red[QR_CA], cb = red[QR_CB];
   const int go = (red[QR_GO] != 0.0) ? 1 : 0;
-  const double *x = b.x + (size_t)win * XSTRIDE;
   double *xc = b.xc + (size_t)win * XSTRIDE;
+  const double *xl = lds + E_X;   // (the state as fetched at the start)
   {
-    const double *lam = b.lam + wm.lm_off, *lmg = b.lm_gbuf[st.cur] + wm.lm_off, *lmd = b.lm_dh2 + wm.lm_off, *lmy = b.lm_y + wm.lm_off;
+    const double *lmg = b.lm_gbuf[cur0] + wm.lm_off, *lmd = b.lm_dh2 + wm.lm_off, *lmy = b.lm_y + wm.lm_off;
     double *lamc = b.lamc + wm.lm_off;
-    for (int l = tid; l < L; l += 512) lamc[l] = go ? lam[l] - ca * lmg[l] / lmd[l] - cb * lmy[l] : lam[l];
+    for (int l = tid, n = 0; l < L; l += 512, ++n) {
+      const double la = n < 2 ? lam_r[n < 1 ? 0 : 1] : lam[l];
+      if (!go) { lamc[l] = la; continue; }
+      const double vl = (need_lin0 && n < 2) ? vl_r[n < 1 ? 0 : 1] : lmg[l] / lmd[l];
+      const double yl = lmy_in_lds ? lds[E_WS + l] : lmy[l];
+      lamc[l] = la - ca * vl - cb * yl;
+    }
   }
   if (!go) {
-    for (int e = tid; e < XSTRIDE; e += 512) xc[e] = x[e];
+    for (int e = tid; e < XSTRIDE; e += 512) xc[e] = xl[e];
     return;
   }
   double *del = lds + E_DEL;
@@ -1185,14 +1213,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   E_BARRIER();
   if (wave == 4) {
-    if (lane < 11) pose_plus(x + XO_POSE + 7 * lane, del + 6 * lane, xc + XO_POSE + 7 * lane);
-    else if (lane < 13) pose_plus(x + XO_EX + 7 * (lane - 11), del + CD_EX0 + 6 * (lane - 11), xc + XO_EX + 7 * (lane - 11));
-    else if (lane == 13) xc[XO_TD] = x[XO_TD] + del[CD_TD];
+    if (lane < 11) pose_plus(xl + XO_POSE + 7 * lane, del + 6 * lane, xc + XO_POSE + 7 * lane);
+    else if (lane < 13) pose_plus(xl + XO_EX + 7 * (lane - 11), del + CD_EX0 + 6 * (lane - 11), xc + XO_EX + 7 * (lane - 11));
+    else if (lane == 13) xc[XO_TD] = xl[XO_TD] + del[CD_TD];
   } else if (wave == 0) {
     for (int e = lane; e < 143; e += 64) {
       const int k = e / 13, c = e - 13 * k;
-      if (c < 9) xc[XO_SB + 9 * k + c] = x[XO_SB + 9 * k + c] + del[CD_B0 + e];
-      else xc[XO_LB + 4 * k + (c - 9)] = x[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
+      if (c < 9) xc[XO_SB + 9 * k + c] = xl[XO_SB + 9 * k + c] + del[CD_B0 + e];
+      else xc[XO_LB + 4 * k + (c - 9)] = xl[XO_LB + 4 * k + (c - 9)] + del[CD_B0 + e];
     }
   }
   ESTAMP(4, 7);   // dogleg + candidate
