@@ -279,17 +279,7 @@ __device__ __noinline__ int mw8_chol80(int cw_, double mu, int F, int cmask) {
         for (int c = 0; c < 16; ++c) a[c] += (c == lr) ? md : 0.0;
       }
       double myrinv = 1.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        double piv = readlane_d(a[q], q);
-        if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
-        const double rinv = rsqrt(piv);
-        const double lq = (lr == q) ? piv * rinv : (lr > q ? a[q] * rinv : 0.0);
-        a[q] = lq;
-        if (lr == q) myrinv = rinv;
-#pragma unroll
-        for (int q2 = q + 1; q2 < 16; ++q2) a[q2] -= lq * readlane_d(lq, q2);
-      }
+      fail |= chol_rows<16>(a, lr, myrinv);
       if (lk == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) { lds[pm_at(16 * j + lr, 16 * j + c)] = a[c]; LD16[lr * 17 + c] = a[c]; }   // (zeros above the diagonal)
@@ -463,17 +453,9 @@ __device__ __noinline__ void mw8_role_chain(int up_, const double *bimg_, const 
     }
     FSTAMP(0);
     double myrinv = 1.0;
+    fail |= chol_rows<13>(a, c, myrinv);
 #pragma unroll
-    for (int j = 0; j < 13; ++j) {
-      double piv = readlane_d(a[j], j);
-      if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
-      const double rinv = rsqrt(piv);
-      const double lj = (c == j) ? piv * rinv : (c > j ? a[j] * rinv : 0.0);
-      l[j] = lj;
-      if (c == j) myrinv = rinv;
-#pragma unroll
-      for (int q = j + 1; q < 13; ++q) a[q] -= lj * readlane_d(lj, q);
-    }
+    for (int j = 0; j < 13; ++j) l[j] = a[j];
 #pragma unroll
     for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(l[j]));
     FSTAMP(1);

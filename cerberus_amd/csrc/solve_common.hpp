@@ -29,6 +29,40 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Right-looking Cholesky of an N x N matrix (N <= 16) in registers, lane = row (a[q]: entry (row, q) in, L(row, q) out; the four 16-lane
+// groups of a wave may replicate the work), pivots and column entries broadcast with v_readlane; myrinv: 1 / L(row, row). A column step
+// is the pivot's dependent chain — v_readlane -> class check -> v_rsq_f64 + five Newton operations -> scale: ~240 cycles — followed by the
+// trailing update (a v_readlane pair + multiply-add per remaining column, ~24 cycles each). The pivot of the NEXT column is therefore
+// formed one step ahead as a wave-uniform scalar: piv' = a(q+1, q+1) - (a(q+1, q) rinv)^2, the very multiply-add the vector update
+// performs in lane q + 1, so that its reciprocal square root runs beside the current column's trailing updates instead of after them.
+// The same operations on the same values as the plain loop (readlane the pivot after the update): bitwise the same factor.
+// Returns 1 if a pivot was not positive and finite (it is replaced by 1, as Eigen's LLT would go on with garbage; the caller retries).
+template <int N>
+__device__ __forceinline__ int chol_rows(double (&a)[N], int row, double &myrinv) {
+  int fail = 0;
+  double piv = readlane_d(a[0], 0);
+  if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+  double rinv = rsqrt(piv);
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double pivn = 1.0, rinvn = 1.0;
+    if (q + 1 < N) {
+      const double a10 = readlane_d(a[q], q + 1), a11 = readlane_d(a[q + 1 < N ? q + 1 : q], q + 1);
+      const double l10 = a10 * rinv;
+      pivn = __builtin_fma(-l10, l10, a11);
+      if (!(pivn > 0.0) || !isfinite(pivn)) { fail = 1; pivn = 1.0; }
+      rinvn = rsqrt(pivn);
+    }
+    const double lq = (row == q) ? piv * rinv : (row > q ? a[q] * rinv : 0.0);
+    a[q] = lq;
+    if (row == q) myrinv = rinv;
+#pragma unroll
+    for (int q2 = q + 1; q2 < N; ++q2) a[q2] = __builtin_fma(-lq, readlane_d(lq, q2), a[q2]);
+    piv = pivn; rinv = rinvn;
+  }
+  return fail;
+}
+
 __device__ __forceinline__ int tri26(int a, int b) { return a * 26 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 __device__ __forceinline__ int tri23(int a, int b) { return a * 23 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 // Entry (c1, c2) of the 26-column view [pose_s 6 | pose_j 6 | ex0 6 | ex1 6 | td | r] of a Gram slot: index into the packed 23-column
