@@ -82,20 +82,25 @@ constexpr int VLD = pb::VLD;   // of the 32 x 48 noise Jacobian
 constexpr int FCLD = pb::FCLD; // of dF = F - I, stored with its 16 non-zero columns only (preint_blocks.hpp)
 
 // C(32 x 32) = A(32 x 4 KS) * op(B): row-major A (lda), B given as Bt = B^T row-major (ldb) when BT, else B row-major
-template <int KS, bool BT>
+// ONLY0 / ONLY1: bit kk set = k-step kk of both operands is zero in rows 16 .. 31 / in rows 0 .. 15 (a structural property of the caller's
+// matrices): three of the step's four products are exact zeros and are not issued, the operands of the zero half are not read.
+template <int KS, bool BT, unsigned ONLY0 = 0u, unsigned ONLY1 = 0u>
 __device__ __forceinline__ void gemm32(const double *A, int lda, const double *B, int ldb, const double *kscale, mfma_d4 acc[4]) {
   const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const int k = 4 * kk + lk;
-    double a0 = A[lr * lda + k], a1 = A[(16 + lr) * lda + k];
+    const bool lo = !((ONLY1 >> kk) & 1u), hi = !((ONLY0 >> kk) & 1u);   // which row halves of the operands carry anything
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (lo) { a0 = A[lr * lda + k]; b0 = BT ? B[lr * ldb + k] : B[k * ldb + lr]; }
+    if (hi) { a1 = A[(16 + lr) * lda + k]; b1 = BT ? B[(16 + lr) * ldb + k] : B[k * ldb + 16 + lr]; }
     if (kscale) { const double sc = kscale[k]; a0 *= sc; a1 *= sc; }
-    const double b0 = BT ? B[lr * ldb + k] : B[k * ldb + lr];
-    const double b1 = BT ? B[(16 + lr) * ldb + k] : B[k * ldb + 16 + lr];
-    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[3], 0, 0, 0);
+    if (lo) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+    if (lo && hi) {
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[2], 0, 0, 0);
+    }
+    if (hi) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[3], 0, 0, 0);
   }
 }
 __device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]) {
@@ -165,7 +170,10 @@ __device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const dou
   store32(Pm, FLD, accP);
   __syncthreads();
   gemm32_fk_t(Pm, dFm, accP);                        // Q + Q dF^T
-  gemm32<12, true>(Vm, VLD, Vm, VLD, nd, accP);      // + V N V^T
+  // + V N V^T. Of V's 12 k-steps (4 noise columns each) four touch one half of the rows only (preint_blocks.hpp: columns 12 .. 15 are the bias
+  // random walks' rows 21 .. 26; 32 .. 35 the foot-position noise of legs 0 / 1, rows 9 .. 14; 40 .. 47 leg 3's, rows 18 .. 20, the calf
+  // lengths' rows 27 .. 30 and padding): 36 instead of 48 matrix instructions
+  gemm32<12, true, pb::V_KSTEPS_ROWS_LO_ONLY, pb::V_KSTEPS_ROWS_HI_ONLY>(Vm, VLD, Vm, VLD, nd, accP);
   __syncthreads();
   store32(Pm, FLD, accP);
   __syncthreads();

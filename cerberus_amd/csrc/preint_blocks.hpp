@@ -81,6 +81,10 @@ constexpr unsigned long long mk_blk(int off, int ld, int c0, int s0, int c1 = C_
 }
 constexpr int fc_off(int r, int c) { return O_FC + r * FCLD + kidx(c); }
 constexpr int vm_off(int r, int c) { return O_VM + r * VLD + c; }
+// k-steps (4 columns each) of V whose non-zero rows all lie in 0 .. 15 / in 16 .. 31 (from the block table below; checked on the host by
+// tests/test_host_math.py against the table itself)
+constexpr unsigned V_KSTEPS_ROWS_LO_ONLY = 1u << 8;
+constexpr unsigned V_KSTEPS_ROWS_HI_ONLY = (1u << 3) | (1u << 10) | (1u << 11);
 
 constexpr Tables make_tables() {
   Tables t{};

@@ -249,4 +249,7 @@ void hc_preint_blocks(int mode, const double *in, double *dF, double *V) {
     for (int c = 0; c < 48; ++c) V[r * 48 + c] = L[pb::O_VM + r * pb::VLD + c];
   }
 }
+
+// kernels_preint.hip skips the matrix instructions of V N V^T whose operands are structurally zero: the two k-step masks it is compiled with
+void hc_v_kstep_masks(unsigned *lo_only, unsigned *hi_only) { *lo_only = pb::V_KSTEPS_ROWS_LO_ONLY; *hi_only = pb::V_KSTEPS_ROWS_HI_ONLY; }
 }

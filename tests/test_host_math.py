@@ -327,3 +327,18 @@ def test_lane_parallel_preintegration_blocks_match_the_blocks_written_out(hc):
             scale = np.abs(b).max()
             assert np.abs(a - b).max() <= 4e-16 * max(1.0, scale) + 1e-15 * np.abs(b).max(), (name, np.abs(a - b).max())
         assert np.count_nonzero(out[0][0]) >= 140 and np.count_nonzero(out[0][1]) >= 300, (np.count_nonzero(out[0][0]), np.count_nonzero(out[0][1]))
+        # k-steps (4 noise columns) of V N V^T whose products with one half of the rows kernels_preint.hip does not issue: that half of V
+        # must be structurally zero there — in the blocks as the reference writes them and in the lane-parallel ones — and every other
+        # k-step must have something in both halves (else the masks leave work on the table without saying so)
+        lo, hi = C.c_uint(0), C.c_uint(0)
+        hc.hc_v_kstep_masks(C.byref(lo), C.byref(hi))
+        assert lo.value & hi.value == 0
+        for _, V in out:
+            for kk in range(12):
+                top, bot = V[:16, 4 * kk:4 * kk + 4], V[16:, 4 * kk:4 * kk + 4]
+                if (lo.value >> kk) & 1:
+                    assert not bot.any() and top.any(), kk
+                elif (hi.value >> kk) & 1:
+                    assert not top.any() and bot.any(), kk
+                else:
+                    assert top.any() and bot.any(), kk
