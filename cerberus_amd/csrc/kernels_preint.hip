@@ -110,7 +110,8 @@ __device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr] = acc[t][r];
 }
-// F = I + dF, and dF has non-zero columns only at K = {3 .. 8, 21 .. 30} (d/d theta, d/d v, d/d ba, d/d bg, d/d rho): 16 of 31.
+// F = I + dF, and dF has non-zero columns only at K = {3 .. 8, 21 .. 30} (d/d theta, d/d v, d/d ba, d/d bg, d/d rho): 16 of 31
+// (compact order: preint_blocks.hpp — the two k-steps whose columns live in rows 0 .. 15 only come first and cost half the products).
 // With dFc = (F - I)[:, K] in LDS (32 x 16, leading dimension FCLD) the products keep their identity part in the accumulators and
 // contract over the 16 columns of K only:
 //   F X = X + dF[:, K] X[K, :],   Q F^T = Q + Q[:, K] dF[:, K]^T        (4 k-steps instead of 8 each).
@@ -127,10 +128,13 @@ __device__ __forceinline__ void gemm32_fk(const double *A, const double *B, mfma
   }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
+    const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);   // (rows 16 .. 31 of dF are zero in the k-steps of the mask: a1 = 0)
     acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+    if (hi) {
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+    }
   }
 }
 // acc += A[:, K] * dFc^T
@@ -145,10 +149,11 @@ __device__ __forceinline__ void gemm32_fk_t(const double *A, const double *Bt, m
   }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
+    const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);   // (here dF is the B operand: b1 = 0 in the k-steps of the mask)
     acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
+    if (hi) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
     acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+    if (hi) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
   }
 }
 __device__ __forceinline__ void load32(const double *C, int ldc, mfma_d4 acc[4]) {

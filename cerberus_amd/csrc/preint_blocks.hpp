@@ -22,7 +22,7 @@ namespace vilo {
 namespace pb {
 
 // ---- LDS map of the step (doubles) ----
-constexpr int FCLD = 17;    // dF has non-zero columns only at K = {3 .. 8, 21 .. 30}: stored compact, column kidx(c), odd leading dimension
+constexpr int FCLD = 17;    // dF has non-zero columns only at K = {3 .. 8, 21 .. 30}: stored compact, column kidx(c) (order: below), odd leading dimension
 constexpr int VLD = 49;     // V: 32 x 48 (46 noise dimensions), odd leading dimension
 constexpr int O_FC = 0;                      // [32 x 17]
 constexpr int O_VM = O_FC + 32 * FCLD;       // [32 x 49]
@@ -38,8 +38,20 @@ constexpr int O_ND = O_COEF + 16;            // [48] noise diagonal
 constexpr int O_DUMMY = O_ND + 48;            // [9] where idle lanes write
 constexpr int PB_TOTAL = O_DUMMY + 9;
 
-PB_HD constexpr int kidx(int c) { return c < 9 ? c - 3 : c - 15; }      // column of F -> compact column (c in K)
-PB_HD constexpr int fk_col(int k) { return k < 6 ? 3 + k : 15 + k; }    // and back
+// Compact order of K: first the eight columns whose entries all lie in rows 0 .. 15 — d/dv (6 .. 8: the dt I block of the position rows),
+// d/dba (21 .. 23: position and velocity rows), d/drho of legs 0 and 1 (27, 28: their epsilon rows 9 .. 14) —, then theta (3 .. 5), bg
+// (24 .. 26) and the calf lengths of legs 2 and 3 (29, 30), which reach into rows 16 .. 20 as well: the first two k-steps of F X and Q F^T
+// have nothing in one half of dF's rows, and kernels_preint.hip issues half of their products (DF_KSTEPS_ROWS_LO_ONLY).
+PB_HD constexpr int kidx(int c) {     // column of F -> compact column (c in K)
+  return c < 6 ? c + 5 : c < 9 ? c - 6 : c < 24 ? c - 18 : c < 27 ? c - 13 : c < 29 ? c - 21 : c - 15;
+}
+PB_HD constexpr int fk_col(int k) {   // and back: 6 7 8 21 | 22 23 27 28 | 3 4 5 24 | 25 26 29 30
+  return k < 3 ? 6 + k : k < 6 ? 18 + k : k < 8 ? 21 + k : k < 11 ? k - 5 : k < 14 ? 13 + k : 15 + k;
+}
+constexpr unsigned DF_KSTEPS_ROWS_LO_ONLY = 0x3u;
+static_assert(fk_col(kidx(3)) == 3 && fk_col(kidx(8)) == 8 && fk_col(kidx(21)) == 21 && fk_col(kidx(26)) == 26 && fk_col(kidx(27)) == 27 && fk_col(kidx(30)) == 30, "K");
+static_assert(kidx(4) == kidx(3) + 1 && kidx(5) == kidx(3) + 2 && kidx(7) == kidx(6) + 1 && kidx(8) == kidx(6) + 2 && kidx(22) == kidx(21) + 1 && kidx(23) == kidx(21) + 2 &&
+              kidx(25) == kidx(24) + 1 && kidx(26) == kidx(24) + 2, "the 3 x 3 blocks' columns stay adjacent");
 
 // ---- pool slots ----
 constexpr int S_R0 = 0, S_R1 = 1, S_K7 = 2, S_RA0 = 3, S_RA1 = 4, S_RWX = 5, S_RBR = 6, S_I = 7;

@@ -252,4 +252,6 @@ void hc_preint_blocks(int mode, const double *in, double *dF, double *V) {
 
 // kernels_preint.hip skips the matrix instructions of V N V^T whose operands are structurally zero: the two k-step masks it is compiled with
 void hc_v_kstep_masks(unsigned *lo_only, unsigned *hi_only) { *lo_only = pb::V_KSTEPS_ROWS_LO_ONLY; *hi_only = pb::V_KSTEPS_ROWS_HI_ONLY; }
+// the same for dF = F - I in its compact column order: the mask and the 16 columns of F in that order
+void hc_df_kstep_mask(unsigned *lo_only, int *cols16) { *lo_only = pb::DF_KSTEPS_ROWS_LO_ONLY; for (int k = 0; k < 16; ++k) cols16[k] = pb::fk_col(k); }
 }

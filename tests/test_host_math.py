@@ -342,3 +342,10 @@ def test_lane_parallel_preintegration_blocks_match_the_blocks_written_out(hc):
                     assert not top.any() and bot.any(), kk
                 else:
                     assert top.any() and bot.any(), kk
+        dlo, cols = C.c_uint(0), (C.c_int * 16)()
+        hc.hc_df_kstep_mask(C.byref(dlo), cols)
+        assert sorted(cols) == [3, 4, 5, 6, 7, 8] + list(range(21, 31))
+        for dF, _ in out:
+            for kk in range(4):
+                bot = dF[16:, [cols[4 * kk + u] for u in range(4)]]
+                assert bot.any() != bool((dlo.value >> kk) & 1), kk   # masked k-steps: nothing in rows 16 .. 31; the others: something
