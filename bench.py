@@ -40,6 +40,19 @@ REPROPAGATION_KERNELS = ("k_repropagate", "k_prepare_preint")   # config 3: once
 REPROPAGATION_FLOPS = 15.0e6
 
 
+def sustained_mfma_tflops():
+    """(all SIMDs fed by four waves, one wave per SIMD) FP64-MFMA TFLOP/s by wall clock from the committed output of tools/micro/mfma_f64_rate.hip
+    (15 independent accumulators per wave); (None, None) if the file is not there."""
+    import re
+    try:
+        txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_mfma_f64_rate.txt")).read()
+        part = txt.split("-- 15 independent accumulators per wave")[1]
+        rate = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"waves per CU\s+(\d+):.*?->\s+([0-9.]+) TFLOP/s", part)}
+        return rate.get(16), rate.get(4)
+    except Exception:
+        return None, None
+
+
 def kernels_sha16():
     """Fingerprint of the kernel sources (cerberus_amd/csrc): profiles/*_pmc.json carries the one of the tree its counters were collected
     on, so a bench line can say whether the committed counter evidence belongs to the kernels that ran."""
@@ -289,7 +302,7 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="2: BASELINE configs[1] (200 landmarks, 500 Hz; the headline metric); "
                     "3: BASELINE configs[2] (1000 landmarks, 400 Hz, K1 re-propagation inside every iteration)")
@@ -510,6 +523,7 @@ def main():
         if alg_flops and rp:
             alg_flops += REPROPAGATION_FLOPS
         tag = "_config3" if rp else ""
+        sust = sustained_mfma_tflops()
         out = {
             "metric": "GN iters/sec, 10-KF x 200-landmark VILO window; 1/2/4/8-GPU batch throughput" if not rp else
                       "GN iters/sec, 10-KF x 1000-landmark VILO window + 400 Hz IMU preintegration re-propagated every iteration (BASELINE configs[2])",
@@ -545,8 +559,9 @@ def main():
                                   "whole_iteration_frac": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 78.6 if alg_flops else None,
                                   # what the matrix cores sustain by wall clock with every SIMD issuing FP64 MFMAs back to back (the shader clock
                                   # drops under that load): tools/micro/mfma_f64_rate.hip, profiles/round3_mfma_f64_rate.txt
-                                  "sustained_mfma_tflops": 44.2, "sustained_mfma_tflops_one_wave_per_simd": 33.2,
-                                  "whole_iteration_frac_of_sustained": alg_flops * W / (iter_ms * 1e-3) / 1e12 / 44.2 if alg_flops else None,
+                                  "sustained_mfma_tflops": sust[0], "sustained_mfma_tflops_one_wave_per_simd": sust[1],
+                                  "sustained_mfma_source": "profiles/round3_mfma_f64_rate.txt (15 accumulators per wave: 16 / 4 waves per CU), parsed at run time",
+                                  "whole_iteration_frac_of_sustained": alg_flops * W / (iter_ms * 1e-3) / 1e12 / sust[0] if (alg_flops and sust[0]) else None,
                                   "mfma_util": ev["mfma"],
                                   "mfma_util_source": "profiles/%s_mfma%s.json: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc" % (PROFILE_ROUND, tag) if ev["mfma"] else None},
                          # calibrated HBM bytes per window of every kernel of the iteration against the algorithmic bytes of the whole iteration
