@@ -1,0 +1,295 @@
+"""ROS bag (format 2.0) reader / writer of cerberus_amd/host/vilo_rosbag.* (ctypes) and the message-level replay that stands in for
+the reference's node (src/main.cpp): IMU + JointState pairs -> inputIMU / inputLeg with the contact source CONTACT_SENSOR_TYPE selects
+(:255-330; type 0's Kalman-filter estimate is an absent submodule: the planner's flags stand in), /feature_tracker/feature point
+clouds -> inputFeature (:204-234), images deserialised and dropped (their consumer, the feature tracker, is out of scope).
+
+    write_stream_bag(path, stream_frames...)   a synthetic sensor stream (cerberus_amd.sequence.Stream) as a bag with the reference's topics
+    BagReader(path)                            iterate the messages of a bag in file order
+    replay(messages, measurement_processor)    feed messages — from a bag, or the same ones kept in memory — to vilo::MeasurementProcessor
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import sequence
+
+IMU_TOPIC, LEG_TOPIC = "/hardware_a1/imu", "/hardware_a1/joint_foot"          # config/a1_config/hardware_a1_vilo_config.yaml: imu_topic, leg_topic
+IMAGE0_TOPIC, IMAGE1_TOPIC = "/camera_forward/infra1/image_rect_raw", "/camera_forward/infra2/image_rect_raw"
+FEATURE_TOPIC = "/feature_tracker/feature"                                        # main.cpp:415
+KIND_IMU, KIND_JOINT_STATE, KIND_IMAGE, KIND_POINT_CLOUD, KIND_OTHER = range(5)
+NUM_DOF, NUM_LEG = 12, 4
+
+
+class BagMsg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("rec_secs", C.c_uint32), ("rec_nsecs", C.c_uint32), ("seq", C.c_uint32), ("secs", C.c_uint32), ("nsecs", C.c_uint32),
+                ("topic", C.c_char * 256), ("type", C.c_char * 64), ("frame_id", C.c_char * 64),
+                ("orientation", C.c_double * 4), ("angular_velocity", C.c_double * 3), ("linear_acceleration", C.c_double * 3),
+                ("n_position", C.c_int32), ("n_velocity", C.c_int32), ("n_effort", C.c_int32),
+                ("position", C.c_double * 32), ("velocity", C.c_double * 32), ("effort", C.c_double * 32),
+                ("height", C.c_uint32), ("width", C.c_uint32), ("step", C.c_uint32), ("encoding", C.c_char * 32), ("is_bigendian", C.c_int32),
+                ("n_points", C.c_int32), ("n_channels", C.c_int32),
+                ("data", C.POINTER(C.c_uint8)), ("data_len", C.c_uint32), ("points", C.POINTER(C.c_float)), ("channels", C.POINTER(C.c_float)),
+                ("channel_names", (C.c_char * 32) * 16)]
+
+
+def _lib():
+    H = sequence.host_lib()
+    if not getattr(H, "_bag_ready", False):
+        H.vilo_bag_writer_open.restype = C.c_void_p
+        H.vilo_bag_writer_open.argtypes = [C.c_char_p, C.c_int]
+        H.vilo_bag_write_imu.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]
+        H.vilo_bag_write_joint_state.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        H.vilo_bag_write_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32,
+                                           C.c_void_p]
+        H.vilo_bag_write_point_cloud.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
+                                                 C.c_void_p]
+        H.vilo_bag_writer_close.argtypes = [C.c_void_p]
+        H.vilo_bag_reader_open.restype = C.c_void_p
+        H.vilo_bag_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        H.vilo_bag_reader_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        H.vilo_bag_reader_next.argtypes = [C.c_void_p, C.POINTER(BagMsg)]
+        H.vilo_bag_reader_close.argtypes = [C.c_void_p]
+        H._bag_ready = True
+    return H
+
+
+def to_stamp(t):
+    """ros::Time(t) (fromSec): whole seconds + nanoseconds rounded to nearest, with the carry"""
+    secs = int(math.floor(t))
+    nsecs = int(round((t - secs) * 1e9))
+    if nsecs >= 1000000000:
+        secs, nsecs = secs + 1, nsecs - 1000000000
+    return secs, nsecs
+
+
+def to_sec(secs, nsecs):
+    """ros::Time::toSec()"""
+    return float(secs) + 1e-9 * float(nsecs)
+
+
+class BagWriter:
+    def __init__(self, path, chunk_threshold=768 * 1024):
+        self.H = _lib()
+        self.h = C.c_void_p(self.H.vilo_bag_writer_open(str(path).encode(), int(chunk_threshold)))
+        if not self.h:
+            raise OSError("cannot create %s" % path)
+
+    def write(self, m):
+        """m: a message dict as BagReader yields them / as stream_messages makes them"""
+        H, k, t = self.H, m["kind"], m["topic"].encode()
+        if k == KIND_IMU:
+            acc, gyr = np.ascontiguousarray(m["linear_acceleration"], np.float64), np.ascontiguousarray(m["angular_velocity"], np.float64)
+            rc = H.vilo_bag_write_imu(self.h, t, m["seq"], m["secs"], m["nsecs"], m.get("frame_id", "").encode(), acc.ctypes.data, gyr.ctypes.data)
+        elif k == KIND_JOINT_STATE:
+            p, v, e = (np.ascontiguousarray(m[x], np.float64) for x in ("position", "velocity", "effort"))
+            assert len(p) == len(v) == len(e)
+            rc = H.vilo_bag_write_joint_state(self.h, t, m["seq"], m["secs"], m["nsecs"], len(p), p.ctypes.data, v.ctypes.data, e.ctypes.data)
+        elif k == KIND_IMAGE:
+            d = np.ascontiguousarray(m["data"], np.uint8)
+            assert d.size == m["step"] * m["height"]
+            rc = H.vilo_bag_write_image(self.h, t, m["seq"], m["secs"], m["nsecs"], m.get("frame_id", "").encode(), m["height"], m["width"], m["encoding"].encode(),
+                                        m["step"], d.ctypes.data)
+        elif k == KIND_POINT_CLOUD:
+            pts = np.ascontiguousarray(m["points"], np.float32)
+            ch = np.ascontiguousarray(m["channels"], np.float32)
+            names = (C.c_char_p * len(m["channel_names"]))(*[n.encode() for n in m["channel_names"]])
+            assert ch.shape == (len(m["channel_names"]), len(pts))
+            rc = H.vilo_bag_write_point_cloud(self.h, t, m["seq"], m["secs"], m["nsecs"], len(pts), pts.ctypes.data, len(m["channel_names"]), names, ch.ctypes.data)
+        else:
+            raise ValueError("message kind %r" % k)
+        if rc != 0:
+            raise OSError("bag write failed")
+
+    def close(self):
+        if self.h:
+            rc = self.H.vilo_bag_writer_close(self.h)
+            self.h = None
+            if rc != 0:
+                raise OSError("bag close failed")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class BagError(Exception):
+    pass
+
+
+class BagReader:
+    """for m in BagReader(path): m is a dict (kind, topic, type, seq, secs, nsecs, rec_secs, rec_nsecs + the type's fields)"""
+    ERRORS = {-1: "I/O error", -2: "not a bag, or a damaged one", -3: "compressed chunk (bz2 / lz4): no decompressor in this build"}
+
+    def __init__(self, path):
+        self.H = _lib()
+        rc = C.c_int()
+        self.h = C.c_void_p(self.H.vilo_bag_reader_open(str(path).encode(), C.byref(rc)))
+        if not self.h:
+            raise BagError("%s: %s" % (path, self.ERRORS.get(rc.value, rc.value)))
+        cc, ck, ip = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self.H.vilo_bag_reader_info(self.h, C.byref(cc), C.byref(ck), C.byref(ip))
+        self.conn_count, self.chunk_count, self.index_pos = cc.value, ck.value, ip.value
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        o = BagMsg()
+        rc = self.H.vilo_bag_reader_next(self.h, C.byref(o))
+        if rc == 1:
+            raise StopIteration
+        if rc < 0:
+            raise BagError(self.ERRORS.get(rc, rc))
+        m = dict(kind=o.kind, topic=o.topic.decode(), type=o.type.decode(), seq=o.seq, secs=o.secs, nsecs=o.nsecs, rec_secs=o.rec_secs, rec_nsecs=o.rec_nsecs,
+                 frame_id=o.frame_id.decode())
+        if o.kind == KIND_IMU:
+            m.update(orientation=np.array(o.orientation), angular_velocity=np.array(o.angular_velocity), linear_acceleration=np.array(o.linear_acceleration))
+        elif o.kind == KIND_JOINT_STATE:
+            m.update(position=np.array(o.position[:min(o.n_position, 32)]), velocity=np.array(o.velocity[:min(o.n_velocity, 32)]),
+                     effort=np.array(o.effort[:min(o.n_effort, 32)]))
+        elif o.kind == KIND_IMAGE:
+            m.update(height=o.height, width=o.width, step=o.step, encoding=o.encoding.decode(), is_bigendian=o.is_bigendian,
+                     data=np.ctypeslib.as_array(o.data, (o.data_len,)).copy() if o.data_len else np.zeros(0, np.uint8))
+        elif o.kind == KIND_POINT_CLOUD:
+            n, nc = o.n_points, o.n_channels
+            m.update(points=np.ctypeslib.as_array(o.points, (n, 3)).copy() if n else np.zeros((0, 3), np.float32),
+                     channels=np.ctypeslib.as_array(o.channels, (nc, n)).copy() if n * nc else np.zeros((nc, 0), np.float32),
+                     channel_names=[o.channel_names[c].value.decode() for c in range(min(nc, 16))])
+        return m
+
+    def close(self):
+        if self.h:
+            self.H.vilo_bag_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# a synthetic stream as the reference's messages
+# ---------------------------------------------------------------------------------------------------------------------------------
+def stream_messages(frame, t_prev, seq0, rate=500.0, with_images=False):
+    """One Stream frame (samples of the interval (t_prev, header] + the features tracked in the image at `header`) as message dicts in the order
+    a recorder would have seen them: the IMU / JointState pairs, then the image pair (optional: 8 x 8 dummies), then the feature cloud.
+    JointState carries 12 joints + 4 feet: velocity[12 + i] the planner's contact flag, effort[12 + i] the foot force (main.cpp:274-278);
+    the synthetic stream has one contact signal, which goes into both. Returns (messages, next seq)."""
+    out, seq = [], seq0
+    n = len(frame["samples"])
+    h = 1.0 / rate
+    stamps = [t_prev + (i + 1) * h for i in range(n - 1)] + [frame["header"]]
+    for t, s in zip(stamps, frame["samples"]):
+        secs, nsecs = to_stamp(t)
+        out.append(dict(kind=KIND_IMU, topic=IMU_TOPIC, seq=seq, secs=secs, nsecs=nsecs, frame_id="imu", linear_acceleration=s[1:4].copy(),
+                        angular_velocity=s[4:7].copy()))
+        pos, vel, eff = np.zeros(16), np.zeros(16), np.zeros(16)
+        pos[:12], vel[:12] = s[7:19], s[19:31]
+        vel[12:], eff[12:] = s[31:35], s[31:35]
+        out.append(dict(kind=KIND_JOINT_STATE, topic=LEG_TOPIC, seq=seq, secs=secs, nsecs=nsecs, position=pos, velocity=vel, effort=eff))
+        seq += 1
+    secs, nsecs = to_stamp(frame["header"])
+    if with_images:
+        for topic in (IMAGE0_TOPIC, IMAGE1_TOPIC):
+            out.append(dict(kind=KIND_IMAGE, topic=topic, seq=seq, secs=secs, nsecs=nsecs, frame_id="cam", height=8, width=8, step=8, encoding="mono8",
+                            data=(np.arange(64, dtype=np.uint8) + (seq & 0xff)).astype(np.uint8)))
+    # one point per (feature, camera): x y z = the normalised image point; channels id, camera_id, p_u, p_v, velocity_x, velocity_y (main.cpp:204-234)
+    ids, obs, st = frame["ids"], frame["obs"], frame["stereo"]
+    pts, ch = [], [[] for _ in range(6)]
+    for i in range(len(ids)):
+        for cam in range(2 if st[i] else 1):
+            p = obs[i, 3 * cam:3 * cam + 3]
+            v = obs[i, 6 + 2 * cam:8 + 2 * cam]
+            pts.append(p)
+            for c, val in enumerate((ids[i], cam, 0.0, 0.0, v[0], v[1])):
+                ch[c].append(val)
+    out.append(dict(kind=KIND_POINT_CLOUD, topic=FEATURE_TOPIC, seq=seq, secs=secs, nsecs=nsecs, points=np.array(pts, np.float32).reshape(-1, 3),
+                    channels=np.array(ch, np.float32).reshape(6, -1), channel_names=["id", "camera_id", "p_u", "p_v", "velocity_x", "velocity_y"]))
+    return out, seq + 1
+
+
+def write_stream_bag(path, frames, t0, with_images=False, chunk_threshold=768 * 1024):
+    """frames: Stream.next() dicts in order; t0: the stamp just before the first frame's first sample. Returns the messages written."""
+    msgs, seq, t_prev = [], 0, t0
+    with BagWriter(path, chunk_threshold) as w:
+        for f in frames:
+            ms, seq = stream_messages(f, t_prev, seq, with_images=with_images)
+            for m in ms:
+                w.write(m)
+            msgs += ms
+            t_prev = f["header"]
+    return msgs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the node
+# ---------------------------------------------------------------------------------------------------------------------------------
+def contacts_from_joint_state(m, contact_sensor_type):
+    """main.cpp:274-278, 319-330: which four numbers reach Estimator::inputLeg as contact information"""
+    if contact_sensor_type == 2:
+        return np.asarray(m["effort"][NUM_DOF:NUM_DOF + NUM_LEG], np.float64)       # foot force sensor readings
+    return np.asarray(m["velocity"][NUM_DOF:NUM_DOF + NUM_LEG], np.float64)         # the planner's flags (type 1; type 0: in place of the absent filter)
+
+
+def replay(messages, mp, contact_sensor_type=1, imu_topic=IMU_TOPIC, leg_topic=LEG_TOPIC, feature_topic=FEATURE_TOPIC, on_image=None, sync_slop=0.5e-3):
+    """Feed messages to a sequence.MeasurementProcessor the way the reference's node feeds its estimator. IMU and JointState messages are paired
+    by stamp (the reference: an ApproximateTime synchroniser over two topics that "actually have the same time stamp", main.cpp:427-437): a
+    pair is the two queue heads when their stamps differ by less than sync_slop, otherwise the older head is dropped. on_image(k, header_t): called
+    after every processed image. Returns counters."""
+    cnt = dict(pairs=0, dropped=0, images=0, clouds=0, processed=0, other=0)
+    imu_q, leg_q = [], []
+    for m in messages:
+        k, topic = m["kind"], m["topic"]
+        if k == KIND_IMU and topic == imu_topic:
+            imu_q.append(m)
+        elif k == KIND_JOINT_STATE and topic == leg_topic:
+            leg_q.append(m)
+        elif k == KIND_IMAGE:
+            cnt["images"] += 1          # (getImageFromMsg's consumer, the feature tracker, is out of scope)
+            continue
+        elif k == KIND_POINT_CLOUD and topic == feature_topic:
+            cnt["clouds"] += 1
+            t = to_sec(m["secs"], m["nsecs"])
+            ch = m["channels"]
+            ids_f, cam = ch[0].astype(np.int64), ch[1].astype(np.int64)
+            order, ids, obs, stereo = {}, [], [], []
+            for i in range(len(ids_f)):           # featureFrame[feature_id].emplace_back(camera_id, xyz_uv_velocity)
+                fid = int(ids_f[i])
+                if fid not in order:
+                    order[fid] = len(ids)
+                    ids.append(fid); obs.append(np.zeros(11)); stereo.append(0)
+                o = obs[order[fid]]
+                c = int(cam[i])
+                o[3 * c:3 * c + 3] = m["points"][i].astype(np.float64)
+                o[6 + 2 * c:8 + 2 * c] = (ch[4][i], ch[5][i])
+                if c == 1:
+                    stereo[order[fid]] = 1
+            n = mp.input_feature(t, np.array(ids, np.int32), np.array(obs).reshape(-1, 11), np.array(stereo, np.uint8))
+            cnt["processed"] += n
+            if n and on_image:
+                on_image(cnt["processed"], t)
+            continue
+        else:
+            cnt["other"] += 1
+            continue
+        while imu_q and leg_q:
+            ti, tl = to_sec(imu_q[0]["secs"], imu_q[0]["nsecs"]), to_sec(leg_q[0]["secs"], leg_q[0]["nsecs"])
+            if abs(ti - tl) < sync_slop:
+                a, j = imu_q.pop(0), leg_q.pop(0)
+                s = np.zeros(35)
+                s[1:4], s[4:7] = a["linear_acceleration"], a["angular_velocity"]
+                s[7:19], s[19:31] = j["position"][:NUM_DOF], j["velocity"][:NUM_DOF]
+                s[31:35] = contacts_from_joint_state(j, contact_sensor_type)
+                mp.input_sample(ti, s)
+                cnt["pairs"] += 1
+                n = mp.process()
+                cnt["processed"] += n
+                if n and on_image:
+                    on_image(cnt["processed"], ti)
+            elif ti < tl:
+                imu_q.pop(0); cnt["dropped"] += 1
+            else:
+                leg_q.pop(0); cnt["dropped"] += 1
+    return cnt

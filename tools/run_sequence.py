@@ -1,6 +1,8 @@
 """Replay a synthetic sensor stream frame by frame through the sliding-window manager on the GPU and print, per image, the
 error of the newest pose / velocity against ground truth, the solver summary and the time per image.
     python tools/run_sequence.py [--images 60] [--robots 1] [--no-leg] [--dump DIR] [--csv FILE]
+    python tools/run_sequence.py --write-bag FILE [--images 60]     the synthetic stream as a ROS bag with the reference's topics
+    python tools/run_sequence.py --bag FILE [--contact-sensor-type 1] [--csv FILE]     replay a bag (cerberus_amd/rosbag.py: the reference's node)
 --csv writes robot 0's trajectory in the 20-column layout of the reference's VILO_RESULT_PATH file (src/main.cpp:156-196):
 time [ns], robot position (3), velocity (3), six Kalman-filter columns (no KF here: zeros), the mocap position (here: the synthetic
 ground truth), Rho1..Rho4 — so the reference's evaluation scripts read it unchanged."""
@@ -23,9 +25,43 @@ def main():
     ap.add_argument("--dump", default=None)
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--csv", default=None)
+    ap.add_argument("--write-bag", default=None, help="write the synthetic stream of robot 0 (IMU, JointState, feature clouds) to this bag and stop")
+    ap.add_argument("--bag", default=None, help="replay this bag instead of a synthetic stream (one robot)")
+    ap.add_argument("--contact-sensor-type", type=int, default=1, help="--bag: 0 / 1 the planner's flags (0: in place of the absent Kalman filter), 2 foot forces")
     a = ap.parse_args()
     cfg = synth.default_config()
+    if a.write_bag:
+        from cerberus_amd import rosbag
+        stream = sequence.Stream(cfg, seed=100)
+        frames = [stream.next() for _ in range(a.images)]
+        msgs = rosbag.write_stream_bag(a.write_bag, frames, frames[0]["header"] - len(frames[0]["samples"]) / 500.0)
+        print("%s: %d messages of %d images (%d bytes)" % (a.write_bag, len(msgs), a.images, os.path.getsize(a.write_bag)))
+        return
     ctx = api.Context(cfg, 0)
+    if a.bag:
+        from cerberus_amd import rosbag
+        sw = sequence.SlidingWindow(ctx, cfg, use_leg=0 if a.no_leg else 1)
+        mp = sequence.MeasurementProcessor(sw)
+        csv = open(a.csv, "w") if a.csv else None
+        t_last = [time.perf_counter()]
+
+        def on_image(k, t):
+            st = sw.state()
+            j = api.T.F - 2 if st["n_optimizations"] > 0 else max(st["frame_count"] - 1, 0)
+            now = time.perf_counter()
+            if not a.quiet:
+                print("img %3d t %.6f frame_count %2d feats %3d solves %3d  p = %s  %.1f ms" % (k, t, st["frame_count"], st["feature_count"], st["n_optimizations"],
+                                                                                             np.array2string(st["Ps"][j], precision=4), 1e3 * (now - t_last[0])))
+            t_last[0] = now
+            if csv and st["n_optimizations"] > 0:
+                cols = ["%.0f" % (t * 1e9)] + ["%.5f" % v for v in list(st["Ps"][j]) + list(st["Vs"][j]) + [0.0] * 9 + list(st["Rho"][j])]
+                csv.write(",".join(cols) + ",\n")
+
+        cnt = rosbag.replay(rosbag.BagReader(a.bag), mp, contact_sensor_type=a.contact_sensor_type, on_image=on_image)
+        if csv:
+            csv.close()
+        print("%s: %s" % (a.bag, cnt))
+        return
     streams = [sequence.Stream(cfg, seed=100 + r, t0=0.37 * r) for r in range(a.robots)]
     if a.dump:
         os.makedirs(a.dump, exist_ok=True)
