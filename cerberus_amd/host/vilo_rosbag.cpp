@@ -240,7 +240,7 @@ bool BagWriter::write(const std::string &topic, int kind, uint32_t secs, uint32_
   }
   const Conn &c = conns_[it->second];
   if (c.kind != kind) return false;
-  if (!conn_in_chunk_[c.id]) { connection_record(c, &chunk_); conn_in_chunk_[c.id] = true; }
+  if (!conn_in_chunk_[c.id]) { connection_record(c, &chunk_); conn_in_chunk_[c.id] = true; }   // (once per bag, in the chunk of the connection's first message: as rosbag does)
   const uint64_t t = (uint64_t)secs | ((uint64_t)nsecs << 32);
   const uint64_t tcmp = ((uint64_t)secs << 32) | nsecs;   // (ordering only)
   if (chunk_index_.empty()) { chunk_t0_ = tcmp; chunk_t1_ = tcmp; }   // (the chunk's first message)
@@ -270,7 +270,7 @@ bool BagWriter::flush_chunk() {
     info.counts[kv.first] = (uint32_t)kv.second.size();
   }
   infos_.push_back(info);
-  chunk_.clear(); chunk_index_.clear(); conn_in_chunk_.clear();
+  chunk_.clear(); chunk_index_.clear();
   return std::fwrite(out.data(), 1, out.size(), f_) == out.size();
 }
 bool BagWriter::close() {

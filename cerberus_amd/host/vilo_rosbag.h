@@ -101,7 +101,7 @@ class BagWriter {
   std::map<std::string, uint32_t> by_topic_;
   std::vector<uint8_t> chunk_;
   std::map<uint32_t, std::vector<IndexEntry>> chunk_index_;
-  std::map<uint32_t, bool> conn_in_chunk_;
+  std::map<uint32_t, bool> conn_in_chunk_;   // connection record written (in the chunk of its first message)
   uint64_t chunk_t0_ = 0, chunk_t1_ = 0;
   std::vector<ChunkInfo> infos_;
 };

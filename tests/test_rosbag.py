@@ -94,11 +94,12 @@ def test_every_message_type_round_trips_bit_for_bit(tmp_path):
             msgs.append(dict(kind=rb.KIND_POINT_CLOUD, topic="/feature_tracker/feature", seq=i, secs=secs, nsecs=nsecs, points=rng.normal(size=(n, 3)).astype(np.float32),
                              channels=rng.normal(size=(6, n)).astype(np.float32), channel_names=["id", "camera_id", "p_u", "p_v", "velocity_x", "velocity_y"]))
     p = tmp_path / "all.bag"
-    with rb.BagWriter(p, chunk_threshold=4096) as w:   # small chunks: many of them, connections repeated per chunk
+    with rb.BagWriter(p, chunk_threshold=4096) as w:   # small chunks: many of them; a connection record only in the chunk of the connection's first message
         for m in msgs:
             w.write(m)
     r = rb.BagReader(p)
     assert r.conn_count == 5 and r.chunk_count > 5 and r.index_pos > 4096
+    assert p.read_bytes()[:r.index_pos].count(b"type=sensor_msgs/") == 5      # (the connection records inside the chunks: one per topic)
     back = list(r)
     assert len(back) == len(msgs)
     for a, b in zip(msgs, back):
