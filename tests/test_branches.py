@@ -82,8 +82,11 @@ def test_runs_of_rejected_steps(ctx, cfg, ocfg, seed):
                                      sig_ba=0.3, sig_bg=0.05)
     assert br[REJECTED_RUN] >= 2 and br[ACCEPTED] >= 1, br
     # (the start is metres / tens of degrees off and the first costs are ~1e11: the linear systems are badly conditioned and the two
-    # implementations drift apart by ~1e-4 relative over the accepted steps; what is pinned here is the accept / reject / radius logic)
-    _compare(summ, osum, w_g, w_o, 12, tol=1e-3)
+    # implementations drift apart over the accepted steps; what is pinned here is the accept / reject / radius logic, and the drift stays
+    # within a small multiple of what was measured — cost trace / states, single-wave form: seed 42 1.1e-7 / 2.1e-8, seed 48
+    # 3.0e-4 / 1.3e-5 (one Gauss-Newton solve of a reduced system of condition ~1e10), seed 51 9.5e-6 / 1.3e-6; the eight-wave form the
+    # same to a factor of two. test_single_steps_* compares the same starts one iteration at a time at 1e-8 / 1e-6.)
+    _compare(summ, osum, w_g, w_o, 12, tol={42: 3e-6, 48: 1e-3, 51: 1e-4}[seed])
 
 
 def test_mu_escalation(ctx, cfg, ocfg):

@@ -43,8 +43,9 @@ def _close(a, b, tol):
 @pytest.mark.parametrize("form", ["split", "mw", "mw8"])
 def test_forms_agree_on_plain_windows(results, form):
     _close(results[form]["plain"], results["wave"]["plain"], 1e-9)
-    # (badly conditioned far-off start: the forms' different summation orders show at ~1e-5 after 12 iterations; the decisions must agree)
-    _close(results[form]["rejected"], results["wave"]["rejected"], 1e-3)
+    # (badly conditioned far-off start: the forms' different summation orders show at 1e-6 .. 1e-5 after 12 iterations — measured: it passes
+    # at 1e-5 and not at 1e-6 —; the decisions must agree)
+    _close(results[form]["rejected"], results["wave"]["rejected"], 1e-4)
     assert all(w["successful"] + 2 <= w["iterations"] for w in results[form]["rejected"])   # (rejected steps happened)
 
 
