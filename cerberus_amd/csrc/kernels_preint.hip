@@ -75,113 +75,124 @@ __device__ void jac_cov_update(const double *Fm, const double *Vm, const double 
 
 // The same update for the 31-dim IMU-leg state on the FP64 matrix cores: all four products are 32 x 32 (x 32 or x 48) GEMMs of
 // zero-padded LDS matrices, 2 x 2 output tiles of v_mfma_f64_16x16x4 (lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16] of a
-// 4-deep k-step and owns C[(l / 16) + 4 r][l % 16], r = 0..3). One wave, 144 MFMAs per sample instead of ~4300 LDS-fed FMAs per lane.
+// 4-deep k-step and owns C[(l / 16) + 4 r][l % 16], r = 0..3).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 constexpr int FLD = 33;        // leading dimension of the 32 x 32 matrices (odd: rows land in different LDS banks)
 constexpr int VLD = pb::VLD;   // of the 32 x 48 noise Jacobian
 constexpr int FCLD = pb::FCLD; // of dF = F - I, stored with its 16 non-zero columns only (preint_blocks.hpp)
 
-// C(32 x 32) = A(32 x 4 KS) * op(B): row-major A (lda), B given as Bt = B^T row-major (ldb) when BT, else B row-major
-// ONLY0 / ONLY1: bit kk set = k-step kk of both operands is zero in rows 16 .. 31 / in rows 0 .. 15 (a structural property of the caller's
-// matrices): three of the step's four products are exact zeros and are not issued, the operands of the zero half are not read.
-template <int KS, bool BT, unsigned ONLY0 = 0u, unsigned ONLY1 = 0u>
-__device__ __forceinline__ void gemm32(const double *A, int lda, const double *B, int ldb, const double *kscale, mfma_d4 acc[4]) {
-  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 4 * kk + lk;
-    const bool lo = !((ONLY1 >> kk) & 1u), hi = !((ONLY0 >> kk) & 1u);   // which row halves of the operands carry anything
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-    if (lo) { a0 = A[lr * lda + k]; b0 = BT ? B[lr * ldb + k] : B[k * ldb + lr]; }
-    if (hi) { a1 = A[(16 + lr) * lda + k]; b1 = BT ? B[(16 + lr) * ldb + k] : B[k * ldb + 16 + lr]; }
-    if (kscale) { const double sc = kscale[k]; a0 *= sc; a1 *= sc; }
-    if (lo) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
-    if (lo && hi) {
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[2], 0, 0, 0);
-    }
-    if (hi) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[3], 0, 0, 0);
-  }
-}
-__device__ __forceinline__ void store32(double *C, int ldc, const mfma_d4 acc[4]) {
-  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr] = acc[t][r];
-}
 // F = I + dF, and dF has non-zero columns only at K = {3 .. 8, 21 .. 30} (d/d theta, d/d v, d/d ba, d/d bg, d/d rho): 16 of 31
 // (compact order: preint_blocks.hpp — the two k-steps whose columns live in rows 0 .. 15 only come first and cost half the products).
-// With dFc = (F - I)[:, K] in LDS (32 x 16, leading dimension FCLD) the products keep their identity part in the accumulators and
-// contract over the 16 columns of K only:
-//   F X = X + dF[:, K] X[K, :],   Q F^T = Q + Q[:, K] dF[:, K]^T        (4 k-steps instead of 8 each).
-__device__ __forceinline__ int fk_col(int k) { return pb::fk_col(k); }
-// acc (32 x 32, accumulator order) += dFc * B[K, :]   (B row-major 32 x FLD in LDS); all 16 operands of a lane in flight first
-__device__ __forceinline__ void gemm32_fk(const double *A, const double *B, mfma_d4 acc[4]) {
-  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
-  double a0[4], a1[4], b0[4], b1[4];
+// With dFc = (F - I)[:, K] (32 x 16, leading dimension FCLD) the products keep their identity part in the accumulators and contract
+// over the 16 columns of K only:
+//   F X = X + dF[:, K] X[K, :],   Q F^T = Q + Q[:, K] dF[:, K]^T        (4 k-steps instead of 8 each),
+// and V N V^T has four of its 12 k-steps (4 noise columns each) in one half of the rows only (preint_blocks.hpp: columns 12 .. 15 are the
+// bias random walks' rows 21 .. 26; 32 .. 35 the foot-position noise of legs 0 / 1, rows 9 .. 14; 40 .. 47 leg 3's, rows 18 .. 20, the calf
+// lengths' rows 27 .. 30 and padding): three of such a step's four products are exact zeros and are not issued. 78 matrix instructions
+// per sample: jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468).
+//
+// The consumer wave of the pair below takes the step's dF and V operands out of LDS in one go, so that the producer can build the next
+// step's blocks while these products run.
+constexpr int PAIR_THREADS = 128;   // the IMU-leg kernels' workgroup: producer + consumer wave (preint_imu_leg_body)
+struct FvOperands {
+  double f0[4], f1[4];     // dF[lr][4 kk + lk], dF[16 + lr][4 kk + lk] (compact columns): the A operand of dF X and the B operand of Q dF^T
+  double v0[12], v1[12];   // V[lr][4 kk + lk], V[16 + lr][4 kk + lk]: both operands of V N V^T
+  double sc[12];           // nd[4 kk + lk]
+};
+__device__ __forceinline__ void load_fv_operands(const double *dFm, const double *Vm, const double *nd, FvOperands &o) {
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const int kc = 4 * kk + lk, k = fk_col(kc);
-    a0[kk] = A[lr * FCLD + kc]; a1[kk] = A[(16 + lr) * FCLD + kc];
-    b0[kk] = B[k * FLD + lr]; b1[kk] = B[k * FLD + 16 + lr];
+    const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);
+    o.f0[kk] = dFm[lr * FCLD + 4 * kk + lk];
+    o.f1[kk] = hi ? dFm[(16 + lr) * FCLD + 4 * kk + lk] : 0.0;
   }
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);   // (rows 16 .. 31 of dF are zero in the k-steps of the mask: a1 = 0)
-    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
-    if (hi) {
-      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
-    }
-  }
-}
-// acc += A[:, K] * dFc^T
-__device__ __forceinline__ void gemm32_fk_t(const double *A, const double *Bt, mfma_d4 acc[4]) {
-  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
-  double a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int kc = 4 * kk + lk, k = fk_col(kc);
-    a0[kk] = A[lr * FLD + k]; a1[kk] = A[(16 + lr) * FLD + k];
-    b0[kk] = Bt[lr * FCLD + kc]; b1[kk] = Bt[(16 + lr) * FCLD + kc];
-  }
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);   // (here dF is the B operand: b1 = 0 in the k-steps of the mask)
-    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc[0], 0, 0, 0);
-    if (hi) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], acc[2], 0, 0, 0);
-    if (hi) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc[3], 0, 0, 0);
+  for (int kk = 0; kk < 12; ++kk) {
+    const bool lo = !((pb::V_KSTEPS_ROWS_HI_ONLY >> kk) & 1u), hi = !((pb::V_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);
+    o.v0[kk] = lo ? Vm[lr * VLD + 4 * kk + lk] : 0.0;
+    o.v1[kk] = hi ? Vm[(16 + lr) * VLD + 4 * kk + lk] : 0.0;
+    o.sc[kk] = nd[4 * kk + lk];
   }
 }
-__device__ __forceinline__ void load32(const double *C, int ldc, mfma_d4 acc[4]) {
-  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
+__device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }   // (one wave's LDS operations complete in program order: only the compiler must keep it)
+// The consumer's LDS keeps of the 32 x 32 jacobian / covariance only what the next product reads (the matrices themselves live in its
+// accumulators from one step to the next): the rows K = {3 .. 8, 21 .. 30} as the B operand of dF X[K, :], the columns K of Q as the A
+// operand of Q[:, K] dF^T — 8.6 KB instead of two full operand-order copies (16.9 KB); the difference holds the producer's block descriptors.
+__device__ __forceinline__ bool in_K(int c) { return (c >= 3 && c <= 8) || (c >= 21 && c <= 30); }
+__device__ __forceinline__ void store_rows_K(double *XK, const mfma_d4 acc[4]) {   // XK[kidx(row)][col] = X[row][col], row in K
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = C[(16 * (t >> 1) + lk + 4 * r) * ldc + 16 * (t & 1) + lr];
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * (t >> 1) + lk + 4 * r;
+      if (in_K(row)) XK[pb::kidx(row) * FLD + 16 * (t & 1) + lr] = acc[t][r];
+    }
 }
-// jacobian <- F jacobian ; covariance <- F covariance F^T + V diag(nd) V^T   (imu_leg_integration_base.cpp:467-468); dFm = (F - I)[:, K].
-// Q = F P overwrites P in LDS once every product that reads P has its operands. accJ / accP: the jacobian and the covariance in
-// accumulator order, the same values as Jm / Pm (they stay in registers from one step to the next: LDS holds the operand-order copy).
-__device__ __forceinline__ void jac_cov_update_mfma(const double *dFm, const double *Vm, const double *nd, double *Jm, double *Pm, mfma_d4 accJ[4],
-                                                    mfma_d4 accP[4]) {
-  gemm32_fk(dFm, Jm, accJ);   // J + dF J
-  gemm32_fk(dFm, Pm, accP);   // Q = P + dF P
-  __syncthreads();
-  store32(Jm, FLD, accJ);
-  store32(Pm, FLD, accP);
-  __syncthreads();
-  gemm32_fk_t(Pm, dFm, accP);                        // Q + Q dF^T
-  // + V N V^T. Of V's 12 k-steps (4 noise columns each) four touch one half of the rows only (preint_blocks.hpp: columns 12 .. 15 are the bias
-  // random walks' rows 21 .. 26; 32 .. 35 the foot-position noise of legs 0 / 1, rows 9 .. 14; 40 .. 47 leg 3's, rows 18 .. 20, the calf
-  // lengths' rows 27 .. 30 and padding): 36 instead of 48 matrix instructions
-  gemm32<12, true, pb::V_KSTEPS_ROWS_LO_ONLY, pb::V_KSTEPS_ROWS_HI_ONLY>(Vm, VLD, Vm, VLD, nd, accP);
-  __syncthreads();
-  store32(Pm, FLD, accP);
-  __syncthreads();
+__device__ __forceinline__ void store_cols_K(double *XK, const mfma_d4 acc[4]) {   // XK[row][kidx(col)] = X[row][col], col in K
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = 16 * (t & 1) + lr;
+    if (in_K(col)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) XK[(16 * (t >> 1) + lk + 4 * r) * FCLD + pb::kidx(col)] = acc[t][r];
+    }
+  }
+}
+constexpr int JK_N = 16 * FLD, PQ_N = 32 * FCLD;   // PQ: P[K, :] (16 x FLD = 528) and Q[:, K] (32 x FCLD = 544) take turns in one region
+static_assert(PQ_N >= 16 * FLD, "the region holds either");
+__device__ __forceinline__ void jac_cov_update_regs(const FvOperands &o, double *JK, double *PQ, mfma_d4 accJ[4], mfma_d4 accP[4]) {
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+  auto fk = [&](const double *BK, mfma_d4 acc[4]) {   // acc += dFc * X[K, :] (BK: the rows K of X, compact order); operands in flight first
+    double b0[4], b1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { const int kc = 4 * kk + lk; b0[kk] = BK[kc * FLD + lr]; b1[kk] = BK[kc * FLD + 16 + lr]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.f0[kk], b0[kk], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.f0[kk], b1[kk], acc[1], 0, 0, 0);
+      if (hi) {
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.f1[kk], b0[kk], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.f1[kk], b1[kk], acc[3], 0, 0, 0);
+      }
+    }
+  };
+  fk(JK, accJ);   // J + dF J
+  fk(PQ, accP);   // Q = P + dF P
+  wave_fence();
+  store_rows_K(JK, accJ);
+  store_cols_K(PQ, accP);   // Q[:, K]
+  wave_fence();
+  {   // Q + Q[:, K] dFc^T
+    double a0[4], a1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { const int kc = 4 * kk + lk; a0[kk] = PQ[lr * FCLD + kc]; a1[kk] = PQ[(16 + lr) * FCLD + kc]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bool hi = !((pb::DF_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);
+      accP[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], o.f0[kk], accP[0], 0, 0, 0);
+      if (hi) accP[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], o.f1[kk], accP[1], 0, 0, 0);
+      accP[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], o.f0[kk], accP[2], 0, 0, 0);
+      if (hi) accP[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], o.f1[kk], accP[3], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 12; ++kk) {   // + V N V^T
+    const bool lo = !((pb::V_KSTEPS_ROWS_HI_ONLY >> kk) & 1u), hi = !((pb::V_KSTEPS_ROWS_LO_ONLY >> kk) & 1u);
+    const double a0 = o.v0[kk] * o.sc[kk], a1 = o.v1[kk] * o.sc[kk];
+    if (lo) accP[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, o.v0[kk], accP[0], 0, 0, 0);
+    if (lo && hi) {
+      accP[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, o.v1[kk], accP[1], 0, 0, 0);
+      accP[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, o.v0[kk], accP[2], 0, 0, 0);
+    }
+    if (hi) accP[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, o.v1[kk], accP[3], 0, 0, 0);
+  }
+  wave_fence();
+  store_rows_K(PQ, accP);   // P[K, :] of the next step
+  wave_fence();
 }
 
 __device__ inline void put33(double *M, int ld, int r0, int c0, const m3 &A) {
@@ -223,26 +234,35 @@ __device__ __forceinline__ void leg_sample_terms(const vilo_config &cfg, const v
 // One IMULegIntegrationBase, batch form (STREAM = false: constructor + every push_back of the interval, state starts at the
 // identity) or streaming form (STREAM = true: the object lives in HBM between calls, this call push_back()s the new samples).
 // Both run the same arithmetic in the same order: pushing an interval in pieces gives bitwise the batch result.
+//
+// A workgroup is a PAIR of waves: the producer (wave 0) carries the state and builds each step's dF, V and noise diagonal in LDS (FP64
+// VALU and LDS work, ~ 9 k cycles a step); the consumer (wave 1) takes its matrix-instruction operands of that step out of LDS into registers
+// in one go, hands the block back and runs the 78 matrix instructions of jacobian <- F jacobian, covariance <- F covariance F^T + V N V^T
+// (~ 5 k cycles of the matrix pipe) while the producer is already on the next step. One s_barrier per step ("blocks ready"); "blocks taken"
+// is an LDS flag the producer finds set long before it needs it. Neither role needs more than half the register file, so the two waves
+// of four intervals share a CU's four SIMDs as before (LDS: four per CU) and a step costs max(producer, consumer) instead of the sum.
 template <bool STREAM>
 __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, const vilo_sample *samples, int s_begin, int s_end, const double *ln, vilo_preint *outp,
                                     PreintStream *st, double *terms /* HBM scratch of this interval: 4 * LT_N doubles per sample (+ one sample when STREAM) */,
                                     double *ff_io = nullptr /* repropagate(): the object's force filter (36 doubles, O_FF layout), in and out */) {
   // dF (its 16 non-zero columns), V, the step's 3 x 3 matrix pool, coefficients and noise diagonal: one array, the offsets of
   // preint_blocks.hpp. Padded to 32 rows (48 noise columns) with odd leading dimensions: row 31 and noise 46, 47 stay zero, so the FP64
-  // MFMA tiles of jac_cov_update_mfma need no masks.
+  // MFMA tiles of jac_cov_update_regs need no masks.
   __shared__ double Ls[pb::PB_TOTAL];
-  // (Q = F P overwrites P once every product that reads P has its operands: four intervals per CU, one per SIMD — 39 776 B each)
-  __shared__ double Jm[32 * FLD], Pm[32 * FLD];
+  __shared__ double JK[JK_N], PQ[PQ_N];   // the consumer's (jac_cov_update_regs)
+  __shared__ int fv_taken;                // steps whose operands the consumer has in registers
+  // the producer's descriptors of the lane-parallel block construction: product / block (8 round + lane / 9), entry lane % 9 (lane 63: the
+  // no-op). In LDS, [round][lane]: as registers they would put the producer over the half register file it shares a SIMD in.
+  __shared__ unsigned pdesc[pb::N_PROD_ROUNDS * 64];
+  __shared__ unsigned long long bdesc[pb::N_BLK_ROUNDS * 64];
   double *const Fm = Ls + pb::O_FC, *const Vm = Ls + pb::O_VM, *const nd = Ls + pb::O_ND;
-  const int lane = threadIdx.x;
-  // this lane's descriptors of the lane-parallel block construction: product / block (8 round + lane / 9), entry lane % 9 (lane 63: the no-op)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool producer = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
   const int pb_grp = lane / 9, pb_ent = lane - 9 * pb_grp;
-  unsigned pdesc[pb::N_PROD_ROUNDS];
-  unsigned long long bdesc[pb::N_BLK_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[r] = c_pb_tab.prod[8 * r + pb_grp];
-#pragma unroll
-  for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) bdesc[r] = c_pb_tab.blk[8 * r + pb_grp];
+  if (tid < 64) {
+    for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[64 * r + lane] = c_pb_tab.prod[8 * r + pb_grp];
+    for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) bdesc[64 * r + lane] = c_pb_tab.blk[8 * r + pb_grp];
+  }
   if (STREAM) ln = st->rec.lin_ba;   // lin_ba(3) lin_bg(3) lin_rho(4) are consecutive in vilo_preint
   const v3 ba = ld3(ln), bg = ld3(ln + 3);
   double rho[4] = {ln[6], ln[7], ln[8], ln[9]};
@@ -261,20 +281,16 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     dq = mkq(r.delta_q[3], r.delta_q[0], r.delta_q[1], r.delta_q[2]);
     for (int j = 0; j < 4; ++j) eps[j] = ld3(r.delta_eps + 3 * j);
     sum_dt = r.sum_dt;
-    for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = 0.0; Pm[e] = 0.0; }
-    __syncthreads();
-    for (int e = lane; e < 31 * 31; e += 64) { Jm[(e / 31) * FLD + (e % 31)] = r.jacobian[e]; Pm[(e / 31) * FLD + (e % 31)] = r.covariance[e]; }
-  } else {
-    for (int e = lane; e < 32 * FLD; e += 64) { Jm[e] = ((e / FLD) == (e % FLD) && e / FLD < 31) ? 1.0 : 0.0; Pm[e] = 0.0; }
   }
   // dF = F - I and V have a fixed sparsity pattern: zeroed once, every sample overwrites the same entries
-  for (int e = lane; e < pb::PB_TOTAL; e += 64) Ls[e] = 0.0;
+  for (int e = tid; e < pb::PB_TOTAL; e += 128) Ls[e] = 0.0;
+  if (tid == 0) fv_taken = 0;
   __syncthreads();
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
-  if (lane < 9) { Ls[pb::O_POOL + 9 * pb::S_RBR + lane] = cfg.R_br[lane]; Ls[pb::O_POOL + 9 * pb::S_I + lane] = (lane % 4 == 0) ? 1.0 : 0.0; }
-  if (lane == 0) {
+  if (tid < 9) { Ls[pb::O_POOL + 9 * pb::S_RBR + lane] = cfg.R_br[lane]; Ls[pb::O_POOL + 9 * pb::S_I + lane] = (lane % 4 == 0) ? 1.0 : 0.0; }
+  if (tid == 0) {
     const double an2 = cfg.acc_n * cfg.acc_n, anz2 = cfg.acc_n_z * cfg.acc_n_z, gn2 = cfg.gyr_n * cfg.gyr_n;
     const double aw2 = cfg.acc_w * cfg.acc_w, gw2 = cfg.gyr_w * cfg.gyr_w, pn2 = cfg.phi_n * cfg.phi_n, dpn2 = cfg.dphi_n * cfg.dphi_n;
     nd[0] = an2; nd[1] = an2; nd[2] = anz2; nd[3] = gn2; nd[4] = gn2; nd[5] = gn2;
@@ -285,13 +301,13 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   // IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) resets what the constructor sets EXCEPT the contact-force filter
   // (foot_force_min / max / window / window_idx / var, :29-41): a re-integration starts from the filter state the previous pass over the
   // samples left in the object (contact_sensor_type 2 only: the other types have no filter)
-  if (!STREAM && ff_io && cfg.contact_sensor_type == 2 && lane < 36) ffs[lane] = ff_io[lane];
-  if (STREAM && lane < 36) ffs[lane] = lane < 4 ? st->ff_min[lane] : lane < 8 ? st->ff_max[lane - 4] : lane < 12 ? st->ff_var[lane - 8] : lane < 32 ? st->ff_win[lane - 12] : (double)st->ff_idx[lane - 32];
+  if (!STREAM && ff_io && cfg.contact_sensor_type == 2 && tid < 36) ffs[lane] = ff_io[lane];
+  if (STREAM && tid < 36) ffs[lane] = lane < 4 ? st->ff_min[lane] : lane < 8 ? st->ff_max[lane - 4] : lane < 12 ? st->ff_var[lane - 8] : lane < 32 ? st->ff_win[lane - 12] : (double)st->ff_idx[lane - 32];
   // leg terms of every sample the steps below touch, lane = (sample, leg); slot 0 = the sample before the first step
   // (batch: the constructor's sample; streaming: the last sample of the previous push)
   {
     const int nslots = s_end - s_begin + (STREAM ? 1 : 0);
-    for (int idx = lane; idx < 4 * nslots; idx += 64) {
+    for (int idx = tid; idx < 4 * nslots; idx += 128) {
       const int slot = idx >> 2, j = idx & 3;
       const vilo_sample &ss = (STREAM && slot == 0) ? st->last : samples[s_begin + slot - (STREAM ? 1 : 0)];
       const double rho_j = j == 0 ? rho[0] : (j == 1 ? rho[1] : (j == 2 ? rho[2] : rho[3]));   // (a lane-indexed register array would go to scratch)
@@ -300,9 +316,42 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     __syncthreads();
   }
 
-  mfma_d4 accJ[4], accP[4];
-  load32(Jm, FLD, accJ);
-  load32(Pm, FLD, accP);
+  vilo_preint &o = *outp;
+  const int si_first = STREAM ? s_begin : s_begin + 1;
+  if (!producer) {
+    // jacobian and covariance in accumulator order (register r of tile t of lane (lr, lk): row 16 (t / 2) + lk + 4 r, column 16 (t % 2) + lr):
+    // the object's own (streaming), I and 0 (a fresh integration); row / column 31 are padding
+    mfma_d4 accJ[4], accP[4];
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (t >> 1) + lk + 4 * r, col = 16 * (t & 1) + lr;
+        const bool in = row < 31 && col < 31;
+        if (STREAM) { accJ[t][r] = in ? st->rec.jacobian[row * 31 + col] : 0.0; accP[t][r] = in ? st->rec.covariance[row * 31 + col] : 0.0; }
+        else { accJ[t][r] = (in && row == col) ? 1.0 : 0.0; accP[t][r] = 0.0; }
+      }
+    store_rows_K(JK, accJ);
+    store_rows_K(PQ, accP);
+    int n_taken = 0;
+    for (int si = si_first; si < s_end; ++si) {
+      __syncthreads();   // this step's dF, V, nd are in LDS
+      FvOperands op;
+      load_fv_operands(Fm, Vm, nd, op);
+      __hip_atomic_store(&fv_taken, ++n_taken, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the loads: LDS is in order)
+      jac_cov_update_regs(op, JK, PQ, accJ, accP);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (t >> 1) + lk + 4 * r, col = 16 * (t & 1) + lr;
+        if (row < 31 && col < 31) { o.jacobian[row * 31 + col] = accJ[t][r]; o.covariance[row * 31 + col] = accP[t][r]; }
+      }
+    return;
+  }
+  // ---- the producer ----
   // the records of a step's two samples, one step ahead of their use: element lane + 64 q of [endpoint][leg][LT_N]
   double rec[6];
   int rec_dst[6], rec_src[6];
@@ -319,11 +368,9 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
 #pragma unroll
     for (int q = 0; q < 6; ++q) rec[q] = src[rec_src[q]];
   };
-  {
-    const int si0 = STREAM ? s_begin : s_begin + 1;
-    if (si0 < s_end) load_records(si0);
-  }
-  for (int si = STREAM ? s_begin : s_begin + 1; si < s_end; ++si) {
+  if (si_first < s_end) load_records(si_first);
+  int n_built = 0;
+  for (int si = si_first; si < s_end; ++si) {
     const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
     const double dt = s1.dt;
     const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
@@ -386,10 +433,10 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
         pb::coefficients(dt, Ls + pb::O_COEF);
       }
     }
-    __syncthreads();
+    wave_fence();
     // first-level products R_e X and -(R_e g_0)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
+    for (int r = 0; r < 4; ++r) pb::product_entry(pdesc[64 * r + lane], pb_ent, Ls);
     pb::gvec_entry(lane, Ls);
     // the halves q_e v of the leg-odometry velocities (:245): lane 2 leg + endpoint, lanes 0 .. 7
     {
@@ -398,16 +445,18 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       const v3 r = qrot(Q, ld3(Ls + pb::O_VV + 3 * q));
       if (lane < 8) st3(Ls + pb::O_LOV + 3 * q, r);
     }
-    __syncthreads();
+    wave_fence();
     // second level: (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e
 #pragma unroll
-    for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[r], pb_ent, Ls);
+    for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[64 * r + lane], pb_ent, Ls);
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
     for (int j = 0; j < 4; ++j) {
       lo_v[j] = (ld3(Ls + pb::O_LOV + 6 * j) + ld3(Ls + pb::O_LOV + 6 * j + 3)) * 0.5;
       r_eps[j] = eps[j] + lo_v[j] * dt;
     }
+    // nd, dF and V of the previous step: the consumer has them in registers (set ~ a step ago)
+    while (__hip_atomic_load(&fv_taken, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_built) __builtin_amdgcn_s_sleep(1);
     if (lane == 0) {
       double unc[12], rho_unc[4];
       if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
@@ -436,20 +485,19 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       for (int k = 0; k < 12; ++k) nd[30 + k] = unc[k];
       for (int k = 0; k < 4; ++k) nd[42 + k] = rho_unc[k];
     }
-    __syncthreads();
+    wave_fence();
 #pragma unroll
-    for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[r], pb_ent, Ls);
+    for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
     pb::tail_entry(lane, dt, Ls);
-    __syncthreads();
-    jac_cov_update_mfma(Fm, Vm, nd, Jm, Pm, accJ, accP);
+    __syncthreads();   // blocks ready: the consumer takes them
+    ++n_built;
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
     sum_dt += dt;
   }
-  vilo_preint &o = *outp;
   if (!STREAM && ff_io && cfg.contact_sensor_type == 2) {
-    __syncthreads();   // (lane 0's last filter update)
+    wave_fence();   // (lane 0's last filter update)
     if (lane < 36) ff_io[lane] = ffs[lane];
   }
   if (lane == 0) {
@@ -467,13 +515,9 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
       }
     }
   }
-  for (int e = lane; e < 31 * 31; e += 64) {
-    o.jacobian[e] = Jm[(e / 31) * FLD + (e % 31)];
-    o.covariance[e] = Pm[(e / 31) * FLD + (e % 31)];
-  }
 }
 
-__global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
+__global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) k_preint_imu_leg(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets,
                                                        const double *lin, vilo_preint *out, double *terms) {
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -483,7 +527,7 @@ __global__ void __launch_bounds__(64) k_preint_imu_leg(int n, const vilo_config 
 // IMULegIntegrationBase::repropagate (imu_leg_integration_base.cpp:62-86) for every live interval of a resident batch, at the biases of
 // the candidate state the next linearisation pass evaluates: the record an interval's factor reads is integrated again from its samples
 // with linearized_ba / bg / rho = the candidate's (BASELINE configs[2]: "K1 re-propagation of all 10 intervals inside the iteration").
-__global__ void __launch_bounds__(64) k_repropagate(BatchDev b, const vilo_config *cfgp, int mode) {
+__global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) k_repropagate(BatchDev b, const vilo_config *cfgp, int mode) {
   __shared__ double lin_s[10];
   __shared__ int same_s;
   const int f = blockIdx.x, win = f / 10, k = f % 10;
@@ -507,7 +551,7 @@ __global__ void __launch_bounds__(64) k_repropagate(BatchDev b, const vilo_confi
 }
 
 // push_back() on device-resident objects: workgroup k appends samples[offsets[k] .. offsets[k+1]) to stream ids[k]
-__global__ void __launch_bounds__(64) k_preint_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
+__global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) k_preint_stream_push(int n, const vilo_config *cfgp, const vilo_sample *samples, const int *offsets, const int *ids,
                                                            PreintStream *streams, double *terms) {
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -671,7 +715,7 @@ __global__ void k_preint_imu_stream_gather(int n, const int *ids, const int *dst
 
 template <class OUT, class KERNEL>
 static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin, int lin_w,
-                             OUT *out, KERNEL kern, size_t terms_per_sample) {
+                             OUT *out, KERNEL kern, size_t terms_per_sample, int threads) {
   if (!ctx || n < 0 || !samples || !offsets || !lin || !out) return VILO_ERR_BAD_ARG;
   if (n == 0) return VILO_OK;
   VILO_HIP(hipSetDevice(ctx->device));
@@ -687,7 +731,7 @@ static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, c
   VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
   VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * (size_t)lin_w * n, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(),
+  hipLaunchKernelGGL(kern, dim3(n), dim3(threads), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(),
                      d_o.as<int>(), d_l.as<double>(), d_out.as<OUT>(), d_t.as<double>());
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipMemcpyAsync(out, d_out.p, sizeof(OUT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -697,11 +741,11 @@ static int preintegrate_impl(vilo_ctx *ctx, int n, const vilo_sample *samples, c
 
 extern "C" int vilo_preintegrate(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
                                  vilo_preint *out) {
-  return preintegrate_impl(ctx, n, samples, offsets, lin, 10, out, k_preint_imu_leg, 4 * LT_N);
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 10, out, k_preint_imu_leg, 4 * LT_N, PAIR_THREADS);
 }
 extern "C" int vilo_preintegrate_imu(vilo_ctx *ctx, int n, const vilo_sample *samples, const int32_t *offsets, const double *lin,
                                      vilo_preint_imu *out) {
-  return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu, 0);
+  return preintegrate_impl(ctx, n, samples, offsets, lin, 6, out, k_preint_imu, 0, 64);
 }
 
 // ---- device-resident, incrementally updated preintegration (the reference's push_back as samples arrive, estimator.cpp:619-626) ----
@@ -785,7 +829,7 @@ extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, i
     hipLaunchKernelGGL(k_preint_imu_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
                        d_i.as<int>(), s->di);
   else
-    hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
+    hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(PAIR_THREADS), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
                        d_i.as<int>(), s->d, d_t.as<double>());
   VILO_HIP(hipGetLastError());
   VILO_HIP(hipStreamSynchronize(ctx->stream));
@@ -835,7 +879,7 @@ int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, in
 int vilo_repropagate_launch(vilo_ctx *ctx, BatchDev &b, int mode, int stage) {
   if ((!b.rp_on && mode != 2) || !b.rp_samples || !b.leg) return VILO_OK;
   if (stage == 0) {
-    hipLaunchKernelGGL(k_repropagate, dim3(b.W * 10), dim3(64), 0, ctx->stream, b, (const vilo_config *)ctx->d_cfg, mode);
+    hipLaunchKernelGGL(k_repropagate, dim3(b.W * 10), dim3(PAIR_THREADS), 0, ctx->stream, b, (const vilo_config *)ctx->d_cfg, mode);
     VILO_HIP(hipGetLastError());
     return VILO_OK;
   }
