@@ -93,6 +93,7 @@ constexpr int FCLD = pb::FCLD; // of dF = F - I, stored with its 16 non-zero col
 //
 // The consumer wave of the pair below takes the step's dF and V operands out of LDS in one go, so that the producer can build the next
 // step's blocks while these products run.
+constexpr int BLK_ROUNDS_PRODUCER = 5;   // of pb::N_BLK_ROUNDS rounds of block entries: the producer's; the others and the tail are the consumer's
 constexpr int PAIR_THREADS = 128;   // the IMU-leg kernels' workgroup: producer + consumer wave (preint_imu_leg_body)
 struct FvOperands {
   double f0[4], f1[4];     // dF[lr][4 kk + lk], dF[16 + lr][4 kk + lk] (compact columns): the A operand of dF X and the B operand of Q dF^T
@@ -251,13 +252,14 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   __shared__ double Ls[pb::PB_TOTAL];
   __shared__ double JK[JK_N], PQ[PQ_N];   // the consumer's (jac_cov_update_regs)
   __shared__ int fv_taken;                // steps whose operands the consumer has in registers
+  __shared__ int swap_roles;
+  __shared__ int pool_ready;              // steps whose 3 x 3 matrix pool (products included) and coefficients are complete
   // the producer's descriptors of the lane-parallel block construction: product / block (8 round + lane / 9), entry lane % 9 (lane 63: the
   // no-op). In LDS, [round][lane]: as registers they would put the producer over the half register file it shares a SIMD in.
   __shared__ unsigned pdesc[pb::N_PROD_ROUNDS * 64];
   __shared__ unsigned long long bdesc[pb::N_BLK_ROUNDS * 64];
   double *const Fm = Ls + pb::O_FC, *const Vm = Ls + pb::O_VM, *const nd = Ls + pb::O_ND;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool producer = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
   const int pb_grp = lane / 9, pb_ent = lane - 9 * pb_grp;
   if (tid < 64) {
     for (int r = 0; r < pb::N_PROD_ROUNDS; ++r) pdesc[64 * r + lane] = c_pb_tab.prod[8 * r + pb_grp];
@@ -284,8 +286,18 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
   }
   // dF = F - I and V have a fixed sparsity pattern: zeroed once, every sample overwrites the same entries
   for (int e = tid; e < pb::PB_TOTAL; e += 128) Ls[e] = 0.0;
-  if (tid == 0) fv_taken = 0;
+  if (tid == 0) {
+    fv_taken = 0;
+    pool_ready = 0;
+    // Which wave produces: a SIMD hosts two waves of two pairs, and it should get one producer (FP64 VALU) and one consumer (matrix pipe)
+    // rather than two of a kind. The pairs that share SIMDs differ in the wave slot they were given there (HW_ID bits 3:0), so the parity
+    // of wave 0's slot picks its role; any choice computes the same record.
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    swap_roles = (int)(hw_id & 1u);
+  }
   __syncthreads();
+  const bool producer = __builtin_amdgcn_readfirstlane((tid >> 6) ^ swap_roles) == 0;
   const m3 Rbr = ld_m3_rowmajor(cfg.R_br);
   const v3 pbr = ld3(cfg.p_br);
   const m3 I3 = m3_eye();
@@ -336,6 +348,12 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     store_rows_K(PQ, accP);
     int n_taken = 0;
     for (int si = si_first; si < s_end; ++si) {
+      // its share of the step's blocks (the producer builds the others meanwhile), once the pool they are sums of is complete
+      const double dt = samples[si].dt;
+      while (__hip_atomic_load(&pool_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n_taken) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int r = BLK_ROUNDS_PRODUCER; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
+      pb::tail_entry(lane, dt, Ls);
       __syncthreads();   // this step's dF, V, nd are in LDS
       FvOperands op;
       load_fv_operands(Fm, Vm, nd, op);
@@ -449,6 +467,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     // second level: (R_1 [a_1]x) kappa_7, (R_1 [v_1]x) kappa_7, (R_e R_br) J_e
 #pragma unroll
     for (int r = 4; r < pb::N_PROD_ROUNDS; ++r) pb::product_entry(pdesc[64 * r + lane], pb_ent, Ls);
+    __hip_atomic_store(&pool_ready, n_built + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the consumer starts on its blocks
     // epsilon update + noise (uniform, every lane) (:245, :288-374)
     v3 lo_v[4], r_eps[4];
     for (int j = 0; j < 4; ++j) {
@@ -487,8 +506,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     }
     wave_fence();
 #pragma unroll
-    for (int r = 0; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
-    pb::tail_entry(lane, dt, Ls);
+    for (int r = 0; r < BLK_ROUNDS_PRODUCER; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
     __syncthreads();   // blocks ready: the consumer takes them
     ++n_built;
     // propagate() (:88-136)
