@@ -116,6 +116,10 @@ __device__ __forceinline__ void load_fv_operands(const double *dFm, const double
     o.sc[kk] = nd[4 * kk + lk];
   }
 }
+// a wave-uniform double, moved to scalar registers
+__device__ __forceinline__ double uni_d(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 __device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }   // (one wave's LDS operations complete in program order: only the compiler must keep it)
 // The consumer's LDS keeps of the 32 x 32 jacobian / covariance only what the next product reads (the matrices themselves live in its
 // accumulators from one step to the next): the rows K = {3 .. 8, 21 .. 30} as the B operand of dF X[K, :], the columns K of Q as the A
@@ -370,6 +374,13 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     return;
   }
   // ---- the producer ----
+  // the configuration's scalars the steps read, in scalar registers (behind the fences of the loop they would be fetched again every step,
+  // one exposed round trip after the other)
+  const int c_contact_sensor_type = __builtin_amdgcn_readfirstlane(cfg.contact_sensor_type);
+  const double c_v_n_force_thres_ratio = uni_d(cfg.v_n_force_thres_ratio), c_v_n_term1_steep = uni_d(cfg.v_n_term1_steep), c_v_n_max = uni_d(cfg.v_n_max),
+               c_v_n_min_xy = uni_d(cfg.v_n_min_xy), c_v_n_min_z = uni_d(cfg.v_n_min_z), c_v_n_min = uni_d(cfg.v_n_min),
+               c_v_n_term2_var_rescale = uni_d(cfg.v_n_term2_var_rescale), c_v_n_term3_distance_rescale = uni_d(cfg.v_n_term3_distance_rescale),
+               c_rho_c_n = uni_d(cfg.rho_c_n), c_rho_nc_n = uni_d(cfg.rho_nc_n);
   // the records of a step's two samples, one step ahead of their use: element lane + 64 q of [endpoint][leg][LT_N]
   double rec[6];
   int rec_dst[6], rec_src[6];
@@ -387,11 +398,27 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     for (int q = 0; q < 6; ++q) rec[q] = src[rec_src[q]];
   };
   if (si_first < s_end) load_records(si_first);
+  // the IMU rows and contact values of a step's two samples: the first one's carried over from the previous step in scalar registers, the
+  // second one's fetched one step ahead (acc 0 .. 2, gyr 3 .. 5, c 6 .. 9, dt 10)
+  double smp0[10], smp_next[11];
+  auto fetch_sample = [&](const vilo_sample &sm, double *v) {
+    for (int k = 0; k < 3; ++k) { v[k] = sm.acc[k]; v[3 + k] = sm.gyr[k]; }
+    for (int k = 0; k < 4; ++k) v[6 + k] = sm.c[k];
+  };
+  {
+    double v[10];
+    fetch_sample(STREAM ? st->last : samples[s_begin], v);
+    for (int k = 0; k < 10; ++k) smp0[k] = uni_d(v[k]);
+  }
+  if (si_first < s_end) { fetch_sample(samples[si_first], smp_next); smp_next[10] = samples[si_first].dt; }
   int n_built = 0;
   for (int si = si_first; si < s_end; ++si) {
-    const vilo_sample &s0 = (STREAM && si == s_begin) ? st->last : samples[si - 1], &s1 = samples[si];
-    const double dt = s1.dt;
-    const v3 acc_0 = ld3(s0.acc), gyr_0 = ld3(s0.gyr), acc_1 = ld3(s1.acc), gyr_1 = ld3(s1.gyr);
+    double smp1[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) smp1[k] = uni_d(smp_next[k]);
+    if (si + 1 < s_end) { fetch_sample(samples[si + 1], smp_next); smp_next[10] = samples[si + 1].dt; }
+    const double dt = smp1[10];
+    const v3 acc_0 = ld3(smp0), gyr_0 = ld3(smp0 + 3), acc_1 = ld3(smp1), gyr_1 = ld3(smp1 + 3);
     // IMU midpoint update (:152-160)
     const v3 un_acc_0 = qrot(dq, acc_0 - ba);
     const v3 un_gyr = (gyr_0 + gyr_1) * 0.5 - bg;
@@ -405,18 +432,18 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     // contact flags (:183-229); integer-valued as in the reference (Vector4i foot_contact_flag)
     int flag[4];
     double ff_var[4] = {0.0, 0.0, 0.0, 0.0};
-    if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
-      for (int j = 0; j < 4; ++j) flag[j] = s1.c[j] >= 0.5 ? 1 : 0;
+    if (c_contact_sensor_type == 0 || c_contact_sensor_type == 1) {
+      for (int j = 0; j < 4; ++j) flag[j] = smp1[6 + j] >= 0.5 ? 1 : 0;
     } else {
       for (int j = 0; j < 4; ++j) {
-        const double force_mag = 0.5 * (s0.c[j] + s1.c[j]);
+        const double force_mag = 0.5 * (smp0[6 + j] + smp1[6 + j]);
         double fmn = ffs[j], fmx = ffs[4 + j];
         if (force_mag < fmn) fmn = 0.9 * fmn + 0.1 * force_mag;
         if (force_mag > fmx) fmx = 0.9 * fmx + 0.1 * force_mag;
         fmn *= 0.9991;
         fmx *= 0.997;
-        const double thr = fmn + cfg.v_n_force_thres_ratio * (fmx - fmn);
-        flag[j] = (int)(1.0 / (1 + exp(-cfg.v_n_term1_steep * (force_mag - thr))));
+        const double thr = fmn + c_v_n_force_thres_ratio * (fmx - fmn);
+        flag[j] = (int)(1.0 / (1 + exp(-c_v_n_term1_steep * (force_mag - thr))));
         const int fidx = ((int)ffs[32 + j] + 1) % 5;
         double win[5];
         for (int k = 0; k < 5; ++k) win[k] = (k == fidx) ? force_mag : ffs[12 + 5 * j + k];
@@ -478,26 +505,26 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     while (__hip_atomic_load(&fv_taken, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_built) __builtin_amdgcn_s_sleep(1);
     if (lane == 0) {
       double unc[12], rho_unc[4];
-      if (cfg.contact_sensor_type == 0 || cfg.contact_sensor_type == 1) {
+      if (c_contact_sensor_type == 0 || c_contact_sensor_type == 1) {
         for (int j = 0; j < 4; ++j) {
-          const double n_xy = cfg.v_n_max * (1 - flag[j]) + flag[j] * cfg.v_n_min_xy;
-          const double n_z = cfg.v_n_max * (1 - flag[j]) + flag[j] * cfg.v_n_min_z;
+          const double n_xy = c_v_n_max * (1 - flag[j]) + flag[j] * c_v_n_min_xy;
+          const double n_z = c_v_n_max * (1 - flag[j]) + flag[j] * c_v_n_min_z;
           unc[3 * j] = n_xy; unc[3 * j + 1] = n_xy; unc[3 * j + 2] = n_z;
         }
       } else {
         for (int j = 0; j < 4; ++j) {
-          const double n1 = cfg.v_n_max * (1 - flag[j]) + cfg.v_n_min;
-          const double n2 = cfg.v_n_term2_var_rescale * ff_var[j];
+          const double n1 = c_v_n_max * (1 - flag[j]) + c_v_n_min;
+          const double n2 = c_v_n_term2_var_rescale * ff_var[j];
           const v3 tmp = lo_v[j] - dv;
-          unc[3 * j] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.x * tmp.x;
-          unc[3 * j + 1] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.y * tmp.y;
-          unc[3 * j + 2] = n1 + n2 + cfg.v_n_term3_distance_rescale * tmp.z * tmp.z;
+          unc[3 * j] = n1 + n2 + c_v_n_term3_distance_rescale * tmp.x * tmp.x;
+          unc[3 * j + 1] = n1 + n2 + c_v_n_term3_distance_rescale * tmp.y * tmp.y;
+          unc[3 * j + 2] = n1 + n2 + c_v_n_term3_distance_rescale * tmp.z * tmp.z;
         }
       }
       int fsum = 0;
-      for (int j = 0; j < 4; ++j) { rho_unc[j] = cfg.rho_c_n * flag[j] + cfg.rho_nc_n; fsum += flag[j]; }
+      for (int j = 0; j < 4; ++j) { rho_unc[j] = c_rho_c_n * flag[j] + c_rho_nc_n; fsum += flag[j]; }
       if (fsum < 1e-6) {
-        for (int j = 0; j < 4; ++j) rho_unc[j] = cfg.rho_nc_n;
+        for (int j = 0; j < 4; ++j) rho_unc[j] = c_rho_nc_n;
         for (int k = 0; k < 12; ++k) unc[k] = 10e10;
       }
       // (nd[0 .. 30): the IMU, bias and encoder variances do not change from step to step: written before the loop)
@@ -509,6 +536,8 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     for (int r = 0; r < BLK_ROUNDS_PRODUCER; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
     __syncthreads();   // blocks ready: the consumer takes them
     ++n_built;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) smp0[k] = smp1[k];
     // propagate() (:88-136)
     dp = r_dp; dv = r_dv; dq = qnormalized(rq);
     for (int j = 0; j < 4; ++j) eps[j] = r_eps[j];
