@@ -1,8 +1,9 @@
 // Contact (IMU + leg) preintegration on gfx950: IMULegIntegrationBase's constructor + push_back()/propagate()/
 // midPointIntegration() (imu_leg_integration_base.cpp:7-470) and the classic IntegrationBase
-// (integration_base.h:18-170), batched over intervals: one wave per interval, samples sequential (each step
-// depends on the previous one), the 31x31 jacobian / covariance updates parallel over columns (lane = column),
-// F / V / jacobian / covariance resident in LDS, leg kinematics of the 4 legs x 2 endpoints on 8 lanes.
+// (integration_base.h:18-170), batched over intervals, samples sequential (each step depends on the previous one).
+// IMU-leg (31 states): a producer / consumer pair of waves per interval — dF = F - I and V built lane-parallel in LDS by one wave,
+// jacobian <- F jacobian, covariance <- F covariance F^T + V N V^T on the FP64 matrix cores by the other (preint_imu_leg_body).
+// IMU only (15 states): one wave per interval, the updates parallel over columns (lane = column), everything resident in LDS.
 //
 // The batch form, the streaming form and the re-propagation of a resident batch are three instantiations of one body and must give
 // bitwise the same record (tests: streaming == batch). With the default -ffp-contract=fast the optimiser fuses a multiply with an
