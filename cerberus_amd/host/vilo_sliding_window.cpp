@@ -352,6 +352,94 @@ void parallel_for(int n, const std::function<void(int)> &fn) {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
+// The device-resident preintegration objects brought up to date with the windows' sample buffers: the objects of intervals whose
+// linearisation point changed are reset (constructor), every sample not pushed yet is push_back()ed, one reset and one push launch per
+// pool for all the windows that share it. read_back (the image step of a window whose prior is carried on the host): the records of the
+// changed intervals come back into pre_ / pre_imu_. Without it this is what a caller runs BETWEEN images (pushSamples): the reference
+// integrates every IMU / leg message as it arrives (processIMULeg -> push_back, estimator.cpp:612-632), and pushing an interval in pieces
+// gives bitwise the record of pushing it at once, so how often it is called changes when the work is done, not the result.
+int SlidingWindow::pushPending(vilo_ctx *ctx, SlidingWindow *const *ws, int n, bool read_back) {
+  const int use_leg = ws[0]->opt_.use_leg;
+  const bool resident = ws[0]->resident_;
+  for (int w0 = 0; w0 < n;) {
+    int w1 = w0 + 1;
+    while (w1 < n && ws[w1]->pool_ == ws[w0]->pool_) ++w1;
+    vilo_preint_streams *pool = ws[w0]->pool_;
+    std::vector<int32_t> rid, pid, gid, offsets(1, 0);
+    std::vector<vilo_sample> first, samples;
+    std::vector<double> lin;
+    std::vector<std::pair<int, int>> which;
+    for (int w = w0; w < w1; ++w) {
+      SlidingWindow &s = *ws[w];
+      for (int j = 1; j <= WS; ++j) {
+        if (s.buf_[j].empty()) continue;
+        if (s.need_reset_[j]) {
+          rid.push_back(s.sid_[j]); first.push_back(s.buf_[j][0]); lin.insert(lin.end(), s.lin_[j], s.lin_[j] + (use_leg ? 10 : 6));
+          s.need_reset_[j] = false; s.pushed_[j] = 0;
+        }
+        const int have = (int)s.buf_[j].size() - 1;
+        if (s.pushed_[j] < have) {
+          pid.push_back(s.sid_[j]);
+          samples.insert(samples.end(), s.buf_[j].begin() + 1 + s.pushed_[j], s.buf_[j].end());
+          offsets.push_back((int32_t)samples.size());
+          s.pushed_[j] = have;
+        }
+        if (!read_back) continue;
+        if (s.dirty_[j] && !resident) { gid.push_back(s.sid_[j]); which.push_back({w, j}); }
+        if (resident) s.dirty_[j] = false;
+      }
+    }
+    int rc = vilo_preint_streams_reset(ctx, pool, (int)rid.size(), rid.data(), first.data(), lin.data());
+    if (rc == VILO_OK) rc = vilo_preint_streams_push(ctx, pool, (int)pid.size(), pid.data(), samples.data(), offsets.data());
+    if (rc != VILO_OK) return rc;
+    if (read_back) {
+      if (use_leg) {
+        std::vector<vilo_preint> out(gid.size());
+        rc = vilo_preint_streams_read(ctx, pool, (int)gid.size(), gid.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_[which[k].second] = out[k];
+      } else {
+        std::vector<vilo_preint_imu> out(gid.size());
+        rc = vilo_preint_streams_read_imu(ctx, pool, (int)gid.size(), gid.data(), out.data());
+        if (rc != VILO_OK) return rc;
+        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_imu_[which[k].second] = out[k];
+      }
+      for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->dirty_[which[k].second] = false;
+    }
+    w0 = w1;
+  }
+  return VILO_OK;
+}
+
+// What the reference does per message, for a fleet between two images: the samples buffered since the last call go to the windows'
+// device-resident preintegration objects now (windows without streaming preintegration, or with nothing new, are left alone).
+int SlidingWindow::pushSamples(vilo_ctx *ctx, SlidingWindow *const *ws, int n) {
+  std::vector<SlidingWindow *> act;
+  for (int w = 0; w < n; ++w) {
+    SlidingWindow &s = *ws[w];
+    if (!s.opt_.streaming_preintegration) continue;
+    if (!s.pool_) {
+      int rc = s.opt_.use_leg ? vilo_preint_streams_create(ctx, NF, &s.pool_) : vilo_preint_streams_create_imu(ctx, NF, &s.pool_);
+      if (rc != VILO_OK) return rc;
+      s.own_pool_ = true;
+      for (int j = 0; j < NF; ++j) { s.sid_[j] = j; s.need_reset_[j] = !s.buf_[j].empty(); s.pushed_[j] = 0; }
+    }
+    act.push_back(&s);
+  }
+  // one call of pushPending serves windows of one factor kind; windows sharing a pool are of one kind and are kept adjacent
+  std::stable_sort(act.begin(), act.end(), [](const SlidingWindow *a, const SlidingWindow *b) {
+    return a->opt_.use_leg != b->opt_.use_leg ? a->opt_.use_leg < b->opt_.use_leg : std::less<const void *>()(a->pool_, b->pool_);
+  });
+  for (size_t i = 0; i < act.size();) {
+    size_t k = i + 1;
+    while (k < act.size() && act[k]->opt_.use_leg == act[i]->opt_.use_leg) ++k;
+    const int rc = pushPending(ctx, act.data() + i, (int)(k - i), /*read_back=*/false);
+    if (rc != VILO_OK) return rc;
+    i = k;
+  }
+  return VILO_OK;
+}
+
 int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n) {
   if (n <= 0) return VILO_OK;
   const bool timing = getenv("VILO_HOST_TIMING") != nullptr;
@@ -397,49 +485,8 @@ int SlidingWindow::optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *ws, int n)
     }
   const bool resident = ws[0]->resident_;
   if (streaming) {
-    for (int w0 = 0; w0 < n;) {
-      int w1 = w0 + 1;
-      while (w1 < n && ws[w1]->pool_ == ws[w0]->pool_) ++w1;
-      vilo_preint_streams *pool = ws[w0]->pool_;
-      std::vector<int32_t> rid, pid, gid, offsets(1, 0);
-      std::vector<vilo_sample> first, samples;
-      std::vector<double> lin;
-      std::vector<std::pair<int, int>> which;
-      for (int w = w0; w < w1; ++w) {
-        SlidingWindow &s = *ws[w];
-        for (int j = 1; j <= WS; ++j) {
-          if (s.buf_[j].empty()) continue;
-          if (s.need_reset_[j]) {
-            rid.push_back(s.sid_[j]); first.push_back(s.buf_[j][0]); lin.insert(lin.end(), s.lin_[j], s.lin_[j] + (use_leg ? 10 : 6));
-            s.need_reset_[j] = false; s.pushed_[j] = 0;
-          }
-          const int have = (int)s.buf_[j].size() - 1;
-          if (s.pushed_[j] < have) {
-            pid.push_back(s.sid_[j]);
-            samples.insert(samples.end(), s.buf_[j].begin() + 1 + s.pushed_[j], s.buf_[j].end());
-            offsets.push_back((int32_t)samples.size());
-            s.pushed_[j] = have;
-          }
-          if (s.dirty_[j] && !resident) { gid.push_back(s.sid_[j]); which.push_back({w, j}); }
-          if (resident) s.dirty_[j] = false;
-        }
-      }
-      int rc = vilo_preint_streams_reset(ctx, pool, (int)rid.size(), rid.data(), first.data(), lin.data());
-      if (rc == VILO_OK) rc = vilo_preint_streams_push(ctx, pool, (int)pid.size(), pid.data(), samples.data(), offsets.data());
-      if (use_leg) {
-        std::vector<vilo_preint> out(gid.size());
-        if (rc == VILO_OK) rc = vilo_preint_streams_read(ctx, pool, (int)gid.size(), gid.data(), out.data());
-        if (rc != VILO_OK) return rc;
-        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_[which[k].second] = out[k];
-      } else {
-        std::vector<vilo_preint_imu> out(gid.size());
-        if (rc == VILO_OK) rc = vilo_preint_streams_read_imu(ctx, pool, (int)gid.size(), gid.data(), out.data());
-        if (rc != VILO_OK) return rc;
-        for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->pre_imu_[which[k].second] = out[k];
-      }
-      for (size_t k = 0; k < which.size(); ++k) ws[which[k].first]->dirty_[which[k].second] = false;
-      w0 = w1;
-    }
+    const int rc = pushPending(ctx, ws, n, /*read_back=*/true);
+    if (rc != VILO_OK) return rc;
   } else {
     std::vector<vilo_sample> samples;
     std::vector<int32_t> offsets(1, 0);
@@ -658,6 +705,7 @@ void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *s, int n) { ((Slidi
 void vilo_sw_process_samples(void *h, const vilo_sample *s, int n) {
   for (int i = 0; i < n; ++i) ((SlidingWindow *)h)->processIMULeg(s[i]);
 }
+int vilo_sw_push_samples(vilo_ctx *ctx, void *const *hs, int n) { return SlidingWindow::pushSamples(ctx, (SlidingWindow *const *)hs, n); }
 int vilo_sw_process_image(void *h, double header, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
   return ((SlidingWindow *)h)->processImage(header, n, ids, obs11, stereo);
 }

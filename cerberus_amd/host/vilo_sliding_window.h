@@ -78,6 +78,11 @@ class SlidingWindow {
   // that returned true, endImage on every robot.
   bool beginImage(double header, int n, const int *ids, const double *obs11, const uint8_t *stereo);
   static int optimizeBatch(vilo_ctx *ctx, SlidingWindow *const *windows, int n);
+  // Between images: push_back() the samples buffered so far into the windows' device-resident preintegration objects — what the
+  // reference does with every message (processIMULeg, estimator.cpp:612-632). Call it per message, per N messages or never: an interval
+  // pushed in pieces is bitwise the interval pushed at once, so only when the device work happens changes (the image step finds the
+  // interval already integrated). One reset and one push launch per pool for the whole fleet.
+  static int pushSamples(vilo_ctx *ctx, SlidingWindow *const *windows, int n);
   void endImage();
 
   void vector2double();
@@ -103,6 +108,7 @@ class SlidingWindow {
   int intervalSamples(int j) const { return (int)buf_[j].size(); }
 
  private:
+  static int pushPending(vilo_ctx *ctx, SlidingWindow *const *ws, int n, bool read_back);
   struct PriorStore {
     vilo_prior p;
     std::vector<double> x0, J0, r0;
@@ -167,6 +173,7 @@ void vilo_sw_set_extrinsics(void *h, const double *tic2x3, const double *ric2x9,
 void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const double *v /* may be NULL */);
 void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *samples, int n);
 void vilo_sw_process_samples(void *h, const vilo_sample *samples, int n);
+int vilo_sw_push_samples(vilo_ctx *ctx, void *const *hs, int n_windows);   // SlidingWindow::pushSamples
 int vilo_sw_process_image(void *h, double header, int n, const int *ids, const double *obs11, const uint8_t *stereo);
 // fleet: n_windows robots, robot w has n_feat[w] features starting at feat_offset[w] in the concatenated arrays
 int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int n_windows, const double *headers, const int *feat_offset, const int *ids,

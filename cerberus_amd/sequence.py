@@ -44,6 +44,7 @@ def host_lib():
         _host.vilo_sw_set_extrinsics.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, C.c_double]
         _host.vilo_sw_init_first_pose.argtypes = [C.c_void_p, T.c_double_p, T.c_double_p, T.c_double_p]
         _host.vilo_sw_process_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _host.vilo_sw_push_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _host.vilo_sw_process_image.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _host.vilo_sw_process_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _host.vilo_sw_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 10
@@ -206,6 +207,14 @@ class MeasurementProcessor:
         if getattr(self, "h", None):
             self.H.vilo_mp_destroy(self.h)
             self.h = None
+
+
+def push_samples(ctx, windows):
+    """Between images: the samples the windows have buffered since the last call go to their device-resident preintegration objects
+    (SlidingWindow::pushSamples: the reference's push_back per message). Changes when the integration happens, not its result."""
+    H = host_lib()
+    hs = (C.c_void_p * len(windows))(*[w.h for w in windows])
+    ctx._check(H.vilo_sw_push_samples(ctx.h, hs, len(windows)))
 
 
 def process_images(ctx, windows, frames):

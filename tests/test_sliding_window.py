@@ -38,7 +38,7 @@ def test_host_library_exports_the_window_manager():
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", HOST], capture_output=True, text=True, check=True).stdout
     for sym in ("create", "destroy", "set_extrinsics", "init_first_pose", "init_first_imu_pose", "process_samples", "process_image",
-                "process_images", "get_state", "last_summary"):
+                "process_images", "push_samples", "get_state", "last_summary"):
         assert " T vilo_sw_" + sym in out, sym
     assert " T vilo_fw_add_frame" in out
 
@@ -301,3 +301,56 @@ def test_fleet_in_lockstep_equals_robots_one_by_one(ctx, cfg):
         for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "Rho"):
             np.testing.assert_array_equal(st[key], alone[r][key])
         assert st["prior_n"] == alone[r]["prior_n"] and st["n_optimizations"] == N - 10
+
+
+@pytest.mark.gpu
+def test_samples_pushed_as_they_arrive_give_the_same_replay(ctx, cfg):
+    """SlidingWindow::pushSamples between images (the reference integrates every IMU / leg message as it arrives, estimator.cpp:612-632):
+    one robot pushing after every message, and a fleet sharing one pool pushing every third message, against the default (all samples
+    of an interval pushed in the image step): bitwise the same estimates, through the MARGIN_SECOND_NEW merges and the repropagations."""
+    from cerberus_amd import api, sequence
+    N = 18
+    ref = _run(ctx, cfg, N, seed=41)[1]
+    stream = sequence.Stream(cfg, seed=41)
+    sw = sequence.SlidingWindow(ctx, cfg)
+    sw.set_extrinsics(*stream.extrinsics())
+    for k in range(N):
+        f = stream.next()
+        if k == 0:
+            t = f["truth"]
+            sw.init_first_pose(t[0:3], sequence.quat_to_R(t[3:7]).ravel(), t[7:10])
+        for s in f["samples"]:
+            sw.process_samples(np.ascontiguousarray([s]))
+            sequence.push_samples(ctx, [sw])
+        sw.process_image(f["header"], f["ids"], f["obs"], f["stereo"])
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "Rho"):
+            np.testing.assert_array_equal(sw.state()[key], ref[k][1][key])
+    assert {st["marginalization_flag"] for _, st in ref[10:]} == {0, 1}
+    # a fleet: one pool, one push launch for all robots per call
+    R = 3
+    alone = [_run(ctx, cfg, N, seed=300 + r, t0=0.3 * r)[1][-1][1] for r in range(R)]
+    streams = [sequence.Stream(cfg, seed=300 + r, t0=0.3 * r) for r in range(R)]
+    robots = [sequence.SlidingWindow(ctx, cfg) for _ in range(R)]
+    pool, priors = api.PreintStreams(ctx, 11 * R), api.PriorPool(ctx, 2 * R)
+    for r, (s, w) in enumerate(zip(streams, robots)):
+        w.set_extrinsics(*s.extrinsics())
+        w.attach_streams(pool, 11 * r)
+        w.attach_prior_pool(priors, 2 * r)
+    for k in range(N):
+        frames = [s.next() for s in streams]
+        if k == 0:
+            for w, f in zip(robots, frames):
+                t = f["truth"]
+                w.init_first_pose(t[0:3], sequence.quat_to_R(t[3:7]).ravel(), t[7:10])
+        n_msg = max(len(f["samples"]) for f in frames)
+        for m0 in range(0, n_msg, 3):
+            for w, f in zip(robots, frames):
+                part = f["samples"][m0:m0 + 3]
+                if len(part):
+                    w.process_samples(part)
+            sequence.push_samples(ctx, robots)
+        sequence.process_images(ctx, robots, frames)
+    for r in range(R):
+        st = robots[r].state()
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "Rho"):
+            np.testing.assert_array_equal(st[key], alone[r][key])

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--csv", default=None)
     ap.add_argument("--write-bag", default=None, help="write the synthetic stream of robot 0 (IMU, JointState, feature clouds) to this bag and stop")
     ap.add_argument("--bag", default=None, help="replay this bag instead of a synthetic stream (one robot)")
+    ap.add_argument("--push-every", type=int, default=0, help="push the IMU / leg samples to the device-resident preintegration objects every N messages, "
+                    "as they arrive, instead of in the image step (0: in the image step); same estimates, shorter image step")
     ap.add_argument("--contact-sensor-type", type=int, default=1, help="--bag: 0 / 1 the planner's flags (0: in place of the absent Kalman filter), 2 foot forces")
     a = ap.parse_args()
     cfg = synth.default_config()
@@ -77,8 +79,20 @@ def main():
     csv = open(a.csv, "w") if a.csv else None
     for k in range(a.images):
         frames = [s.next() for s in streams]
-        for w, f in zip(robots, frames):
-            sequence.feed(w, f, k == 0)
+        if a.push_every > 0:
+            # the samples reach the device as they arrive (SlidingWindow::pushSamples every --push-every messages), not in the image step
+            for w, f in zip(robots, frames):
+                sequence.feed(w, dict(f, samples=f["samples"][:0]), k == 0)
+            n_msg = max(len(f["samples"]) for f in frames)
+            for m0 in range(0, n_msg, a.push_every):
+                for w, f in zip(robots, frames):
+                    part = f["samples"][m0:m0 + a.push_every]
+                    if len(part):
+                        w.process_samples(part)
+                sequence.push_samples(ctx, robots)
+        else:
+            for w, f in zip(robots, frames):
+                sequence.feed(w, f, k == 0)
         t0 = time.perf_counter()
         sequence.process_images(ctx, robots, frames)
         t_img.append(time.perf_counter() - t0)
