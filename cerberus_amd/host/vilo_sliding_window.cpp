@@ -759,6 +759,21 @@ void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *s, int n) { ((Slidi
 void vilo_sw_process_samples(void *h, const vilo_sample *s, int n) {
   for (int i = 0; i < n; ++i) ((SlidingWindow *)h)->processIMULeg(s[i]);
 }
+// self-check of the fleet's worker pool (tests/test_sliding_window.py): `repeats` jobs of n items each; 0 if every item ran exactly once
+// per job and no two jobs overlapped
+int vilo_sw_parallel_selfcheck(int n, int repeats) {
+  std::vector<std::atomic<int>> hits((size_t)std::max(n, 1));
+  for (auto &h : hits) h.store(0);
+  std::atomic<int> bad{0};
+  for (int r = 0; r < repeats; ++r) {
+    vilo::parallel_for_public(n, [&](int i) {
+      if (i < 0 || i >= n || hits[(size_t)i].fetch_add(1) != r) bad.fetch_add(1);
+    });
+    for (int i = 0; i < n; ++i)
+      if (hits[(size_t)i].load() != r + 1) bad.fetch_add(1);
+  }
+  return bad.load();
+}
 int vilo_sw_push_samples(vilo_ctx *ctx, void *const *hs, int n) { return SlidingWindow::pushSamples(ctx, (SlidingWindow *const *)hs, n); }
 int vilo_sw_process_image(void *h, double header, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
   return ((SlidingWindow *)h)->processImage(header, n, ids, obs11, stereo);

@@ -174,6 +174,7 @@ void vilo_sw_init_first_pose(void *h, const double *p, const double *R, const do
 void vilo_sw_init_first_imu_pose(void *h, const vilo_sample *samples, int n);
 void vilo_sw_process_samples(void *h, const vilo_sample *samples, int n);
 int vilo_sw_push_samples(vilo_ctx *ctx, void *const *hs, int n_windows);   // SlidingWindow::pushSamples
+int vilo_sw_parallel_selfcheck(int n, int repeats);   // the fleet's worker pool: 0 if every item of every job ran exactly once
 int vilo_sw_process_image(void *h, double header, int n, const int *ids, const double *obs11, const uint8_t *stereo);
 // fleet: n_windows robots, robot w has n_feat[w] features starting at feat_offset[w] in the concatenated arrays
 int vilo_sw_process_images(vilo_ctx *ctx, void *const *hs, int n_windows, const double *headers, const int *feat_offset, const int *ids,

@@ -43,6 +43,16 @@ def test_host_library_exports_the_window_manager():
     assert " T vilo_fw_add_frame" in out
 
 
+def test_worker_pool_runs_every_item_of_every_job_once():
+    """The fleet's host bookkeeping (beginImage / vector2double / double2vector / endImage over the robots) runs on a persistent pool of
+    threads: many jobs in a row, sizes around the inline threshold and well above the thread count."""
+    import ctypes as C
+    H = C.CDLL(HOST)
+    H.vilo_sw_parallel_selfcheck.argtypes = [C.c_int, C.c_int]
+    for n, rep in ((1, 3), (7, 5), (8, 50), (64, 200), (1000, 50), (257, 300)):
+        assert H.vilo_sw_parallel_selfcheck(n, rep) == 0, (n, rep)
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden", "seq_window_rejected_steps.vwin")
 
 
