@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "solver_types.hpp"
+#include "worker_pool.hpp"
 
 int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o);
 
@@ -377,18 +378,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       }
     }
   };
-  {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nt = std::max(1, std::min({hw > 0 ? hw : 1, 16, W / 8}));
-    if (nt <= 1) {
-      for (int w = 0; w < W; ++w) fill_window(w);
-    } else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nt; ++t)
-        th.emplace_back([&, t] { for (int w = t; w < W; w += nt) fill_window(w); });
-      for (auto &x : th) x.join();
-    }
-  }
+  vilo::parallel_items(W, 8, fill_window);   // (worker_pool.hpp: host threads parked between batches)
   for (int w = 0; w < W; ++w)
     if (win_err[w]) {
       ctx->err = win_err[w] == 1 ? "unsupported prior block" : "prior couples speed/leg biases of two frames";
