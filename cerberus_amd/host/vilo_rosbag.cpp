@@ -1,6 +1,8 @@
 // ROS bag (format 2.0) reader / writer and ROS 1 (de)serialisation of the messages the reference's node consumes: see vilo_rosbag.h.
 #include "vilo_rosbag.h"
 
+#include <dlfcn.h>
+
 #include <cstring>
 
 namespace vilo {
@@ -219,10 +221,124 @@ bool BagWriter::open(const char *path, size_t chunk_threshold) {
   f_ = std::fopen(path, "wb");
   if (!f_) return false;
   threshold_ = chunk_threshold;
+  compression_ = "none";
   conns_.clear(); by_topic_.clear(); chunk_.clear(); chunk_index_.clear(); conn_in_chunk_.clear(); infos_.clear();
   std::vector<uint8_t> blank(MAGIC_N + BAG_HEADER_RECORD, (uint8_t)' ');   // the header record is written by close()
   std::memcpy(blank.data(), MAGIC, MAGIC_N);
   return std::fwrite(blank.data(), 1, blank.size(), f_) == blank.size();
+}
+// ---- chunk compression: rosbag writes chunks "none", "bz2" (one bz2 stream of the chunk's records) or "lz4" (roslz4: one LZ4 frame,
+// format 1.4.1 — magic 0x184D2204, independent blocks, content checksum). Neither library has headers in this image and the product must
+// not depend on them, so libbz2.so.1.0 / liblz4.so.1 are looked up at run time (dlopen) and used through their stable C ABI
+// (BZ2_bzBuffToBuff{Decompress,Compress}; LZ4F_* of the frame API); without them such chunks are refused as before (VILO_BAG_ERR_COMPRESSED). ----
+namespace {
+struct Bz2Api {
+  int (*decompress)(char *, unsigned *, char *, unsigned, int, int) = nullptr;
+  int (*compress)(char *, unsigned *, char *, unsigned, int, int, int) = nullptr;
+};
+const Bz2Api *bz2_api() {
+  static const Bz2Api api = [] {
+    Bz2Api a;
+    void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (h) {
+      a.decompress = (decltype(a.decompress))dlsym(h, "BZ2_bzBuffToBuffDecompress");
+      a.compress = (decltype(a.compress))dlsym(h, "BZ2_bzBuffToBuffCompress");
+    }
+    return a;
+  }();
+  return (api.decompress && api.compress) ? &api : nullptr;
+}
+// lz4frame.h of liblz4 1.7 .. 1.9 (the structs are part of the library's ABI)
+struct Lz4FrameInfo { int blockSizeID, blockMode, contentChecksumFlag, frameType; unsigned long long contentSize; unsigned dictID; int blockChecksumFlag; };
+struct Lz4Preferences { Lz4FrameInfo frameInfo; int compressionLevel; unsigned autoFlush, favorDecSpeed, reserved[3]; };
+struct Lz4Api {
+  size_t (*create_dctx)(void **, unsigned) = nullptr;
+  size_t (*free_dctx)(void *) = nullptr;
+  size_t (*decompress)(void *, void *, size_t *, const void *, size_t *, const void *) = nullptr;
+  unsigned (*is_error)(size_t) = nullptr;
+  size_t (*bound)(size_t, const Lz4Preferences *) = nullptr;
+  size_t (*compress_frame)(void *, size_t, const void *, size_t, const Lz4Preferences *) = nullptr;
+};
+const Lz4Api *lz4_api() {
+  static const Lz4Api api = [] {
+    Lz4Api a;
+    void *h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (h) {
+      a.create_dctx = (decltype(a.create_dctx))dlsym(h, "LZ4F_createDecompressionContext");
+      a.free_dctx = (decltype(a.free_dctx))dlsym(h, "LZ4F_freeDecompressionContext");
+      a.decompress = (decltype(a.decompress))dlsym(h, "LZ4F_decompress");
+      a.is_error = (decltype(a.is_error))dlsym(h, "LZ4F_isError");
+      a.bound = (decltype(a.bound))dlsym(h, "LZ4F_compressFrameBound");
+      a.compress_frame = (decltype(a.compress_frame))dlsym(h, "LZ4F_compressFrame");
+    }
+    return a;
+  }();
+  return (api.create_dctx && api.free_dctx && api.decompress && api.is_error && api.bound && api.compress_frame) ? &api : nullptr;
+}
+// VILO_BAG_OK, VILO_BAG_ERR_COMPRESSED (no library for this compression) or VILO_BAG_ERR_FORMAT (the stream is not what the header says)
+int chunk_decompress(const std::string &compression, const std::vector<uint8_t> &src, uint32_t size, std::vector<uint8_t> *out) {
+  out->assign(size, 0);
+  if (compression == "bz2") {
+    const Bz2Api *a = bz2_api();
+    if (!a) return VILO_BAG_ERR_COMPRESSED;
+    unsigned n = size;
+    const int rc = a->decompress((char *)out->data(), &n, (char *)src.data(), (unsigned)src.size(), 0, 0);
+    return (rc == 0 && n == size) ? VILO_BAG_OK : VILO_BAG_ERR_FORMAT;
+  }
+  if (compression == "lz4") {
+    const Lz4Api *a = lz4_api();
+    if (!a) return VILO_BAG_ERR_COMPRESSED;
+    void *ctx = nullptr;
+    if (a->is_error(a->create_dctx(&ctx, 100 /* LZ4F_VERSION */)) || !ctx) return VILO_BAG_ERR_COMPRESSED;
+    size_t in_pos = 0, out_pos = 0, hint = 1;
+    bool ok = true;
+    while (ok && in_pos < src.size()) {
+      size_t dn = size - out_pos, sn = src.size() - in_pos;
+      hint = a->decompress(ctx, out->data() + out_pos, &dn, src.data() + in_pos, &sn, nullptr);
+      if (a->is_error(hint) || (dn == 0 && sn == 0)) { ok = false; break; }
+      in_pos += sn; out_pos += dn;
+      if (hint == 0) break;   // the frame is complete
+    }
+    a->free_dctx(ctx);
+    return (ok && hint == 0 && out_pos == size && in_pos == src.size()) ? VILO_BAG_OK : VILO_BAG_ERR_FORMAT;
+  }
+  return VILO_BAG_ERR_COMPRESSED;
+}
+bool chunk_compress(const std::string &compression, const std::vector<uint8_t> &src, std::vector<uint8_t> *out) {
+  if (compression == "bz2") {
+    const Bz2Api *a = bz2_api();
+    if (!a) return false;
+    unsigned n = (unsigned)(src.size() + src.size() / 100 + 600);
+    out->assign(n, 0);
+    if (a->compress((char *)out->data(), &n, (char *)src.data(), (unsigned)src.size(), 9, 0, 30) != 0) return false;   // (rosbag: block size 9)
+    out->resize(n);
+    return true;
+  }
+  if (compression == "lz4") {
+    const Lz4Api *a = lz4_api();
+    if (!a) return false;
+    Lz4Preferences pr;
+    std::memset(&pr, 0, sizeof(pr));
+    pr.frameInfo.blockSizeID = 7;          // LZ4F_max4MB
+    pr.frameInfo.blockMode = 1;            // LZ4F_blockIndependent (roslz4 writes and expects independent blocks)
+    pr.frameInfo.contentChecksumFlag = 1;  // the stream checksum roslz4 appends
+    out->assign(a->bound(src.size(), &pr), 0);
+    const size_t n = a->compress_frame(out->data(), out->size(), src.data(), src.size(), &pr);
+    if (a->is_error(n)) return false;
+    out->resize(n);
+    return true;
+  }
+  return false;
+}
+}  // namespace
+
+int BagWriter::setCompression(const std::string &name) {
+  if (name != "none" && name != "bz2" && name != "lz4") return VILO_BAG_ERR_FORMAT;
+  if ((name == "bz2" && !bz2_api()) || (name == "lz4" && !lz4_api())) return VILO_BAG_ERR_COMPRESSED;
+  if (!chunk_.empty() && name != compression_ && !flush_chunk()) return VILO_BAG_ERR_IO;   // (a chunk has one compression)
+  compression_ = name;
+  return VILO_BAG_OK;
 }
 void BagWriter::connection_record(const Conn &c, std::vector<uint8_t> *out) const {
   std::vector<uint8_t> h, d;
@@ -259,8 +375,13 @@ bool BagWriter::flush_chunk() {
   auto unpack = [](uint64_t tcmp) { return (tcmp >> 32) | ((tcmp & 0xffffffffULL) << 32); };   // back to secs (low) | nsecs (high)
   info.t0 = unpack(chunk_t0_); info.t1 = unpack(chunk_t1_);
   std::vector<uint8_t> out, h;
-  put_field_u8(&h, "op", 0x05); put_field_str(&h, "compression", "none"); put_field_u32(&h, "size", (uint32_t)chunk_.size());
-  put_record(&out, h, chunk_);
+  put_field_u8(&h, "op", 0x05); put_field_str(&h, "compression", compression_); put_field_u32(&h, "size", (uint32_t)chunk_.size());   // (size: uncompressed)
+  if (compression_ == "none") put_record(&out, h, chunk_);
+  else {
+    std::vector<uint8_t> packed;
+    if (!chunk_compress(compression_, chunk_, &packed)) return false;
+    put_record(&out, h, packed);
+  }
   for (const auto &kv : chunk_index_) {
     if (kv.second.empty()) continue;
     std::vector<uint8_t> ih, id;
@@ -363,10 +484,16 @@ int BagReader::load_next_chunk() {
     if (op == 0x05) {
       auto c = hf.find("compression");
       if (c == hf.end()) return VILO_BAG_ERR_FORMAT;
-      if (c->second != "none") return VILO_BAG_ERR_COMPRESSED;
       uint32_t size;
-      if (!field_u32(hf, "size", &size) || size != d.size()) return VILO_BAG_ERR_FORMAT;
-      chunk_.swap(d); pos_ = 0;
+      if (!field_u32(hf, "size", &size)) return VILO_BAG_ERR_FORMAT;
+      if (c->second == "none") {
+        if (size != d.size()) return VILO_BAG_ERR_FORMAT;
+        chunk_.swap(d);
+      } else {
+        const int drc = chunk_decompress(c->second, d, size, &chunk_);
+        if (drc != VILO_BAG_OK) return drc;
+      }
+      pos_ = 0;
       return VILO_BAG_OK;
     }
     if (op == 0x07) { if (!register_connection(hf, d, &conns_)) return VILO_BAG_ERR_FORMAT; continue; }
@@ -477,6 +604,7 @@ int vilo_bag_write_point_cloud(void *h, const char *topic, uint32_t seq, uint32_
   vilo::serialize(m, &d);
   return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_POINT_CLOUD, secs, nsecs, d) ? 0 : -1;
 }
+int vilo_bag_writer_set_compression(void *h, const char *name) { return h && name ? ((vilo::BagWriter *)h)->setCompression(name) : vilo::VILO_BAG_ERR_FORMAT; }
 int vilo_bag_writer_close(void *h) {
   vilo::BagWriter *w = (vilo::BagWriter *)h;
   const bool ok = w->close();

@@ -17,7 +17,8 @@
 // little endian, a header being fields <field_len u32><name>=<value>. Records: bag header (op 3; index_pos, conn_count, chunk_count; padded
 // to 4096 bytes), chunk (op 5; compression, size; data = connection (op 7) and message data (op 2) records), index data (op 4) after each
 // chunk, and at index_pos the connection records again + one chunk info (op 6) per chunk. The reader walks the chunks in file order and
-// needs neither index; chunks compressed with bz2 / lz4 are refused (VILO_BAG_ERR_COMPRESSED: no decompressor in this build). Messages
+// needs neither index; chunks compressed with bz2 / lz4 (rosbag record --bz2 / --lz4) are decompressed with the system's libbz2 / liblz4,
+// loaded at run time — without them such a bag is refused (VILO_BAG_ERR_COMPRESSED). Messages
 // are ROS 1 serialisation: little endian, strings and arrays prefixed with a u32 count.
 #pragma once
 #include <cstdint>
@@ -85,6 +86,9 @@ class BagWriter {
  public:
   ~BagWriter() { close(); }
   bool open(const char *path, size_t chunk_threshold = 768 * 1024);
+  // "none" (default), "bz2" or "lz4": how the chunks written from now on are compressed (rosbag record --bz2 / --lz4). VILO_BAG_OK,
+  // VILO_BAG_ERR_COMPRESSED if the system has no libbz2 / liblz4 to load, VILO_BAG_ERR_FORMAT for another name.
+  int setCompression(const std::string &name);
   // messages may be written in any order of topics; a topic's type is fixed by its first message
   bool write(const std::string &topic, int kind, uint32_t secs, uint32_t nsecs, const std::vector<uint8_t> &data);
   bool close();   // flushes the last chunk, writes the index section and the bag header
@@ -97,6 +101,7 @@ class BagWriter {
   bool flush_chunk();
   FILE *f_ = nullptr;
   size_t threshold_ = 0;
+  std::string compression_ = "none";
   std::vector<Conn> conns_;
   std::map<std::string, uint32_t> by_topic_;
   std::vector<uint8_t> chunk_;
@@ -164,6 +169,7 @@ int vilo_bag_write_image(void *h, const char *topic, uint32_t seq, uint32_t secs
 // channels: n_channels x n_points float32, channel-major
 int vilo_bag_write_point_cloud(void *h, const char *topic, uint32_t seq, uint32_t secs, uint32_t nsecs, int n_points, const float *xyz, int n_channels,
                                const char *const *channel_names, const float *channels);
+int vilo_bag_writer_set_compression(void *h, const char *name);   // BagWriter::setCompression
 int vilo_bag_writer_close(void *h);   // 0 ok; frees the handle
 
 void *vilo_bag_reader_open(const char *path, int *rc);

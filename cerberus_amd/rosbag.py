@@ -45,6 +45,7 @@ def _lib():
         H.vilo_bag_write_point_cloud.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
                                                  C.c_void_p]
         H.vilo_bag_writer_close.argtypes = [C.c_void_p]
+        H.vilo_bag_writer_set_compression.argtypes = [C.c_void_p, C.c_char_p]
         H.vilo_bag_reader_open.restype = C.c_void_p
         H.vilo_bag_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         H.vilo_bag_reader_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -69,11 +70,16 @@ def to_sec(secs, nsecs):
 
 
 class BagWriter:
-    def __init__(self, path, chunk_threshold=768 * 1024):
+    def __init__(self, path, chunk_threshold=768 * 1024, compression="none"):
+        """compression: "none", "bz2" or "lz4" (rosbag record --bz2 / --lz4), through the system's libbz2 / liblz4 loaded at run time"""
         self.H = _lib()
         self.h = C.c_void_p(self.H.vilo_bag_writer_open(str(path).encode(), int(chunk_threshold)))
         if not self.h:
             raise OSError("cannot create %s" % path)
+        rc = self.H.vilo_bag_writer_set_compression(self.h, compression.encode())
+        if rc != 0:
+            self.close()
+            raise BagError("chunk compression %r: %s" % (compression, "no library to load" if rc == -3 else "unknown"))
 
     def write(self, m):
         """m: a message dict as BagReader yields them / as stream_messages makes them"""
@@ -121,7 +127,7 @@ class BagError(Exception):
 
 class BagReader:
     """for m in BagReader(path): m is a dict (kind, topic, type, seq, secs, nsecs, rec_secs, rec_nsecs + the type's fields)"""
-    ERRORS = {-1: "I/O error", -2: "not a bag, or a damaged one", -3: "compressed chunk (bz2 / lz4): no decompressor in this build"}
+    ERRORS = {-1: "I/O error", -2: "not a bag, or a damaged one", -3: "compressed chunk: no library to decompress it with (bz2 / lz4 need the system's libbz2 / liblz4), or an unknown compression"}
 
     def __init__(self, path):
         self.H = _lib()
@@ -210,10 +216,10 @@ def stream_messages(frame, t_prev, seq0, rate=500.0, with_images=False):
     return out, seq + 1
 
 
-def write_stream_bag(path, frames, t0, with_images=False, chunk_threshold=768 * 1024):
+def write_stream_bag(path, frames, t0, with_images=False, chunk_threshold=768 * 1024, compression="none"):
     """frames: Stream.next() dicts in order; t0: the stamp just before the first frame's first sample. Returns the messages written."""
     msgs, seq, t_prev = [], 0, t0
-    with BagWriter(path, chunk_threshold) as w:
+    with BagWriter(path, chunk_threshold, compression) as w:
         for f in frames:
             ms, seq = stream_messages(f, t_prev, seq, with_images=with_images)
             for m in ms:

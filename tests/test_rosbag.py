@@ -71,7 +71,8 @@ def test_byte_layout_of_a_minimal_bag(tmp_path):
     assert at == len(raw)
 
 
-def test_every_message_type_round_trips_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
+def test_every_message_type_round_trips_bit_for_bit(tmp_path, compression):
     from cerberus_amd import rosbag as rb
     rng = np.random.default_rng(3)
     msgs = []
@@ -94,12 +95,14 @@ def test_every_message_type_round_trips_bit_for_bit(tmp_path):
             msgs.append(dict(kind=rb.KIND_POINT_CLOUD, topic="/feature_tracker/feature", seq=i, secs=secs, nsecs=nsecs, points=rng.normal(size=(n, 3)).astype(np.float32),
                              channels=rng.normal(size=(6, n)).astype(np.float32), channel_names=["id", "camera_id", "p_u", "p_v", "velocity_x", "velocity_y"]))
     p = tmp_path / "all.bag"
-    with rb.BagWriter(p, chunk_threshold=4096) as w:   # small chunks: many of them; a connection record only in the chunk of the connection's first message
+    with rb.BagWriter(p, chunk_threshold=4096, compression=compression) as w:   # small chunks: many of them; a connection record only in the chunk of the connection's first message
         for m in msgs:
             w.write(m)
     r = rb.BagReader(p)
     assert r.conn_count == 5 and r.chunk_count > 5 and r.index_pos > 4096
-    assert p.read_bytes()[:r.index_pos].count(b"type=sensor_msgs/") == 5      # (the connection records inside the chunks: one per topic)
+    if compression == "none":
+        assert p.read_bytes()[:r.index_pos].count(b"type=sensor_msgs/") == 5      # (the connection records inside the chunks: one per topic)
+    assert p.read_bytes().count(b"compression=" + compression.encode()) == r.chunk_count
     back = list(r)
     assert len(back) == len(msgs)
     for a, b in zip(msgs, back):
@@ -134,13 +137,98 @@ def test_damaged_compressed_and_foreign_bags_are_refused(tmp_path):
     hl = struct.unpack_from("<I", raw, at)[0]
     hdr = raw[at + 4:at + 4 + hl].replace(b"\x10\x00\x00\x00compression=none", b"\x0f\x00\x00\x00compression=lz4")
     (tmp_path / "lz4.bag").write_bytes(raw[:at] + struct.pack("<I", len(hdr)) + hdr + raw[at + 4 + hl:])
-    with pytest.raises(rb.BagError, match="compressed"):
+    with pytest.raises(rb.BagError, match="damaged"):                # (the bytes are not an LZ4 frame)
         list(rb.BagReader(tmp_path / "lz4.bag"))
+    hdr = raw[at + 4:at + 4 + hl].replace(b"\x10\x00\x00\x00compression=none", b"\x10\x00\x00\x00compression=zstd")
+    (tmp_path / "zstd.bag").write_bytes(raw[:at] + struct.pack("<I", len(hdr)) + hdr + raw[at + 4 + hl:])
+    with pytest.raises(rb.BagError, match="compress"):
+        list(rb.BagReader(tmp_path / "zstd.bag"))
     # a topic of a type the reader does not know is passed over as KIND_OTHER, the rest of the bag still reads
     other = raw.replace(b"type=sensor_msgs/Imu", b"type=sensor_msgs/Gps")
     (tmp_path / "other.bag").write_bytes(other)
     kinds = [m["kind"] for m in rb.BagReader(tmp_path / "other.bag")]
     assert kinds == [rb.KIND_OTHER] * 10
+
+
+def _records(raw, at, end):
+    """top-level records of a bag file: (offset, header fields, data)"""
+    out = []
+    while at < end:
+        hl = struct.unpack_from("<I", raw, at)[0]
+        h, f, q = raw[at + 4:at + 4 + hl], {}, 0
+        while q < len(h):
+            n = struct.unpack_from("<I", h, q)[0]
+            k, v = h[q + 4:q + 4 + n].split(b"=", 1)
+            f[k.decode()] = v
+            q += 4 + n
+        dl = struct.unpack_from("<I", raw, at + 4 + hl)[0]
+        out.append((at, f, raw[at + 8 + hl:at + 8 + hl + dl]))
+        at += 8 + hl + dl
+    return out
+
+
+def _record(fields, data):
+    h = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k.encode() + b"=" + v for k, v in fields.items())
+    return struct.pack("<I", len(h)) + h + struct.pack("<I", len(data)) + data
+
+
+def test_compressed_chunks_against_independent_codecs(tmp_path):
+    """bz2: the writer's chunks decompress with Python's bz2 to the chunks of the same bag written uncompressed, and a bag whose chunks were
+    compressed by Python's bz2 (the file rebuilt record by record here) reads back message for message. lz4: the writer's chunks are LZ4
+    frames as roslz4 writes them (magic 0x184D2204, version 01, independent blocks, content checksum) and decompress through liblz4's own
+    frame API, called from here, to the uncompressed chunks."""
+    import bz2
+    import ctypes as C
+    from cerberus_amd import rosbag as rb
+    rng = np.random.default_rng(8)
+    msgs = [dict(kind=rb.KIND_IMU, topic="/imu", seq=i, secs=5 + i // 50, nsecs=(i * 20000000) % 1000000000, frame_id="imu", linear_acceleration=rng.normal(size=3),
+                 angular_velocity=rng.normal(size=3)) if i % 3 else
+            dict(kind=rb.KIND_JOINT_STATE, topic="/leg", seq=i, secs=5 + i // 50, nsecs=(i * 20000000) % 1000000000, position=rng.normal(size=16), velocity=rng.normal(size=16),
+                 effort=rng.normal(size=16)) for i in range(400)]
+    raws = {}
+    for comp in ("none", "bz2", "lz4"):
+        with rb.BagWriter(tmp_path / (comp + ".bag"), chunk_threshold=8192, compression=comp) as w:
+            for m in msgs:
+                w.write(m)
+        raws[comp] = (tmp_path / (comp + ".bag")).read_bytes()
+    chunks = {c: [(f, d) for _, f, d in _records(raws[c], 13 + 4096, len(raws[c])) if f["op"] == b"\x05"] for c in raws}
+    assert len(chunks["none"]) > 5 and len(chunks["bz2"]) == len(chunks["lz4"]) == len(chunks["none"])
+    lz4 = C.CDLL("liblz4.so.1")
+    lz4.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    lz4.LZ4F_decompress.restype = C.c_size_t
+    lz4.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+    lz4.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+    for (f0, d0), (fb, db), (fl, dl) in zip(chunks["none"], chunks["bz2"], chunks["lz4"]):
+        assert fb["compression"] == b"bz2" and fl["compression"] == b"lz4" and fb["size"] == fl["size"] == f0["size"] == struct.pack("<I", len(d0))
+        assert bz2.decompress(db) == d0
+        assert struct.unpack_from("<I", dl)[0] == 0x184D2204 and dl[4] >> 6 == 1 and dl[4] & 0x20 and dl[4] & 0x04 and not dl[4] & 0x08
+        ctx = C.c_void_p()
+        assert lz4.LZ4F_createDecompressionContext(C.byref(ctx), 100) == 0
+        out, dn, sn = C.create_string_buffer(len(d0)), C.c_size_t(len(d0)), C.c_size_t(len(dl))
+        assert lz4.LZ4F_decompress(ctx, out, C.byref(dn), dl, C.byref(sn), None) == 0 and dn.value == len(d0) and sn.value == len(dl)
+        lz4.LZ4F_freeDecompressionContext(ctx)
+        assert out.raw == d0
+    # the reader on chunks it did not compress: the uncompressed file with every chunk recompressed by Python's bz2
+    raw = raws["none"]
+    body, index_pos = b"", None
+    for at, f, d in _records(raw, 13 + 4096, len(raw)):
+        if f["op"] == b"\x05":
+            f = dict(f, compression=b"bz2")
+            d = bz2.compress(d, 9)
+        elif f["op"] == b"\x07" and index_pos is None:
+            index_pos = 13 + 4096 + len(body)      # (the index section starts with the connection records)
+        body += _record(f, d)
+    (hat, hf, hd), = _records(raw, 13, 13 + 4096)
+    hdr = _record(dict(hf, index_pos=struct.pack("<Q", index_pos)), hd)
+    assert len(hdr) == 4096
+    (tmp_path / "pybz2.bag").write_bytes(raw[:13] + hdr + body)
+    back = list(rb.BagReader(tmp_path / "pybz2.bag"))
+    assert len(back) == len(msgs)
+    for a, b in zip(msgs, back):
+        assert (a["kind"], a["seq"], a["secs"], a["nsecs"]) == (b["kind"], b["seq"], b["secs"], b["nsecs"])
+        for key in ("linear_acceleration", "angular_velocity", "position", "velocity", "effort"):
+            if key in a:
+                np.testing.assert_array_equal(np.asarray(a[key]), b[key])
 
 
 def test_stamps_are_ros_time():

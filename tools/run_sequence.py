@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--csv", default=None)
     ap.add_argument("--write-bag", default=None, help="write the synthetic stream of robot 0 (IMU, JointState, feature clouds) to this bag and stop")
     ap.add_argument("--bag", default=None, help="replay this bag instead of a synthetic stream (one robot)")
+    ap.add_argument("--compression", default="none", choices=("none", "bz2", "lz4"), help="--write-bag: chunk compression (rosbag record --bz2 / --lz4)")
     ap.add_argument("--push-every", type=int, default=0, help="push the IMU / leg samples to the device-resident preintegration objects every N messages, "
                     "as they arrive, instead of in the image step (0: in the image step); same estimates, shorter image step")
     ap.add_argument("--contact-sensor-type", type=int, default=1, help="--bag: 0 / 1 the planner's flags (0: in place of the absent Kalman filter), 2 foot forces")
@@ -36,7 +37,7 @@ def main():
         from cerberus_amd import rosbag
         stream = sequence.Stream(cfg, seed=100)
         frames = [stream.next() for _ in range(a.images)]
-        msgs = rosbag.write_stream_bag(a.write_bag, frames, frames[0]["header"] - len(frames[0]["samples"]) / 500.0)
+        msgs = rosbag.write_stream_bag(a.write_bag, frames, frames[0]["header"] - len(frames[0]["samples"]) / 500.0, compression=a.compression)
         print("%s: %d messages of %d images (%d bytes)" % (a.write_bag, len(msgs), a.images, os.path.getsize(a.write_bag)))
         return
     ctx = api.Context(cfg, 0)
