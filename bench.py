@@ -232,8 +232,9 @@ def parity_sample(cfg, windows, ids, landmarks, rate, summ, n=8, repropagate=Fal
         for a, b in zip(windows[i].state_arrays(), w_ref.state_arrays()):
             max_state = max(max_state, float(np.abs(a - b).max() / max(1.0, np.abs(b).max())))
         max_cost = max(max_cost, abs(summ[i].final_cost - osum.final_cost) / max(abs(osum.final_cost), 1e-300))
-    return {"windows": n, "max_state_err": max_state, "max_cost_rel": max_cost, "tolerance": 1e-6,
-            "what": "final states (relative to max(1, |state block|)) and final cost of the first %d windows of the timed batch after the last timed step vs "
+    return {"windows": n, "max_state_err": max_state, "max_cost_rel": max_cost, "tolerance": 1e-8,
+            "what": "SOLVER parity (the oracle is handed the preintegration records the GPU integrated; K1 has its own goldens and "
+                    "tests/test_gpu_parity.py::test_path_parity_with_the_oracles_own_preintegration covers the whole path): final states (relative to max(1, |state block|)) and final cost of the first %d windows of the timed batch after the last timed step vs "
                     "oracle/liboracle.so on the same seeds, %d fixed iterations%s" % (n, ITERS, ", intervals integrated again per evaluation" if repropagate else "")}
 
 
@@ -282,6 +283,80 @@ def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
            "parity_sample": parity_sample(cfg, windows, [20000000 + i for i in range(W)], 1000, 400, summ, n=2, repropagate=True)}
     batch.close()
     return out
+
+
+class ControlPlane:
+    """The two control collectives the bench contract asks for (barrier, max-over-ranks of the elapsed time) plus the shard report. The data
+    path has no collective (windows are independent), so which library carries these three calls changes nothing that is measured."""
+
+    def __init__(self, dist, group, backend, note):
+        self.dist, self.group, self.backend, self.note = dist, group, backend, note
+
+    def device(self, local_rank):
+        return "cuda:%d" % local_rank if self.backend == "nccl" else "cpu"
+
+    def barrier(self, local_rank):
+        if self.dist is None:
+            return
+        if self.backend == "nccl":
+            self.dist.barrier(group=self.group, device_ids=[local_rank])
+        else:
+            self.dist.barrier(group=self.group)
+
+    def max_over_ranks(self, x, local_rank):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device=self.device(local_rank))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def all_gather(self, vec, local_rank, world):
+        import torch
+        mine = torch.tensor(vec, dtype=torch.float64, device=self.device(local_rank))
+        out = [torch.zeros(len(vec), dtype=torch.float64, device=mine.device) for _ in range(world)]
+        self.dist.all_gather(out, mine, group=self.group)
+        return [[float(v) for v in x.tolist()] for x in out]
+
+
+def init_control_plane(rank, world, local_rank, want=None, probe_timeout_s=120.0):
+    """One rank per GPU. The default process group is gloo (CPU tensors; it needs nothing from the GPUs and always comes up on 127.0.0.1).
+    RCCL ("nccl" on ROCm) is then tried as a second group with one probe all-reduce on the rank's own GPU, in a thread with a deadline;
+    the ranks agree over gloo on whether EVERY probe succeeded. If so the barrier and the max-over-ranks reduction run over RCCL, otherwise
+    over gloo — a box where RCCL cannot start (two ranks on one GPU: "Duplicate GPU detected"; a missing IPC mode) still produces the line.
+    VILO_BENCH_BACKEND=gloo skips the probe."""
+    import datetime
+    import threading
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    want = want or os.environ.get("VILO_BENCH_BACKEND", "nccl")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if want != "nccl":
+        return ControlPlane(dist, None, "gloo", "VILO_BENCH_BACKEND=%s" % want)
+    res = {"ok": 0, "err": "probe did not return within %.0f s" % probe_timeout_s, "group": None}
+
+    def probe():
+        try:
+            if not torch.cuda.is_available():
+                raise RuntimeError("no GPU visible to this rank")
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=60))
+            t = torch.ones(1, dtype=torch.float64, device="cuda:%d" % local_rank)
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError("probe all-reduce returned %r, expected %d" % (t.item(), world))
+            res.update(ok=1, err=None, group=g)
+        except BaseException as e:   # (DistBackendError, RuntimeError, ... : anything means "not over RCCL on this box")
+            res.update(ok=0, err=repr(e)[:300])
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    th.join(probe_timeout_s)
+    flag = torch.tensor([res["ok"] if not th.is_alive() else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # gloo: every rank learns whether every probe succeeded
+    if int(flag.item()) == 1:
+        return ControlPlane(dist, res["group"], "nccl", "RCCL probe all-reduce succeeded on every rank")
+    return ControlPlane(dist, None, "gloo", "RCCL unavailable, control collectives over gloo: %s" % (res["err"] or "a peer's probe failed"))
 
 
 def self_launch(n):
@@ -337,21 +412,12 @@ def main():
         return 2
     import torch
     dist = None
+    ctl = ControlPlane(None, None, "none", "single rank")
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm; VILO_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box
-        backend = os.environ.get("VILO_BENCH_BACKEND", "nccl")
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            # the rank's own GPU is named explicitly (RCCL otherwise guesses it from the global rank at the first collective)
-            try:
-                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            except TypeError:   # (a torch without the device_id argument)
-                dist.init_process_group(backend, rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        ctl = init_control_plane(rank, world, local_rank)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
@@ -387,8 +453,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+        ctl.barrier(local_rank)
         torch.cuda.synchronize()
 
     # Warm-up steps run with an event pair around every kernel: the per-kernel table of the line comes from them. The timed steps
@@ -426,14 +491,10 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = ctl.max_over_ranks(elapsed, local_rank)
         # which windows each rank solved (first / last seed and a checksum of its first window's observations): shows the shards are disjoint
-        mine = torch.tensor([float(20260925 + ids[0]), float(20260925 + ids[-1]), float(windows[0].obs.sum())], dtype=torch.float64, device=t.device)
-        shards = [torch.zeros(3, dtype=torch.float64, device=t.device) for _ in range(world)]
-        dist.all_gather(shards, mine)
-        shard_info = [[int(x[0].item()), int(x[1].item()), float(x[2].item())] for x in shards]
+        shards = ctl.all_gather([float(20260925 + ids[0]), float(20260925 + ids[-1]), float(windows[0].obs.sum())], local_rank, world)
+        shard_info = [[int(x[0]), int(x[1]), float(x[2])] for x in shards]
     else:
         shard_info = [[20260925 + ids[0], 20260925 + ids[-1], float(windows[0].obs.sum())]]
 
@@ -472,10 +533,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
         barrier()
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        el = ctl.max_over_ranks(el, local_rank)
         summ_s = bs.download()
         assert sum(s_.iterations for s_ in summ_s) == Ws * ITERS
         bs.close()
@@ -529,6 +587,7 @@ def main():
                       "GN iters/sec, 10-KF x 1000-landmark VILO window + 400 Hz IMU preintegration re-propagated every iteration (BASELINE configs[2])",
             "value": value, "unit": "GN window-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "value_per_gpu": value / world, "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
+            "control_backend": ctl.backend, "control_backend_note": ctl.note,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload + ": synthetic 10-KF x %d-landmark window, 4-leg contact preintegration (%d Hz), "
@@ -635,11 +694,15 @@ def main():
                 out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256], n_cpu=2 if rp else 8)
             except Exception as e:
                 out["marginalize"] = {"error": repr(e)}
-            out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks, rate=args.rate, repropagate=rp)
-            try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks) if not rp else None
-            except Exception as e:   # the single-thread number above is the contract; this one is extra information
-                out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            # rank 0, one thread, after the timed region (at N > 1 the other ranks are done with their GPUs by now and only wait for this
+            # rank at the process group's teardown): every line the driver records carries the CPU figure beside `value`
+            out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks, budget_s=15.0 if world == 1 else 10.0, rate=args.rate, repropagate=rp)
+            if world == 1:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks) if not rp else None
+                except Exception as e:   # the single-thread number above is the contract; this one is extra information
+                    out["cpu_baseline_all_cores"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
@@ -653,6 +716,14 @@ def main():
     batch.close()
     ctx.close()
     if dist is not None:
+        sys.stdout.flush(); sys.stderr.flush()
+        if ctl.backend == "gloo" and "unavailable" in ctl.note:
+            # a failed RCCL probe may have left a communicator half-built (or its thread waiting for a peer): nothing to tear down cleanly
+            try:
+                dist.barrier()
+            except Exception:
+                pass
+            os._exit(exit_code)
         dist.destroy_process_group()
     return exit_code
 

@@ -31,6 +31,59 @@ __device__ __forceinline__ double block_sum128(double v, double *red) {
   return v;
 }
 
+// The three decisions of the bookkeeping, each taken by ONE thread of the window's workgroup (shared by accept_body below and by the full
+// batch's pose assembly, kernels_asm_full.hip, which runs the same bookkeeping with its loads arranged differently).
+// HandleInvalidStep: FAILURE at max_num_consecutive_invalid_steps (5, Ceres default), else DoglegStrategy::StepIsInvalid (mu *= 10, no reuse).
+// The candidate pass linearised the unchanged point again (the solver left xc = x): the next step starts from it.
+__device__ __forceinline__ void accept_invalid_step(SolverState &st, const AcceptParams &ap) {
+  st.num_invalid++;
+  if (st.num_invalid >= 5) { st.done = 1; st.termination = 2; }
+  else st.mu *= 10.0;
+  st.need_lin = 1;
+  st.iter++;
+  if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
+  if (st.iter >= ap.max_num_iterations && !st.done) { st.done = 1; st.termination = 0; }
+  if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
+}
+// IterationZero: the initial point's cost
+__device__ __forceinline__ void accept_initial_point(SolverState &st, const AcceptParams &ap, double cand, double vis, double imu, double pri) {
+  st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
+  st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
+  // a non-finite evaluation at the initial point: ceres::Solve fails in IterationZero ("Residual and Jacobian evaluation
+  // failed", ResidualBlock::Evaluate's IsArrayValid) and leaves the parameters alone; this window is done, the others go on
+  if (!(cand < 1.7976931348623157e308)) { st.done = 1; st.termination = 2; }
+  // "Maximum solver time reached" is checked before every iteration, the first included
+  if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
+  st.cur ^= 1;   // the pass that gave this cost also linearised the point: its landmark gradients become the current ones
+}
+// IsStepSuccessful + Handle{Successful,Unsuccessful}Step + DoglegStrategy::Step{Accepted,Rejected}; returns 1 if the candidate is accepted
+__device__ __forceinline__ int accept_decide(SolverState &st, const AcceptParams &ap, double cand, double vis, double imu, double pri, double x_cost0, double mcc0) {
+  int accepted;
+  const double rel = (x_cost0 - cand) / mcc0;
+  st.cand_cost = cand;
+  st.num_invalid = 0;
+  if (rel > ap.min_relative_decrease) {
+    accepted = 1;
+    st.x_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
+    if (rel < 0.25) st.radius *= 0.5;
+    if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
+    st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+    st.need_lin = 1;
+    st.cur ^= 1;   // the candidate's linearisation (made by the pass that evaluated its cost) becomes the current one
+    st.num_successful++;
+  } else {
+    accepted = 0;
+    st.radius *= 0.5;
+    st.need_lin = 0;
+  }
+  st.iter++;
+  if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
+  if (st.iter >= ap.max_num_iterations) { st.done = 1; st.termination = 0; }
+  // max_solver_time_in_seconds: "Maximum solver time reached" before the next iteration starts (TrustRegionMinimizer's iteration check)
+  if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
+  return accepted;
+}
+
 // red: 128 doubles (8 used), dxs: VILO_MAX_PRIOR_DIM doubles, accept_sp: one int (LDS); part: null, or (blockDim.x / 96) * 96 doubles of LDS —
 // then the prior's H dx is taken by every thread of the workgroup, a slice of the columns each (k_assemble_s: 8 slices of 12 columns; with
 // one row per thread the 73 KB of H are 96 dependent loads per thread, 6 round trips of a batch's 16: 15 k of the bookkeeping's 19 k cycles
@@ -50,18 +103,7 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
   const double x_cost0 = st.x_cost, mcc0 = st.model_cost_change;
   double *x = b.x + (size_t)win * XSTRIDE, *xc = b.xc + (size_t)win * XSTRIDE;
   if (!ap.init_mode && !step_valid0) {
-    if (tid == 0) {
-      // HandleInvalidStep: FAILURE at max_num_consecutive_invalid_steps (5, Ceres default), else DoglegStrategy::StepIsInvalid (mu *= 10,
-      // no reuse). The candidate pass linearised the unchanged point again (the solver left xc = x): the next step starts from it.
-      st.num_invalid++;
-      if (st.num_invalid >= 5) { st.done = 1; st.termination = 2; }
-      else st.mu *= 10.0;
-      st.need_lin = 1;
-      st.iter++;
-      if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
-      if (st.iter >= ap.max_num_iterations && !st.done) { st.done = 1; st.termination = 0; }
-      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-    }
+    if (tid == 0) accept_invalid_step(st, ap);
     return;
   }
   // candidate cost = 1/2 (visual rho sums + |imu residuals|^2 + |prior residual|^2). Every load of the three parts is issued before the
@@ -114,16 +156,7 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
       if (!b.imu_skip[(size_t)win * 10 + k] && b.prep_bad[(size_t)win * 10 + k]) cand = 1.7976931348623157e308;
   }
   if (ap.init_mode) {
-    if (tid == 0) {
-      st.x_cost = cand; st.cand_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
-      st.cost_trace[0] = cand; st.radius_trace[0] = st.radius;
-      // a non-finite evaluation at the initial point: ceres::Solve fails in IterationZero ("Residual and Jacobian evaluation
-      // failed", ResidualBlock::Evaluate's IsArrayValid) and leaves the parameters alone; this window is done, the others go on
-      if (!(cand < 1.7976931348623157e308)) { st.done = 1; st.termination = 2; }
-      // "Maximum solver time reached" is checked before every iteration, the first included
-      if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-      st.cur ^= 1;   // the pass that gave this cost also linearised the point: its landmark gradients become the current ones
-    }
+    if (tid == 0) accept_initial_point(st, ap, cand, vis, imu, pri);
     if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;
     return;
   }
@@ -150,30 +183,7 @@ __device__ __forceinline__ void accept_body(BatchDev &b, const AcceptParams &ap,
     if (tid == 0) { st.done = 1; st.termination = 1; st.cand_cost = cand; }
     return;
   }
-  if (tid == 0) {
-    const double rel = (x_cost0 - cand) / mcc0;
-    st.cand_cost = cand;
-    st.num_invalid = 0;
-    if (rel > ap.min_relative_decrease) {
-      accept_s = 1;
-      st.x_cost = cand; st.vis_cost = vis; st.imu_cost = imu; st.prior_cost = pri;
-      if (rel < 0.25) st.radius *= 0.5;
-      if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
-      st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
-      st.need_lin = 1;
-      st.cur ^= 1;   // the candidate's linearisation (made by the pass that evaluated its cost) becomes the current one
-      st.num_successful++;
-    } else {
-      accept_s = 0;
-      st.radius *= 0.5;
-      st.need_lin = 0;
-    }
-    st.iter++;
-    if (st.iter < 64) { st.cost_trace[st.iter] = st.x_cost; st.radius_trace[st.iter] = st.radius; }
-    if (st.iter >= ap.max_num_iterations) { st.done = 1; st.termination = 0; }
-    // max_solver_time_in_seconds: "Maximum solver time reached" before the next iteration starts (TrustRegionMinimizer's iteration check)
-    if (!st.done && ap.max_solver_time_us > 0 && (wall_clock64() - st.t_start) >= 100LL * ap.max_solver_time_us) { st.done = 1; st.termination = 0; }
-  }
+  if (tid == 0) accept_s = accept_decide(st, ap, cand, vis, imu, pri, x_cost0, mcc0);
   __syncthreads();
   if (accept_s) {
     if (tid < wm.prior_n) b.prior_hd[(size_t)win * 96 + tid] = my_hd;

@@ -128,7 +128,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   // ---- visual Gram slots: AS_NG chunks per trip, one per thread group, each into its own image / gradient copy ----
   {
     double *const Cg = grp ? Cl1 + (grp - 1) * CL_N : Cl, *const gg = grp ? gl1 + (grp - 1) * CD_N : gl, *const stage = lds + AS_ST0 + grp * AC_STAGE;
-    auto rmw = [&](int hi, int lo, double v) { Cg[cl_pos(hi, lo)] += v; };   // hi >= lo
+    auto rmw = [&](int hi, int lo, double v) { lds_add(&Cg[cl_pos(hi, lo)], v); };   // hi >= lo
     const int nch = min(wm.n_chunks, 64), ntrip = (nch + AS_NG - 1) / AS_NG;
     double pf[8];
     auto prefetch = [&](int ch) {
@@ -153,7 +153,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
       if (ch < nch) {
         const unsigned ct = chunk_tab[ch];
         const int cs_ = (int)(ct & 255), km = (int)((ct >> 8) & 255);
-        assemble_visual_compact_chunk(lt, cs_, km, stage, Rt, rmw, [&](int cd, double v) { gg[cd] += v; });
+        assemble_visual_compact_chunk(lt, cs_, km, stage, Rt, rmw, [&](int cd, double v) { lds_add(&gg[cd], v); });
         if (lt >= 64 && lt < 128) {
           // wave 1 of the group: the {tic, tic2}^2 entries, three lanes per entry (each a third of the chunk's frames), partial sums added in lane order
           const int wl = lt - 64, q = wl % 21, g3 = min(wl / 21, 2);
@@ -270,9 +270,9 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
     const int pe1 = tri39(pa, pbc), pe2 = (pcls == 4) ? pe1 : tri39(pa + 19, pcls == 3 ? 38 : pbc + 19);
     for (int k = 0; k + 1 < F; ++k) {
       const double vm = grams[780 * k + pe1], vt = grams[780 * k + pe2];
-      if (pcls == 1) { Cl[cl_pos(6 * k + pbc, 6 * k + pa)] += vm; Cl[cl_pos(6 * (k + 1) + pbc, 6 * (k + 1) + pa)] += vt; }
-      else if (pcls == 3) { gl[6 * k + pa] += vm; gl[6 * (k + 1) + pa] += vt; }
-      else Cl[cl_pos(6 * (k + 1) + (pbc - 19), 6 * k + pa)] += vm;
+      if (pcls == 1) { lds_add(&Cl[cl_pos(6 * k + pbc, 6 * k + pa)], vm); lds_add(&Cl[cl_pos(6 * (k + 1) + pbc, 6 * (k + 1) + pa)], vt); }
+      else if (pcls == 3) { lds_add(&gl[6 * k + pa], vm); lds_add(&gl[6 * (k + 1) + pa], vt); }
+      else lds_add(&Cl[cl_pos(6 * (k + 1) + (pbc - 19), 6 * k + pa)], vm);
     }
   }
   // diagonal and gradient of the frames' speed / leg-bias dimensions (the prior's share of the gradient is there already)

@@ -111,7 +111,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   // ---- plain (non-atomic) read-modify-write scatter: every target has exactly one owner thread. Two packed Gram entries can hit the
   //      same target only if they are "twins" (the same local pair taken once in the pose_s block and once in the pose_j block; for IMU
   //      factors once in the frame-i half and once in the frame-j half of the previous factor), so a thread owns an entry and its twin ----
-  auto rmw = [&](int hi, int lo, double v) { Cl[cl_pos(hi, lo)] += v; };   // hi >= lo
+  auto rmw = [&](int hi, int lo, double v) { lds_add(&Cl[cl_pos(hi, lo)], v); };   // hi >= lo
   if (COMPACT) {
     // chunk by chunk: the chunk's slots (kmax x 184 doubles, contiguous) come into LDS with coalesced loads — every byte once — and the
     // owner threads gather from there; the next chunk's slots are in flight (registers) while this one is scattered
@@ -134,7 +134,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       lds_barrier();
       PCLK(w_t0 = clock64());
       if (ch + 1 < nch) prefetch(ch + 1);
-      assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { gl[cd] += v; });
+      assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { lds_add(&gl[cd], v); });
       if (tid >= 64 && tid < 128) {
         // wave 1: the {tic, tic2}^2 entries, three lanes per entry (each a third of the chunk's frames), partial sums added in lane order
         const int wl = tid - 64, q = wl % 21, grp = min(wl / 21, 2);
@@ -195,7 +195,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
           double sum = 0.0;
 #pragma unroll
           for (int t = 0; t < 11; ++t) sum += (t < km) ? v1[c2][t] : 0.0;
-          if (isg) gl[cls == 4 ? ra_ : 6 * s_ + a] += sum;
+          if (isg) lds_add(&gl[cls == 4 ? ra_ : 6 * s_ + a], sum);
           else if (cls == 1) rmw(6 * s_ + bc, 6 * s_ + a, sum);
           else if (cls == 3) rmw(rb, 6 * s_ + a, sum);
           else rmw(rb, ra_, sum);
@@ -206,7 +206,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
             if (t < km) {
               const int j_ = s_ + t;
               const double val = (cls == 2) ? v1[c2][t] : v2[c2][t];
-              if (cls == 3 && isg) gl[6 * j_ + a] += val;
+              if (cls == 3 && isg) lds_add(&gl[6 * j_ + a], val);
               else if (cls == 1) rmw(6 * j_ + bc, 6 * j_ + a, val);
               else if (cls == 2) rmw(6 * j_ + (bc - 6), 6 * s_ + a, val);
               else rmw(rb, 6 * j_ + a, val);
@@ -314,7 +314,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
       if (pcls && has_i) {
         const double vm = Gi[pe1], vt = Gi[pe2];
         if (pcls == 1) { rmw(6 * k + pbc, 6 * k + pa, vm); rmw(6 * (k + 1) + pbc, 6 * (k + 1) + pa, vt); }
-        else if (pcls == 3) { gl[6 * k + pa] += vm; gl[6 * (k + 1) + pa] += vt; }
+        else if (pcls == 3) { lds_add(&gl[6 * k + pa], vm); lds_add(&gl[6 * (k + 1) + pa], vt); }
         else rmw(6 * (k + 1) + (pbc - 19), 6 * k + pa, vm);
       }
       if (tid >= 200 && tid < 213) {

@@ -20,6 +20,10 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 // (HIP's __syncthreads() also drains vmcnt, which serialises every prefetch behind the barrier).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // single-wave workgroups: LDS writes of this wave are visible to its later reads once lgkmcnt has drained
+// image[e] += v in LDS as ONE instruction (ds_add_f64, no return value): an owner thread's read-modify-writes of the assembly scatter are then
+// a stream of independent LDS operations instead of a chain of read -> add -> write round trips. A target still has exactly one owner thread and
+// a wave's LDS operations execute in program order, so the sums keep their fixed order (batch of N == batch of 1, bitwise).
+__device__ __forceinline__ void lds_add(double *p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // broadcast lane `src` (wave-uniform index) of a double through SGPRs (v_readlane): a few cycles, no LDS round trip
 __device__ __forceinline__ double readlane_d(double v, int src) {

@@ -3,9 +3,12 @@
 // step of a fleet. Items are handed out one by one through an atomic counter; the caller works too. One job at a time per pool; every
 // shared library that includes this has its own pool.
 #pragma once
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -13,56 +16,81 @@
 
 namespace vilo {
 
+// Three properties the per-call spawn / join it replaced had for free, kept here on purpose:
+//   * fork(): a child process inherits the pool object but none of its threads. The pool remembers the pid that started the threads; in any
+//     other process run() works through the items on the calling thread (no waiting for workers that do not exist).
+//   * exceptions: fn throwing on the CALLING thread must not unwind run() while workers still dereference fn_ — the caller's share runs under
+//     try / catch, the remaining items are cancelled, run() waits for busy_ == 0 and only then rethrows. A worker's exception is carried
+//     over to the caller the same way (first one wins).
+//   * process exit: the workers are detached and the shared state lives in a block that is never freed, so static destruction neither
+//     joins (a child after fork() would join threads it never had) nor pulls memory from under a worker that is just waking up.
 class WorkerPool {
+  struct State {
+    std::mutex m, run_m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0, busy = 0;
+    std::atomic<int> next{0};
+    unsigned long long gen = 0;
+    std::exception_ptr err;
+  };
+
  public:
-  explicit WorkerPool(int nt) {
-    for (int t = 0; t < nt; ++t) th_.emplace_back([this] { worker(); });
+  explicit WorkerPool(int nt) : st_(new State), nt_(nt), pid_(getpid()) {
+    for (int t = 0; t < nt; ++t) std::thread([s = st_] { worker(s); }).detach();
   }
-  ~WorkerPool() {
-    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-    cv_work_.notify_all();
-    for (auto &x : th_) x.join();
-  }
-  int size() const { return (int)th_.size(); }
+  ~WorkerPool() {}   // (the workers stay parked on st_, which is leaked deliberately: see above)
+  int size() const { return nt_; }
   void run(int n, const std::function<void(int)> &fn) {
-    std::lock_guard<std::mutex> serial(run_m_);   // one job at a time
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; n_ = n; next_.store(0); busy_ = (int)th_.size(); ++gen_;
+    if (getpid() != pid_) {   // a fork()ed child: no workers here
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
     }
-    cv_work_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [&] { return busy_ == 0; });
-    fn_ = nullptr;
+    State &s = *st_;
+    std::lock_guard<std::mutex> serial(s.run_m);   // one job at a time
+    {
+      std::lock_guard<std::mutex> lk(s.m);
+      s.fn = &fn; s.n = n; s.next.store(0); s.busy = nt_; ++s.gen; s.err = nullptr;
+    }
+    s.cv_work.notify_all();
+    drain(&s);
+    std::exception_ptr err;
+    {
+      std::unique_lock<std::mutex> lk(s.m);
+      s.cv_done.wait(lk, [&] { return s.busy == 0; });
+      s.fn = nullptr;
+      err = s.err;
+      s.err = nullptr;
+    }
+    if (err) std::rethrow_exception(err);
   }
 
  private:
-  void drain() {
-    for (int i; (i = next_.fetch_add(1)) < n_;) (*fn_)(i);
+  static void drain(State *s) {
+    try {
+      for (int i; (i = s->next.fetch_add(1)) < s->n;) (*s->fn)(i);
+    } catch (...) {
+      s->next.store(s->n);   // cancel what has not been handed out
+      std::lock_guard<std::mutex> lk(s->m);
+      if (!s->err) s->err = std::current_exception();
+    }
   }
-  void worker() {
+  static void worker(State *s) {
     unsigned long long seen = 0;
     for (;;) {
       {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
+        std::unique_lock<std::mutex> lk(s->m);
+        s->cv_work.wait(lk, [&] { return s->gen != seen; });
+        seen = s->gen;
       }
-      drain();
-      std::lock_guard<std::mutex> lk(m_);
-      if (--busy_ == 0) cv_done_.notify_one();
+      drain(s);
+      std::lock_guard<std::mutex> lk(s->m);
+      if (--s->busy == 0) s->cv_done.notify_one();
     }
   }
-  std::vector<std::thread> th_;
-  std::mutex m_, run_m_;
-  std::condition_variable cv_work_, cv_done_;
-  const std::function<void(int)> *fn_ = nullptr;
-  int n_ = 0, busy_ = 0;
-  std::atomic<int> next_{0};
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
+  State *st_;
+  int nt_;
+  pid_t pid_;
 };
 
 // fn(0) .. fn(n - 1) on up to 16 threads (the caller included), inline when there are fewer than 2 * min_per_thread items
