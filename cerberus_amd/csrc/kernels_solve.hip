@@ -1346,6 +1346,7 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr, int reduce_waves = 0);   // kernels_wave.hip
 int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);                                                                    // kernels_wave.hip
+int vilo_launch_assemble_full(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams &ap, int which);   // kernels_asm_full.hip
 
 int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
   const double sq = ctx->cfg.focal_length / 1.5, ha = ctx->cfg.huber_delta, gn = ctx->cfg.g_norm;
@@ -1423,14 +1424,28 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
     // VILO_FUSE_ACCEPT_MAX_WINDOWS moves the threshold (0: never).
     static const int fuse_max = [] { const char *e = getenv("VILO_FUSE_ACCEPT_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
     const bool fuse_accept = W <= fuse_max || reduce_later;   // (the reduce workgroups ride in k_assemble_c's launch, beside the bookkeeping)
-    if (!fuse_accept) {
-      P0(5);
-      hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+    // full batches with compact slots: the assembly in two kernels by LDS footprint (kernels_asm_full.hip: pose part at four workgroups per
+    // CU with the bookkeeping as its first phase — no k_accept launch, the prior's H never read —, speed / leg-bias part at eight).
+    // VILO_ASM_FULL_MIN_WINDOWS moves the threshold (0: never).
+    static const int full_min = [] { const char *e = getenv("VILO_ASM_FULL_MIN_WINDOWS"); return e ? atoi(e) : 513; }();
+    const bool asm_full = !fuse_accept && b.compact && full_min > 0 && W >= full_min;
+    if (asm_full) {
+      P0(8);
+      if (vilo_launch_assemble_full(ctx, b, sp, s, ap, 0) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+      P0(2);
+      if (vilo_launch_assemble_full(ctx, b, sp, s, ap, 1) != VILO_OK) return VILO_ERR_HIP;
+      P1();
+    } else {
+      if (!fuse_accept) {
+        P0(5);
+        hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+        P1();
+      }
+      P0(8);
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr, reduce_later ? b.n_waves : 0) != VILO_OK) return VILO_ERR_HIP;
       P1();
     }
-    P0(8);
-    if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr, reduce_later ? b.n_waves : 0) != VILO_OK) return VILO_ERR_HIP;
-    P1();
     ap.init_mode = 0;
     if (vilo_solver_form(ctx, b) == 3) {
       // three-stage form (kernels_split.hip): chain -> pose system -> back-substitutions + step, then the complete single-wave solver for

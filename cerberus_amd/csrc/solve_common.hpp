@@ -118,6 +118,36 @@ __device__ __forceinline__ double wave_max(double v) {
   return __shfl(v, 0, 64);
 }
 
+// The same sums / maxima through the DPP data path (v_mov_b32_dpp: a VALU move with a lane pattern, a few cycles) instead of twelve
+// ds_bpermute round trips through the LDS crossbar (~ 900 cycles per double, one after the other): row_shr 1 / 2 / 4 / 8 leave every row's
+// total in its lane 15, row_bcast:15 / :31 carry the rows' totals on to lane 63, which is broadcast. A different (fixed) order of the
+// additions than wave_sum's tree: used where no other kernel has to reproduce the sum bit for bit.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move_d<0x111, 0xf>(v);
+  v += dpp_move_d<0x112, 0xf>(v);
+  v += dpp_move_d<0x114, 0xf>(v);
+  v += dpp_move_d<0x118, 0xf>(v);
+  v += dpp_move_d<0x142, 0xa>(v);
+  v += dpp_move_d<0x143, 0xc>(v);
+  return readlane_d(v, 63);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {   // of non-negative values (a lane without a source contributes 0)
+  v = fmax(v, dpp_move_d<0x111, 0xf>(v));
+  v = fmax(v, dpp_move_d<0x112, 0xf>(v));
+  v = fmax(v, dpp_move_d<0x114, 0xf>(v));
+  v = fmax(v, dpp_move_d<0x118, 0xf>(v));
+  v = fmax(v, dpp_move_d<0x142, 0xa>(v));
+  v = fmax(v, dpp_move_d<0x143, 0xc>(v));
+  return readlane_d(v, 63);
+}
+
 struct SolveParams {
   double min_lm_diagonal, max_lm_diagonal;
   double min_radius, gradient_tolerance;

@@ -124,6 +124,6 @@ extern "C" int vilo_get_kernel_times(const vilo_ctx *ctx, double *ms, long long 
   return VILO_NKERNEL;
 }
 extern "C" const char *vilo_kernel_name(int kind) {
-  static const char *names[VILO_NKERNEL] = {"k_visual_linearize", "k_imu_linearize", "(unused)", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state", "k_imu_raw", "k_assemble", "k_solve_wave", "k_repropagate", "k_prepare_preint", "k_chain", "k_solve_mid", "k_backsub"};
+  static const char *names[VILO_NKERNEL] = {"k_visual_linearize", "k_imu_linearize", "k_assemble_bias", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state", "k_imu_raw", "k_assemble", "k_solve_wave", "k_repropagate", "k_prepare_preint", "k_chain", "k_solve_mid", "k_backsub"};
   return (kind >= 0 && kind < VILO_NKERNEL) ? names[kind] : "";
 }

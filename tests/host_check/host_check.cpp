@@ -161,6 +161,40 @@ void hc_assemble_compact(int nch, const unsigned *chunk_tab, const double *slots
   }
 }
 
+// The same through the PASS form of the full batch's pose assembly (kernels_asm_full.hip: passes of <= AC_PASS frames through a six-slot
+// stage; assemble_compact.hpp's ac_pass_* bodies): the pass split, the four waves' bodies and the lane groups of T8 / T5 + T6 emulated as the
+// kernel runs them.
+void hc_assemble_compact_passes(int nch, const unsigned *chunk_tab, const double *slots, const double *poses, double *H80, double *g80) {
+  double Rt[12 * 9];
+  for (int f = 0; f < 11; ++f) {
+    const m3 R = qR(ldq_pose(poses + 7 * f));
+    for (int q = 0; q < 9; ++q) Rt[9 * f + q] = R.a[q];
+  }
+  for (int q = 0; q < 9; ++q) Rt[99 + q] = (q % 4 == 0) ? 1.0 : 0.0;
+  auto rmw = [&](int hi, int lo, double v) { H80[hi * 80 + lo] += v; };
+  auto gadd = [&](int cd, double v) { g80[cd] += v; };
+  for (int ch = 0; ch < nch; ++ch) {
+    const int s = chunk_tab[ch] & 255, km = (chunk_tab[ch] >> 8) & 255, sl0 = chunk_tab[ch] >> 16;
+    const int npass = (km + AC_PASS - 1) / AC_PASS, base = km / npass, rem = km - base * npass;
+    for (int i = 0; i < npass; ++i) {
+      const int t0 = i * base + (i < rem ? i : rem), np = base + (i < rem ? 1 : 0);
+      double ps[(AC_PASS + 1) * VILO_GRAMC];   // the kernel's stage: the pass's slots, garbage up to AC_PASS, then the slot of zeros
+      for (int e = 0; e < (AC_PASS + 1) * VILO_GRAMC; ++e) ps[e] = (e < np * VILO_GRAMC) ? slots[(size_t)(sl0 + t0) * VILO_GRAMC + e] : (e < AC_PASS * VILO_GRAMC ? 1e300 : 0.0);
+      for (int tid = 0; tid < 256; ++tid) assemble_visual_compact_pass(tid, s, t0, np, ps, Rt, rmw, gadd);
+      for (int q = 0; q < 21; ++q) {
+        double p[3];
+        for (int grp = 0; grp < 3; ++grp) p[grp] = ac_t8_pass(q, grp, s, t0, np, ps, Rt);
+        ac_t8_apply(q, (p[0] + p[1]) + p[2], rmw);
+      }
+      for (int q = 0; q < 18; ++q) {
+        double s5[2], s6[2];
+        for (int par = 0; par < 2; ++par) ac_t56_pass(q, par, s, t0, np, ps, Rt, rmw, s5[par], s6[par]);
+        ac_t56_apply(q, s, s5[0] + s5[1], s6[0] + s6[1], rmw);
+      }
+    }
+  }
+}
+
 // dF = F - I (32 x 31, row-major) and V (32 x 48) of one midpoint step of IMULegIntegrationBase.
 // in: R0[9] R1[9] un_gyr[3] a0[3] a1[3] Rbr[9] dt, then per (leg j, endpoint e), q = 2 j + e: v[3] p[3] h0[9] J[9] g0[3]  (27 doubles each).
 // mode 0: the blocks written out one after the other as the reference writes them (imu_leg_integration_base.cpp:376-465), 3 x 3

@@ -1,7 +1,9 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
 oracle on the same seeded inputs. Tolerances (FP64): factor residual/Jacobian <= 1e-11 relative to the
 block's scale, whitened IMU quantities <= 1e-8 (conditioning of the 31x31 covariance), normal-equation
-pieces <= 1e-9, states after an equal number of trust-region iterations <= 1e-7."""
+pieces <= 1e-9, states after an equal number of trust-region iterations <= 1e-8 (the measured differences, printed in
+the assertion messages, are 1e-10 .. 1e-9: the elimination order of the speed / leg-bias chain and the summation order inside MFMA tiles differ
+from the oracle's scalar loops)."""
 import numpy as np
 import pytest
 
@@ -308,7 +310,7 @@ def test_solve_skips_long_intervals(ctx, cfg, ocfg):
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
     np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
 
 def _truncate(w, F):
@@ -340,7 +342,7 @@ def test_solve_partial_window(ctx, cfg, ocfg, F):
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
     np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a[:F] - bb[:F]).max() < 1e-6 * max(1.0, np.abs(bb[:F]).max()) if a.shape[0] == 11 else np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a[:F] - bb[:F]).max() < 1e-8 * max(1.0, np.abs(bb[:F]).max()) if a.shape[0] == 11 else np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max())
 
 
 def test_solve_config2_window_and_tolerances(ctx, cfg, ocfg):
@@ -394,6 +396,32 @@ def test_headline_kernel_set_vs_oracle(ctx, cfg, ocfg):
     assert worst < 1e-8, worst
 
 
+def test_path_parity_with_the_oracles_own_preintegration(ctx, cfg, ocfg):
+    """The WHOLE path against the oracle with nothing shared but the inputs: contact preintegration of the raw samples (K1) + sqrt_info +
+    12 trust-region iterations on the GPU, against the oracle integrating the same samples itself (O.fill_preint) and solving. The other solve
+    tests hand both sides the same records (bench.py's parity_sample and test_headline_kernel_set_vs_oracle: the GPU's; most others: the
+    oracle's), which pins the solver; K1 has its own goldens. What the two integrations differ by (1e-13 relative in the 31 x 31 covariance,
+    whose inverse square root enters every IMU residual: cond ~ 1e6 .. 1e7) bounds the agreement of the states from below at ~ 1e-9 .. 1e-8;
+    tolerance 1e-7, the measured value is printed."""
+    from cerberus_amd import api, synth
+    W = 4
+    ws = [synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i)) for i in range(W)]
+    ctx.preintegrate_windows(ws)          # K1 on the GPU
+    summ = ctx.solve_windows(ws, api.default_solve_opts(True, 12))
+    worst = 0.0
+    for i in range(W):
+        w_o = synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i))
+        O.fill_preint(ocfg, w_o)          # the oracle's own integration of the same samples
+        so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
+        assert (summ[i].iterations, summ[i].num_successful) == (so.iterations, so.num_successful)
+        np.testing.assert_allclose(summ[i].final_cost, so.final_cost, rtol=1e-7)
+        for a, bb in zip(ws[i].state_arrays(), w_o.state_arrays()):
+            if a.size:
+                worst = max(worst, np.abs(a - bb).max() / max(1.0, np.abs(bb).max()))
+    print("MEASURED test_path_parity_with_the_oracles_own_preintegration: states %.2e" % worst)
+    assert worst < 1e-7, worst
+
+
 def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
     """Independent windows in one batch give the same answers as solved alone; ragged landmark counts,
     a window without prior, >64 landmarks per start frame (multi-chunk groups)."""
@@ -414,7 +442,7 @@ def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
         w_o = _fresh(cfg, ocfg, **spec)
         O.solve_window(ocfg, w_o, O.default_opts(True, 5))
         for a, bb in zip(w_b.state_arrays(), w_o.state_arrays()):
-            assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+            assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
 
 @pytest.mark.parametrize("td_const", [1, 0])
@@ -674,7 +702,7 @@ def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 6))
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
 
 def _vins(cfg, ocfg, **kw):
@@ -693,7 +721,7 @@ def test_solve_without_leg_factors(ctx, cfg, ocfg):
     assert sg.iterations == so.iterations and sg.num_successful == so.num_successful
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
     np.testing.assert_array_equal(w_g.leg_bias, lb0)   # not part of the problem
 
 
@@ -725,7 +753,7 @@ def test_marginalize_and_next_solve_without_leg_factors(ctx, cfg, ocfg):
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 5))
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
 
 @pytest.mark.parametrize("with_prior", [True, False])
@@ -759,7 +787,7 @@ def test_solve_window_at_the_feature_cap(ctx, cfg, ocfg):
     assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful) and sg.iterations == 12
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
-        assert np.abs(a - bb).max() < 1e-6 * max(1.0, np.abs(bb).max())
+        assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
 
 def test_gauge_fix(ctx, cfg, ocfg):

@@ -301,6 +301,15 @@ def test_compact_rows_and_their_assembly_match_the_23_column_form(hc):
     assert np.all(np.triu(Hc, 1) == 0.0)
     np.testing.assert_allclose(gc[keep], g[keep], rtol=0, atol=2e-13 * np.abs(g).max())
     assert np.count_nonzero(Hl) > 1500
+    # the full batch's pose assembly runs the same classes pass by pass (<= 6 frames through a six-slot stage, straight-line bodies with
+    # clamped reads and +0.0 for the frames beyond a pass: kernels_asm_full.hip): same system, sums over a chunk's frames reach their target
+    # once per pass
+    Hp = np.zeros((80, 80)); gp = np.zeros(80)
+    hc.hc_assemble_compact_passes(len(chunks), tab.ctypes.data_as(C.POINTER(C.c_uint32)), P(slots), P(np.ascontiguousarray(poses)), P(Hp), P(gp))
+    np.testing.assert_allclose(Hp[np.ix_(keep, keep)], Hl, rtol=0, atol=2e-13 * scale)
+    assert np.all(np.triu(Hp, 1) == 0.0)
+    np.testing.assert_allclose(gp[keep], g[keep], rtol=0, atol=2e-13 * np.abs(g).max())
+    np.testing.assert_allclose(Hp, Hc, rtol=0, atol=1e-14 * scale)
 
 
 def test_lane_parallel_preintegration_blocks_match_the_blocks_written_out(hc):

@@ -22,13 +22,23 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     if C[0, 30] > 0:   # producer / consumer visual kernel: packed wave 0 (window 0)
         print("k_visual_linearize_pc (packed wave 0, %d frames): consumer %d cycles, %d of them at the step barriers; producer %d, %d at the barriers"
               % (C[0, 32], C[0, 28], C[0, 29], C[0, 30], C[0, 31]))
-    d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
-    print("k_assemble, visual slots: work between the chunk barriers per wave (0: T1 T2 T3, 1: T8, 2: T5 T6 T4, 3: T7): %d %d %d %d" % tuple(m[12:16]))
-    print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
-          % (*d, d.sum()))
+    if W >= 513 and C[:, 46].max() > 0:   # full batch: k_assemble_pose + k_assemble_bias (kernels_asm_full.hip)
+        print("k_assemble_pose: bookkeeping + prior image %d | visual slots (passes) %d | IMU pose blocks %d | gradient + scaling %d | tile image out + q %d | sums %d | total %d"
+              % (m[37] - m[36], m[38] - m[37], m[39] - m[38], m[41] - m[39], m[42] - m[41], m[45] - m[42], m[45] - m[36]))
+        print("k_assemble_pose bookkeeping: loads landed + image stored %d | dx scattered, H dx partials %d | H dx + cost partials %d | decision %d | state copy until the passes start %d"
+              % (m[12] - m[36], m[13] - m[12], m[14] - m[13], m[15] - m[14], m[37] - m[15]))
+        print("k_assemble_pose pass loop per wave (wait at the first barrier | stage fill + second barrier | class bodies): " +
+              "  ".join("w%d %d|%d|%d" % (w, m[47 + 3 * w], m[48 + 3 * w], m[49 + 3 * w]) for w in range(4)))
+        print("k_assemble_bias: prologue + IMU factors (frame loop) %d | scaling + prior rows %d | q of the speed / leg-bias rows + sums %d | total %d"
+              % (m[43] - m[40], m[44] - m[43], m[46] - m[44], m[46] - m[40]))
+    else:
+        d = np.diff(C[:, 36:46], axis=1).mean(axis=0)
+        print("k_assemble, visual slots: work between the chunk barriers per wave (0: T1 T2 T3, 1: T8, 2: T5 T6 T4, 3: T7): %d %d %d %d" % tuple(m[12:16]))
+        print("k_assemble: prior image %d | visual slots %d | IMU factors (frame loop) %d | diagonal + gradient %d | scaling %d | tile image out + q %d | prior rows %d | q of the speed / leg-bias rows %d | sums %d | total %d"
+              % (*d, d.sum()))
     if m[34] > 0:
         print("IMU factor 0 (imu_fused_body / k_imu_linearize): stage %d | raw evaluation on lane 0 %d | whitening + Gram %d cycles" % (m[33], m[34], m[35]))
-    if m[46] > 0:
+    if m[46] > 0 and W < 513:
         print("k_assemble_s: trust-region bookkeeping (accept_body) before the assembly: %d cycles" % m[46])
     if W <= 256 and m[16] > 0:
         print("k_solve_mw8 wave B1 (cycles from kernel start): scaling %d | main loop, own work %d, with the tiles' hand-over %d | (unused) %d | Cholesky + solves %d | back-substitutions %d | norms %d | dogleg + candidate %d;  C1: chain role %d, sweeps %d"
