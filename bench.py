@@ -285,6 +285,139 @@ def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
     return out
 
 
+def go1_config(cfg):
+    """The reference's Go1 parameter set where it differs from the A1 one in what this path reads
+    (config/go1_config/hardware_go1_vilo_config.yaml:25-30 against config/a1_config/hardware_a1_vilo_config.yaml): the foot force sensors
+    decide contact (contact_sensor_type 2: the adaptive force model of imu_leg_integration_base.cpp:195-229); the leg geometry is the same
+    (estimator.cpp:141-156, lower_leg_length 0.21 in both files). The calf lengths are estimated on line (BASELINE configs[4]: "online rho
+    calibration" — optimize_leg_bias 1; the yaml file as shipped has it off)."""
+    c = type(cfg).from_buffer_copy(cfg)
+    c.contact_sensor_type = 2
+    return c
+
+
+def replay_block(device, n_images=170, cpu_budget_s=10.0, seed=505, keep_dir=None):
+    """BASELINE configs[4] / [0] (a bag replayed through the estimator, launch/dataset/run_campus_bag_vilo.launch:3-6, src/main.cpp:95-202) with
+    the stand-in this container allows: a synthetic Go1-parameter stream (trot, 500 Hz IMU + joints + foot forces, 15 Hz stereo features) written
+    as a ROS bag, read back through the bag reader (cerberus_amd/host/vilo_rosbag.cpp) and fed message by message through the node's logic
+    (cerberus_amd/rosbag.py) into vilo::SlidingWindow on one GPU: per image the new interval's preintegration, the window's solve, the gauge fix and
+    the marginalisation. Beside it the CPU oracle on the windows the replay dumped (solve on one thread + marginalisation with the Hessian build on
+    four, marginalization_factor.h:22): the reported CPU baseline of this configuration."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from cerberus_amd import api, rosbag, sequence, synth, window_io
+    cfg5 = go1_config(synth.default_config())
+    ctx5 = api.Context(cfg5, device=device)
+    tmp = keep_dir or tempfile.mkdtemp(prefix="vilo_replay_")
+    dumps = os.path.join(tmp, "windows")
+    os.makedirs(dumps, exist_ok=True)
+    mp = sw = None
+    try:
+        stream = sequence.Stream(cfg5, seed=seed)
+        frames = [stream.next() for _ in range(n_images)]
+        rng = np.random.default_rng(seed)
+        for f in frames:   # contact flags of the synthetic gait -> foot forces in newtons, as the Go1's sensors report them
+            f["forces"] = 15.0 + 140.0 * f["samples"][:, 31:35] + 4.0 * rng.normal(size=(len(f["samples"]), 4))
+        bag = os.path.join(tmp, "go1_synthetic.bag")
+        t_start = frames[0]["header"] - len(frames[0]["samples"]) / 500.0
+        t0 = time.perf_counter()
+        msgs = rosbag.write_stream_bag(bag, frames, t_start)
+        write_s = time.perf_counter() - t0
+        sw = sequence.SlidingWindow(ctx5, cfg5, use_leg=1, optimize_leg_bias=1, dump_dir=dumps)
+        sw.set_extrinsics(*stream.extrinsics())
+        tr0 = frames[0]["truth"]
+        sw.init_first_pose(tr0[0:3], sequence.quat_to_R(tr0[3:7]).ravel(), tr0[7:10])   # (the synthetic robot is already walking at the first stamp)
+        mp = sequence.MeasurementProcessor(sw)
+        L = api.lib()
+        L.vilo_last_solve_ms.restype = C.c_double; L.vilo_last_marginalize_ms.restype = C.c_double
+        est_s = [0.0]
+        per_image = []
+
+        def timed(fn):
+            def wrapper(*a, **k):
+                t = time.perf_counter()
+                r = fn(*a, **k)
+                est_s[0] += time.perf_counter() - t
+                return r
+            return wrapper
+        mp.input_sample, mp.input_feature, mp.process = timed(mp.input_sample), timed(mp.input_feature), timed(mp.process)
+        last = [0.0]
+
+        def on_image(k, t):
+            st = sw.state()
+            per_image.append(dict(t=t, est_ms=1e3 * (est_s[0] - last[0]), solve_ms=float(L.vilo_last_solve_ms(ctx5.h)) if st["n_optimizations"] else 0.0,
+                                  marg_ms=float(L.vilo_last_marginalize_ms(ctx5.h)) if st["n_optimizations"] else 0.0, n_opt=int(st["n_optimizations"]),
+                                  rho=st["Rho"][api.T.F - 2].copy(), p=st["Ps"][api.T.F - 2].copy(), feats=int(st["feature_count"])))
+            last[0] = est_s[0]
+        t0 = time.perf_counter()
+        cnt = rosbag.replay(rosbag.BagReader(bag), mp, contact_sensor_type=2, on_image=on_image)
+        wall_s = time.perf_counter() - t0
+        steady = [r for r in per_image if r["n_opt"] > 12]     # the window is full and the prior has settled
+        if not steady:
+            return {"error": "the replay produced no steady images", "counters": cnt}
+        est_ms = float(np.mean([r["est_ms"] for r in steady]))
+        solve_ms = float(np.mean([r["solve_ms"] for r in steady]))
+        marg_ms = float(np.mean([r["marg_ms"] for r in steady]))
+        truth = frames[-1]["truth"]
+        rho_err = float(np.abs(per_image[-1]["rho"] - truth[16:20]).max())
+        rho_err0 = float(np.abs(0.21 - truth[16:20]).max())
+        pos_err = float(np.linalg.norm(per_image[-1]["p"] - truth[0:3]))
+        # ---- CPU oracle on the dumped windows (checker leg / reported baseline: never part of the product path) ----
+        from oracle import oracle_py as O
+        ocfg = O.config_from(cfg5)
+        files = sorted(os.listdir(dumps))
+        O.lib().orc_set_marginalize_threads(4)
+        cpu_solve = cpu_marg = 0.0
+        n_cpu, worst = 0, 0.0
+        for fn in files:
+            if cpu_solve + cpu_marg > cpu_budget_s:
+                break
+            _, w, after, ref, flag = window_io.load(os.path.join(dumps, fn))
+            before = w.clone_state()
+            t1 = time.perf_counter()
+            sm = O.solve_window(ocfg, w, O.default_opts(False, 12))
+            cpu_solve += time.perf_counter() - t1
+            O.gauge_fix(before, w)
+            if after is not None:
+                for a, b in zip(w.state_arrays(), after):
+                    if a.size:
+                        worst = max(worst, float(np.abs(a - b).max() / max(1.0, np.abs(b).max())))
+                w.set_state(after)
+            t1 = time.perf_counter()
+            O.marginalize(ocfg, w, flag, synth.PriorData())
+            cpu_marg += time.perf_counter() - t1
+            n_cpu += 1
+        O.lib().orc_set_marginalize_threads(1)
+        return {
+            "workload": "BASELINE configs[4] stand-in (no real bag in the container): synthetic Go1-parameter stream (contact_sensor_type 2: foot forces, "
+                        "optimize_leg_bias 1: calf lengths estimated on line; 500 Hz IMU / joints / forces, 15 Hz stereo features), %d images written as a "
+                        "rosbag-v2 file (%d messages, %d bytes), read back through the bag reader and replayed message by message through the node's "
+                        "logic into the sliding-window estimator on one GPU" % (n_images, len(msgs), os.path.getsize(bag)),
+            "value": 1e3 / est_ms, "unit": "images/s (estimator time per image: samples in, preintegration push, batch build, solve, gauge fix, marginalisation, slide)",
+            "images": len(per_image), "steady_images": len(steady),
+            "ms_per_image": {"estimator": est_ms, "solve_gpu": solve_ms, "marginalise_gpu": marg_ms,
+                             "preintegration_push_batch_build_and_host_bookkeeping": est_ms - solve_ms - marg_ms,
+                             "whole_replay_wall_per_image_including_python_bag_reading": 1e3 * wall_s / max(1, len(per_image))},
+            "camera_rate_hz": 15.0, "real_time_factor": (1e3 / est_ms) / 15.0,
+            "rho_error_m": {"final": rho_err, "at_start": rho_err0}, "position_error_m_final": pos_err,
+            "mean_features_in_window": float(np.mean([r["feats"] for r in steady])),
+            "counters": cnt, "bag_write_s": write_s,
+            "cpu_baseline": {"value": n_cpu / (cpu_solve + cpu_marg) if n_cpu else None, "unit": "images/s", "cores": 4, "kind": "port",
+                             "sample": "the first %d dumped windows of this replay through oracle/liboracle.so: solve on 1 thread (%.1f ms per window), "
+                                       "marginalisation with the Hessian build on 4 threads like the reference (%.1f ms per window)"
+                                       % (n_cpu, 1e3 * cpu_solve / max(1, n_cpu), 1e3 * cpu_marg / max(1, n_cpu)),
+                             "max_state_difference_gpu_vs_oracle": worst},
+        }
+    finally:
+        mp = sw = None   # (the estimator objects go before their context)
+        import gc
+        gc.collect()
+        ctx5.close()
+        if not keep_dir:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 class ControlPlane:
     """The two control collectives the bench contract asks for (barrier, max-over-ranks of the elapsed time) plus the shard report. The data
     path has no collective (windows are independent), so which library carries these three calls changes nothing that is measured."""
@@ -379,8 +512,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="2: BASELINE configs[1] (200 landmarks, 500 Hz; the headline metric); "
-                    "3: BASELINE configs[2] (1000 landmarks, 400 Hz, K1 re-propagation inside every iteration)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="2: BASELINE configs[1] (200 landmarks, 500 Hz; the headline metric); "
+                    "3: BASELINE configs[2] (1000 landmarks, 400 Hz, K1 re-propagation inside every iteration); "
+                    "5: BASELINE configs[4] stand-in: a synthetic Go1-parameter bag replayed through the sliding-window estimator (--images)")
+    ap.add_argument("--images", type=int, default=170, help="--config 5 and the `replay` side block: images of the replayed stream")
+    ap.add_argument("--no-replay", action="store_true", help="skip the `replay` side block of the default line")
     ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 4096; 1024 with --config 3)")
     ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
     ap.add_argument("--landmarks", type=int, default=0, help="default 200 (1000 with --config 3)")
@@ -399,6 +535,18 @@ def main():
         # that a bare invocation can never measure one GPU and label it N
         return self_launch(args.gpus)
     exit_code = 0
+    if args.config == 5:
+        # one robot's frames depend on each other through the prior: "replicas only" — one GPU, no sharding
+        if args.gpus != 1:
+            print("bench.py: --config 5 is a single stream on one GPU", file=sys.stderr)
+            return 2
+        r = replay_block(int(os.environ.get("LOCAL_RANK", "0")), n_images=args.images, cpu_budget_s=0.0 if args.no_cpu_baseline else 15.0)
+        line = {"metric": "images/s, bag replay through the sliding-window VILO estimator (BASELINE configs[4] stand-in)", "value": r.get("value"),
+                "unit": "images/s", "n_gpus": 1, "steps": r.get("steady_images"), "warmup": 12, "ms_per_step": (r.get("ms_per_image") or {}).get("estimator"),
+                "higher_is_better": True, "scaling": "replicas only", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": r.get("workload")}, "roofline": None, "cpu_baseline": r.get("cpu_baseline"), "replay": r}
+        print(json.dumps(line))
+        return 0 if "error" not in r else 3
     rp = args.config == 3
     args.landmarks = args.landmarks or (1000 if rp else 200)
     args.rate = args.rate or (400 if rp else 500)
@@ -689,6 +837,11 @@ def main():
                 out["config3"]["cpu_baseline"] = c3
             except Exception as e:
                 out["config3"] = {"error": repr(e)}
+        if not args.no_cpu_baseline and world == 1 and not rp and not args.no_replay:
+            try:
+                out["replay"] = replay_block(local_rank, n_images=args.images)
+            except Exception as e:
+                out["replay"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["marginalize"] = marginalize_timing(ctx, cfg, windows[:256], n_cpu=2 if rp else 8)

@@ -226,10 +226,10 @@ class Context:
         if rc != 0:
             raise ViloError("vilo error %d: %s" % (rc, lib().vilo_last_error(self.h).decode()))
 
-    SOLVER_FORMS = {"auto": -1, "wave": 0, "mw": 2, "split": 3, "mw8": 4}
+    SOLVER_FORMS = {"auto": -1, "wave": 0, "split": 3, "mw8": 4}
 
     def set_solver_form(self, form):
-        """vilo_set_solver_form: 'auto' (by batch size), 'wave', 'split' (bitwise equal to 'wave'), 'mw', 'mw8'."""
+        """vilo_set_solver_form: 'auto' (by batch size), 'wave', 'split' (bitwise equal to 'wave'), 'mw8'."""
         self._check(lib().vilo_set_solver_form(self.h, self.SOLVER_FORMS[form]))
 
     def set_compact_rows(self, on):

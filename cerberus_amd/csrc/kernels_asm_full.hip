@@ -1,8 +1,8 @@
 // Assembly of a FULL batch's camera-side normal equations (what Ceres' evaluator hands to its SchurEliminator behind
 // estimator.cpp:1221-1236), cut in two kernels by LDS footprint the way the solver is cut by register footprint (kernels_split.hip):
 //
-//   k_assemble_pose   one 256-thread workgroup per window, 38 KB of LDS and <= 128 registers: FOUR workgroups per CU (k_assemble_c: 49 KB
-//                     and 168 registers, three). The trust-region bookkeeping of the previous step (accept_body.hpp's decisions) runs
+//   k_assemble_pose   one 256-thread workgroup per window, 38 KB of LDS and <= 128 registers: FOUR workgroups per CU (the single-kernel assembly of
+//                     rounds 2 - 4, k_assemble_c, needed 49 KB and 168 registers: three). The trust-region bookkeeping of the previous step (accept_body.hpp's decisions) runs
 //                     first, with the prior's H dx taken from the pre-assembled image this kernel loads into LDS anyway — H itself (59 KB
 //                     per window) is never read and the iteration has no k_accept launch. Then the 80 x 80 pose / extrinsic system:
 //                     prior image + compact Gram slots (pass by pass of <= 6 frames through a six-slot stage, assemble_compact.hpp's
@@ -12,7 +12,7 @@
 //                     poses k - 1 .. k + 1 frame by frame through a ring of two IMU factor Grams, the prior's rows, gradient / scaling / v
 //                     of the 143 dimensions, q = v^T H v of every block that has a speed / leg-bias row, and the sums of both kernels.
 //
-// Both write exactly what k_assemble_c writes (Cimg, Bimg, cam_gin, cam_scale), so every solver form reads them unchanged; the sums that
+// Together they write what k_assemble / k_assemble_s write (Cimg, Bimg, cam_gin, cam_scale), so every solver form reads them unchanged; the sums that
 // cross the two kernels (q, |D^-1 g|^2, max |g|) are added pose part first.
 #include "solve_common.hpp"
 #include "assemble_compact.hpp"

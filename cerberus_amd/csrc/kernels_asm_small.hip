@@ -1,16 +1,16 @@
-// k_assemble_s: the camera-side normal equations of a window (what k_assemble_c of kernels_wave.hip builds: Ceres' Evaluate -> block-sparse
+// k_assemble_s: the camera-side normal equations of a window (what k_assemble_pose + k_assemble_bias of kernels_asm_full.hip build for larger batches: Ceres' Evaluate -> block-sparse
 // J^T J behind estimator.cpp:1221-1236) for SMALL batches — up to one window per CU, where an iteration is a chain of kernel latencies and
 // the assembly's is one chain of ~110 k cycles per window. Same owner-computes scatter (no atomics), cut by parallelism one window can use
 // when it has a CU to itself (768 threads, 137 KB of LDS):
 //   * the visual Gram slots of THREE chunks at a time: thread group g = tid / 256 takes the chunks g, g + 3, ... into its own copy of the
-//     packed image (and of the gradient); the copies are added once in group order (the sums agree with k_assemble_c's chunk-by-chunk
+//     packed image (and of the gradient); the copies are added once in group order (the sums agree with a chunk-by-chunk
 //     order to rounding, not bitwise — like the solver forms, the small-batch assembly is a form of its own);
 //   * all IMU factor Grams of the window in LDS at once (62 KB over the second image copy and the staging areas, free by then): every
 //     entry of A_kk / A_{k+1,k}^T / the coupling rows of every frame is independent work for 768 threads instead of a frame loop with
 //     two barriers per frame;
 //   * the output passes (tile image, prior rows, q) on twice the threads.
 // The trust-region bookkeeping (accept_body.hpp) runs as its first phase and the second half of the frame-parallel visual form in extra
-// workgroups, as in k_assemble_c.
+// workgroups.
 #include <type_traits>
 #include "solve_common.hpp"
 #include "assemble_compact.hpp"
@@ -48,7 +48,7 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= b.W) {
-    // the second half of the frame-parallel visual form, one packed wave per extra workgroup (see k_assemble_c)
+    // the second half of the frame-parallel visual form, one packed wave per extra workgroup
     if (tid < 64) visual_reduce_body(b, (int)blockIdx.x - b.W, 1, true);
     return;
   }
@@ -413,11 +413,13 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
 }
 
 // k_assemble_s for batches of up to VILO_ASM_SMALL_MAX_WINDOWS windows with compact slots (reduce_waves: extra workgroups that finish the
-// frame-parallel visual form). Returns 1 if it took the launch, 0 if the caller's k_assemble_c has to, < 0 on error.
-int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves) {
-  // (one window per CU: measured 256 windows + 4 %, 384 - 8 % against k_assemble_c's three workgroups per CU)
+// frame-parallel visual form).
+bool vilo_assemble_small_takes(const BatchDev &b) {
+  // (one window per CU: measured 256 windows + 4 %, 384 - 8 % against three workgroups per CU)
   static const int small_max = [] { const char *e = getenv("VILO_ASM_SMALL_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
-  if (!b.compact || b.W > small_max || !ap) return 0;
+  return b.compact && b.W <= small_max;
+}
+int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves) {
   const size_t lds_bytes = (size_t)AS_TOTAL * sizeof(double);
   if (!ctx->asm_s_attr_set) {
     if (hipFuncSetAttribute((const void *)k_assemble_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { ctx->err = "k_assemble_s: dynamic LDS opt-in failed"; return VILO_ERR_HIP; }

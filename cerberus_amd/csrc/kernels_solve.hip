@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(64) k_visual_reduce(BatchDev b, int mode) { vi
 
 // both forms behind one call (kernel kind 0 of the profiling table).
 // fuse_imu (solve passes of small batches with compact rows; gn = g_norm): the IMU factors are linearised by extra workgroups of the same
-// launch (imu_fused_body) and the second half of the frame-parallel form is left to k_assemble_c's extra workgroups (reduce_later).
+// launch (imu_fused_body) and the second half of the frame-parallel form is left to k_assemble_s's extra workgroups (reduce_later).
 __global__ void k_lin_small_c(BatchDev b, double sq, double huber_a, double gn, int mode, int n_imu);   // (below, behind the IMU kernels)
 static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream_t s, int mode, bool fuse_imu = false, double gn = 0.0) {
   if (b.n_waves <= 0) return;
@@ -828,7 +828,7 @@ static void launch_visual_linearize(BatchDev &b, double sq, double ha, hipStream
     // (every (packed wave, frame) workgroup writes all the terms and coupling rows it owns, zeros included: nothing to clear first)
     if (compact && fuse_imu) {
       hipLaunchKernelGGL(k_lin_small_c, dim3(b.W * 10 + b.n_waves * VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, gn, mode, b.W * 10);
-      return;   // (k_assemble_c's extra workgroups finish the frame-parallel form)
+      return;   // (k_assemble_s's extra workgroups finish the frame-parallel form)
     }
     if (compact) hipLaunchKernelGGL(k_visual_linearize_tpar_c, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
     else hipLaunchKernelGGL(k_visual_linearize_tpar, dim3(b.n_waves, VILO_MAX_FRAMES), dim3(64), 0, s, b, sq, ha, mode);
@@ -1343,7 +1343,9 @@ __global__ void k_init_state(BatchDev b, double radius0, double mu0, int fail_ba
 // =================================================================================================
 // host-side launch sequence
 // =================================================================================================
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap = nullptr, int reduce_waves = 0);   // kernels_wave.hip
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage);   // kernels_wave.hip
+int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves);   // kernels_asm_small.hip
+bool vilo_assemble_small_takes(const BatchDev &b);                                                                              // kernels_asm_small.hip
 int vilo_launch_split_stage(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int which);   // kernels_split.hip
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);                                                                    // kernels_wave.hip
 int vilo_launch_assemble_full(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams &ap, int which);   // kernels_asm_full.hip
@@ -1392,14 +1394,20 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
       if (vilo_repropagate_launch(ctx, b, 1, 1) != VILO_OK) return VILO_ERR_HIP;
       P1();
     }
-    // Small batches: an iteration is a chain of kernel latencies, so the chain is kept short — the IMU factors are linearised by extra
-    // workgroups of the visual launch (imu_fused_body: k_imu_raw + k_imu_linearize of one factor in one wave, bitwise the same Gram), and
-    // the second half of the frame-parallel visual form runs in extra workgroups of k_assemble_c: three launches per iteration
-    // (linearise, bookkeeping + assemble, solve) instead of eight. The IMU workgroups inside the visual launch pay up to 2048 windows
-    // (768: + 5 %, 1024: + 2.6 %, 2048: + 0.9 %; at 4096 the two forms take the same time and the full batch keeps its separate kernels).
-    // VILO_SMALL_FUSE_MAX_WINDOWS moves the threshold (0: never).
+    // Which assembly a batch gets (compact slots: td a constant block in every window — all of the reference's configurations):
+    //   up to 256 windows (VILO_ASM_SMALL_MAX_WINDOWS): an iteration is a chain of kernel latencies, so the chain is kept short — the IMU
+    //     factors are linearised by extra workgroups of the visual launch (imu_fused_body: k_imu_raw + k_imu_linearize of one factor in
+    //     one wave, bitwise the same Gram), the bookkeeping, the assembly and the second half of the frame-parallel visual form share one
+    //     launch of 768 threads per window (k_assemble_s): three launches per iteration (linearise, bookkeeping + assemble, solve);
+    //   beyond: the assembly in two kernels by LDS footprint (kernels_asm_full.hip: the pose part at four workgroups per CU with the
+    //     bookkeeping as its first phase — no k_accept launch, the prior's H never read —, the speed / leg-bias part at six).
+    // The IMU workgroups inside the visual launch pay up to 2048 windows (768: + 5 %, 1024: + 2.6 %, 2048: + 0.9 %; at 4096 the two forms
+    // take the same time and the full batch keeps its separate kernels): VILO_SMALL_FUSE_MAX_WINDOWS moves that threshold (0: never).
     static const int small_max = [] { const char *e = getenv("VILO_SMALL_FUSE_MAX_WINDOWS"); return e ? atoi(e) : 2048; }();
-    const bool fuse_imu = W <= small_max && visual_launch_takes_imu(b);
+    const bool asm_small = vilo_assemble_small_takes(b);
+    // (beyond the small form a batch with few packed waves — windows of a handful of landmarks — runs the frame-parallel visual form with
+    // its own reduction kernel: only k_assemble_s has workgroups for that reduction)
+    const bool fuse_imu = W <= small_max && visual_launch_takes_imu(b) && (asm_small || !b.lm_part);
     P0(0);
     launch_visual_linearize(b, sq, ha, s, 1, fuse_imu, gn);
     P1();
@@ -1417,19 +1425,12 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
       }
       P1();
     }
-    const bool reduce_later = fuse_imu && b.lm_part;   // (k_assemble_c's extra workgroups run visual_reduce_body)
-    // small batches: the trust-region bookkeeping (k_accept's body) runs as the first phase of k_assemble — an iteration there is a chain
-    // of kernel latencies and loses one (128 windows + 1.1 %, 256 + 1.5 %). A full batch keeps the kernel of its own: its memory-bound
-    // work runs at eight workgroups per CU there, at k_assemble's three it costs more than the launch (4096 windows - 2 %: measured).
-    // VILO_FUSE_ACCEPT_MAX_WINDOWS moves the threshold (0: never).
-    static const int fuse_max = [] { const char *e = getenv("VILO_FUSE_ACCEPT_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
-    const bool fuse_accept = W <= fuse_max || reduce_later;   // (the reduce workgroups ride in k_assemble_c's launch, beside the bookkeeping)
-    // full batches with compact slots: the assembly in two kernels by LDS footprint (kernels_asm_full.hip: pose part at four workgroups per
-    // CU with the bookkeeping as its first phase — no k_accept launch, the prior's H never read —, speed / leg-bias part at eight).
-    // VILO_ASM_FULL_MIN_WINDOWS moves the threshold (0: never).
-    static const int full_min = [] { const char *e = getenv("VILO_ASM_FULL_MIN_WINDOWS"); return e ? atoi(e) : 513; }();
-    const bool asm_full = !fuse_accept && b.compact && full_min > 0 && W >= full_min;
-    if (asm_full) {
+    if (asm_small) {
+      const bool reduce_later = fuse_imu && b.lm_part;   // (k_assemble_s's extra workgroups run visual_reduce_body)
+      P0(8);
+      if (vilo_launch_assemble_small(ctx, b, sp, s, &ap, reduce_later ? b.n_waves : 0) < 0) return VILO_ERR_HIP;
+      P1();
+    } else if (b.compact) {
       P0(8);
       if (vilo_launch_assemble_full(ctx, b, sp, s, ap, 0) != VILO_OK) return VILO_ERR_HIP;
       P1();
@@ -1437,13 +1438,12 @@ int vilo_solve_launch(vilo_ctx *ctx, BatchDev &b, const vilo_solve_opts *o) {
       if (vilo_launch_assemble_full(ctx, b, sp, s, ap, 1) != VILO_OK) return VILO_ERR_HIP;
       P1();
     } else {
-      if (!fuse_accept) {
-        P0(5);
-        hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
-        P1();
-      }
+      // 23-column slots (a window estimates td): the bookkeeping as a kernel of its own, then k_assemble
+      P0(5);
+      hipLaunchKernelGGL(k_accept, dim3(W), dim3(128), 0, s, b, ap);
+      P1();
       P0(8);
-      if (vilo_launch_wave_solver(ctx, b, sp, s, 0, fuse_accept ? &ap : nullptr, reduce_later ? b.n_waves : 0) != VILO_OK) return VILO_ERR_HIP;
+      if (vilo_launch_wave_solver(ctx, b, sp, s, 0) != VILO_OK) return VILO_ERR_HIP;
       P1();
     }
     ap.init_mode = 0;

@@ -1,7 +1,9 @@
 // Single-wave solver for gfx950: what ceres::Solve does per linearisation for Estimator::optimization()
 // (estimator.cpp:1221-1236; DENSE_SCHUR + traditional DOGLEG, Ceres 1.14 semantics), one WAVE per window.
 //
-//   k_assemble        one 256-thread workgroup per window (four per CU): the camera-side normal equations of the window in the layouts
+//   k_assemble        (23-column Gram slots: batches in which a window estimates td; compact slots — every configuration of the reference —
+//                     are assembled by kernels_asm_full.hip / kernels_asm_small.hip)
+//                     one 256-thread workgroup per window (four per CU): the camera-side normal equations of the window in the layouts
 //                     the solver streams. Pose / extrinsic / td system (80 x 80): owner-computes scatter (no atomics) of the
 //                     per-(start frame, t) Gram slots of k_visual_linearize, the pose blocks of the IMU factor Grams and the prior
 //                     image into an LDS image of 15 lower 16 x 16 tiles, written out in FP64-MFMA accumulator order (one coalesced
@@ -17,8 +19,6 @@
 //                     backward solve from the registers  ->  bias and landmark back-substitution  ->  dogleg step and candidate state.
 #include <type_traits>
 #include "solve_common.hpp"
-#include "assemble_compact.hpp"
-#include "accept_body.hpp"
 #include "chain_common.hpp"
 #include "lin_common.hpp"
 
@@ -36,30 +36,19 @@ using namespace vilo;
 
 #define ASM_THREADS 256
 
-template <bool COMPACT>
-__device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, const AcceptParams &ap, int fuse_accept) {
+__device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
   __shared__ double Cl[CL_N];
-  __shared__ double Rt[COMPACT ? 12 * 9 : 1];   // compact slots: rotation matrices of the window's frames, [11] = identity
-  __shared__ double stage[COMPACT ? AC_STAGE : 1];   // compact slots of the chunk being scattered; afterwards the ring of two IMU factor Grams
-  __shared__ double gst[COMPACT ? 1 : 2 * 780];       // (23-column form: the ring has its own storage)
+  __shared__ double gst[2 * 780];   // ring of two IMU factor Grams
   __shared__ double gl[CD_N], hd[CD_N], vS[CD_N], red[12];
   __shared__ unsigned chunk_tab[64];
   __shared__ short inv_pmap[CD_N];
   __shared__ unsigned char act[CD_N];   // cd_active per camera dimension (the predicate has two integer divisions: looked up, not recomputed per entry)
   const int win = blockIdx.x, tid = threadIdx.x;
-  if (fuse_accept) {
-    // k_accept's work first (accept_body.hpp: the candidate's cost, accept / reject, radius and mu, the accepted state): its launch and
-    // this one were consecutive one-workgroup-per-window kernels; threads 0 .. 127 do it, in LDS that the assembly does not need yet
-    double *scr = COMPACT ? stage : gst;
-    accept_body(b, ap, scr, scr + 128, (int *)(scr + 128 + VILO_MAX_PRIOR_DIM));
-    __threadfence_block();
-    __syncthreads();
-  }
   const SolverState &st = b.st[win];
   if (st.done || !st.need_lin) return;
   const WinMeta wm = b.win[win];
   const int F = wm.n_frames, cmask = wm.const_mask, kb = wm.pad, pn = wm.prior_n;
-  const double *gs = b.gram + (size_t)wm.gram_off * (COMPACT ? VILO_GRAMC : VILO_GRAM);
+  const double *gs = b.gram + (size_t)wm.gram_off * VILO_GRAM;
   const double *igram = b.imu_gram + (size_t)win * 10 * 780;
   const double *pd = b.prior_dense + (size_t)win * PD_N;
   double *bimg = b.Bimg + (size_t)win * BI_N;
@@ -84,15 +73,6 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     }
   }
   for (int e = tid; e < CD_N; e += ASM_THREADS) { inv_pmap[e] = -1; act[e] = cd_active(e, F, cmask) ? 1 : 0; }
-  if (COMPACT) {
-    if (tid < 11) {
-      const m3 R = qR(ldq_pose(b.x + (size_t)win * XSTRIDE + XO_POSE + 7 * tid));   // (the accepted state = the point the slots were linearised at)
-#pragma unroll
-      for (int q = 0; q < 9; ++q) Rt[9 * tid + q] = R.a[q];
-    } else if (tid < 20) {
-      Rt[99 + (tid - 11)] = ((tid - 11) % 4 == 0) ? 1.0 : 0.0;
-    }
-  }
   if (tid < min(wm.n_chunks, 64)) {
     const ChunkMeta cm = b.chunk[wm.chunk_off + tid];
     chunk_tab[tid] = (unsigned)cm.s | ((unsigned)cm.kmax << 8) | ((unsigned)(cm.gram_off - wm.gram_off) << 16);
@@ -112,47 +92,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   //      same target only if they are "twins" (the same local pair taken once in the pose_s block and once in the pose_j block; for IMU
   //      factors once in the frame-i half and once in the frame-j half of the previous factor), so a thread owns an entry and its twin ----
   auto rmw = [&](int hi, int lo, double v) { lds_add(&Cl[cl_pos(hi, lo)], v); };   // hi >= lo
-  if (COMPACT) {
-    // chunk by chunk: the chunk's slots (kmax x 184 doubles, contiguous) come into LDS with coalesced loads — every byte once — and the
-    // owner threads gather from there; the next chunk's slots are in flight (registers) while this one is scattered
-    const int nch = min(wm.n_chunks, 64);
-    double pf[8];
-    auto prefetch = [&](int ch) {
-      const unsigned ct = chunk_tab[ch];
-      const int n = (int)((ct >> 8) & 255) * VILO_GRAMC;
-      const double *src = gs + (size_t)(ct >> 16) * VILO_GRAMC;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; pf[i] = (e < n) ? src[e] : 0.0; }
-    };
-    if (nch > 0) prefetch(0);
-    long long w_work = 0, w_t0 = 0;   // (profiling build only: cycles each wave works on a chunk between the barriers)
-    for (int ch = 0; ch < nch; ++ch) {
-      const unsigned ct = chunk_tab[ch];
-      lds_barrier();   // (the previous chunk's readers are done)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const int e = tid + ASM_THREADS * i; if (e < AC_STAGE) stage[e] = pf[i]; }
-      lds_barrier();
-      PCLK(w_t0 = clock64());
-      if (ch + 1 < nch) prefetch(ch + 1);
-      assemble_visual_compact_chunk(tid, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, [&](int cd, double v) { lds_add(&gl[cd], v); });
-      if (tid >= 64 && tid < 128) {
-        // wave 1: the {tic, tic2}^2 entries, three lanes per entry (each a third of the chunk's frames), partial sums added in lane order
-        const int wl = tid - 64, q = wl % 21, grp = min(wl / 21, 2);
-        const double part = (wl < 63) ? ac_t8_partial(q, grp, 3, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt) : 0.0;
-        const double p1 = __shfl(part, q + 21, 64), p2 = __shfl(part, q + 42, 64);
-        if (wl < 21) ac_t8_apply(q, (part + p1) + p2, rmw);
-      } else if (tid >= 128 && tid < 192) {
-        // wave 2: the tic / tic2 x pose entries, two lanes per entry (odd / even frames), the sums over the frames added in lane order
-        const int wl = tid - 128, q = wl % 18, par = min(wl / 18, 1);
-        double s5 = 0.0, s6 = 0.0;
-        if (wl < 36) ac_t56_partial(q, par, (int)(ct & 255), (int)((ct >> 8) & 255), stage, Rt, rmw, s5, s6);
-        const double o5 = __shfl(s5, q + 18, 64), o6 = __shfl(s6, q + 18, 64);
-        if (wl < 18) ac_t56_apply(q, (int)(ct & 255), s5 + o5, s6 + o6, rmw);
-      }
-      PCLK(w_work += clock64() - w_t0);
-    }
-    PCLK(if ((tid & 63) == 0) b.st[win].phase_clk[12 + (tid >> 6)] = w_work);
-  } else {
+  {
     // visual Gram slots: 246 owner groups, one per thread
     // V1 pose_s x pose_s (21, twin pose_j x pose_j), V2 pose_s x pose_j (36), V3 pose_s x rest (84, twin pose_j x rest),
     // V4 rest x rest (105); rest = ex0 (6) ex1 (6) td r = local columns 12 .. 25
@@ -227,7 +167,7 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
   //        [338, 626)  coupling rows    with poses k - 1 (Gj), k (Gi + Gj), k + 1 (Gi); rows 13 .. 15 zero padding
   //        pose blocks of factor k      -> the pose image (63 owner threads), diagonal and gradient of the frame's 13 dimensions (13 threads)
   {
-    double *ring = COMPACT ? stage : gst;
+    double *ring = gst;
     // pose-block owners: I1 pose_i x pose_i (21, twin +19), I3 pose gradient (6, twin +19), I4 pose_i x pose_j (36): threads 128 .. 190 of the last trip
     int pa = 0, pbc = 0, pcls = 0;
     {
@@ -450,20 +390,8 @@ __device__ __forceinline__ void assemble_body(BatchDev &b, int jacobi_scaling, d
     bimg[BI_SCAL + 2] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
   }
 }
-__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
-  assemble_body<false>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
-}
-// compact Gram slots (BatchDev::compact): the extrinsic-translation blocks are 3 x 3 transforms of the slots' B blocks (assemble_compact.hpp)
-// Workgroups beyond the windows' (small batches, vilo_solve_launch's reduce_later): the second half of the frame-parallel visual form, one
-// packed wave each on their first wave. It writes what only the solver's launch reads (landmark sums, coupling rows), so it runs beside the
-// bookkeeping + assembly of the windows instead of in a launch of its own; the gradient buffer it fills is the one the linearisation
-// pass noted (b.lin_cur), since the bookkeeping of the same launch may flip st.cur under it.
-__global__ void __launch_bounds__(ASM_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_assemble_c(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal, AcceptParams ap, int fuse_accept) {
-  if ((int)blockIdx.x >= b.W) {
-    if (threadIdx.x < 64) visual_reduce_body(b, (int)blockIdx.x - b.W, 1, true);
-    return;
-  }
-  assemble_body<true>(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal, ap, fuse_accept);
+__global__ void __launch_bounds__(ASM_THREADS) k_assemble(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_lm_diagonal) {
+  assemble_body(b, jacobi_scaling, min_lm_diagonal, max_lm_diagonal);
 }
 
 // =================================================================================================
@@ -1315,36 +1243,26 @@ __global__ void __launch_bounds__(64) k_solve_mid(BatchDev b, SolveParams sp) {
 // =================================================================================================
 // launch
 // =================================================================================================
-int vilo_launch_mw_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);    // kernels_mw.hip
-int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves);   // kernels_asm_small.hip
 int vilo_launch_mw8_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s);   // kernels_mw8.hip
-// Which solver (0 single wave, 2 two waves, 4 four waves per window, 3 the single wave in three stages): as many waves per window as the
-// batch leaves SIMDs for — four up to one window per CU (256 on an MI355X), two up to two windows per CU, the single-wave form beyond; in
-// three stages once the batch fills the two-waves-per-SIMD stages too. vilo_set_solver_form pins a form
-// (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
+// Which solver (VILO_SOLVER_*: 0 the single wave, 3 the single wave in three stages, 4 eight waves per window): as many waves per window as
+// the batch leaves SIMDs for — eight up to two rounds of one window per CU (512 on an MI355X; measured against the single wave with the
+// two-kernel assembly: 320 windows + 5 %, 384 + 7 %, 512 + 4 %), the single wave beyond, in three stages once the batch fills the
+// two-waves-per-SIMD stages too (VILO_MW8_MAX_WINDOWS / VILO_SPLIT_MIN_WINDOWS move the two thresholds). vilo_set_solver_form
+// pins a form (the tests run every form against the oracle; a deployment that needs bitwise equal answers across batch sizes pins one too).
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b) {
   const int forced = ctx->solver_form;   // (vilo_set_solver_form; VILO_SOLVER gives the default at vilo_create)
-  static const int max_w8 = [] { const char *e = getenv("VILO_MW8_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
-  static const int max_w2 = [] { const char *e = getenv("VILO_MW_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
+  static const int max_w8 = [] { const char *e = getenv("VILO_MW8_MAX_WINDOWS"); return e ? atoi(e) : 512; }();
   static const int min_w3 = [] { const char *e = getenv("VILO_SPLIT_MIN_WINDOWS"); return e ? atoi(e) : 1025; }();
   if (forced >= 0) return forced;
-  return b.W <= max_w8 ? 4 : (b.W <= max_w2 ? 2 : (b.W < min_w3 ? 0 : 3));
+  return b.W <= max_w8 ? 4 : (b.W < min_w3 ? 0 : 3);
 }
-int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage, const AcceptParams *ap, int reduce_waves) {
+int vilo_launch_wave_solver(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, int stage) {
   size_t lds_bytes = (size_t)WS_TOTAL * sizeof(double);
   if (const char *e = getenv("VILO_WAVE_LDS")) lds_bytes = (size_t)atol(e);   // occupancy experiments: more LDS per workgroup = fewer windows per CU
   if (stage == 0) {
-    // small batches with compact slots: the 512-thread form of the assembly (kernels_asm_small.hip)
-    const int took = vilo_launch_assemble_small(ctx, b, sp, s, ap, reduce_waves);
-    if (took != 0) return took < 0 ? took : VILO_OK;
-    // (ap: the trust-region bookkeeping — k_accept's body — runs as the kernel's first phase)
-    const AcceptParams ap0 = ap ? *ap : AcceptParams{};
-    if (b.compact) hipLaunchKernelGGL(k_assemble_c, dim3(b.W + reduce_waves), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
-    else hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal, ap0, ap ? 1 : 0);
+    hipLaunchKernelGGL(k_assemble, dim3(b.W), dim3(ASM_THREADS), 0, s, b, sp.jacobi_scaling, sp.min_lm_diagonal, sp.max_lm_diagonal);
   } else if (vilo_solver_form(ctx, b) == 4) {
     return vilo_launch_mw8_solver(ctx, b, sp, s);
-  } else if (vilo_solver_form(ctx, b) == 2) {
-    return vilo_launch_mw_solver(ctx, b, sp, s);
   } else {
     if (!ctx->wave_attr_set) {
       VILO_HIP(hipFuncSetAttribute((const void *)k_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -1,6 +1,6 @@
 // Pieces of the linearisation pass that more than one translation unit needs: which buffer a pass writes, the per-lane view of a packed
 // wave, and the second half of the frame-parallel visual form (k_visual_reduce's body: kernels_solve.hip launches it as a kernel of its
-// own, kernels_wave.hip runs it in extra workgroups of k_assemble_c for small batches).
+// own, kernels_asm_small.hip runs it in extra workgroups of k_assemble_s for small batches).
 #pragma once
 #include "solve_common.hpp"
 
@@ -43,7 +43,7 @@ __device__ __forceinline__ LaneSeg lane_segment(const WaveMeta &wv, const ChunkM
 // Second half of the TPAR form: per landmark, the (frame, camera) terms in the order the walking form adds them (frames ascending,
 // left camera before right; an unobserved factor contributed +0.0).
 // cur_of: the landmark-gradient buffer the current linearisation uses (SolverState::cur, or the snapshot of it the linearisation pass
-// took — b.lin_cur — when this body runs beside the trust-region bookkeeping that flips it: small batches, k_assemble_c's extra workgroups)
+// took — b.lin_cur — when this body runs beside the trust-region bookkeeping that flips it: small batches, k_assemble_s's extra workgroups)
 __device__ __forceinline__ void visual_reduce_body(BatchDev &b, int wave_id, int mode, bool snapshot) {
   const WaveMeta wv = b.wave[wave_id];
   const SolverState &st = b.st[wv.win];

@@ -166,6 +166,6 @@ struct BatchDev {
   int *prep_bad;                   // [W * 10] covariance of the record not positive definite
   int rp_on, leg;
   int compact;                // 1: every window keeps td constant: the solve passes use the compact 16-column visual rows / Gram slots (visual_lin.hpp GK_*)
-  int *lin_cur;               // [W] SolverState::cur as the last linearisation pass of a small batch saw it (visual_reduce_body in k_assemble_c's launch)
+  int *lin_cur;               // [W] SolverState::cur as the last linearisation pass of a small batch saw it (visual_reduce_body in k_assemble_s's launch)
   int *win_bad;               // [W] 1: a preintegration covariance of the window has no sqrt_info: the window fails alone (termination FAILURE)
 };

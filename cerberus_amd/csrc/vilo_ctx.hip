@@ -54,7 +54,7 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   ctx->d_cfg = nullptr;
   ctx->profile = 0;
   if (const char *e = getenv("VILO_SOLVER"))
-    ctx->solver_form = !strcmp(e, "mw8") ? VILO_SOLVER_MW8 : (!strcmp(e, "mw") ? VILO_SOLVER_MW : (!strcmp(e, "wave") ? VILO_SOLVER_WAVE : (!strcmp(e, "split") ? VILO_SOLVER_SPLIT : VILO_SOLVER_AUTO)));
+    ctx->solver_form = !strcmp(e, "mw8") ? VILO_SOLVER_MW8 : (!strcmp(e, "wave") ? VILO_SOLVER_WAVE : (!strcmp(e, "split") ? VILO_SOLVER_SPLIT : VILO_SOLVER_AUTO));
   ctx->compact_rows = getenv("VILO_NO_COMPACT") ? 0 : 1;
   for (int i = 0; i < VILO_NKERNEL; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
@@ -95,7 +95,7 @@ extern "C" int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode) {
 // single wave in elimination order and agree with it to rounding, not bitwise, so a caller that needs the same answer for a window
 // whatever the size of the batch it shares pins one (the choice is part of the key of a batch's captured launch sequence).
 extern "C" int vilo_set_solver_form(vilo_ctx *ctx, int form) {
-  if (!ctx || !(form == VILO_SOLVER_AUTO || form == VILO_SOLVER_WAVE || form == VILO_SOLVER_MW || form == VILO_SOLVER_SPLIT || form == VILO_SOLVER_MW8)) return VILO_ERR_BAD_ARG;
+  if (!ctx || !(form == VILO_SOLVER_AUTO || form == VILO_SOLVER_WAVE || form == VILO_SOLVER_SPLIT || form == VILO_SOLVER_MW8)) return VILO_ERR_BAD_ARG;
   ctx->solver_form = form;
   return VILO_OK;
 }

@@ -1,4 +1,4 @@
-// Device helpers shared by the single-wave solver (kernels_wave.hip) and the multi-wave solver (kernels_mw.hip): tile numbering of the
+// Device helpers shared by the single-wave solver (kernels_wave.hip) and the eight-wave solver (kernels_mw8.hip): tile numbering of the
 // 80 x 80 pose system (15 lower 16 x 16 tiles in FP64-MFMA accumulator order) and the 16 x 16 Cholesky + inverse of one diagonal tile.
 #pragma once
 #include "solve_common.hpp"

@@ -3,6 +3,8 @@
 
 #include <dlfcn.h>
 
+#include <new>
+
 #include <cstring>
 
 namespace vilo {
@@ -278,6 +280,10 @@ const Lz4Api *lz4_api() {
 }
 // VILO_BAG_OK, VILO_BAG_ERR_COMPRESSED (no library for this compression) or VILO_BAG_ERR_FORMAT (the stream is not what the header says)
 int chunk_decompress(const std::string &compression, const std::vector<uint8_t> &src, uint32_t size, std::vector<uint8_t> *out) {
+  // `size` is the header's word for the uncompressed length (untrusted): rosbag's chunks are < 1 MiB by default and neither codec expands
+  // real data a thousandfold, so a header that asks for more than that of its own compressed bytes (or for more than 1 GiB) is refused
+  // before anything is allocated
+  if (size > (1u << 30) || (uint64_t)size > 1024ull * (uint64_t)src.size() + (1u << 16)) return VILO_BAG_ERR_FORMAT;
   out->assign(size, 0);
   if (compression == "bz2") {
     const Bz2Api *a = bz2_api();
@@ -436,6 +442,12 @@ int read_record(FILE *f, std::vector<uint8_t> *header, std::vector<uint8_t> *dat
   if (hl && std::fread(header->data(), 1, hl, f) != hl) return VILO_BAG_ERR_FORMAT;
   if (std::fread(b, 1, 4, f) != 4) return VILO_BAG_ERR_FORMAT;
   const uint32_t dl = get_u32(b);
+  // the length comes from the (untrusted) file: never allocate more than the file still holds
+  const long here = std::ftell(f);
+  if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) return VILO_BAG_ERR_IO;
+  const long end = std::ftell(f);
+  if (end < 0 || std::fseek(f, here, SEEK_SET) != 0) return VILO_BAG_ERR_IO;
+  if ((unsigned long)dl > (unsigned long)(end - here)) return VILO_BAG_ERR_FORMAT;
   data->resize(dl);
   if (dl && std::fread(data->data(), 1, dl, f) != dl) return VILO_BAG_ERR_FORMAT;
   return 1;
@@ -558,73 +570,119 @@ void copy_str(char *dst, size_t cap, const std::string &s) {
 }
 }  // namespace
 
+namespace {
+// a C entry point's body: exceptions become the error code
+template <class F>
+int c_guard(int err, F f) {
+  try {
+    return f();
+  } catch (...) {
+    return err;
+  }
+}
+}  // namespace
+
 extern "C" {
 void *vilo_bag_writer_open(const char *path, int chunk_threshold_bytes) {
-  vilo::BagWriter *w = new vilo::BagWriter;
-  if (!w->open(path, chunk_threshold_bytes > 0 ? (size_t)chunk_threshold_bytes : 768 * 1024)) { delete w; return nullptr; }
-  return w;
+  vilo::BagWriter *w = nullptr;
+  try {
+    w = new vilo::BagWriter;
+    if (!w->open(path, chunk_threshold_bytes > 0 ? (size_t)chunk_threshold_bytes : 768 * 1024)) { delete w; return nullptr; }
+    return w;
+  } catch (...) {
+    delete w;
+    return nullptr;
+  }
 }
 int vilo_bag_write_imu(void *h, const char *topic, uint32_t seq, uint32_t secs, uint32_t nsecs, const char *frame_id, const double *acc3, const double *gyr3) {
-  vilo::ImuMsg m;
-  m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs; m.header.frame_id = frame_id ? frame_id : "";
-  for (int i = 0; i < 3; ++i) { m.linear_acceleration[i] = acc3[i]; m.angular_velocity[i] = gyr3[i]; }
-  std::vector<uint8_t> d;
-  vilo::serialize(m, &d);
-  return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_IMU, secs, nsecs, d) ? 0 : -1;
+  return c_guard(-1, [&]() -> int {
+    vilo::ImuMsg m;
+    m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs; m.header.frame_id = frame_id ? frame_id : "";
+    for (int i = 0; i < 3; ++i) { m.linear_acceleration[i] = acc3[i]; m.angular_velocity[i] = gyr3[i]; }
+    std::vector<uint8_t> d;
+    vilo::serialize(m, &d);
+    return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_IMU, secs, nsecs, d) ? 0 : -1;
+  });
 }
 int vilo_bag_write_joint_state(void *h, const char *topic, uint32_t seq, uint32_t secs, uint32_t nsecs, int n, const double *position, const double *velocity,
                                const double *effort) {
-  vilo::JointStateMsg m;
-  m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs;
-  m.position.assign(position, position + n); m.velocity.assign(velocity, velocity + n); m.effort.assign(effort, effort + n);
-  std::vector<uint8_t> d;
-  vilo::serialize(m, &d);
-  return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_JOINT_STATE, secs, nsecs, d) ? 0 : -1;
+  return c_guard(-1, [&]() -> int {
+    vilo::JointStateMsg m;
+    m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs;
+    m.position.assign(position, position + n); m.velocity.assign(velocity, velocity + n); m.effort.assign(effort, effort + n);
+    std::vector<uint8_t> d;
+    vilo::serialize(m, &d);
+    return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_JOINT_STATE, secs, nsecs, d) ? 0 : -1;
+  });
 }
 int vilo_bag_write_image(void *h, const char *topic, uint32_t seq, uint32_t secs, uint32_t nsecs, const char *frame_id, uint32_t height, uint32_t width,
                          const char *encoding, uint32_t step, const uint8_t *data) {
-  vilo::ImageMsg m;
-  m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs; m.header.frame_id = frame_id ? frame_id : "";
-  m.height = height; m.width = width; m.step = step; m.encoding = encoding ? encoding : "mono8";
-  m.data.assign(data, data + (size_t)step * height);
-  std::vector<uint8_t> d;
-  vilo::serialize(m, &d);
-  return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_IMAGE, secs, nsecs, d) ? 0 : -1;
+  return c_guard(-1, [&]() -> int {
+    vilo::ImageMsg m;
+    m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs; m.header.frame_id = frame_id ? frame_id : "";
+    m.height = height; m.width = width; m.step = step; m.encoding = encoding ? encoding : "mono8";
+    m.data.assign(data, data + (size_t)step * height);
+    std::vector<uint8_t> d;
+    vilo::serialize(m, &d);
+    return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_IMAGE, secs, nsecs, d) ? 0 : -1;
+  });
 }
 int vilo_bag_write_point_cloud(void *h, const char *topic, uint32_t seq, uint32_t secs, uint32_t nsecs, int n_points, const float *xyz, int n_channels,
                                const char *const *channel_names, const float *channels) {
-  vilo::PointCloudMsg m;
-  m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs;
-  m.points.assign(xyz, xyz + 3 * (size_t)n_points);
-  for (int c = 0; c < n_channels; ++c) {
-    m.channel_name.push_back(channel_names[c]);
-    m.channel_values.push_back(std::vector<float>(channels + (size_t)c * n_points, channels + (size_t)(c + 1) * n_points));
-  }
-  std::vector<uint8_t> d;
-  vilo::serialize(m, &d);
-  return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_POINT_CLOUD, secs, nsecs, d) ? 0 : -1;
+  return c_guard(-1, [&]() -> int {
+    vilo::PointCloudMsg m;
+    m.header.seq = seq; m.header.secs = secs; m.header.nsecs = nsecs;
+    m.points.assign(xyz, xyz + 3 * (size_t)n_points);
+    for (int c = 0; c < n_channels; ++c) {
+      m.channel_name.push_back(channel_names[c]);
+      m.channel_values.push_back(std::vector<float>(channels + (size_t)c * n_points, channels + (size_t)(c + 1) * n_points));
+    }
+    std::vector<uint8_t> d;
+    vilo::serialize(m, &d);
+    return ((vilo::BagWriter *)h)->write(topic, vilo::BAG_POINT_CLOUD, secs, nsecs, d) ? 0 : -1;
+  });
 }
-int vilo_bag_writer_set_compression(void *h, const char *name) { return h && name ? ((vilo::BagWriter *)h)->setCompression(name) : vilo::VILO_BAG_ERR_FORMAT; }
+int vilo_bag_writer_set_compression(void *h, const char *name) {
+  return c_guard(vilo::VILO_BAG_ERR_FORMAT, [&]() -> int { return h && name ? ((vilo::BagWriter *)h)->setCompression(name) : vilo::VILO_BAG_ERR_FORMAT; });
+}
 int vilo_bag_writer_close(void *h) {
   vilo::BagWriter *w = (vilo::BagWriter *)h;
-  const bool ok = w->close();
+  const int rc = c_guard(-1, [&]() -> int { return w->close() ? 0 : -1; });
   delete w;
-  return ok ? 0 : -1;
+  return rc;
 }
 
+// (no C++ exception may cross the C boundary into ctypes / cgo: an allocation failure or a length error on a damaged bag is a return code)
 void *vilo_bag_reader_open(const char *path, int *rc) {
-  ReaderHandle *r = new ReaderHandle;
-  const int e = r->r.open(path);
-  if (rc) *rc = e;
-  if (e != vilo::VILO_BAG_OK) { delete r; return nullptr; }
-  return r;
+  ReaderHandle *r = nullptr;
+  try {
+    r = new ReaderHandle;
+    const int e = r->r.open(path);
+    if (rc) *rc = e;
+    if (e != vilo::VILO_BAG_OK) { delete r; return nullptr; }
+    return r;
+  } catch (...) {
+    delete r;
+    if (rc) *rc = vilo::VILO_BAG_ERR_FORMAT;
+    return nullptr;
+  }
 }
 int vilo_bag_reader_info(void *h, uint32_t *conn_count, uint32_t *chunk_count, uint64_t *index_pos) {
   ReaderHandle *r = (ReaderHandle *)h;
   *conn_count = r->r.conn_count; *chunk_count = r->r.chunk_count; *index_pos = r->r.index_pos;
   return 0;
 }
+static int bag_reader_next_impl(void *h, vilo_bag_msg *o);
 int vilo_bag_reader_next(void *h, vilo_bag_msg *o) {
+  try {
+    return bag_reader_next_impl(h, o);
+  } catch (const std::bad_alloc &) {
+    return vilo::VILO_BAG_ERR_IO;
+  } catch (...) {
+    return vilo::VILO_BAG_ERR_FORMAT;
+  }
+}
+static int bag_reader_next_impl(void *h, vilo_bag_msg *o) {
   ReaderHandle *r = (ReaderHandle *)h;
   const int rc = r->r.next(&r->m);
   if (rc != vilo::VILO_BAG_OK) return rc;

@@ -182,7 +182,8 @@ def stream_messages(frame, t_prev, seq0, rate=500.0, with_images=False):
     """One Stream frame (samples of the interval (t_prev, header] + the features tracked in the image at `header`) as message dicts in the order
     a recorder would have seen them: the IMU / JointState pairs, then the image pair (optional: 8 x 8 dummies), then the feature cloud.
     JointState carries 12 joints + 4 feet: velocity[12 + i] the planner's contact flag, effort[12 + i] the foot force (main.cpp:274-278);
-    the synthetic stream has one contact signal, which goes into both. Returns (messages, next seq)."""
+    the synthetic stream has one contact signal, which goes into both unless the frame carries `forces` ([samples][4], newtons) for the
+    efforts. Returns (messages, next seq)."""
     out, seq = [], seq0
     n = len(frame["samples"])
     h = 1.0 / rate
@@ -194,6 +195,8 @@ def stream_messages(frame, t_prev, seq0, rate=500.0, with_images=False):
         pos, vel, eff = np.zeros(16), np.zeros(16), np.zeros(16)
         pos[:12], vel[:12] = s[7:19], s[19:31]
         vel[12:], eff[12:] = s[31:35], s[31:35]
+        if "forces" in frame:       # foot force readings of their own (CONTACT_SENSOR_TYPE 2 reads effort[12 .. 15], main.cpp:274-278)
+            eff[12:] = frame["forces"][len(out) // 2]
         out.append(dict(kind=KIND_JOINT_STATE, topic=LEG_TOPIC, seq=seq, secs=secs, nsecs=nsecs, position=pos, velocity=vel, effort=eff))
         seq += 1
     secs, nsecs = to_stamp(frame["header"])

@@ -328,13 +328,12 @@ int vilo_debug_marg_general_count(const vilo_ctx *ctx);
  * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
 int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
 /* Solver form of the batches this context solves from here on. VILO_SOLVER_AUTO (default) picks by batch size: eight waves per window
- * (one workgroup per window, its waves in fixed roles) up to 256 windows, two waves up to 512, one wave up to 1024, the single wave in three kernels beyond. All forms restate the same algorithm; the
- * multi-wave forms eliminate in another order and agree with the single wave to rounding (1e-9 on well-conditioned windows), SPLIT and
- * WAVE agree bitwise. Pin a form when a window must get the same answer whatever the size of the batch it shares. The environment
- * variable VILO_SOLVER (wave | mw | mw8 | split) only sets the default a context is created with. */
+ * (one workgroup per window, its waves in fixed roles) up to 256 windows, one wave up to 1024, the single wave in three kernels beyond. All
+ * forms restate the same algorithm; the eight-wave form eliminates in another order and agrees with the single wave to rounding (1e-9 on
+ * well-conditioned windows), SPLIT and WAVE agree bitwise. Pin a form when a window must get the same answer whatever the size of the
+ * batch it shares. The environment variable VILO_SOLVER (wave | mw8 | split) only sets the default a context is created with. */
 #define VILO_SOLVER_AUTO (-1)
 #define VILO_SOLVER_WAVE 0
-#define VILO_SOLVER_MW 2
 #define VILO_SOLVER_SPLIT 3
 #define VILO_SOLVER_MW8 4
 int vilo_set_solver_form(vilo_ctx *ctx, int form);

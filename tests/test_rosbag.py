@@ -150,6 +150,34 @@ def test_damaged_compressed_and_foreign_bags_are_refused(tmp_path):
     assert kinds == [rb.KIND_OTHER] * 10
 
 
+def test_lengths_a_damaged_bag_claims_are_never_allocated(tmp_path):
+    """Sizes in a bag come from the file. A record whose data length exceeds what the file still holds, and a compressed chunk whose header
+    asks for gigabytes, are refused with the format error — before any allocation of that size, and as a return code through the C
+    boundary (ADVICE round 4: they used to end in std::bad_alloc / length_error inside ctypes)."""
+    import resource
+    from cerberus_amd import rosbag as rb
+    p = tmp_path / "ok.bag"
+    with rb.BagWriter(p, compression="bz2") as w:
+        for i in range(10):
+            w.write(dict(kind=rb.KIND_IMU, topic="/imu", seq=i, secs=1, nsecs=i, linear_acceleration=np.zeros(3), angular_velocity=np.zeros(3)))
+    raw = p.read_bytes()
+    at = 13 + 4096                                                   # the chunk record
+    hl = struct.unpack_from("<I", raw, at)[0]
+    # (1) the chunk's data length says 3 GiB
+    huge = raw[:at + 4 + hl] + struct.pack("<I", 3 << 30) + raw[at + 8 + hl:]
+    (tmp_path / "dl.bag").write_bytes(huge)
+    # (2) the header's `size` field (uncompressed length of the bz2 stream) says 3.9 GiB
+    hdr = raw[at + 4:at + 4 + hl]
+    q = hdr.index(b"size=")
+    hdr2 = hdr[:q + 5] + struct.pack("<I", 0xF0000000) + hdr[q + 9:]
+    (tmp_path / "size.bag").write_bytes(raw[:at + 4] + hdr2 + raw[at + 4 + hl:])
+    soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+    for name in ("dl.bag", "size.bag"):
+        with pytest.raises(rb.BagError, match="damaged|format"):
+            list(rb.BagReader(tmp_path / name))
+    assert resource.getrlimit(resource.RLIMIT_AS) == (soft, hard)
+
+
 def _records(raw, at, end):
     """top-level records of a bag file: (offset, header fields, data)"""
     out = []
@@ -344,3 +372,28 @@ def test_replay_from_a_bag_is_the_replay_from_memory_bit_for_bit(ctx, cfg, tmp_p
     for (ta, fa, na, pa, va, ra), (tb, fb, nb, pb, vb, rb_) in zip(a, b):
         assert (ta, fa, na) == (tb, fb, nb)
         np.testing.assert_array_equal(pa, pb); np.testing.assert_array_equal(va, vb); np.testing.assert_array_equal(ra, rb_)
+
+
+@pytest.mark.gpu
+def test_go1_parameter_replay_of_a_bag_matches_the_oracle_window_by_window(tmp_path):
+    """bench.py's replay configuration (BASELINE configs[4] stand-in: contact_sensor_type 2 foot forces, calf lengths estimated on line, the
+    stream written as a bag and read back): every one of the first 30 windows the estimator solved on the GPU — dumped with the result — is
+    solved again by the CPU oracle from the same dumped input (states 1e-8, same iteration count, cost 1e-7), and the prior the estimator
+    carried into the next image is the oracle's marginalisation of the dumped result (normal equations 1e-5: cond(Amm))."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle_py as O
+    from cerberus_amd import synth
+    from test_sliding_window import _oracle_replay
+    r = bench.replay_block(0, n_images=42, cpu_budget_s=0.0, keep_dir=str(tmp_path))
+    assert "error" not in r, r
+    dumps = os.path.join(str(tmp_path), "windows")
+    n = len(os.listdir(dumps))
+    assert n >= 30 and r["counters"]["dropped"] == 0 and r["counters"]["clouds"] == 42
+    cfg5 = bench.go1_config(synth.default_config())
+    assert cfg5.contact_sensor_type == 2
+    _oracle_replay(O.config_from(cfg5), dumps, 30, tol_state=1e-8)
+    assert r["rho_error_m"]["final"] < r["rho_error_m"]["at_start"]      # the calf lengths move towards the truth

@@ -1,5 +1,5 @@
-"""The four forms of the per-linearisation solver (kernels_wave.hip: one wave per window; kernels_split.hip: the same in three stages,
-the form of full batches; kernels_mw.hip / kernels_mw8.hip: two / four waves per window, the forms of small batches) are chosen by batch
+"""The three forms of the per-linearisation solver (kernels_wave.hip: one wave per window; kernels_split.hip: the same in three stages,
+the form of full batches; kernels_mw8.hip: eight waves per window, the form of small batches) are chosen by batch
 size, so a test at one size sees one of them. Here every form is pinned in turn (VILO_SOLVER, read once per process: one subprocess each)
 on the same windows: plain ones, two whose factorisation fails at the initial mu (DoglegStrategy::ComputeGaussNewtonStep's retry) and two
 that start far off with a huge trust region (runs of rejected steps, each reusing the linearisation).
@@ -28,7 +28,7 @@ def _run(form, **env_extra):
 
 @pytest.fixture(scope="module")
 def results():
-    return {"wave": _run("wave"), "split": _run("split"), "split_redo": _run("split", VILO_DEBUG_REDO="1"), "mw": _run("mw"), "mw8": _run("mw8")}
+    return {"wave": _run("wave"), "split": _run("split"), "split_redo": _run("split", VILO_DEBUG_REDO="1"), "mw8": _run("mw8")}
 
 
 def _close(a, b, tol):
@@ -40,7 +40,7 @@ def _close(a, b, tol):
             assert np.abs(sa - sb).max() <= tol * max(1.0, np.abs(sb).max())
 
 
-@pytest.mark.parametrize("form", ["split", "mw", "mw8"])
+@pytest.mark.parametrize("form", ["split", "mw8"])
 def test_forms_agree_on_plain_windows(results, form):
     _close(results[form]["plain"], results["wave"]["plain"], 1e-9)
     # (badly conditioned far-off start: the forms' different summation orders show at 1e-6 .. 1e-5 after 12 iterations — measured: it passes
@@ -57,7 +57,7 @@ def test_three_stage_form_is_the_single_wave_solver_bitwise(results, variant):
 
 
 def test_every_form_escalates_mu(results):
-    for form in ("wave", "split", "mw", "mw8"):
+    for form in ("wave", "split", "mw8"):
         for w in results[form]["escalation"]:
             assert w["retries"] >= 1 and w["iterations"] == 8
             assert w["cost_trace"][-1] <= w["cost_trace"][0]
@@ -97,5 +97,5 @@ def test_the_form_is_a_property_of_the_context_not_of_the_process(results):
         b.download()
         assert [[a.tolist() for a in w.state_arrays()] for w in ws] == got[form], form
     b.close()
-    assert api.lib().vilo_set_solver_form(ca.h, 1) != 0   # no such form
+    assert api.lib().vilo_set_solver_form(ca.h, 1) != 0 and api.lib().vilo_set_solver_form(ca.h, 2) != 0   # no such forms (2 was the two-wave form of rounds 3 - 4)
     ca.close(); cb.close()
