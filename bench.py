@@ -9,7 +9,7 @@ share nothing (weak scaling, no data-path collective); `value` = window-iteratio
 time. Inputs are resident in HBM before the timed region (batch created + preintegrated during setup).
 
 Workload = BASELINE.json configs[1]: synthetic 10-KF x 200-landmark window, A1 4-leg contact preintegration,
-500 Hz IMU/leg samples; `--windows` independent instances per GPU (config 4 batches 1024 over 8 GPUs).
+500 Hz IMU/leg samples; `--windows` independent instances per GPU (default 16384; config 4 batches 1024 over 8 GPUs).
 `--config 3` = BASELINE.json configs[2]: 1000 landmarks (NUM_OF_F, parameters.h:24), 400 Hz samples (27 per interval), and every
 iteration integrates all 10 intervals of every window again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
 at the biases of the point it linearises, sqrt_info of the new covariances included.
@@ -33,7 +33,7 @@ def algorithmic_bytes(sum_k, L, F=11, n_prior=86):
 
 
 ALG_FLOPS_PER_WINDOW_ITERATION = {200: 13.7e6, 1000: 47.0e6}   # FP64 flops of one window-iteration (FMA = 2)
-ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")   # launched once per iteration
+ITERATION_KERNELS = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_assemble", "k_assemble_bias", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")   # launched once per iteration (k_assemble = k_assemble_pose: the bookkeeping is its first phase; k_accept runs once per solve, for the last candidate)
 REPROPAGATION_KERNELS = ("k_repropagate", "k_prepare_preint")   # config 3: once per iteration as well
 # K1 re-propagation adds the raw samples (280 B each) to the compulsory traffic and ~15 Mflop (sparse-aware; 75 Mflop as
 # dense 31 x 31 products) to the flops of one window-iteration
@@ -65,7 +65,11 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "round4"
+PROFILE_ROUND = "round5"
+# windows per GPU of the headline line: the kernels of an iteration are launched once for all windows of the batch, and every kernel's tail (its
+# last partial round of workgroups) and launch gap is paid once per batch — measured on one MI355X with the round-5 kernels: 4096 windows 1.77 M,
+# 8192 1.835 M, 12288 1.864 M, 16384 1.877 M window-iterations/s (18 GB of the 288 GB resident)
+DEFAULT_WINDOWS = 16384
 STRONG_TOTAL = 1024   # BASELINE configs[3]
 
 
@@ -517,7 +521,7 @@ def main():
                     "5: BASELINE configs[4] stand-in: a synthetic Go1-parameter bag replayed through the sliding-window estimator (--images)")
     ap.add_argument("--images", type=int, default=170, help="--config 5 and the `replay` side block: images of the replayed stream")
     ap.add_argument("--no-replay", action="store_true", help="skip the `replay` side block of the default line")
-    ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 4096; 1024 with --config 3)")
+    ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 16384; 1024 with --config 3)")
     ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
     ap.add_argument("--landmarks", type=int, default=0, help="default 200 (1000 with --config 3)")
     ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
@@ -550,7 +554,7 @@ def main():
     rp = args.config == 3
     args.landmarks = args.landmarks or (1000 if rp else 200)
     args.rate = args.rate or (400 if rp else 500)
-    args.windows = args.windows or (1024 if rp else 4096)
+    args.windows = args.windows or (1024 if rp else DEFAULT_WINDOWS)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -722,12 +722,15 @@ __device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq,
   for (int g = 0; g < 4; ++g)
     if (g == tb_g) { tb_s = cs[g]; tb_km = (g < wv.nseg) ? ckm[g] : 0; }
   long long p_wait = 0, pw0 = 0;   // (profiling build only)
+  long long p_tab = 0, p_eval = 0, p_store = 0, pk0 = 0, pk1 = 0;
   const long long p_start = pclk64();
   for (int t = 0; t < kmax; ++t) {
+    PCLK(pk0 = clock64());
     if (t >= 1) {
       if (lane < 24 && t < tb_km) vis_build_pair_row(xs, wt, tb_s, min(tb_s + t, VILO_MAX_FRAMES - 1), tb_kind, tb_r, tab + tb_g * VT_N);
       lds_fence();
     }
+    PCLK(p_tab += clock64() - pk0);
     const int j = min(s + t, VILO_MAX_FRAMES - 1);
     const unsigned char fl = fl_next;
     double ob[11];
@@ -750,6 +753,7 @@ __device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq,
       const int nstep = (t == 0) ? 0 : 2 * t - 1 + cam;
       const bool produce = active && (fl & 1) && (cam == 0 || (fl & 2));
       double *xr0 = X + (nstep & 1) * PC_XN + lane * XLANEC, *xr1 = xr0 + XROWC;
+      PCLK(pk0 = clock64());
       if (produce) {
         double x0[XROWC], x1[XROWC], Jl[2], obc[5], tc[4][3];
         double rho0;
@@ -773,6 +777,7 @@ __device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq,
 #pragma unroll
         for (int c = 0; c < 3; ++c) { wc_e0[c] += te0[c]; wc_e1[c] += te1[c]; }
         cost += rho0;
+        PCLK(asm volatile("" ::: "memory"); pk1 = clock64(); p_eval += pk1 - pk0);
 #pragma unroll
         for (int c = 0; c < XROWC; ++c) { xr0[c] = x0[c]; xr1[c] = x1[c]; }
         xr0[2 * XROWC] = Jl[0]; xr0[2 * XROWC + 1] = Jl[1];
@@ -781,12 +786,12 @@ __device__ __forceinline__ void visual_linearize_pc_body(BatchDev &b, double sq,
         for (int c = 0; c < XROWC; ++c) { xr0[c] = 0.0; xr1[c] = 0.0; }
         xr0[2 * XROWC] = 0.0; xr0[2 * XROWC + 1] = 0.0;
       }
-      PCLK(pw0 = clock64());
+      PCLK(pw0 = clock64(); if (produce) p_store += pw0 - pk1);
       step_barrier();
       PCLK(p_wait += clock64() - pw0);
     }
   }
-  PCLK(if (wave_id == 0 && lane == 0) { st.phase_clk[30] = clock64() - p_start; st.phase_clk[31] = p_wait; });
+  PCLK(if (wave_id == 0 && lane == 0) { st.phase_clk[30] = clock64() - p_start; st.phase_clk[31] = p_wait; st.phase_clk[59] = p_tab; st.phase_clk[60] = p_eval; st.phase_clk[61] = p_store; });
   if (active) {
     // (rows of poses before the landmark's start frame are zero since vilo_batch_create and nobody writes them: not stored again)
     for (int f = s + kmax; f < VILO_MAX_FRAMES; ++f)

@@ -22,6 +22,8 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 128, 4096]:
     if C[0, 30] > 0:   # producer / consumer visual kernel: packed wave 0 (window 0)
         print("k_visual_linearize_pc (packed wave 0, %d frames): consumer %d cycles, %d of them at the step barriers; producer %d, %d at the barriers"
               % (C[0, 32], C[0, 28], C[0, 29], C[0, 30], C[0, 31]))
+        if C[0, 60] > 0:
+            print("   producer: pair tables %d | factor evaluation (lane 0's stamps) %d | row stores %d" % (C[0, 59], C[0, 60], C[0, 61]))
     if W >= 513 and C[:, 46].max() > 0:   # full batch: k_assemble_pose + k_assemble_bias (kernels_asm_full.hip)
         print("k_assemble_pose: bookkeeping + prior image %d | visual slots (passes) %d | IMU pose blocks %d | gradient + scaling %d | tile image out + q %d | sums %d | total %d"
               % (m[37] - m[36], m[38] - m[37], m[39] - m[38], m[41] - m[39], m[42] - m[41], m[45] - m[42], m[45] - m[36]))

@@ -42,18 +42,19 @@ if sys.argv[1] == "--config3":
     sys.exit(0)
 
 prof, sq = sys.argv[1], sys.argv[2]
-js = trace_and_pmc(prof, "", 4096, "--windows 4096")
+PROF_WINDOWS = int(os.environ.get("PROF_WINDOWS", "4096"))   # windows per dispatch of the profiled runs (tools/profile_gpu.sh / profile_sq.sh)
+js = trace_and_pmc(prof, "", PROF_WINDOWS, "--windows %d" % PROF_WINDOWS)
 lines = open(os.path.join(R, "gpurun_out", "prof_" + sq, "summary.txt")).read().rstrip("\n").split("\n")
 res = json.loads(lines[-1])
 open(os.path.join(R, "profiles", RND + "_sq_counters.txt"), "w").write("\n".join(lines[:-1]) + "\n")
-json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py --steps 1 --warmup 1 --windows 4096): per-dispatch means summed over the "
+json.dump({"note": "rocprofv3 --pmc SQ passes of tools/profile_sq.sh (bench.py --steps 1 --warmup 1 --windows %d): per-dispatch" % PROF_WINDOWS + " means summed over the "
                    "chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles; " + RND, "kernels_sha16": kernels_sha16(), "commit": _commit(),
-           "windows_per_dispatch": 4096, "kernels": res}, open(os.path.join(R, "profiles", RND + "_mfma.json"), "w"))
+           "windows_per_dispatch": PROF_WINDOWS, "kernels": res}, open(os.path.join(R, "profiles", RND + "_mfma.json"), "w"))
 if len(sys.argv) > 3:
     shutil.copy(sys.argv[3], os.path.join(R, "profiles", RND + "_bench_final.json"))
 if len(sys.argv) > 4:
     shutil.copy(sys.argv[4], os.path.join(R, "profiles", RND + "_bench_config3.json"))
-it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_accept", "k_assemble", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")
+it = ("k_visual_linearize", "k_imu_raw", "k_imu_linearize", "k_assemble", "k_assemble_bias", "k_chain", "k_solve_mid", "k_backsub", "k_solve_wave")
 tot = 0.0
 for k in it:
     b, us = js["hbm_bytes_per_dispatch"][k], js["kernel_trace"][k]["avg_us"]
@@ -61,5 +62,5 @@ for k in it:
     c = res.get(k, {})
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) if "GRBM_GUI_ACTIVE" in c else float("nan")
     print("%-20s %8.1f us  %7.1f KB/window  %5.2f TB/s  mfma busy %4.1f %%  active %4.1f %%  wait %4.1f %%" %
-          (k, us, b / 4096 / 1e3, b / us / 1e6, 100 * busy, 100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1), 100 * c.get("SQ_WAIT_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1)))
-print("iteration: %.1f KB per window-iteration = %.2f x 299 088 B; kernels %.1f us" % (tot / 4096 / 1e3, tot / 4096 / 299088, sum(js["kernel_trace"][k]["avg_us"] for k in it)))
+          (k, us, b / PROF_WINDOWS / 1e3, b / us / 1e6, 100 * busy, 100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1), 100 * c.get("SQ_WAIT_ANY", 0) / c.get("SQ_WAVE_CYCLES", 1)))
+print("iteration: %.1f KB per window-iteration = %.2f x 299 088 B; kernels %.1f us" % (tot / PROF_WINDOWS / 1e3, tot / PROF_WINDOWS / 299088, sum(js["kernel_trace"][k]["avg_us"] for k in it)))

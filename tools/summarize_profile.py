@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KNOWN = ("k_repropagate", "k_lin_small_c", "k_visual_linearize", "k_imu_linearize", "k_assemble_s", "k_assemble", "k_solve_wave", "k_solve_mid", "k_solve_mw8", "k_solve_mw", "k_chain", "k_backsub", "k_imu_raw", "k_visual_cost_walk", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
+KNOWN = ("k_repropagate", "k_lin_small_c", "k_visual_linearize", "k_imu_linearize", "k_assemble_bias", "k_assemble_s", "k_assemble", "k_solve_wave", "k_solve_mid", "k_solve_mw8", "k_solve_mw", "k_chain", "k_backsub", "k_imu_raw", "k_visual_cost_walk", "k_visual_cost", "k_imu_cost", "k_accept", "k_init_state",
          "k_preint_imu_leg", "k_prepare_preint", "k_calib_copy", "k_marginalize")
 
 

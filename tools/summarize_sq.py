@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KNOWN = ("k_repropagate", "k_visual_linearize", "k_visual_cost_walk", "k_visual_cost", "k_visual", "k_imu_linearize", "k_imu_raw", "k_imu_cost", "k_imu", "k_assemble", "k_solve_wave", "k_solve_mid", "k_solve_mw", "k_chain", "k_backsub", "k_accept",
+KNOWN = ("k_repropagate", "k_visual_linearize", "k_visual_cost_walk", "k_visual_cost", "k_visual", "k_imu_linearize", "k_imu_raw", "k_imu_cost", "k_imu", "k_assemble_bias", "k_assemble_s", "k_assemble", "k_solve_wave", "k_solve_mid", "k_solve_mw8", "k_chain", "k_backsub", "k_accept",
          "k_init_state", "k_preint_imu_leg", "k_prepare_preint", "k_marginalize")
 
 
