@@ -9,7 +9,7 @@ share nothing (weak scaling, no data-path collective); `value` = window-iteratio
 time. Inputs are resident in HBM before the timed region (batch created + preintegrated during setup).
 
 Workload = BASELINE.json configs[1]: synthetic 10-KF x 200-landmark window, A1 4-leg contact preintegration,
-500 Hz IMU/leg samples; `--windows` independent instances per GPU (default 16384; config 4 batches 1024 over 8 GPUs).
+500 Hz IMU/leg samples; `--windows` independent instances per GPU (default 32768; config 4 batches 1024 over 8 GPUs).
 `--config 3` = BASELINE.json configs[2]: 1000 landmarks (NUM_OF_F, parameters.h:24), 400 Hz samples (27 per interval), and every
 iteration integrates all 10 intervals of every window again (IMULegIntegrationBase::repropagate, imu_leg_integration_base.cpp:62-86)
 at the biases of the point it linearises, sqrt_info of the new covariances included.
@@ -68,8 +68,8 @@ def kernels_sha16():
 PROFILE_ROUND = "round5"
 # windows per GPU of the headline line: the kernels of an iteration are launched once for all windows of the batch, and every kernel's tail (its
 # last partial round of workgroups) and launch gap is paid once per batch — measured on one MI355X with the round-5 kernels: 4096 windows 1.77 M,
-# 8192 1.835 M, 12288 1.864 M, 16384 1.877 M window-iterations/s (18 GB of the 288 GB resident)
-DEFAULT_WINDOWS = 16384
+# 8192 1.835 M, 12288 1.864 M, 16384 1.877 M, 24576 1.901 M, 32768 1.911 M window-iterations/s (36 GB of the 288 GB resident)
+DEFAULT_WINDOWS = 32768
 STRONG_TOTAL = 1024   # BASELINE configs[3]
 
 
@@ -521,7 +521,7 @@ def main():
                     "5: BASELINE configs[4] stand-in: a synthetic Go1-parameter bag replayed through the sliding-window estimator (--images)")
     ap.add_argument("--images", type=int, default=170, help="--config 5 and the `replay` side block: images of the replayed stream")
     ap.add_argument("--no-replay", action="store_true", help="skip the `replay` side block of the default line")
-    ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 16384; 1024 with --config 3)")
+    ap.add_argument("--windows", type=int, default=0, help="independent windows per GPU (default 32768; 1024 with --config 3)")
     ap.add_argument("--total-windows", type=int, default=0, help="BASELINE configs[3] mode: this many windows in total, window w on GPU w mod N (strong scaling)")
     ap.add_argument("--landmarks", type=int, default=0, help="default 200 (1000 with --config 3)")
     ap.add_argument("--rate", type=int, default=0, help="IMU / leg sample rate of the synthetic windows (Hz): default 500 (400 with --config 3)")
@@ -808,12 +808,14 @@ def main():
                 import threading
                 lib.vilo_set_profiling(ctx.h, 0)
                 S = max(2, args.streams)
-                ctxs, batches = [ctx], [batch]
-                for k in range(1, S):
+                Ws = min(W, 16384)   # (windows per stream: bounded so that the side block's set-up stays under half a minute)
+                ctxs, batches = [], []
+                for k in range(S):
                     ck = api.Context(cfg, device=local_rank)
-                    wk = [make_synth_window(cfg, args.landmarks, args.rate, 30260925 + 100000 * k + i) for i in range(W)]
+                    wk = [make_synth_window(cfg, args.landmarks, args.rate, 30260925 + 100000 * k + i) for i in range(Ws)]
                     ck.preintegrate_windows(wk)
                     ctxs.append(ck); batches.append(make_batch(ck, wk))
+                    del wk
 
                 def run(b, n):
                     for _ in range(n):
@@ -828,9 +830,9 @@ def main():
                 [t.start() for t in th]; [t.join() for t in th]
                 dt2 = time.perf_counter() - t2
                 out["two_streams" if S == 2 else "multi_stream"] = {
-                    "value": S * W * ITERS * args.steps / dt2, "unit": "GN window-iterations/s", "streams": S, "windows_per_gpu": S * W,
-                    "note": "%d batches of %d windows on %d HIP streams, same kernels; not the headline value" % (S, W, S)}
-                for b, ck in zip(batches[1:], ctxs[1:]):
+                    "value": S * Ws * ITERS * args.steps / dt2, "unit": "GN window-iterations/s", "streams": S, "windows_per_gpu": S * Ws,
+                    "note": "%d batches of %d windows on %d HIP streams, same kernels; not the headline value" % (S, Ws, S)}
+                for b, ck in zip(batches, ctxs):
                     b.close(); ck.close()
             except Exception as e:
                 out["two_streams"] = {"error": repr(e)}

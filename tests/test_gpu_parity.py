@@ -401,8 +401,8 @@ def test_path_parity_with_the_oracles_own_preintegration(ctx, cfg, ocfg):
     12 trust-region iterations on the GPU, against the oracle integrating the same samples itself (O.fill_preint) and solving. The other solve
     tests hand both sides the same records (bench.py's parity_sample and test_headline_kernel_set_vs_oracle: the GPU's; most others: the
     oracle's), which pins the solver; K1 has its own goldens. What the two integrations differ by (1e-13 relative in the 31 x 31 covariance,
-    whose inverse square root enters every IMU residual: cond ~ 1e6 .. 1e7) bounds the agreement of the states from below at ~ 1e-9 .. 1e-8;
-    tolerance 1e-7, the measured value is printed."""
+    whose inverse square root enters every IMU residual) shows in the states at the level of the solver's own rounding: measured 2.3e-10,
+    tolerance 1e-8 like the solver-only tests; the measured value is printed."""
     from cerberus_amd import api, synth
     W = 4
     ws = [synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i)) for i in range(W)]
@@ -414,12 +414,12 @@ def test_path_parity_with_the_oracles_own_preintegration(ctx, cfg, ocfg):
         O.fill_preint(ocfg, w_o)          # the oracle's own integration of the same samples
         so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
         assert (summ[i].iterations, summ[i].num_successful) == (so.iterations, so.num_successful)
-        np.testing.assert_allclose(summ[i].final_cost, so.final_cost, rtol=1e-7)
+        np.testing.assert_allclose(summ[i].final_cost, so.final_cost, rtol=1e-8)
         for a, bb in zip(ws[i].state_arrays(), w_o.state_arrays()):
             if a.size:
                 worst = max(worst, np.abs(a - bb).max() / max(1.0, np.abs(bb).max()))
     print("MEASURED test_path_parity_with_the_oracles_own_preintegration: states %.2e" % worst)
-    assert worst < 1e-7, worst
+    assert worst < 1e-8, worst
 
 
 def test_batch_of_windows_matches_single(ctx, cfg, ocfg):

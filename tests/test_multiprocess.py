@@ -104,3 +104,53 @@ def test_bench_py_refuses_a_world_size_that_is_not_its_gpus_flag():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                          timeout=120, env=env, cwd=ROOT)
     assert out.returncode == 2
+
+
+CONTROL_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import bench
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ctl = bench.init_control_plane(rank, world, 0, want="nccl", probe_timeout_s=60.0)   # no GPU here: the RCCL probe must fail on every rank
+    ctl.barrier(0)
+    t = ctl.max_over_ranks(1.0 + rank, 0)
+    sh = ctl.all_gather([float(rank), float(10 + rank)], 0, world)
+    if rank == 0:
+        print(json.dumps({"backend": ctl.backend, "note": ctl.note, "max": t, "shards": sh}))
+    sys.stdout.flush()
+    os._exit(0)
+""") % ROOT
+
+
+def test_control_plane_falls_back_to_gloo_when_rccl_cannot_start(tmp_path):
+    """bench.py's control collectives (barrier, max-over-ranks, shard report): gloo is the default process group, RCCL is probed and the
+    ranks agree over gloo whether every probe succeeded. Without a GPU the probe fails on both ranks: the three calls must run over gloo."""
+    import json
+    script = tmp_path / "ctl_worker.py"
+    script.write_text(CONTROL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    env.pop("VILO_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29537", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["backend"] == "gloo" and "RCCL unavailable" in res["note"]
+    assert res["max"] == 2.0 and res["shards"] == [[0.0, 10.0], [1.0, 11.0]]
+
+
+@pytest.mark.gpu
+def test_bench_py_survives_an_rccl_that_cannot_start():
+    """Two ranks on the ONE GPU of the test box with the default backend: RCCL refuses ("Duplicate GPU detected" — how round 4's only attempt
+    at the nccl leg died). The line must still come out, over gloo, with the contract fields an N > 1 line needs."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29539")
+    env.pop("VILO_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29539", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "64",
+                          "--no-single-window", "--no-strong", "--no-replay", "--no-config3"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_in_process_group"] == 2
+    assert d["control_backend"] == "gloo" and "RCCL unavailable" in d["control_backend_note"]
+    assert d["cpu_baseline"] and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0      # rank 0 times it at N > 1 too
+    assert d["roofline"]["frac"] > 0 and d["parity_sample"]["max_state_err"] < d["parity_sample"]["tolerance"]
