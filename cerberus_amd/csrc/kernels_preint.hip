@@ -121,6 +121,15 @@ __device__ __forceinline__ void load_fv_operands(const double *dFm, const double
 __device__ __forceinline__ double uni_d(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
+// The "blocks ready" rendezvous of a producer / consumer pair. The two roles reach it at different program sites (each inside its own loop
+// over the interval's steps), so it is spelled as what it is, the hardware's arrival-counting s_barrier between workgroup-scope fences,
+// and not as __syncthreads(), whose contract is that all threads reach the same call. Invariant: both roles execute it exactly
+// s_end - si_first times (once a step) before they leave their loops; the kernel is built for gfx950 only.
+__device__ __forceinline__ void pair_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }   // (one wave's LDS operations complete in program order: only the compiler must keep it)
 // The consumer's LDS keeps of the 32 x 32 jacobian / covariance only what the next product reads (the matrices themselves live in its
 // accumulators from one step to the next): the rows K = {3 .. 8, 21 .. 30} as the B operand of dF X[K, :], the columns K of Q as the A
@@ -359,7 +368,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
 #pragma unroll
       for (int r = BLK_ROUNDS_PRODUCER; r < pb::N_BLK_ROUNDS; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
       pb::tail_entry(lane, dt, Ls);
-      __syncthreads();   // this step's dF, V, nd are in LDS
+      pair_barrier();   // this step's dF, V, nd are in LDS
       FvOperands op;
       load_fv_operands(Fm, Vm, nd, op);
       __hip_atomic_store(&fv_taken, ++n_taken, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the loads: LDS is in order)
@@ -535,7 +544,7 @@ __device__ __forceinline__ void preint_imu_leg_body(const vilo_config &cfg, cons
     wave_fence();
 #pragma unroll
     for (int r = 0; r < BLK_ROUNDS_PRODUCER; ++r) pb::block_entry(bdesc[64 * r + lane], pb_ent, Ls);
-    __syncthreads();   // blocks ready: the consumer takes them
+    pair_barrier();   // blocks ready: the consumer takes them
     ++n_built;
 #pragma unroll
     for (int k = 0; k < 10; ++k) smp0[k] = smp1[k];

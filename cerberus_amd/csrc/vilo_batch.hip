@@ -32,6 +32,7 @@ struct vilo_batch {
   // re-propagation buffers (vilo_batch_set_samples): reused by later calls while they are large enough (the arena cannot free)
   vilo_sample *rp_s = nullptr; int *rp_o = nullptr; double *rp_t = nullptr; size_t rp_cap = 0;
   double *rp_ff = nullptr;          // [W * 10][VILO_FF_N]
+  double *rp_ff0 = nullptr;         // the same right after the objects' first integration: what vilo_batch_reset brings back (contact_sensor_type 2)
   vilo_preint *rp_orig = nullptr;   // [W * 10] the records as created, kept from the first vilo_batch_set_samples on
   int n_solves = 0;
   bool graph_failed = false;
@@ -653,6 +654,10 @@ extern "C" int vilo_batch_set_samples(vilo_ctx *ctx, vilo_batch *bt, const vilo_
   if (ctx->cfg.contact_sensor_type == 2) {
     int rc = vilo_repropagate_launch(ctx, D, 2, 0);
     if (rc != VILO_OK) { D.rp_on = 0; return rc; }
+    // a reset batch is the batch as it was after this call: the filter state the first integration left, not the one the last solve's
+    // re-integrations left (reset + solve is then repeatable bit for bit: bench steps, Monte-Carlo restarts, graph replays)
+    if (!bt->rp_ff0) { rc = dev_alloc(ctx, bt, &bt->rp_ff0, n * VILO_FF_N); if (rc != VILO_OK) { D.rp_on = 0; return rc; } }
+    VILO_HIP(hipMemcpyAsync(bt->rp_ff0, bt->rp_ff, sizeof(double) * n * VILO_FF_N, hipMemcpyDeviceToDevice, ctx->stream));
   }
   if (bt->gexec) { (void)hipGraphExecDestroy(bt->gexec); bt->gexec = nullptr; }   // the captured launch sequence changes
   return VILO_OK;
@@ -664,6 +669,8 @@ extern "C" int vilo_batch_reset(vilo_ctx *ctx, vilo_batch *bt) {
   VILO_HIP(hipMemcpyAsync(bt->d.x, bt->d.x0, sizeof(double) * (size_t)bt->W * XSTRIDE, hipMemcpyDeviceToDevice, ctx->stream));
   if (bt->d.n_lm > 0)
     VILO_HIP(hipMemcpyAsync(bt->d.lam, bt->d.lam0, sizeof(double) * (size_t)bt->d.n_lm, hipMemcpyDeviceToDevice, ctx->stream));
+  if (bt->d.rp_on && bt->rp_ff0 && ctx->cfg.contact_sensor_type == 2)   // the contact-force filters of the intervals' objects as set_samples left them
+    VILO_HIP(hipMemcpyAsync(bt->rp_ff, bt->rp_ff0, sizeof(double) * (size_t)bt->W * 10 * VILO_FF_N, hipMemcpyDeviceToDevice, ctx->stream));
   return VILO_OK;
 }
 

@@ -145,14 +145,26 @@ const char *bag_type_md5(int kind) {   // as published with the message packages
     default: return "";
   }
 }
-const char *bag_type_definition(int kind) {   // top-level definitions (rosbag stores them with the dependencies appended; nothing here reads them)
+// Message definitions as rosbag stores them: the top-level text followed by one "MSG: <package>/<type>" section per dependency, separated by
+// lines of 80 '='. rosbag's Python API, rqt_bag and `rostopic echo -b` build the message classes from this text (the md5sums above are what
+// a C++ subscriber checks); the comments of the .msg files are left out, which neither changes the classes nor the md5sums.
+#define VILO_MSG_SEP "================================================================================\n"
+#define VILO_MSG_HEADER VILO_MSG_SEP "MSG: std_msgs/Header\nuint32 seq\ntime stamp\nstring frame_id\n"
+const char *bag_type_definition(int kind) {
   switch (kind) {
     case BAG_IMU:
       return "Header header\ngeometry_msgs/Quaternion orientation\nfloat64[9] orientation_covariance\ngeometry_msgs/Vector3 angular_velocity\n"
-             "float64[9] angular_velocity_covariance\ngeometry_msgs/Vector3 linear_acceleration\nfloat64[9] linear_acceleration_covariance\n";
-    case BAG_JOINT_STATE: return "Header header\nstring[] name\nfloat64[] position\nfloat64[] velocity\nfloat64[] effort\n";
-    case BAG_IMAGE: return "Header header\nuint32 height\nuint32 width\nstring encoding\nuint8 is_bigendian\nuint32 step\nuint8[] data\n";
-    case BAG_POINT_CLOUD: return "Header header\ngeometry_msgs/Point32[] points\nChannelFloat32[] channels\n";
+             "float64[9] angular_velocity_covariance\ngeometry_msgs/Vector3 linear_acceleration\nfloat64[9] linear_acceleration_covariance\n"
+             VILO_MSG_HEADER
+             VILO_MSG_SEP "MSG: geometry_msgs/Quaternion\nfloat64 x\nfloat64 y\nfloat64 z\nfloat64 w\n"
+             VILO_MSG_SEP "MSG: geometry_msgs/Vector3\nfloat64 x\nfloat64 y\nfloat64 z\n";
+    case BAG_JOINT_STATE: return "Header header\nstring[] name\nfloat64[] position\nfloat64[] velocity\nfloat64[] effort\n" VILO_MSG_HEADER;
+    case BAG_IMAGE: return "Header header\nuint32 height\nuint32 width\nstring encoding\nuint8 is_bigendian\nuint32 step\nuint8[] data\n" VILO_MSG_HEADER;
+    case BAG_POINT_CLOUD:
+      return "Header header\ngeometry_msgs/Point32[] points\nChannelFloat32[] channels\n"
+             VILO_MSG_HEADER
+             VILO_MSG_SEP "MSG: geometry_msgs/Point32\nfloat32 x\nfloat32 y\nfloat32 z\n"
+             VILO_MSG_SEP "MSG: sensor_msgs/ChannelFloat32\nstring name\nfloat32[] values\n";
     default: return "";
   }
 }

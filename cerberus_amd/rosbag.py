@@ -262,7 +262,11 @@ def replay(messages, mp, contact_sensor_type=1, imu_topic=IMU_TOPIC, leg_topic=L
             cnt["clouds"] += 1
             t = to_sec(m["secs"], m["nsecs"])
             ch = m["channels"]
+            if len(ch) < 6:
+                raise BagError("%s at %.6f has %d channels: feature_callback reads id, camera_id, p_u, p_v, velocity_x, velocity_y (main.cpp:204-234)" % (topic, t, len(ch)))
             ids_f, cam = ch[0].astype(np.int64), ch[1].astype(np.int64)
+            if len(cam) and (cam.min() < 0 or cam.max() > 1):
+                raise BagError("%s at %.6f: camera_id outside {0, 1}" % (topic, t))
             order, ids, obs, stereo = {}, [], [], []
             for i in range(len(ids_f)):           # featureFrame[feature_id].emplace_back(camera_id, xyz_uv_velocity)
                 fid = int(ids_f[i])
@@ -287,6 +291,9 @@ def replay(messages, mp, contact_sensor_type=1, imu_topic=IMU_TOPIC, leg_topic=L
             ti, tl = to_sec(imu_q[0]["secs"], imu_q[0]["nsecs"]), to_sec(leg_q[0]["secs"], leg_q[0]["nsecs"])
             if abs(ti - tl) < sync_slop:
                 a, j = imu_q.pop(0), leg_q.pop(0)
+                if min(len(j["position"]), len(j["velocity"])) < NUM_DOF + NUM_LEG or (contact_sensor_type == 2 and len(j["effort"]) < NUM_DOF + NUM_LEG):
+                    raise BagError("%s at %.6f carries %d / %d / %d position / velocity / effort entries: the node reads %d joints + %d feet (main.cpp:274-278)"
+                                   % (leg_topic, tl, len(j["position"]), len(j["velocity"]), len(j["effort"]), NUM_DOF, NUM_LEG))
                 s = np.zeros(35)
                 s[1:4], s[4:7] = a["linear_acceleration"], a["angular_velocity"]
                 s[7:19], s[19:31] = j["position"][:NUM_DOF], j["velocity"][:NUM_DOF]

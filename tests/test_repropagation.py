@@ -237,6 +237,15 @@ def test_gpu_solve_with_repropagation_and_the_force_based_contact_model_vs_oracl
         b.set_samples()
         b.solve(opts)
         sg = b.download()[0]
+        first_states = [a.copy() for a in w_g.state_arrays()]
+        # reset + solve again is the same solve, bit for bit: vilo_batch_reset brings back the contact-force filters as the objects' first
+        # integration left them, not as the last solve's re-integrations did
+        b.reset()
+        b.solve(opts)
+        sg_again = b.download()[0]
+        assert sg_again.final_cost == sg.final_cost and list(sg_again.cost_trace[:6]) == list(sg.cost_trace[:6])
+        for a, bb in zip(w_g.state_arrays(), first_states):
+            np.testing.assert_array_equal(a, bb)
     finally:
         b.close()
         ctx2.close()

@@ -178,6 +178,37 @@ def test_lengths_a_damaged_bag_claims_are_never_allocated(tmp_path):
     assert resource.getrlimit(resource.RLIMIT_AS) == (soft, hard)
 
 
+def test_connection_records_carry_the_dependencies_and_the_node_refuses_short_messages(tmp_path):
+    """A connection's message_definition is what rosbag's Python API builds the classes from: the top-level text plus a "MSG:" section per
+    dependency. And the node's logic names what it cannot use (a JointState without the four feet, a feature cloud without its six channels)
+    instead of indexing past the end."""
+    from cerberus_amd import rosbag as rb
+    p = tmp_path / "defs.bag"
+    with rb.BagWriter(p) as w:
+        w.write(dict(kind=rb.KIND_IMU, topic="/imu", seq=0, secs=1, nsecs=0, linear_acceleration=np.zeros(3), angular_velocity=np.zeros(3)))
+        w.write(dict(kind=rb.KIND_JOINT_STATE, topic="/leg", seq=0, secs=1, nsecs=0, position=np.zeros(16), velocity=np.zeros(16), effort=np.zeros(16)))
+        w.write(dict(kind=rb.KIND_POINT_CLOUD, topic="/f", seq=0, secs=1, nsecs=0, points=np.zeros((1, 3), np.float32), channels=np.zeros((6, 1), np.float32),
+                     channel_names=["id", "camera_id", "p_u", "p_v", "velocity_x", "velocity_y"]))
+    raw = p.read_bytes()
+    sep = b"=" * 80 + b"\n"
+    for dep in (b"MSG: std_msgs/Header\nuint32 seq\ntime stamp\nstring frame_id\n", b"MSG: geometry_msgs/Quaternion\nfloat64 x\nfloat64 y\nfloat64 z\nfloat64 w\n",
+                b"MSG: geometry_msgs/Vector3\nfloat64 x\nfloat64 y\nfloat64 z\n", b"MSG: geometry_msgs/Point32\nfloat32 x\nfloat32 y\nfloat32 z\n",
+                b"MSG: sensor_msgs/ChannelFloat32\nstring name\nfloat32[] values\n"):
+        assert sep + dep in raw, dep
+
+    class Sink:
+        def input_sample(self, t, s): pass
+        def input_feature(self, t, ids, obs, stereo): return 0
+        def process(self): return 0
+    imu = dict(kind=rb.KIND_IMU, topic=rb.IMU_TOPIC, seq=0, secs=1, nsecs=0, linear_acceleration=np.zeros(3), angular_velocity=np.zeros(3))
+    short = dict(kind=rb.KIND_JOINT_STATE, topic=rb.LEG_TOPIC, seq=0, secs=1, nsecs=0, position=np.zeros(12), velocity=np.zeros(12), effort=np.zeros(12))
+    with pytest.raises(rb.BagError, match="12 joints"):
+        rb.replay([imu, short], Sink())
+    cloud = dict(kind=rb.KIND_POINT_CLOUD, topic=rb.FEATURE_TOPIC, seq=0, secs=1, nsecs=0, points=np.zeros((1, 3), np.float32), channels=np.zeros((2, 1), np.float32))
+    with pytest.raises(rb.BagError, match="channels"):
+        rb.replay([cloud], Sink())
+
+
 def _records(raw, at, end):
     """top-level records of a bag file: (offset, header fields, data)"""
     out = []
