@@ -75,6 +75,121 @@ __device__ __forceinline__ void sqrt_info_wave(const double *cov, double *U_out,
   }
 }
 
+// Two records per wave, the factor broadcast through LDS (the form k_prepare_preint runs). The register form above leaves half a wave
+// idle (31 rows) and pays two v_readlane per multiply-add; a v_readlane cannot serve two records (one scalar for 64 lanes), an LDS read
+// whose address is uniform per half-wave can. Lanes 0 .. 30 and 32 .. 62 own the rows of two records; L is kept as a packed lower
+// triangle (entry (r, c) at r (r + 1) / 2 + c: 496 doubles per record — triangular numbers are distinct modulo 32, so a column's
+// write has no bank conflict), column j written by its rows and read back by all lanes for the trailing update, and the back
+// substitution of M^-1 reads the rows of the same triangle. Same operands, same order, same sqrt and divisions as sqrt_info_wave:
+// bitwise the same sqrt_info. The covariance is staged through the triangle's own 496 doubles in two passes (16 + 15 source rows).
+__device__ __forceinline__ constexpr int tri_at(int r, int c) { return r * (r + 1) / 2 + c; }
+// (a wave's LDS operations execute in issue order: only the compiler must keep it. The pointer is an operand because a clobber alone does
+// not cover a __shared__ array whose address never escapes)
+__device__ __forceinline__ void lds_order(double *p) { asm volatile("" : : "v"(p) : "memory"); }
+// offset (doubles) in vilo_preint of the e-th of PreintHead's 126 values: the first 33 are the record's own leading scalars in order,
+// the others entries of the Jacobian (fill_preint_head above is the same table as a loop)
+__device__ __forceinline__ int head_src(int e) {
+  if (e < 33) return e;
+  int row, col;
+  if (e < 78) {
+    const int m = (e - 33) / 9, idx = (e - 33) % 9;
+    row = (m < 2 ? 0 : (m == 2 ? 3 : 6)) + idx / 3;
+    col = ((m == 0 || m == 3) ? 21 : 24) + idx % 3;
+  } else if (e < 114) {
+    const int j = (e - 78) / 9, idx = (e - 78) % 9;
+    row = 9 + 3 * j + idx / 3;
+    col = 24 + idx % 3;
+  } else {
+    const int j = (e - 114) / 3;
+    row = 9 + 3 * j + (e - 114) % 3;
+    col = 27 + j;
+  }
+  return 33 + row * 31 + col;
+}
+static_assert(offsetof(vilo_preint, jacobian) == 33 * sizeof(double) && offsetof(vilo::PreintHead, dp_dba) == 33 * sizeof(double), "head_src");
+
+__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
+  constexpr int N = 31, NT = N * (N + 1) / 2, NA = 16 * N /* = NT: the first staging pass takes 16 source rows */;
+  static_assert(NA == NT, "staging passes");
+  __shared__ double Ls[2][NT];
+  const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+  const int f = 2 * blockIdx.x + half;
+  const bool live = f < n && !(skip && skip[f]);
+  const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+  if (!lv) return;
+  const int fs = live ? f : (f ^ 1);   // a half without a record computes along on the other half's and stores nothing
+  const double *src = (const double *)(pre + fs);
+  double *L = Ls[half];
+  if (live) {
+    double *hd = (double *)&out[f].head;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = l + 32 * q;
+      if (e < 126) hd[e] = src[head_src(e)];
+    }
+  }
+  const double *cov = src + (offsetof(vilo_preint, covariance) / sizeof(double));
+  const int row = l < N ? l : N - 1, sr = N - 1 - row;   // lane = row of the index-reversed covariance = source row sr, read backwards
+  double a[N];
+  {
+    double st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = cov[min(l + 32 * q, NT - 1)];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (l + 32 * q < NT) L[l + 32 * q] = st[q];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) st[q] = cov[NT + min(l + 32 * q, N * N - NT - 1)];
+    lds_order(L);
+    if (sr < 16) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) a[j] = L[sr * N + (N - 1 - j)];
+    }
+    lds_order(L);
+#pragma unroll
+    for (int q = 0; q < 15; ++q) if (l + 32 * q < N * N - NT) L[l + 32 * q] = st[q];
+    lds_order(L);
+    if (sr >= 16) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) a[j] = L[(sr - 16) * N + (N - 1 - j)];
+    }
+    lds_order(L);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double p0 = bcast_lane(a[j], j), p1 = bcast_lane(a[j], 32 + j);
+    double piv = half ? p1 : p0;
+    if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
+    const double d = sqrt(piv);
+    const double lj = (row == j) ? d : a[j] / d;
+    if (l < N && l >= j) L[tri_at(row, j)] = lj;
+    lds_order(L);
+#pragma unroll
+    for (int q = j + 1; q < N; ++q) {
+      a[q] -= lj * L[tri_at(q, j)];
+      asm volatile("" : "+v"(a[q]));   // (here and now: left to itself the compiler sinks every column's update to where the entry is next read — a left-looking loop with all of L in registers)
+    }
+    lds_order(L);
+  }
+  if (bad && live && l == 0) status[per_record ? f : 0] = 1;
+  // M(i,k) = L(N-1-i, N-1-k) (upper). Column c = lane of U = M^-1 by back substitution, as in sqrt_info_wave
+  double u[N];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[tri_at(N - 1 - i, N - 1 - k)] * u[k];
+    double v = s / L[tri_at(N - 1 - i, N - 1 - i)];
+    asm volatile("" : "+v"(v) : "v"(L) : "memory");   // (the next row's reads stay behind this row's arithmetic: hoisted together they spill)
+    u[i] = (i <= l) ? v : 0.0;
+  }
+  if (live && l < N) {
+    double *U_out = out[f].sqrt_info;
+#pragma unroll
+    for (int i = 0; i < N; ++i) U_out[i * N + l] = u[i];
+  }
+}
+
 // The reference's route taken literally (imu_leg_factor.cpp:197-198: LLT(covariance.inverse()).matrixL().transpose()): the inverse by
 // Gauss-Jordan elimination with partial pivoting (what Eigen's inverse() does for a 31 x 31 matrix up to the elimination order), then the
 // lower Cholesky factor of it, transposed. The covariance has a condition number of 1e13 .. 1e14, so this route carries ~1e-5 of relative
@@ -141,14 +256,6 @@ __device__ void sqrt_info_literal_wave(const double *cov, double *U_out, double 
 // "covariance not positive definite" flag goes to status[f] instead of status[0], so that a batch can fail the one window it concerns.
 // (the literal route is a kernel of its own: it needs two LDS matrices, the default one a single staging copy — 8 KB instead of 16 KB
 // per wave lets the register file, not LDS, set the occupancy)
-__global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
-  __shared__ double R[31 * 32];
-  const int f = blockIdx.x;
-  if (f >= n || (skip && skip[f])) return;
-  const vilo_preint &p = pre[f];
-  if (threadIdx.x == 0) fill_preint_head(p, out[f].head);
-  sqrt_info_wave<31>(p.covariance, out[f].sqrt_info, R, nullptr, status + (per_record ? f : 0));
-}
 __global__ void __launch_bounds__(64) k_prepare_preint_literal(int n, const vilo_preint *pre, PreintPrepared *out, int *status, const unsigned char *skip, int per_record) {
   __shared__ double R[31 * 32], Ub[31 * 32];
   const int f = blockIdx.x;
@@ -172,7 +279,7 @@ __global__ void __launch_bounds__(64) k_prepare_preint_imu(int n, const vilo_pre
 int vilo_launch_prepare_preint(vilo_ctx *ctx, int n, const vilo_preint *d_pre, PreintPrepared *d_out, int *d_status, const unsigned char *d_skip, int per_record) {
   if (n <= 0) return VILO_OK;
   if (ctx->sqrt_info_mode) hipLaunchKernelGGL(k_prepare_preint_literal, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
-  else hipLaunchKernelGGL(k_prepare_preint, dim3(n), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
+  else hipLaunchKernelGGL(k_prepare_preint, dim3((n + 1) / 2), dim3(64), 0, ctx->stream, n, d_pre, d_out, d_status, d_skip, per_record);
   VILO_HIP(hipGetLastError());
   return VILO_OK;
 }

@@ -571,9 +571,18 @@ extern "C" int vilo_batch_prepare(vilo_ctx *ctx, vilo_batch *bt) {
   VILO_HIP(hipSetDevice(ctx->device));
   BatchDev &D = bt->d;
   VILO_HIP(hipMemsetAsync(bt->d_prep_bad, 0, sizeof(int) * (size_t)bt->W * 10, ctx->stream));
+  const bool timed = ctx->profile == 1 || ctx->profile == 2 + 11;   // (kind 11 = k_prepare_preint, vilo_kernel_name)
+  if (timed) {
+    for (hipEvent_t &e : ctx->prep_ev) if (!e) VILO_HIP(hipEventCreate(&e));
+    VILO_HIP(hipEventRecord(ctx->prep_ev[0], ctx->stream));
+  }
   int rc = bt->leg ? vilo_launch_prepare_preint(ctx, bt->W * 10, (const vilo_preint *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1)
                    : vilo_launch_prepare_preint_imu(ctx, bt->W * 10, (const vilo_preint_imu *)bt->d_pre, D.prep, bt->d_prep_bad, D.imu_skip, 1);
   if (rc == VILO_OK && !bt->leg) rc = vilo_launch_embed_sqrt15(ctx, D);
+  if (timed) {
+    VILO_HIP(hipEventRecord(ctx->prep_ev[1], ctx->stream));
+    ctx->prep_pending = true;
+  }
   return rc;
 }
 
@@ -708,6 +717,11 @@ extern "C" int vilo_batch_solve(vilo_ctx *ctx, vilo_batch *bt, const vilo_solve_
   float ms = 0.f;
   VILO_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_solve_ms = ms;
+  if (ctx->prep_pending) {   // (recorded on this stream before ev1: complete)
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ctx->prep_ev[0], ctx->prep_ev[1]) == hipSuccess) { ctx->kernel_ms[11] += t; ctx->kernel_launches[11] += 1; }
+    ctx->prep_pending = false;
+  }
   if (ctx->profile) {
     for (size_t i = 0; i < ctx->pev_kind.size(); ++i) {
       float t = 0.f;

@@ -75,6 +75,7 @@ extern "C" void vilo_destroy(vilo_ctx *ctx) {
   for (auto &c : ctx->pool_free) (void)hipFree(c.first);
   for (auto &h : ctx->host_stage) free(h.first);
   for (hipEvent_t e : ctx->pev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->prep_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);

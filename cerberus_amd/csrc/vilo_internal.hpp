@@ -37,6 +37,8 @@ struct vilo_ctx {
   int profile;
   std::vector<hipEvent_t> pev;      // event pool
   std::vector<int> pev_kind;        // kernel kind of interval i = [pev[2i], pev[2i+1]]
+  hipEvent_t prep_ev[2] = {nullptr, nullptr};   // around vilo_batch_prepare's launch (kind 11), read with the next solve's intervals
+  bool prep_pending = false;
   double kernel_ms[VILO_NKERNEL];
   long long kernel_launches[VILO_NKERNEL];
   double initial_mu = 1e-8;         // DoglegStrategy's mu at the start of a solve (Ceres: min_mu; vilo_debug_set_initial_mu: per-step comparisons with the oracle)
