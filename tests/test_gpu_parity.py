@@ -62,6 +62,34 @@ def test_eval_imu_leg_and_imu(ctx, ocfg, small_window):
             assert _rel(Js[b][k], J_o[b]) < 1e-8, ("imu J", k, b)
 
 
+def test_sqrt_info_does_not_depend_on_the_records_wave_partner(ctx, small_window):
+    """k_prepare_preint factors two records per wave (lanes 0 .. 30 and 32 .. 62). A record's sqrt_info — seen through the whitened
+    residual and Jacobians — must be the same bit for bit alone in a wave (n = 1, the last record of an odd count), as the first or the
+    second of a pair, and next to a partner whose covariance is not positive definite (which alone must fail the call)."""
+    from cerberus_amd import api
+    w = small_window
+    P = [w.pose[:-1], w.speed_bias[:-1], w.leg_bias[:-1], w.pose[1:], w.speed_bias[1:], w.leg_bias[1:]]
+    r_all, J_all = ctx.eval_imu_leg(w.preint, P)
+
+    def sub(idx):
+        return ctx.eval_imu_leg(w.preint[idx], [p[idx] for p in P])
+
+    for idx in ([0], [3], [9], [0, 1, 2], [1, 2, 3], [9, 4, 7, 2, 5], [2, 2]):
+        r, Js = sub(idx)
+        for q, k in enumerate(idx):
+            np.testing.assert_array_equal(r[q], r_all[k], err_msg="records %s, position %d" % (idx, q))
+            for b in range(6):
+                np.testing.assert_array_equal(Js[b][q], J_all[b][k])
+    bad = w.preint.copy()
+    bad[1, 33 + 961 + 5 * 31 + 5] = -1.0   # vilo_preint: 33 scalars, jacobian, covariance; a negative diagonal entry
+    with pytest.raises(api.ViloError, match="positive definite"):
+        ctx.eval_imu_leg(bad[:3], [p[:3] for p in P])
+    with pytest.raises(api.ViloError, match="positive definite"):
+        ctx.eval_imu_leg(bad[1:2], [p[1:2] for p in P])
+    r, _ = ctx.eval_imu_leg(bad[2:5], [p[2:5] for p in P])
+    np.testing.assert_array_equal(r, r_all[2:5])
+
+
 def test_eval_prior_and_pose_plus(ctx, small_window):
     w = small_window
     rng = np.random.default_rng(3)
