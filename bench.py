@@ -619,11 +619,17 @@ def main():
         return {lib.vilo_kernel_name(i).decode(): {"ms_total": ms[i], "launches": int(launches[i]), "avg_ms": ms[i] / max(1, launches[i])} for i in range(nk)}
 
     lib.vilo_set_profiling(ctx.h, 1)
-    for _ in range(args.warmup):
+    warm_counted = args.warmup
+    for wi in range(args.warmup):
         batch.reset()
         if not rp:
             batch.prepare()
         batch.solve(opts)
+        if wi == 0 and args.warmup >= 2:
+            # a kernel's first launch in a process carries the loading of its code (milliseconds in front of k_init_state, the first
+            # kernel of a solve): the table is taken over the warm-up steps behind the first
+            lib.vilo_set_profiling(ctx.h, 1)
+            warm_counted = args.warmup - 1
     kern_warm = kernel_table() if args.warmup > 0 else None
     dom_kind = None
     if kern_warm:
@@ -656,7 +662,7 @@ def main():
         v["steps"] = args.steps
     if kern_warm:
         for v in kern_warm.values():
-            v["steps"] = args.warmup
+            v["steps"] = warm_counted
         kern = dict(kern_warm)
         kern[dom_name] = kern_timed[dom_name]
     else:
@@ -780,7 +786,7 @@ def main():
                                                  for k in it_kernels if k in ev["pmc"]} if ev["pmc"] else None)},
             "kernels": kern,
             "kernels_note": "HIP events on the solver's stream; `steps` = the steps an entry was measured over: the dominant kernel over the timed steps, "
-                            "the others over the warm-up steps (the timed steps carry the dominant kernel's event pairs only)",
+                            "the others over the warm-up steps behind the first, which carries the kernels' code loading (the timed steps carry the dominant kernel's event pairs only)",
             "gpu_ms_per_step": gpu_ms / args.steps, "setup_s": setup_s, "mean_final_cost": final_cost,
         }
         if strong:
