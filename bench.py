@@ -74,8 +74,8 @@ STRONG_TOTAL = 1024   # BASELINE configs[3]
 
 
 def profile_evidence(W_run, tag=""):
-    """Counter evidence of the committed rocprofv3 passes (tools/profile_gpu.sh, tools/profile_sq.sh; measured at 4096 windows per
-    dispatch): calibrated HBM bytes per dispatch and the matrix-core busy fraction per kernel. Per-window figures, so they scale."""
+    """Counter evidence of the committed rocprofv3 passes (tools/profile_gpu.sh, tools/profile_sq.sh; `windows_per_dispatch` of the
+    file says at which batch size): calibrated HBM bytes per dispatch and the matrix-core busy fraction per kernel. Per-window figures, so they scale."""
     out = {"pmc": None, "mfma": None}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc%s.json" % (PROFILE_ROUND, tag))))
@@ -599,6 +599,10 @@ def main():
             b.set_samples()   # samples resident: every iteration integrates the intervals again at the point it linearises
         return b
     batch = make_batch(ctx, windows)
+    # the batch is resident: of the host copies only the first 256 windows are read again (parity sample, marginalisation timing, the
+    # single window) — 0.5 MB per window that 8 ranks x 32 768 windows would otherwise hold on one host
+    for w in windows[256:]:
+        w.release_inputs()
     setup_s = time.perf_counter() - t0
     opts = api.default_solve_opts(fixed_iterations=True, max_num_iterations=ITERS)
     lib = api.lib()

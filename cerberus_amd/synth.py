@@ -108,6 +108,13 @@ class Window:
         # |Vs[0]| > 0.2), ESTIMATE_TD=0 (td constant), OPTIMIZE_LEG_BIAS=1 (estimator.cpp:1074-1105)
         self.leg_bias_const, self.ex_const, self.td_const = 0, 0, 1
 
+    def release_inputs(self):
+        """Drop the host arrays a device batch has copied (observations, samples, preintegration records, prior): what stays is what
+        `Batch.download` writes into (the state arrays) and the scalars. For harnesses that keep tens of thousands of windows resident."""
+        self.obs = self.obs_is_stereo = self.samples = self.preint = self.preint_imu = None
+        self.prior = None
+        self.truth_pose = self.truth_speed_bias = self.truth_leg_bias = self.truth_inv_depth = None
+
     def state_arrays(self):
         return [self.pose, self.speed_bias, self.leg_bias, self.ex_pose, self.td, self.inv_depth]
 
