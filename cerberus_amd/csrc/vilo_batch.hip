@@ -90,6 +90,38 @@ int dev_upload_raw(vilo_ctx *ctx, vilo_batch *bt, T **p, const T *h, size_t n) {
   if (n) VILO_HIP(hipMemcpy(*p, h, n * sizeof(T), hipMemcpyHostToDevice));
   return VILO_OK;
 }
+// The tables of a batch are a dozen and a half small arrays: uploaded one by one, a window's batch pays a blocking copy for each (what a
+// frame-by-frame caller pays per image). They are laid out in ONE host blob at the offsets of one device allocation and go up in one copy;
+// the device pointers are set when the blob is flushed (nothing may read them before). Arrays of 256 KB and more keep their own copy
+// straight from the caller's memory.
+struct UploadBlob {
+  struct Item { void **pp; size_t off; };
+  std::vector<char> host;
+  std::vector<Item> items;
+  template <class T>
+  int add(vilo_ctx *ctx, vilo_batch *bt, T **p, const T *h, size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= ((size_t)256 << 10)) return dev_upload_raw(ctx, bt, p, h, n);
+    const size_t off = (host.size() + 255) & ~(size_t)255;
+    host.resize(off + std::max<size_t>(bytes, sizeof(T)));
+    if (bytes) memcpy(host.data() + off, h, bytes);
+    *p = nullptr;
+    items.push_back({(void **)p, off});
+    return VILO_OK;
+  }
+  template <class T>
+  int add(vilo_ctx *ctx, vilo_batch *bt, T **p, const std::vector<T> &h) { return add(ctx, bt, p, h.data(), h.size()); }
+  int flush(vilo_ctx *ctx, vilo_batch *bt) {
+    if (items.empty()) return VILO_OK;
+    void *base = nullptr;
+    int rc = dev_alloc_bytes(ctx, bt, &base, host.size());
+    if (rc != VILO_OK) return rc;
+    VILO_HIP(hipMemcpy(base, host.data(), host.size(), hipMemcpyHostToDevice));
+    for (const Item &it : items) *it.pp = (char *)base + it.off;
+    items.clear(); host.clear();
+    return VILO_OK;
+  }
+};
 #define TRYB(x) do { int rc_ = (x); if (rc_ != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc_; } } while (0)
 
 
@@ -394,9 +426,10 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   D.compact = ctx->compact_rows;
   for (int w = 0; w < W; ++w)
     if (!(wins[w].const_mask & CONST_TD)) D.compact = 0;
-  TRYB(dev_upload(ctx, bt, &D.win, wins));
-  TRYB(dev_upload(ctx, bt, &D.chunk, chunks));
-  TRYB(dev_upload(ctx, bt, &D.wave, waves));
+  UploadBlob blob;
+  TRYB(blob.add(ctx, bt, &D.win, wins));
+  TRYB(blob.add(ctx, bt, &D.chunk, chunks));
+  TRYB(blob.add(ctx, bt, &D.wave, waves));
   {
     // launch order of the packed waves: by decreasing number of frames walked. A single-wave workgroup can only start on the SIMD the
     // dispatcher's cyclic pointer names, so waves of mixed length in flight on one CU leave SIMDs idle behind a long one (measured: 2.7
@@ -415,14 +448,14 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
         g0 = g1; ++gi;
       }
     }
-    TRYB(dev_upload(ctx, bt, &D.wave_order, order));
+    TRYB(blob.add(ctx, bt, &D.wave_order, order));
   }
-  TRYB(dev_upload_raw(ctx, bt, &D.obs, obs, obs_total));
-  TRYB(dev_upload_raw(ctx, bt, &D.flags, flags, flags_total));
-  TRYB(dev_upload(ctx, bt, &D.x0, x0));
-  TRYB(dev_upload(ctx, bt, &D.lam0, lam0));
-  TRYB(dev_upload(ctx, bt, &D.lm_s, lm_s));
-  TRYB(dev_upload(ctx, bt, &D.lm_perm, bt->perm_host));
+  TRYB(blob.add(ctx, bt, &D.obs, obs, obs_total));
+  TRYB(blob.add(ctx, bt, &D.flags, flags, flags_total));
+  TRYB(blob.add(ctx, bt, &D.x0, x0));
+  TRYB(blob.add(ctx, bt, &D.lam0, lam0));
+  TRYB(blob.add(ctx, bt, &D.lm_s, lm_s));
+  TRYB(blob.add(ctx, bt, &D.lm_perm, bt->perm_host));
   TRYB(dev_alloc(ctx, bt, &D.x, (size_t)W * XSTRIDE));
   TRYB(dev_alloc(ctx, bt, &D.xc, (size_t)W * XSTRIDE));
   TRYB(dev_alloc(ctx, bt, &D.lam, (size_t)lm_total));
@@ -448,25 +481,26 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
   TRYB(dev_alloc(ctx, bt, &D.imu_lin, (size_t)W * 10 * 31 * 39));
   TRYB(dev_alloc(ctx, bt, &D.imu_raw, (size_t)W * 10 * 31 * 39));
-  if (hipMemset(D.imu_raw, 0, sizeof(double) * (size_t)W * 10 * 31 * 39) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
+  if (hipMemsetAsync(D.imu_raw, 0, sizeof(double) * (size_t)W * 10 * 31 * 39, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   TRYB(dev_alloc(ctx, bt, &D.imu_gram, (size_t)W * 10 * 780));
   TRYB(dev_alloc(ctx, bt, &D.imu_cost, (size_t)W * 10));
-  TRYB(dev_upload(ctx, bt, &D.imu_skip, iskip));
+  TRYB(blob.add(ctx, bt, &D.imu_skip, iskip));
   TRYB(dev_alloc(ctx, bt, &D.prior_H, (size_t)W * 96 * 96));
   TRYB(dev_alloc(ctx, bt, &D.prior_dense, (size_t)W * PD_N));
   TRYB(dev_alloc(ctx, bt, &D.prior_hd, (size_t)W * 96));
   TRYB(dev_alloc(ctx, bt, &D.prior_b0, (size_t)W * 96));
   TRYB(dev_alloc(ctx, bt, &D.prior_c0, (size_t)W));
-  TRYB(dev_upload(ctx, bt, &D.prior_x0, px0));
-  TRYB(dev_upload(ctx, bt, &D.prior_map, pmap));
+  TRYB(blob.add(ctx, bt, &D.prior_x0, px0));
+  TRYB(blob.add(ctx, bt, &D.prior_map, pmap));
   if (hipMemsetAsync(D.prior_dense, 0, sizeof(double) * (size_t)W * PD_N, ctx->stream) != hipSuccess ||
       hipMemsetAsync(D.prior_b0, 0, sizeof(double) * (size_t)W * 96, ctx->stream) != hipSuccess ||
       hipMemsetAsync(D.prior_c0, 0, sizeof(double) * (size_t)W, ctx->stream) != hipSuccess ||
       hipMemsetAsync(D.prior_H, 0, sizeof(double) * (size_t)W * 96 * 96, ctx->stream) != hipSuccess) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
-  TRYB(dev_upload(ctx, bt, &D.prior_bsize, pbs));
-  TRYB(dev_upload(ctx, bt, &D.prior_bidx, pbi));
-  TRYB(dev_upload(ctx, bt, &D.prior_bxoff, pbx));
-  TRYB(dev_upload(ctx, bt, &D.prior_bstate, pbst));
+  TRYB(blob.add(ctx, bt, &D.prior_bsize, pbs));
+  TRYB(blob.add(ctx, bt, &D.prior_bidx, pbi));
+  TRYB(blob.add(ctx, bt, &D.prior_bxoff, pbx));
+  TRYB(blob.add(ctx, bt, &D.prior_bstate, pbst));
+  TRYB(blob.flush(ctx, bt));   // D.win ... D.prior_bstate are device pointers from here on
   TRYB(dev_alloc(ctx, bt, &D.cam_g, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_dh2, (size_t)W * CD_N));
   TRYB(dev_alloc(ctx, bt, &D.cam_y, (size_t)W * CD_N));
@@ -480,7 +514,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   TRYB(dev_alloc(ctx, bt, &D.st, (size_t)W));
   TRYB(dev_alloc(ctx, bt, &D.status, 1));
   TRYB(dev_alloc(ctx, bt, &D.lin_cur, (size_t)W));
-  if (hipMemset(D.status, 0, sizeof(int)) != hipSuccess || hipMemset(D.st, 0, sizeof(SolverState) * (size_t)W) != hipSuccess) {
+  if (hipMemsetAsync(D.status, 0, sizeof(int), ctx->stream) != hipSuccess || hipMemsetAsync(D.st, 0, sizeof(SolverState) * (size_t)W, ctx->stream) != hipSuccess) {
     vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP;
   }
   if (any_prior) {
