@@ -1,5 +1,6 @@
 // See vilo_sensor_buffer.h.
 #include "vilo_sensor_buffer.h"
+#include <chrono>
 
 #include <cstring>
 
@@ -81,15 +82,30 @@ extern "C" {
 using vilo::MeasurementProcessor;
 void *vilo_mp_create(void *sw) { return new MeasurementProcessor((vilo::SlidingWindow *)sw); }
 void vilo_mp_destroy(void *h) { delete (MeasurementProcessor *)h; }
-void vilo_mp_input_imu(void *h, double t, const double *acc, const double *gyr) { ((MeasurementProcessor *)h)->inputIMU(t, acc, gyr); }
-void vilo_mp_input_leg(void *h, double t, const double *phi, const double *dphi, const double *c) { ((MeasurementProcessor *)h)->inputLeg(t, phi, dphi, c); }
+namespace {
+struct Busy {   // adds the time of one entry point to the processor's account
+  MeasurementProcessor *p;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit Busy(void *h) : p((MeasurementProcessor *)h) {}
+  ~Busy() { p->busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+void vilo_mp_input_imu(void *h, double t, const double *acc, const double *gyr) { Busy b(h); b.p->inputIMU(t, acc, gyr); }
+void vilo_mp_input_leg(void *h, double t, const double *phi, const double *dphi, const double *c) { Busy b(h); b.p->inputLeg(t, phi, dphi, c); }
+void vilo_mp_input_sample(void *h, double t, const double *row35) {
+  Busy b(h);
+  b.p->inputIMU(t, row35 + 1, row35 + 4);
+  b.p->inputLeg(t, row35 + 7, row35 + 19, row35 + 31);
+}
 int vilo_mp_input_feature(void *h, double t, int n, const int *ids, const double *obs11, const uint8_t *stereo) {
+  Busy b(h);
   vilo::FeatureFrame f;
   f.t = t;
   f.ids.assign(ids, ids + n); f.obs11.assign(obs11, obs11 + 11 * (size_t)n); f.stereo.assign(stereo, stereo + n);
-  return ((MeasurementProcessor *)h)->inputFeature(f);
+  return b.p->inputFeature(f);
 }
-int vilo_mp_process(void *h) { return ((MeasurementProcessor *)h)->processMeasurements(); }
+int vilo_mp_process(void *h) { Busy b(h); return b.p->processMeasurements(); }
+double vilo_mp_busy_ms(void *h) { return 1e-6 * (double)((MeasurementProcessor *)h)->busy_ns; }
 int vilo_mp_queue_size(void *h) { return (int)((MeasurementProcessor *)h)->buf.size(); }
 int vilo_mp_last_interval(void *h, vilo_sample *out, int max_n) {
   const std::vector<vilo_sample> &v = ((MeasurementProcessor *)h)->last_interval;

@@ -63,6 +63,7 @@ class MeasurementProcessor {
   SlidingWindow *est;
   double prevTime = -1.0, curTime = 0.0;   // clearState :43-44
   std::vector<vilo_sample> last_interval;  // the samples handed to processIMULeg for the newest image (dt filled in)
+  long long busy_ns = 0;                   // wall time spent inside the C entry points below (vilo_mp_busy_ms): what a C++ node pays per message
 };
 
 }  // namespace vilo
@@ -78,5 +79,9 @@ int vilo_mp_input_feature(void *h, double t, int n, const int *ids, const double
 int vilo_mp_process(void *h);
 // introspection for tests: queue length, and the samples (with dt) of the newest processed interval
 int vilo_mp_queue_size(void *h);
+// wall time spent so far inside vilo_mp_input_imu / _input_leg / _input_sample / _input_feature / _process of this processor (ms)
+double vilo_mp_busy_ms(void *h);
+// one sample row as the synthetic stream lays it out (vilo_sample: dt acc gyr phi dphi c): inputIMU + inputLeg with one call
+void vilo_mp_input_sample(void *h, double t, const double *row35);
 int vilo_mp_last_interval(void *h, vilo_sample *out, int max_n);
 }

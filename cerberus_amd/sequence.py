@@ -171,6 +171,9 @@ class MeasurementProcessor:
         self.H.vilo_mp_input_imu.argtypes = [C.c_void_p, C.c_double, T.c_double_p, T.c_double_p]
         self.H.vilo_mp_input_leg.argtypes = [C.c_void_p, C.c_double, T.c_double_p, T.c_double_p, T.c_double_p]
         self.H.vilo_mp_input_feature.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.H.vilo_mp_input_sample.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        self.H.vilo_mp_busy_ms.argtypes = [C.c_void_p]
+        self.H.vilo_mp_busy_ms.restype = C.c_double
         self.H.vilo_mp_queue_size.argtypes = [C.c_void_p]
         self.H.vilo_mp_process.argtypes = [C.c_void_p]
         self.H.vilo_mp_last_interval.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -179,8 +182,12 @@ class MeasurementProcessor:
     def input_sample(self, t, sample):
         """sample: one row of the Stream's sample array (dt ignored: the processor derives it from the stamps)"""
         s = np.ascontiguousarray(sample, np.float64)
-        self.H.vilo_mp_input_imu(self.h, t, _dp(s[1:4]), _dp(s[4:7]))
-        self.H.vilo_mp_input_leg(self.h, t, _dp(s[7:19]), _dp(s[19:31]), _dp(s[31:35]))
+        assert s.size == T.SAMPLE_DOUBLES
+        self.H.vilo_mp_input_sample(self.h, t, s.ctypes.data)   # = inputIMU(acc, gyr) + inputLeg(phi, dphi, c)
+
+    def busy_ms(self):
+        """wall time spent inside this processor's C entry points so far (message intake, preintegration, solve, marginalisation, slide)"""
+        return float(self.H.vilo_mp_busy_ms(self.h))
 
     def input_feature(self, t, ids, obs, stereo):
         ids, obs, stereo = np.ascontiguousarray(ids, np.int32), np.ascontiguousarray(obs), np.ascontiguousarray(stereo, np.uint8)

@@ -66,7 +66,10 @@ def test_interval_extraction_and_dt(cfg):
     for f, tp in ((fa, t_prev), (fb, fa["header"])):
         for t, s in zip(_stamps(f, tp), f["samples"]):
             mp.input_sample(t, s)
+    b0 = mp.busy_ms()
     assert mp.process() == 2 and sw.state()["frame_count"] == 9
+    # the processor keeps the account of the wall time spent inside its entry points (bench.py's replay figure)
+    assert 0.0 < b0 < mp.busy_ms() < 1e4
 
 
 @pytest.mark.gpu
