@@ -149,21 +149,21 @@ class BagReader:
             raise StopIteration
         if rc < 0:
             raise BagError(self.ERRORS.get(rc, rc))
-        m = dict(kind=o.kind, topic=o.topic.decode(), type=o.type.decode(), seq=o.seq, secs=o.secs, nsecs=o.nsecs, rec_secs=o.rec_secs, rec_nsecs=o.rec_nsecs,
-                 frame_id=o.frame_id.decode())
+        m = dict(kind=o.kind, topic=o.topic.decode("utf-8", "replace"), type=o.type.decode("utf-8", "replace"), seq=o.seq, secs=o.secs, nsecs=o.nsecs, rec_secs=o.rec_secs, rec_nsecs=o.rec_nsecs,
+                 frame_id=o.frame_id.decode("utf-8", "replace"))
         if o.kind == KIND_IMU:
             m.update(orientation=np.array(o.orientation), angular_velocity=np.array(o.angular_velocity), linear_acceleration=np.array(o.linear_acceleration))
         elif o.kind == KIND_JOINT_STATE:
             m.update(position=np.array(o.position[:min(o.n_position, 32)]), velocity=np.array(o.velocity[:min(o.n_velocity, 32)]),
                      effort=np.array(o.effort[:min(o.n_effort, 32)]))
         elif o.kind == KIND_IMAGE:
-            m.update(height=o.height, width=o.width, step=o.step, encoding=o.encoding.decode(), is_bigendian=o.is_bigendian,
+            m.update(height=o.height, width=o.width, step=o.step, encoding=o.encoding.decode("utf-8", "replace"), is_bigendian=o.is_bigendian,
                      data=np.ctypeslib.as_array(o.data, (o.data_len,)).copy() if o.data_len else np.zeros(0, np.uint8))
         elif o.kind == KIND_POINT_CLOUD:
             n, nc = o.n_points, o.n_channels
             m.update(points=np.ctypeslib.as_array(o.points, (n, 3)).copy() if n else np.zeros((0, 3), np.float32),
                      channels=np.ctypeslib.as_array(o.channels, (nc, n)).copy() if n * nc else np.zeros((nc, 0), np.float32),
-                     channel_names=[o.channel_names[c].value.decode() for c in range(min(nc, 16))])
+                     channel_names=[o.channel_names[c].value.decode("utf-8", "replace") for c in range(min(nc, 16))])
         return m
 
     def close(self):

@@ -178,6 +178,77 @@ def test_lengths_a_damaged_bag_claims_are_never_allocated(tmp_path):
     assert resource.getrlimit(resource.RLIMIT_AS) == (soft, hard)
 
 
+@pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
+def test_mutated_bags_end_in_messages_or_an_error(tmp_path, compression):
+    """A bag is untrusted input: 300 random mutations of a valid file (bytes overwritten, runs zeroed or set to 0xff, truncations, a
+    length field multiplied) are read to the end. Every one must give messages or a BagError — no crash, no hang, and no allocation
+    beyond a few times the file (an address-space limit is in force while reading)."""
+    import resource
+    from cerberus_amd import rosbag as rb
+    p = tmp_path / "ok.bag"
+    rng = np.random.default_rng(20260926)
+    with rb.BagWriter(p, compression=compression, chunk_threshold=2048) as w:
+        for i in range(12):
+            w.write(dict(kind=rb.KIND_IMU, topic="/imu", seq=i, secs=1, nsecs=i, linear_acceleration=rng.normal(size=3), angular_velocity=rng.normal(size=3)))
+            w.write(dict(kind=rb.KIND_JOINT_STATE, topic="/leg", seq=i, secs=1, nsecs=i, position=rng.normal(size=16), velocity=rng.normal(size=16), effort=rng.normal(size=16)))
+        w.write(dict(kind=rb.KIND_POINT_CLOUD, topic="/f", seq=0, secs=1, nsecs=50, points=rng.normal(size=(5, 3)).astype(np.float32),
+                     channels=rng.normal(size=(6, 5)).astype(np.float32), channel_names=["id", "camera_id", "p_u", "p_v", "velocity_x", "velocity_y"]))
+    raw = bytearray(p.read_bytes())
+    n_ok = len(list(rb.BagReader(p)))
+    assert n_ok == 25
+    soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+    outcomes = {"messages": 0, "error": 0}
+    q = tmp_path / "mut.bag"
+    try:
+        for it in range(300):
+            b = bytearray(raw)
+            kind = it % 5
+            at = int(rng.integers(0, len(b)))
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 8))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[at:at + int(rng.integers(1, 64))] = b"\x00" * min(int(rng.integers(1, 64)), len(b) - at)
+            elif kind == 2:
+                n = min(int(rng.integers(1, 16)), len(b) - at)
+                b[at:at + n] = b"\xff" * n
+            elif kind == 3:
+                b = b[:max(14, at)]
+            else:
+                at = min(at, len(b) - 4)
+                v = struct.unpack_from("<I", b, at)[0]
+                struct.pack_into("<I", b, at, (v * int(rng.integers(2, 1 << 16))) & 0xFFFFFFFF)
+            q.write_bytes(bytes(b))
+            # (the limit is set per read and lifted again: pytest itself may need more than the reader is allowed)
+            used = 0
+            try:
+                with open("/proc/self/statm") as f:
+                    used = int(f.read().split()[0]) * resource.getpagesize()
+            except OSError:
+                pass
+            if used:
+                resource.setrlimit(resource.RLIMIT_AS, (used + (512 << 20), hard))
+            try:
+                msgs = list(rb.BagReader(q))
+                outcomes["messages"] += 1
+                assert len(msgs) <= n_ok + 2
+            except rb.BagError:
+                outcomes["error"] += 1
+            finally:
+                resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+    finally:
+        resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+    assert outcomes["messages"] + outcomes["error"] == 300 and outcomes["error"] > 30, outcomes
+    if compression == "none":
+        # text fields are bytes from the file too: a channel name that is not UTF-8 comes back with a replacement character
+        b = bytearray(raw)
+        at = bytes(b).rindex(b"velocity_x")   # (the cloud is the last message of the file)
+        b[at + 3] = 0xa2
+        q.write_bytes(bytes(b))
+        names = [m["channel_names"] for m in rb.BagReader(q) if m["kind"] == rb.KIND_POINT_CLOUD]
+        assert len(names) == 1 and names[0][4] == "vel\ufffdcity_x"
+
+
 def test_connection_records_carry_the_dependencies_and_the_node_refuses_short_messages(tmp_path):
     """A connection's message_definition is what rosbag's Python API builds the classes from: the top-level text plus a "MSG:" section per
     dependency. And the node's logic names what it cannot use (a JointState without the four feet, a feature cloud without its six channels)
