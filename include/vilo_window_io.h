@@ -111,12 +111,17 @@ static int vilo_window_read(const char *path, vilo_window_file *wf) {
   char magic[8];
   int32_t hdr[16];
   int rc, F, L;
+  long fsz;
   memset(wf, 0, sizeof *wf);
   if (!f) return -1;
+  if (fseek(f, 0, SEEK_END) != 0 || (fsz = ftell(f)) < 0 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return -1; }
   rc = vilo__r(f, magic, 8) | vilo__r(f, hdr, sizeof hdr);
   if (rc || memcmp(magic, "VILOWIN1", 8) != 0 || hdr[0] != 1 || hdr[11] != (int32_t)sizeof(vilo_config)) { fclose(f); return -2; }
   F = hdr[1]; L = hdr[2];
   if (F < 2 || F > VILO_MAX_FRAMES || L < 0 || hdr[3] < 0) { fclose(f); return -2; }
+  /* a dump is untrusted input: the counts it states are bounded by what the file can hold (16 bytes per landmark, 89 per observation)
+     before anything is allocated for them */
+  if ((uint64_t)L * 16u + (uint64_t)hdr[3] * 89u > (uint64_t)fsz) { fclose(f); return -2; }
   wf->desc.n_frames = F; wf->desc.n_landmarks = L; wf->desc.n_obs = hdr[3]; wf->desc.use_leg = hdr[4];
   wf->desc.leg_bias_const = hdr[5]; wf->desc.ex_const = hdr[6]; wf->desc.td_const = hdr[7];
   wf->has_after = hdr[9]; wf->marginalization_flag = hdr[10];
@@ -150,7 +155,10 @@ static int vilo_window_read(const char *path, vilo_window_file *wf) {
     wf->prior.n = ph[0]; wf->prior.n_blocks = ph[1];
     for (k = 0; k < VILO_MAX_PRIOR_BLOCKS; ++k) { wf->prior.block_id[k] = ph[2 + k]; wf->prior.block_size[k] = ph[2 + VILO_MAX_PRIOR_BLOCKS + k]; wf->prior.block_idx[k] = ph[2 + 2 * VILO_MAX_PRIOR_BLOCKS + k]; }
     wf->prior.valid = ph[2 + 3 * VILO_MAX_PRIOR_BLOCKS];
-    for (k = 0; k < wf->prior.n_blocks; ++k) xs += wf->prior.block_size[k];
+    for (k = 0; k < wf->prior.n_blocks; ++k) {
+      if (wf->prior.block_size[k] < 0 || wf->prior.block_size[k] > 16) { fclose(f); vilo_window_free(wf); return -2; }
+      xs += wf->prior.block_size[k];
+    }
     wf->prior.x0 = (double *)vilo__own(wf, sizeof(double) * (size_t)(xs ? xs : 1));
     wf->prior.J0 = (double *)vilo__own(wf, sizeof(double) * (size_t)wf->prior.n * wf->prior.n + 8);
     wf->prior.r0 = (double *)vilo__own(wf, sizeof(double) * (size_t)wf->prior.n + 8);

@@ -50,6 +50,21 @@ def test_c_header_roundtrip_is_byte_exact(tmp_path, cfg, ocfg, with_after, with_
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+def test_c_header_reader_survives_mutated_dumps(tmp_path):
+    """A dump is untrusted input for whoever replays it: 2000 seeded mutations of the golden dump go through
+    vilo_window_read built with the address and undefined-behaviour sanitizers — each comes back as a window or as an error code; the counts
+    a header states are bounded by the file's size before anything is allocated for them."""
+    exe = str(tmp_path / "window_io_fuzz")
+    src = os.path.join(ROOT, "tests", "host_check", "window_io_check.cpp")
+    base = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe, src]
+    if subprocess.call(base[:5] + ["-fsanitize=address,undefined"] + base[5:], stderr=subprocess.DEVNULL) != 0:
+        subprocess.check_call(base)   # (no sanitizer runtime on this host: the plain build still must not crash)
+    golden = os.path.join(ROOT, "tests", "golden", "seq_window_rejected_steps.vwin")
+    out = subprocess.run([exe, "--fuzz", golden, str(tmp_path / "scratch.vwin"), "2000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr[-3000:]
+    assert "refused" in out.stdout
+
+
 @pytest.mark.gpu
 def test_replay_dumped_window_on_gpu(tmp_path, cfg, ocfg):
     """Dump a window together with the oracle's result as the stored 'reference result', reload it and replay it through
