@@ -1,6 +1,7 @@
 """Shader-clock phase breakdown (profiling build: VILO_BUILD_PROF=1 python __graft_entry__.py, then
 VILO_GPU_LIB=cerberus_amd/lib/libvilo_gpu_prof.so python tools/phase_clocks_r3.py [windows ...]) of k_assemble(_c) and of the solver the
-batch size selects (k_solve_mw up to 512 windows, k_solve_wave beyond)."""
+batch size selects (k_solve_mw8 up to 512 windows, k_solve_wave beyond; the `k_solve_mw` lines below print only for builds that still carry the
+two-wave form of rounds 3 - 4)."""
 import sys
 
 import numpy as np
