@@ -217,18 +217,26 @@ def cpu_baseline_all_cores(n_landmarks, budget_s=6.0):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def parity_sample(cfg, windows, ids, landmarks, rate, summ, n=8, repropagate=False):
-    """Checker leg (outside the timed region): the final states of the first n windows of the timed batch — as the timed kernels left
-    them — against the oracle run on the same seeds for the same fixed number of iterations. The preintegration records are the ones the
+def sample_indices(W, per_place=3):
+    """Which windows of a batch of W the parity sample looks at: the first, the middle and the LAST `per_place` — the tail of a launch is
+    where a 32-bit stride, an arena-chunk boundary or a partial last round of workgroups would show."""
+    idx = list(range(min(per_place, W))) + [W // 2 - 1 + k for k in range(per_place)] + [W - per_place + k for k in range(per_place)]
+    return sorted({i for i in idx if 0 <= i < W})
+
+
+def parity_sample(cfg, windows, ids, landmarks, rate, summ, idx=None, repropagate=False):
+    """Checker leg (outside the timed region): the final states of the first, middle and last windows of the timed batch (`idx`,
+    sample_indices) — as the timed kernels left them — against the oracle run on the same seeds for the same fixed number of iterations;
+    and every window's final cost finite and within [0.1, 10] x the batch's median. The preintegration records are the ones the
     GPU integrated (K1 has its own goldens); everything after them is recomputed by the oracle."""
     import contextlib
     import numpy as np
     from oracle import oracle_py as O
     ocfg = O.config_from(cfg)
     opts = O.default_opts(fixed_iterations=True, max_num_iterations=ITERS)
-    n = min(n, len(windows))
+    idx = sample_indices(len(windows)) if idx is None else [i for i in idx if i < len(windows)]
     max_state, max_cost = 0.0, 0.0
-    for i in range(n):
+    for i in idx:
         w_ref = make_synth_window(cfg, landmarks, rate, 20260925 + ids[i])
         w_ref.preint[...] = windows[i].preint
         with (O.repropagation(w_ref) if repropagate else contextlib.nullcontext()):
@@ -236,10 +244,17 @@ def parity_sample(cfg, windows, ids, landmarks, rate, summ, n=8, repropagate=Fal
         for a, b in zip(windows[i].state_arrays(), w_ref.state_arrays()):
             max_state = max(max_state, float(np.abs(a - b).max() / max(1.0, np.abs(b).max())))
         max_cost = max(max_cost, abs(summ[i].final_cost - osum.final_cost) / max(abs(osum.final_cost), 1e-300))
-    return {"windows": n, "max_state_err": max_state, "max_cost_rel": max_cost, "tolerance": 1e-8,
+    costs = np.array([s.final_cost for s in summ], dtype=np.float64)
+    med = float(np.median(costs))
+    outliers = [int(i) for i in np.nonzero(~(np.isfinite(costs) & (costs >= 0.1 * med) & (costs <= 10.0 * med)))[0]]
+    states_finite = all(bool(np.isfinite(a).all()) for w in windows for a in w.state_arrays())
+    return {"windows": len(idx), "window_indices": idx, "max_state_err": max_state, "max_cost_rel": max_cost, "tolerance": 1e-8,
+            "all_windows": {"n": int(costs.size), "final_cost_median": med, "final_cost_min": float(np.nanmin(costs)), "final_cost_max": float(np.nanmax(costs)),
+                            "outside_0.1x_10x_of_median": len(outliers), "first_outliers": outliers[:8], "states_finite": states_finite,
+                            "ok": not outliers and states_finite},
             "what": "SOLVER parity (the oracle is handed the preintegration records the GPU integrated; K1 has its own goldens and "
-                    "tests/test_gpu_parity.py::test_path_parity_with_the_oracles_own_preintegration covers the whole path): final states (relative to max(1, |state block|)) and final cost of the first %d windows of the timed batch after the last timed step vs "
-                    "oracle/liboracle.so on the same seeds, %d fixed iterations%s" % (n, ITERS, ", intervals integrated again per evaluation" if repropagate else "")}
+                    "tests/test_gpu_parity.py::test_path_parity_with_the_oracles_own_preintegration covers the whole path): final states (relative to max(1, |state block|)) and final cost of the first, middle and last windows of the timed batch (window_indices) after the last timed step vs "
+                    "oracle/liboracle.so on the same seeds, %d fixed iterations%s; all_windows: every window's downloaded final cost and states" % (ITERS, ", intervals integrated again per evaluation" if repropagate else "")}
 
 
 def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
@@ -284,7 +299,7 @@ def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
            "roofline": {"bound": "hbm", "kernel": dom, "kernel_avg_ms": kern[dom]["avg_ms"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "algorithmic_bytes_per_window_iteration": b_alg},
            # (parity_sample regenerates window i from seed 20260925 + ids[i]: these windows were drawn from 40260925 + i)
-           "parity_sample": parity_sample(cfg, windows, [20000000 + i for i in range(W)], 1000, 400, summ, n=2, repropagate=True)}
+           "parity_sample": parity_sample(cfg, windows, [20000000 + i for i in range(W)], 1000, 400, summ, idx=[0, W - 1], repropagate=True)}
     batch.close()
     return out
 
@@ -605,8 +620,11 @@ def main():
     batch = make_batch(ctx, windows)
     # the batch is resident: of the host copies only the first 256 windows are read again (parity sample, marginalisation timing, the
     # single window) — 0.5 MB per window that 8 ranks x 32 768 windows would otherwise hold on one host
-    for w in windows[256:]:
+    sample_idx = [0, W - 1] if rp else sample_indices(W)
+    for i, w in enumerate(windows[256:], 256):
+        rec = w.preint if i in sample_idx else None
         w.release_inputs()
+        w.preint = rec
     setup_s = time.perf_counter() - t0
     opts = api.default_solve_opts(fixed_iterations=True, max_num_iterations=ITERS)
     lib = api.lib()
@@ -803,7 +821,7 @@ def main():
             out["small_batches"] = small
         if not args.no_cpu_baseline:
             # checker leg, outside the timed region: did the timed kernels produce the reference's states?
-            out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, n=2 if rp else 8, repropagate=rp)
+            out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, idx=sample_idx, repropagate=rp)
         if (args.single_window_latency or world == 1) and not args.no_single_window:   # absolute rate of ONE window on one GPU
             b1 = make_batch(ctx, windows[:1])
             lib.vilo_set_profiling(ctx.h, 0)
@@ -880,6 +898,8 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
         bad = [k for k in ("parity_sample",) if isinstance(out.get(k), dict) and max(out[k]["max_state_err"], out[k]["max_cost_rel"]) > out[k]["tolerance"]]
+        if isinstance(out.get("parity_sample"), dict) and not out["parity_sample"]["all_windows"]["ok"]:
+            bad.append("parity_sample.all_windows")
         c3p = (out.get("config3") or {}).get("parity_sample") if isinstance(out.get("config3"), dict) else None
         if c3p and max(c3p["max_state_err"], c3p["max_cost_rel"]) > c3p["tolerance"]:
             bad.append("config3.parity_sample")

@@ -833,7 +833,7 @@ __device__ v3 R2ypr_deg(const m3 &R) {
   const double y = atan2(nn.y, nn.x);
   const double p = atan2(-nn.z, nn.x * cos(y) + nn.y * sin(y));
   const double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
-  return mk3(y, p, r) * (180.0 / M_PI);
+  return mk3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);   // `ypr / M_PI * 180.0` as utility.h:98 writes it (an ulp from `* (180 / pi)`)
 }
 __device__ quat quat_from_R_dev(const m3 &m) {
   quat q;

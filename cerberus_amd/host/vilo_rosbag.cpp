@@ -2,6 +2,7 @@
 #include "vilo_rosbag.h"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
 
 #include <new>
 
@@ -292,10 +293,12 @@ const Lz4Api *lz4_api() {
 }
 // VILO_BAG_OK, VILO_BAG_ERR_COMPRESSED (no library for this compression) or VILO_BAG_ERR_FORMAT (the stream is not what the header says)
 int chunk_decompress(const std::string &compression, const std::vector<uint8_t> &src, uint32_t size, std::vector<uint8_t> *out) {
-  // `size` is the header's word for the uncompressed length (untrusted): rosbag's chunks are < 1 MiB by default and neither codec expands
-  // real data a thousandfold, so a header that asks for more than that of its own compressed bytes (or for more than 1 GiB) is refused
-  // before anything is allocated
-  if (size > (1u << 30) || (uint64_t)size > 1024ull * (uint64_t)src.size() + (1u << 16)) return VILO_BAG_ERR_FORMAT;
+  // `size` is the header's word for the uncompressed length (untrusted), checked before anything is allocated. rosbag's chunks are 768 KiB
+  // by default (`--chunksize` is in KiB and rarely beyond tens of MiB): 256 MiB is the absolute cap for either codec. An LZ4 block cannot
+  // expand more than 255-fold (one length byte per 255 repeated bytes), so its claim is also held to the compressed bytes it comes with;
+  // bz2 has no such bound worth using — 768 KiB of zeros are 46 bytes, three black 640 x 480 images 160 — and gets the cap only.
+  if (size > (1u << 28)) return VILO_BAG_ERR_FORMAT;
+  if (compression == "lz4" && (uint64_t)size > 256ull * (uint64_t)src.size() + (1u << 16)) return VILO_BAG_ERR_FORMAT;
   out->assign(size, 0);
   if (compression == "bz2") {
     const Bz2Api *a = bz2_api();
@@ -443,7 +446,7 @@ bool BagWriter::close() {
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 // one top-level record from the file. 1: got one, 0: clean end of file, < 0: error
-int read_record(FILE *f, std::vector<uint8_t> *header, std::vector<uint8_t> *data) {
+int read_record(FILE *f, long file_size, std::vector<uint8_t> *header, std::vector<uint8_t> *data) {
   uint8_t b[4];
   const size_t got = std::fread(b, 1, 4, f);
   if (got == 0) return 0;
@@ -454,12 +457,11 @@ int read_record(FILE *f, std::vector<uint8_t> *header, std::vector<uint8_t> *dat
   if (hl && std::fread(header->data(), 1, hl, f) != hl) return VILO_BAG_ERR_FORMAT;
   if (std::fread(b, 1, 4, f) != 4) return VILO_BAG_ERR_FORMAT;
   const uint32_t dl = get_u32(b);
-  // the length comes from the (untrusted) file: never allocate more than the file still holds
+  // the length comes from the (untrusted) file: never allocate more than the file still holds (its size was taken once, at open: a seek
+  // to the end and back per record would throw away the read buffer every time)
   const long here = std::ftell(f);
-  if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) return VILO_BAG_ERR_IO;
-  const long end = std::ftell(f);
-  if (end < 0 || std::fseek(f, here, SEEK_SET) != 0) return VILO_BAG_ERR_IO;
-  if ((unsigned long)dl > (unsigned long)(end - here)) return VILO_BAG_ERR_FORMAT;
+  if (here < 0) return VILO_BAG_ERR_IO;
+  if (here > file_size || (unsigned long)dl > (unsigned long)(file_size - here)) return VILO_BAG_ERR_FORMAT;
   data->resize(dl);
   if (dl && std::fread(data->data(), 1, dl, f) != dl) return VILO_BAG_ERR_FORMAT;
   return 1;
@@ -480,11 +482,14 @@ int BagReader::open(const char *path) {
   close();
   f_ = std::fopen(path, "rb");
   if (!f_) return VILO_BAG_ERR_IO;
+  struct stat st;
+  if (fstat(fileno(f_), &st) != 0) { close(); return VILO_BAG_ERR_IO; }
+  file_size_ = (long)st.st_size;
   char magic[MAGIC_N];
   if (std::fread(magic, 1, MAGIC_N, f_) != MAGIC_N || std::memcmp(magic, MAGIC, MAGIC_N) != 0) { close(); return VILO_BAG_ERR_FORMAT; }
   std::vector<uint8_t> h, d;
   std::map<std::string, std::string> hf;
-  if (read_record(f_, &h, &d) != 1 || !parse_fields(h.data(), h.size(), &hf) || field_op(hf) != 0x03 || !field_u64(hf, "index_pos", &index_pos) ||
+  if (read_record(f_, file_size_, &h, &d) != 1 || !parse_fields(h.data(), h.size(), &hf) || field_op(hf) != 0x03 || !field_u64(hf, "index_pos", &index_pos) ||
       !field_u32(hf, "conn_count", &conn_count) || !field_u32(hf, "chunk_count", &chunk_count)) {
     close();
     return VILO_BAG_ERR_FORMAT;
@@ -500,7 +505,7 @@ int BagReader::load_next_chunk() {
   std::vector<uint8_t> h, d;
   std::map<std::string, std::string> hf;
   for (;;) {
-    const int rc = read_record(f_, &h, &d);
+    const int rc = read_record(f_, file_size_, &h, &d);
     if (rc == 0) return VILO_BAG_END;
     if (rc < 0) return rc;
     if (!parse_fields(h.data(), h.size(), &hf)) return VILO_BAG_ERR_FORMAT;

@@ -125,6 +125,7 @@ class BagReader {
  private:
   int load_next_chunk();
   FILE *f_ = nullptr;
+  long file_size_ = 0;          // taken once at open (fstat): bounds every length a record states
   std::vector<uint8_t> chunk_;
   size_t pos_ = 0;
   std::map<uint32_t, std::pair<std::string, std::string>> conns_;   // conn -> (topic, type)

@@ -115,6 +115,15 @@ class Window:
         self.prior = None
         self.truth_pose = self.truth_speed_bias = self.truth_leg_bias = self.truth_inv_depth = None
 
+    def twin(self):
+        """Another window over the SAME input arrays (observations, samples, records, prior) with state arrays of its own: harnesses fill
+        large batches with twins of a few generated windows without holding 0.5 MB of inputs per position."""
+        import copy
+        t = copy.copy(self)
+        t.pose, t.speed_bias, t.leg_bias = self.pose.copy(), self.speed_bias.copy(), self.leg_bias.copy()
+        t.ex_pose, t.td, t.inv_depth = self.ex_pose.copy(), self.td.copy(), self.inv_depth.copy()
+        return t
+
     def state_arrays(self):
         return [self.pose, self.speed_bias, self.leg_bias, self.ex_pose, self.td, self.inv_depth]
 

@@ -726,7 +726,7 @@ static V3 R2ypr(const M3 &R) {
   double y = std::atan2(n[1], n[0]);
   double p = std::atan2(-n[2], n[0] * std::cos(y) + n[1] * std::sin(y));
   double r = std::atan2(a[0] * std::sin(y) - a[1] * std::cos(y), -o[0] * std::sin(y) + o[1] * std::cos(y));
-  return v3(y, p, r) * (180.0 / M_PI);
+  return v3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);   // `ypr / M_PI * 180.0` (utility.h:98): not `* (180 / pi)`, an ulp apart
 }
 static M3 ypr2R(const V3 &ypr) {
   const double y = ypr[0] / 180.0 * M_PI, p = ypr[1] / 180.0 * M_PI, r = ypr[2] / 180.0 * M_PI;
@@ -760,6 +760,17 @@ static Quat quat_from_R(const M3 &m) {
     q.x = v[0]; q.y = v[1]; q.z = v[2];
   }
   return q;
+}
+
+extern "C" void orc_R2ypr(const double R[9], double ypr[3]) {
+  M3 m;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = R[3 * i + j];
+  V3 v = R2ypr(m);
+  for (int i = 0; i < 3; ++i) ypr[i] = v[i];
+}
+extern "C" void orc_ypr2R(const double ypr[3], double R[9]) {
+  M3 m = ypr2R(v3(ypr[0], ypr[1], ypr[2]));
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = m(i, j);
 }
 
 // double2vector gauge fix (estimator.cpp:903-957) followed by vector2double's re-pack (:848-873):

@@ -322,6 +322,18 @@ def gauge_fix(before_arrays, w):
     lib().orc_gauge_fix(C.byref(sb), C.byref(sa), C.c_int(w.F))
 
 
+def R2ypr(R):
+    out = np.zeros(3)
+    lib().orc_R2ypr(np.ascontiguousarray(R, dtype=np.float64).ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out
+
+
+def ypr2R(ypr):
+    out = np.zeros((3, 3))
+    lib().orc_ypr2R(np.ascontiguousarray(ypr, dtype=np.float64).ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out
+
+
 def marginalize(cfg, w, mode, prior_out, want_A=False):
     """prior_out: cerberus_amd.synth.PriorData-like (struct + x0/J0/r0 buffers). Returns (rc, m, A, b)."""
     d, s = w.desc(_THIS)

@@ -341,4 +341,46 @@ int ref_marginalize(const orc_config *cfg, const orc_window *w, const orc_state 
   return 0;
 }
 
+// ---- Utility::R2ypr / ypr2R (utils/utility.h:83-125): the reference's own bodies (header-only, compiled here)
+void ref_R2ypr(const double R[9], double ypr[3]) {
+  Eigen::Matrix3d M;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M(i, j) = R[3 * i + j];
+  Eigen::Vector3d v = Utility::R2ypr(M);
+  for (int i = 0; i < 3; ++i) ypr[i] = v(i);
+}
+void ref_ypr2R(const double ypr[3], double R[9]) {
+  Eigen::Matrix3d M = Utility::ypr2R(Eigen::Vector3d(ypr[0], ypr[1], ypr[2]));
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = M(i, j);
+}
+// ---- the gauge fix of Estimator::double2vector (estimator.cpp:905-957; that file needs ROS and OpenCV and cannot be compiled here):
+// its statements written down around the reference's Utility::R2ypr / ypr2R, followed by vector2double's re-pack (:848-873). `before` =
+// Rs[0] / Ps[0] as they stood when vector2double ran, `after` = the solver's para_* output, overwritten with the fixed states.
+void ref_gauge_fix(const orc_state *before, orc_state *after, int F) {
+  auto quat = [](const double *p) { return Eigen::Quaterniond(p[6], p[3], p[4], p[5]); };
+  Eigen::Matrix3d Rs0 = quat(before->pose).toRotationMatrix();
+  Eigen::Vector3d origin_R0 = Utility::R2ypr(Rs0);
+  Eigen::Vector3d origin_P0(before->pose[0], before->pose[1], before->pose[2]);
+  Eigen::Matrix3d R00 = quat(after->pose).toRotationMatrix();
+  Eigen::Vector3d origin_R00 = Utility::R2ypr(R00);
+  double y_diff = origin_R0.x() - origin_R00.x();
+  Eigen::Matrix3d rot_diff = Utility::ypr2R(Eigen::Vector3d(y_diff, 0, 0));
+  if (std::abs(std::abs(origin_R0.y()) - 90) < 1.0 || std::abs(std::abs(origin_R00.y()) - 90) < 1.0) rot_diff = Rs0 * R00.transpose();
+  const Eigen::Vector3d P0(after->pose[0], after->pose[1], after->pose[2]);
+  for (int i = 0; i < F; ++i) {
+    double *pp = after->pose + 7 * i, *sb = after->speed_bias + 9 * i;
+    Eigen::Matrix3d Ri = rot_diff * quat(pp).normalized().toRotationMatrix();
+    Eigen::Vector3d Pi = rot_diff * Eigen::Vector3d(pp[0] - P0(0), pp[1] - P0(1), pp[2] - P0(2)) + origin_P0;
+    Eigen::Vector3d Vi = rot_diff * Eigen::Vector3d(sb[0], sb[1], sb[2]);
+    Eigen::Quaterniond q{Ri};
+    pp[0] = Pi(0); pp[1] = Pi(1); pp[2] = Pi(2);
+    pp[3] = q.x(); pp[4] = q.y(); pp[5] = q.z(); pp[6] = q.w();
+    sb[0] = Vi(0); sb[1] = Vi(1); sb[2] = Vi(2);
+  }
+  for (int c = 0; c < 2; ++c) {
+    double *pp = after->ex_pose + 7 * c;
+    Eigen::Quaterniond q{quat(pp).normalized().toRotationMatrix()};
+    pp[3] = q.x(); pp[4] = q.y(); pp[5] = q.z(); pp[6] = q.w();
+  }
+}
+
 }  // extern "C"

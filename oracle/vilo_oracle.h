@@ -223,6 +223,9 @@ int orc_solve_window(const orc_config *cfg, const orc_window *w, orc_state *s, c
 
 /* double2vector gauge fix (estimator.cpp:903-957): s_before = states before the solve (Rs/Ps in window). */
 void orc_gauge_fix(const orc_state *before, orc_state *after, int n_frames);
+/* Utility::R2ypr / ypr2R (utils/utility.h:83-125), degrees, row-major 3x3 */
+void orc_R2ypr(const double R[9], double ypr[3]);
+void orc_ypr2R(const double ypr[3], double R[9]);
 
 /* Marginalisation (estimator.cpp:1247-1455 + marginalization_factor.cpp:98-333).
  * mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. out arrays must hold >= 128 entries each dimension:

@@ -315,3 +315,151 @@ def test_gpu_force_model_repropagation_vs_reference(gwin):
     finally:
         b.close()
         c.close()
+
+
+# ------------------------------------------------------------------------------ contact inputs no gait produces (reference branches)
+GE = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preint_contact_edges.npz"))
+
+
+def _edge_inputs(gwin):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_edges as E
+    return (E.contact_edges(gwin.samples, gwin.sample_offsets, seed=int(GE["flag_seed"])),
+            E.force_edges(gwin.samples, gwin.sample_offsets, seed=int(GE["force_seed"])))
+
+
+def test_golden_contact_edges_reach_the_branches():
+    """What the fixture is for: intervals 1, 8 (whole interval) and 0, 4, 7 (part of it) integrate steps with all four flags 0 —
+    imu_leg_integration_base.cpp:354-358 sets the leg-velocity variances to 10e10, so the foot-position covariance is ~1e11 dt^2 per
+    step — and intervals 2, 3, 6 decide contact on c >= 0.5 exactly (:183-194): with `>` instead of `>=` interval 6 would be in the air."""
+    cov = np.abs(GE["flags"][:, 994:]).max(axis=1)
+    assert (cov[[0, 1, 4, 7, 8]] > 1e6).all() and (cov[[2, 3, 6]] < 1.0).all(), cov
+    covf = np.abs(GE["force"][:, 994:]).max(axis=1)
+    assert (covf[1::2] > 1e6).all() and (covf[0::2] < 1.0).all(), covf
+
+
+def test_oracle_contact_edges(gwin):
+    import copy
+    cfg = O.default_config()
+    cfg2 = copy.copy(cfg)
+    cfg2.contact_sensor_type = 2
+    w = gwin
+    ce, fe = _edge_inputs(gwin)
+    pre = np.array([O.preintegrate_imu_leg(cfg, ce[w.sample_offsets[k]:w.sample_offsets[k + 1]], w.lin[k]) for k in range(w.F - 1)])
+    _check_records(pre, GE["flags"], 1e-12, 1e-10, 1e-9)
+    pre = np.array([O.preintegrate_imu_leg(cfg2, fe[w.sample_offsets[k]:w.sample_offsets[k + 1]], w.lin[k]) for k in range(w.F - 1)])
+    _check_records(pre, GE["force"], 1e-12, 1e-10, 1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_contact_edges_vs_reference(ctx, gwin):
+    """k_preint_imu_leg on the same inputs: all feet in the air (kernels_preint.hip, `10e10` branch), the 0.5 threshold with non-binary c,
+    and both again through the force model — and the factor built on such a record (sqrt_info of a covariance with 1e7 entries beside 1e-8
+    ones) against the oracle's."""
+    import copy
+    from cerberus_amd import api
+    w = gwin
+    ce, fe = _edge_inputs(gwin)
+    pre = ctx.preintegrate(ce, w.sample_offsets, w.lin)
+    _check_records(pre, GE["flags"], 1e-11, 1e-9, 1e-8)
+    c2 = copy.copy(synth.default_config())
+    c2.contact_sensor_type = 2
+    c = api.Context(c2, 0)
+    try:
+        _check_records(c.preintegrate(fe, w.sample_offsets, w.lin), GE["force"], 1e-11, 1e-9, 1e-8)
+    finally:
+        c.close()
+    # IMULegFactor on the in-the-air records: whitened residual / Jacobian through the C-ABI against the oracle on the reference's record
+    P = _split(G["imu_params"], [7, 9, 4, 7, 9, 4])
+    r, Js = ctx.eval_imu_leg(GE["flags"], P)
+    cfg = O.default_config()
+    for k in range(r.shape[0]):
+        ro, Jo = O.eval_imu_leg(cfg, GE["flags"][k], [p[k] for p in P])
+        Jo, Jg = np.hstack(Jo), np.hstack([J[k] for J in Js])
+        assert _rel(r[k], ro) < 1e-8, (k, _rel(r[k], ro))
+        assert _rel(Jg, Jo) < 1e-8, (k, _rel(Jg, Jo))
+
+
+# ------------------------------------------------------------------------------ gauge fix at the Euler singularity (estimator.cpp:925-934)
+GG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gauge_fix_edges.npz"))
+
+
+def _gauge_cases(fix, w):
+    """fix(before_arrays, w): the implementation under test; compares every case of the fixture with what ref_gauge_fix gave."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_gauge as MG
+    worst = 0.0
+    for n in range(GG["cases"].shape[0]):
+        g = {k: GG["%s_%d" % (k, n)] for k in ("before_pose", "before_sb", "after_pose", "after_sb", "after_ex", "fixed_pose", "fixed_sb", "fixed_ex")}
+        fp, fs, fe = MG.run_fix(fix, w, g["before_pose"], g["before_sb"], g["after_pose"], g["after_sb"], g["after_ex"])
+        for a, b in ((fp, g["fixed_pose"]), (fs, g["fixed_sb"]), (fe, g["fixed_ex"])):
+            worst = max(worst, np.abs(a - b).max())
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg="case %d: pitch before / after %s" % (n, GG["cases"][n]))
+        # what the fix is for: frame 0 keeps its position, and its yaw (regular branch) or its whole rotation (singular branch)
+        np.testing.assert_allclose(fp[0, :3], g["before_pose"][0, :3], atol=1e-12)
+        if GG["branch_taken"][n]:
+            assert min(np.abs(fp[0, 3:] - g["before_pose"][0, 3:]).max(), np.abs(fp[0, 3:] + g["before_pose"][0, 3:]).max()) < 1e-8
+    return worst
+
+
+def test_golden_gauge_cases_cover_both_branches():
+    t = GG["branch_taken"]
+    assert t.sum() >= 8 and (~t).sum() >= 3
+    c = GG["cases"]
+    assert any(abs(a) < 89 and abs(b) > 89 for a, b in c[t]) and any(abs(a) > 89 and abs(b) < 89 for a, b in c[t])   # either clause alone
+
+
+def test_oracle_gauge_fix_at_the_euler_singularity(gwin):
+    _gauge_cases(O.gauge_fix, gwin)
+
+
+@pytest.mark.gpu
+def test_gpu_gauge_fix_at_the_euler_singularity(ctx, gwin):
+    """vilo_gauge_fix (k_gauge_fix, kernels_marg.hip) with frame 0 pitched to +-89.5 / +-90 / 88.9 -> 89.2 degrees before and / or after
+    the solve, against the reference-built fixture."""
+    worst = _gauge_cases(ctx.gauge_fix, gwin)
+    print("gauge fix, worst absolute difference to the reference-built fixture: %.2e" % worst)
+
+
+# ------------------------------------------------------------------------------ marginalisation against the exact Schur complement
+def _exact_marginal(gwin, mode):
+    from marg_exact import block_table, exact_schur
+    w, cfg = gwin, O.default_config()
+    w.preint[...] = G["preint"]
+    po = synth.PriorData()
+    rc, m, A, b = O.marginalize(cfg, w, mode, po, want_A=True)
+    assert rc == 0
+    H, g = exact_schur(A, b, m)
+    return po, H, g, block_table(po)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_oracle_marginalization_vs_exact_schur_complement(gwin, mode):
+    """The oracle's prior per kept block pair, scaled by the blocks' own diagonals, against the 60-digit Schur complement of the same
+    normal equations. MARGIN_OLD: the reference's route — Amm^-1 from an eigen-decomposition of a matrix of condition 1.6e11
+    (marginalization_factor.cpp:281-286) — leaves 2.4e-6 in these units (measured; the compiled reference with the build's eigensolver:
+    1.3e-4); MARGIN_SECOND_NEW drops one well-conditioned pose: 4e-14."""
+    from marg_exact import scaled_errors
+    po, H, g, blocks = _exact_marginal(gwin, mode)
+    eh, eb, gh, gb = scaled_errors(po, H, g, blocks)
+    print("MEASURED oracle vs exact Schur complement, mode %d: H %.2e, b %.2e in units of the blocks' diagonals (of the largest entry: %.2e, %.2e)" % (mode, eh, eb, gh, gb))
+    assert max(eh, eb) < (1e-5 if mode == 0 else 1e-11), (eh, eb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gpu_marginalization_vs_exact_schur_complement(ctx, gwin, mode):
+    """vilo_marginalize (k_marginalize_lds: landmarks eliminated first, the dense frame-0 dimensions by Cholesky, no eigen-decomposition of
+    Amm) held to the exact Schur complement per kept block pair in units of the blocks' own diagonals — and the compiled reference's frozen
+    result (tests/golden/reference_vectors.npz) measured in the same units beside it."""
+    from marg_exact import scaled_errors
+    po, H, g, blocks = _exact_marginal(gwin, mode)
+    p = synth.PriorData()
+    ctx.marginalize(gwin, mode, p)
+    eh, eb, gh, gb = scaled_errors(p, H, g, blocks)
+    oh, ob, _, _ = scaled_errors(po, H, g, blocks)
+    print("MEASURED HIP vs exact Schur complement, mode %d: H %.2e, b %.2e in units of the blocks' diagonals (of the largest entry: %.2e, %.2e); "
+          "oracle in the same units: %.2e, %.2e" % (mode, eh, eb, gh, gb, oh, ob))
+    assert max(eh, eb) < (1e-7 if mode == 0 else 1e-11), (eh, eb)

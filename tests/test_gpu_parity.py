@@ -424,6 +424,51 @@ def test_headline_kernel_set_vs_oracle(ctx, cfg, ocfg):
     assert worst < 1e-8, worst
 
 
+def test_the_tail_of_a_headline_sized_batch(ctx, cfg, ocfg):
+    """bench.py's default launch is 32 768 windows; the oracle comparisons above look at batches of 1100. Here a batch of that size: 253
+    generated windows (the bench's seeds) repeated over the first 32 765 positions as twins (shared inputs, own state arrays — position p
+    holds window p % 253, so replicas land in different workgroups, packed waves and arena chunks), three further seeds in the LAST three
+    positions. 12 fixed iterations with the bench's kernel set. Checked: (1) every replica's final states and cost are bitwise those of the
+    window's first position — a result does not depend on where in a launch the window sits, up to the last workgroup; (2) the first, a
+    middle and the last three windows against the oracle at SURVEY 8(c)'s 1e-8; (3) every cost finite and within [0.1, 10] x the median
+    (bench.py's `parity_sample.all_windows`)."""
+    from cerberus_amd import api, synth
+    W, U = 32768, 253
+    uniq = [synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=20260925 + i)) for i in range(U + 3)]
+    ctx.preintegrate_windows(uniq)
+    ws = [uniq[p] if p < U else uniq[p % U].twin() for p in range(W - 3)] + uniq[U:]
+    b = api.Batch(ctx, ws)
+    try:
+        b.prepare()
+        b.solve(api.default_solve_opts(True, 12))
+        summ = b.download()
+    finally:
+        b.close()
+    assert all(s.iterations == 12 for s in summ)
+    costs = np.array([s.final_cost for s in summ])
+    med = np.median(costs)
+    assert np.isfinite(costs).all() and (costs >= 0.1 * med).all() and (costs <= 10 * med).all(), (costs.min(), med, costs.max())
+    mism = 0
+    for p in range(U, W - 3):
+        same = summ[p].final_cost == summ[p % U].final_cost and all(np.array_equal(a, bb) for a, bb in zip(ws[p].state_arrays(), ws[p % U].state_arrays()))
+        mism += 0 if same else 1
+    assert mism == 0, "%d of %d replicas differ from their window's first position" % (mism, W - 3 - U)
+    worst = 0.0
+    for p in (0, 1, W // 2, W - 3, W - 2, W - 1):
+        src = uniq[U + p - (W - 3)] if p >= W - 3 else uniq[p % U]
+        seed = 20260925 + (U + p - (W - 3) if p >= W - 3 else p % U)
+        w_o = synth.make_window(cfg, params=synth.default_params(n_landmarks=200, seed=seed))
+        w_o.preint[...] = src.preint
+        so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
+        assert (summ[p].iterations, summ[p].num_successful) == (so.iterations, so.num_successful)
+        np.testing.assert_allclose(summ[p].final_cost, so.final_cost, rtol=1e-8)
+        for a, bb in zip(ws[p].state_arrays(), w_o.state_arrays()):
+            if a.size:
+                worst = max(worst, np.abs(a - bb).max() / max(1.0, np.abs(bb).max()))
+    print("MEASURED test_the_tail_of_a_headline_sized_batch: states %.2e over positions 0, 1, W/2, W-3..W-1 of %d" % (worst, W))
+    assert worst < 1e-8, worst
+
+
 def test_path_parity_with_the_oracles_own_preintegration(ctx, cfg, ocfg):
     """The WHOLE path against the oracle with nothing shared but the inputs: contact preintegration of the raw samples (K1) + sqrt_info +
     12 trust-region iterations on the GPU, against the oracle integrating the same samples itself (O.fill_preint) and solving. The other solve

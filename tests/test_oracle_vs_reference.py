@@ -274,3 +274,45 @@ def test_marginalization_of_a_rank_deficient_block(cfg):
         np.testing.assert_allclose(Ho[key], Hr[key], rtol=0, atol=1e-9 * hmax, err_msg=str(key))
     for key in br:
         np.testing.assert_allclose(bo[key], br[key], rtol=0, atol=1e-9 * bmax, err_msg=str(key))
+
+
+def test_euler_angles_of_the_gauge_fix():
+    """Utility::R2ypr / ypr2R (utils/utility.h:83-125), compiled from the reference, beside the oracle's restatement: random rotations and
+    the neighbourhood of pitch +-90 degrees, where double2vector (estimator.cpp:925-934) switches branches on what R2ypr returns."""
+    rng = np.random.default_rng(3)
+    yprs = [rng.uniform([-180, -89, -180], [180, 89, 180]) for _ in range(50)]
+    yprs += [np.array([y, p, r]) for y in (-170.0, 0.0, 33.0) for p in (89.5, -89.5, 90.0, -90.0, 89.0, 88.9, 89.999999) for r in (-20.0, 0.0, 75.0)]
+    for ypr in yprs:
+        Ro = O.ypr2R(ypr)
+        ao = O.R2ypr(Ro)
+        with R.as_oracle():
+            Rr = O.ypr2R(ypr)
+            ar = O.R2ypr(Rr)
+            ar2 = O.R2ypr(Ro)
+        np.testing.assert_array_equal(Ro, Rr)          # the same expressions in the same order
+        np.testing.assert_array_equal(ao, ar2)
+        np.testing.assert_array_equal(ao, ar)
+
+
+def test_contact_edge_inputs_side_by_side(cfg, window):
+    """tests/golden/make_golden_edges.py's inputs — all feet in the air (imu_leg_integration_base.cpp:354-358), non-binary c around the 0.5
+    threshold (:183-194), and the force model with every flag 0 — through oracle and compiled reference side by side (the frozen records:
+    tests/test_golden.py::test_oracle_contact_edges)."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_edges as E
+    w = window
+    cfg2 = copy.copy(cfg)
+    cfg2.contact_sensor_type = 2
+    for c, smp in ((cfg, E.contact_edges(w.samples, w.sample_offsets)), (cfg2, E.force_edges(w.samples, w.sample_offsets))):
+        for k in range(w.F - 1):
+            s = smp[w.sample_offsets[k]:w.sample_offsets[k + 1]]
+            po = _split(O.preintegrate_imu_leg(c, s, w.lin[k]))
+            with R.as_oracle():
+                pr = _split(O.preintegrate_imu_leg(c, s, w.lin[k]))
+            for f in ("sum_dt", "dp", "dq", "dv", "de", "lin"):
+                np.testing.assert_allclose(po[f], pr[f], rtol=1e-12, atol=1e-14, err_msg=f)
+            np.testing.assert_allclose(po["jac"], pr["jac"], rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(po["cov"], pr["cov"], rtol=1e-9, atol=1e-18 + 1e-12 * np.abs(pr["cov"]).max())

@@ -178,6 +178,25 @@ def test_lengths_a_damaged_bag_claims_are_never_allocated(tmp_path):
     assert resource.getrlimit(resource.RLIMIT_AS) == (soft, hard)
 
 
+@pytest.mark.parametrize("compression", ["bz2", "lz4"])
+def test_chunks_of_blank_images_read_back(tmp_path, compression):
+    """A chunk of three black 640 x 480 mono8 images (921 672 bytes) is 160 bytes of bz2 — nearly 6000 : 1. The reader's guard against
+    a lying `size` field must not take such a chunk for a lie (a bound of 1024 x the compressed bytes did): bz2 chunks are
+    held to an absolute cap, LZ4 ones to the codec's own 255 : 1. Black, constant and saturated frames, default chunk threshold."""
+    from cerberus_amd import rosbag as rb
+    p = tmp_path / "black.bag"
+    imgs = [np.zeros(640 * 480, np.uint8), np.zeros(640 * 480, np.uint8), np.zeros(640 * 480, np.uint8), np.full(640 * 480, 255, np.uint8),
+            np.full(640 * 480, 17, np.uint8), np.zeros(640 * 480, np.uint8)]
+    with rb.BagWriter(p, compression=compression) as w:
+        for i, im in enumerate(imgs):
+            w.write(dict(kind=rb.KIND_IMAGE, topic="/cam0", seq=i, secs=1, nsecs=i, frame_id="cam", height=480, width=640, step=640, encoding="mono8", data=im))
+    assert p.stat().st_size < 40000          # (the point: thousands to one)
+    back = [m for m in rb.BagReader(p) if m["kind"] == rb.KIND_IMAGE]
+    assert len(back) == len(imgs)
+    for m, im in zip(back, imgs):
+        assert (m["height"], m["width"]) == (480, 640) and np.array_equal(np.frombuffer(bytes(m["data"]), np.uint8), im)
+
+
 @pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
 def test_mutated_bags_end_in_messages_or_an_error(tmp_path, compression):
     """A bag is untrusted input: 300 random mutations of a valid file (bytes overwritten, runs zeroed or set to 0xff, truncations, a
