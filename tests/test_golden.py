@@ -445,15 +445,40 @@ def test_oracle_marginalization_vs_exact_schur_complement(gwin, mode):
     po, H, g, blocks = _exact_marginal(gwin, mode)
     eh, eb, gh, gb = scaled_errors(po, H, g, blocks)
     print("MEASURED oracle vs exact Schur complement, mode %d: H %.2e, b %.2e in units of the blocks' diagonals (of the largest entry: %.2e, %.2e)" % (mode, eh, eb, gh, gb))
-    assert max(eh, eb) < (1e-5 if mode == 0 else 1e-11), (eh, eb)
+    assert max(eh, eb) < (2e-5 if mode == 0 else 1e-11), (eh, eb)
+
+
+def test_what_fp64_inputs_allow_for_margin_old(gwin):
+    """Why MARGIN_OLD is held to 2e-5 and not to 1e-7 in these units: round the INPUT — the assembled normal equations, every entry moved by
+    at most one unit in the last place (relative 1.1e-16) — and the exact (60-digit) Schur complement itself moves by ~6e-6 of the blocks'
+    diagonals. Not through Amm's conditioning (Jacobi-scaled, its condition number is 9; unscaled 1.6e11): the kept blocks' information
+    is what is left of Arr after subtracting a nearly equal Arm Amm^-1 Amr. Two FP64 implementations assemble A with different rounding,
+    so none can be held closer to the exact complement of the OTHER's A than this floor — oracle 2.4e-6, HIP path 3.7e-6, the compiled
+    reference (with the build's eigensolver) 1.3e-4."""
+    from marg_exact import exact_schur
+    w, cfg = gwin, O.default_config()
+    w.preint[...] = G["preint"]
+    po = synth.PriorData()
+    rc, m, A, b = O.marginalize(cfg, w, 0, po, want_A=True)
+    H, g = exact_schur(A, b, m)
+    d = np.sqrt(np.diag(H))
+    rng = np.random.default_rng(0)
+    E = rng.uniform(-1, 1, size=A.shape)
+    H2, g2 = exact_schur(A * (1 + 1.1e-16 * 0.5 * (E + E.T)), b * (1 + 1.1e-16 * rng.uniform(-1, 1, size=b.shape)), m)
+    floor_h, floor_b = (np.abs(H2 - H) / np.outer(d, d)).max(), (np.abs(g2 - g) / d).max()
+    dm = np.sqrt(np.diag(A[:m, :m]))
+    print("MEASURED one-ulp input rounding moves the exact Schur complement by H %.2e, b %.2e (blocks' diagonals); cond(Amm) %.1e, Jacobi-scaled %.1e"
+          % (floor_h, floor_b, np.linalg.cond(A[:m, :m]), np.linalg.cond(A[:m, :m] / np.outer(dm, dm))))
+    assert 1e-6 < floor_h < 2e-5
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gpu_marginalization_vs_exact_schur_complement(ctx, gwin, mode):
     """vilo_marginalize (k_marginalize_lds: landmarks eliminated first, the dense frame-0 dimensions by Cholesky, no eigen-decomposition of
-    Amm) held to the exact Schur complement per kept block pair in units of the blocks' own diagonals — and the compiled reference's frozen
-    result (tests/golden/reference_vectors.npz) measured in the same units beside it."""
+    Amm) held to the exact Schur complement per kept block pair in units of the blocks' own diagonals, the oracle in the same units beside
+    it. MARGIN_OLD: measured 3.7e-6 (oracle 2.4e-6) against a floor of ~6e-6 that the FP64 rounding of the inputs alone sets
+    (test_what_fp64_inputs_allow_for_margin_old); MARGIN_SECOND_NEW: 9e-15."""
     from marg_exact import scaled_errors
     po, H, g, blocks = _exact_marginal(gwin, mode)
     p = synth.PriorData()
@@ -462,4 +487,4 @@ def test_gpu_marginalization_vs_exact_schur_complement(ctx, gwin, mode):
     oh, ob, _, _ = scaled_errors(po, H, g, blocks)
     print("MEASURED HIP vs exact Schur complement, mode %d: H %.2e, b %.2e in units of the blocks' diagonals (of the largest entry: %.2e, %.2e); "
           "oracle in the same units: %.2e, %.2e" % (mode, eh, eb, gh, gb, oh, ob))
-    assert max(eh, eb) < (1e-7 if mode == 0 else 1e-11), (eh, eb)
+    assert max(eh, eb) < (2e-5 if mode == 0 else 1e-11), (eh, eb)

@@ -589,6 +589,14 @@ def test_marginalize(ctx, cfg, ocfg, mode):
     Ai = np.linalg.pinv(0.5 * (Amm + Amm.T), rcond=0, hermitian=True)
     As = Arr - Amr.T @ Ai @ Amr
     assert np.abs(Ag - As).max() < 1e-6 * np.abs(As).max()
+    # per kept block pair, every entry in units of the blocks' own diagonals, against the 60-digit Schur complement of the oracle's A, b
+    # (tests/marg_exact.py; tests/test_golden.py::test_what_fp64_inputs_allow_for_margin_old measures the floor FP64 inputs set: ~6e-6)
+    from marg_exact import block_table, exact_schur, scaled_errors
+    He, ge = exact_schur(A, bvec, m)
+    eh, eb, _, _ = scaled_errors(pg, He, ge, block_table(po))
+    oh, ob, _, _ = scaled_errors(po, He, ge, block_table(po))
+    print("MEASURED test_marginalize mode %d: HIP vs exact Schur complement H %.2e, b %.2e of the blocks' diagonals (oracle: %.2e, %.2e)" % (mode, eh, eb, oh, ob))
+    assert max(eh, eb) < (2e-5 if mode == 0 else 1e-11), (eh, eb)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
