@@ -107,6 +107,41 @@ def make_synth_window(cfg, n_landmarks, rate, seed):
     return synth.make_window(cfg, params=prm)
 
 
+def cpu_info():
+    """the host the CPU figures were timed on."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def reference_evaluate_timing(cfg, n_landmarks, rate, budget_s=4.0):
+    """The COMPILED REFERENCE's own factor classes (oracle/_ref/libref.so: the Cerberus sources built against the Eigen / Ceres stand-ins)
+    timed on one host core: one pass = Evaluate() with Jacobians of every cost function of a config-2 window, which is what one Ceres
+    iteration asks of them at least once. Not a Ceres timing (no loss correction, elimination or dogleg in it) and not real Eigen — the part
+    of the reference's per-iteration cost that CAN be run here, stated beside the "port" figure."""
+    from oracle import oracle_py as O
+    from oracle import ref_py as R
+    if not R.available():
+        return None
+    ocfg = O.config_from(cfg)
+    w = make_synth_window(cfg, n_landmarks, rate, 777000)
+    O.fill_preint(ocfg, w)
+    t1, nf = R.time_evaluate(ocfg, w, reps=2)
+    reps = max(3, min(2000, int(budget_s / max(t1, 1e-6))))
+    t, nf = R.time_evaluate(ocfg, w, reps=reps)
+    return {"ms_per_evaluation_pass": 1e3 * t, "residual_blocks_per_pass": nf, "us_per_residual_block": 1e6 * t / max(nf, 1), "passes_timed": reps,
+            "upper_bound_iters_per_s": 1.0 / t, "cores": 1, "kind": "reference",
+            "what": "every cost function of one config-2 window (prior + 10 IMULegFactor + %d projection factors) Evaluate()d with Jacobians by the compiled "
+                    "reference's classes; Ceres' own share of an iteration is not in it, Eigen is the build's stand-in" % (nf - 11)}
+
+
 def cpu_baseline(cfg, n_landmarks, budget_s=15.0, rate=500, repropagate=False):
     """The oracle (CPU restatement of the reference path, scalar FP64, 1 thread) on windows of the same workload."""
     import contextlib
@@ -124,7 +159,7 @@ def cpu_baseline(cfg, n_landmarks, budget_s=15.0, rate=500, repropagate=False):
             t_total += time.perf_counter() - t0
         n_it += sm.iterations
         n_win += 1
-    return {"value": n_it / t_total, "unit": "GN iters/s", "cores": 1, "kind": "port",
+    return {"value": n_it / t_total, "unit": "GN iters/s", "cores": 1, "kind": "port", **cpu_info(),
             "sample": "%d synthetic %d-landmark %d Hz windows x %d iterations%s, oracle/liboracle.so (g++ -O3), 1 thread, %.1f s"
                       % (n_win, n_landmarks, rate, ITERS, ", every factor evaluation integrating its interval again" if repropagate else "", t_total)}
 
@@ -889,6 +924,11 @@ def main():
             # rank 0, one thread, after the timed region (at N > 1 the other ranks are done with their GPUs by now and only wait for this
             # rank at the process group's teardown): every line the driver records carries the CPU figure beside `value`
             out["cpu_baseline"] = cpu_baseline(cfg, args.landmarks, budget_s=15.0 if world == 1 else 10.0, rate=args.rate, repropagate=rp)
+            if world == 1 and not rp:
+                try:
+                    out["cpu_baseline"]["reference_evaluate"] = reference_evaluate_timing(cfg, args.landmarks, args.rate)
+                except Exception as e:   # (the library is built from /root/reference where that exists and travels prebuilt)
+                    out["cpu_baseline"]["reference_evaluate"] = {"error": repr(e)}
             if world == 1:
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.landmarks) if not rp else None

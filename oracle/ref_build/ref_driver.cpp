@@ -9,6 +9,7 @@
 // cannot be compiled without the whole ROS/OpenCV estimator; ref_marginalize below re-enumerates the blocks in the same
 // order and hands them to the reference's MarginalizationInfo).
 #include <cstring>
+#include <ctime>
 #include <unordered_map>
 #include <vector>
 
@@ -381,6 +382,78 @@ void ref_gauge_fix(const orc_state *before, orc_state *after, int F) {
     Eigen::Quaterniond q{quat(pp).normalized().toRotationMatrix()};
     pp[3] = q.x(); pp[4] = q.y(); pp[5] = q.z(); pp[6] = q.w();
   }
+}
+
+// ---- what the reference pays per trust-region iteration for factor evaluation alone: every cost function of the window as
+// Estimator::optimization adds them (estimator.cpp:1110-1216: the prior, WINDOW_SIZE IMULegFactors, per observation of a landmark
+// TwoFrameOneCam / TwoFrameTwoCam / OneFrameTwoCam), each Evaluate()d with residuals AND Jacobians `reps` times, timed here (no ctypes
+// call per factor). Returns seconds per pass over the window's factors; n_factors_out = residual blocks evaluated per pass. Ceres'
+// own work per iteration (loss correction, local parameterisation, Schur elimination, dogleg) is NOT in it, and Eigen is the build's
+// stand-in (shim/Eigen/mini_eigen.h, eager loops): a floor-ish figure for the reference's Evaluate cost, not a Ceres timing.
+double ref_time_evaluate(const orc_config *cfg, const orc_window *w, const orc_state *s, int reps, int *n_factors_out) {
+  apply_config(cfg);
+  const int F = w->n_frames, L = w->n_landmarks;
+  static double para_Pose[11][7], para_SpeedBias[11][9], para_LegBias[11][4], para_Ex_Pose[2][7], para_Td[1][1];
+  std::vector<double> featbuf(L > 0 ? L : 1);
+  std::memcpy(para_Pose, s->pose, sizeof(double) * 7 * F);
+  std::memcpy(para_SpeedBias, s->speed_bias, sizeof(double) * 9 * F);
+  std::memcpy(para_LegBias, s->leg_bias, sizeof(double) * 4 * F);
+  std::memcpy(para_Ex_Pose, s->ex_pose, sizeof(double) * 14);
+  para_Td[0][0] = s->td[0];
+  for (int k = 0; k < L; ++k) featbuf[k] = s->inv_depth[k];
+  struct Blk { ceres::CostFunction *f; std::vector<double *> p; };
+  std::vector<Blk> blocks;
+  if (w->prior && w->prior->valid) {
+    std::unordered_map<int, double *> addr_of_id;
+    for (int i = 0; i < F; ++i) { addr_of_id[ORC_BLK_POSE * 16 + i] = para_Pose[i]; addr_of_id[ORC_BLK_SB * 16 + i] = para_SpeedBias[i]; addr_of_id[ORC_BLK_LB * 16 + i] = para_LegBias[i]; }
+    addr_of_id[ORC_BLK_EX * 16 + 0] = para_Ex_Pose[0]; addr_of_id[ORC_BLK_EX * 16 + 1] = para_Ex_Pose[1]; addr_of_id[ORC_BLK_TD * 16] = para_Td[0];
+    std::vector<double *> last_blocks;
+    MarginalizationInfo *info = info_from_record(w->prior, &last_blocks, &addr_of_id);
+    blocks.push_back({new MarginalizationFactor(info), last_blocks});
+  }
+  for (int i = 0; i + 1 < F; ++i) {
+    if (w->use_leg)
+      blocks.push_back({new IMULegFactor(il_from_record(&w->preint[i])),
+                        {para_Pose[i], para_SpeedBias[i], para_LegBias[i], para_Pose[i + 1], para_SpeedBias[i + 1], para_LegBias[i + 1]}});
+    else
+      blocks.push_back({new IMUFactor(imu_from_record(&w->preint_imu[i])), {para_Pose[i], para_SpeedBias[i], para_Pose[i + 1], para_SpeedBias[i + 1]}});
+  }
+  for (int k = 0; k < L; ++k) {
+    const int o0 = w->lm_obs_offset[k], o1 = w->lm_obs_offset[k + 1], imu_i = w->lm_start_frame[k];
+    const double *f0 = w->obs + 11 * o0;
+    for (int o = o0; o < o1; ++o) {
+      const int imu_j = imu_i + (o - o0);
+      const double *fj = w->obs + 11 * o;
+      if (imu_j != imu_i)
+        blocks.push_back({new ProjectionTwoFrameOneCamFactor(v3(f0), v3(fj), Eigen::Vector2d(f0[6], f0[7]), Eigen::Vector2d(fj[6], fj[7]), f0[10], fj[10]),
+                          {para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], &featbuf[k], para_Td[0]}});
+      if (w->obs_is_stereo[o]) {
+        if (imu_j != imu_i)
+          blocks.push_back({new ProjectionTwoFrameTwoCamFactor(v3(f0), v3(fj + 3), Eigen::Vector2d(f0[6], f0[7]), Eigen::Vector2d(fj[8], fj[9]), f0[10], fj[10]),
+                            {para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Ex_Pose[1], &featbuf[k], para_Td[0]}});
+        else
+          blocks.push_back({new ProjectionOneFrameTwoCamFactor(v3(f0), v3(fj + 3), Eigen::Vector2d(f0[6], f0[7]), Eigen::Vector2d(fj[8], fj[9]), f0[10], fj[10]),
+                            {para_Ex_Pose[0], para_Ex_Pose[1], &featbuf[k], para_Td[0]}});
+      }
+    }
+  }
+  *n_factors_out = (int)blocks.size();
+  std::vector<double> res(128), jac(128 * 128);
+  std::vector<double *> jp(16);
+  double sink = 0.0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int r = 0; r < reps; ++r)
+    for (Blk &b : blocks) {
+      const int nr = b.f->num_residuals();
+      int off = 0;
+      for (size_t q = 0; q < b.p.size(); ++q) { jp[q] = jac.data() + off; off += nr * b.f->parameter_block_sizes()[q]; }
+      b.f->Evaluate(b.p.data(), res.data(), jp.data());
+      sink += res[0];
+    }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (sink == 12345.678) *n_factors_out = -1;   // (keeps the loop)
+  return ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / reps;
 }
 
 }  // extern "C"

@@ -89,3 +89,14 @@ def repropagate_imu_leg(cfg, samples, lin0, lins):
                                       C.c_int(s.shape[0] - 1), lin0.ctypes.data_as(O.dp), C.c_int(lins.shape[0]), lins.ctypes.data_as(O.dp),
                                       C.cast(out.ctypes.data, C.POINTER(O.Preint)))
     return out
+
+
+def time_evaluate(cfg, w, reps=20):
+    """Seconds per pass over ALL cost functions of window w (prior, IMULegFactors, projection factors as Estimator::optimization adds them),
+    each Evaluate()d with Jacobians by the compiled reference, timed inside the library; and the number of residual blocks per pass."""
+    L = ref_lib()
+    L.ref_time_evaluate.restype = C.c_double
+    d, s = w.desc(O)
+    n = C.c_int(0)
+    t = L.ref_time_evaluate(C.byref(cfg), C.byref(d), C.byref(s), C.c_int(reps), C.byref(n))
+    return t, n.value
