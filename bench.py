@@ -525,28 +525,38 @@ def init_control_plane(rank, world, local_rank, want=None, probe_timeout_s=120.0
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if want != "nccl":
         return ControlPlane(dist, None, "gloo", "VILO_BENCH_BACKEND=%s" % want)
-    res = {"ok": 0, "err": "probe did not return within %.0f s" % probe_timeout_s, "group": None}
+    # Agree over gloo FIRST on whether a probe can be attempted at all: dist.new_group is a collective every rank must enter, so no rank
+    # may go into it while a peer has already decided against (no GPU visible to it) — the others would sit in it until the deadline. The
+    # same exchange finds two ranks on one device ("Duplicate GPU detected" inside RCCL otherwise, after a communicator is half built).
+    have = 1 if torch.cuda.is_available() and torch.cuda.device_count() > 0 else 0
+    mine = torch.tensor([have, local_rank if have else -1 - rank], dtype=torch.int64)
+    every = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(every, mine)
+    devs = [int(e[1]) for e in every]
+    if not all(int(e[0]) for e in every):
+        return ControlPlane(dist, None, "gloo", "RCCL unavailable, control collectives over gloo: a rank sees no GPU (agreed before any rank built a communicator)")
+    if len(set(devs)) != world:
+        return ControlPlane(dist, None, "gloo", "RCCL unavailable, control collectives over gloo: ranks share a device %r (RCCL refuses duplicate GPUs; agreed before any rank built a communicator)" % (devs,))
+    g = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=60))   # every rank enters: agreed above; lazy — no communicator yet
+    res = {"ok": 0, "err": "probe did not return within %.0f s" % probe_timeout_s}
 
-    def probe():
+    def probe():   # the first collective builds the communicator: that is what can fail or hang, so it runs under a deadline
         try:
-            if not torch.cuda.is_available():
-                raise RuntimeError("no GPU visible to this rank")
-            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=60))
             t = torch.ones(1, dtype=torch.float64, device="cuda:%d" % local_rank)
             dist.all_reduce(t, group=g)
             torch.cuda.synchronize()
             if int(t.item()) != world:
                 raise RuntimeError("probe all-reduce returned %r, expected %d" % (t.item(), world))
-            res.update(ok=1, err=None, group=g)
+            res.update(ok=1, err=None)
         except BaseException as e:   # (DistBackendError, RuntimeError, ... : anything means "not over RCCL on this box")
             res.update(ok=0, err=repr(e)[:300])
     th = threading.Thread(target=probe, daemon=True)
     th.start()
     th.join(probe_timeout_s)
     flag = torch.tensor([res["ok"] if not th.is_alive() else 0], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # gloo: every rank learns whether every probe succeeded
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # gloo, main thread, after the probe thread returned or was given up: every rank learns whether every probe succeeded
     if int(flag.item()) == 1:
-        return ControlPlane(dist, res["group"], "nccl", "RCCL probe all-reduce succeeded on every rank")
+        return ControlPlane(dist, g, "nccl", "RCCL probe all-reduce succeeded on every rank")
     return ControlPlane(dist, None, "gloo", "RCCL unavailable, control collectives over gloo: %s" % (res["err"] or "a peer's probe failed"))
 
 

@@ -1,5 +1,5 @@
-// Eight-wave solver for gfx950, the form of batches that leave most of the chip idle (one workgroup = one window per CU, up to 256
-// windows): what ceres::Solve does per linearisation for Estimator::optimization(), estimator.cpp:1221-1236 — DENSE_SCHUR + traditional
+// Eight-wave solver for gfx950, the form of batches that leave most of the chip idle (one workgroup = one window per CU; used up to 512
+// windows — VILO_MW8_MAX_WINDOWS — in a second round of workgroups from 257 on): what ceres::Solve does per linearisation for Estimator::optimization(), estimator.cpp:1221-1236 — DENSE_SCHUR + traditional
 // DOGLEG, Ceres 1.14 semantics. At this size a solve is ONE latency chain per window, so the window's work is cut into roles that run side
 // by side, two waves per SIMD at 256 registers each (the four-wave form this replaces ran its serial parts on one wave each):
 //

@@ -264,6 +264,13 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
     }
     const int F = d.n_frames, L = d.n_landmarks;
+    // the observation table is indexed through lm_obs_offset: [0] = 0, non-decreasing, [L] = n_obs — a window that comes out of a file
+    // (vilo_window_io.h) is untrusted, and the packing below reads obs[11 * (offset + t)] for t < K
+    if (L > 0) {
+      bool ok = d.n_obs >= 0 && d.lm_obs_offset[0] == 0 && d.lm_obs_offset[L] == d.n_obs;
+      for (int l = 0; ok && l < L; ++l) ok = d.lm_obs_offset[l + 1] >= d.lm_obs_offset[l] && d.lm_start_frame[l] >= 0 && d.lm_start_frame[l] < F;
+      if (!ok) { ctx->err = "lm_obs_offset must start at 0, not decrease and end at n_obs; start frames must lie in the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+    }
     WinMeta &wm = wins[w];
     memset(&wm, 0, sizeof(wm));
     wm.n_frames = F; wm.L = L; wm.use_leg = d.use_leg; wm.pad = -1;
@@ -332,7 +339,16 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
     lm_total += L;
     const vilo_prior *pr = vilo_win_prior(d, rf);
     if (pr && pr->valid && pr->n > 0) {
-      if (pr->n > VILO_MAX_PRIOR_DIM || pr->n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+      if (pr->n > VILO_MAX_PRIOR_DIM || pr->n_blocks < 0 || pr->n_blocks > VILO_MAX_PRIOR_BLOCKS) { vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+      // block tables: sizes are the global sizes the estimator uses (1, 4, 7, 9), a block's local rows lie inside the prior, its id
+      // names a block kind and index that exist (kind * 16 + index; the assembly indexes its LDS image through these)
+      for (int k = 0; k < pr->n_blocks; ++k) {
+        const int gs = pr->block_size[k], ls = gs == 7 ? 6 : gs, idx = pr->block_idx[k], id = pr->block_id[k];
+        static const int kind_size[5] = {7, 9, 4, 7, 1};   // VILO_BLK_POSE, _SB, _LB, _EX, _TD
+        if (id < 0 || id >= 16 * 5 || gs != kind_size[id >> 4] || (id & 15) >= ((id >> 4) == VILO_BLK_EX ? 2 : (id >> 4) == VILO_BLK_TD ? 1 : VILO_MAX_FRAMES) || idx < 0 || idx + ls > pr->n) {
+          ctx->err = "prior block table out of range"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
+        }
+      }
       any_prior = true;
     }
   }

@@ -67,6 +67,11 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   return VILO_OK;
 }
 
+extern "C" int vilo_device_count(void) {
+  int ndev = 0;
+  return (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ? ndev : 0;
+}
+
 extern "C" void vilo_destroy(vilo_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);

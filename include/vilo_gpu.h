@@ -170,6 +170,9 @@ typedef struct vilo_batch vilo_batch;  /* device-resident batch of independent w
 /* Replaces Estimator::setParameter (estimator.cpp:112-174) for the solver side. device = HIP ordinal. */
 int vilo_create(vilo_ctx **ctx, const vilo_config *cfg, int device);
 void vilo_destroy(vilo_ctx *ctx);
+/* HIP devices this process sees (0 without a usable device): the "host thread per GPU" form of SURVEY 8(e) creates one context per ordinal
+ * below it, each used from its own thread (tests/host_check/multi_device_check.cpp). */
+int vilo_device_count(void);
 const char *vilo_last_error(const vilo_ctx *ctx);
 
 /* ---- ceres::CostFunction-shaped batched factor evaluation (host pointers) ------------------------
@@ -328,7 +331,7 @@ int vilo_debug_marg_general_count(const vilo_ctx *ctx);
  * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
 int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
 /* Solver form of the batches this context solves from here on. VILO_SOLVER_AUTO (default) picks by batch size: eight waves per window
- * (one workgroup per window, its waves in fixed roles) up to 256 windows, one wave up to 1024, the single wave in three kernels beyond. All
+ * (one workgroup per window, its waves in fixed roles) up to 512 windows (VILO_MW8_MAX_WINDOWS; one per CU, a second round from 257 on), one wave up to 1024, the single wave in three kernels beyond. All
  * forms restate the same algorithm; the eight-wave form eliminates in another order and agrees with the single wave to rounding (1e-9 on
  * well-conditioned windows), SPLIT and WAVE agree bitwise. Pin a form when a window must get the same answer whatever the size of the
  * batch it shares. The environment variable VILO_SOLVER (wave | mw8 | split) only sets the default a context is created with. */
