@@ -350,7 +350,7 @@ def go1_config(cfg):
     return c
 
 
-def replay_block(device, n_images=170, cpu_budget_s=10.0, seed=505, keep_dir=None):
+def replay_block(device, n_images=170, cpu_budget_s=10.0, seed=505, keep_dir=None, prior_form="factor"):
     """BASELINE configs[4] / [0] (a bag replayed through the estimator, launch/dataset/run_campus_bag_vilo.launch:3-6, src/main.cpp:95-202) with
     the stand-in this container allows: a synthetic Go1-parameter stream (trot, 500 Hz IMU + joints + foot forces, 15 Hz stereo features) written
     as a ROS bag, read back through the bag reader (cerberus_amd/host/vilo_rosbag.cpp) and fed message by message through the node's logic
@@ -363,6 +363,9 @@ def replay_block(device, n_images=170, cpu_budget_s=10.0, seed=505, keep_dir=Non
     from cerberus_amd import api, rosbag, sequence, synth, window_io
     cfg5 = go1_config(synth.default_config())
     ctx5 = api.Context(cfg5, device=device)
+    # nobody looks at the rows of the prior's J0 in a replay (it is only ever used through J0^T J0, J0^T r0, |r0|^2): the marginalisation may
+    # leave the pivoted Cholesky factor where no eigenvalue would be dropped (include/vilo_gpu.h: vilo_set_prior_form) instead of sqrt(S) V^T
+    ctx5.set_prior_form(prior_form)
     tmp = keep_dir or tempfile.mkdtemp(prefix="vilo_replay_")
     dumps = os.path.join(tmp, "windows")
     os.makedirs(dumps, exist_ok=True)
@@ -452,7 +455,7 @@ def replay_block(device, n_images=170, cpu_budget_s=10.0, seed=505, keep_dir=Non
                         "rosbag-v2 file (%d messages, %d bytes), read back through the bag reader and replayed message by message through the node's "
                         "logic into the sliding-window estimator on one GPU" % (n_images, len(msgs), os.path.getsize(bag)),
             "value": 1e3 / est_ms, "unit": "images/s (estimator time per image = wall time inside the library's entry points, what a C++ node pays: every message in, preintegration push, batch build, solve, gauge fix, marginalisation, slide)",
-            "images": len(per_image), "steady_images": len(steady),
+            "images": len(per_image), "steady_images": len(steady), "prior_form": prior_form,
             "ms_per_image": {"estimator": est_ms, "solve_gpu": solve_ms, "marginalise_gpu": marg_ms,
                              "preintegration_push_batch_build_and_host_bookkeeping": est_ms - solve_ms - marg_ms,
                              "estimator_through_the_python_wrappers": py_ms,

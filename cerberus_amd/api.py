@@ -232,6 +232,11 @@ class Context:
         """vilo_set_solver_form: 'auto' (by batch size), 'wave', 'split' (bitwise equal to 'wave'), 'mw8'."""
         self._check(lib().vilo_set_solver_form(self.h, self.SOLVER_FORMS[form]))
 
+    def set_prior_form(self, form):
+        """vilo_set_prior_form: 'eigen' (J0 = sqrt(S) V^T like the reference, default) or 'factor' (pivoted Cholesky factor where no
+        eigenvalue would be dropped: same J0^T J0 / J0^T r0, a quarter of a single window's marginalisation time)."""
+        self._check(lib().vilo_set_prior_form(self.h, {"eigen": 0, "factor": 1}[form]))
+
     def set_compact_rows(self, on):
         """vilo_set_compact_rows: batches created afterwards may / may not use the compact 16-column visual rows."""
         self._check(lib().vilo_set_compact_rows(self.h, 1 if on else 0))

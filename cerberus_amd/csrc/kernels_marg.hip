@@ -458,9 +458,16 @@ __device__ __forceinline__ void jacobi_sweeps(double *P, double *part /* [3][JW]
   }
 }
 
+// factor_form (vilo_set_prior_form(ctx, VILO_PRIOR_FACTOR): callers that never look at J0 itself — a resident prior pool): the prior is
+// only ever used through J0^T J0, J0^T r0 and |r0|^2, which any X with X X^T = A' gives alike with J0 = X^T, r0 = X^-1 b — the reference's
+// sqrt(S) V^T is Q X^T for an orthogonal Q. What the eigen form adds is the threshold: eigenvalues <= eps are dropped
+// (marginalization_factor.cpp:297-305). So the pivoted Cholesky factor is taken as it stands IF it has full rank AND lambda_min(A') > eps is
+// certain: lambda_min = 1 / |X^-1|_2^2 >= 1 / |X^-1|_F^2, and X^-1 comes out of the same forward substitutions that give r0 (n unit
+// right-hand sides beside b, 8 lanes per column; ~30 k cycles instead of the sweeps' 1.5 M). Anything else goes on to the sweeps.
 __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetric, destroyed */, double *P /* MG_NMAX x MG_LD */, const double *br, int n, double eps,
-                                 double *cs /* LDS [96] */, double *J0, double *r0, int *status_w, long long *clk_w /* [8] or null */) {
-  __shared__ int bad, conv;
+                                 double *cs /* LDS [96] */, double *J0, double *r0, int *status_w, long long *clk_w /* [8] or null */, bool factor_form) {
+  __shared__ int bad, conv, fast_ok;
+  __shared__ int piv[MG_NMAX];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ty = tid >> 5, tx = tid & 31;
   for (int e = tid; e < MG_NMAX * MG_LD; e += MGT) P[e] = 0.0;
@@ -484,7 +491,12 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
   int r = 0;
   {
     __shared__ double dgb[2][MG_NMAX];   // the diagonal, double-buffered: step k reads [k & 1] while the finished rows write [(k + 1) & 1]
-    if (tid < MG_NMAX) dgb[0][tid] = (tid < n) ? Ar[tid * (MG_LD + 1)] : 0.0;
+    __shared__ double dinv0[MG_NMAX];   // 1 / (the diagonal A' started with): what a remaining diagonal entry is measured against (factor form)
+    if (tid < MG_NMAX) {
+      const double d_ = (tid < n) ? Ar[tid * (MG_LD + 1)] : 0.0;
+      dgb[0][tid] = d_;
+      dinv0[tid] = (d_ > 0.0) ? 1.0 / d_ : 0.0;
+    }
     __syncthreads();
     const int ri = tid >> 3, rq = tid & 7, ric = min(ri, MG_NMAX - 1);
     bool taken = ri >= n;
@@ -506,6 +518,17 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
         if (d1 > 0.0) best = fmax(best, __hiloint2double(__double2hiint(d1), (__double2loint(d1) & ~127) | (63 - lane)));
         best = wave_max_nonneg(best);
         if (!(best > 0.0)) { done = true; break; }
+        // factor form: what is left of A' is positive semi-definite with trace <= (n - k) * (largest diagonal entry); once that is <= eps
+        // every eigenvalue of the remainder is, and the eigen form would drop them too (a sequence's prior never fixes the four gauge
+        // directions: their pivots come out as +- 1e-9 noise, and a factor that carried them on could not be certified below)
+        if (factor_form) {
+          if (best * (double)(n - k) <= eps) { done = true; break; }
+          // ... or when every remaining diagonal entry is rounding noise of the entry it started as (<= 1e-12 of it: n u times the growth
+          // of the elimination) — with information up to 1e15 in A' the gauge pivots come out as +- 1e-2, far above eps, and an eigen
+          // decomposition keeps or drops such a direction by the sign its noise happens to have
+          const double rel = wave_max_nonneg(fmax(d0 * dinv0[lane], d1 * ((lane + 64 < MG_NMAX) ? dinv0[l1] : 0.0)));
+          if (rel <= 1e-12) { done = true; break; }
+        }
         const int j = 127 - (__double2loint(best) & 127);
         const double pv = dg[j], aij = Ar[ric * MG_LD + j];
         double acc = 0.0;
@@ -522,6 +545,7 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
           P[k * MG_LD + ri] = x;
           dgb[(k + 1) & 1][ri] = taken ? 0.0 : dg[ri] - x * x;
         }
+        if (tid == 0) piv[k] = j;
         __syncthreads();
         ++r;
       }
@@ -533,6 +557,58 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
   }
   __syncthreads();
   if (clk_w && tid == 0) clk_w[7] = (long long)__builtin_readcyclecounter();
+  if (factor_form && r >= 1) {
+    // X (n x r, r <= n: a semi-definite A' — the four gauge directions no prior of a sequence ever fixes — stops the factorisation at the
+    // first pivot <= 0, and what is left of A' then is rounding noise the eigen form drops as well). Its pivot rows form a lower triangle
+    // X_p in pivot order; sigma_min(X) >= sigma_min(X_p) >= 1 / |X_p^-1|_F. X_p y = v by forward substitution: step k fixes y[k] from row
+    // piv[k]. Column c < r: v = e_c (a column of X_p^-1); column r: v = b on the pivot rows (b lies in the range of A' up to rounding, so
+    // J0^T r0 = X X_p^-1 b_p reproduces it). Thread (c, q) = (tid / 8, tid % 8) sums the products k' = q mod 8; Y[k][c] in the spent A'.
+    double *Y = Ar;
+    const int c = tid >> 3, q = tid & 7, cc = min(c, r);
+    double ssq = 0.0;
+    for (int k = 0; k < r; ++k) {
+      const int j = piv[k];
+      double acc = 0.0;
+      for (int kk = q; kk < k; kk += 8) acc += P[kk * MG_LD + j] * Y[kk * MG_LD + cc];
+      acc += dpp_mov<0xB1>(0.0, acc);
+      acc += dpp_mov<0x4E>(0.0, acc);
+      acc += dpp_mov<0x141>(0.0, acc);
+      if (q == 0 && c <= r) {
+        const double rhs = (c < r) ? (c == k ? 1.0 : 0.0) : br[j];
+        const double y = (rhs - acc) / P[k * MG_LD + j];
+        Y[k * MG_LD + c] = y;
+        if (c < r) ssq += y * y;
+      }
+      lds_fence();   // (the column's next step reads what lane q == 0 of these 8 lanes just wrote: same wave, LDS operations in order)
+    }
+    if (tid == 0) fast_ok = 0;
+    if (tid < MG_NMAX) cs[tid] = 0.0;
+    __syncthreads();
+    if (q == 0 && c < r) cs[c] = ssq;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int i = 0; i < r; ++i) tot += cs[i];
+      fast_ok = (isfinite(tot) && tot * eps < 1.0) ? 1 : 0;   // 1 / |X_p^-1|_F^2 > eps: no eigenvalue of X X^T in (0, eps]
+    }
+    __syncthreads();
+    if (fast_ok) {
+      if (tid < n) {
+        const double rv = (tid < r) ? Y[tid * MG_LD + r] : 0.0;
+        r0[tid] = rv;
+        if (!isfinite(rv) || bad) *status_w = 1;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int i = ty + 32 * a;
+        if (i >= n) continue;
+        for (int j = tx; j < n; j += 32) J0[i * n + j] = (i < r) ? P[i * MG_LD + j] : 0.0;
+      }
+      if (clk_w && tid == 0) clk_w[5] = (long long)__builtin_readcyclecounter();
+      return;
+    }
+    __syncthreads();
+  }
   const int ne = max(4, (r + 1) & ~1), h = ne >> 1;   // zero columns fill up; at least two pairs, so the move below has no special case
   static_assert(JW * 12 >= MG_NMAX && JW <= MGT / 64, "row split of the Jacobi sweeps");
   double *part = Ar;   // [3][JW][48] partial dot products; A' is spent
@@ -564,7 +640,7 @@ __device__ void prior_factor_lds(double *Ar /* n x n, ld MG_LD, bitwise symmetri
 }
 
 __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const MargWin *mw, const int *drop_lm, int max_l0, double *J0_out,
-                                                         double *r0_out, int *status, int *need_general, long long *clk /* [W][8] or null */) {
+                                                         double *r0_out, int *status, int *need_general, long long *clk /* [W][8] or null */, int factor_form) {
   extern __shared__ double ml[];
   double *A1 = ml, *tile = ml + MG_TILE_OFF;
   double *b1 = ml + MG_R0, *dinv = b1 + MG_TMAX, *deps = dinv + MG_TILE, *gl = deps + MG_TILE, *Ce = gl + MG_TILE, *cs = Ce + 19 * 19;
@@ -805,7 +881,7 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   __syncthreads();
   stamp(4);
   double *J0 = J0_out + (size_t)win * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, *r0 = r0_out + (size_t)win * VILO_MAX_PRIOR_DIM;
-  prior_factor_lds(Ar, V2, br, n, eps, cs, J0, r0, &status[win], clk ? clk + win * 8 : nullptr);
+  prior_factor_lds(Ar, V2, br, n, eps, cs, J0, r0, &status[win], clk ? clk + win * 8 : nullptr, factor_form != 0);
   stamp(6);
 }
 
@@ -1078,7 +1154,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   std::vector<int> general(W, force_general ? 1 : 0);
   if (!force_general) {
     hipLaunchKernelGGL(k_marginalize_lds, dim3(W), dim3(MGT), lds_bytes, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_J0.as<double>(),
-                       d_r0.as<double>(), d_status.as<int>(), d_general.as<int>(), want_clk ? d_clk.as<long long>() : nullptr);
+                       d_r0.as<double>(), d_status.as<int>(), d_general.as<int>(), want_clk ? d_clk.as<long long>() : nullptr, ctx->prior_form);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize_lds launch failed"; return fail(VILO_ERR_HIP); }
     if (hipMemcpy(general.data(), d_general.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
     if (want_clk) {

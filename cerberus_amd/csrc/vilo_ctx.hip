@@ -97,6 +97,12 @@ extern "C" int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode) {
   ctx->sqrt_info_mode = mode;
   return VILO_OK;
 }
+// Form of the square root a marginalisation leaves (include/vilo_gpu.h).
+extern "C" int vilo_set_prior_form(vilo_ctx *ctx, int form) {
+  if (!ctx || (form != VILO_PRIOR_EIGEN && form != VILO_PRIOR_FACTOR)) return VILO_ERR_BAD_ARG;
+  ctx->prior_form = form;
+  return VILO_OK;
+}
 // Which of the solver's forms the batches of this context take. The forms restate one algorithm; the multi-wave ones differ from the
 // single wave in elimination order and agree with it to rounding, not bitwise, so a caller that needs the same answer for a window
 // whatever the size of the batch it shares pins one (the choice is part of the key of a batch's captured launch sequence).

@@ -42,6 +42,7 @@ struct vilo_ctx {
   double kernel_ms[VILO_NKERNEL];
   long long kernel_launches[VILO_NKERNEL];
   double initial_mu = 1e-8;         // DoglegStrategy's mu at the start of a solve (Ceres: min_mu; vilo_debug_set_initial_mu: per-step comparisons with the oracle)
+  int prior_form = 0;               // vilo_set_prior_form: 0 J0 = sqrt(S) V^T as the reference writes it, 1 any X^T with X X^T = A' (pivoted Cholesky factor) where no eigenvalue would be dropped
   int sqrt_info_mode = 0;           // 0: Cholesky of the index-reversed covariance + triangular inverse; 1: the reference's inverse() + LLT, literally
   bool wave_attr_set = false, mid_attr_set = false, mw8_attr_set = false, asm_s_attr_set = false, marg_attr_set = false, prior_attr_set = false;   // dynamic-LDS opt-ins done on this context's device
   // solver form of the batches this context solves (vilo_set_solver_form; -1: chosen from the batch size) and whether batches created on it

@@ -330,6 +330,19 @@ int vilo_debug_marg_general_count(const vilo_ctx *ctx);
  * forming the inverse of a covariance whose condition number is 1e13..1e14. 1: the reference's route literally (inverse by pivoted Gauss-Jordan
  * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
 int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
+/* Form of the prior's square root that vilo_marginalize / vilo_batch_marginalize / vilo_optimize_windows* leave (per context).
+ * VILO_PRIOR_EIGEN (default): J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b over the eigenpairs with S > 1e-8, what MarginalizationInfo::marginalize
+ * writes (marginalization_factor.cpp:297-305; rows of J0 mutually orthogonal, defined up to order and sign).
+ * VILO_PRIOR_FACTOR: J0 = X^T, r0 = X_p^-1 b_p for the diagonally pivoted Cholesky factor X X^T = A' (n x r; a semi-definite A' — the
+ * gauge directions — gives r < n, the rest of J0 is zero rows like the eigen form's dropped ones; X_p: its pivot rows), wherever the
+ * device certifies that X X^T has no eigenvalue in (0, 1e-8]  (1 / |X_p^-1|_F^2 > 1e-8) — an orthogonal transformation of the eigen
+ * form: J0^T J0, J0^T r0 and |r0|^2, which is all MarginalizationFactor::Evaluate's contribution to a solve depends on, are the same to
+ * rounding, but the ROWS of J0 (and the residual vector of the factor) are in another basis. A window that cannot be certified gets the
+ * eigen form. For callers that never look at J0 itself (a replay, a resident prior pool): a single window's marginalisation takes a
+ * quarter of the time. */
+#define VILO_PRIOR_EIGEN 0
+#define VILO_PRIOR_FACTOR 1
+int vilo_set_prior_form(vilo_ctx *ctx, int form);
 /* Solver form of the batches this context solves from here on. VILO_SOLVER_AUTO (default) picks by batch size: eight waves per window
  * (one workgroup per window, its waves in fixed roles) up to 512 windows (VILO_MW8_MAX_WINDOWS; one per CU, a second round from 257 on), one wave up to 1024, the single wave in three kernels beyond. All
  * forms restate the same algorithm; the eight-wave form eliminates in another order and agrees with the single wave to rounding (1e-9 on

@@ -26,8 +26,9 @@ def block_table(prior):
 
 def scaled_errors(prior, H_exact, b_exact, exact_blocks):
     """prior: a synth.PriorData (any block order); H_exact / b_exact in the order exact_blocks = block_table(the oracle's prior) describes.
-    Returns (worst |dH_ij| / sqrt(H_ii H_jj) over all kept block pairs, worst |db_i| / sqrt(H_ii), the same two normalised by the largest
-    entry of H / b instead — what the tests used before)."""
+    Returns (worst |dH_ij| / sqrt(H_ii H_jj) over all kept block pairs, worst |db_i| / sqrt(H_ii) relative to max(1, max_i |b_i| / sqrt(H_ii))
+    — the gradient in whitened units, held to the accuracy of its largest component —, the same two normalised by the largest entry of H / b
+    instead: what the tests used before)."""
     n = prior.struct.n
     J, r = prior.J0[: n * n].reshape(n, n), prior.r0[:n]
     H, g = J.T @ J, J.T @ r
@@ -44,4 +45,4 @@ def scaled_errors(prior, H_exact, b_exact, exact_blocks):
             diff = np.abs(H[ia:ia + la, ic:ic + lc] - H_exact[ja:ja + la, jc:jc + lc])
             eh = max(eh, float((diff / np.outer(d[ja:ja + la], d[jc:jc + lc])).max()))
             gh = max(gh, float(diff.max() / np.abs(H_exact).max()))
-    return eh, eb, gh, gb
+    return eh, eb / max(1.0, float(np.abs(b_exact / d).max())), gh, gb

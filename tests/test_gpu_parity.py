@@ -691,6 +691,61 @@ def test_marginalize_seed_sweep(ctx, cfg, ocfg):
     print("worst relative deviation of J0^T J0 / J0^T r0 from the oracle over the sweep: %.2e" % worst)
 
 
+def test_prior_factor_form_carries_the_same_information(cfg, ocfg):
+    """vilo_set_prior_form(VILO_PRIOR_FACTOR): where A' has full rank and lambda_min(A') > eps is certified, the marginalisation leaves the
+    pivoted Cholesky factor (J0 = X^T, r0 = X^-1 b) instead of sqrt(S) V^T (marginalization_factor.cpp:297-305) — an orthogonal
+    transformation of it. Everything a solve takes from the prior is the same to rounding: J0^T J0, J0^T r0 per entry in units of the
+    diagonal, |r0|^2; the rows themselves are NOT orthogonal any more (that is how the test knows the path was taken). A window without
+    a prior (A' semi-definite: the gauge directions, as in every real sequence) gives a factor of n - 4 columns and as many non-zero rows
+    as the eigen form keeps. And a solve from the factor-form prior gives the states of the solve from the eigen-form one."""
+    from cerberus_amd import api
+    from cerberus_amd.synth import PriorData
+    ce, cf = api.Context(cfg, 0), api.Context(cfg, 0)
+    cf.set_prior_form("factor")
+    assert api.lib().vilo_set_prior_form(cf.h, 7) != 0
+    try:
+        worst = 0.0
+        for k in range(8):
+            kw = dict(n_landmarks=(12, 60, 200, 700)[k % 4], seed=5000 + k, with_prior=(k % 4 != 3))
+            w = _fresh(cfg, ocfg, **kw)
+            for mode in ((0, 1) if kw["with_prior"] else (0,)):
+                pe, pf = PriorData(), PriorData()
+                ce.marginalize(w, mode, pe)
+                cf.marginalize(w, mode, pf)
+                assert pe.blocks() == pf.blocks() and pe.n == pf.n
+                n = pe.n
+                Je, Jf = pe.J0_matrix(), pf.J0_matrix()
+                if not kw["with_prior"]:
+                    kept_e, kept_f = int((np.abs(Je).max(axis=1) > 0).sum()), int((np.abs(Jf).max(axis=1) > 0).sum())
+                    assert kept_f <= n - 4 and abs(kept_e - kept_f) <= 2, (kept_e, kept_f, n)
+                He, Hf = Je.T @ Je, Jf.T @ Jf
+                d = np.sqrt(np.diag(He))
+                e_h = (np.abs(He - Hf) / np.outer(d, d)).max()
+                e_b = (np.abs(Je.T @ pe.r0[:n] - Jf.T @ pf.r0[:n]) / d).max() / max(1.0, np.abs(Je.T @ pe.r0[:n] / d).max())
+                e_c = abs(pe.r0[:n] @ pe.r0[:n] - pf.r0[:n] @ pf.r0[:n]) / (pe.r0[:n] @ pe.r0[:n])
+                worst = max(worst, e_h, e_b, e_c)
+                # semi-definite A': the eigen form projects b orthogonally onto the eigenvectors it keeps, the factor form reproduces b on the
+                # pivot rows; b's component along the four gauge directions is zero in exact arithmetic and rounding noise here (measured: up to
+                # 9e-6 of the largest whitened gradient entry at 700 landmarks), which is what the two forms differ by
+                tol = (1e-11, 1e-9, 1e-9) if kw["with_prior"] else (1e-9, 1e-4, 1e-6)
+                assert e_h < tol[0] and e_b < tol[1] and e_c < tol[2], (kw, mode, e_h, e_b, e_c)
+                nz = np.abs(Jf).max(axis=1) > 0
+                G = Jf[nz] @ Jf[nz].T
+                dg = np.sqrt(np.diag(G))
+                assert np.abs(G / np.outer(dg, dg) - np.eye(int(nz.sum()))).max() > 1e-3, "the factor form's rows are not mutually orthogonal"
+                # the next solve does not notice
+                we, wf = _fresh(cfg, ocfg, n_landmarks=40, seed=6000 + k), _fresh(cfg, ocfg, n_landmarks=40, seed=6000 + k)
+                if pe.blocks() == we.prior.blocks():   # (a prior over the blocks a fresh window's prior has: MARGIN_OLD's)
+                    we.prior, wf.prior = pe.copy(), pf.copy()
+                    ce.solve_windows([we], api.default_solve_opts(True, 6))
+                    ce.solve_windows([wf], api.default_solve_opts(True, 6))
+                    for a, bb in zip(we.state_arrays(), wf.state_arrays()):
+                        assert np.abs(a - bb).max() < 1e-9 * max(1.0, np.abs(bb).max())
+        print("MEASURED factor form vs eigen form of the prior: worst deviation %.2e" % worst)
+    finally:
+        ce.close(); cf.close()
+
+
 def test_optimize_windows_is_solve_plus_gauge_fix_plus_marginalize(ctx, cfg, ocfg):
     """vilo_optimize_windows (one device batch) against the three separate entry points, and against the oracle's chain."""
     import ctypes as C

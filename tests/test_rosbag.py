@@ -496,7 +496,8 @@ def test_replay_from_a_bag_is_the_replay_from_memory_bit_for_bit(ctx, cfg, tmp_p
 
 
 @pytest.mark.gpu
-def test_go1_parameter_replay_of_a_bag_matches_the_oracle_window_by_window(tmp_path):
+@pytest.mark.parametrize("prior_form", ["factor", "eigen"])
+def test_go1_parameter_replay_of_a_bag_matches_the_oracle_window_by_window(tmp_path, prior_form):
     """bench.py's replay configuration (BASELINE configs[4] stand-in: contact_sensor_type 2 foot forces, calf lengths estimated on line, the
     stream written as a bag and read back): every one of the first 30 windows the estimator solved on the GPU — dumped with the result — is
     solved again by the CPU oracle from the same dumped input (states 1e-8, same iteration count, cost 1e-7), and the prior the estimator
@@ -509,7 +510,9 @@ def test_go1_parameter_replay_of_a_bag_matches_the_oracle_window_by_window(tmp_p
     from oracle import oracle_py as O
     from cerberus_amd import synth
     from test_sliding_window import _oracle_replay
-    r = bench.replay_block(0, n_images=42, cpu_budget_s=0.0, keep_dir=str(tmp_path))
+    # (prior_form: what the marginalisation leaves as J0 — bench.py's replay lets it be the pivoted Cholesky factor, vilo_set_prior_form; the
+    # oracle is handed the dumped prior either way and must reproduce the window's solve and the NEXT prior's normal equations)
+    r = bench.replay_block(0, n_images=42, cpu_budget_s=0.0, keep_dir=str(tmp_path), prior_form=prior_form)
     assert "error" not in r, r
     dumps = os.path.join(str(tmp_path), "windows")
     n = len(os.listdir(dumps))
