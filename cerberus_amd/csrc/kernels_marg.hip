@@ -1027,6 +1027,13 @@ extern "C" int vilo_gauge_fix(vilo_ctx *ctx, int W, const vilo_window_state *bef
 struct vilo_batch;
 BatchDev *vilo_batch_dev(vilo_batch *bt);
 const int *vilo_batch_perm(vilo_batch *bt, int win, int *L);
+int vilo_batch_scratch(vilo_ctx *ctx, vilo_batch *bt, void **p, size_t bytes);   // vilo_batch.hip: arena scratch, freed with the batch
+// per-call buffers out of the batch's arena (they go back to the context's pool with the batch)
+struct ArenaBuf {
+  vilo_ctx *c; vilo_batch *b; void *p = nullptr;
+  hipError_t alloc(size_t n) { return vilo_batch_scratch(c, b, &p, n) == VILO_OK ? hipSuccess : hipErrorOutOfMemory; }
+  template <class T> T *as() { return (T *)p; }
+};
 
 // Marginalisation of every window of an existing batch at its current device state (b.x, b.lam). `state` holds the same
 // values on the host (they become keep_block_data of the new prior); modes[w]: 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW, < 0 skip
@@ -1128,7 +1135,8 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   std::vector<int> drop_flat((size_t)W * max_l0, 0);
   for (int w = 0; w < W; ++w)
     for (size_t i = 0; i < drops[w].size(); ++i) drop_flat[(size_t)w * max_l0 + i] = drops[w][i];
-  DevBuf d_mw, d_drop, d_scr, d_J0, d_r0, d_status, d_general, d_clk;
+  ArenaBuf d_mw{ctx, bt}, d_drop{ctx, bt}, d_J0{ctx, bt}, d_r0{ctx, bt}, d_status{ctx, bt}, d_general{ctx, bt}, d_clk{ctx, bt};
+  DevBuf d_scr;
   const bool want_clk = getenv("VILO_MARG_CLOCKS") != nullptr;
   if (want_clk && d_clk.alloc(sizeof(long long) * 8 * W) != hipSuccess) { return VILO_ERR_HIP; }
   auto fail = [&](int code) { return code; };
@@ -1223,7 +1231,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     }
   }
   if (refs && refs[0].prior_pool) {
-    DevBuf d_dst, d_src;
+    ArenaBuf d_dst{ctx, bt}, d_src{ctx, bt};
     if (d_dst.alloc(sizeof(int) * W) != hipSuccess || d_src.alloc(sizeof(int) * W) != hipSuccess ||
         hipMemcpy(d_dst.p, dst_slot.data(), sizeof(int) * W, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_src.p, src_slot.data(), sizeof(int) * W, hipMemcpyHostToDevice) != hipSuccess)

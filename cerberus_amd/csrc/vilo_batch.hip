@@ -44,6 +44,15 @@ struct vilo_batch {
 
 namespace {
 
+// win_bad[w] = any live interval of window w whose covariance had no sqrt_info (prep_bad, written by the preparation)
+__global__ void k_fold_win_bad(int W, const int *prep_bad, const unsigned char *imu_skip, int *win_bad) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  int bad = 0;
+  for (int k = 0; k < 10; ++k) bad |= (!imu_skip[(size_t)w * 10 + k] && prep_bad[(size_t)w * 10 + k]) ? 1 : 0;
+  win_bad[w] = bad;
+}
+
 // bump allocation out of 64 MB (or larger) arena chunks; chunks are recycled through the context's free list
 int dev_alloc_bytes(vilo_ctx *ctx, vilo_batch *bt, void **p, size_t bytes) {
   *p = nullptr;
@@ -193,6 +202,9 @@ int prior_block_cd(int id, int *state_off) {
 }  // namespace
 
 BatchDev *vilo_batch_dev(vilo_batch *bt) { return &bt->d; }
+// scratch that lives as long as the batch, out of its arena (other translation units: the marginalisation's per-call buffers — a
+// hipMalloc / hipFree pair per buffer costs more than the kernels of a one-window call)
+int vilo_batch_scratch(vilo_ctx *ctx, vilo_batch *bt, void **p, size_t bytes) { return dev_alloc_bytes(ctx, bt, p, bytes); }
 const int *vilo_batch_perm(vilo_batch *bt, int win, int *L) {
   *L = bt->L_host[win];
   return bt->perm_host.data() + bt->lm_off_host[win];
@@ -269,7 +281,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
     if (L > 0) {
       bool ok = d.n_obs >= 0 && d.lm_obs_offset[0] == 0 && d.lm_obs_offset[L] == d.n_obs;
       for (int l = 0; ok && l < L; ++l) ok = d.lm_obs_offset[l + 1] >= d.lm_obs_offset[l] && d.lm_start_frame[l] >= 0 && d.lm_start_frame[l] < F;
-      if (!ok) { ctx->err = "lm_obs_offset must start at 0, not decrease and end at n_obs; start frames must lie in the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+      if (!ok) { ctx->err = "landmark observation table: lm_obs_offset must start at 0, not decrease and end at n_obs; start frames must lie in the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
     }
     WinMeta &wm = wins[w];
     memset(&wm, 0, sizeof(wm));
@@ -595,15 +607,16 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
     D.prep_bad = bt->d_prep_bad;   // (per-interval flags of the records in force: the marginalisation looks at the intervals it uses)
     if (rc == VILO_OK) rc = vilo_batch_prepare(ctx, bt);
     // a covariance that is not positive definite has no sqrt_info: that window alone fails (termination FAILURE, like a non-finite
-    // IterationZero); the flag is looked at for live intervals only
-    std::vector<int> bad((size_t)W * 10, 0), winbad(W, 0);
-    if (rc == VILO_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-                          hipMemcpy(bad.data(), bt->d_prep_bad, sizeof(int) * bad.size(), hipMemcpyDeviceToHost) != hipSuccess)) rc = VILO_ERR_HIP;
+    // IterationZero); the flag is looked at for live intervals only — folded per window on the device (no round trip through the host:
+    // a one-window batch is built for every image of a replay)
+    if (rc == VILO_OK) rc = dev_alloc(ctx, bt, &D.win_bad, (size_t)W);
+    if (rc == VILO_OK) {
+      hipLaunchKernelGGL(k_fold_win_bad, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, W, bt->d_prep_bad, D.imu_skip, D.win_bad);
+      if (hipGetLastError() != hipSuccess) rc = VILO_ERR_HIP;
+    }
+    // (the uploads above came out of this call's host vectors and the context's reusable staging: they are complete when it returns)
+    if (rc == VILO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = VILO_ERR_HIP;
     if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
-    for (int w = 0; w < W; ++w)
-      for (int k = 0; k < 10; ++k)
-        if (!iskip[(size_t)w * 10 + k] && bad[(size_t)w * 10 + k]) winbad[w] = 1;
-    if (dev_upload(ctx, bt, &D.win_bad, winbad) != VILO_OK) { vilo_batch_destroy(ctx, bt); return VILO_ERR_HIP; }
   }
   const double t_prep = now();
   int rc = vilo_batch_reset(ctx, bt);
