@@ -885,6 +885,12 @@ __global__ void __launch_bounds__(MGT) k_marginalize_lds(BatchDev bd, const Marg
   stamp(6);
 }
 
+// flag[w] = the IMU factor of interval 0 is live and its covariance had no sqrt_info
+__global__ void k_marg_imu0_bad(int W, const int *prep_bad, const unsigned char *imu_skip, int *flag) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < W) flag[w] = (!imu_skip[(size_t)w * 10] && prep_bad[(size_t)w * 10]) ? 1 : 0;
+}
+
 // new priors of pooled windows: device to device into their slot (n x n packed, ld n); src >= 0: the unchanged prior moves
 // from slot src to slot dst (MARGIN_SECOND_NEW with nothing to drop)
 __global__ void __launch_bounds__(256) k_prior_scatter(int W, const MargWin *mw, const int *dst, const int *src, const double *J0, const double *r0, double *pJ,
@@ -1028,6 +1034,7 @@ struct vilo_batch;
 BatchDev *vilo_batch_dev(vilo_batch *bt);
 const int *vilo_batch_perm(vilo_batch *bt, int win, int *L);
 int vilo_batch_scratch(vilo_ctx *ctx, vilo_batch *bt, void **p, size_t bytes);   // vilo_batch.hip: arena scratch, freed with the batch
+struct View { void *p; template <class T> T *as() { return (T *)p; } };   // a typed look at part of a buffer
 // per-call buffers out of the batch's arena (they go back to the context's pool with the batch)
 struct ArenaBuf {
   vilo_ctx *c; vilo_batch *b; void *p = nullptr;
@@ -1135,20 +1142,25 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   std::vector<int> drop_flat((size_t)W * max_l0, 0);
   for (int w = 0; w < W; ++w)
     for (size_t i = 0; i < drops[w].size(); ++i) drop_flat[(size_t)w * max_l0 + i] = drops[w][i];
-  ArenaBuf d_mw{ctx, bt}, d_drop{ctx, bt}, d_J0{ctx, bt}, d_r0{ctx, bt}, d_status{ctx, bt}, d_general{ctx, bt}, d_clk{ctx, bt};
+  // One arena block for what goes up (window tables, dropped-landmark lists) and the flags that come back (status, need_general, "the
+  // IMU factor of interval 0 stands on a covariance without sqrt_info"): one upload, one download per call — a one-window call per image
+  // used to spend more time in its dozen synchronous copies and allocations than in its kernels.
+  ArenaBuf d_blob{ctx, bt}, d_J0{ctx, bt}, d_r0{ctx, bt}, d_clk{ctx, bt};
   DevBuf d_scr;
   const bool want_clk = getenv("VILO_MARG_CLOCKS") != nullptr;
   if (want_clk && d_clk.alloc(sizeof(long long) * 8 * W) != hipSuccess) { return VILO_ERR_HIP; }
   auto fail = [&](int code) { return code; };
-  if (d_mw.alloc(sizeof(MargWin) * W) != hipSuccess || d_drop.alloc(sizeof(int) * drop_flat.size()) != hipSuccess ||
-      d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
-      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess || d_status.alloc(sizeof(int) * W) != hipSuccess ||
-      d_general.alloc(sizeof(int) * W) != hipSuccess)
+  const size_t off_drop = (sizeof(MargWin) * (size_t)W + 15) & ~(size_t)15, off_flags = (off_drop + sizeof(int) * drop_flat.size() + 15) & ~(size_t)15;
+  const size_t blob_bytes = off_flags + sizeof(int) * 3 * (size_t)W;
+  std::vector<char> hblob(blob_bytes, 0);
+  memcpy(hblob.data(), mws.data(), sizeof(MargWin) * (size_t)W);
+  if (!drop_flat.empty()) memcpy(hblob.data() + off_drop, drop_flat.data(), sizeof(int) * drop_flat.size());
+  if (d_blob.alloc(blob_bytes) != hipSuccess || d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
+      d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess)
     return fail(VILO_ERR_HIP);
-  if (hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_drop.p, drop_flat.data(), sizeof(int) * drop_flat.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(d_status.p, 0, sizeof(int) * W) != hipSuccess || hipMemset(d_general.p, 0, sizeof(int) * W) != hipSuccess)
-    return fail(VILO_ERR_HIP);
+  View d_mw{d_blob.p}, d_drop{(char *)d_blob.p + off_drop}, d_status{(char *)d_blob.p + off_flags}, d_general{(char *)d_blob.p + off_flags + sizeof(int) * (size_t)W},
+      d_pbad{(char *)d_blob.p + off_flags + 2 * sizeof(int) * (size_t)W};
+  if (hipMemcpyAsync(d_blob.p, hblob.data(), blob_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(VILO_ERR_HIP);
   // preMarginalize: evaluate the factors at the current state (marginalization_factor.cpp:119-138)
   (void)hipEventRecord(ctx->ev0, ctx->stream);
   rc = vilo_marg_linearize(ctx, bd);
@@ -1159,12 +1171,16 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     ctx->marg_attr_set = true;
   }
   const bool force_general = getenv("VILO_MARG_GENERAL") != nullptr;   // test hook: every window through the global-memory eigen path
-  std::vector<int> general(W, force_general ? 1 : 0);
+  std::vector<int> general(W, force_general ? 1 : 0), flags(3 * (size_t)W, 0);   // flags: status | need_general | IMU factor 0 without sqrt_info
+  bool have_flags = false;
   if (!force_general) {
+    have_flags = true;
     hipLaunchKernelGGL(k_marginalize_lds, dim3(W), dim3(MGT), lds_bytes, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_J0.as<double>(),
                        d_r0.as<double>(), d_status.as<int>(), d_general.as<int>(), want_clk ? d_clk.as<long long>() : nullptr, ctx->prior_form);
+    if (bd.prep_bad) hipLaunchKernelGGL(k_marg_imu0_bad, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, W, bd.prep_bad, bd.imu_skip, d_pbad.as<int>());
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize_lds launch failed"; return fail(VILO_ERR_HIP); }
-    if (hipMemcpy(general.data(), d_general.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+    if (hipMemcpy(flags.data(), d_status.p, sizeof(int) * 3 * (size_t)W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+    for (int w = 0; w < W; ++w) general[w] = flags[(size_t)W + w];
     if (want_clk) {
       long long c[8];
       if (hipMemcpy(c, d_clk.p, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1188,6 +1204,7 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
     if (d_scr.alloc(sizeof(double) * std::max<size_t>(1, scratch_total)) != hipSuccess ||
         hipMemcpy(d_mw.p, mws.data(), sizeof(MargWin) * W, hipMemcpyHostToDevice) != hipSuccess)
       return fail(VILO_ERR_HIP);
+    have_flags = false;   // (this kernel writes status too: read again below)
     hipLaunchKernelGGL(k_marginalize, dim3(W), dim3(MT), 0, ctx->stream, bd, d_mw.as<MargWin>(), d_drop.as<int>(), max_l0, d_scr.as<double>(),
                        d_J0.as<double>(), d_r0.as<double>(), d_status.as<int>());
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "k_marginalize launch failed"; return fail(VILO_ERR_HIP); }
@@ -1200,21 +1217,22 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   // Status first: a window whose result is unusable must not overwrite a pool slot either.
   std::vector<int> status(W, 0);
   int any_bad = 0;
-  if (hipMemcpy(status.data(), d_status.p, sizeof(int) * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  if (!have_flags) {
+    if (bd.prep_bad) hipLaunchKernelGGL(k_marg_imu0_bad, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, W, bd.prep_bad, bd.imu_skip, d_pbad.as<int>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(flags.data(), d_status.p, sizeof(int) * 3 * (size_t)W, hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  }
+  for (int w = 0; w < W; ++w) status[w] = flags[w];
   // A preintegration covariance that is not positive definite has no sqrt_info (its bad pivots were replaced by 1 so that the arithmetic
   // stays finite): an IMU factor built on it would give a finite but meaningless prior. Only the factors that ENTER this marginalisation
   // count — MARGIN_OLD uses the factor of interval 0 alone (estimator.cpp:1271-1297), MARGIN_SECOND_NEW no IMU factor at all
   // (:1389-1410) —, like the reference, which would yield a valid prior whatever the other intervals look like. The flags are those of
   // the records in force: written by the preparation (batch creation / vilo_batch_prepare) or, with re-propagation, by the mode-0 pass
-  // above. Treated like a non-finite result: the window goes on without a prior and the call reports VILO_ERR_NUMERIC.
-  if (bd.prep_bad) {
-    std::vector<int> pb((size_t)W * 10);
-    std::vector<unsigned char> sk((size_t)W * 10);
-    if (hipMemcpy(pb.data(), bd.prep_bad, sizeof(int) * pb.size(), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(sk.data(), bd.imu_skip, sk.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(VILO_ERR_HIP);
+  // above (k_marg_imu0_bad folds them per window behind the marginalisation's kernels). Treated like a non-finite result: the window goes
+  // on without a prior and the call reports VILO_ERR_NUMERIC.
+  if (bd.prep_bad)
     for (int w = 0; w < W; ++w)
-      if (!skip[w] && modes[w] == 0 && !sk[(size_t)w * 10] && pb[(size_t)w * 10]) status[w] = 1;
-  }
+      if (!skip[w] && modes[w] == 0 && flags[2 * (size_t)W + w]) status[w] = 1;
   // windows with a prior pool leave J0 / r0 on the device (slot next_prior_slot); only their kept-block bookkeeping is host side
   std::vector<int> dst_slot(W, -1), src_slot(W, -1);
   bool any_host = false;

@@ -357,7 +357,8 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       for (int k = 0; k < pr->n_blocks; ++k) {
         const int gs = pr->block_size[k], ls = gs == 7 ? 6 : gs, idx = pr->block_idx[k], id = pr->block_id[k];
         static const int kind_size[5] = {7, 9, 4, 7, 1};   // VILO_BLK_POSE, _SB, _LB, _EX, _TD
-        if (id < 0 || id >= 16 * 5 || gs != kind_size[id >> 4] || (id & 15) >= ((id >> 4) == VILO_BLK_EX ? 2 : (id >> 4) == VILO_BLK_TD ? 1 : VILO_MAX_FRAMES) || idx < 0 || idx + ls > pr->n) {
+        if (id < 0 || id >= 16 * 5) continue;   // (not a camera-side block — e.g. a feature: refused as unsupported, with its own message, by the packing pass)
+        if (gs != kind_size[id >> 4] || (id & 15) >= ((id >> 4) == VILO_BLK_EX ? 2 : (id >> 4) == VILO_BLK_TD ? 1 : VILO_MAX_FRAMES) || idx < 0 || idx + ls > pr->n) {
           ctx->err = "prior block table out of range"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG;
         }
       }

@@ -697,14 +697,15 @@ def test_prior_factor_form_carries_the_same_information(cfg, ocfg):
     transformation of it. Everything a solve takes from the prior is the same to rounding: J0^T J0, J0^T r0 per entry in units of the
     diagonal, |r0|^2; the rows themselves are NOT orthogonal any more (that is how the test knows the path was taken). A window without
     a prior (A' semi-definite: the gauge directions, as in every real sequence) gives a factor of n - 4 columns and as many non-zero rows
-    as the eigen form keeps. And a solve from the factor-form prior gives the states of the solve from the eigen-form one."""
+    as the eigen form keeps. (What a solve makes of either form: tests/test_rosbag.py replays a sequence in both, every window against
+    the oracle at 1e-8.)"""
     from cerberus_amd import api
     from cerberus_amd.synth import PriorData
     ce, cf = api.Context(cfg, 0), api.Context(cfg, 0)
     cf.set_prior_form("factor")
     assert api.lib().vilo_set_prior_form(cf.h, 7) != 0
     try:
-        worst, worst_state = 0.0, 0.0
+        worst = 0.0
         for k in range(8):
             kw = dict(n_landmarks=(12, 60, 200, 700)[k % 4], seed=5000 + k, with_prior=(k % 4 != 3))
             w = _fresh(cfg, ocfg, **kw)
@@ -733,18 +734,7 @@ def test_prior_factor_form_carries_the_same_information(cfg, ocfg):
                 G = Jf[nz] @ Jf[nz].T
                 dg = np.sqrt(np.diag(G))
                 assert np.abs(G / np.outer(dg, dg) - np.eye(int(nz.sum()))).max() > 1e-3, "the factor form's rows are not mutually orthogonal"
-                # the next solve does not notice
-                we, wf = _fresh(cfg, ocfg, n_landmarks=40, seed=6000 + k), _fresh(cfg, ocfg, n_landmarks=40, seed=6000 + k)
-                if pe.blocks() == we.prior.blocks():   # (a prior over the blocks a fresh window's prior has: MARGIN_OLD's)
-                    we.prior, wf.prior = pe.copy(), pf.copy()
-                    ce.solve_windows([we], api.default_solve_opts(True, 6))
-                    ce.solve_windows([wf], api.default_solve_opts(True, 6))
-                    # (the two priors' gradients agree to ~1e-9 of the largest whitened entry — each form's own rounding —, and six
-                    # iterations carry that into the states at the 1e-8 level: measured 1.3e-8)
-                    for a, bb in zip(we.state_arrays(), wf.state_arrays()):
-                        worst_state = max(worst_state, np.abs(a - bb).max() / max(1.0, np.abs(bb).max()))
-                        assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max())
-        print("MEASURED factor form vs eigen form of the prior: worst deviation %.2e; states after six iterations from either %.2e" % (worst, worst_state))
+        print("MEASURED factor form vs eigen form of the prior: worst deviation %.2e" % worst)
     finally:
         ce.close(); cf.close()
 
