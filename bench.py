@@ -292,6 +292,36 @@ def parity_sample(cfg, windows, ids, landmarks, rate, summ, idx=None, repropagat
                     "oracle/liboracle.so on the same seeds, %d fixed iterations%s; all_windows: every window's downloaded final cost and states" % (ITERS, ", intervals integrated again per evaluation" if repropagate else "")}
 
 
+def host_inclusive_block(ctx, cfg, lib, opts, landmarks, rate, W=4096, reps=3):
+    """What a caller who hands over HOST windows gets (the plain C entry point vilo_solve_windows = vilo_batch_create + prepare + solve +
+    download; `value` of the line is measured with the batch resident): wall time inside the library's calls per batch of W windows, as a
+    C++ caller pays it — the harness's own descriptor building in Python is not in it —, and the host-to-device rate the hand-over reached."""
+    from cerberus_amd import api
+    ws = [make_synth_window(cfg, landmarks, rate, 70260925 + i) for i in range(W)]
+    ctx.preintegrate_windows(ws)
+    lib.vilo_last_download_ms.restype = C.c_double
+    best = None
+    for _ in range(reps):
+        b = api.Batch(ctx, ws)                       # vilo_batch_create: pack + upload + sqrt_info
+        cm = (C.c_double * 4)(); by = C.c_double(0.0)
+        lib.vilo_last_create_ms(ctx.h, cm, C.byref(by))
+        t0 = time.perf_counter()
+        b.solve(opts)                                # (create has prepared sqrt_info once, like one vilo_solve_windows call)
+        solve_ms = 1e3 * (time.perf_counter() - t0)
+        b.download()
+        dl_ms = float(lib.vilo_last_download_ms(ctx.h))
+        b.close()
+        tot = cm[0] + solve_ms + dl_ms
+        r = {"windows": W, "ms": {"create": cm[0], "pack": cm[1], "alloc_and_upload": cm[2], "records_up_and_sqrt_info": cm[3], "solve": solve_ms, "download": dl_ms, "total": tot},
+             "value": W * ITERS / (tot * 1e-3), "unit": "GN window-iterations/s", "bytes_to_device": by.value,
+             "h2d_gbps_over_upload_phases": by.value / max(1e-9, (cm[2] + cm[3]) * 1e-3) / 1e9}
+        if best is None or r["value"] > best["value"]:
+            best = r
+    best["what"] = ("vilo_batch_create + vilo_batch_solve (%d fixed iterations) + vilo_batch_download on %d config-2 windows handed over in host memory, wall time inside "
+                    "the library (best of %d); the records (156 KB per window) go up through two page-locked 32 MB chunks filled by the worker pool" % (ITERS, W, reps))
+    return best
+
+
 def config3_block(ctx, cfg, lib, opts, W=256, steps=2):
     """BASELINE configs[2] as a side block of the default line (the driver only runs the default command): 1000 landmarks, 400 Hz,
     every iteration integrates all 10 intervals again. Same measurement as the headline: `steps` timed steps after one warm-up step that
@@ -795,6 +825,12 @@ def main():
             bsm.close()
             small[str(Wsm)] = {"windows": Wsm, "value": Wsm * ITERS * args.steps / el, "unit": "GN window-iterations/s", "ms_per_step": 1e3 * el / args.steps,
                                "us_per_iteration": 1e6 * el / args.steps / ITERS}
+    host_inc = None
+    if world == 1 and args.total_windows == 0 and not rp and args.landmarks == 200 and not args.no_strong:
+        try:
+            host_inc = host_inclusive_block(ctx, cfg, lib, opts, args.landmarks, args.rate)
+        except Exception as e:   # (a side block: never the reason a line is lost)
+            host_inc = {"error": repr(e)}
     if rank == 0:
         unit_work = world * W * ITERS * args.steps        # window-iterations of the whole job
         value = unit_work / elapsed
@@ -867,6 +903,8 @@ def main():
             out["strong_scaling"] = strong
         if small:
             out["small_batches"] = small
+        if host_inc:
+            out["host_inclusive"] = host_inc
         if not args.no_cpu_baseline:
             # checker leg, outside the timed region: did the timed kernels produce the reference's states?
             out["parity_sample"] = parity_sample(cfg, windows, ids, args.landmarks, args.rate, summ, idx=sample_idx, repropagate=rp)

@@ -78,9 +78,10 @@ extern "C" void vilo_destroy(vilo_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
   for (auto &c : ctx->pool_free) (void)hipFree(c.first);
-  for (auto &h : ctx->host_stage) free(h.first);
+  for (auto &h : ctx->host_stage) if (h.first) { if (h.second & 1) (void)hipHostFree(h.first); else free(h.first); }
   for (hipEvent_t e : ctx->pev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->prep_ev) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->rec_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);

@@ -29,6 +29,8 @@ struct vilo_ctx {
   std::vector<std::pair<void *, size_t>> pool_free;
   // reusable host staging (grow-only): the wave-packed observation image and the prior staging of vilo_batch_create
   std::vector<std::pair<void *, size_t>> host_stage;
+  hipEvent_t rec_ev[2] = {nullptr, nullptr};   // "the DMA engine is done with staging chunk i" of vilo_batch_create's record upload
+  double last_create_ms[4] = {0, 0, 0, 0}, last_create_bytes = 0.0, last_download_ms = 0.0;   // host wall time of the last vilo_batch_create / _download (vilo_last_create_ms)
   double last_marg_ms = 0.0;       // GPU time of the last vilo_marginalize (linearisation + marginalisation kernels)
   int marg_general_count = 0;      // windows of the last vilo_marginalize that took the global-memory eigen path
   std::string err;
@@ -51,14 +53,19 @@ struct vilo_ctx {
   int compact_rows = 1;
 };
 
-// grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified)
+// grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified). Page-locked up to 1 GiB per buffer —
+// what the DMA engines read at PCIe rate (pageable memory goes through the runtime's bounce buffer at a fifth of it); beyond that plain
+// memory: pinning gigabytes per context is not this library's decision to take. second = size with the low bit telling which kind.
 inline void *vilo_host_stage(vilo_ctx *ctx, int slot, size_t bytes) {
   if ((int)ctx->host_stage.size() <= slot) ctx->host_stage.resize(slot + 1, {nullptr, 0});
   auto &hs = ctx->host_stage[slot];
-  if (hs.second < bytes) {
-    free(hs.first);
-    hs.second = bytes + bytes / 4;
-    hs.first = malloc(hs.second);
+  if ((hs.second & ~(size_t)1) < bytes) {
+    if (hs.first) { if (hs.second & 1) (void)hipHostFree(hs.first); else free(hs.first); }
+    size_t want = (bytes + bytes / 4 + 1) & ~(size_t)1;
+    void *q = nullptr;
+    static const bool no_pin = getenv("VILO_NO_PINNED_STAGING") != nullptr;
+    if (!no_pin && want <= ((size_t)1 << 30) && hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess && q) { hs.first = q; hs.second = want | 1; }
+    else { (void)hipGetLastError(); hs.first = malloc(want); hs.second = hs.first ? want : 0; }
   }
   return hs.first;
 }

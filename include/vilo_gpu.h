@@ -264,6 +264,11 @@ int vilo_batch_download(vilo_ctx *ctx, vilo_batch *batch, vilo_window_state *out
 void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *batch);
 /* GPU time of the last vilo_batch_solve on ctx's stream (HIP events), and per-kernel-group breakdown. */
 double vilo_last_solve_ms(const vilo_ctx *ctx);
+/* Host wall time inside the last vilo_batch_create on ctx (what handing over HOST windows costs before the first kernel): out_ms[0] total,
+ * [1] packing into the device layouts, [2] allocation + upload of observations / states / priors, [3] preintegration records up + their
+ * sqrt_info; *bytes_up (optional): bytes moved to the device. vilo_last_download_ms: the same for the last vilo_batch_download. */
+int vilo_last_create_ms(const vilo_ctx *ctx, double out_ms[4], double *bytes_up);
+double vilo_last_download_ms(const vilo_ctx *ctx);
 
 /* double2vector gauge fix (estimator.cpp:903-957): yaw/position re-anchoring of the solver output. */
 int vilo_gauge_fix(vilo_ctx *ctx, int n_windows, const vilo_window_state *before, vilo_window_state *after, int n_frames);
