@@ -65,7 +65,7 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "round5"
+PROFILE_ROUND = "round6"
 # windows per GPU of the headline line: the kernels of an iteration are launched once for all windows of the batch, and every kernel's tail (its
 # last partial round of workgroups) and launch gap is paid once per batch — measured on one MI355X with the round-5 kernels: 4096 windows 1.77 M,
 # 8192 1.835 M, 12288 1.864 M, 16384 1.877 M, 24576 1.901 M, 32768 1.911 M window-iterations/s (36 GB of the 288 GB resident)

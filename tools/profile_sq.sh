@@ -10,7 +10,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1 --warmup 1 --windows $WIN --no-cpu-baseline --no-single-window --no-strong"
+# a third argument replaces the workload, e.g. "--config 3 --windows 1024" for BASELINE configs[2]
+ARGS="--steps 1 --warmup 1 ${3:---windows $WIN} --no-cpu-baseline --no-single-window --no-strong --no-replay --no-config3"
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 i=0
 while read -r LINE; do
