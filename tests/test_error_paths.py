@@ -147,3 +147,41 @@ def test_a_bad_covariance_only_spoils_the_marginalisations_that_use_its_factor(c
     w7.preint[7, cov0 + 5 * 31 + 5] = -1.0
     rc, summ = _solve_rc(ctx, [w7])
     assert summ[0].termination == 2
+
+
+def test_mutated_window_tables_never_reach_the_packing_loops(ctx, cfg, ocfg):
+    """A window that comes out of a file is untrusted (include/vilo_window_io.h bounds its counts by the file's size, nothing more): the tables
+    vilo_batch_create indexes through — lm_obs_offset into the observations, lm_start_frame into the frames, the prior's block table into
+    the prior and, on the device, into the assembly's LDS image — are checked before anything is packed. 400 seeded
+    mutations of one table entry each: every call returns — OK with a finite result where the mutation happened to be harmless,
+    BAD_ARG / UNSUPPORTED with a message otherwise — and a good window solved afterwards on the same context gives what it gave before."""
+    from cerberus_amd import api
+    ref = _win(cfg, ocfg, n_landmarks=30, seed=77)
+    want = api.Context.solve_windows(ctx, [ref], api.default_solve_opts(True, 3))[0].final_cost
+    rng = np.random.default_rng(11)
+    outcomes = {OK: 0, BAD_ARG: 0, UNSUPPORTED: 0, NUMERIC: 0}
+    for k in range(400):
+        w = _win(cfg, ocfg, n_landmarks=30, seed=77)
+        what = k % 5
+        big = int(rng.choice([-1, -7, 1 << 20, 1 << 30, 12, 97, 255, 11, 86, 87]))
+        if what == 0:
+            w.lm_obs_offset[rng.integers(0, w.L + 1)] = big
+        elif what == 1:
+            w.lm_start_frame[rng.integers(0, w.L)] = big
+        elif what == 2:
+            w.prior.struct.block_idx[rng.integers(0, w.prior.struct.n_blocks)] = big
+        elif what == 3:
+            w.prior.struct.block_size[rng.integers(0, w.prior.struct.n_blocks)] = big
+        else:
+            w.prior.struct.block_id[rng.integers(0, w.prior.struct.n_blocks)] = big
+        rc, summ = _solve_rc(ctx, [w])
+        assert rc in outcomes, (k, what, big, rc)
+        outcomes[rc] += 1
+        if rc in (BAD_ARG, UNSUPPORTED):
+            assert len(api.lib().vilo_last_error(ctx.h)) > 0
+        if rc == OK:
+            assert np.isfinite(summ[0].final_cost)
+    assert outcomes[BAD_ARG] + outcomes[UNSUPPORTED] > 300, outcomes     # (most single-entry mutations break a table)
+    again = _win(cfg, ocfg, n_landmarks=30, seed=77)
+    assert ctx.solve_windows([again], api.default_solve_opts(True, 3))[0].final_cost == want
+    print("mutated tables:", outcomes)
