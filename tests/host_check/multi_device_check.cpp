@@ -73,7 +73,7 @@ int main() {
   vilo_default_config(&cfg);
   const int ndev = vilo_device_count();
   if (ndev <= 0) { fprintf(stderr, "no GPU\n"); return 2; }
-  const int T = ndev >= 2 ? (ndev > 8 ? 8 : ndev) : 2, PER = 3;
+  const int T = ndev >= 2 ? (ndev > 8 ? 8 : ndev) : 2, PER = 24;   // (24 windows per call: the packing and the staged record copy go through the worker pool, from all threads at once)
   printf("devices %d threads %d\n", ndev, T);
   std::vector<std::vector<Win>> wins(T, std::vector<Win>(PER)), again(T, std::vector<Win>(PER));
   for (int d = 0; d < T; ++d)

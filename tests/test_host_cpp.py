@@ -80,5 +80,5 @@ def test_one_context_per_device_one_thread_each():
     ndev, nthr = int(m.group(1)), int(m.group(2))
     assert nthr == (min(ndev, 8) if ndev >= 2 else 2)
     assert ("multi_device_leg ran" in out.stdout) == (ndev >= 2)
-    assert len(re.findall(r"^win \d+ \d+ cost ", out.stdout, flags=re.M)) == 3 * nthr
+    assert len(re.findall(r"^win \d+ \d+ cost ", out.stdout, flags=re.M)) == 24 * nthr
     print(out.stdout.splitlines()[0], "|", out.stdout.splitlines()[-1])
