@@ -1,0 +1,88 @@
+"""Test helper: cost and gradient of a window's least-squares problem assembled in Python from the factor classes' own Evaluate() — the
+oracle's (default) or, inside `with ref_py.as_oracle():`, the COMPILED REFERENCE's (oracle/_ref/libref.so) — with the residual blocks
+enumerated as Estimator::optimization adds them (estimator.cpp:1107-1216), ceres::HuberLoss(1.0) on the visual blocks (:1062) applied as
+Ceres applies a loss (rho'(s) J^T r, cost rho(s) / 2) and PoseLocalParameterization's [I6; 0] Jacobian on the 7-dim blocks. Nothing of
+the solvers under test is in it: it says what the cost function IS, so that a state can be tested for being a stationary point of it."""
+import numpy as np
+
+from oracle import oracle_py as O
+
+
+def _blocks(w):
+    """state arrays by block kind (VILO_BLK_*: 0 pose, 1 speed / bias, 2 leg bias, 3 extrinsic, 4 td)"""
+    return {0: w.pose, 1: w.speed_bias, 2: w.leg_bias, 3: w.ex_pose, 4: w.td.reshape(1, 1)}
+
+
+def cost_and_gradient(cfg, w, huber_delta=1.0):
+    """Returns (cost, g, h): g[(kind, index)] / g[('lam', l)] = gradient in the block's LOCAL coordinates, h likewise = the diagonal of the
+    Gauss-Newton Hessian sum_blocks rho' J^T J (what a gradient entry is measured against: g_i / sqrt(h_i) is dimensionless)."""
+    F = w.F
+    g, h = {}, {}
+    cost = 0.0
+
+    def add(key, J, r, wgt):
+        J = J[:, :6] if J.shape[1] == 7 else J
+        g[key] = g.get(key, 0.0) + wgt * (J.T @ r)
+        h[key] = h.get(key, 0.0) + wgt * (J * J).sum(axis=0)
+
+    def block(keys, r, Js, robust):
+        nonlocal cost
+        s = float(r @ r)
+        if robust and s > huber_delta ** 2:
+            cost += 0.5 * (2.0 * huber_delta * np.sqrt(s) - huber_delta ** 2)
+            wgt = huber_delta / np.sqrt(s)
+        else:
+            cost += 0.5 * s
+            wgt = 1.0
+        for key, J in zip(keys, Js):
+            add(key, J, r, wgt)
+    st = _blocks(w)
+    pr = w.prior
+    if pr.struct.valid:
+        keys = [(pr.struct.block_id[k] // 16, pr.struct.block_id[k] % 16) for k in range(pr.struct.n_blocks)]
+        r, Js = O.eval_prior(pr.struct, [st[kind][idx] for kind, idx in keys])
+        block(keys, r, Js, False)
+    for k in range(F - 1):
+        keys = [(0, k), (1, k), (2, k), (0, k + 1), (1, k + 1), (2, k + 1)]
+        if w.use_leg:
+            r, Js = O.eval_imu_leg(cfg, w.preint[k], [st[kd][i] for kd, i in keys])
+        else:
+            keys = [(0, k), (1, k), (0, k + 1), (1, k + 1)]
+            r, Js = O.eval_imu(cfg, w.preint_imu[k], [st[kd][i] for kd, i in keys])
+        block(keys, r, Js, False)
+    td = w.td
+    for l in range(w.L):
+        s, o0, o1 = int(w.lm_start_frame[l]), int(w.lm_obs_offset[l]), int(w.lm_obs_offset[l + 1])
+        f0 = w.obs[o0]
+        lam = w.inv_depth[l:l + 1]
+        for o in range(o0, o1):
+            j = s + (o - o0)
+            fj = w.obs[o]
+            if j != s:
+                obs = np.concatenate([f0[0:3], fj[0:3], f0[6:8], fj[6:8], [f0[10], fj[10]]])
+                r, Js = O.eval_proj(0, cfg, obs, [w.pose[s], w.pose[j], w.ex_pose[0], lam, td])
+                block([(0, s), (0, j), (3, 0), ("lam", l), (4, 0)], r, Js, True)
+            if w.obs_is_stereo[o]:
+                obs = np.concatenate([f0[0:3], fj[3:6], f0[6:8], fj[8:10], [f0[10], fj[10]]])
+                if j != s:
+                    r, Js = O.eval_proj(1, cfg, obs, [w.pose[s], w.pose[j], w.ex_pose[0], w.ex_pose[1], lam, td])
+                    block([(0, s), (0, j), (3, 0), (3, 1), ("lam", l), (4, 0)], r, Js, True)
+                else:
+                    r, Js = O.eval_proj(2, cfg, obs, [w.ex_pose[0], w.ex_pose[1], lam, td])
+                    block([(3, 0), (3, 1), ("lam", l), (4, 0)], r, Js, True)
+    return cost, g, h
+
+
+def free_gradient(w, g):
+    """the entries of g (or h) that belong to blocks the solve may move (SetParameterBlockConstant, estimator.cpp:1074-1105), as one vector"""
+    out = []
+    for key, v in sorted(g.items(), key=lambda kv: (str(type(kv[0][0])), kv[0])):
+        kind = key[0]
+        if kind == 4 and w.td_const:
+            continue
+        if kind == 3 and w.ex_const:
+            continue
+        if kind == 2 and w.leg_bias_const:
+            continue
+        out.append(np.atleast_1d(v).ravel())
+    return np.concatenate(out)

@@ -1,0 +1,67 @@
+"""What can be said about "the reference Ceres solution" without Ceres: whatever path a trust-region method takes, where it converges the
+gradient of the cost vanishes. The cost function is not ours — it is the sum of the reference's OWN residual blocks, and
+tests/ref_gradient.py assembles its value and gradient in Python from `Evaluate()` of the compiled reference classes
+(oracle/_ref/libref.so: IMULegFactor, the three projection factors, MarginalizationFactor, built from /root/reference), enumerated as
+Estimator::optimization adds them, with the Huber loss and the pose parameterisation applied as Ceres applies them. Neither solver under
+test is involved in that evaluation. Checked at the state the oracle (CPU) and the HIP path (`-m gpu`) reach after 40 iterations:
+  * the cost the solver reports IS the reference's cost at that state (1e-12),
+  * the gradient, every entry in units of the square root of its Gauss-Newton diagonal, is ten orders of magnitude below the start's and
+    below 1e-4 in absolute terms (the floor of evaluating it in FP64: the IMU rows carry information up to 1e14).
+So the HIP solver stops where any convergent minimiser of the reference's problem stops; what stays unpinned is the trajectory there."""
+import numpy as np
+import pytest
+
+from cerberus_amd import synth
+from oracle import oracle_py as O
+from oracle import ref_py as R
+import ref_gradient as RG
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref.so not built (needs /root/reference at build time)")
+CASES = [(41, 30), (42, 60), (5, 24)]
+
+
+def _whitened(w, g, h):
+    return np.abs(RG.free_gradient(w, g) / np.sqrt(RG.free_gradient(w, h))).max()
+
+
+def _check(cfg, w, final_cost, start):
+    with R.as_oracle():
+        c1, g1, h1 = RG.cost_and_gradient(cfg, w)
+    wf = _whitened(w, g1, h1)
+    assert abs(c1 - final_cost) <= 1e-12 * c1, (c1, final_cost)
+    assert wf < 1e-4 and wf < 1e-9 * start, (wf, start)
+    return wf
+
+
+@pytest.mark.parametrize("seed,L", CASES)
+def test_the_oracle_stops_at_a_stationary_point_of_the_references_cost(seed, L):
+    cfg = O.default_config()
+    w = synth.make_window(synth.default_config(), n_landmarks=L, seed=seed)
+    O.fill_preint(cfg, w)
+    with R.as_oracle():
+        c0, g0, h0 = RG.cost_and_gradient(cfg, w)
+    assert abs(c0 - O.window_cost(cfg, w)) <= 1e-14 * c0            # (the enumeration is the one the solvers use)
+    start = _whitened(w, g0, h0)
+    sm = O.solve_window(cfg, w, O.default_opts(True, 40))
+    wf = _check(cfg, w, sm.final_cost, start)
+    print("MEASURED oracle, seed %d: whitened gradient %.1e -> %.1e" % (seed, start, wf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,L", CASES)
+def test_the_hip_solver_stops_at_a_stationary_point_of_the_references_cost(seed, L):
+    from cerberus_amd import api
+    cfg, ocfg = synth.default_config(), O.default_config()
+    ctx = api.Context(cfg, 0)
+    try:
+        w = synth.make_window(cfg, n_landmarks=L, seed=seed)
+        ctx.preintegrate_window(w)
+        with R.as_oracle():
+            c0, g0, h0 = RG.cost_and_gradient(ocfg, w)
+        start = _whitened(w, g0, h0)
+        sm = ctx.solve_windows([w], api.default_solve_opts(True, 40))[0]
+        assert abs(sm.initial_cost - c0) <= 1e-10 * c0
+        wf = _check(ocfg, w, sm.final_cost, start)
+        print("MEASURED HIP solver, seed %d: whitened gradient of the reference's cost %.1e -> %.1e, cost %.6f" % (seed, start, wf, sm.final_cost))
+    finally:
+        ctx.close()
