@@ -86,3 +86,83 @@ def free_gradient(w, g):
             continue
         out.append(np.atleast_1d(v).ravel())
     return np.concatenate(out)
+
+
+def dense_jacobian(cfg, w, huber_delta=1.0):
+    """The whole problem as Ceres' evaluator hands it to the linear solver: r (all residual blocks stacked, loss-corrected) and the dense
+    Jacobian in LOCAL coordinates over the free blocks — Corrector's first branch (rho'' <= 0 for Huber: residual and Jacobian of a block
+    times sqrt(rho'), corrector.cc) — with the column layout {key: slice}. Inverse depths last."""
+    rows_r, rows_J = [], []
+    keys_seen = {}
+
+    def free(key):
+        k = key[0]
+        return not ((k == 4 and w.td_const) or (k == 3 and w.ex_const) or (k == 2 and w.leg_bias_const))
+
+    def block(keys, r, Js, robust):
+        s = float(r @ r)
+        sc = np.sqrt(huber_delta / np.sqrt(s)) if (robust and s > huber_delta ** 2) else 1.0
+        rows_r.append(sc * r)
+        ent = []
+        for key, J in zip(keys, Js):
+            J = J[:, :6] if J.shape[1] == 7 else J
+            if free(key):
+                keys_seen.setdefault(key, J.shape[1])
+                ent.append((key, sc * J))
+        rows_J.append(ent)
+    # (same enumeration as cost_and_gradient)
+    st = _blocks(w)
+    pr = w.prior
+    if pr.struct.valid:
+        keys = [(pr.struct.block_id[k] // 16, pr.struct.block_id[k] % 16) for k in range(pr.struct.n_blocks)]
+        r, Js = O.eval_prior(pr.struct, [st[kind][idx] for kind, idx in keys])
+        block(keys, r, Js, False)
+    for k in range(w.F - 1):
+        keys = [(0, k), (1, k), (2, k), (0, k + 1), (1, k + 1), (2, k + 1)]
+        r, Js = O.eval_imu_leg(cfg, w.preint[k], [st[kd][i] for kd, i in keys])
+        block(keys, r, Js, False)
+    td = w.td
+    for l in range(w.L):
+        s, o0, o1 = int(w.lm_start_frame[l]), int(w.lm_obs_offset[l]), int(w.lm_obs_offset[l + 1])
+        f0 = w.obs[o0]
+        lam = w.inv_depth[l:l + 1]
+        for o in range(o0, o1):
+            j = s + (o - o0)
+            fj = w.obs[o]
+            if j != s:
+                obs = np.concatenate([f0[0:3], fj[0:3], f0[6:8], fj[6:8], [f0[10], fj[10]]])
+                r, Js = O.eval_proj(0, cfg, obs, [w.pose[s], w.pose[j], w.ex_pose[0], lam, td])
+                block([(0, s), (0, j), (3, 0), (9, l), (4, 0)], r, Js, True)
+            if w.obs_is_stereo[o]:
+                obs = np.concatenate([f0[0:3], fj[3:6], f0[6:8], fj[8:10], [f0[10], fj[10]]])
+                if j != s:
+                    r, Js = O.eval_proj(1, cfg, obs, [w.pose[s], w.pose[j], w.ex_pose[0], w.ex_pose[1], lam, td])
+                    block([(0, s), (0, j), (3, 0), (3, 1), (9, l), (4, 0)], r, Js, True)
+                else:
+                    r, Js = O.eval_proj(2, cfg, obs, [w.ex_pose[0], w.ex_pose[1], lam, td])
+                    block([(3, 0), (3, 1), (9, l), (4, 0)], r, Js, True)
+    cols, n = {}, 0
+    for key in sorted(keys_seen):
+        cols[key] = slice(n, n + keys_seen[key])
+        n += keys_seen[key]
+    m = sum(len(r) for r in rows_r)
+    J = np.zeros((m, n))
+    at = 0
+    for r, ent in zip(rows_r, rows_J):
+        for key, Jb in ent:
+            J[at:at + len(r), cols[key]] += Jb
+        at += len(r)
+    return np.concatenate(rows_r), J, cols
+
+
+def apply_step(w, cols, delta):
+    """x (+) delta on w's state arrays: PoseLocalParameterization::Plus on the 7-dim blocks, plain addition elsewhere"""
+    st = _blocks(w)
+    for key, sl in cols.items():
+        d = delta[sl]
+        if key[0] == 9:
+            w.inv_depth[key[1]] += d[0]
+        elif key[0] in (0, 3):
+            st[key[0]][key[1]][:] = O.pose_plus(st[key[0]][key[1]], d)
+        else:
+            st[key[0]][key[1]][:] += d

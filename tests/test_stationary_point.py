@@ -65,3 +65,66 @@ def test_the_hip_solver_stops_at_a_stationary_point_of_the_references_cost(seed,
         print("MEASURED HIP solver, seed %d: whitened gradient of the reference's cost %.1e -> %.1e, cost %.6f" % (seed, start, wf, sm.final_cost))
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------ one iteration = the Gauss-Newton step of the reference's linearisation
+def _dense_gauss_newton_step(cfg, w):
+    """One iteration as Ceres 1.14 takes it near a solution, in dense numpy algebra on the compiled reference's Jacobians: Jacobi scaling
+    1 / (1 + |column|) (first iteration), D^2 = clamp(diag(Js^T Js), 1e-6, 1e32), (Js^T Js + mu D^2) y = -Js^T r with mu = min_mu = 1e-8;
+    the Gauss-Newton point is the step when |D y| <= radius (1e4). Returns (delta in local coordinates, columns, |D y|)."""
+    with R.as_oracle():
+        r, J, cols = RG.dense_jacobian(cfg, w)
+    scale = 1.0 / (1.0 + np.linalg.norm(J, axis=0))
+    Js = J * scale
+    A, g = Js.T @ Js, Js.T @ r
+    D2 = np.clip(np.diag(A), 1e-6, 1e32)
+    y = np.linalg.solve(A + 1e-8 * np.diag(D2), -g)
+    return scale * y, cols, float(np.sqrt((D2 * y * y).sum()))
+
+
+def _step_case(seed, L, solve_one):
+    """six oracle iterations to get near the solution, then ONE iteration of the solver under test from there against the dense step"""
+    cfg = O.default_config()
+    w = synth.make_window(synth.default_config(), n_landmarks=L, seed=seed)
+    O.fill_preint(cfg, w)
+    O.solve_window(cfg, w, O.default_opts(True, 6))
+    x6 = w.clone_state()
+    delta, cols, dy = _dense_gauss_newton_step(cfg, w)
+    assert dy < 1e4                                   # inside the initial trust region: the dogleg step IS the Gauss-Newton step
+    w_np, w_sv = (synth.make_window(synth.default_config(), n_landmarks=L, seed=seed) for _ in range(2))
+    for v in (w_np, w_sv):
+        v.preint[...] = w.preint
+        v.set_state(x6)
+    RG.apply_step(w_np, cols, delta)
+    sm = solve_one(w_sv)
+    assert (sm.iterations, sm.num_successful) == (1, 1)
+    worst = 0.0
+    for a, b, c in zip(w_np.state_arrays(), w_sv.state_arrays(), x6):
+        if a.size == 0:
+            continue
+        step = np.abs(b - c).max()
+        err = np.abs(a - b).max()
+        assert err <= 1e-6 * step + 1e-12, (err, step)
+        worst = max(worst, err / max(step, 1e-300))
+    return worst
+
+
+@pytest.mark.parametrize("seed,L", CASES)
+def test_one_oracle_iteration_is_the_dense_gauss_newton_step_of_the_references_jacobian(seed, L):
+    cfg = O.default_config()
+    worst = _step_case(seed, L, lambda w: O.solve_window(cfg, w, O.default_opts(True, 1)))
+    print("MEASURED oracle step vs dense numpy step on the reference's Jacobian, seed %d: %.1e of the step" % (seed, worst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,L", CASES)
+def test_one_hip_iteration_is_the_dense_gauss_newton_step_of_the_references_jacobian(seed, L):
+    """The Schur-eliminated, Jacobi-scaled, mu-regularised solve of the HIP kernels (landmarks eliminated, block-tridiagonal chain, Cholesky
+    of the 80 x 80 pose system) against ONE dense numpy.linalg.solve on the Jacobian the compiled reference's classes return."""
+    from cerberus_amd import api
+    ctx = api.Context(synth.default_config(), 0)
+    try:
+        worst = _step_case(seed, L, lambda w: ctx.solve_windows([w], api.default_solve_opts(True, 1))[0])
+        print("MEASURED HIP step vs dense numpy step on the reference's Jacobian, seed %d: %.1e of the step" % (seed, worst))
+    finally:
+        ctx.close()
