@@ -118,8 +118,12 @@ def dense_jacobian(cfg, w, huber_delta=1.0):
         r, Js = O.eval_prior(pr.struct, [st[kind][idx] for kind, idx in keys])
         block(keys, r, Js, False)
     for k in range(w.F - 1):
-        keys = [(0, k), (1, k), (2, k), (0, k + 1), (1, k + 1), (2, k + 1)]
-        r, Js = O.eval_imu_leg(cfg, w.preint[k], [st[kd][i] for kd, i in keys])
+        if w.use_leg:
+            keys = [(0, k), (1, k), (2, k), (0, k + 1), (1, k + 1), (2, k + 1)]
+            r, Js = O.eval_imu_leg(cfg, w.preint[k], [st[kd][i] for kd, i in keys])
+        else:   # USE_LEG 0: IMUFactor, no leg-bias blocks in the problem (estimator.cpp:1160-1171)
+            keys = [(0, k), (1, k), (0, k + 1), (1, k + 1)]
+            r, Js = O.eval_imu(cfg, w.preint_imu[k], [st[kd][i] for kd, i in keys])
         block(keys, r, Js, False)
     td = w.td
     for l in range(w.L):

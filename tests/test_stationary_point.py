@@ -128,3 +128,60 @@ def test_one_hip_iteration_is_the_dense_gauss_newton_step_of_the_references_jaco
         print("MEASURED HIP step vs dense numpy step on the reference's Jacobian, seed %d: %.1e of the step" % (seed, worst))
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------ USE_LEG 0: IMUFactor instead of IMULegFactor
+def _vins_window(seed, L):
+    cfg = O.default_config()
+    w = synth.make_window(synth.default_config(), n_landmarks=L, seed=seed, with_prior=False)
+    w.use_leg = 0
+    O.fill_preint(cfg, w)
+    return w
+
+
+def _vins_step(solve_one, seed=51, L=40):
+    """config/a1_config/hardware_a1_vins_config.yaml (USE_LEG 0): near the solution one iteration against the dense step on the reference's
+    IMUFactor / projection Jacobians. No prior: the four gauge directions are regularised by mu D^2 alone, so the step is compared where it
+    is determined — through the cost it reaches and the non-gauge part (positions relative to frame 0 would need the gauge fixed; the
+    candidate cost and model decrease do not)."""
+    cfg = O.default_config()
+    w = _vins_window(seed, L)
+    O.solve_window(cfg, w, O.default_opts(True, 6))
+    x6 = w.clone_state()
+    with R.as_oracle():
+        r, J, cols = RG.dense_jacobian(cfg, w)
+        c6, _, _ = RG.cost_and_gradient(cfg, w)
+    assert not any(k[0] == 2 for k in cols)          # (no leg-bias block in the problem)
+    scale = 1.0 / (1.0 + np.linalg.norm(J, axis=0))
+    Js = J * scale
+    A, g = Js.T @ Js, Js.T @ r
+    D2 = np.clip(np.diag(A), 1e-6, 1e32)
+    y = np.linalg.solve(A + 1e-8 * np.diag(D2), -g)
+    assert np.sqrt((D2 * y * y).sum()) < 1e4
+    w_np = _vins_window(seed, L); w_np.set_state(x6)
+    RG.apply_step(w_np, cols, scale * y)
+    with R.as_oracle():
+        c_np, _, _ = RG.cost_and_gradient(cfg, w_np)
+    w_sv = _vins_window(seed, L); w_sv.set_state(x6)
+    sm = solve_one(w_sv)
+    assert (sm.iterations, sm.num_successful) == (1, 1)
+    assert abs(sm.initial_cost - c6) <= 1e-10 * c6
+    assert abs(sm.final_cost - c_np) <= 1e-9 * c_np, (sm.final_cost, c_np)
+    return abs(sm.final_cost - c_np) / c_np, c6 - c_np
+
+
+def test_one_oracle_iteration_without_leg_factors_reaches_the_dense_steps_cost():
+    cfg = O.default_config()
+    err, dec = _vins_step(lambda w: O.solve_window(cfg, w, O.default_opts(True, 1)))
+    print("MEASURED USE_LEG 0, oracle: cost after one iteration vs after the dense step on the reference's Jacobian %.1e (decrease %.3g)" % (err, dec))
+
+
+@pytest.mark.gpu
+def test_one_hip_iteration_without_leg_factors_reaches_the_dense_steps_cost():
+    from cerberus_amd import api
+    ctx = api.Context(synth.default_config(), 0)
+    try:
+        err, dec = _vins_step(lambda w: ctx.solve_windows([w], api.default_solve_opts(True, 1))[0])
+        print("MEASURED USE_LEG 0, HIP: cost after one iteration vs after the dense step on the reference's Jacobian %.1e (decrease %.3g)" % (err, dec))
+    finally:
+        ctx.close()
