@@ -1152,15 +1152,18 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
   auto fail = [&](int code) { return code; };
   const size_t off_drop = (sizeof(MargWin) * (size_t)W + 15) & ~(size_t)15, off_flags = (off_drop + sizeof(int) * drop_flat.size() + 15) & ~(size_t)15;
   const size_t blob_bytes = off_flags + sizeof(int) * 3 * (size_t)W;
-  std::vector<char> hblob(blob_bytes, 0);
-  memcpy(hblob.data(), mws.data(), sizeof(MargWin) * (size_t)W);
-  if (!drop_flat.empty()) memcpy(hblob.data() + off_drop, drop_flat.data(), sizeof(int) * drop_flat.size());
+  // (the context's reusable page-locked staging: it outlives the asynchronous copy on every return path)
+  char *hblob = (char *)vilo_host_stage(ctx, 6, blob_bytes);
+  if (!hblob) return fail(VILO_ERR_HIP);
+  memset(hblob, 0, blob_bytes);
+  memcpy(hblob, mws.data(), sizeof(MargWin) * (size_t)W);
+  if (!drop_flat.empty()) memcpy(hblob + off_drop, drop_flat.data(), sizeof(int) * drop_flat.size());
   if (d_blob.alloc(blob_bytes) != hipSuccess || d_J0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM) != hipSuccess ||
       d_r0.alloc(sizeof(double) * (size_t)W * VILO_MAX_PRIOR_DIM) != hipSuccess)
     return fail(VILO_ERR_HIP);
   View d_mw{d_blob.p}, d_drop{(char *)d_blob.p + off_drop}, d_status{(char *)d_blob.p + off_flags}, d_general{(char *)d_blob.p + off_flags + sizeof(int) * (size_t)W},
       d_pbad{(char *)d_blob.p + off_flags + 2 * sizeof(int) * (size_t)W};
-  if (hipMemcpyAsync(d_blob.p, hblob.data(), blob_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(VILO_ERR_HIP);
+  if (hipMemcpyAsync(d_blob.p, hblob, blob_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(VILO_ERR_HIP);
   // preMarginalize: evaluate the factors at the current state (marginalization_factor.cpp:119-138)
   (void)hipEventRecord(ctx->ev0, ctx->stream);
   rc = vilo_marg_linearize(ctx, bd);

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--compression", default="none", choices=("none", "bz2", "lz4"), help="--write-bag: chunk compression (rosbag record --bz2 / --lz4)")
     ap.add_argument("--push-every", type=int, default=0, help="push the IMU / leg samples to the device-resident preintegration objects every N messages, "
                     "as they arrive, instead of in the image step (0: in the image step); same estimates, shorter image step")
+    ap.add_argument("--prior-form", default="factor", choices=("factor", "eigen"), help="what a marginalisation leaves as the prior's J0: the certified pivoted "
+                    "Cholesky factor (same information, a quarter of the time) or sqrt(S) V^T as the reference writes it (vilo_set_prior_form)")
     ap.add_argument("--contact-sensor-type", type=int, default=1, help="--bag: 0 / 1 the planner's flags (0: in place of the absent Kalman filter), 2 foot forces")
     a = ap.parse_args()
     cfg = synth.default_config()
@@ -41,6 +43,7 @@ def main():
         print("%s: %d messages of %d images (%d bytes)" % (a.write_bag, len(msgs), a.images, os.path.getsize(a.write_bag)))
         return
     ctx = api.Context(cfg, 0)
+    ctx.set_prior_form(a.prior_form)
     if a.bag:
         from cerberus_amd import rosbag
         sw = sequence.SlidingWindow(ctx, cfg, use_leg=0 if a.no_leg else 1)
