@@ -839,7 +839,28 @@ extern "C" void vilo_preint_streams_destroy(vilo_ctx *ctx, vilo_preint_streams *
   (void)hipSetDevice(s->device);
   if (s->d) (void)hipFree(s->d);
   if (s->di) (void)hipFree(s->di);
+  for (auto &c : s->scr) {
+    if (c.done) { if (c.pending) (void)hipEventSynchronize(c.done); (void)hipEventDestroy(c.done); }
+    if (c.dev) (void)hipFree(c.dev);
+    if (c.host) (void)hipHostFree(c.host);
+  }
   delete s;
+}
+// the pool's call scratch [which] with room for `bytes`, free to be written (the previous asynchronous use has completed)
+static int streams_scratch(vilo_ctx *ctx, vilo_preint_streams *s, int which, size_t bytes) {
+  vilo_preint_streams::Scratch &c = s->scr[which];
+  if (!c.done) VILO_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  if (c.pending) { VILO_HIP(hipEventSynchronize(c.done)); c.pending = false; }
+  if (c.bytes < bytes) {
+    if (c.dev) VILO_HIP(hipFree(c.dev));
+    if (c.host) VILO_HIP(hipHostFree(c.host));
+    c.dev = c.host = nullptr; c.bytes = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    VILO_HIP(hipMalloc(&c.dev, want));
+    VILO_HIP(hipHostMalloc(&c.host, want, hipHostMallocDefault));
+    c.bytes = want;
+  }
+  return VILO_OK;
 }
 static int check_ids(const vilo_preint_streams *s, int n, const int32_t *ids) {
   for (int i = 0; i < n; ++i) {
@@ -855,15 +876,24 @@ extern "C" int vilo_preint_streams_reset(vilo_ctx *ctx, vilo_preint_streams *s, 
   if (check_ids(s, n, ids) != VILO_OK) return VILO_ERR_BAD_ARG;
   VILO_HIP(hipSetDevice(ctx->device));
   const int lw = s->kind ? 6 : 10;
-  DevBuf d_i, d_f, d_l;
-  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_f.alloc(sizeof(vilo_sample) * (size_t)n)); VILO_HIP(d_l.alloc(sizeof(double) * lw * (size_t)n));
-  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  VILO_HIP(hipMemcpyAsync(d_f.p, first, sizeof(vilo_sample) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  VILO_HIP(hipMemcpyAsync(d_l.p, lin, sizeof(double) * lw * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  if (s->kind) hipLaunchKernelGGL(k_preint_imu_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->di);
-  else hipLaunchKernelGGL(k_preint_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i.as<int>(), d_f.as<vilo_sample>(), d_l.as<double>(), s->d);
+  // [first samples | linearisation points | ids] in one buffer, one copy; asynchronous on the context's stream (the caller's arrays are
+  // free on return: they were copied into the pool's page-locked mirror)
+  const size_t o_f = 0, o_l = o_f + sizeof(vilo_sample) * (size_t)n, o_i = o_l + sizeof(double) * lw * (size_t)n, total = o_i + sizeof(int) * (size_t)n;
+  int rc = streams_scratch(ctx, s, 0, total);
+  if (rc != VILO_OK) return rc;
+  vilo_preint_streams::Scratch &c = s->scr[0];
+  memcpy((char *)c.host + o_f, first, sizeof(vilo_sample) * (size_t)n);
+  memcpy((char *)c.host + o_l, lin, sizeof(double) * lw * (size_t)n);
+  memcpy((char *)c.host + o_i, ids, sizeof(int) * (size_t)n);
+  VILO_HIP(hipMemcpyAsync(c.dev, c.host, total, hipMemcpyHostToDevice, ctx->stream));
+  const vilo_sample *d_f = (const vilo_sample *)((char *)c.dev + o_f);
+  const double *d_l = (const double *)((char *)c.dev + o_l);
+  const int *d_i = (const int *)((char *)c.dev + o_i);
+  if (s->kind) hipLaunchKernelGGL(k_preint_imu_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i, d_f, d_l, s->di);
+  else hipLaunchKernelGGL(k_preint_stream_reset, dim3(n), dim3(64), 0, ctx->stream, n, d_i, d_f, d_l, s->d);
   VILO_HIP(hipGetLastError());
-  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  VILO_HIP(hipEventRecord(c.done, ctx->stream));
+  c.pending = true;
   return VILO_OK;
 }
 extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, const vilo_sample *samples,
@@ -876,20 +906,28 @@ extern "C" int vilo_preint_streams_push(vilo_ctx *ctx, vilo_preint_streams *s, i
   const int ns = offsets[n] - offsets[0];
   if (ns == 0) return VILO_OK;
   VILO_HIP(hipSetDevice(ctx->device));
-  DevBuf d_i, d_s, d_o, d_t;
-  VILO_HIP(d_i.alloc(sizeof(int) * (size_t)n)); VILO_HIP(d_s.alloc(sizeof(vilo_sample) * (size_t)offsets[n])); VILO_HIP(d_o.alloc(sizeof(int) * (size_t)(n + 1)));
-  if (!s->kind) VILO_HIP(d_t.alloc(sizeof(double) * 4 * LT_N * ((size_t)offsets[n] + (size_t)n)));   // leg terms: every sample + the stream's last one
-  VILO_HIP(hipMemcpyAsync(d_i.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  VILO_HIP(hipMemcpyAsync(d_s.p, samples, sizeof(vilo_sample) * (size_t)offsets[n], hipMemcpyHostToDevice, ctx->stream));
-  VILO_HIP(hipMemcpyAsync(d_o.p, offsets, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+  // [samples | offsets | ids] up in one copy, the leg-term scratch of the push kernel behind them; asynchronous on the context's stream:
+  // whatever uses the objects next (a batch's gather, vilo_preint_streams_read) is queued behind the kernel
+  const size_t o_s = 0, o_o = o_s + sizeof(vilo_sample) * (size_t)offsets[n], o_i = o_o + sizeof(int) * (size_t)(n + 1);
+  const size_t up = o_i + sizeof(int) * (size_t)n, o_t = (up + 255) & ~(size_t)255;
+  const size_t total = o_t + (s->kind ? 0 : sizeof(double) * 4 * LT_N * ((size_t)offsets[n] + (size_t)n));   // leg terms: every sample + the stream's last one
+  int rc = streams_scratch(ctx, s, 1, total);
+  if (rc != VILO_OK) return rc;
+  vilo_preint_streams::Scratch &c = s->scr[1];
+  memcpy((char *)c.host + o_s, samples, sizeof(vilo_sample) * (size_t)offsets[n]);
+  memcpy((char *)c.host + o_o, offsets, sizeof(int) * (size_t)(n + 1));
+  memcpy((char *)c.host + o_i, ids, sizeof(int) * (size_t)n);
+  VILO_HIP(hipMemcpyAsync(c.dev, c.host, up, hipMemcpyHostToDevice, ctx->stream));
+  const vilo_sample *d_s = (const vilo_sample *)((char *)c.dev + o_s);
+  const int *d_o = (const int *)((char *)c.dev + o_o), *d_i = (const int *)((char *)c.dev + o_i);
   if (s->kind)
-    hipLaunchKernelGGL(k_preint_imu_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
-                       d_i.as<int>(), s->di);
+    hipLaunchKernelGGL(k_preint_imu_stream_push, dim3(n), dim3(64), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s, d_o, d_i, s->di);
   else
-    hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(PAIR_THREADS), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s.as<vilo_sample>(), d_o.as<int>(),
-                       d_i.as<int>(), s->d, d_t.as<double>());
+    hipLaunchKernelGGL(k_preint_stream_push, dim3(n), dim3(PAIR_THREADS), 0, ctx->stream, n, (const vilo_config *)ctx->d_cfg, d_s, d_o, d_i, s->d,
+                       (double *)((char *)c.dev + o_t));
   VILO_HIP(hipGetLastError());
-  VILO_HIP(hipStreamSynchronize(ctx->stream));
+  VILO_HIP(hipEventRecord(c.done, ctx->stream));
+  c.pending = true;
   return VILO_OK;
 }
 extern "C" int vilo_preint_streams_read_imu(vilo_ctx *ctx, vilo_preint_streams *s, int n, const int32_t *ids, vilo_preint_imu *out) {

@@ -123,6 +123,11 @@ struct vilo_preint_streams {
   int n, device, kind;   // kind 0: IMULegIntegrationBase objects (d), 1: IntegrationBase objects (di)
   PreintStream *d;
   PreintImuStream *di;
+  // what a reset / push call hands the device (ids, offsets, samples; the push kernel's leg-term scratch): one grow-only device buffer and
+  // its page-locked host mirror per kind of call [0 reset, 1 push], and the event after which both may be written again. The calls are
+  // asynchronous on the context's stream — a hipMalloc / hipFree per argument and a stream synchronisation per call cost a one-robot
+  // replay more than the push kernel itself.
+  struct Scratch { void *dev = nullptr, *host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool pending = false; } scr[2];
 };
 // the prior a window sees: the host struct of its desc, or the host mirror of its pool slot
 inline const vilo_prior *vilo_win_prior(const vilo_window_desc &d, const vilo_resident_refs *r) {
