@@ -335,12 +335,25 @@ class Context:
     def solve_windows(self, windows, opts=None):
         """Estimator::optimization() solve half on a list of windows; states updated in place."""
         opts = opts or default_solve_opts()
-        b = Batch(self, windows)
-        try:
-            b.solve(opts)
-            return b.download()
-        finally:
-            b.close()
+        n = len(windows)
+        descs, states = (T.WindowDesc * n)(), (T.WindowState * n)()
+        for i, w in enumerate(windows):
+            descs[i], states[i] = w.desc(T)
+        return self.solve_window_descs(descs, states, opts)
+
+    def solve_window_descs(self, descs, states, opts):
+        """vilo_solve_windows on descriptor arrays the caller built (and keeps alive); VILO_ERR_NUMERIC is a per-window outcome
+        (termination 2 in that window's summary), everything else raises."""
+        n = len(descs)
+        summ = (T.SolveSummary * n)()
+        rc = lib().vilo_solve_windows(self.h, n, descs, states, C.byref(opts), summ)
+        if rc != -4:   # VILO_ERR_NUMERIC
+            self._check(rc)
+        return list(summ)
+
+    def set_host_pipeline(self, lanes, sub_windows=1024):
+        """vilo_set_host_pipeline: how vilo_solve_windows cuts a call with many host windows into sub-batches (lanes < 2: never)."""
+        self._check(lib().vilo_set_host_pipeline(self.h, lanes, sub_windows))
 
     def gauge_fix(self, before_arrays, w):
         keep = [np.ascontiguousarray(a) for a in before_arrays]

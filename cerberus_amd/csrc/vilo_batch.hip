@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "solver_types.hpp"
@@ -45,6 +46,40 @@ struct vilo_batch {
 namespace {
 
 // win_bad[w] = any live interval of window w whose covariance had no sqrt_info (prep_bad, written by the preparation)
+// What the solver reads of an IMULegIntegrationBase record (vilo_preint, 1955 doubles): the 33 scalars, the bias columns 21 .. 30 of the
+// Jacobian's rows 0 .. 20 (PreintHead, factors.hpp) and ONE triangle of the covariance (k_prepare_preint's Cholesky of the index-reversed
+// matrix takes the source's upper triangle; the literal inverse() route reads all of it and keeps the full upload). Host windows bring
+// their records up in this form — 739 doubles, 38 % of the bytes — and the device lays them out as the record the kernels index: the
+// Jacobian entries no factor reads are zero in that copy, the covariance's lower triangle is the mirror of the upper.
+#define REC_C_JAC 33
+#define REC_C_TRI (33 + 21 * 10)
+#define REC_C_N (REC_C_TRI + 31 * 32 / 2)   // 739
+static inline int rec_tri_off(int r) { return r * 31 - r * (r - 1) / 2; }   // first entry of row r (columns r .. 30) of the packed upper triangle
+static void rec_compact(const vilo_preint *src, double *dst) {
+  memcpy(dst, src, sizeof(double) * 33);
+  for (int r = 0; r < 21; ++r) memcpy(dst + REC_C_JAC + 10 * r, src->jacobian + r * 31 + 21, sizeof(double) * 10);
+  for (int r = 0; r < 31; ++r) memcpy(dst + REC_C_TRI + rec_tri_off(r), src->covariance + r * 31 + r, sizeof(double) * (31 - r));
+}
+__global__ void __launch_bounds__(256) k_expand_records(int n, const double *comp, vilo_preint *out) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const double *c = comp + (size_t)f * REC_C_N;
+  double *o = (double *)(out + f);
+  for (int e = threadIdx.x; e < (int)(sizeof(vilo_preint) / sizeof(double)); e += 256) {
+    double v;
+    if (e < 33) v = c[e];
+    else if (e < 33 + 961) {
+      const int r = (e - 33) / 31, q = (e - 33) - 31 * r;
+      v = (r < 21 && q >= 21) ? c[REC_C_JAC + 10 * r + q - 21] : 0.0;
+    } else {
+      const int r = (e - 33 - 961) / 31, q = (e - 33 - 961) - 31 * r;
+      const int a = min(r, q), b = max(r, q);
+      v = c[REC_C_TRI + a * 31 - a * (a - 1) / 2 + (b - a)];
+    }
+    o[e] = v;
+  }
+}
+
 __global__ void k_fold_win_bad(int W, const int *prep_bad, const unsigned char *imu_skip, int *win_bad) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
@@ -224,6 +259,7 @@ extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
 }
 
 int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, void *d_out);
+int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);   // kernels_wave.hip
 
 extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *init, vilo_batch **out) {
   return vilo_batch_create_refs(ctx, W, in, nullptr, init, out);
@@ -241,10 +277,10 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
   double t_prior = 0.0;
+  size_t rec_bytes_up = 0;   // bytes of preintegration records that crossed the bus when not the full records'
   std::vector<WinMeta> wins(W);
   std::vector<ChunkMeta> chunks;
   std::vector<WaveMeta> waves;
-  std::vector<std::vector<int>> chunk_ids;   // landmarks (window order) of every chunk
   std::vector<double> x0((size_t)W * XSTRIDE, 0.0), lam0;
   std::vector<unsigned char> lm_s;   // start frame per landmark (device order)
   std::vector<double> px0((size_t)W * 280, 0.0);
@@ -291,36 +327,44 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
     wm.const_mask = ((d.leg_bias_const || !d.use_leg) ? CONST_LB : 0) | (d.ex_const ? CONST_EX : 0) | (d.td_const ? CONST_TD : 0);
     bt->lm_off_host[w] = lm_total;
     bt->L_host[w] = L;
-    // landmark chunks: group by start frame, <= 64 per chunk, list order preserved inside a group
+    // landmark chunks: group by start frame (a stable counting sort: list order preserved inside a group), <= 64 per chunk. The device
+    // order of the window's landmarks is perm_host[lm_total ..): a chunk's landmarks are its lm_off .. lm_off + n entries of it.
     int local = 0;
-    for (int sf = 0; sf < F; ++sf) {
-      std::vector<int> ids;
-      for (int l = 0; l < L; ++l)
-        if (d.lm_start_frame[l] == sf) ids.push_back(l);
-      for (size_t c0 = 0; c0 < ids.size(); c0 += 64) {
-        const int n = (int)std::min<size_t>(64, ids.size() - c0);
-        ChunkMeta cm;
-        memset(&cm, 0, sizeof(cm));
-        cm.win = w; cm.s = sf; cm.n = n; cm.lm_off = lm_total + local; cm.lm_local = local;
-        int kmax = 0;
-        for (int i = 0; i < n; ++i) {
-          const int l = ids[c0 + i];
-          const int K = d.lm_obs_offset[l + 1] - d.lm_obs_offset[l];
-          if (K < 1 || sf + K > F) { ctx->err = "landmark observation range outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
-          kmax = std::max(kmax, K);
+    {
+      int first[VILO_MAX_FRAMES + 1] = {0};
+      for (int l = 0; l < L; ++l) {
+        const int sf = d.lm_start_frame[l];
+        if (sf < 0 || sf >= F) { ctx->err = "landmark start_frame outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+        ++first[sf + 1];
+      }
+      for (int sf = 0; sf < F; ++sf) first[sf + 1] += first[sf];
+      const size_t base = bt->perm_host.size();
+      bt->perm_host.resize(base + L); lam0.resize(base + L); lm_s.resize(base + L);
+      int fill[VILO_MAX_FRAMES];
+      for (int sf = 0; sf < F; ++sf) fill[sf] = first[sf];
+      for (int l = 0; l < L; ++l) {
+        const int sf = d.lm_start_frame[l], at = fill[sf]++;
+        bt->perm_host[base + at] = l; lam0[base + at] = s.inv_depth[l]; lm_s[base + at] = (unsigned char)sf;
+      }
+      for (int sf = 0; sf < F; ++sf) {
+        for (int c0 = first[sf]; c0 < first[sf + 1]; c0 += 64) {
+          const int n = std::min(64, first[sf + 1] - c0);
+          ChunkMeta cm;
+          memset(&cm, 0, sizeof(cm));
+          cm.win = w; cm.s = sf; cm.n = n; cm.lm_off = lm_total + local; cm.lm_local = local;
+          int kmax = 0;
+          for (int i = 0; i < n; ++i) {
+            const int l = bt->perm_host[base + c0 + i];
+            const int K = d.lm_obs_offset[l + 1] - d.lm_obs_offset[l];
+            if (K < 1 || sf + K > F) { ctx->err = "landmark observation range outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
+            kmax = std::max(kmax, K);
+          }
+          cm.kmax = kmax;
+          cm.gram_off = gram_total;
+          gram_total += kmax;
+          local += n;
+          chunks.push_back(cm);
         }
-        cm.kmax = kmax;
-        cm.gram_off = gram_total;
-        gram_total += kmax;
-        for (int i = 0; i < n; ++i) {
-          const int l = ids[c0 + i];
-          bt->perm_host.push_back(l);
-          lam0.push_back(s.inv_depth[l]);
-          lm_s.push_back((unsigned char)sf);
-        }
-        chunk_ids.push_back(std::vector<int>(ids.begin() + c0, ids.begin() + c0 + n));
-        local += n;
-        chunks.push_back(cm);
       }
     }
     if (local != L) { ctx->err = "landmark start_frame outside the window"; vilo_batch_destroy(ctx, bt); return VILO_ERR_BAD_ARG; }
@@ -365,6 +409,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       any_prior = true;
     }
   }
+  t_prior = now() - t_begin;   // (pass 1's share of the packing time, for VILO_HOST_TIMING)
   // ---- pass 2 (one host thread per slice of windows): the heavy copies — wave-packed observation image, states, prior staging ----
   double *obs = (double *)vilo_host_stage(ctx, 2, sizeof(double) * std::max<size_t>(1, obs_total));
   unsigned char *flags = (unsigned char *)vilo_host_stage(ctx, 3, std::max<size_t>(1, flags_total));
@@ -391,9 +436,10 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       memset(ob, 0, sizeof(double) * (size_t)wv.kmax * 11 * lanes);
       memset(fl, 0, (size_t)wv.kmax * lanes);
       for (int g = 0; g < wv.nseg; ++g) {
-        const std::vector<int> &ids = chunk_ids[wv.seg_chunk[g]];
-        for (size_t i = 0; i < ids.size(); ++i) {
-          const int l = ids[i], lane = wv.seg_lane0[g] + (int)i;
+        const ChunkMeta &cm = chunks[wv.seg_chunk[g]];
+        const int *ids = bt->perm_host.data() + cm.lm_off;   // the chunk's landmarks (window order)
+        for (int i = 0; i < cm.n; ++i) {
+          const int l = ids[i], lane = wv.seg_lane0[g] + i;
           const int o0 = d.lm_obs_offset[l], K = d.lm_obs_offset[l + 1] - o0;
           for (int t = 0; t < K; ++t) {
             for (int f = 0; f < 11; ++f) ob[((size_t)t * 11 + f) * lanes + lane] = d.obs[(size_t)(o0 + t) * 11 + f];
@@ -440,7 +486,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       }
     }
   };
-  vilo::parallel_items(W, 8, fill_window);   // (worker_pool.hpp: host threads parked between batches)
+  vilo::parallel_items(W, 8, fill_window, ctx->pool);   // (worker_pool.hpp: host threads parked between batches)
   for (int w = 0; w < W; ++w)
     if (win_err[w]) {
       ctx->err = win_err[w] == 1 ? "unsupported prior block" : "prior couples speed/leg biases of two frames";
@@ -448,6 +494,10 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       return VILO_ERR_UNSUPPORTED;
     }
   const double t_packed = now();
+  // a lane of vilo_solve_windows' pipeline: the uploads of the lanes go one after the other at the link's rate (side by side every lane's
+  // solve would start when ALL uploads are through); held until this batch's uploads are complete, i.e. to the end of the call
+  std::unique_lock<std::mutex> dma_turn;
+  if (ctx->dma_turn) dma_turn = std::unique_lock<std::mutex>(*ctx->dma_turn);
   BatchDev &D = bt->d;
   D.W = W; D.n_chunks = (int)chunks.size(); D.n_lm = lm_total; D.n_gram = gram_total; D.n_waves = (int)waves.size();
   // compact visual rows / Gram slots in the solve passes: td must be a constant block in every window (estimate_td: 0, all of the
@@ -596,7 +646,35 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
       }
       host_rec.push_back(w);
     }
-    if (rc == VILO_OK && !host_rec.empty()) {
+    static const bool no_compact_rec = getenv("VILO_FULL_RECORD_UPLOAD") != nullptr;
+    if (rc == VILO_OK && leg && (int)host_rec.size() == W && ctx->sqrt_info_mode == 0 && !no_compact_rec) {
+      // every window's records from host memory, default sqrt_info route: the compact form (above) through the two page-locked chunks, the
+      // worker pool gathering chunk k + 1 while the DMA engine reads chunk k; the device expands each chunk behind its copy
+      const size_t per_win = sizeof(double) * REC_C_N * 10, chunk_w = std::max<size_t>(1, ((size_t)32 << 20) / per_win);
+      char *ring[2] = {(char *)vilo_host_stage(ctx, 4, per_win * chunk_w), (char *)vilo_host_stage(ctx, 5, per_win * chunk_w)};
+      if (!ctx->rec_ev[0]) { (void)hipEventCreateWithFlags(&ctx->rec_ev[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->rec_ev[1], hipEventDisableTiming); }
+      void *d_comp = nullptr;
+      if (!ring[0] || !ring[1] || !ctx->rec_ev[0] || !ctx->rec_ev[1] || dev_alloc_bytes(ctx, bt, &d_comp, per_win * (size_t)W) != VILO_OK) rc = VILO_ERR_HIP;
+      bool used[2] = {false, false};
+      for (size_t c0 = 0, ci = 0; rc == VILO_OK && c0 < (size_t)W; c0 += chunk_w, ++ci) {
+        const int sl = (int)(ci & 1);
+        const size_t cn = std::min(chunk_w, (size_t)W - c0);
+        if (used[sl] && hipEventSynchronize(ctx->rec_ev[sl]) != hipSuccess) { rc = VILO_ERR_HIP; break; }
+        vilo::parallel_items((int)cn, 4, [&](int i) {
+          const int w = (int)c0 + i, nr = in[w].n_frames - 1;
+          double *dst = (double *)(ring[sl] + per_win * (size_t)i);
+          for (int k = 0; k < nr; ++k) rec_compact(in[w].preint + k, dst + (size_t)REC_C_N * k);
+          if (nr < 10) memset(dst + (size_t)REC_C_N * nr, 0, sizeof(double) * REC_C_N * (size_t)(10 - nr));   // (intervals the window does not have: zero records, as before)
+        }, ctx->pool);
+        if (hipMemcpyAsync((char *)d_comp + per_win * c0, ring[sl], per_win * cn, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = VILO_ERR_HIP; break; }
+        if (hipEventRecord(ctx->rec_ev[sl], ctx->stream) != hipSuccess) { rc = VILO_ERR_HIP; break; }
+        used[sl] = true;
+        hipLaunchKernelGGL(k_expand_records, dim3((unsigned)(cn * 10)), dim3(256), 0, ctx->stream, (int)(cn * 10), (const double *)d_comp + (size_t)REC_C_N * 10 * c0,
+                           (vilo_preint *)d_pre + 10 * c0);
+      }
+      if (rc == VILO_OK && hipGetLastError() != hipSuccess) rc = VILO_ERR_HIP;
+      rec_bytes_up = per_win * (size_t)W;
+    } else if (rc == VILO_OK && !host_rec.empty()) {
       // The caller's records (156 KB per window, pageable) go up through two page-locked chunks of the context: the worker pool copies
       // chunk k + 1 into one while the DMA engine reads chunk k out of the other. (One hipMemcpyAsync per window straight from the caller's
       // arrays moved 640 MB of a 4096-window batch at 11.5 GB/s — the runtime's own bounce buffer, one thread.)
@@ -613,7 +691,7 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
           const int w = host_rec[c0 + i];
           const void *src = leg ? (const void *)in[w].preint : (const void *)in[w].preint_imu;
           memcpy(ring[sl] + per_win * (size_t)i, src, rec * (size_t)(in[w].n_frames - 1));
-        });
+        }, ctx->pool);
         // consecutive windows of the chunk that are consecutive in the batch go up in one copy
         for (size_t i = 0; i < cn && rc == VILO_OK;) {
           size_t j = i + 1;
@@ -653,9 +731,9 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   if (rc != VILO_OK) { vilo_batch_destroy(ctx, bt); return rc; }
   ctx->last_create_ms[0] = now() - t_begin; ctx->last_create_ms[1] = t_packed - t_begin; ctx->last_create_ms[2] = t_uploaded - t_packed; ctx->last_create_ms[3] = t_prep - t_uploaded;
   ctx->last_create_bytes = (double)(sizeof(double) * (obs_total + (size_t)W * XSTRIDE + (any_prior ? (size_t)W * (96 * 96 + 96) : 0)) + flags_total +
-                                    (in[0].use_leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu)) * (size_t)W * 10);
+                                    (rec_bytes_up ? rec_bytes_up : (in[0].use_leg ? sizeof(vilo_preint) : sizeof(vilo_preint_imu)) * (size_t)W * 10));
   if (timing)
-    fprintf(stderr, "[vilo_batch_create] W=%d pack %.2f ms (prior staging %.2f) alloc+upload %.2f ms preint %.2f ms reset %.2f ms\n", W, t_packed - t_begin, t_prior,
+    fprintf(stderr, "[vilo_batch_create] W=%d pack %.2f ms (of which the serial table pass %.2f) alloc+upload %.2f ms preint %.2f ms reset %.2f ms\n", W, t_packed - t_begin, t_prior,
             t_uploaded - t_packed, t_prep - t_uploaded, now() - t_prep);
   *out = bt;
   return VILO_OK;
@@ -869,19 +947,115 @@ extern "C" int vilo_batch_download(vilo_ctx *ctx, vilo_batch *bt, vilo_window_st
   return VILO_OK;
 }
 
-extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
-                                  const vilo_solve_opts *opts, vilo_solve_summary *out) {
+// one batch of host windows through create / solve / download on context c; `keep` (optional) receives the caller's states of these windows
+// as they were before the download overwrote them
+static int solve_host_batch(vilo_ctx *c, int n, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
+                            vilo_solve_summary *out, std::vector<double> *keep, double *solve_ms) {
   vilo_batch *bt = nullptr;
-  int rc = vilo_batch_create(ctx, n_windows, in, inout, &bt);
+  int rc = vilo_batch_create(c, n, in, inout, &bt);
   if (rc != VILO_OK) return rc;
-  rc = vilo_batch_solve(ctx, bt, opts);
-  if (rc == VILO_OK) rc = vilo_batch_download(ctx, bt, inout, out);
+  rc = vilo_batch_solve(c, bt, opts);
+  if (rc == VILO_OK && solve_ms) *solve_ms = c->last_solve_ms;
+  if (rc == VILO_OK && keep) {
+    for (int w = 0; w < n; ++w) {
+      const int F = in[w].n_frames, L = in[w].n_landmarks;
+      const vilo_window_state &s = inout[w];
+      keep->insert(keep->end(), s.pose, s.pose + 7 * F);
+      keep->insert(keep->end(), s.speed_bias, s.speed_bias + 9 * F);
+      keep->insert(keep->end(), s.leg_bias, s.leg_bias + 4 * F);
+      keep->insert(keep->end(), s.ex_pose, s.ex_pose + 14);
+      keep->push_back(s.td[0]);
+      if (L > 0) keep->insert(keep->end(), s.inv_depth, s.inv_depth + L);
+    }
+  }
+  if (rc == VILO_OK) rc = vilo_batch_download(c, bt, inout, out);
   if (rc == VILO_OK && out) {
-    for (int w = 0; w < n_windows; ++w)
+    for (int w = 0; w < n; ++w)
       if (out[w].termination == 2) rc = VILO_ERR_NUMERIC;
   }
-  vilo_batch_destroy(ctx, bt);
+  vilo_batch_destroy(c, bt);
   return rc;
+}
+static void restore_host_states(int n, const vilo_window_desc *in, vilo_window_state *inout, const std::vector<double> &keep) {
+  const double *q = keep.data();
+  for (int w = 0; w < n; ++w) {
+    const int F = in[w].n_frames, L = in[w].n_landmarks;
+    vilo_window_state &s = inout[w];
+    memcpy(s.pose, q, sizeof(double) * 7 * F); q += 7 * F;
+    memcpy(s.speed_bias, q, sizeof(double) * 9 * F); q += 9 * F;
+    memcpy(s.leg_bias, q, sizeof(double) * 4 * F); q += 4 * F;
+    memcpy(s.ex_pose, q, sizeof(double) * 14); q += 14;
+    s.td[0] = *q++;
+    if (L > 0) { memcpy(s.inv_depth, q, sizeof(double) * L); q += L; }
+  }
+}
+
+// Estimator::optimization()'s solve half on host windows. Small calls: one batch. From two sub-batches' worth of windows up (default
+// 2 x 1024; vilo_set_host_pipeline) the call is cut into sub-batches that go through `lanes` internal contexts of the same device, one
+// host thread each: while one lane's records are on the DMA engines or its windows in the solver, the other lanes pack theirs — the three
+// resources a hand-over of host windows needs (host cores, PCIe, GPU) work at the same time instead of one after the other. The windows
+// are independent and every lane solves with the form the whole call would take as ONE batch, so the answer is the monolithic call's bit
+// for bit (tests/test_gpu_parity.py::test_host_pipeline_...). Nothing is written to `inout` unless every sub-batch came through (or
+// failed numerically, which is a per-window outcome): the states a finished sub-batch overwrote are put back.
+extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                                  const vilo_solve_opts *opts, vilo_solve_summary *out) {
+  if (!ctx || !in || !inout || !opts || n_windows <= 0) return VILO_ERR_BAD_ARG;
+  const int sub = ctx->pipe_sub, lanes_want = ctx->pipe_lanes;
+  if (lanes_want < 2 || sub <= 0 || n_windows < 2 * sub || ctx->profile) return solve_host_batch(ctx, n_windows, in, inout, opts, out, nullptr, nullptr);
+  const int n_sub = (n_windows + sub - 1) / sub, per = (n_windows + n_sub - 1) / n_sub;   // equal shares: no small tail batch
+  const int n_lanes = std::min(lanes_want, n_sub);
+  while ((int)ctx->lanes.size() < n_lanes) {
+    vilo_ctx *l = nullptr;
+    const int rc = vilo_create(&l, &ctx->cfg, ctx->device);
+    if (rc != VILO_OK) { ctx->err = "vilo_solve_windows: no context for a pipeline lane"; return rc; }
+    // the lanes pack side by side: each brings its own share of the host's threads (at most the shared pool's 16, at least 2)
+    const int hw = (int)std::thread::hardware_concurrency();
+    l->dma_turn = &ctx->dma_m;
+    l->pool = new vilo::WorkerPool(std::max(2, std::min(16, (hw > 0 ? hw : 1) / std::max(1, lanes_want))) - 1);
+    ctx->lanes.push_back(l);
+  }
+  BatchDev probe;
+  memset(&probe, 0, sizeof(probe));
+  probe.W = n_windows;
+  const int form = vilo_solver_form(ctx, probe);   // what ONE batch of all the windows would be solved with
+  std::vector<int> rcs(n_sub, VILO_OK);
+  std::vector<std::vector<double>> keep(n_sub);
+  std::vector<double> ms(n_sub, 0.0);
+  std::vector<std::thread> th;
+  for (int li = 0; li < n_lanes; ++li) {
+    vilo_ctx *l = ctx->lanes[li];
+    l->cfg = ctx->cfg; l->sqrt_info_mode = ctx->sqrt_info_mode; l->solver_form = form; l->compact_rows = ctx->compact_rows;
+    l->initial_mu = ctx->initial_mu; l->prior_form = ctx->prior_form; l->err.clear();
+    th.emplace_back([&, li, l] {
+      for (int i = li; i < n_sub; i += n_lanes) {
+        const int w0 = i * per, n = std::min(per, n_windows - w0);
+        if (n <= 0) break;
+        rcs[i] = solve_host_batch(l, n, in + w0, inout + w0, opts, out ? out + w0 : nullptr, &keep[i], &ms[i]);
+        if (rcs[i] != VILO_OK && rcs[i] != VILO_ERR_NUMERIC) break;
+      }
+    });
+  }
+  for (std::thread &t : th) t.join();
+  int rc = VILO_OK;
+  for (int i = 0; i < n_sub; ++i)
+    if (rcs[i] != VILO_OK && rcs[i] != VILO_ERR_NUMERIC) { rc = rcs[i]; ctx->err = ctx->lanes[i % n_lanes]->err; break; }
+  if (rc != VILO_OK) {   // a sub-batch was refused or lost its device: the call as a whole did not happen
+    for (int i = 0; i < n_sub; ++i) {
+      const int w0 = i * per, n = std::min(per, n_windows - w0);
+      if (n > 0 && !keep[i].empty() && (rcs[i] == VILO_OK || rcs[i] == VILO_ERR_NUMERIC)) restore_host_states(n, in + w0, inout + w0, keep[i]);
+    }
+    return rc;
+  }
+  ctx->last_solve_ms = 0.0;
+  for (int i = 0; i < n_sub; ++i) { ctx->last_solve_ms += ms[i]; if (rcs[i] == VILO_ERR_NUMERIC) rc = VILO_ERR_NUMERIC; }
+  return rc;
+}
+
+// lanes < 2 or sub_windows <= 0: every vilo_solve_windows call is one batch
+extern "C" int vilo_set_host_pipeline(vilo_ctx *ctx, int lanes, int sub_windows) {
+  if (!ctx || lanes < 0 || lanes > 8 || sub_windows < 0) return VILO_ERR_BAD_ARG;
+  ctx->pipe_lanes = lanes; ctx->pipe_sub = sub_windows;
+  return VILO_OK;
 }
 
 // host wall time inside the last vilo_batch_create of this context: [0] total, [1] packing, [2] allocation + upload of observations /

@@ -56,6 +56,10 @@ extern "C" int vilo_create(vilo_ctx **out, const vilo_config *cfg, int device) {
   if (const char *e = getenv("VILO_SOLVER"))
     ctx->solver_form = !strcmp(e, "mw8") ? VILO_SOLVER_MW8 : (!strcmp(e, "wave") ? VILO_SOLVER_WAVE : (!strcmp(e, "split") ? VILO_SOLVER_SPLIT : VILO_SOLVER_AUTO));
   ctx->compact_rows = getenv("VILO_NO_COMPACT") ? 0 : 1;
+  if (const char *e = getenv("VILO_HOST_PIPELINE")) {   // "lanes,sub_windows"; "0" switches the sub-batch pipeline of vilo_solve_windows off
+    int l = 0, sw = 1024;
+    if (sscanf(e, "%d,%d", &l, &sw) >= 1 && l >= 0 && l <= 8 && sw >= 0) { ctx->pipe_lanes = l; ctx->pipe_sub = sw; }
+  }
   for (int i = 0; i < VILO_NKERNEL; ++i) { ctx->kernel_ms[i] = 0.0; ctx->kernel_launches[i] = 0; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
       hipEventCreate(&ctx->ev1) != hipSuccess || hipMalloc((void **)&ctx->d_cfg, sizeof(vilo_config)) != hipSuccess ||
@@ -74,6 +78,9 @@ extern "C" int vilo_device_count(void) {
 
 extern "C" void vilo_destroy(vilo_ctx *ctx) {
   if (!ctx) return;
+  for (vilo_ctx *l : ctx->lanes) vilo_destroy(l);
+  ctx->lanes.clear();
+  if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; ctx->pool = nullptr; }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);

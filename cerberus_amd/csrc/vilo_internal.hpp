@@ -5,12 +5,14 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/vilo_gpu.h"
 #include "factors.hpp"
+#include "worker_pool.hpp"
 
 #define VILO_F 11          // frames in a full window
 #define VILO_NB 13         // speed-bias (9) + leg-bias (4) local dims per frame: the "B part"
@@ -51,6 +53,12 @@ struct vilo_ctx {
   // may use the compact 16-column visual rows (vilo_set_compact_rows). VILO_SOLVER / VILO_NO_COMPACT give the defaults at vilo_create.
   int solver_form = -1;
   int compact_rows = 1;
+  // vilo_solve_windows on many host windows: sub-batches of pipe_sub windows through pipe_lanes internal contexts of the same device
+  // (created at the first such call, destroyed with this one), one host thread each (vilo_set_host_pipeline; VILO_HOST_PIPELINE=lanes,sub)
+  int pipe_lanes = 4, pipe_sub = 1024;
+  std::vector<vilo_ctx *> lanes;
+  vilo::WorkerPool *pool = nullptr;   // a lane's own host threads (null: the library's shared pool)
+  std::mutex dma_m, *dma_turn = nullptr;   // the lanes' uploads take turns (a lane points at its parent's mutex)
 };
 
 // grow-only host buffer number `slot` of a context, at least `bytes` long (contents unspecified). Page-locked up to 1 GiB per buffer —

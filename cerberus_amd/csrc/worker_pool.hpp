@@ -32,6 +32,7 @@ class WorkerPool {
     int n = 0, busy = 0;
     std::atomic<int> next{0};
     unsigned long long gen = 0;
+    bool stop = false;   // shutdown(): the workers leave (the block itself stays, like everything else here)
     std::exception_ptr err;
   };
 
@@ -41,6 +42,14 @@ class WorkerPool {
   }
   ~WorkerPool() {}   // (the workers stay parked on st_, which is leaked deliberately: see above)
   int size() const { return nt_; }
+  // A pool that belongs to an object with a lifetime (a context's pipeline lane): its workers end; run() afterwards works on the caller alone.
+  void shutdown() {
+    State &s = *st_;
+    std::lock_guard<std::mutex> serial(s.run_m);
+    { std::lock_guard<std::mutex> lk(s.m); s.stop = true; }
+    s.cv_work.notify_all();
+    pid_ = -1;
+  }
   void run(int n, const std::function<void(int)> &fn) {
     if (getpid() != pid_) {   // a fork()ed child: no workers here
       for (int i = 0; i < n; ++i) fn(i);
@@ -80,7 +89,8 @@ class WorkerPool {
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(s->m);
-        s->cv_work.wait(lk, [&] { return s->gen != seen; });
+        s->cv_work.wait(lk, [&] { return s->gen != seen || s->stop; });
+        if (s->stop) return;
         seen = s->gen;
       }
       drain(s);
@@ -93,14 +103,16 @@ class WorkerPool {
   pid_t pid_;
 };
 
-// fn(0) .. fn(n - 1) on up to 16 threads (the caller included), inline when there are fewer than 2 * min_per_thread items
-inline void parallel_items(int n, int min_per_thread, const std::function<void(int)> &fn) {
+// fn(0) .. fn(n - 1) on up to 16 threads (the caller included), inline when there are fewer than 2 * min_per_thread items; `own`: a pool
+// of the caller's instead of the library's shared one (jobs of one pool run one at a time: callers that work side by side bring their own)
+inline void parallel_items(int n, int min_per_thread, const std::function<void(int)> &fn, WorkerPool *own = nullptr) {
   const int hw = (int)std::thread::hardware_concurrency();
   const int nt = std::max(1, std::min({hw > 0 ? hw : 1, 16, n / std::max(1, min_per_thread)}));
   if (nt <= 1) {
     for (int i = 0; i < n; ++i) fn(i);
     return;
   }
+  if (own) { own->run(n, fn); return; }
   static WorkerPool pool(std::max(1, std::min(hw > 0 ? hw : 1, 16) - 1));   // (+ the caller)
   pool.run(n, fn);
 }

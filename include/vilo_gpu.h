@@ -243,6 +243,11 @@ int vilo_preint_streams_read_imu(vilo_ctx *ctx, vilo_preint_streams *pool, int n
  * solver result (double2vector's gauge fix is vilo_gauge_fix below). */
 int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
                        const vilo_solve_opts *opts, vilo_solve_summary *out);
+/* Many host windows in one vilo_solve_windows call (from 2 * sub_windows up) go through `lanes` internal contexts of the same device in
+ * sub-batches, one host thread per lane, so that packing, the PCIe transfer and the solver work at the same time; the result is the one
+ * batch's bit for bit, and `inout` is written only if every sub-batch came through. Default 4 lanes of 1024 windows
+ * (VILO_HOST_PIPELINE="lanes,sub_windows" at vilo_create); lanes < 2 or sub_windows == 0: always one batch. */
+int vilo_set_host_pipeline(vilo_ctx *ctx, int lanes, int sub_windows);
 
 /* Device-resident form of the same call, for batches (independent windows: robots / replays / seeds). */
 int vilo_batch_create(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, const vilo_window_state *init,

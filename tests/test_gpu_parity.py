@@ -495,6 +495,55 @@ def test_path_parity_with_the_oracles_own_preintegration(ctx, cfg, ocfg):
     assert worst < 1e-8, worst
 
 
+def test_host_pipeline_gives_the_one_batch_answer(cfg, ocfg):
+    """vilo_solve_windows cut into sub-batches over internal lanes (vilo_set_host_pipeline): bit for bit the one batch's states, costs and
+    summaries, ragged windows and an uneven last share included; a window with a NaN state fails alone; a refused window anywhere leaves every state
+    of the call as it was (estimator.cpp:848-901: the call takes host arrays and either optimises them or does not)."""
+    import ctypes as C
+    from cerberus_amd import api, _ctypes as T
+    specs = [dict(n_landmarks=40, seed=1), dict(n_landmarks=7, seed=2), dict(n_landmarks=90, seed=3), dict(n_landmarks=40, seed=4, with_prior=False)]
+    base = [_fresh(cfg, ocfg, **s) for s in specs]
+    N = 23
+
+    def crowd():
+        return [base[i % 4].twin() for i in range(N)]
+    opts = api.default_solve_opts(True, 4)
+    one, piped = crowd(), crowd()
+    c1 = api.Context(cfg, 0); c1.set_host_pipeline(0, 0)
+    c3 = api.Context(cfg, 0); c3.set_host_pipeline(3, 4)      # 23 windows -> 6 sub-batches of 4, 4, 4, 4, 4, 3 over three lanes
+    try:
+        s1 = c1.solve_windows(one, opts)
+        s3 = c3.solve_windows(piped, opts)
+        for a, b in zip(s1, s3):
+            assert bytes(a) == bytes(b)
+        for wa, wb in zip(one, piped):
+            for x, y in zip(wa.state_arrays(), wb.state_arrays()):
+                np.testing.assert_array_equal(x, y)
+        assert not np.array_equal(piped[0].pose, base[0].pose)       # (it did move)
+        # a window with a non-finite observation fails by itself, in whatever sub-batch it sits
+        sick = crowd()
+        sick[17].pose[4, 1] = np.nan
+        s = c3.solve_windows(sick, opts)
+        assert s[17].termination == 2 and all(x.termination != 2 for i, x in enumerate(s) if i != 17)
+        for i in (0, 16, 18, 22):
+            for x, y in zip(sick[i].state_arrays(), one[i].state_arrays()):
+                np.testing.assert_array_equal(x, y)
+        # a refused window in the LAST sub-batch: the sub-batches before it had been solved and downloaded by then
+        bad = crowd()
+        before = [w.clone_state() for w in bad]
+        bad[21].lm_obs_offset = bad[21].lm_obs_offset.copy(); bad[21].lm_obs_offset[3] = bad[21].lm_obs_offset[5] + 1
+        descs, states, summ = (T.WindowDesc * N)(), (T.WindowState * N)(), (T.SolveSummary * N)()
+        for i, w in enumerate(bad):
+            descs[i], states[i] = w.desc(T)
+        rc = api.lib().vilo_solve_windows(c3.h, N, descs, states, C.byref(opts), summ)
+        assert rc == -2 and b"landmark observation table" in api.lib().vilo_last_error(c3.h)
+        for w, k in zip(bad, before):
+            for x, y in zip(w.state_arrays(), k):
+                np.testing.assert_array_equal(x, y)
+    finally:
+        c1.close(); c3.close()
+
+
 def test_batch_of_windows_matches_single(ctx, cfg, ocfg):
     """Independent windows in one batch give the same answers as solved alone; ragged landmark counts,
     a window without prior, >64 landmarks per start frame (multi-chunk groups)."""
