@@ -339,9 +339,26 @@ def host_inclusive_block(ctx, cfg, lib, opts, landmarks, rate, W=4096, reps=3):
         assert sum(s.iterations for s in summ) == W * ITERS
         best = ms if best is None else min(best, ms)
     same = all(np.array_equal(a, np.concatenate([np.ravel(x) for x in w.state_arrays()])) for a, w in zip(final_one, (ws[0], ws[W // 2], ws[-1])))
+    # Estimator::optimization() as a whole on the same host windows: solve + gauge fix + marginalisation (MARGIN_OLD), the priors back in host memory
+    from cerberus_amd.synth import PriorData
+    outs = [PriorData() for _ in ws]
+    priors, summ_o = (T.Prior * W)(), (T.SolveSummary * W)()
+    for i, o in enumerate(outs):
+        priors[i] = o.struct
+    fl = (C.c_int * W)(*([0] * W))
+    opt_ms = None
+    for _ in range(2):
+        restore()
+        t0 = time.perf_counter()
+        ctx._check(lib.vilo_optimize_windows(ctx.h, W, descs, states, C.byref(opts), fl, priors, summ_o))
+        ms = 1e3 * (time.perf_counter() - t0)
+        opt_ms = ms if opt_ms is None else min(opt_ms, ms)
+    assert all(priors[i].valid == 1 and priors[i].n == 86 for i in (0, W // 2, W - 1))
     return {"windows": W, "value": W * ITERS / (best * 1e-3), "unit": "GN window-iterations/s", "ms": best,
             "h2d_gbps": one["bytes_to_device"] / (best * 1e-3) / 1e9, "bytes_to_device": one["bytes_to_device"],
             "bitwise_equal_to_one_batch": bool(same), "as_one_batch": one,
+            "optimize_windows": {"ms": opt_ms, "windows_per_s": W / (opt_ms * 1e-3),
+                                 "what": "ONE vilo_optimize_windows call on the same host windows: %d iterations, gauge fix, MARGIN_OLD marginalisation, the next priors (86 x 86) back in host memory" % ITERS},
             "what": ("ONE vilo_solve_windows call (%d fixed iterations) on %d config-2 windows handed over in host memory, wall time of the call (best of %d): "
                      "sub-batches of 1024 windows through four lanes of the context — host threads pack while the DMA engines and the solver work on "
                      "the lanes before; `as_one_batch`: the same windows as a single batch, phase by phase" % (ITERS, W, reps))}

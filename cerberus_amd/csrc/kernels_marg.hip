@@ -1261,12 +1261,17 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
                        refs[0].prior_pool->dJ, refs[0].prior_pool->dr);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return VILO_ERR_HIP;
   }
-  std::vector<double> J0, r0((size_t)W * VILO_MAX_PRIOR_DIM);
+  // priors that go back to host memory: through the context's reusable page-locked staging (a fresh pageable vector of W x 74 KB was
+  // zero-filled, then filled again through the runtime's bounce buffer: most of a fleet's marginalisation call)
+  const double *J0 = nullptr, *r0 = nullptr;
   if (any_host) {
-    J0.resize((size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM);
-    if (hipMemcpy(J0.data(), d_J0.p, J0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(r0.data(), d_r0.p, r0.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    const size_t nJ = (size_t)W * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, nr = (size_t)W * VILO_MAX_PRIOR_DIM;
+    double *hJ = (double *)vilo_host_stage(ctx, 7, sizeof(double) * (nJ + nr));
+    if (!hJ) return fail(VILO_ERR_HIP);
+    if (hipMemcpyAsync(hJ, d_J0.p, nJ * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(hJ + nJ, d_r0.p, nr * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
       return fail(VILO_ERR_HIP);
+    J0 = hJ; r0 = hJ + nJ;
   }
   for (int w = 0; w < W; ++w) {
     const MargWin &M = mws[w];
@@ -1309,10 +1314,8 @@ static int marginalize_batch(vilo_ctx *ctx, vilo_batch *bt, int W, const vilo_wi
       xo += kept_gs[w][k];
     }
     if (pooled) continue;
-    for (int i = 0; i < M.n; ++i) {
-      for (int j = 0; j < M.n; ++j) p.J0[(size_t)i * M.n + j] = J0[(size_t)w * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM + (size_t)i * M.n + j];
-      p.r0[i] = r0[(size_t)w * VILO_MAX_PRIOR_DIM + i];
-    }
+    memcpy(p.J0, J0 + (size_t)w * VILO_MAX_PRIOR_DIM * VILO_MAX_PRIOR_DIM, sizeof(double) * (size_t)M.n * M.n);   // (n x n packed on both sides)
+    memcpy(p.r0, r0 + (size_t)w * VILO_MAX_PRIOR_DIM, sizeof(double) * M.n);
   }
   if (any_bad) { ctx->err = "non-finite marginalisation result (the windows concerned continue without a prior)"; return VILO_ERR_NUMERIC; }
   return VILO_OK;
@@ -1384,6 +1387,15 @@ extern "C" int vilo_optimize_windows_resident(vilo_ctx *ctx, int W, const vilo_w
 extern "C" int vilo_optimize_windows(vilo_ctx *ctx, int W, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
                                      const int *marginalization_flag, vilo_prior *next_prior, vilo_solve_summary *summaries) {
   if (marginalization_flag && !next_prior) return VILO_ERR_BAD_ARG;
+  if (!ctx || W <= 0 || !in || !inout || !opts) return VILO_ERR_BAD_ARG;
+  // many host windows: sub-batches over the context's pipeline lanes (vilo_set_host_pipeline), like vilo_solve_windows — each window's
+  // solve, gauge fix and marginalisation are its own, so the call's results are the one batch's
+  int rc = VILO_OK;
+  if (vilo_run_on_lanes(ctx, W, in, inout, [&](vilo_ctx *l, int w0, int n) {
+        return vilo_optimize_windows_resident(l, n, in + w0, nullptr, inout + w0, opts, marginalization_flag ? marginalization_flag + w0 : nullptr,
+                                              next_prior ? next_prior + w0 : nullptr, summaries ? summaries + w0 : nullptr);
+      }, &rc))
+    return rc;
   return vilo_optimize_windows_resident(ctx, W, in, nullptr, inout, opts, marginalization_flag, next_prior, summaries);
 }
 

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -947,27 +948,12 @@ extern "C" int vilo_batch_download(vilo_ctx *ctx, vilo_batch *bt, vilo_window_st
   return VILO_OK;
 }
 
-// one batch of host windows through create / solve / download on context c; `keep` (optional) receives the caller's states of these windows
-// as they were before the download overwrote them
-static int solve_host_batch(vilo_ctx *c, int n, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts,
-                            vilo_solve_summary *out, std::vector<double> *keep, double *solve_ms) {
+// one batch of host windows through create / solve / download on context c
+static int solve_host_batch(vilo_ctx *c, int n, const vilo_window_desc *in, vilo_window_state *inout, const vilo_solve_opts *opts, vilo_solve_summary *out) {
   vilo_batch *bt = nullptr;
   int rc = vilo_batch_create(c, n, in, inout, &bt);
   if (rc != VILO_OK) return rc;
   rc = vilo_batch_solve(c, bt, opts);
-  if (rc == VILO_OK && solve_ms) *solve_ms = c->last_solve_ms;
-  if (rc == VILO_OK && keep) {
-    for (int w = 0; w < n; ++w) {
-      const int F = in[w].n_frames, L = in[w].n_landmarks;
-      const vilo_window_state &s = inout[w];
-      keep->insert(keep->end(), s.pose, s.pose + 7 * F);
-      keep->insert(keep->end(), s.speed_bias, s.speed_bias + 9 * F);
-      keep->insert(keep->end(), s.leg_bias, s.leg_bias + 4 * F);
-      keep->insert(keep->end(), s.ex_pose, s.ex_pose + 14);
-      keep->push_back(s.td[0]);
-      if (L > 0) keep->insert(keep->end(), s.inv_depth, s.inv_depth + L);
-    }
-  }
   if (rc == VILO_OK) rc = vilo_batch_download(c, bt, inout, out);
   if (rc == VILO_OK && out) {
     for (int w = 0; w < n; ++w)
@@ -976,10 +962,26 @@ static int solve_host_batch(vilo_ctx *c, int n, const vilo_window_desc *in, vilo
   vilo_batch_destroy(c, bt);
   return rc;
 }
+static void snapshot_host_states(int n, const vilo_window_desc *in, const vilo_window_state *st, std::vector<double> &keep) {
+  size_t tot = 0;
+  for (int w = 0; w < n; ++w) tot += (size_t)20 * in[w].n_frames + 15 + (size_t)std::max(0, in[w].n_landmarks);
+  keep.resize(tot);
+  double *q = keep.data();
+  for (int w = 0; w < n; ++w) {
+    const int F = in[w].n_frames, L = std::max(0, in[w].n_landmarks);
+    const vilo_window_state &s = st[w];
+    memcpy(q, s.pose, sizeof(double) * 7 * F); q += 7 * F;
+    memcpy(q, s.speed_bias, sizeof(double) * 9 * F); q += 9 * F;
+    memcpy(q, s.leg_bias, sizeof(double) * 4 * F); q += 4 * F;
+    memcpy(q, s.ex_pose, sizeof(double) * 14); q += 14;
+    *q++ = s.td[0];
+    if (L > 0) { memcpy(q, s.inv_depth, sizeof(double) * L); q += L; }
+  }
+}
 static void restore_host_states(int n, const vilo_window_desc *in, vilo_window_state *inout, const std::vector<double> &keep) {
   const double *q = keep.data();
   for (int w = 0; w < n; ++w) {
-    const int F = in[w].n_frames, L = in[w].n_landmarks;
+    const int F = in[w].n_frames, L = std::max(0, in[w].n_landmarks);
     vilo_window_state &s = inout[w];
     memcpy(s.pose, q, sizeof(double) * 7 * F); q += 7 * F;
     memcpy(s.speed_bias, q, sizeof(double) * 9 * F); q += 9 * F;
@@ -990,24 +992,29 @@ static void restore_host_states(int n, const vilo_window_desc *in, vilo_window_s
   }
 }
 
-// Estimator::optimization()'s solve half on host windows. Small calls: one batch. From two sub-batches' worth of windows up (default
-// 2 x 1024; vilo_set_host_pipeline) the call is cut into sub-batches that go through `lanes` internal contexts of the same device, one
-// host thread each: while one lane's records are on the DMA engines or its windows in the solver, the other lanes pack theirs — the three
-// resources a hand-over of host windows needs (host cores, PCIe, GPU) work at the same time instead of one after the other. The windows
-// are independent and every lane solves with the form the whole call would take as ONE batch, so the answer is the monolithic call's bit
-// for bit (tests/test_gpu_parity.py::test_host_pipeline_...). Nothing is written to `inout` unless every sub-batch came through (or
-// failed numerically, which is a per-window outcome): the states a finished sub-batch overwrote are put back.
-extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
-                                  const vilo_solve_opts *opts, vilo_solve_summary *out) {
-  if (!ctx || !in || !inout || !opts || n_windows <= 0) return VILO_ERR_BAD_ARG;
+// A call on many HOST windows (vilo_solve_windows, vilo_optimize_windows), cut into sub-batches that go through `lanes` internal contexts
+// of the same device, one host thread each (vilo_set_host_pipeline; default 4 lanes of 1024 windows, from two sub-batches' worth of windows
+// up): while one lane's windows are on the DMA engines or in the solver, the other lanes pack theirs — the three resources a hand-over of
+// host windows needs (host cores, PCIe, GPU) work at the same time instead of one after the other. The windows are independent and every
+// lane solves with the form the whole call would take as ONE batch, so the answer is the one batch's bit for bit
+// (tests/test_gpu_parity.py::test_host_pipeline_...). `inout` comes back changed only if every sub-batch came through (or failed
+// numerically, which is a per-window outcome): the states a finished sub-batch overwrote are put back.
+// Returns false when the call is not one to cut (few windows, pipeline off, per-kernel profiling on): the caller runs it as one batch.
+bool vilo_run_on_lanes(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                       const std::function<int(vilo_ctx *lane, int w0, int n)> &fn, int *rc_out) {
   const int sub = ctx->pipe_sub, lanes_want = ctx->pipe_lanes;
-  if (lanes_want < 2 || sub <= 0 || n_windows < 2 * sub || ctx->profile) return solve_host_batch(ctx, n_windows, in, inout, opts, out, nullptr, nullptr);
+  if (lanes_want < 2 || sub <= 0 || n_windows < 2 * sub || ctx->profile) return false;
+  for (int w = 0; w < n_windows; ++w) {   // (what the snapshots below index with; the sub-batches' own checks say why)
+    const vilo_window_state &s = inout[w];
+    if (in[w].n_frames < 2 || in[w].n_frames > VILO_MAX_FRAMES || in[w].n_landmarks < 0 || in[w].n_landmarks > VILO_NUM_OF_F || !s.pose || !s.speed_bias || !s.leg_bias ||
+        !s.ex_pose || !s.td || (in[w].n_landmarks && !s.inv_depth)) return false;
+  }
   const int n_sub = (n_windows + sub - 1) / sub, per = (n_windows + n_sub - 1) / n_sub;   // equal shares: no small tail batch
   const int n_lanes = std::min(lanes_want, n_sub);
   while ((int)ctx->lanes.size() < n_lanes) {
     vilo_ctx *l = nullptr;
     const int rc = vilo_create(&l, &ctx->cfg, ctx->device);
-    if (rc != VILO_OK) { ctx->err = "vilo_solve_windows: no context for a pipeline lane"; return rc; }
+    if (rc != VILO_OK) { ctx->err = "no context for a pipeline lane"; *rc_out = rc; return true; }
     // the lanes pack side by side: each brings its own share of the host's threads (at most the shared pool's 16, at least 2)
     const int hw = (int)std::thread::hardware_concurrency();
     l->dma_turn = &ctx->dma_m;
@@ -1019,8 +1026,10 @@ extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_windo
   probe.W = n_windows;
   const int form = vilo_solver_form(ctx, probe);   // what ONE batch of all the windows would be solved with
   std::vector<int> rcs(n_sub, VILO_OK);
+  std::vector<char> ran(n_sub, 0);
   std::vector<std::vector<double>> keep(n_sub);
-  std::vector<double> ms(n_sub, 0.0);
+  std::vector<double> solve_ms(n_lanes, 0.0), marg_ms(n_lanes, 0.0);
+  std::vector<int> general(n_lanes, 0);
   std::vector<std::thread> th;
   for (int li = 0; li < n_lanes; ++li) {
     vilo_ctx *l = ctx->lanes[li];
@@ -1030,7 +1039,11 @@ extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_windo
       for (int i = li; i < n_sub; i += n_lanes) {
         const int w0 = i * per, n = std::min(per, n_windows - w0);
         if (n <= 0) break;
-        rcs[i] = solve_host_batch(l, n, in + w0, inout + w0, opts, out ? out + w0 : nullptr, &keep[i], &ms[i]);
+        snapshot_host_states(n, in + w0, inout + w0, keep[i]);
+        l->last_solve_ms = 0.0; l->last_marg_ms = 0.0; l->marg_general_count = 0;
+        rcs[i] = fn(l, w0, n);
+        ran[i] = 1;
+        solve_ms[li] += l->last_solve_ms; marg_ms[li] += l->last_marg_ms; general[li] += l->marg_general_count;
         if (rcs[i] != VILO_OK && rcs[i] != VILO_ERR_NUMERIC) break;
       }
     });
@@ -1042,13 +1055,26 @@ extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_windo
   if (rc != VILO_OK) {   // a sub-batch was refused or lost its device: the call as a whole did not happen
     for (int i = 0; i < n_sub; ++i) {
       const int w0 = i * per, n = std::min(per, n_windows - w0);
-      if (n > 0 && !keep[i].empty() && (rcs[i] == VILO_OK || rcs[i] == VILO_ERR_NUMERIC)) restore_host_states(n, in + w0, inout + w0, keep[i]);
+      if (n > 0 && ran[i]) restore_host_states(n, in + w0, inout + w0, keep[i]);
     }
-    return rc;
+    *rc_out = rc;
+    return true;
   }
-  ctx->last_solve_ms = 0.0;
-  for (int i = 0; i < n_sub; ++i) { ctx->last_solve_ms += ms[i]; if (rcs[i] == VILO_ERR_NUMERIC) rc = VILO_ERR_NUMERIC; }
-  return rc;
+  ctx->last_solve_ms = 0.0; ctx->last_marg_ms = 0.0; ctx->marg_general_count = 0;
+  for (int li = 0; li < n_lanes; ++li) { ctx->last_solve_ms += solve_ms[li]; ctx->last_marg_ms += marg_ms[li]; ctx->marg_general_count += general[li]; }
+  for (int i = 0; i < n_sub; ++i) if (rcs[i] == VILO_ERR_NUMERIC) rc = VILO_ERR_NUMERIC;
+  *rc_out = rc;
+  return true;
+}
+
+// Estimator::optimization()'s solve half on host windows (estimator.cpp:1054-1245)
+extern "C" int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                                  const vilo_solve_opts *opts, vilo_solve_summary *out) {
+  if (!ctx || !in || !inout || !opts || n_windows <= 0) return VILO_ERR_BAD_ARG;
+  int rc = VILO_OK;
+  if (vilo_run_on_lanes(ctx, n_windows, in, inout, [&](vilo_ctx *l, int w0, int n) { return solve_host_batch(l, n, in + w0, inout + w0, opts, out ? out + w0 : nullptr); }, &rc))
+    return rc;
+  return solve_host_batch(ctx, n_windows, in, inout, opts, out);
 }
 
 // lanes < 2 or sub_windows <= 0: every vilo_solve_windows call is one batch

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -147,4 +148,7 @@ inline double vilo_win_sum_dt(const vilo_window_desc &d, const vilo_resident_ref
   return d.use_leg ? d.preint[k].sum_dt : d.preint_imu[k].sum_dt;
 }
 struct vilo_batch;
+// vilo_batch.hip: a call on many host windows cut into sub-batches over the context's pipeline lanes (false: not a call to cut)
+bool vilo_run_on_lanes(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
+                       const std::function<int(vilo_ctx *lane, int w0, int n)> &fn, int *rc_out);
 int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_resident_refs *refs, const vilo_window_state *init, vilo_batch **out);

@@ -528,6 +528,29 @@ def test_host_pipeline_gives_the_one_batch_answer(cfg, ocfg):
         for i in (0, 16, 18, 22):
             for x, y in zip(sick[i].state_arrays(), one[i].state_arrays()):
                 np.testing.assert_array_equal(x, y)
+        # Estimator::optimization() as a whole (solve, gauge fix, marginalisation) takes the same lanes: states and priors of the one batch
+        from cerberus_amd.synth import PriorData
+
+        def optimise(c, ws):
+            descs, states, summ, priors = (T.WindowDesc * N)(), (T.WindowState * N)(), (T.SolveSummary * N)(), (T.Prior * N)()
+            outs = [PriorData() for _ in ws]
+            for i, w in enumerate(ws):
+                descs[i], states[i] = w.desc(T)
+                priors[i] = outs[i].struct
+            fl = (C.c_int * N)(*[i % 2 for i in range(N)])
+            c._check(api.lib().vilo_optimize_windows(c.h, N, descs, states, C.byref(opts), fl, priors, summ))
+            for i, o in enumerate(outs):
+                o.struct = priors[i]
+            return outs
+        o1, o3 = crowd(), crowd()
+        p1, p3 = optimise(c1, o1), optimise(c3, o3)
+        assert sum(p.n > 0 for p in p1) >= N - 6     # (MARGIN_SECOND_NEW of a window without a prior leaves none)
+        for wa, wb, pa, pb in zip(o1, o3, p1, p3):
+            for x, y in zip(wa.state_arrays(), wb.state_arrays()):
+                np.testing.assert_array_equal(x, y)
+            assert pa.blocks() == pb.blocks() and pa.n == pb.n and pa.struct.valid == pb.struct.valid
+            np.testing.assert_array_equal(pa.J0_matrix(), pb.J0_matrix())
+            np.testing.assert_array_equal(pa.r0[:pa.n], pb.r0[:pb.n])
         # a refused window in the LAST sub-batch: the sub-batches before it had been solved and downloaded by then
         bad = crowd()
         before = [w.clone_state() for w in bad]

@@ -31,3 +31,25 @@ for st in settings:
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     print("vilo_solve_windows, %d windows x 12 iterations, pipeline %-7s host to host: %6.1f ms -> %8.0f window-iterations/s" % (W, st, 1e3 * best, W * 12 / best), flush=True)
+
+# Estimator::optimization() as a whole on the same host windows: vilo_optimize_windows = solve + gauge fix + marginalisation (MARGIN_OLD),
+# the priors (74 KB per window) come back to host memory
+import ctypes as C  # noqa: E402
+from cerberus_amd.synth import PriorData  # noqa: E402
+outs = [PriorData() for _ in ws]
+priors, summ = (T.Prior * W)(), (T.SolveSummary * W)()
+for i, o in enumerate(outs):
+    priors[i] = o.struct
+fl = (C.c_int * W)(*([0] * W))
+for st in settings[:1] + settings[-1:]:
+    lanes, sub = (int(x) for x in st.split(","))
+    ctx.set_host_pipeline(lanes, sub)
+    best = None
+    for rep in range(3):
+        for w, s in zip(ws, states0):
+            w.set_state(s)
+        t0 = time.perf_counter()
+        ctx._check(api.lib().vilo_optimize_windows(ctx.h, W, descs, states, C.byref(opts), fl, priors, summ))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    print("vilo_optimize_windows, %d windows (12 iterations + marginalisation), pipeline %-7s host to host: %6.1f ms -> %8.0f windows/s" % (W, st, 1e3 * best, W / best), flush=True)
