@@ -1035,19 +1035,29 @@ bool vilo_run_on_lanes(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in,
     vilo_ctx *l = ctx->lanes[li];
     l->cfg = ctx->cfg; l->sqrt_info_mode = ctx->sqrt_info_mode; l->solver_form = form; l->compact_rows = ctx->compact_rows;
     l->initial_mu = ctx->initial_mu; l->prior_form = ctx->prior_form; l->err.clear();
-    th.emplace_back([&, li, l] {
-      for (int i = li; i < n_sub; i += n_lanes) {
-        const int w0 = i * per, n = std::min(per, n_windows - w0);
-        if (n <= 0) break;
+  }
+  auto lane_work = [&](int li) {
+    vilo_ctx *l = ctx->lanes[li];
+    for (int i = li; i < n_sub; i += n_lanes) {
+      const int w0 = i * per, n = std::min(per, n_windows - w0);
+      if (n <= 0) break;
+      try {
         snapshot_host_states(n, in + w0, inout + w0, keep[i]);
         l->last_solve_ms = 0.0; l->last_marg_ms = 0.0; l->marg_general_count = 0;
-        rcs[i] = fn(l, w0, n);
         ran[i] = 1;
-        solve_ms[li] += l->last_solve_ms; marg_ms[li] += l->last_marg_ms; general[li] += l->marg_general_count;
-        if (rcs[i] != VILO_OK && rcs[i] != VILO_ERR_NUMERIC) break;
+        rcs[i] = fn(l, w0, n);
+      } catch (...) {   // (host allocation failure inside a lane's thread: reported, not thrown across the C boundary)
+        rcs[i] = VILO_ERR_HIP; l->err = "host allocation failed in a pipeline lane";
       }
-    });
+      solve_ms[li] += l->last_solve_ms; marg_ms[li] += l->last_marg_ms; general[li] += l->marg_general_count;
+      if (rcs[i] != VILO_OK && rcs[i] != VILO_ERR_NUMERIC) break;
+    }
+  };
+  std::vector<int> inline_lanes;   // (a lane whose thread the process could not start is worked on this one)
+  for (int li = 0; li < n_lanes; ++li) {
+    try { th.emplace_back(lane_work, li); } catch (...) { inline_lanes.push_back(li); }
   }
+  for (int li : inline_lanes) lane_work(li);
   for (std::thread &t : th) t.join();
   int rc = VILO_OK;
   for (int i = 0; i < n_sub; ++i)
