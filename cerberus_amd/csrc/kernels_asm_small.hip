@@ -414,11 +414,12 @@ k_assemble_s(BatchDev b, int jacobi_scaling, double min_lm_diagonal, double max_
 
 // k_assemble_s for batches of up to VILO_ASM_SMALL_MAX_WINDOWS windows with compact slots (reduce_waves: extra workgroups that finish the
 // frame-parallel visual form).
-bool vilo_assemble_small_takes(const BatchDev &b) {
+int vilo_assemble_small_max() {
   // (one window per CU: measured 256 windows + 4 %, 384 - 8 % against three workgroups per CU)
   static const int small_max = [] { const char *e = getenv("VILO_ASM_SMALL_MAX_WINDOWS"); return e ? atoi(e) : 256; }();
-  return b.compact && b.W <= small_max;
+  return small_max;
 }
+bool vilo_assemble_small_takes(const BatchDev &b) { return b.compact && !b.full_regime && b.W <= vilo_assemble_small_max(); }
 int vilo_launch_assemble_small(vilo_ctx *ctx, BatchDev &b, const SolveParams &sp, hipStream_t s, const AcceptParams *ap, int reduce_waves) {
   const size_t lds_bytes = (size_t)AS_TOTAL * sizeof(double);
   if (!ctx->asm_s_attr_set) {

@@ -166,6 +166,7 @@ struct BatchDev {
   int *prep_bad;                   // [W * 10] covariance of the record not positive definite
   int rp_on, leg;
   int compact;                // 1: every window keeps td constant: the solve passes use the compact 16-column visual rows / Gram slots (visual_lin.hpp GK_*)
+  int full_regime;            // 1: a sub-batch of a larger call (vilo_run_on_lanes): the kernel set of a full batch whatever this batch's own size — no small assembly, no frame-parallel visual form — so that a window's answer is the one it has in the whole call as ONE batch, bit for bit
   int *lin_cur;               // [W] SolverState::cur as the last linearisation pass of a small batch saw it (visual_reduce_body in k_assemble_s's launch)
   int *win_bad;               // [W] 1: a preintegration covariance of the window has no sqrt_info: the window fails alone (termination FAILURE)
 };

@@ -261,6 +261,12 @@ extern "C" void vilo_batch_destroy(vilo_ctx *ctx, vilo_batch *bt) {
 
 int vilo_launch_preint_gather(vilo_ctx *ctx, const vilo_preint_streams *pool, int n, const int *d_ids, const int *d_dst, void *d_out);
 int vilo_solver_form(const vilo_ctx *ctx, const BatchDev &b);   // kernels_wave.hip
+int vilo_assemble_small_max();                                  // kernels_asm_small.hip
+// up to this many packed waves a batch takes the frame-parallel form of the visual linearisation (tuning aids: VILO_TPAR_MAX_WAVES; VILO_NO_TPAR=1 = 0)
+static size_t vilo_tpar_max_waves() {
+  static const size_t v = [] { const char *e = getenv("VILO_TPAR_MAX_WAVES"); return getenv("VILO_NO_TPAR") ? (size_t)0 : (e ? (size_t)atol(e) : (size_t)256); }();
+  return v;
+}
 
 extern "C" int vilo_batch_create(vilo_ctx *ctx, int W, const vilo_window_desc *in, const vilo_window_state *init, vilo_batch **out) {
   return vilo_batch_create_refs(ctx, W, in, nullptr, init, out);
@@ -553,9 +559,9 @@ int vilo_batch_create_refs(vilo_ctx *ctx, int W, const vilo_window_desc *in, con
   // few windows: one workgroup per (packed wave, frame) instead of per packed wave, so that the chip is not left to 3 waves per window
   // (the landmark-side terms every such workgroup writes: all of them, zeros included — nothing reads an entry nobody wrote)
   D.lm_part = nullptr;
-  const char *tp_env = getenv("VILO_TPAR_MAX_WAVES");   // tuning aid; VILO_NO_TPAR=1 = 0
-  const size_t tpar_max = getenv("VILO_NO_TPAR") ? 0 : (tp_env ? (size_t)atol(tp_env) : 256);
-  if (waves.size() <= tpar_max) TRYB(dev_alloc(ctx, bt, &D.lm_part, (size_t)lm_total * VILO_MAX_FRAMES * 2 * 21));
+  const size_t tpar_max = vilo_tpar_max_waves();
+  D.full_regime = ctx->regime_full;
+  if (waves.size() <= tpar_max && !ctx->regime_full) TRYB(dev_alloc(ctx, bt, &D.lm_part, (size_t)lm_total * VILO_MAX_FRAMES * 2 * 21));
   TRYB(dev_alloc(ctx, bt, &D.gram, (size_t)gram_total * VILO_GRAM));
   TRYB(dev_alloc(ctx, bt, &D.chunk_cost, waves.size() * VILO_MAX_FRAMES));   // per (packed wave, frame offset) partial costs
   TRYB(dev_alloc(ctx, bt, &D.prep, (size_t)W * 10));
@@ -1009,6 +1015,14 @@ bool vilo_run_on_lanes(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in,
     if (in[w].n_frames < 2 || in[w].n_frames > VILO_MAX_FRAMES || in[w].n_landmarks < 0 || in[w].n_landmarks > VILO_NUM_OF_F || !s.pose || !s.speed_bias || !s.leg_bias ||
         !s.ex_pose || !s.td || (in[w].n_landmarks && !s.inv_depth)) return false;
   }
+  // The kernel set of a batch depends on its size (small assembly up to 256 windows, frame-parallel visual form up to 256 packed waves,
+  // compact rows while every window keeps td constant), and those forms agree to rounding, not bitwise. The lanes run the kernel set of a
+  // FULL batch whatever their share (BatchDev::full_regime) with the row form of the whole call, so a call is cut only if as ONE batch it
+  // would certainly be a full one too: more windows than the small assembly takes, more windows with landmarks (>= packed waves) than the
+  // frame-parallel form takes.
+  int with_lm = 0, all_td_const = 1;
+  for (int w = 0; w < n_windows; ++w) { with_lm += in[w].n_landmarks > 0 ? 1 : 0; if (!in[w].td_const) all_td_const = 0; }
+  if (n_windows <= vilo_assemble_small_max() || (size_t)with_lm <= vilo_tpar_max_waves()) return false;
   const int n_sub = (n_windows + sub - 1) / sub, per = (n_windows + n_sub - 1) / n_sub;   // equal shares: no small tail batch
   const int n_lanes = std::min(lanes_want, n_sub);
   while ((int)ctx->lanes.size() < n_lanes) {
@@ -1033,7 +1047,7 @@ bool vilo_run_on_lanes(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in,
   std::vector<std::thread> th;
   for (int li = 0; li < n_lanes; ++li) {
     vilo_ctx *l = ctx->lanes[li];
-    l->cfg = ctx->cfg; l->sqrt_info_mode = ctx->sqrt_info_mode; l->solver_form = form; l->compact_rows = ctx->compact_rows;
+    l->sqrt_info_mode = ctx->sqrt_info_mode; l->solver_form = form; l->compact_rows = (ctx->compact_rows && all_td_const) ? 1 : 0; l->regime_full = 1;
     l->initial_mu = ctx->initial_mu; l->prior_form = ctx->prior_form; l->err.clear();
   }
   auto lane_work = [&](int li) {

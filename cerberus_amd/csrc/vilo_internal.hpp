@@ -58,6 +58,7 @@ struct vilo_ctx {
   // (created at the first such call, destroyed with this one), one host thread each (vilo_set_host_pipeline; VILO_HOST_PIPELINE=lanes,sub)
   int pipe_lanes = 4, pipe_sub = 1024;
   std::vector<vilo_ctx *> lanes;
+  int regime_full = 0;   // a lane: its batches take the kernel set of a full batch whatever their size (BatchDev::full_regime)
   vilo::WorkerPool *pool = nullptr;   // a lane's own host threads (null: the library's shared pool)
   std::mutex dma_m, *dma_turn = nullptr;   // the lanes' uploads take turns (a lane points at its parent's mutex)
 };

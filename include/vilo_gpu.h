@@ -243,10 +243,12 @@ int vilo_preint_streams_read_imu(vilo_ctx *ctx, vilo_preint_streams *pool, int n
  * solver result (double2vector's gauge fix is vilo_gauge_fix below). */
 int vilo_solve_windows(vilo_ctx *ctx, int n_windows, const vilo_window_desc *in, vilo_window_state *inout,
                        const vilo_solve_opts *opts, vilo_solve_summary *out);
-/* Many host windows in one vilo_solve_windows call (from 2 * sub_windows up) go through `lanes` internal contexts of the same device in
- * sub-batches, one host thread per lane, so that packing, the PCIe transfer and the solver work at the same time; the result is the one
- * batch's bit for bit, and `inout` is written only if every sub-batch came through. Default 4 lanes of 1024 windows
- * (VILO_HOST_PIPELINE="lanes,sub_windows" at vilo_create); lanes < 2 or sub_windows == 0: always one batch. */
+/* Many host windows in one vilo_solve_windows / vilo_optimize_windows call (from 2 * sub_windows up, and more than 256 of them with
+ * landmarks: a call that as one batch takes the full batch's kernels) go through `lanes` internal contexts of the same device in
+ * sub-batches, one host thread per lane, so that packing, the PCIe transfer and the solver work at the same time. The sub-batches run the
+ * full batch's kernel set and the whole call's solver form whatever their size: the result is the one batch's bit for bit, and `inout` is
+ * written only if every sub-batch came through. Default 4 lanes of 1024 windows (VILO_HOST_PIPELINE="lanes,sub_windows" at vilo_create);
+ * lanes < 2 or sub_windows == 0: always one batch. */
 int vilo_set_host_pipeline(vilo_ctx *ctx, int lanes, int sub_windows);
 
 /* Device-resident form of the same call, for batches (independent windows: robots / replays / seeds). */
