@@ -567,6 +567,31 @@ def test_host_pipeline_gives_the_one_batch_answer(cfg, ocfg):
         c1.close(); c3.close()
 
 
+def test_host_records_arrive_as_what_the_solver_reads(ctx, cfg):
+    """Host windows' IMU-leg records cross PCIe as 739 of their 1955 doubles (scalars, bias columns of the Jacobian's first 21 rows, upper
+    triangle of the covariance) and are laid out as records again on the device: every entry the preparation reads is the caller's, the
+    covariance's lower triangle mirrors the upper one, what no factor reads is zero — for the last window of a batch as for the first."""
+    from cerberus_amd import api, synth, _ctypes as T
+    ws = [synth.make_window(cfg, n_landmarks=20, seed=5100 + i) for i in range(70)]
+    ctx.preintegrate_windows(ws)
+    b = api.Batch(ctx, ws)
+    try:
+        for wi in (0, 37, 69):
+            dev = b.fetch(13, wi).reshape(10, T.PREINT_DOUBLES)
+            host = ws[wi].preint
+            np.testing.assert_array_equal(dev[:, :33], host[:, :33])
+            Jd, Jh = dev[:, 33:33 + 961].reshape(10, 31, 31), host[:, 33:33 + 961].reshape(10, 31, 31)
+            np.testing.assert_array_equal(Jd[:, :21, 21:], Jh[:, :21, 21:])
+            assert np.all(Jd[:, 21:, :] == 0) and np.all(Jd[:, :, :21] == 0) and np.abs(Jh[:, :21, :21]).max() > 0
+            Cd, Ch = dev[:, 33 + 961:].reshape(10, 31, 31), host[:, 33 + 961:].reshape(10, 31, 31)
+            iu = np.triu_indices(31)
+            for k in range(10):
+                np.testing.assert_array_equal(Cd[k][iu], Ch[k][iu])
+                np.testing.assert_array_equal(Cd[k], Cd[k].T)
+    finally:
+        b.close()
+
+
 def test_host_pipeline_on_a_random_crowd(cfg):
     """300 windows of 0 .. 400 landmarks, with and without prior, solved to convergence (not a fixed iteration count): the call cut over
     2 .. 6 lanes into shares of 7 .. 64 windows — shares that as batches of their own would take the small assembly and the frame-parallel
