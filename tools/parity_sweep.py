@@ -1,0 +1,144 @@
+"""A randomised GPU-against-oracle sweep of the whole path, beyond what the -m gpu suite holds at fixed seeds (run on the GPU box; the
+oracle is the checker, as in tests/): N random windows — 1 .. 600 landmarks, with / without prior, IMU-leg or plain IMU factors, constant or
+estimated extrinsics / leg biases — through
+
+  solve      vilo_solve_windows (ONE call for all windows: the sub-batch pipeline when N allows) against oracle solve_window, fixed 8
+             iterations and to convergence: final states relative to max(1, |state|), final cost relative
+  gauge fix  vilo_gauge_fix against the oracle's on the solved states
+  marginalise  both flags, eigen form and factor form, against the oracle's prior: J0^T J0 / J0^T r0 per kept block pair in units of the
+             blocks' own diagonals (tests/marg_exact.py scaling, against the ORACLE's information here: its own distance from the exact
+             complement is what tests/test_golden.py measures)
+
+and prints the worst case per category with the window that produced it. python tools/parity_sweep.py [N] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cerberus_amd import api, synth  # noqa: E402
+from cerberus_amd.synth import PriorData  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if a.size else 0.0
+
+
+def info_err(pg, po):
+    """worst |dH_ij| / sqrt(H_ii H_jj), worst |db_i| / sqrt(H_ii) (relative to the largest whitened gradient entry) over the kept blocks"""
+    from marg_exact import block_table
+    n = po.struct.n
+    Jo, ro = po.J0[: n * n].reshape(n, n), po.r0[:n]
+    Jg, rg = pg.J0[: n * n].reshape(n, n), pg.r0[:n]
+    Ho, bo, Hg, bg = Jo.T @ Jo, Jo.T @ ro, Jg.T @ Jg, Jg.T @ rg
+    to, tg = block_table(po), block_table(pg)
+    assert set(to) == set(tg) and pg.struct.n == n
+    d = np.sqrt(np.maximum(np.diag(Ho), 1e-300))
+    eh = eb = 0.0
+    for a, (ia, la) in tg.items():
+        ja, _ = to[a]
+        eb = max(eb, float((np.abs(bg[ia:ia + la] - bo[ja:ja + la]) / d[ja:ja + la]).max()))
+        for c, (ic, lc) in tg.items():
+            jc, _ = to[c]
+            eh = max(eh, float((np.abs(Hg[ia:ia + la, ic:ic + lc] - Ho[ja:ja + la, jc:jc + lc]) / np.outer(d[ja:ja + la], d[jc:jc + lc])).max()))
+    return eh, eb / max(1.0, float(np.abs(bo / d).max()))
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+    rng = np.random.default_rng(seed)
+    cfg, ocfg = synth.default_config(), O.default_config()
+    ctx = api.Context(cfg, 0)
+    specs = []
+    for i in range(N):
+        leg = int(rng.integers(0, 6) != 0)
+        # (the generator's prior carries leg-bias blocks: windows with plain IMU factors go without one, as in tests/test_gpu_parity.py::_vins)
+        specs.append(dict(n_landmarks=int(rng.choice([1, 3, 8, 20, 60, 130, 200, 333, 600])), seed=int(rng.integers(1, 1 << 30)),
+                          with_prior=bool(rng.integers(0, 5) != 0) and leg == 1, use_leg=leg,
+                          consts=[(0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1)][int(rng.integers(0, 4))]))
+
+    def fresh(sp):
+        w = synth.make_window(cfg, n_landmarks=sp["n_landmarks"], seed=sp["seed"], with_prior=sp["with_prior"])
+        w.use_leg = sp["use_leg"]
+        w.leg_bias_const, w.ex_const, w.td_const = sp["consts"]
+        O.fill_preint(ocfg, w)
+        return w
+    worst, differ, split = {}, {}, {}
+
+    def note(key, val, i):
+        if key not in worst or val > worst[key][0]:
+            worst[key] = (val, i, specs[i])
+    t0 = time.time()
+    for name, opts_g, opts_o in (("solve, 8 fixed iterations", api.default_solve_opts(True, 8), O.default_opts(True, 8)),
+                                 ("solve, to convergence (<= 12)", api.default_solve_opts(False, 12), O.default_opts(False, 12))):
+        for leg in (1, 0):     # (one IMU factor kind per batch)
+            idx = [i for i in range(N) if specs[i]["use_leg"] == leg]
+            if not idx:
+                continue
+            wg = [fresh(specs[i]) for i in idx]
+            sg = ctx.solve_windows(wg, opts_g)
+            for k, i in enumerate(idx):
+                wo = fresh(specs[i])
+                before = wo.clone_state()
+                so = O.solve_window(ocfg, wo, opts_o)
+                kind = ", windows with a prior" if specs[i]["with_prior"] else ", windows WITHOUT a prior (4 gauge directions free)"
+                note(name + kind + ": final cost", abs(sg[k].final_cost - so.final_cost) / max(1.0, abs(so.final_cost)), i)
+                if sg[k].num_successful != so.num_successful:
+                    # a step whose relative decrease is rounding noise (a window that stagnates with fixed iterations: tolerances are
+                    # off) is accepted on one side and rejected on the other; from there the two are different, equally valid runs
+                    split[name] = split.get(name, []) + [i]
+                else:
+                    note(name + kind + ": states", max(rel(a, b) for a, b in zip(wg[k].state_arrays(), wo.state_arrays())), i)
+                if sg[k].iterations != so.iterations or sg[k].termination != so.termination:
+                    differ[name] = differ.get(name, 0) + 1
+                if name.startswith("solve, 8"):
+                    # gauge fix and both marginalisations at the oracle's solved state (identical inputs for both sides)
+                    wg2 = fresh(specs[i])
+                    wg2.set_state(wo.clone_state())
+                    ctx.gauge_fix(before, wg2)
+                    O.gauge_fix(before, wo)
+                    note("gauge fix", max(rel(a, b) for a, b in zip(wg2.state_arrays(), wo.state_arrays())), i)
+                    wg2.set_state(wo.clone_state())
+                    for mode in (0, 1):
+                        po = PriorData()
+                        if O.marginalize(ocfg, wo, mode, po)[0] != 0 or not po.struct.valid:
+                            continue
+                        for form in ("eigen", "factor"):
+                            ctx.set_prior_form(form)
+                            pg = PriorData()
+                            ctx.marginalize(wg2, mode, pg)
+                            assert pg.struct.valid == 1 and pg.blocks() == po.blocks()
+                            if specs[i]["with_prior"]:
+                                eh, eb = info_err(pg, po)
+                                note("marginalise flag %d, %s form: information, per block diagonal" % (mode, form), eh, i)
+                                note("marginalise flag %d, %s form: gradient, per block diagonal" % (mode, form), eb, i)
+                            else:
+                                # no prior: A' is semi-definite (the four gauge directions carry rounding noise that the 1e-8 eigenvalue
+                                # threshold keeps or drops): compared in units of the largest entry, like the suite's no-prior test
+                                n = po.struct.n
+                                Jo, Jg = po.J0[: n * n].reshape(n, n), pg.J0[: n * n].reshape(n, n)
+                                Ho, Hg = Jo.T @ Jo, Jg.T @ Jg
+                                note("marginalise flag %d, %s form, NO prior (semi-definite): information, of the largest entry" % (mode, form), float(np.abs(Hg - Ho).max() / np.abs(Ho).max()), i)
+                                bo, bg = Jo.T @ po.r0[:n], Jg.T @ pg.r0[:n]
+                                note("marginalise flag %d, %s form, NO prior (semi-definite): gradient, of the largest entry" % (mode, form), float(np.abs(bg - bo).max() / np.abs(bo).max()), i)
+                        ctx.set_prior_form("eigen")
+    print("parity sweep: %d random windows (seed %d), %.0f s" % (N, seed, time.time() - t0))
+    for k in sorted(worst):
+        v, i, sp = worst[k]
+        print("  %-104s %.2e   (window %d: %d landmarks, prior %d, use_leg %d, consts %s)" % (k, v, i, sp["n_landmarks"], sp["with_prior"], sp["use_leg"], sp["consts"]))
+    for k in sorted(split):
+        print("  %s: %d window(s) where a step with a relative decrease of rounding noise is accepted on one side, rejected on the other (%s) — states not compared, costs are" % (k, len(split[k]), split[k]))
+    for k in sorted(differ):
+        print("  %s: %d windows stop at another iteration or for another reason than the oracle's" % (k, differ[k]))
+    if not differ:
+        print("  every window stops at the oracle's iteration, for the oracle's reason")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
