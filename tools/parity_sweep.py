@@ -9,6 +9,10 @@ estimated extrinsics / leg biases — through
              blocks' own diagonals (tests/marg_exact.py scaling, against the ORACLE's information here: its own distance from the exact
              complement is what tests/test_golden.py measures)
 
+  factors    vilo_preintegrate on intervals of random length under the three contact models — the gait's flags mixed with fractional values
+             around the 0.5 threshold and runs with every foot in the air, foot forces for model 2 — against the oracle's integration, and
+             IMULegFactor::Evaluate on the resulting records at the windows' states
+
 and prints the worst case per category with the window that produced it. python tools/parity_sweep.py [N] [seed]"""
 import os
 import sys
@@ -68,7 +72,11 @@ def main():
         w.leg_bias_const, w.ex_const, w.td_const = sp["consts"]
         O.fill_preint(ocfg, w)
         return w
-    worst, differ, split = {}, {}, {}
+    worst, differ, split, worst2 = {}, {}, {}, {}
+
+    def note2(key, val, tag):
+        if key not in worst2 or val > worst2[key][0]:
+            worst2[key] = (val, tag)
 
     def note(key, val, i):
         if key not in worst or val > worst[key][0]:
@@ -127,7 +135,81 @@ def main():
                                 bo, bg = Jo.T @ po.r0[:n], Jg.T @ pg.r0[:n]
                                 note("marginalise flag %d, %s form, NO prior (semi-definite): gradient, of the largest entry" % (mode, form), float(np.abs(bg - bo).max() / np.abs(bo).max()), i)
                         ctx.set_prior_form("eigen")
-    print("parity sweep: %d random windows (seed %d), %.0f s" % (N, seed, time.time() - t0))
+    # ---- the factor level: preintegration (three contact models, contact inputs no gait produces) and IMULegFactor / IMUFactor::Evaluate ----
+    import copy
+
+    def relm(a, b):
+        return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+    n_int = 0
+    pd_count = [0, 0, 0]
+    one_sided, cls_count = [], {}
+    for ctype in (0, 1, 2):
+        c2, o2 = copy.copy(cfg), copy.copy(ocfg)
+        c2.contact_sensor_type = ctype; o2.contact_sensor_type = ctype
+        cc = api.Context(c2, 0)
+        for rep in range(max(4, N // 10)):
+            w = synth.make_window(cfg, n_landmarks=3, seed=int(rng.integers(1, 1 << 30)))
+            smp = np.array(w.samples, copy=True)
+            nS = int(w.sample_offsets[-1])
+            # contact inputs: the gait's flags, fractional values around the 0.5 threshold, runs with every foot in the air
+            c = smp[:nS, 31:35]
+            frac = rng.random(c.shape) < 0.25
+            c[frac] = rng.choice([0.0, 0.3, 0.49999, 0.5, 0.7, 1.0], size=int(frac.sum()))
+            for _ in range(3):
+                a0 = int(rng.integers(0, max(1, nS - 6)))
+                c[a0:a0 + int(rng.integers(1, 6))] = 0.0
+            if ctype == 2:
+                c[:] = 15.0 + 140.0 * c + 4.0 * rng.normal(size=c.shape)       # foot forces (tests/test_gpu_parity.py::_force_samples)
+            # intervals of random length inside the window's ten (>= 2 samples), biases away from the generator's
+            offs = [0]
+            parts, lins = [], []
+            for k in range(10):
+                a0, a1 = int(w.sample_offsets[k]), int(w.sample_offsets[k + 1])
+                n = int(rng.integers(2, a1 - a0 + 1))
+                parts.append(smp[a0:a0 + n]); offs.append(offs[-1] + n)
+                lins.append(w.lin[k] + np.concatenate([0.05 * rng.normal(size=3), 0.01 * rng.normal(size=3), 0.01 * rng.normal(size=4)]))
+            S, L = np.ascontiguousarray(np.concatenate(parts)), np.ascontiguousarray(np.stack(lins))
+            out = cc.preintegrate(S, np.array(offs, np.int32), L)
+            P = [w.pose[:-1], w.speed_bias[:-1], w.leg_bias[:-1], w.pose[1:], w.speed_bias[1:], w.leg_bias[1:]]
+            for k in range(10):
+                b = O.preintegrate_imu_leg(o2, S[offs[k]:offs[k + 1]], L[k])
+                # a covariance without sqrt_info (not positive definite in FP64: e.g. the 10e10 uncertainties of feet in the air next to
+                # 1e-11 ones) must be refused by both sides
+                try:
+                    rg, Jg = cc.eval_imu_leg(out[k:k + 1], [p[k:k + 1] for p in P])
+                    gpu_ok = True
+                except api.ViloError:
+                    gpu_ok = False
+                try:
+                    O.sqrt_info(b[33 + 961:].reshape(31, 31))
+                    orc_ok = True
+                except FloatingPointError:
+                    orc_ok = False
+                pd_count[0] += 1 if (gpu_ok and orc_ok) else 0
+                pd_count[1] += 1 if (not gpu_ok and not orc_ok) else 0
+                pd_count[2] += 1 if gpu_ok != orc_ok else 0
+                n_int += 1
+                tag = "preintegration, contact model %d: " % ctype
+                note2(tag + "state (33 scalars)", float(np.abs(out[k][:33] - b[:33]).max() / max(1.0, np.abs(b[:33]).max())), ctype)
+                note2(tag + "jacobian, of its largest entry", relm(out[k][33:33 + 961], b[33:33 + 961]), ctype)
+                note2(tag + "covariance, of its largest entry", relm(out[k][33 + 961:], b[33 + 961:]), ctype)
+                cov = b[33 + 961:].reshape(31, 31)
+                ev = np.linalg.eigvalsh(0.5 * (cov + cov.T))
+                cond = float(ev[-1] / ev[0]) if ev[0] > 0 else np.inf
+                cls = "cond(covariance) <= 1e15" if cond <= 1e15 else "cond(covariance) > 1e15: singular to FP64 working precision"
+                if gpu_ok != orc_ok:
+                    one_sided.append("%.1e" % cond)
+                if gpu_ok and orc_ok:
+                    ro, Jo = O.eval_imu_leg(o2, b, [p[k] for p in P])
+                    note2("IMULegFactor::Evaluate on those records, %s: whitened residual" % cls, relm(rg[0], ro), ctype)
+                    note2("IMULegFactor::Evaluate on those records, %s: whitened Jacobians" % cls, max(relm(Jg[q][0], Jo[q]) for q in range(6)), ctype)
+                    cls_count[cls] = cls_count.get(cls, 0) + 1
+        cc.close()
+    print("parity sweep: %d random windows (seed %d), %d random preintegration intervals, %.0f s" % (N, seed, n_int, time.time() - t0))
+    for k in sorted(worst2):
+        print("  %-128s %.2e   (contact model %d)" % (k, worst2[k][0], worst2[k][1]))
+    print("  covariances with sqrt_info on both sides: %d (%s), refused by both (not positive definite in FP64): %d, refused by one side only: %d (their condition numbers: %s)"
+          % (pd_count[0], ", ".join("%s: %d" % kv for kv in sorted(cls_count.items())), pd_count[1], pd_count[2], ", ".join(one_sided) or "-"))
     for k in sorted(worst):
         v, i, sp = worst[k]
         print("  %-104s %.2e   (window %d: %d landmarks, prior %d, use_leg %d, consts %s)" % (k, v, i, sp["n_landmarks"], sp["with_prior"], sp["use_leg"], sp["consts"]))
