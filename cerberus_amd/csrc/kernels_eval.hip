@@ -192,8 +192,9 @@ __global__ void __launch_bounds__(64) k_prepare_preint(int n, const vilo_preint 
 
 // The reference's route taken literally (imu_leg_factor.cpp:197-198: LLT(covariance.inverse()).matrixL().transpose()): the inverse by
 // Gauss-Jordan elimination with partial pivoting (what Eigen's inverse() does for a 31 x 31 matrix up to the elimination order), then the
-// lower Cholesky factor of it, transposed. The covariance has a condition number of 1e13 .. 1e14, so this route carries ~1e-5 of relative
-// error that the default route (sqrt_info_wave: no inverse of the covariance is formed) does not; selectable with vilo_set_sqrt_info_mode.
+// lower Cholesky factor of it, transposed; selectable with vilo_set_sqrt_info_mode. The covariance's condition number of 1e13 .. 1e14 is
+// units (variances of 1e-11 beside ones of 0.1; ~ 15 after diagonal equilibration): this route and the default one (sqrt_info_wave: no
+// inverse of the covariance is formed) both give the exact matrix to a few 1e-15 row by row (tests/test_oracle_factors.py, 100 digits).
 template <int N>
 __device__ void sqrt_info_literal_wave(const double *cov, double *U_out, double *A /*LDS N*(N+1)*/, double *B /*LDS N*(N+1)*/, int *status) {
   const int lane = threadIdx.x;

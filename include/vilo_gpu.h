@@ -339,8 +339,10 @@ int vilo_debug_marg_general_count(const vilo_ctx *ctx);
 /* Per-kernel GPU time of the solve pipeline, HIP events on ctx's stream. kinds: see vilo_kernel_name(). */
 /* How sqrt_info = LLT(covariance.inverse()).matrixL().transpose() (imu_leg_factor.cpp:197-198, imu_factor.h) is computed for the batches and
  * factor evaluations that follow. 0 (default): Cholesky of the index-reversed covariance and a triangular inverse — the same matrix without
- * forming the inverse of a covariance whose condition number is 1e13..1e14. 1: the reference's route literally (inverse by pivoted Gauss-Jordan
- * elimination, then LLT); agrees with mode 0 to ~1e-5 relative, which is the conditioning floor of that formula. */
+ * forming the inverse. 1: the reference's route literally (inverse by pivoted Gauss-Jordan elimination, then LLT). Both give the exact
+ * matrix to a few 1e-15 row by row (the covariance's condition number of 1e13..1e14 is units: ~15 after diagonal equilibration), and the
+ * whitened residuals / Jacobians of either agree with the compiled reference's to 1e-13 (tests/test_golden.py); mode 1 exists so that the
+ * reference's formula is also there as written. */
 int vilo_set_sqrt_info_mode(vilo_ctx *ctx, int mode);
 /* Form of the prior's square root that vilo_marginalize / vilo_batch_marginalize / vilo_optimize_windows* leave (per context).
  * VILO_PRIOR_EIGEN (default): J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b over the eigenpairs with S > 1e-8, what MarginalizationInfo::marginalize

@@ -1,6 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
 oracle on the same seeded inputs. Tolerances (FP64): factor residual/Jacobian <= 1e-11 relative to the
-block's scale, whitened IMU quantities <= 1e-8 (conditioning of the 31x31 covariance), normal-equation
+block's scale, whitened IMU quantities <= 1e-11 per entry / 1e-13 per row (measured 2e-12 / 6e-15), normal-equation
 pieces <= 1e-9, states after an equal number of trust-region iterations <= 1e-8 (the measured differences, printed in
 the assertion messages, are 1e-10 .. 1e-9: the elimination order of the speed / leg-bias chain and the summation order inside MFMA tiles differ
 from the oracle's scalar loops)."""
@@ -50,16 +50,16 @@ def test_eval_imu_leg_and_imu(ctx, ocfg, small_window):
     r, Js = ctx.eval_imu_leg(w.preint, P)
     for k in range(10):
         r_o, J_o = O.eval_imu_leg(ocfg, w.preint[k], [p[k] for p in P])
-        assert _rel(r[k], r_o) < 1e-8, ("imu_leg residual", k, _rel(r[k], r_o))
-        for b in range(6):
-            assert _rel(Js[b][k], J_o[b]) < 1e-8, ("imu_leg J", k, b, _rel(Js[b][k], J_o[b]))
+        assert (np.abs(r[k] - r_o) / np.maximum(np.abs(r_o), 1e-12 * np.abs(r_o).max())).max() < 1e-11, ("imu_leg residual", k)
+        Jg, Jo = np.hstack([Js[b][k] for b in range(6)]), np.hstack(J_o)
+        assert (np.linalg.norm(Jg - Jo, axis=1) / np.linalg.norm(Jo, axis=1)).max() < 1e-13, ("imu_leg J", k)
     P4 = [w.pose[:-1], w.speed_bias[:-1], w.pose[1:], w.speed_bias[1:]]
     r, Js = ctx.eval_imu(w.preint_imu, P4)
     for k in range(10):
         r_o, J_o = O.eval_imu(ocfg, w.preint_imu[k], [p[k] for p in P4])
-        assert _rel(r[k], r_o) < 1e-8
-        for b in range(4):
-            assert _rel(Js[b][k], J_o[b]) < 1e-8, ("imu J", k, b)
+        assert (np.abs(r[k] - r_o) / np.maximum(np.abs(r_o), 1e-12 * np.abs(r_o).max())).max() < 1e-11
+        Jg, Jo = np.hstack([Js[b][k] for b in range(4)]), np.hstack(J_o)
+        assert (np.linalg.norm(Jg - Jo, axis=1) / np.linalg.norm(Jo, axis=1)).max() < 1e-13, ("imu J", k)
 
 
 def test_sqrt_info_does_not_depend_on_the_records_wave_partner(ctx, small_window):

@@ -158,10 +158,48 @@ def test_sqrt_info_properties(small_window):
         assert np.allclose(U, np.triu(U))
         M = U @ cov @ U.T  # = I when U^T U = cov^-1
         np.testing.assert_allclose(M, np.eye(31), atol=1e-6)
-        # reference-literal route (LU inverse + LLT) is the same matrix up to conditioning noise
+        # the reference-literal route (inverse with partial pivoting + LLT) is the same matrix, row by row (see the next test)
         U1 = O.sqrt_info(cov, 1)
-        rel = np.abs(U1 - U).max() / np.abs(U).max()
-        assert rel < 1e-5, rel
+        rows = np.linalg.norm(U1 - U, axis=1) / np.linalg.norm(U, axis=1)
+        assert rows.max() < 1e-12, rows.max()
+
+
+def test_sqrt_info_routes_against_100_digit_arithmetic(cfg, small_window):
+    """LLT(cov^-1).matrixL()^T (imu_leg_factor.cpp:197-198) evaluated in 100-digit arithmetic from the FP64 covariance: the default route
+    (Cholesky of the index-reversed covariance + triangular inverse) and the reference's route taken literally (inverse, then LLT) both give
+    it to a few 1e-15 — row by row for the factor, per diagonal for the information it stands for. The covariance's raw condition number
+    (1e13 .. 1e14 for a trot, 1e20 with every foot in the air at some sample) is units — variances of 1e-11 beside ones of 0.1 or 10e10 —:
+    after diagonal equilibration it is ~ 15, which is what these factorisations see. One integration step alone leaves a rank-deficient
+    covariance (no sqrt_info exists)."""
+    import mpmath as mp
+    from cerberus_amd import synth
+    w = small_window
+    recs = [(w.preint[k][33 + 961:].reshape(31, 31), "trot") for k in (0, 5, 9)]
+    # an interval with three samples of every foot in the air (imu_leg_integration_base.cpp:354-358: uncertainties 10e10)
+    a0, a1 = int(w.sample_offsets[2]), int(w.sample_offsets[3])
+    smp = np.array(w.samples[a0:a1], copy=True)
+    smp[5:8, 31:35] = 0.0
+    recs.append((O.preintegrate_imu_leg(cfg, smp, w.lin[2])[33 + 961:].reshape(31, 31), "feet in the air"))
+    for cov, what in recs:
+        d = np.sqrt(np.diag(cov))
+        eq = np.linalg.eigvalsh(cov / np.outer(d, d))
+        raw = np.linalg.eigvalsh(0.5 * (cov + cov.T))
+        assert eq[-1] / eq[0] < 50 and raw[-1] / raw[0] > 1e12, (what, eq[-1] / eq[0], raw[-1] / raw[0])
+        with mp.workdps(100):
+            Cm = mp.matrix(cov.tolist())
+            inv = mp.inverse((Cm + Cm.T) / 2)
+            Ue = np.array(mp.cholesky(inv).T.tolist(), dtype=np.float64)
+            Le = np.array(inv.tolist(), dtype=np.float64)
+        dl = np.sqrt(np.diag(Le))
+        for mode in (0, 1):
+            U = O.sqrt_info(cov, mode)
+            rows = np.linalg.norm(U - Ue, axis=1) / np.linalg.norm(Ue, axis=1)
+            info = np.abs(U.T @ U - Le) / np.outer(dl, dl)
+            assert rows.max() < 2e-14 and info.max() < 5e-14, (what, mode, rows.max(), info.max())   # measured: 3e-15, 6e-15
+    one_step = O.preintegrate_imu_leg(cfg, w.samples[a0:a0 + 2], w.lin[2])[33 + 961:].reshape(31, 31)
+    d = np.sqrt(np.diag(one_step))
+    eq = np.linalg.eigvalsh(one_step / np.outer(d, d))
+    assert eq[0] < 1e-12 * eq[-1]
 
 
 def test_preintegration_imu_subblock_consistency(cfg, small_window):

@@ -135,47 +135,48 @@ def _imu_params(w, k, rng, noise=1e-2):
     return P
 
 
-def _unwhiten(cov, r, Js):
-    """Remove the information square root: the whitened quantities depend on inv(cov), whose rounding differs between
-    Eigen-style LU (reference build) and the oracle; U^-1 (U r) compares the factor's own algebra at full precision."""
-    U = O.sqrt_info(cov, mode=1)
-    return np.linalg.solve(U, r), [np.linalg.solve(U, J) for J in Js]
+def _per_entry(a, b):
+    """largest |a_i - b_i| / |b_i| (entries below 1e-12 of the largest one are held to that floor)"""
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-12 * np.abs(b).max())).max())
+
+
+def _per_row(A, B):
+    return float((np.linalg.norm(A - B, axis=1) / np.linalg.norm(B, axis=1)).max())
 
 
 def test_imu_leg_factor(cfg, window):
+    """Whitened residual and Jacobians, oracle against the compiled reference: rounding level — the covariance's raw condition number of
+    1e13 .. 1e14 is a matter of units (equilibrated: ~ 15, tests/test_oracle_factors.py::test_sqrt_info_routes_against_100_digit_arithmetic),
+    and LLT(cov^-1) comes out the same to 1e-15 whichever way it is computed. Measured: 7e-14 per entry, 2e-15 per row."""
     w, rng = window, np.random.default_rng(3)
-    for k in (0, 3, 9):
-        P = _imu_params(w, k, rng)
+    for trial in range(30):
+        k = int(rng.integers(0, 10))
+        P = _imu_params(w, k, rng, noise=10.0 ** rng.uniform(-4, -1))
         ro, Jo = O.eval_imu_leg(cfg, w.preint[k], P)
         with R.as_oracle():
             rr, Jr = O.eval_imu_leg(cfg, w.preint[k], P)
-        # whitened residual/Jacobians: same to the conditioning of the 31x31 covariance inverse
-        scale = np.abs(rr).max()
-        np.testing.assert_allclose(ro, rr, rtol=0, atol=1e-6 * scale)
-        cov = _split(w.preint[k])["cov"]
-        uo, UJo = _unwhiten(cov, ro, Jo)
-        ur, UJr = _unwhiten(cov, rr, Jr)
-        np.testing.assert_allclose(uo, ur, rtol=1e-7, atol=1e-9 * np.abs(ur).max())
-        for a, b in zip(UJo, UJr):
-            np.testing.assert_allclose(a, b, rtol=0, atol=1e-7 * max(1.0, np.abs(b).max()))
-        # the information-weighted quantities the solver consumes: J^T J and J^T r
+        assert _per_entry(ro, rr) < 1e-11
         Jo_, Jr_ = np.hstack(Jo), np.hstack(Jr)
+        assert _per_row(Jo_, Jr_) < 1e-13
+        # the information-weighted quantities the solver consumes: J^T J per diagonal, J^T r in whitened units
         Ho, Hr = Jo_.T @ Jo_, Jr_.T @ Jr_
-        np.testing.assert_allclose(Ho, Hr, rtol=0, atol=1e-6 * np.abs(Hr).max())
-        np.testing.assert_allclose(Jo_.T @ ro, Jr_.T @ rr, rtol=0, atol=1e-6 * np.abs(Jr_.T @ rr).max())
+        d = np.sqrt(np.diag(Hr))
+        d[d == 0] = 1.0                              # (the quaternion's w column of a pose block: identically zero)
+        assert (np.abs(Ho - Hr) / np.outer(d, d)).max() < 1e-13
+        assert (np.abs(Jo_.T @ ro - Jr_.T @ rr) / d).max() < 1e-12 * max(1.0, (np.abs(Jr_.T @ rr) / d).max())
 
 
 def test_imu_factor(cfg, window):
     w, rng = window, np.random.default_rng(4)
-    for k in (1, 7):
-        P6 = _imu_params(w, k, rng)
+    for trial in range(30):
+        k = int(rng.integers(0, 10))
+        P6 = _imu_params(w, k, rng, noise=10.0 ** rng.uniform(-4, -1))
         P = [P6[0], P6[1], P6[3], P6[4]]
         ro, Jo = O.eval_imu(cfg, w.preint_imu[k], P)
         with R.as_oracle():
             rr, Jr = O.eval_imu(cfg, w.preint_imu[k], P)
-        np.testing.assert_allclose(ro, rr, rtol=0, atol=1e-7 * np.abs(rr).max())
-        for a, b in zip(Jo, Jr):
-            np.testing.assert_allclose(a, b, rtol=0, atol=1e-7 * np.abs(np.hstack(Jr)).max())
+        assert _per_entry(ro, rr) < 1e-11            # measured: 8e-14
+        assert _per_row(np.hstack(Jo), np.hstack(Jr)) < 1e-13
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])

@@ -142,7 +142,7 @@ def main():
         return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
     n_int = 0
     pd_count = [0, 0, 0]
-    one_sided, cls_count = [], {}
+    one_sided, cls_count, worst_cond = [], {}, [0.0]
     for ctype in (0, 1, 2):
         c2, o2 = copy.copy(cfg), copy.copy(ocfg)
         c2.contact_sensor_type = ctype; o2.contact_sensor_type = ctype
@@ -193,23 +193,32 @@ def main():
                 note2(tag + "state (33 scalars)", float(np.abs(out[k][:33] - b[:33]).max() / max(1.0, np.abs(b[:33]).max())), ctype)
                 note2(tag + "jacobian, of its largest entry", relm(out[k][33:33 + 961], b[33:33 + 961]), ctype)
                 note2(tag + "covariance, of its largest entry", relm(out[k][33 + 961:], b[33 + 961:]), ctype)
+                cg_, co_ = out[k][33 + 961:].reshape(31, 31), b[33 + 961:].reshape(31, 31)
+                dd = np.sqrt(np.abs(np.diag(co_)))
+                note2(tag + "covariance, per diagonal (|dC_ij| / sqrt(C_ii C_jj))", float((np.abs(cg_ - co_) / np.outer(dd, dd)).max()), ctype)
+                # What the accuracy of LLT(cov^-1) depends on is the condition number after diagonal equilibration (the raw one — 1e11 for a
+                # trot, 1e21 with feet in the air — is units: 1e-11 variances beside 10e10 ones; Cholesky does not see that scaling). It is
+                # ~ 15 for every interval of two integration steps or more and ~ 1e16 for an interval of ONE step, whose covariance
+                # V N V^T is rank-deficient: sqrt_info does not exist there, in any arithmetic.
                 cov = b[33 + 961:].reshape(31, 31)
-                ev = np.linalg.eigvalsh(0.5 * (cov + cov.T))
+                dg = np.sqrt(np.abs(np.diag(cov)))
+                ev = np.linalg.eigvalsh(0.5 * (cov + cov.T) / np.outer(dg, dg))
                 cond = float(ev[-1] / ev[0]) if ev[0] > 0 else np.inf
-                cls = "cond(covariance) <= 1e15" if cond <= 1e15 else "cond(covariance) > 1e15: singular to FP64 working precision"
+                worst_cond[0] = max(worst_cond[0], cond if offs[k + 1] - offs[k] > 2 else 0.0)
+                cls = "two steps or more" if offs[k + 1] - offs[k] > 2 else "ONE step (covariance rank-deficient, equilibrated cond ~ 1e16: no sqrt_info in any arithmetic)"
                 if gpu_ok != orc_ok:
-                    one_sided.append("%.1e" % cond)
+                    one_sided.append("%d steps, equilibrated cond %.1e" % (offs[k + 1] - offs[k] - 1, cond))
                 if gpu_ok and orc_ok:
                     ro, Jo = O.eval_imu_leg(o2, b, [p[k] for p in P])
-                    note2("IMULegFactor::Evaluate on those records, %s: whitened residual" % cls, relm(rg[0], ro), ctype)
-                    note2("IMULegFactor::Evaluate on those records, %s: whitened Jacobians" % cls, max(relm(Jg[q][0], Jo[q]) for q in range(6)), ctype)
+                    note2("IMULegFactor::Evaluate on those records, intervals of %s: whitened residual, per entry" % cls, float((np.abs(rg[0] - ro) / np.maximum(np.abs(ro), 1e-12 * np.abs(ro).max())).max()), ctype)
+                    note2("IMULegFactor::Evaluate on those records, intervals of %s: whitened Jacobians, per row" % cls, float((np.linalg.norm(np.hstack([Jg[q][0] for q in range(6)]) - np.hstack(Jo), axis=1) / np.linalg.norm(np.hstack(Jo), axis=1)).max()), ctype)
                     cls_count[cls] = cls_count.get(cls, 0) + 1
         cc.close()
     print("parity sweep: %d random windows (seed %d), %d random preintegration intervals, %.0f s" % (N, seed, n_int, time.time() - t0))
     for k in sorted(worst2):
-        print("  %-128s %.2e   (contact model %d)" % (k, worst2[k][0], worst2[k][1]))
-    print("  covariances with sqrt_info on both sides: %d (%s), refused by both (not positive definite in FP64): %d, refused by one side only: %d (their condition numbers: %s)"
-          % (pd_count[0], ", ".join("%s: %d" % kv for kv in sorted(cls_count.items())), pd_count[1], pd_count[2], ", ".join(one_sided) or "-"))
+        print("  %-150s %.2e   (contact model %d)" % (k, worst2[k][0], worst2[k][1]))
+    print("  covariances with sqrt_info on both sides: %d (%s), refused by both (not positive definite in FP64): %d, refused by one side only: %d (%s); largest equilibrated condition number of a covariance of two steps or more: %.1f"
+          % (pd_count[0], ", ".join("%s: %d" % kv for kv in sorted(cls_count.items())), pd_count[1], pd_count[2], "; ".join(one_sided) or "-", worst_cond[0]))
     for k in sorted(worst):
         v, i, sp = worst[k]
         print("  %-104s %.2e   (window %d: %d landmarks, prior %d, use_leg %d, consts %s)" % (k, v, i, sp["n_landmarks"], sp["with_prior"], sp["use_leg"], sp["consts"]))
