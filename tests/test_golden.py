@@ -388,8 +388,8 @@ def test_gpu_contact_edges_vs_reference(ctx, gwin):
     for k in range(r.shape[0]):
         ro, Jo = O.eval_imu_leg(cfg, GE["flags"][k], [p[k] for p in P])
         Jo, Jg = np.hstack(Jo), np.hstack([J[k] for J in Js])
-        assert _rel(r[k], ro) < 1e-8, (k, _rel(r[k], ro))
-        assert _rel(Jg, Jo) < 1e-8, (k, _rel(Jg, Jo))
+        assert _per_entry(r[k], ro) < 1e-11, (k, _per_entry(r[k], ro))      # (raw condition numbers of 1e20 here: units, like everywhere else)
+        assert _per_row(Jg, Jo) < 1e-13, (k, _per_row(Jg, Jo))
 
 
 # ------------------------------------------------------------------------------ gauge fix at the Euler singularity (estimator.cpp:925-934)
