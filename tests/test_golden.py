@@ -110,7 +110,7 @@ def test_oracle_marginalization(gwin, mode):
     p = synth.PriorData()
     assert O.marginalize(cfg, w, mode, p)[0] == 0
     ids, H, b, x0 = _info_blocks(p)
-    tol = 1e-5 if mode == 0 else 1e-6    # eps * cond(Amm), see test_oracle_vs_reference.test_marginalization
+    tol = 1e-5 if mode == 0 else 1e-11   # MARGIN_OLD: eps * cond(Amm), see test_oracle_vs_reference.test_marginalization; MARGIN_SECOND_NEW: rounding (measured 1e-14)
     np.testing.assert_array_equal(ids, G["marg%d_ids" % mode])
     np.testing.assert_allclose(H, G["marg%d_H" % mode], rtol=0, atol=tol * np.abs(G["marg%d_H" % mode]).max())
     np.testing.assert_allclose(b, G["marg%d_b" % mode], rtol=0, atol=tol * np.abs(G["marg%d_b" % mode]).max())
@@ -208,7 +208,7 @@ def test_gpu_marginalization_vs_reference(ctx, gwin, mode):
     p = synth.PriorData()
     ctx.marginalize(w, mode, p)
     ids, H, b, x0 = _info_blocks(p)
-    tol = 1e-5 if mode == 0 else 1e-6
+    tol = 1e-5 if mode == 0 else 1e-11   # (MARGIN_SECOND_NEW drops one well-conditioned pose block: rounding level, measured 1e-14)
     np.testing.assert_array_equal(ids, G["marg%d_ids" % mode])
     np.testing.assert_allclose(H, G["marg%d_H" % mode], rtol=0, atol=tol * np.abs(G["marg%d_H" % mode]).max())
     np.testing.assert_allclose(b, G["marg%d_b" % mode], rtol=0, atol=tol * np.abs(G["marg%d_b" % mode]).max())

@@ -317,7 +317,7 @@ def test_solve_parity(ctx, cfg, ocfg, iters):
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
     # states after an equal number of iterations <= 1e-8
     np.testing.assert_allclose(ct_g, ct_o, rtol=1e-8)
-    np.testing.assert_allclose(rt_g, rt_o, rtol=1e-7)
+    np.testing.assert_allclose(rt_g, rt_o, rtol=1e-8)
     worst = 0.0
     for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], w_g.state_arrays(), w_o.state_arrays()):
         err = np.abs(a - bb).max() / max(1.0, np.abs(bb).max())
@@ -336,7 +336,7 @@ def test_solve_skips_long_intervals(ctx, cfg, ocfg):
     summ = ctx.solve_windows([w_g], api.default_solve_opts(True, 4))[0]
     osum = O.solve_window(ocfg, w_o, O.default_opts(True, 4))
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
-    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
@@ -368,7 +368,7 @@ def test_solve_partial_window(ctx, cfg, ocfg, F):
     summ = ctx.solve_windows([w_g], api.default_solve_opts(True, 4))[0]
     osum = O.solve_window(ocfg, w_o, O.default_opts(True, 4))
     assert summ.iterations == osum.iterations and summ.num_successful == osum.num_successful
-    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(summ.final_cost, osum.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a[:F] - bb[:F]).max() < 1e-8 * max(1.0, np.abs(bb[:F]).max()) if a.shape[0] == 11 else np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max())
 
@@ -676,7 +676,7 @@ def test_small_and_large_batches_linearise_identically(ctx, cfg, ocfg, td_const)
         w_o = fresh(300)
         O.solve_window(ocfg, w_o, O.default_opts(False, 12))
         for name, a, bb in zip(["pose", "sb", "lb", "ex", "td", "lam"], crowd[0].state_arrays(), w_o.state_arrays()):
-            assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
+            assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), (name, np.abs(a - bb).max())
 
 
 def test_size_independent_properties(ctx, cfg):
@@ -960,7 +960,7 @@ def test_marginalized_prior_feeds_next_solve(ctx, cfg, ocfg):
         w.prior = p.copy()
     sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 6))[0]
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 6))
-    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
@@ -979,7 +979,7 @@ def test_solve_without_leg_factors(ctx, cfg, ocfg):
     sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 5))[0]
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 5))
     assert sg.iterations == so.iterations and sg.num_successful == so.num_successful
-    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
     np.testing.assert_array_equal(w_g.leg_bias, lb0)   # not part of the problem
@@ -1011,7 +1011,7 @@ def test_marginalize_and_next_solve_without_leg_factors(ctx, cfg, ocfg):
         w.prior = pg.copy()
     sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 5))[0]
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 5))
-    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 
@@ -1034,7 +1034,7 @@ def test_solve_window_without_landmarks(ctx, cfg, ocfg, with_prior):
     np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         if a.size:
-            assert np.abs(a - bb).max() < 1e-7 * max(1.0, np.abs(bb).max())
+            assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max())
 
 
 def test_solve_window_at_the_feature_cap(ctx, cfg, ocfg):
@@ -1045,7 +1045,7 @@ def test_solve_window_at_the_feature_cap(ctx, cfg, ocfg):
     sg = ctx.solve_windows([w_g], api.default_solve_opts(True, 12))[0]
     so = O.solve_window(ocfg, w_o, O.default_opts(True, 12))
     assert (sg.iterations, sg.num_successful) == (so.iterations, so.num_successful) and sg.iterations == 12
-    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-7)
+    np.testing.assert_allclose(sg.final_cost, so.final_cost, rtol=1e-8)
     for a, bb in zip(w_g.state_arrays(), w_o.state_arrays()):
         assert np.abs(a - bb).max() < 1e-8 * max(1.0, np.abs(bb).max()), np.abs(a - bb).max()   # measured: 1e-10 .. 1e-9
 

@@ -235,7 +235,7 @@ def test_marginalization(cfg, window, mode):
     eigenvalues from 5e3 to 8e14 (condition 1.6e11), so two correct FP64 eigensolvers differ by up to eps * cond ~ 1e-5
     in the Schur complement; against a 60-digit mpmath evaluation the oracle is within 7e-8 and the shim-built reference
     within 2e-6 of the largest entry (measured)."""
-    tol = 1e-5 if mode == 0 else 1e-6
+    tol = 1e-5 if mode == 0 else 1e-11   # (MARGIN_SECOND_NEW drops one well-conditioned pose block: rounding level, measured 1e-14)
     w = window
     po, pr = synth.PriorData(), synth.PriorData()
     rc_o, _, _, _ = O.marginalize(cfg, w, mode, po)
