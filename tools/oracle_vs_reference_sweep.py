@@ -1,0 +1,171 @@
+"""How far the CPU oracle (oracle/, the checker of every GPU parity test) is from the reference's OWN classes compiled here
+(oracle/_ref/libref.so, oracle/ref_build) over randomised inputs, beyond the fixed seeds of tests/test_oracle_vs_reference.py: kinematics,
+preintegration under the three contact models with contact inputs no gait produces, IMULegFactor / IMUFactor, the three projection
+factors, the prior factor, PoseLocalParameterization::Plus, MarginalizationInfo on random windows. Needs /root/reference to have been
+compiled (it only exists in the build container); prints the worst case per quantity with the metric it is held in.
+python tools/oracle_vs_reference_sweep.py [N] [seed]"""
+import copy
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cerberus_amd import synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+from oracle import ref_py as R  # noqa: E402
+from conftest import rand_pose  # noqa: E402
+
+
+def per_entry(a, b):
+    a, b = np.ravel(a), np.ravel(b)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-12 * max(1e-300, np.abs(b).max()))).max())
+
+
+def per_row(A, B):
+    n = np.linalg.norm(B, axis=1)
+    return float((np.linalg.norm(A - B, axis=1) / np.where(n > 0, n, 1.0)).max())
+
+
+def per_diag(A, B):
+    d = np.sqrt(np.abs(np.diag(B)))
+    d[d == 0] = 1.0
+    return float((np.abs(A - B) / np.outer(d, d)).max())
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+    rng = np.random.default_rng(seed)
+    scfg, cfg = synth.default_config(), O.default_config()
+    worst = {}
+
+    def note(k, v):
+        worst[k] = max(worst.get(k, 0.0), float(v))
+    # ---- A1Kinematics (src/legKinematics/A1Kinematics.cpp:43-221) ----
+    RF = np.array([[0.1805, 0.047, 0.0838, 0.21], [0.1805, -0.047, -0.0838, 0.21], [-0.1805, 0.047, 0.0838, 0.21], [-0.1805, -0.047, -0.0838, 0.21]])
+    for _ in range(N):
+        q, lc, rf = rng.uniform(-1.5, 1.5, size=3), rng.uniform(0.15, 0.25), RF[int(rng.integers(0, 4))]
+        a = O.kin(q, lc, rf)
+        with R.as_oracle():
+            b = O.kin(q, lc, rf)
+        for name in a:
+            note("kinematics %-8s absolute" % name, np.abs(np.asarray(a[name]) - np.asarray(b[name])).max())
+    # ---- preintegration + the factors on its records ----
+    n_int = 0
+    for ctype in (0, 1, 2):
+        c2 = copy.copy(cfg)
+        c2.contact_sensor_type = ctype
+        for rep in range(max(3, N // 20)):
+            w = synth.make_window(scfg, n_landmarks=3, seed=int(rng.integers(1, 1 << 30)))
+            smp = np.array(w.samples, copy=True)
+            nS = int(w.sample_offsets[-1])
+            c = smp[:nS, 31:35]
+            frac = rng.random(c.shape) < 0.25
+            c[frac] = rng.choice([0.0, 0.3, 0.49999, 0.5, 0.7, 1.0], size=int(frac.sum()))
+            for _ in range(3):
+                a0 = int(rng.integers(0, max(1, nS - 6)))
+                c[a0:a0 + int(rng.integers(1, 6))] = 0.0
+            if ctype == 2:
+                c[:] = 15.0 + 140.0 * c + 4.0 * rng.normal(size=c.shape)
+            for k in range(10):
+                a0, a1 = int(w.sample_offsets[k]), int(w.sample_offsets[k + 1])
+                n = int(rng.integers(3, a1 - a0 + 1))           # (two integration steps or more: one step alone leaves a rank-deficient covariance)
+                lin = w.lin[k] + np.concatenate([0.05 * rng.normal(size=3), 0.01 * rng.normal(size=3), 0.01 * rng.normal(size=4)])
+                S = smp[a0:a0 + n]
+                po = O.preintegrate_imu_leg(c2, S, lin)
+                with R.as_oracle():
+                    pr = O.preintegrate_imu_leg(c2, S, lin)
+                n_int += 1
+                tag = "IMULegIntegrationBase, contact model %d: " % ctype
+                note(tag + "state (33 scalars), of max(1, |.|)", np.abs(po[:33] - pr[:33]).max() / max(1.0, np.abs(pr[:33]).max()))
+                note(tag + "jacobian, per entry", per_entry(po[33:994], pr[33:994]))
+                note(tag + "covariance, per diagonal", per_diag(po[994:].reshape(31, 31), pr[994:].reshape(31, 31)))
+                P = [w.pose[k].copy(), w.speed_bias[k].copy(), w.leg_bias[k].copy(), w.pose[k + 1].copy(), w.speed_bias[k + 1].copy(), w.leg_bias[k + 1].copy()]
+                for p in P:
+                    nz = 10.0 ** rng.uniform(-4, -1)
+                    p[:] = O.pose_plus(p, nz * rng.normal(size=6)) if p.size == 7 else p + nz * rng.normal(size=p.size)
+                try:
+                    O.sqrt_info(pr[994:].reshape(31, 31))
+                except FloatingPointError:
+                    continue
+                ro, Jo = O.eval_imu_leg(c2, pr, P)
+                with R.as_oracle():
+                    rr, Jr = O.eval_imu_leg(c2, pr, P)
+                note("IMULegFactor::Evaluate: whitened residual, per entry", per_entry(ro, rr))
+                note("IMULegFactor::Evaluate: whitened Jacobians, per row", per_row(np.hstack(Jo), np.hstack(Jr)))
+                if ctype == 0:
+                    qo = O.preintegrate_imu(c2, S, lin[:6])
+                    with R.as_oracle():
+                        qr = O.preintegrate_imu(c2, S, lin[:6])
+                    note("IntegrationBase: state, jacobian, covariance, per entry", per_entry(qo, qr))
+                    P4 = [P[0], P[1], P[3], P[4]]
+                    ro, Jo = O.eval_imu(c2, qr, P4)
+                    with R.as_oracle():
+                        rr, Jr = O.eval_imu(c2, qr, P4)
+                    note("IMUFactor::Evaluate: whitened residual, per entry", per_entry(ro, rr))
+                    note("IMUFactor::Evaluate: whitened Jacobians, per row", per_row(np.hstack(Jo), np.hstack(Jr)))
+    # ---- projection factors, pose plus ----
+    for kind in (0, 1, 2):
+        for _ in range(N):
+            pi, pj = rand_pose(rng, 0.5), rand_pose(rng, 0.5)
+            ex0, ex1 = rand_pose(rng, 0.05), rand_pose(rng, 0.05)
+            ex1[0] += 0.1
+            obs = np.concatenate([[0.3 * rng.normal(), 0.3 * rng.normal(), 1.0], [0.3 * rng.normal(), 0.3 * rng.normal(), 1.0],
+                                  0.1 * rng.normal(size=2), 0.1 * rng.normal(size=2), [0.002, 0.004]])
+            lam, td = np.array([abs(0.3 + 0.1 * rng.normal()) + 0.02]), np.array([0.01])
+            P = [[pi, pj, ex0, lam, td], [pi, pj, ex0, ex1, lam, td], [ex0, ex1, lam, td]][kind]
+            ro, Jo = O.eval_proj(kind, cfg, obs, P)
+            with R.as_oracle():
+                rr, Jr = O.eval_proj(kind, cfg, obs, P)
+            note("Projection factor kind %d: residual, of max(1, |r|)" % kind, np.abs(ro - rr).max() / max(1.0, np.abs(rr).max()))
+            note("Projection factor kind %d: Jacobians, of max(1, largest entry)" % kind, np.abs(np.hstack(Jo) - np.hstack(Jr)).max() / max(1.0, np.abs(np.hstack(Jr)).max()))
+    for _ in range(N):
+        x, d = rand_pose(rng, 1.0), 10.0 ** rng.uniform(-6, 0) * rng.normal(size=6)
+        a = O.pose_plus(x, d)
+        with R.as_oracle():
+            b = O.pose_plus(x, d)
+        note("PoseLocalParameterization::Plus, absolute", np.abs(a - b).max())
+    # ---- prior factor and marginalisation on random windows ----
+    n_marg = 0
+    for i in range(max(6, N // 10)):
+        L = int(rng.choice([3, 8, 20, 60, 130, 200]))
+        w = synth.make_window(scfg, n_landmarks=L, seed=int(rng.integers(1, 1 << 30)))
+        O.fill_preint(cfg, w)
+        pr = w.prior
+        params, off = [], 0
+        for k in range(pr.struct.n_blocks):
+            gs = pr.struct.block_size[k]
+            x = pr.x0[off:off + gs].copy()
+            off += gs
+            params.append(O.pose_plus(x, 1e-2 * rng.normal(size=6)) if gs == 7 else x + 1e-2 * rng.normal(size=gs))
+        ro, Jo = O.eval_prior(pr.struct, params)
+        with R.as_oracle():
+            rr, Jr = O.eval_prior(pr.struct, params)
+        note("MarginalizationFactor::Evaluate: residual, per entry", per_entry(ro, rr))
+        note("MarginalizationFactor::Evaluate: Jacobian, of its largest entry", np.abs(np.hstack(Jo) - np.hstack(Jr)).max() / np.abs(np.hstack(Jr)).max())
+        for mode in (0, 1):
+            po, pr_ = synth.PriorData(), synth.PriorData()
+            if O.marginalize(cfg, w, mode, po)[0] != 0 or R.marginalize(cfg, w, mode, pr_) != 0:
+                continue
+            n_marg += 1
+            Ho, bo, xo = R.prior_information(po)
+            Hr, br, xr = R.prior_information(pr_)
+            assert set(xo) == set(xr)
+            dg = {a: np.sqrt(np.abs(np.diag(Hr[(a, a)]))) for a in xr}
+            eh = max(float((np.abs(Ho[(a, c)] - Hr[(a, c)]) / np.outer(dg[a], dg[c])).max()) for (a, c) in Hr)
+            bscale = max(1.0, max(float((np.abs(br[a]) / dg[a]).max()) for a in br))
+            eb = max(float((np.abs(bo[a] - br[a]) / dg[a]).max()) for a in br) / bscale
+            name = "MARGIN_OLD" if mode == 0 else "MARGIN_SECOND_NEW"
+            note("MarginalizationInfo::marginalize %s: information, per block diagonal" % name, eh)
+            note("MarginalizationInfo::marginalize %s: gradient, whitened" % name, eb)
+            note("MarginalizationInfo::marginalize %s: linearisation points, absolute" % name, max(float(np.abs(xo[a] - xr[a]).max()) for a in xr))
+    print("oracle against the compiled reference: %d evaluations per factor class, %d preintegration intervals, %d marginalisations (seed %d)" % (N, n_int, n_marg, seed))
+    for k in sorted(worst):
+        print("  %-92s %.2e" % (k, worst[k]))
+
+
+if __name__ == "__main__":
+    main()
