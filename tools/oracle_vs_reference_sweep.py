@@ -35,9 +35,8 @@ def per_diag(A, B):
     return float((np.abs(A - B) / np.outer(d, d)).max())
 
 
-def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+def sweep(N, seed):
+    """-> ({quantity: worst value}, intervals integrated, marginalisations compared)"""
     rng = np.random.default_rng(seed)
     scfg, cfg = synth.default_config(), O.default_config()
     worst = {}
@@ -162,6 +161,13 @@ def main():
             note("MarginalizationInfo::marginalize %s: information, per block diagonal" % name, eh)
             note("MarginalizationInfo::marginalize %s: gradient, whitened" % name, eb)
             note("MarginalizationInfo::marginalize %s: linearisation points, absolute" % name, max(float(np.abs(xo[a] - xr[a]).max()) for a in xr))
+    return worst, n_int, n_marg
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+    worst, n_int, n_marg = sweep(N, seed)
     print("oracle against the compiled reference: %d evaluations per factor class, %d preintegration intervals, %d marginalisations (seed %d)" % (N, n_int, n_marg, seed))
     for k in sorted(worst):
         print("  %-92s %.2e" % (k, worst[k]))

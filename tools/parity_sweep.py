@@ -52,9 +52,9 @@ def info_err(pg, po):
     return eh, eb / max(1.0, float(np.abs(bo / d).max()))
 
 
-def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+def sweep(N, seed):
+    """-> dict(worst: windows' categories -> (value, window, spec), worst2: factor categories -> (value, contact model), split, differ,
+    pd_count, cls_count, one_sided, worst_cond, n_int, seconds)"""
     rng = np.random.default_rng(seed)
     cfg, ocfg = synth.default_config(), O.default_config()
     ctx = api.Context(cfg, 0)
@@ -214,11 +214,21 @@ def main():
                     note2("IMULegFactor::Evaluate on those records, intervals of %s: whitened Jacobians, per row" % cls, float((np.linalg.norm(np.hstack([Jg[q][0] for q in range(6)]) - np.hstack(Jo), axis=1) / np.linalg.norm(np.hstack(Jo), axis=1)).max()), ctype)
                     cls_count[cls] = cls_count.get(cls, 0) + 1
         cc.close()
-    print("parity sweep: %d random windows (seed %d), %d random preintegration intervals, %.0f s" % (N, seed, n_int, time.time() - t0))
+    ctx.close()
+    return dict(worst=worst, worst2=worst2, split=split, differ=differ, pd_count=pd_count, cls_count=cls_count, one_sided=one_sided,
+                worst_cond=worst_cond[0], n_int=n_int, seconds=time.time() - t0)
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+    r = sweep(N, seed)
+    worst, worst2, split, differ, pd_count, cls_count, one_sided = r["worst"], r["worst2"], r["split"], r["differ"], r["pd_count"], r["cls_count"], r["one_sided"]
+    print("parity sweep: %d random windows (seed %d), %d random preintegration intervals, %.0f s" % (N, seed, r["n_int"], r["seconds"]))
     for k in sorted(worst2):
         print("  %-150s %.2e   (contact model %d)" % (k, worst2[k][0], worst2[k][1]))
     print("  covariances with sqrt_info on both sides: %d (%s), refused by both (not positive definite in FP64): %d, refused by one side only: %d (%s); largest equilibrated condition number of a covariance of two steps or more: %.1f"
-          % (pd_count[0], ", ".join("%s: %d" % kv for kv in sorted(cls_count.items())), pd_count[1], pd_count[2], "; ".join(one_sided) or "-", worst_cond[0]))
+          % (pd_count[0], ", ".join("%s: %d" % kv for kv in sorted(cls_count.items())), pd_count[1], pd_count[2], "; ".join(one_sided) or "-", r["worst_cond"]))
     for k in sorted(worst):
         v, i, sp = worst[k]
         print("  %-104s %.2e   (window %d: %d landmarks, prior %d, use_leg %d, consts %s)" % (k, v, i, sp["n_landmarks"], sp["with_prior"], sp["use_leg"], sp["consts"]))
@@ -228,7 +238,6 @@ def main():
         print("  %s: %d windows stop at another iteration or for another reason than the oracle's" % (k, differ[k]))
     if not differ:
         print("  every window stops at the oracle's iteration, for the oracle's reason")
-    ctx.close()
 
 
 if __name__ == "__main__":
