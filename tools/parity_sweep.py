@@ -1,6 +1,6 @@
 """A randomised GPU-against-oracle sweep of the whole path, beyond what the -m gpu suite holds at fixed seeds (run on the GPU box; the
 oracle is the checker, as in tests/): N random windows — 1 .. 600 landmarks, with / without prior, IMU-leg or plain IMU factors, constant or
-estimated extrinsics / leg biases — through
+estimated extrinsics / leg biases / td — through
 
   solve      vilo_solve_windows (ONE call for all windows: the sub-batch pipeline when N allows) against oracle solve_window, fixed 8
              iterations and to convergence: final states relative to max(1, |state|), final cost relative
@@ -64,7 +64,7 @@ def sweep(N, seed):
         # (the generator's prior carries leg-bias blocks: windows with plain IMU factors go without one, as in tests/test_gpu_parity.py::_vins)
         specs.append(dict(n_landmarks=int(rng.choice([1, 3, 8, 20, 60, 130, 200, 333, 600])), seed=int(rng.integers(1, 1 << 30)),
                           with_prior=bool(rng.integers(0, 5) != 0) and leg == 1, use_leg=leg,
-                          consts=[(0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1)][int(rng.integers(0, 4))]))
+                          consts=[(0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0), (1, 0, 0)][int(rng.integers(0, 6))]))   # (leg bias, extrinsics, td constant)
 
     def fresh(sp):
         w = synth.make_window(cfg, n_landmarks=sp["n_landmarks"], seed=sp["seed"], with_prior=sp["with_prior"])
@@ -84,8 +84,8 @@ def sweep(N, seed):
     t0 = time.time()
     for name, opts_g, opts_o in (("solve, 8 fixed iterations", api.default_solve_opts(True, 8), O.default_opts(True, 8)),
                                  ("solve, to convergence (<= 12)", api.default_solve_opts(False, 12), O.default_opts(False, 12))):
-        for leg in (1, 0):     # (one IMU factor kind per batch)
-            idx = [i for i in range(N) if specs[i]["use_leg"] == leg]
+        for leg, tdc in ((1, 1), (1, 0), (0, 1), (0, 0)):     # (one IMU factor kind per batch; a batch with a window that estimates td takes the 23-column visual rows, one without the compact ones)
+            idx = [i for i in range(N) if specs[i]["use_leg"] == leg and specs[i]["consts"][2] == tdc]
             if not idx:
                 continue
             wg = [fresh(specs[i]) for i in idx]
