@@ -592,6 +592,55 @@ def test_host_records_arrive_as_what_the_solver_reads(ctx, cfg):
         b.close()
 
 
+def test_host_pipeline_under_changing_settings_and_refused_windows(cfg, ocfg):
+    """One context, forty calls: the number of windows, the lanes and the share size change from call to call (lanes are created once and
+    reused), every third call carries a refused window at a random position (first share, last share, anywhere) — the call must say so
+    and leave every state as it was — and every good call must give the one batch's answer bit for bit."""
+    import ctypes as C
+    from cerberus_amd import api, _ctypes as T
+    rng = np.random.default_rng(99)
+    base = [_fresh(cfg, ocfg, n_landmarks=int(n), seed=700 + i, with_prior=bool(i % 3)) for i, n in enumerate((5, 17, 33, 64, 9))]
+    opts = api.default_solve_opts(True, 3)
+    c1 = api.Context(cfg, 0); c1.set_host_pipeline(0, 0)
+    cp = api.Context(cfg, 0)
+    try:
+        ref = {}
+        for call in range(40):
+            N = int(rng.choice([257, 300, 513, 777]))
+            lanes, sub = int(rng.integers(2, 7)), int(rng.integers(16, 130))
+            cp.set_host_pipeline(lanes, sub)
+            ws = [base[(i * 7 + call) % 5].twin() for i in range(N)]
+            before = [w.clone_state() for w in ws]
+            bad_at = None
+            if call % 3 == 2:
+                bad_at = int(rng.choice([0, N - 1, int(rng.integers(0, N))]))
+                ws[bad_at].lm_start_frame = ws[bad_at].lm_start_frame.copy()
+                ws[bad_at].lm_start_frame[0] = 11                    # outside the window
+            descs, states, summ = (T.WindowDesc * N)(), (T.WindowState * N)(), (T.SolveSummary * N)()
+            for i, w in enumerate(ws):
+                descs[i], states[i] = w.desc(T)
+            rc = api.lib().vilo_solve_windows(cp.h, N, descs, states, C.byref(opts), summ)
+            if bad_at is not None:
+                assert rc == -2, (call, rc)
+                for w, k in zip(ws, before):
+                    for x, y in zip(w.state_arrays(), k):
+                        np.testing.assert_array_equal(x, y)
+                continue
+            assert rc == 0, (call, rc, api.lib().vilo_last_error(cp.h))
+            for i in (0, N // 2, N - 1, int(rng.integers(0, N))):
+                # the window's answer in a one-batch call that takes the solver form a call of N windows takes (eight waves per window up
+                # to 512 windows, the single wave beyond: the two agree to rounding, not bitwise)
+                key = ((i * 7 + call) % 5, N > 512)
+                if key not in ref:
+                    one = [base[key[0]].twin() for _ in range(600 if key[1] else 300)]
+                    c1.solve_windows(one, opts)
+                    ref[key] = one[0].clone_state()
+                for x, y in zip(ws[i].state_arrays(), ref[key]):
+                    np.testing.assert_array_equal(x, y)
+    finally:
+        c1.close(); cp.close()
+
+
 def test_host_pipeline_on_a_random_crowd(cfg):
     """300 windows of 0 .. 400 landmarks, with and without prior, solved to convergence (not a fixed iteration count): the call cut over
     2 .. 6 lanes into shares of 7 .. 64 windows — shares that as batches of their own would take the small assembly and the frame-parallel
